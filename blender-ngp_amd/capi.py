@@ -1,0 +1,120 @@
+"""ctypes view of a C header: parses `int name(args);` prototypes and attaches argtypes/restype to a loaded library.
+
+Used for libngp_hip.so (include/ngp_hip.h) by the tests and bench.py, and for the CPU oracle by the tests.  This module is
+plumbing only: it contains no algorithm and never falls back to a CPU implementation — if libngp_hip.so is missing,
+`load_ngp_hip()` raises.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+_SCALARS = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
+    "uint16_t": ctypes.c_uint16, "uint8_t": ctypes.c_uint8, "float": ctypes.c_float, "double": ctypes.c_double, "void": None,
+}
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return text
+
+
+def parse_prototypes(header_path):
+    """Returns {name: (restype, [argtypes], [argnames])} for every function prototype in the header."""
+    text = _strip_comments(open(header_path).read())
+    text = re.sub(r"#[^\n]*", " ", text)
+    # drop typedef struct bodies and enums
+    text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
+    text = re.sub(r"enum\s*\{.*?\}\s*;", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(\w+)\s*\(([^()]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("static") or "typedef" in ret or not ret:
+            continue
+        ret = ret.replace("extern", "").replace('"C"', "").strip()
+        if "*" in ret:
+            restype = ctypes.c_char_p if "char" in ret else ctypes.c_void_p
+        else:
+            restype = _SCALARS.get(ret.replace("const", "").strip(), ctypes.c_int)
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                a = re.sub(r"\[[^\]]*\]", "*", a)  # array params decay to pointers
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                    argnames.append(a.split("*")[-1].strip())
+                else:
+                    toks = a.replace("const", "").split()
+                    argtypes.append(_SCALARS[toks[0]])
+                    argnames.append(toks[-1])
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+class CLib:
+    def __init__(self, so_path, header_path, prefix):
+        if not os.path.exists(so_path):
+            raise FileNotFoundError("%s not built (run `python blender-ngp_amd/build.py` / `make -C oracle`)" % so_path)
+        self.lib = ctypes.CDLL(so_path)
+        self.so_path = so_path
+        self.protos = {k: v for k, v in parse_prototypes(header_path).items() if k.startswith(prefix)}
+        for name, (restype, argtypes, _) in self.protos.items():
+            fn = getattr(self.lib, name)  # raises AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+def ptr(x):
+    """Device/host pointer of a torch tensor, numpy array, ctypes object, int or None as c_void_p-compatible int."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return ctypes.addressof(x)
+
+
+_ngp = None
+
+
+def load_ngp_hip():
+    """libngp_hip.so with typed entry points; every call returns 0 or raises with ngp_hip_last_error()."""
+    global _ngp
+    if _ngp is None:
+        _ngp = CLib(os.path.join(HERE, "lib", "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), "ngp_hip_")
+    return _ngp
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load_ngp_hip()
+        raise RuntimeError("ngp_hip call failed (%d): %s" % (rc, lib.ngp_hip_last_error().decode()))
+
+
+# numpy views of the PODs in include/ngp_hip.h (identical layouts are used by the oracle)
+AABB = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)])
+RAY = np.dtype([("o", "<f4", 3), ("d", "<f4", 3)])
+XFORM = np.dtype([("start", "<f4", 12), ("end", "<f4", 12)])
+COORD = np.dtype([("pos", "<f4", 3), ("dt", "<f4"), ("dir", "<f4", 3)])
+PAYLOAD = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"), ("max_weight", "<f4"), ("idx", "<u4"), ("n_steps", "<u2"), ("alive", "u1"), ("pad", "u1")])
+IMAGE_META = np.dtype([
+    ("pixels", "<u8"), ("image_data_type", "<i4"), ("res", "<i4", 2), ("focal_length", "<f4", 2), ("principal_point", "<f4", 2),
+    ("rolling_shutter", "<f4", 4), ("lens_mode", "<i4"), ("lens_params", "<f4", 7), ("depth", "<u8"), ("rays", "<u8")], align=True)
+GRID_LEVEL = np.dtype([("scale", "<f4"), ("resolution", "<u4"), ("offset", "<u4"), ("size", "<u4")])
+NET_DESC = np.dtype([("n_levels", "<u4"), ("n_grid_entries", "<u4"), ("levels", GRID_LEVEL, 16)])
+
+assert AABB.itemsize == 24 and RAY.itemsize == 24 and XFORM.itemsize == 96 and COORD.itemsize == 28 and PAYLOAD.itemsize == 40
+assert NET_DESC.itemsize == 8 + 16 * 16

@@ -1,0 +1,680 @@
+// network.hip — the tiny-cuda-nn replacement for the NeRF path, written for gfx950 (wave64, MFMA 32x32x16 f16).
+//
+// Replaces (reference call sites): NerfNetwork::inference_mixed_precision_impl / density / forward_impl / backward_impl
+// (include/neural-graphics-primitives/nerf_network.h:103-284) and the tcnn GridEncoding + FullyFusedMLP + SphericalHarmonics
+// kernels they dispatch to; Trainer::optimizer_step (src/testbed_nerf.cu:2950).
+//
+// Design (MI355X-first, not a port of tcnn's 128-sample/threadblock warp-MMA tiling):
+//   * ONE wave owns 32 samples end to end.  Activations are kept TRANSPOSED (features x samples) so that the MFMA result
+//     layout D[row = feature][col = sample = lane&31] of one layer is, after an in-register f32->f16 pack, directly the
+//     B operand (K x N) of the next layer: register r of lane-group g holds feature (r&3)+8(r>>2)+4g, and because a
+//     matrix product is invariant under a permutation of K applied to both operands, the weights (A operand) are simply
+//     stored pre-permuted.  No LDS round trip, no cross-lane traffic between layers.
+//   * The two 32-lane halves of the wave split the 16 hash levels (8 each): their 16 fp16 features are exactly the two
+//     K-blocks that half contributes to the first MFMA.  The hash gather therefore feeds the matrix core from registers.
+//   * Weights (20 KiB fp16) are staged ONCE per workgroup into LDS already in A-operand order (1 KiB per 32x16 tile, one
+//     conflict-free ds_read_b128 per MFMA), which keeps the kernel at ~100 VGPRs so several waves per SIMD can hide the
+//     gather latency.
+//   * Backward: the same structure run in reverse with transposed, pre-permuted weights; the final dL/dx tile lands as
+//     8 levels per lane, so the hash-grid scatter (packed-f16 atomics) is issued from registers.  Activations / deltas are
+//     streamed out as [feature][sample] planes for the weight-gradient kernel, whose contraction runs over samples.
+//
+// Roofline: the hash pass is HBM/L2-request bound (512 B gathered per sample, 4 B per request); the MLP is ~20 kFLOP per
+// sample, i.e. a few % of the MFMA peak by construction (SURVEY §7 "Tiny-N MFMA").
+#include "ngp_device.cuh"
+
+#pragma clang fp contract(fast)
+
+namespace ngp {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NGP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// parameter offsets (nerf_network.h:361-394: density MLP, rgb MLP, grid)
+constexpr uint32_t W1_OFF = 0;                    // [64][32]
+constexpr uint32_t W2_OFF = 64 * 32;              // [16][64]
+constexpr uint32_t W3_OFF = W2_OFF + 16 * 64;     // [64][32]
+constexpr uint32_t W4_OFF = W3_OFF + 64 * 32;     // [64][64]
+constexpr uint32_t W5_OFF = W4_OFF + 64 * 64;     // [16][64]
+constexpr uint32_t GRID_OFF = W5_OFF + 16 * 64;   // 10240
+
+// K-slot -> feature maps.  slot = (kb, g, e): K-block kb, lane group g = lane>>5, element e of the 8-half operand.
+enum { MAP_ENC = 0, MAP_HID = 1, MAP_RGBIN = 2, MAP_CH = 3 };
+__device__ __forceinline__ int slot_feature(int map, int kb, int g, int e) {
+	switch (map) {
+		case MAP_ENC: return 16 * g + 8 * kb + e;                         // hash features: levels 8g..8g+7
+		case MAP_HID: return 16 * kb + 8 * (e >> 2) + 4 * g + (e & 3);    // rows of a 32x32 D tile pair
+		case MAP_RGBIN: return kb == 0 ? (8 * (e >> 2) + 4 * g + (e & 3)) : (16 + 8 * g + e); // [density out | SH]
+		default: return 8 * g + e;                                        // 16 output channels
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// LDS weight tiles.  A tile = 64 lanes x 8 halves in A-operand order for one (mt, kb).
+// forward tile ids
+constexpr int T_W1 = 0;   // + mt*2 + kb   (4)
+constexpr int T_W2 = 4;   // + kb          (4)
+constexpr int T_W3 = 8;   // + mt*2 + kb   (4)
+constexpr int T_W4 = 12;  // + mt*4 + kb   (8)
+constexpr int T_W5 = 20;  // + kb          (4)
+constexpr int N_FWD_TILES = 24;
+// backward (transposed) tile ids, placed after the forward ones
+constexpr int T_W5T = 24; // + mt          (2)   A[i = h3 feat][slot = channel]
+constexpr int T_W4T = 26; // + mt*4 + kb   (8)   A[i = h2 feat][slot = h3 feat]
+constexpr int T_W3T = 34; // + kb          (4)   A[i = rgb-in feat][slot = h2 feat]
+constexpr int T_W2T = 38; // + mt          (2)   A[i = h1 feat][slot = density-out feat]
+constexpr int T_W1T = 40; // + kb          (4)   A[i = x feat][slot = h1 feat]
+constexpr int N_ALL_TILES = 44;
+
+// element of forward tile: W[row i][col slot_feature]
+__device__ __forceinline__ h8 gather_tile(const half_t* __restrict__ P, int tile, int lane) {
+	const int i32 = lane & 31, g = lane >> 5;
+	h8 r;
+	int w_off, n_out, n_in, mt, kb, map; bool transposed = false;
+	if (tile < T_W2)       { w_off = W1_OFF; n_out = 64; n_in = 32; mt = (tile - T_W1) >> 1; kb = (tile - T_W1) & 1; map = MAP_ENC; }
+	else if (tile < T_W3)  { w_off = W2_OFF; n_out = 16; n_in = 64; mt = 0; kb = tile - T_W2; map = MAP_HID; }
+	else if (tile < T_W4)  { w_off = W3_OFF; n_out = 64; n_in = 32; mt = (tile - T_W3) >> 1; kb = (tile - T_W3) & 1; map = MAP_RGBIN; }
+	else if (tile < T_W5)  { w_off = W4_OFF; n_out = 64; n_in = 64; mt = (tile - T_W4) >> 2; kb = (tile - T_W4) & 3; map = MAP_HID; }
+	else if (tile < T_W5T) { w_off = W5_OFF; n_out = 16; n_in = 64; mt = 0; kb = tile - T_W5; map = MAP_HID; }
+	else if (tile < T_W4T) { w_off = W5_OFF; n_out = 16; n_in = 64; mt = tile - T_W5T; kb = 0; map = MAP_CH; transposed = true; }
+	else if (tile < T_W3T) { w_off = W4_OFF; n_out = 64; n_in = 64; mt = (tile - T_W4T) >> 2; kb = (tile - T_W4T) & 3; map = MAP_HID; transposed = true; }
+	else if (tile < T_W2T) { w_off = W3_OFF; n_out = 64; n_in = 32; mt = 0; kb = tile - T_W3T; map = MAP_HID; transposed = true; }
+	else if (tile < T_W1T) { w_off = W2_OFF; n_out = 16; n_in = 64; mt = tile - T_W2T; kb = 0; map = MAP_RGBIN; transposed = true; }
+	else                   { w_off = W1_OFF; n_out = 64; n_in = 32; mt = 0; kb = tile - T_W1T; map = MAP_HID; transposed = true; }
+	const half_t* W = P + w_off;
+	const int i = mt * 32 + i32;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		const int f = slot_feature(map, kb, g, e);
+		half_t v = (half_t)0.0f;
+		if (!transposed) { if (i < n_out && f < n_in) v = W[i * n_in + f]; }     // A[i = out][slot = in feature f]
+		else             { if (f < n_out && i < n_in) v = W[f * n_in + i]; }     // A[i = in][slot = out feature f]
+		r[e] = v;
+	}
+	return r;
+}
+
+__device__ __forceinline__ void stage_weights(h8* lds_tiles, const half_t* __restrict__ params, int first_tile, int n_tiles) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	for (int t = w; t < n_tiles; t += nw) lds_tiles[t * 64 + lane] = gather_tile(params, first_tile + t, lane);
+	__syncthreads();
+}
+
+// f32 D tile (32 rows) -> two f16 K-blocks (B operand of the next layer), optional ReLU, optional positive-mask output
+template <bool RELU>
+__device__ __forceinline__ void d_to_b(const f32x16& d, h8& b0, h8& b1) {
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		float v0 = d[e], v1 = d[8 + e];
+		if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+		b0[e] = (half_t)v0; b1[e] = (half_t)v1;
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// hash-grid level (tcnn kernel_grid, 3-D, F = 2, linear interpolation, Hash grid type)
+__device__ __forceinline__ uint32_t grid_index(const NgpGridLevel& lv, uint32_t x, uint32_t y, uint32_t z) {
+	uint32_t stride = 1, index = 0;
+	if (stride <= lv.size) { index += x * stride; stride *= lv.resolution; }
+	if (stride <= lv.size) { index += y * stride; stride *= lv.resolution;
+		if (stride <= lv.size) { index += z * stride; stride *= lv.resolution; } }
+	if (lv.size < stride) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+	if ((lv.size & (lv.size - 1)) == 0) return index & (lv.size - 1);
+	return index >= lv.size ? index % lv.size : index;
+}
+
+struct LevelPos { uint32_t gx, gy, gz; float fx, fy, fz; };
+__device__ __forceinline__ LevelPos level_pos(const NgpGridLevel& lv, float px, float py, float pz) {
+	LevelPos p;
+	float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
+	float flx = floorf(x), fly = floorf(y), flz = floorf(z);
+	p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
+	p.fx = x - flx; p.fy = y - fly; p.fz = z - flz;
+	return p;
+}
+
+__device__ __forceinline__ void encode_level(const NgpGridLevel lv, const h2* __restrict__ grid, float px, float py, float pz, half_t& o0, half_t& o1) {
+	const LevelPos p = level_pos(lv, px, py, pz);
+	h2 v[8];
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		const uint32_t idx = grid_index(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
+		// uniform base + 32-bit per-lane byte offset (the whole table is < 4 GiB): saddr-form global_load_dword
+		v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
+	}
+	float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		// weight = prod_d (bit ? frac : 1 - frac), multiplied in x, y, z order
+		float w = (c & 1) ? p.fx : (1.0f - p.fx);
+		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
+		w *= ((c >> 2) & 1) ? p.fz : (1.0f - p.fz);
+		r0 += w * (float)v[c][0];
+		r1 += w * (float)v[c][1];
+	}
+	o0 = (half_t)r0; o1 = (half_t)r1;
+}
+
+// lane (j, g) encodes levels 8g..8g+7 of its sample: x0 = levels 8g..8g+3, x1 = levels 8g+4..8g+7  (MAP_ENC)
+__device__ __forceinline__ void encode_half(const NgpNetDesc* __restrict__ desc, const h2* __restrict__ grid, int g, float px, float py, float pz, h8& x0, h8& x1) {
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		half_t a, b;
+		encode_level(desc->levels[8 * g + m], grid, px, py, pz, a, b);
+		x0[2 * m] = a; x0[2 * m + 1] = b;
+	}
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		half_t a, b;
+		encode_level(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
+		x1[2 * m] = a; x1[2 * m + 1] = b;
+	}
+}
+
+// SphericalHarmonics degree 4 of 2d-1; lane group g takes coefficients 8g..8g+7
+__device__ __forceinline__ h8 sh4_half(int g, float dx, float dy, float dz) {
+	float x = dx * 2.0f - 1.0f, y = dy * 2.0f - 1.0f, z = dz * 2.0f - 1.0f;
+	float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+	h8 r;
+	if (g == 0) {
+		r[0] = (half_t)0.28209479177387814f;
+		r[1] = (half_t)(-0.48860251190291987f * y);
+		r[2] = (half_t)(0.48860251190291987f * z);
+		r[3] = (half_t)(-0.48860251190291987f * x);
+		r[4] = (half_t)(1.0925484305920792f * xy);
+		r[5] = (half_t)(-1.0925484305920792f * yz);
+		r[6] = (half_t)(0.94617469575755997f * z2 - 0.31539156525251999f);
+		r[7] = (half_t)(-1.0925484305920792f * xz);
+	} else {
+		r[0] = (half_t)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+		r[1] = (half_t)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+		r[2] = (half_t)(2.8906114426405538f * xy * z);
+		r[3] = (half_t)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+		r[4] = (half_t)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+		r[5] = (half_t)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+		r[6] = (half_t)(1.4453057213202769f * z * (x2 - y2));
+		r[7] = (half_t)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+	}
+	return r;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// MLP forward for one 32-sample tile held by a wave.  Returns density-net D tile and (optionally) the rgb output tile;
+// hidden activations are returned in B-operand form for the backward recompute.
+struct FwdActs { h8 h1[4]; h8 rin[2]; h8 h2[4]; h8 h3[4]; };
+
+template <bool DENSITY_ONLY, bool KEEP>
+__device__ __forceinline__ void mlp_forward(const h8* __restrict__ lt, int lane, const h8& x0, const h8& x1, const h8& sh, f32x16& dd, f32x16& oo, FwdActs* acts) {
+	const f32x16 zero = {};
+	f32x16 a0 = NGP_MFMA(lt[(T_W1 + 0) * 64 + lane], x0, zero);
+	a0 = NGP_MFMA(lt[(T_W1 + 1) * 64 + lane], x1, a0);
+	f32x16 a1 = NGP_MFMA(lt[(T_W1 + 2) * 64 + lane], x0, zero);
+	a1 = NGP_MFMA(lt[(T_W1 + 3) * 64 + lane], x1, a1);
+	h8 h[4];
+	d_to_b<true>(a0, h[0], h[1]);
+	d_to_b<true>(a1, h[2], h[3]);
+	if (KEEP) { for (int k = 0; k < 4; ++k) acts->h1[k] = h[k]; }
+	dd = zero;
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) dd = NGP_MFMA(lt[(T_W2 + kb) * 64 + lane], h[kb], dd);
+	if (DENSITY_ONLY) return;
+	h8 r0, junk;
+	d_to_b<false>(dd, r0, junk);
+	if (KEEP) { acts->rin[0] = r0; acts->rin[1] = sh; }
+	a0 = NGP_MFMA(lt[(T_W3 + 0) * 64 + lane], r0, zero);
+	a0 = NGP_MFMA(lt[(T_W3 + 1) * 64 + lane], sh, a0);
+	a1 = NGP_MFMA(lt[(T_W3 + 2) * 64 + lane], r0, zero);
+	a1 = NGP_MFMA(lt[(T_W3 + 3) * 64 + lane], sh, a1);
+	d_to_b<true>(a0, h[0], h[1]);
+	d_to_b<true>(a1, h[2], h[3]);
+	if (KEEP) { for (int k = 0; k < 4; ++k) acts->h2[k] = h[k]; }
+	a0 = zero; a1 = zero;
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) {
+		a0 = NGP_MFMA(lt[(T_W4 + kb) * 64 + lane], h[kb], a0);
+		a1 = NGP_MFMA(lt[(T_W4 + 4 + kb) * 64 + lane], h[kb], a1);
+	}
+	d_to_b<true>(a0, h[0], h[1]);
+	d_to_b<true>(a1, h[2], h[3]);
+	if (KEEP) { for (int k = 0; k < 4; ++k) acts->h3[k] = h[k]; return; }
+	oo = zero;
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) oo = NGP_MFMA(lt[(T_W5 + kb) * 64 + lane], h[kb], oo);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Fused forward kernel: hash encode -> density MLP -> SH -> rgb MLP.  MODE 0 inference (rgb sigma), 1 density only,
+// 2 training forward (also stores the encoded features for backward).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) nerf_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
+                                                           const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                           half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_FWD_TILES * 64];
+	stage_weights(lds_tiles, params, 0, MODE == 1 ? T_W3 : N_FWD_TILES);
+
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+	const uint32_t n_tiles = (n + 31) / 32;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 32 + j;
+		const bool valid = s < n;
+		const float* c = coords + (size_t)(valid ? s : 0) * coord_stride;
+		const float px = c[0], py = c[1], pz = c[2];
+		h8 x0, x1;
+		encode_half(desc, grid, g, px, py, pz, x0, x1);
+		if (MODE == 2 && valid) {
+			h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
+			dst[0] = x0; dst[1] = x1;
+		}
+		h8 sh = {};
+		if (MODE != 1) sh = sh4_half(g, c[4], c[5], c[6]);
+		f32x16 dd, oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off)); // keep the LDS weight reads inside the loop (no LICM into 96 VGPRs)
+		mlp_forward<MODE == 1, false>(lds_tiles + lt_off, lane, x0, x1, sh, dd, oo, nullptr);
+		if (valid && g == 0) {
+			if (MODE == 1) {
+				out[s] = (half_t)dd[0];
+			} else {
+				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+				h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = (half_t)dd[0];
+				*(h4*)(out + (size_t)s * out_stride) = o;
+			}
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Activation / delta planes written by the backward kernel for the weight-gradient kernel: plane[row][sample] fp16.
+constexpr int P_DOUT = 0;    // 16 rows (channel)
+constexpr int P_H3 = 16;     // 64
+constexpr int P_DH3 = 80;    // 64
+constexpr int P_H2 = 144;    // 64
+constexpr int P_DH2 = 208;   // 64
+constexpr int P_RIN = 272;   // 32
+constexpr int P_DDENS = 304; // 16
+constexpr int P_H1 = 320;    // 64
+constexpr int P_DH1 = 384;   // 64
+constexpr int P_X = 448;     // 32
+constexpr int N_PLANE_ROWS = 480;
+
+__device__ __forceinline__ void store_plane(half_t* __restrict__ planes, uint32_t n, int row0, int map, int kb, int g, uint32_t s, const h8& v) {
+#pragma unroll
+	for (int e = 0; e < 8; ++e) *(half_t*)((char*)planes + (size_t)((((uint32_t)(row0 + slot_feature(map, kb, g, e))) * n + s) * 2u)) = v[e];
+}
+
+__device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8& fwd_act) {
+	h8 r;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		float v = t[8 * half_idx + e];
+		r[e] = ((float)fwd_act[e] > 0.0f) ? (half_t)v : (half_t)0.0f;
+	}
+	return r;
+}
+
+__device__ __forceinline__ void scatter_level(const NgpGridLevel lv, h2* __restrict__ grid_grad, float px, float py, float pz, float g0, float g1) {
+	const LevelPos p = level_pos(lv, px, py, pz);
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		float w = (c & 1) ? p.fx : (1.0f - p.fx);
+		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
+		w *= ((c >> 2) & 1) ? p.fz : (1.0f - p.fz);
+		const uint32_t idx = grid_index(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
+		h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);
+		h2* dst = (h2*)((char*)grid_grad + (size_t)((lv.offset + idx) * 4u));
+		__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)dst, val);
+	}
+}
+
+// Backward kernel: recompute forward from the saved encoding, dgrad chain, grid scatter, plane dump.  n % 32 == 0.
+__global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
+                                                            const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                            const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
+                                                            half_t* __restrict__ grads, half_t* __restrict__ planes) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
+	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
+
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+	const uint32_t n_tiles = n / 32;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+	h2* __restrict__ grid_grad = (h2*)(grads + GRID_OFF);
+	const f32x16 zero = {};
+
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 32 + j;
+		const float* c = coords + (size_t)s * coord_stride;
+		const float px = c[0], py = c[1], pz = c[2];
+		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
+		const h8 x0 = xs[0], x1 = xs[1];
+		const h8 sh = sh4_half(g, c[4], c[5], c[6]);
+		FwdActs a;
+		f32x16 dd, oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off)); // keep the LDS weight reads inside the loop
+		const h8* lt = lds_tiles + lt_off;
+		mlp_forward<false, true>(lt, lane, x0, x1, sh, dd, oo, &a);
+
+		// dL/dout -> B operand (MAP_CH): channels 0..2 live on g == 0, e = 0..2
+		const half_t* dl = dL_dout + (size_t)s * dl_stride;
+		h8 dout = {};
+		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; }
+		const half_t dsigma = dl[3];
+
+		// rgb net, output layer:   d_h3 = relu'(h3) * (W5^T dout)
+		f32x16 t0 = NGP_MFMA(lt[(T_W5T + 0) * 64 + lane], dout, zero);
+		f32x16 t1 = NGP_MFMA(lt[(T_W5T + 1) * 64 + lane], dout, zero);
+		h8 dh[4];
+		dh[0] = mask_delta(t0, 0, a.h3[0]); dh[1] = mask_delta(t0, 1, a.h3[1]);
+		dh[2] = mask_delta(t1, 0, a.h3[2]); dh[3] = mask_delta(t1, 1, a.h3[3]);
+		store_plane(planes, n, P_DOUT, MAP_CH, 0, g, s, dout);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H3, MAP_HID, kb, g, s, a.h3[kb]); store_plane(planes, n, P_DH3, MAP_HID, kb, g, s, dh[kb]); }
+
+		// hidden layer: d_h2 = relu'(h2) * (W4^T d_h3)
+		t0 = zero; t1 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) {
+			t0 = NGP_MFMA(lt[(T_W4T + kb) * 64 + lane], dh[kb], t0);
+			t1 = NGP_MFMA(lt[(T_W4T + 4 + kb) * 64 + lane], dh[kb], t1);
+		}
+		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
+		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, P_DH2, MAP_HID, kb, g, s, dh[kb]); }
+		store_plane(planes, n, P_RIN, MAP_RGBIN, 0, g, s, a.rin[0]);
+		store_plane(planes, n, P_RIN, MAP_RGBIN, 1, g, s, a.rin[1]);
+
+		// input layer of the rgb net: d_in = W3^T d_h2 (rows 0..15 = density-net output gradient)
+		t0 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W3T + kb) * 64 + lane], dh[kb], t0);
+		h8 dden;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
+		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
+		store_plane(planes, n, P_DDENS, MAP_RGBIN, 0, g, s, dden);
+
+		// density net: d_h1 = relu'(h1) * (W2^T d_dens);  d_x = W1^T d_h1
+		t0 = NGP_MFMA(lt[(T_W2T + 0) * 64 + lane], dden, zero);
+		t1 = NGP_MFMA(lt[(T_W2T + 1) * 64 + lane], dden, zero);
+		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
+		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, P_DH1, MAP_HID, kb, g, s, dh[kb]); }
+		store_plane(planes, n, P_X, MAP_ENC, 0, g, s, x0);
+		store_plane(planes, n, P_X, MAP_ENC, 1, g, s, x1);
+
+		t0 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W1T + kb) * 64 + lane], dh[kb], t0);
+
+		// t0 row = x feature (r&3)+8(r>>2)+4g  =>  this lane owns levels 4q+2g (regs 4q,4q+1) and 4q+2g+1 (regs 4q+2,4q+3), q = 0..3.
+		// tcnn kernel_grid_backward: grad[idx] += half2(w * dL/dx) with dL/dx in fp16.
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const float ga0 = (float)(half_t)t0[4 * q + 0], ga1 = (float)(half_t)t0[4 * q + 1];
+			const float gb0 = (float)(half_t)t0[4 * q + 2], gb1 = (float)(half_t)t0[4 * q + 3];
+			const int lvl = 4 * q + 2 * g;
+			scatter_level(desc->levels[lvl], grid_grad, px, py, pz, ga0, ga1);
+			scatter_level(desc->levels[lvl + 1], grid_grad, px, py, pz, gb0, gb1);
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight gradients: dW[o][i] = sum_s dY[o][s] * H[i][s].  Contraction over samples: both operands are read straight from
+// the [row][sample] planes (64 B per lane per 64-sample step, a full 128-B line per row), K-slot <-> sample mapping is
+// identical for A and B so it never has to be made explicit.  6 balanced jobs (2 output tiles, 3 operand row groups each):
+//   0: W4 rows 0..31   1: W4 rows 32..63   2: W5   3: W2   4: W3 (both row tiles)   5: W1 (both row tiles)
+struct WgradJob { int dy_row, dy_rows, h_row, h_rows, w_off, n_in, two_mt; int mt0; };
+__device__ __forceinline__ WgradJob wgrad_job(int job) {
+	switch (job) {
+		case 0: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 0};
+		case 1: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 1};
+		case 2: return {P_DOUT, 16, P_H3, 64, (int)W5_OFF, 64, 0, 0};
+		case 3: return {P_DDENS, 16, P_H1, 64, (int)W2_OFF, 64, 0, 0};
+		case 4: return {P_DH2, 64, P_RIN, 32, (int)W3_OFF, 32, 1, 0};
+		default: return {P_DH1, 64, P_X, 32, (int)W1_OFF, 32, 1, 0};
+	}
+}
+
+// grid (n_chunks, 6); block 256 = 4 waves; wave w handles samples [chunk*chunk_len + w*chunk_len/4, ...) in steps of 64.
+__global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restrict__ planes, uint32_t n, uint32_t chunk_len, float* __restrict__ partials /* [n_chunks][10240] */) {
+	__shared__ float red[4][2][16][64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, g = lane >> 5;
+	const WgradJob jb = wgrad_job(blockIdx.y);
+	const uint32_t per_wave = chunk_len / 4;
+	const uint32_t s_begin = blockIdx.x * chunk_len + w * per_wave, s_end = s_begin + per_wave;
+
+	// operand row groups: R0, R1, R2.  two_mt: A rows (mt 0,1) + one B group;  else: one A group + B groups (nt 0,1)
+	const half_t* rowp[3]; bool rowok[3];
+	if (jb.two_mt) {
+		rowp[0] = planes + (size_t)(jb.dy_row + r32) * n;       rowok[0] = true;
+		rowp[1] = planes + (size_t)(jb.dy_row + 32 + r32) * n;  rowok[1] = true;
+		rowp[2] = planes + (size_t)(jb.h_row + r32) * n;        rowok[2] = true;
+	} else {
+		const int ar = jb.mt0 * 32 + r32;
+		rowok[0] = ar < jb.dy_rows;
+		rowp[0] = planes + (size_t)(jb.dy_row + (rowok[0] ? ar : 0)) * n;
+		rowp[1] = planes + (size_t)(jb.h_row + r32) * n;        rowok[1] = true;
+		rowp[2] = planes + (size_t)(jb.h_row + 32 + r32) * n;   rowok[2] = true;
+	}
+	f32x16 acc0 = {}, acc1 = {};
+	for (uint32_t s = s_begin; s < s_end; s += 64) {
+		h8 op[3][4];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			const h8* p = (const h8*)(rowp[k] + s + 32 * g);
+#pragma unroll
+			for (int kb = 0; kb < 4; ++kb) { h8 v = p[kb]; if (!rowok[k]) { const h8 z = {}; v = z; } op[k][kb] = v; }
+		}
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) {
+			if (jb.two_mt) { acc0 = NGP_MFMA(op[0][kb], op[2][kb], acc0); acc1 = NGP_MFMA(op[1][kb], op[2][kb], acc1); }
+			else           { acc0 = NGP_MFMA(op[0][kb], op[1][kb], acc0); acc1 = NGP_MFMA(op[0][kb], op[2][kb], acc1); }
+		}
+	}
+	// cross-wave reduction in LDS, then one partial per block
+#pragma unroll
+	for (int r = 0; r < 16; ++r) { red[w][0][r][lane] = acc0[r]; red[w][1][r][lane] = acc1[r]; }
+	__syncthreads();
+	float* dst = partials + (size_t)blockIdx.x * NGP_MLP_N_PARAMS + jb.w_off;
+	for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
+		const int t = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
+		const float v = red[0][t][r][l] + red[1][t][r][l] + red[2][t][r][l] + red[3][t][r][l];
+		const int lg = l >> 5, lc = l & 31;
+		const int row_in_tile = (r & 3) + 8 * (r >> 2) + 4 * lg;
+		int o, i;
+		if (jb.two_mt) { o = t * 32 + row_in_tile; i = lc; }
+		else           { o = jb.mt0 * 32 + row_in_tile; i = t * 32 + lc; }
+		if (o < jb.dy_rows && i < jb.n_in) dst[o * jb.n_in + i] = v;
+	}
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NGP_MLP_N_PARAMS) return;
+	float acc = 0.0f;
+	for (uint32_t c = 0; c < n_chunks; ++c) acc += partials[(size_t)c * NGP_MLP_N_PARAMS + i];
+	grads[i] = (half_t)acc;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// parameter init (nerf_network.h:396-441 order; tcnn Xavier-uniform / U(-1e-4, 1e-4)); element k <- k-th draw of pcg32(seed)
+__global__ void init_params_kernel(uint32_t n_params, uint64_t seed_state, uint64_t seed_inc, float* __restrict__ master, half_t* __restrict__ params, half_t* __restrict__ inference) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_params) return;
+	Pcg32 rng; rng.state = seed_state; rng.inc = seed_inc;
+	rng.advance(k);
+	float scale;
+	if (k < W2_OFF) scale = sqrtf(6.0f / (float)(64 + 32));
+	else if (k < W3_OFF) scale = sqrtf(6.0f / (float)(16 + 64));
+	else if (k < W4_OFF) scale = sqrtf(6.0f / (float)(64 + 32));
+	else if (k < W5_OFF) scale = sqrtf(6.0f / (float)(64 + 64));
+	else if (k < GRID_OFF) scale = sqrtf(6.0f / (float)(16 + 64));
+	else scale = 1e-4f;
+	float v;
+	{
+#pragma clang fp contract(off)
+		v = rng.next_float() * (scale - (-scale)) + (-scale);
+	}
+	master[k] = v;
+	params[k] = (half_t)v;
+	inference[k] = (half_t)v;
+}
+
+// Ema o ExponentialDecay o Adam (tcnn optimizers as configured by configs/nerf/base.json:5-22); one streaming pass.
+__global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, float lr, float beta1, float beta2, float epsilon, float l2_reg,
+                                float loss_scale, float ema_decay, float ema_debias_old, float ema_debias_new,
+                                const half_t* __restrict__ grads, float* __restrict__ master, half_t* __restrict__ params,
+                                float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ ema, half_t* __restrict__ inference) {
+#pragma clang fp contract(off)
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_params) return;
+	float g = (float)grads[i] / loss_scale;
+	half_t p16 = params[i];
+	const bool skip = (i >= n_matrix_params) && g == 0.0f;
+	if (!skip) {
+		float w = master[i];
+		if (i < n_matrix_params) g += l2_reg * w;
+		const float gsq = g * g;
+		const float fm = beta1 * m1[i] + (1.0f - beta1) * g;
+		const float sm = beta2 * m2[i] + (1.0f - beta2) * gsq;
+		m1[i] = fm; m2[i] = sm;
+		const float eff = lr / (sqrtf(sm) + epsilon);
+		const float nw = w - eff * fm;
+		master[i] = nw;
+		p16 = (half_t)nw;
+		params[i] = p16;
+	}
+	const float filtered = (ema[i] * ema_decay * ema_debias_old + (float)p16 * (1.0f - ema_decay)) * ema_debias_new;
+	ema[i] = filtered;
+	inference[i] = (half_t)filtered;
+}
+
+static int fwd_grid(uint32_t n) {
+	uint32_t tiles = div_up(n, 32);
+	uint32_t blocks = div_up(tiles, 4);
+	const uint32_t cap = 256 * 8; // 8 workgroups per CU resident at most; grid-stride the rest
+	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+} // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* d) {
+	if (n_levels != 16 || !d) { set_last_error("ngp_hip_net_make_desc_host: n_levels must be 16", hipErrorInvalidValue); return -1; }
+	uint32_t offset = 0;
+	const float log2_pls = log2f(per_level_scale);
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		const float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+		const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+		const uint64_t dense = (uint64_t)res * res * res;
+		const uint32_t max_params = 0xffffffffu / 2u;
+		uint32_t cnt = dense > max_params ? max_params : (uint32_t)dense;
+		cnt = (cnt + 7u) / 8u * 8u;
+		const uint32_t hashmap = 1u << log2_hashmap_size;
+		const uint32_t size = cnt < hashmap ? cnt : hashmap;
+		d->levels[l].scale = scale; d->levels[l].resolution = res; d->levels[l].offset = offset; d->levels[l].size = size;
+		offset += size;
+	}
+	d->n_levels = n_levels;
+	d->n_grid_entries = offset;
+	return 0;
+}
+
+uint32_t ngp_hip_net_n_params_host(const NgpNetDesc* d) { return NGP_MLP_N_PARAMS + 2u * d->n_grid_entries; }
+
+int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params) {
+	// pcg32(initstate = seed, initseq = 1)
+	uint64_t state = 0u, inc = (1ull << 1u) | 1u;
+	state = state * 0x5851f42d4c957f2dULL + inc;
+	state += seed;
+	state = state * 0x5851f42d4c957f2dULL + inc;
+	const uint32_t n = ngp_hip_net_n_params_host(desc_host);
+	hipLaunchKernelGGL(init_params_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, state, inc, master, (half_t*)params, (half_t*)inference_params);
+	NGP_LAUNCH_CHECK("init_params_kernel");
+	return 0;
+}
+
+int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                           uint32_t n, uint16_t* out, uint32_t out_stride) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(nerf_forward_kernel<0>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<0>");
+	return 0;
+}
+
+int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0) {
+	if (n == 0) return 0;
+	hipLaunchKernelGGL(nerf_forward_kernel<1>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<1>");
+	return 0;
+}
+
+int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(nerf_forward_kernel<2>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
+	return 0;
+}
+
+static uint32_t wgrad_chunks(uint32_t n) {
+	// chunk_len must be a multiple of 256 (4 waves x 64-sample steps); aim for <= 128 chunks
+	uint32_t chunk_len = 256;
+	while (n / chunk_len > 128 && (n % (chunk_len * 2) == 0)) chunk_len *= 2;
+	return n / chunk_len;
+}
+
+uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) {
+	return (uint64_t)N_PLANE_ROWS * n * 2u + (uint64_t)wgrad_chunks(n) * NGP_MLP_N_PARAMS * 4u;
+}
+
+int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                          uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	half_t* planes = (half_t*)scratch;
+	float* partials = (float*)((char*)scratch + (uint64_t)N_PLANE_ROWS * n * 2u);
+	// EGradientMode::Overwrite: the scatter target starts from zero every step
+	NGP_HIP_TRY(hipMemsetAsync(grads + NGP_MLP_N_PARAMS, 0, (size_t)desc_host->n_grid_entries * 2u * sizeof(uint16_t), st));
+	hipLaunchKernelGGL(nerf_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n,
+	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, (half_t*)grads, planes);
+	NGP_LAUNCH_CHECK("nerf_backward_kernel");
+	const uint32_t n_chunks = wgrad_chunks(n);
+	hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
+	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 256)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads);
+	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	return 0;
+}
+
+int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
+                           float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
+                           float* first_moments, float* second_moments, float* ema, uint16_t* inference_params) {
+	const float lr = learning_rate * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+	const float ema_debias_old = 1.0f - powf(ema_decay, (float)(step - 1));
+	const float ema_debias_new = 1.0f / (1.0f - powf(ema_decay, (float)step));
+	hipLaunchKernelGGL(adam_ema_kernel, dim3(div_up(n_params, 256)), dim3(256), 0, (hipStream_t)stream, n_params, n_matrix_params, lr, beta1, beta2, epsilon, l2_reg,
+	                   loss_scale, ema_decay, ema_debias_old, ema_debias_new, (const half_t*)grads, master, (half_t*)params, first_moments, second_moments, ema, (half_t*)inference_params);
+	NGP_LAUNCH_CHECK("adam_ema_kernel");
+	return 0;
+}
+
+} // extern "C"

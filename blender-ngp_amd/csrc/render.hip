@@ -1,0 +1,349 @@
+// render.hip — single-NeRF renderer kernels (Testbed::NerfTracer) + frame accumulate / tonemap for gfx950.
+// Replaces src/testbed_nerf.cu:612-664 (advance_pos_nerf), 705-765 (generate_next_nerf_network_inputs), 767-989
+// (composite_kernel_nerf; Shade mode, no masks / glow), 1748-1781 (shade_kernel_nerf), 1784-1807 (compact_kernel_nerf),
+// 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective camera) and src/render_buffer.cu:235-272, 274-348, 540-567.
+// Compaction uses wave64 ballots: one atomic per wave per counter instead of one per ray.
+#include "ngp_device.cuh"
+
+namespace ngp {
+
+struct InitRaysArgs {
+	uint32_t sample_index; NgpPayload* payloads; int32_t res[2]; float focal_length[2]; Mat34 cam0, cam1; float rolling_shutter[4];
+	float screen_center[2]; float parallax_shift[3]; int snap_to_pixel_centers; Aabb render_aabb; Mat33 to_local; float near_distance;
+	int lens_mode; float lens_params[7]; float* depthbuffer;
+};
+
+__global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
+	const uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= (uint32_t)a.res[0] || y >= (uint32_t)a.res[1]) return;
+	const uint32_t idx = x + (uint32_t)a.res[0] * y;
+	const float u = ((float)x + 0.5f) * (1.f / (float)a.res[0]), v = ((float)y + 0.5f) * (1.f / (float)a.res[1]);
+	const float ray_time = a.rolling_shutter[0] + a.rolling_shutter[1] * u + a.rolling_shutter[2] * v + a.rolling_shutter[3] * ld_random_val(a.sample_index, idx * 72239731u);
+	float cam[12];
+#pragma unroll
+	for (int k = 0; k < 12; ++k) cam[k] = a.cam0.m[k] * ray_time + a.cam1.m[k] * (1.f - ray_time);
+
+	// pixel_to_ray (common_device.cuh:260-317), aperture_size == 0, no distortion grid
+	float ox, oy;
+	ld_random_pixel_offset(a.snap_to_pixel_centers ? 0 : a.sample_index, ox, oy);
+	const float pu = ((float)x + ox) / (float)a.res[0], pv = ((float)y + oy) / (float)a.res[1];
+	v3 dir = mk((pu - a.screen_center[0]) * (float)a.res[0] / a.focal_length[0], (pv - a.screen_center[1]) * (float)a.res[1] / a.focal_length[1], 1.0f);
+	if (a.lens_mode == 1) iterative_opencv_lens_undistortion(a.lens_params, dir.x, dir.y);
+	const v3 head_pos = mk(a.parallax_shift[0], a.parallax_shift[1], 0.f);
+	dir = dir - head_pos * a.parallax_shift[2];
+	dir = mat3_mul(cam, dir);
+	v3 origin = mat3_mul(cam, head_pos) + col(cam, 3);
+	origin = origin + dir * a.near_distance;
+
+	NgpPayload p = a.payloads[idx];
+	p.max_weight = 0.0f;
+	a.depthbuffer[idx] = 1e10f;
+	dir = normalized(dir);
+	float tmin, tmax;
+	aabb_ray_intersect(a.render_aabb, mat3_mul(a.to_local.m, origin), mat3_mul(a.to_local.m, dir), tmin, tmax);
+	const float t = fmaxf(tmin, 0.0f) + 1e-6f;
+	p.origin[0] = origin.x; p.origin[1] = origin.y; p.origin[2] = origin.z;
+	if (!aabb_contains(a.render_aabb, mat3_mul(a.to_local.m, origin + dir * t))) {
+		p.alive = 0;
+	} else {
+		p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
+		p.t = t; p.idx = idx; p.n_steps = 0; p.alive = 1;
+	}
+	a.payloads[idx] = p;
+}
+
+__global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
+                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	NgpPayload& payload = payloads[i];
+	if (!payload.alive) return;
+	const v3 origin = ld3(payload.origin), dir = ld3(payload.dir);
+	const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	const float cone_angle = cone_angle_constant;
+	float t = payload.t;
+	float dt = calc_dt(t, cone_angle);
+	t += ld_random_val(sample_index, i * 786433u) * dt;
+	v3 pos;
+	while (1) {
+		pos = origin + dir * t;
+		if (!aabb_contains(render_aabb, mat3_mul(to_local.m, pos))) { payload.alive = 0; break; }
+		dt = calc_dt(t, cone_angle);
+		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+		mip = mip < min_mip ? min_mip : mip;
+		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip)) break;
+		t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+	}
+	payload.t = t;
+}
+
+struct Payload40 { uint32_t w[10]; };
+
+__global__ void __launch_bounds__(256) compact_rays_kernel(uint32_t n_elements, const float4* __restrict__ src_rgba, const float* __restrict__ src_depth, const Payload40* __restrict__ src_payloads,
+                                                           float4* __restrict__ dst_rgba, float* __restrict__ dst_depth, Payload40* __restrict__ dst_payloads,
+                                                           float4* __restrict__ fin_rgba, float* __restrict__ fin_depth, Payload40* __restrict__ fin_payloads,
+                                                           uint32_t* counter, uint32_t* final_counter) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const bool in_range = i < n_elements;
+	Payload40 p; float4 c = make_float4(0, 0, 0, 0); float d = 0;
+	bool alive = false, hit = false;
+	if (in_range) {
+		p = src_payloads[i]; c = src_rgba[i]; d = src_depth[i];
+		alive = ((const NgpPayload*)&p)->alive != 0;
+		hit = !alive && c.w > 0.001f;
+	}
+	const uint32_t lane = lane_id();
+	const unsigned long long am = __ballot(alive), hm = __ballot(hit);
+	uint32_t abase = 0, hbase = 0;
+	if (lane == 0) {
+		if (am) abase = atomicAdd(counter, (uint32_t)__popcll(am));
+		if (hm) hbase = atomicAdd(final_counter, (uint32_t)__popcll(hm));
+	}
+	abase = __shfl(abase, 0, 64); hbase = __shfl(hbase, 0, 64);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (alive) {
+		const uint32_t idx = abase + (uint32_t)__popcll(am & below);
+		dst_payloads[idx] = p; dst_rgba[idx] = c; dst_depth[idx] = d;
+	} else if (hit) {
+		const uint32_t idx = hbase + (uint32_t)__popcll(hm & below);
+		fin_payloads[idx] = p; fin_rgba[idx] = c; fin_depth[idx] = d;
+	}
+}
+
+__global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aabb, Aabb train_aabb, NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input,
+                                            uint32_t n_steps, const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	NgpPayload& payload = payloads[i];
+	if (!payload.alive) return;
+	const v3 origin = ld3(payload.origin), dir = ld3(payload.dir);
+	const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	const v3 wd = warp_direction(dir);
+	const float cone_angle = cone_angle_constant;
+	float t = payload.t;
+	for (uint32_t j = 0; j < n_steps; ++j) {
+		v3 pos;
+		float dt = 0.0f;
+		while (1) {
+			pos = origin + dir * t;
+			if (!aabb_contains(render_aabb, pos)) { payload.n_steps = (uint16_t)j; return; }
+			dt = calc_dt(t, cone_angle);
+			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+			mip = mip < min_mip ? min_mip : mip;
+			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip)) break;
+			t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+		}
+		const v3 wp = aabb_relative_pos(train_aabb, pos);
+		NgpCoord c;
+		c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt); c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+		network_input[i + (size_t)j * n_elements] = c;
+		t += dt;
+	}
+	payload.t = t;
+	payload.n_steps = (uint16_t)n_steps;
+}
+
+typedef uint16_t us4 __attribute__((ext_vector_type(4)));
+
+__global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aabb aabb, Mat34 camera_matrix, float4* __restrict__ rgba, float* __restrict__ depth,
+                                 NgpPayload* __restrict__ payloads, const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride,
+                                 uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	NgpPayload& payload = payloads[i];
+	if (!payload.alive) return;
+	float4 local_rgba = rgba[i];
+	float local_depth = depth[i];
+	const v3 cam_fwd = col(camera_matrix.m, 2), cam_pos = col(camera_matrix.m, 3);
+	const uint32_t actual_n_steps = payload.n_steps;
+	float max_weight = payload.max_weight;
+	uint32_t j = 0;
+	for (; j < actual_n_steps; ++j) {
+		const size_t s = (size_t)i + (size_t)j * n_elements;
+		const us4 lo = *(const us4*)(network_output + s * out_stride);
+		const NgpCoord in = network_input[s];
+		const v3 pos = unwarp_position(mk(in.pos[0], in.pos[1], in.pos[2]), aabb);
+		const float T = 1.f - local_rgba.w;
+		const float dt = unwarp_dt(in.dt);
+		const float alpha = 1.f - __expf(-network_to_density(h2f(lo[3]), density_activation) * dt);
+		const float weight = alpha * T;
+		local_rgba.x += network_to_rgb(h2f(lo[0]), rgb_activation) * weight;
+		local_rgba.y += network_to_rgb(h2f(lo[1]), rgb_activation) * weight;
+		local_rgba.z += network_to_rgb(h2f(lo[2]), rgb_activation) * weight;
+		local_rgba.w += weight;
+		if (weight > max_weight) { max_weight = weight; local_depth = dot(cam_fwd, pos - cam_pos); }
+		if (local_rgba.w > (1.0f - min_transmittance)) {
+			const float w = local_rgba.w;
+			local_rgba.x /= w; local_rgba.y /= w; local_rgba.z /= w; local_rgba.w /= w;
+			break;
+		}
+	}
+	payload.max_weight = max_weight;
+	if (j < n_steps) { payload.alive = 0; payload.n_steps = (uint16_t)(j + current_step); }
+	rgba[i] = local_rgba;
+	depth[i] = local_depth;
+}
+
+__global__ void shade_kernel(uint32_t n_elements, const float4* __restrict__ rgba, const float* __restrict__ depth, const NgpPayload* __restrict__ payloads,
+                             bool train_in_linear_colors, float4* __restrict__ frame_buffer, float* __restrict__ depth_buffer) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	float4 tmp = rgba[i];
+	if (!train_in_linear_colors) { tmp.x = srgb_to_linear(tmp.x); tmp.y = srgb_to_linear(tmp.y); tmp.z = srgb_to_linear(tmp.z); }
+	const uint32_t idx = payloads[i].idx;
+	const float4 fb = frame_buffer[idx];
+	const float k = 1.0f - tmp.w;
+	frame_buffer[idx] = make_float4(tmp.x + fb.x * k, tmp.y + fb.y * k, tmp.z + fb.z * k, tmp.w + fb.w * k);
+	if (tmp.w > 0.2f) depth_buffer[idx] = depth[i];
+}
+
+__global__ void accumulate_kernel(uint32_t n, const float4* __restrict__ frame_buffer, float4* __restrict__ accumulate_buffer, float sample_count, int color_space) {
+	const uint32_t idx = threadIdx.x + blockIdx.x * blockDim.x;
+	if (idx >= n) return;
+	float4 color = frame_buffer[idx];
+	float4 tmp = accumulate_buffer[idx];
+	if (color_space == NGP_COLOR_SRGB) { color.x = linear_to_srgb(color.x); color.y = linear_to_srgb(color.y); color.z = linear_to_srgb(color.z); }
+	tmp.x = (tmp.x * sample_count + color.x) / (sample_count + 1);
+	tmp.y = (tmp.y * sample_count + color.y) / (sample_count + 1);
+	tmp.z = (tmp.z * sample_count + color.z) / (sample_count + 1);
+	tmp.w = (tmp.w * sample_count + color.w) / (sample_count + 1);
+	accumulate_buffer[idx] = tmp;
+}
+
+__device__ __forceinline__ void tonemap_curve(float x[3], int curve) {
+	if (curve == NGP_TONEMAP_IDENTITY) return;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) x[c] = fmaxf(x[c], 0.f);
+	float k0, k1, k2, k3, k4, k5;
+	if (curve == NGP_TONEMAP_ACES) {
+		k0 = 0.6f * 0.6f * 2.51f; k1 = 0.6f * 0.03f; k2 = 0.0f; k3 = 0.6f * 0.6f * 2.43f; k4 = 0.6f * 0.59f; k5 = 0.14f;
+	} else if (curve == NGP_TONEMAP_HABLE) {
+		const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+		k0 = A * F - A * E; k1 = C * B * F - B * E; k2 = 0.0f; k3 = A * F; k4 = B * F; k5 = D * F * F;
+		const float W = 11.2f;
+		const float nom = k0 * (W * W) + k1 * W + k2, denom = k3 * (W * W) + k4 * W + k5;
+		const float white_scale = denom / nom;
+		k0 = 4.0f * k0 * white_scale; k1 = 2.0f * k1 * white_scale; k2 = k2 * white_scale; k3 = 4.0f * k3; k4 = 2.0f * k4;
+	} else {
+		const float Y = 0.2126f * x[0] + 0.7152f * x[1] + 0.0722f * x[2];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) x[c] = x[c] * (1.f / (Y + 1.0f));
+		return;
+	}
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const float sq = x[c] * x[c];
+		x[c] = (sq * k0 + k1 * x[c] + k2) / (k3 * sq + k4 * x[c] + k5);
+	}
+}
+
+__global__ void tonemap_kernel(uint32_t n, float exposure, float4 background_color, const float4* __restrict__ accumulate_buffer, int color_space, int output_color_space,
+                               int curve, bool clamp_output_color, float4* __restrict__ surface) {
+	const uint32_t idx = threadIdx.x + blockIdx.x * blockDim.x;
+	if (idx >= n) return;
+	if (color_space != NGP_COLOR_SRGB) { background_color.x = srgb_to_linear(background_color.x); background_color.y = srgb_to_linear(background_color.y); background_color.z = srgb_to_linear(background_color.z); }
+	float4 color = accumulate_buffer[idx];
+	const float weight = (1 - color.w) * background_color.w;
+	float c3[3] = {color.x + background_color.x * weight, color.y + background_color.y * weight, color.z + background_color.z * weight};
+	color.w += weight;
+	if (color_space == NGP_COLOR_SRGB) { for (int c = 0; c < 3; ++c) c3[c] = srgb_to_linear(c3[c]); }
+	const float e = powf(2.0f, exposure);
+	for (int c = 0; c < 3; ++c) c3[c] *= e;
+	tonemap_curve(c3, curve);
+	if (output_color_space == NGP_COLOR_SRGB) { for (int c = 0; c < 3; ++c) c3[c] = linear_to_srgb(c3[c]); }
+	if (clamp_output_color) { for (int c = 0; c < 3; ++c) c3[c] = fminf(fmaxf(c3[c], 0.0f), 1.0f); color.w = fminf(fmaxf(color.w, 0.0f), 1.0f); }
+	surface[idx] = make_float4(c3[0], c3[1], c3[2], color.w);
+}
+
+static Mat34 mat34_from_host(const float* m) { Mat34 r; for (int i = 0; i < 12; ++i) r.m[i] = m[i]; return r; }
+static Mat33 mat33_from_host(const float* m) { Mat33 r; for (int i = 0; i < 9; ++i) r.m[i] = m ? m[i] : ((i % 4 == 0) ? 1.0f : 0.0f); return r; }
+
+} // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
+                      const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
+                      const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
+                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer) {
+	InitRaysArgs a;
+	a.sample_index = sample_index; a.payloads = payloads; a.res[0] = res_host[0]; a.res[1] = res_host[1];
+	a.focal_length[0] = focal_length_host[0]; a.focal_length[1] = focal_length_host[1];
+	a.cam0 = mat34_from_host(camera_matrix0_host); a.cam1 = mat34_from_host(camera_matrix1_host);
+	for (int i = 0; i < 4; ++i) a.rolling_shutter[i] = rolling_shutter_host ? rolling_shutter_host[i] : 0.0f;
+	a.screen_center[0] = screen_center_host[0]; a.screen_center[1] = screen_center_host[1];
+	for (int i = 0; i < 3; ++i) a.parallax_shift[i] = parallax_shift_host ? parallax_shift_host[i] : 0.0f;
+	a.snap_to_pixel_centers = snap_to_pixel_centers; a.render_aabb = aabb_from_host(render_aabb_host); a.to_local = mat33_from_host(render_aabb_to_local_host);
+	a.near_distance = near_distance; a.lens_mode = lens_mode;
+	for (int i = 0; i < 7; ++i) a.lens_params[i] = lens_params_host ? lens_params_host[i] : 0.0f;
+	a.depthbuffer = depthbuffer;
+	const dim3 threads(16, 8, 1);
+	const dim3 blocks(div_up((uint32_t)res_host[0], 16), div_up((uint32_t)res_host[1], 8), 1);
+	hipLaunchKernelGGL(init_rays_kernel, blocks, threads, 0, (hipStream_t)stream, a);
+	NGP_LAUNCH_CHECK("init_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host, uint32_t sample_index,
+                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(advance_pos_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
+	NGP_LAUNCH_CHECK("advance_pos_kernel");
+	return 0;
+}
+
+int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads, float* dst_rgba, float* dst_depth,
+                         NgpPayload* dst_payloads, float* dst_final_rgba, float* dst_final_depth, NgpPayload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(compact_rays_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, (const float4*)src_rgba, src_depth, (const Payload40*)src_payloads,
+	                   (float4*)dst_rgba, dst_depth, (Payload40*)dst_payloads, (float4*)dst_final_rgba, dst_final_depth, (Payload40*)dst_final_payloads, counter, final_counter);
+	NGP_LAUNCH_CHECK("compact_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host, NgpPayload* payloads, NgpCoord* network_input,
+                                 uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(generate_next_inputs_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
+	NGP_LAUNCH_CHECK("generate_next_inputs_kernel");
+	return 0;
+}
+
+int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
+                      NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                      int density_activation, float min_transmittance) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
+	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance);
+	NGP_LAUNCH_CHECK("composite_kernel");
+	return 0;
+}
+
+int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(shade_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, (const float4*)rgba, depth, payloads, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer);
+	NGP_LAUNCH_CHECK("shade_kernel");
+	return 0;
+}
+
+int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space) {
+	const uint32_t n = (uint32_t)res_host[0] * (uint32_t)res_host[1];
+	if (!n) return 0;
+	hipLaunchKernelGGL(accumulate_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, (const float4*)frame_buffer, (float4*)accumulate_buffer, sample_count, color_space);
+	NGP_LAUNCH_CHECK("accumulate_kernel");
+	return 0;
+}
+
+int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer, int color_space, int output_color_space,
+                    int tonemap_curve, int clamp_output_color, float* surface) {
+	const uint32_t n = (uint32_t)res_host[0] * (uint32_t)res_host[1];
+	if (!n) return 0;
+	const float4 bg = make_float4(background_color_host[0], background_color_host[1], background_color_host[2], background_color_host[3]);
+	hipLaunchKernelGGL(tonemap_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, exposure, bg, (const float4*)accumulate_buffer, color_space, output_color_space, tonemap_curve, clamp_output_color != 0, (float4*)surface);
+	NGP_LAUNCH_CHECK("tonemap_kernel");
+	return 0;
+}
+
+} // extern "C"

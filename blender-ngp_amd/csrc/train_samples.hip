@@ -1,0 +1,172 @@
+// train_samples.hip — training ray generation + occupancy-grid marching for gfx950.
+// Replaces src/testbed_nerf.cu:1085-1260 (generate_training_samples_nerf) incl. image_idx (1062-1083),
+// nerf_random_image_pos_training (1047-1060) and the camera models of common_device.cuh:145-258.
+//
+// MI355X notes: the reference reserves output slots with two global atomicAdd's PER RAY (1225, 1232).  Here the 64 lanes
+// of a wave reconverge after the counting pass, build an exclusive prefix over their step counts with wave shuffles and the
+// kept-ray ballot, and one lane issues ONE atomic per counter per wave.  The per-ray results (numsteps, coords) are
+// identical to the reference's; only the slot order differs (it is unordered in the reference as well).
+// Index / count arithmetic is exact (-ffp-contract=off): bit-exact against the CPU oracle.
+#include "ngp_device.cuh"
+
+namespace ngp {
+
+struct TrainSampleArgs {
+	uint32_t n_rays; Aabb aabb; uint32_t max_samples; Pcg32 rng;
+	uint32_t* ray_counter; uint32_t* numsteps_counter; uint32_t* ray_indices_out; NgpRay* rays_out; uint32_t* numsteps_out; NgpCoord* coords_out;
+	uint32_t n_training_images; const NgpImageMeta* metadata; const NgpXForm* xforms; const uint8_t* density_grid;
+	int max_level_rand_training; float* max_level_ptr; int snap_to_pixel_centers; int train_envmap; float cone_angle_constant;
+	const float* distortion_data; int32_t distortion_res[2]; uint32_t ray_offset; uint32_t n_rays_global;
+};
+
+__global__ void __launch_bounds__(256) generate_training_samples_kernel(const TrainSampleArgs a) {
+	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
+	const bool in_range = li < a.n_rays;
+	const uint32_t i = li + a.ray_offset;
+
+	// ---- per-ray setup (dead lanes keep numsteps = 0 and take part in the wave scan)
+	uint32_t numsteps = 0;
+	bool keep = false;
+	float startt = 0.f, cone_angle = a.cone_angle_constant, max_level = 1.0f;
+	v3 ro = mk(0, 0, 0), rd_unnorm = mk(0, 0, 1), rd = mk(0, 0, 1), idir = mk(1, 1, 1);
+
+	if (in_range) {
+		const uint32_t img = ((i * a.n_training_images) / a.n_rays_global) % a.n_training_images; // image_idx, no CDF (1082)
+		const NgpImageMeta& md = a.metadata[img];
+		Pcg32 rng = a.rng;
+		rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
+		float u = rng.next_float(), v = rng.next_float();
+		if (a.snap_to_pixel_centers) {
+			int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
+			px = px > 0 ? px : 0; px = px < md.res[0] - 1 ? px : md.res[0] - 1;
+			py = py > 0 ? py : 0; py = py < md.res[1] - 1 ? py : md.res[1] - 1;
+			u = ((float)px + 0.5f) / (float)md.res[0];
+			v = ((float)py + 0.5f) / (float)md.res[1];
+		}
+		if (!pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) {
+			max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
+			const float motionblur_time = rng.next_float();
+			float xform[12];
+			get_xform_given_rolling_shutter(a.xforms[img], md.rolling_shutter, u, v, motionblur_time, xform);
+			if (md.rays) {
+				int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
+				px = px < md.res[0] - 1 ? px : md.res[0] - 1; px = px > 0 ? px : 0;
+				py = py < md.res[1] - 1 ? py : md.res[1] - 1; py = py > 0 ? py : 0;
+				const NgpRay r = md.rays[(uint64_t)px + (uint64_t)py * (uint64_t)md.res[0]];
+				ro = ld3(r.o); rd_unnorm = ld3(r.d);
+			} else {
+				ro = col(xform, 3);
+				v3 d;
+				if (md.lens_mode == 2) d = f_theta_undistortion(u - md.principal_point[0], v - md.principal_point[1], md.lens_params, mk(0.f, 0.f, 1.f));
+				else if (md.lens_mode == 3) d = latlong_to_dir(u, v);
+				else {
+					d = mk((u - md.principal_point[0]) * (float)md.res[0] / md.focal_length[0], (v - md.principal_point[1]) * (float)md.res[1] / md.focal_length[1], 1.0f);
+					if (md.lens_mode == 1) iterative_opencv_lens_undistortion(md.lens_params, d.x, d.y);
+				}
+				if (a.distortion_data) {
+					float o0, o1;
+					read_image2(a.distortion_data, a.distortion_res[0], a.distortion_res[1], u, v, o0, o1);
+					d.x += o0; d.y += o1;
+				}
+				rd_unnorm = mat3_mul(xform, d); // NOT normalized (1189)
+			}
+			rd = normalized(rd_unnorm);
+			float tmin, tmax;
+			aabb_ray_intersect(a.aabb, ro, rd, tmin, tmax);
+			tmin = fmaxf(tmin, 0.0f);
+			startt = tmin;
+			startt += calc_dt(startt, cone_angle) * rng.next_float();
+			idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+
+			// pass 1: count occupied steps (1204-1219)
+			uint32_t j = 0;
+			float t = startt;
+			v3 pos;
+			while (aabb_contains(a.aabb, pos = ro + rd * t) && j < NGP_NERF_STEPS) {
+				const float dt = calc_dt(t, cone_angle);
+				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+				if (density_grid_occupied_at(pos, a.density_grid, mip)) { ++j; t += dt; }
+				else t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+			}
+			numsteps = j;
+			keep = !(j == 0 && !a.train_envmap);
+			if (!keep) numsteps = 0;
+		}
+	}
+
+	// ---- wave-aggregated slot reservation: one atomic per counter per wave
+	const uint32_t lane = lane_id();
+	const uint32_t incl = wave_inclusive_scan(numsteps);
+	const uint32_t wave_total = __shfl(incl, 63, 64);
+	uint32_t wave_base = 0;
+	if (lane == 63 && wave_total) wave_base = atomicAdd(a.numsteps_counter, wave_total);
+	wave_base = __shfl(wave_base, 63, 64);
+	const uint32_t base = wave_base + incl - numsteps;
+	// a ray whose run would overflow is dropped AFTER the counter was bumped (1225-1228)
+	if (keep && base + numsteps > a.max_samples) keep = false;
+	const unsigned long long kept_mask = __ballot(keep);
+	const uint32_t n_kept = (uint32_t)__popcll(kept_mask);
+	uint32_t ray_base = 0;
+	if (lane == 0 && n_kept) ray_base = atomicAdd(a.ray_counter, n_kept);
+	ray_base = __shfl(ray_base, 0, 64);
+	if (!keep) return;
+	const uint32_t ray_idx = ray_base + (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull));
+
+	a.ray_indices_out[ray_idx] = i;
+	NgpRay ray_out; ray_out.o[0] = ro.x; ray_out.o[1] = ro.y; ray_out.o[2] = ro.z; ray_out.d[0] = rd_unnorm.x; ray_out.d[1] = rd_unnorm.y; ray_out.d[2] = rd_unnorm.z;
+	a.rays_out[ray_idx] = ray_out;
+	a.numsteps_out[ray_idx * 2 + 0] = numsteps;
+	a.numsteps_out[ray_idx * 2 + 1] = base;
+
+	// pass 2: write the samples (1239-1253)
+	NgpCoord* co = a.coords_out + base;
+	const v3 warped_dir = warp_direction(rd);
+	float t = startt;
+	uint32_t j = 0;
+	v3 pos;
+	while (aabb_contains(a.aabb, pos = ro + rd * t) && j < numsteps) {
+		const float dt = calc_dt(t, cone_angle);
+		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+		if (density_grid_occupied_at(pos, a.density_grid, mip)) {
+			const v3 wp = aabb_relative_pos(a.aabb, pos);
+			NgpCoord c;
+			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
+			c.dir[0] = warped_dir.x; c.dir[1] = warped_dir.y; c.dir[2] = warped_dir.z;
+			co[j] = c;
+			++j;
+			t += dt;
+		} else {
+			t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+		}
+	}
+	if (a.max_level_rand_training) {
+		float* ml = a.max_level_ptr + base;
+		for (j = 0; j < numsteps; ++j) ml[j] = max_level;
+	}
+}
+
+} // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_hip_generate_training_samples(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
+	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
+	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global) {
+	if (!n_rays) return 0;
+	TrainSampleArgs a;
+	a.n_rays = n_rays; a.aabb = aabb_from_host(aabb_host); a.max_samples = max_samples; a.rng.state = rng_state; a.rng.inc = rng_inc;
+	a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out; a.rays_out = rays_out_unnormalized;
+	a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_training_images = n_training_images; a.metadata = metadata; a.xforms = xforms;
+	a.density_grid = density_grid; a.max_level_rand_training = max_level_rand_training; a.max_level_ptr = max_level_ptr;
+	a.snap_to_pixel_centers = snap_to_pixel_centers; a.train_envmap = train_envmap; a.cone_angle_constant = cone_angle_constant;
+	a.distortion_data = distortion_data;
+	a.distortion_res[0] = distortion_resolution_host ? distortion_resolution_host[0] : 0;
+	a.distortion_res[1] = distortion_resolution_host ? distortion_resolution_host[1] : 0;
+	a.ray_offset = ray_offset; a.n_rays_global = n_rays_global ? n_rays_global : n_rays;
+	hipLaunchKernelGGL(generate_training_samples_kernel, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
+	NGP_LAUNCH_CHECK("generate_training_samples_kernel");
+	return 0;
+}

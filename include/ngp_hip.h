@@ -1,0 +1,181 @@
+/*
+ * ngp_hip.h — C ABI of libngp_hip.so: the MI355X (gfx950) kernels behind the blender-ngp NeRF hot path.
+ *
+ * The reference has no C ABI: its only FFI seam is the pybind11 module `pyngp` (src/python_api.cu:306-888) and
+ * everything below is C++ templates dispatching to CUDA / tiny-cuda-nn.  This header is the seam the north star asks
+ * for ("host code stays C++ calling HIP through a thin C-ABI"): one entry point per reference kernel / tcnn call on
+ * the path, cited below.  The host-side `Testbed` (blender-ngp_amd/host) is the only intended caller; INTEGRATION.md
+ * shows how a maintainer of the reference would bind it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are stream-ordered, none syncs;
+ *   - no allocation happens inside the library; scratch is passed in explicitly;
+ *   - return value: 0 on success, otherwise a hipError_t (or a negative library code); ngp_hip_last_error() returns text;
+ *   - fp16 data crosses the boundary as uint16_t (IEEE binary16 bits);
+ *   - matrices are column-major like Eigen (3x4 camera matrix = 12 floats, column c at [3c..3c+2]).
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_HIP_ABI_VERSION 1
+
+/* ---- constants (src/testbed_nerf.cu:53-73, include/neural-graphics-primitives/nerf.h:24-26) ---- */
+#define NGP_NERF_GRIDSIZE 128u
+#define NGP_NERF_GRID_N_CELLS (128u * 128u * 128u)
+#define NGP_NERF_CASCADES 8u
+#define NGP_NERF_STEPS 1024u
+#define NGP_N_MAX_RANDOM_SAMPLES_PER_RAY 8u
+#define NGP_MLP_N_PARAMS 10240u /* density 32->64->16 (3072) + rgb 32->64->64->16 (7168): configs/nerf/base.json:30-36,52-58 */
+
+/* ---- PODs ---- */
+typedef struct { float min[3], max[3]; } NgpAabb;                    /* bounding_box.cuh:43-268 */
+typedef struct { float o[3], d[3]; } NgpRay;                         /* common.h:169-172 */
+typedef struct { float start[12], end[12]; } NgpXForm;               /* common.h:174-177 TrainingXForm */
+typedef struct { float pos[3]; float dt; float dir[3]; } NgpCoord;   /* nerf.h:86-107 NerfCoordinate (28 B) */
+typedef struct {                                                     /* nerf.h:28-36 NerfPayload (40 B) */
+	float origin[3]; float dir[3]; float t; float max_weight; uint32_t idx; uint16_t n_steps; uint8_t alive; uint8_t pad_;
+} NgpPayload;
+typedef struct {                                                     /* nerf_loader.h:30-45 TrainingImageMetadata */
+	const void* pixels;       /* device: RGBA8 (1), half4 (2), float4 (3) — common_device.cuh:621-626 */
+	int32_t image_data_type;
+	int32_t res[2];
+	float focal_length[2];
+	float principal_point[2];
+	float rolling_shutter[4];
+	int32_t lens_mode;        /* common.h:179-184: 0 perspective, 1 opencv, 2 ftheta, 3 latlong */
+	float lens_params[7];
+	const float* depth;       /* device or NULL */
+	const NgpRay* rays;       /* device or NULL */
+} NgpImageMeta;
+typedef struct { float scale; uint32_t resolution; uint32_t offset; uint32_t size; } NgpGridLevel;
+typedef struct {                                                     /* tcnn GridEncoding geometry (HashGrid, F=2, 3-D) */
+	uint32_t n_levels;        /* must be 16 (configs/nerf/base.json:23-29) */
+	uint32_t n_grid_entries;  /* sum of level sizes; grid params = 2 * n_grid_entries */
+	NgpGridLevel levels[16];
+} NgpNetDesc;
+
+/* enums mirror include/neural-graphics-primitives/common.h:103-141 */
+enum { NGP_LOSS_L2 = 0, NGP_LOSS_L1 = 1, NGP_LOSS_MAPE = 2, NGP_LOSS_SMAPE = 3, NGP_LOSS_HUBER = 4, NGP_LOSS_LOG_L1 = 5, NGP_LOSS_RELATIVE_L2 = 6 };
+enum { NGP_ACT_NONE = 0, NGP_ACT_RELU = 1, NGP_ACT_LOGISTIC = 2, NGP_ACT_EXPONENTIAL = 3 };
+enum { NGP_COLOR_LINEAR = 0, NGP_COLOR_SRGB = 1 };
+enum { NGP_TONEMAP_IDENTITY = 0, NGP_TONEMAP_ACES = 1, NGP_TONEMAP_HABLE = 2, NGP_TONEMAP_REINHARD = 3 };
+
+int ngp_hip_abi_version(void);
+const char* ngp_hip_last_error(void);
+
+/* ============================ network (tiny-cuda-nn replacement) ============================ */
+
+/* tcnn GridEncoding ctor (level scale / resolution / offset table); per_level_scale per src/testbed.cu:2313-2325. Host only. */
+int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* desc_host);
+/* number of parameters: 10240 + 2*n_grid_entries; order density MLP, rgb MLP, grid (nerf_network.h:361-394). Host only. */
+uint32_t ngp_hip_net_n_params_host(const NgpNetDesc* desc_host);
+
+/* NerfNetwork::initialize_params (nerf_network.h:396-441) driven by Trainer(seed) (src/testbed.cu:2445): fills the fp32 master
+ * copy and the fp16 training + inference copies. */
+int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params);
+
+/* NerfNetwork::inference_mixed_precision_impl (nerf_network.h:103-137); call sites src/testbed_nerf.cu:2223, 3256,
+ * src/nerf_renderer.cu:763.  coords: n records of `coord_stride_floats` floats (pos at 0..2, dir at 4..6).
+ * out: fp16, sample i at out[i*out_stride + 0..3] = (r, g, b, sigma) raw network outputs.  `desc_dev` is a device copy of the desc. */
+int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                           uint32_t n, uint16_t* out, uint32_t out_stride);
+
+/* NerfNetwork::density (nerf_network.h:268-284); call site src/testbed_nerf.cu:2833.  out0[i] = density-net output channel 0 (fp16). */
+int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
+                         uint32_t n, uint16_t* out0);
+
+/* NerfNetwork::forward_impl (nerf_network.h:143-185); call site src/testbed_nerf.cu:3330.  Same outputs as inference plus the
+ * encoded features x_saved [n][32] fp16 that backward consumes (the tcnn ForwardContext). */
+int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+
+/* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only. */
+uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
+
+/* NerfNetwork::backward_impl (nerf_network.h:187-266) with EGradientMode::Overwrite; call site src/testbed_nerf.cu:3331.
+ * dL_dout: fp16 [n][dl_stride] with channels 0..3 consumed (extract_rgb 46-60, add_density_gradient 63-74).
+ * grads: fp16 [n_params]; the whole vector is overwritten (MLP part written, grid part zeroed then scatter-added). */
+int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                          uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes);
+
+/* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
+ * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */
+int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
+                           float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
+                           float* first_moments, float* second_moments, float* ema, uint16_t* inference_params);
+
+/* ============================ occupancy grid (src/testbed_nerf.cu:369-610, 2761-2859) ============================ */
+int ngp_hip_mark_untrained_density_grid(void* stream, uint32_t n_elements, float* grid_out, uint32_t n_training_images,
+                                        const NgpImageMeta* metadata, const NgpXForm* xforms, int clear_visible_voxels);      /* :369 */
+int ngp_hip_generate_grid_samples_nonuniform(void* stream, uint32_t n_elements, uint64_t rng_state, uint64_t rng_inc, uint32_t step,
+                                             const NgpAabb* aabb_host, const float* grid_in, float* out_pos, uint32_t* indices,
+                                             uint32_t n_cascades, float thresh);                                              /* :465 */
+int ngp_hip_splat_grid_samples_max(void* stream, uint32_t n_elements, const uint32_t* indices, const uint16_t* network_output,
+                                   float* grid_out, int density_activation);                                                  /* :496 */
+int ngp_hip_ema_grid_samples(void* stream, uint32_t n_elements, float decay, float* grid_out, const float* grid_in);          /* :532 */
+/* reduce_sum(max(v,0)/n) over cascade 0 (:2851-2852): writes one float to mean_out (zeroed inside). */
+int ngp_hip_density_grid_mean(void* stream, const float* grid, uint32_t n_elements, float* mean_out);
+/* grid_to_bitfield (:563) + 7x bitfield_max_pool (:589), as update_density_grid_mean_and_bitfield (:2854-2858) issues them. */
+int ngp_hip_grid_to_bitfield_and_pool(void* stream, const float* grid, uint32_t n_cascades_used, const float* mean_density, uint8_t* bitfield);
+
+/* ============================ training rays (src/testbed_nerf.cu:1085-1260) ============================ */
+/* generate_training_samples_nerf.  ray_offset / n_rays_global are the data-parallel extension: thread i marches global ray
+ * ray_offset+i out of n_rays_global (image choice, rng stream); pass (0, n_rays) for the reference's single-GPU behaviour. */
+int ngp_hip_generate_training_samples(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
+	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
+	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global);
+
+/* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================ */
+int ngp_hip_compute_loss(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
+	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
+	int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const NgpImageMeta* metadata,
+	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const NgpRay* rays_in_unnormalized,
+	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
+	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
+	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
+	float near_distance);
+/* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
+int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
+int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);
+/* tcnn reduce_sum(float*) as used for the loss scalar (:2887): sum of n floats into out (zeroed inside). */
+int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out);
+
+/* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */
+int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
+                      const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
+                      const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
+                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host,
+                      float* depthbuffer);                                                                                     /* :1809 */
+int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
+                        uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant); /* :612 */
+int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,
+                         float* dst_rgba, float* dst_depth, NgpPayload* dst_payloads, float* dst_final_rgba, float* dst_final_depth,
+                         NgpPayload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);                          /* :1784 */
+int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host,
+                                 NgpPayload* payloads, NgpCoord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip,
+                                 float cone_angle_constant);                                                                   /* :705 */
+int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host,
+                      float* rgba, float* depth, NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output,
+                      uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance);    /* :767 */
+int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads,
+                  int train_in_linear_colors, float* frame_buffer, float* depth_buffer);                                       /* :1748 */
+int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space); /* render_buffer.cu:235 */
+int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
+                    int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see orc_core.h header).
+ * Loss / compositing / compaction of one training step.
+ * Follows src/testbed_nerf.cu:121-189 (losses), 1263-1278, 1280-1597 (compute_loss_kernel_train_nerf),
+ * 3314-3322 (fill_rollover call sites; kernels are [tcnn] common_device.h).
+ * Default-off features (envmap, error-map CDF sampling, sharpness, depth supervision, exposure gradients,
+ * testbed.h:651-680) are not restated; the always-on error-map deposit (1465-1491) is.
+ */
+#include "ngp_oracle.h"
+
+typedef struct { float loss[3]; float gradient[3]; } orc_lg;
+
+static inline float orc_copysign1(float a, float b) { return copysignf(a, b); }
+
+/* testbed_nerf.cu:121-189, 1263-1278.  ELossType: common.h:118-126 {L2, L1, Mape, Smape, Huber, LogL1, RelativeL2} */
+static orc_lg orc_loss_and_gradient(const float target[3], const float prediction[3], int loss_type) {
+	orc_lg r;
+	for (int c = 0; c < 3; ++c) {
+		float t = target[c], p = prediction[c];
+		float diff = p - t;
+		switch (loss_type) {
+			case ORC_LOSS_RELATIVE_L2: {
+				float factor = 1.0f / (p * p + 1e-2f);
+				r.loss[c] = diff * diff * factor; r.gradient[c] = 2.0f * diff * factor; break; }
+			case ORC_LOSS_L1: r.loss[c] = fabsf(diff); r.gradient[c] = orc_copysign1(1.0f, diff); break;
+			case ORC_LOSS_MAPE: {
+				float factor = 1.0f / (fabsf(p) + 1e-2f);
+				r.loss[c] = fabsf(diff) * factor; r.gradient[c] = orc_copysign1(factor, diff); break; }
+			case ORC_LOSS_SMAPE: {
+				float factor = 1.0f / (0.5f * (fabsf(p) + fabsf(t)) + 1e-2f);
+				r.loss[c] = fabsf(diff) * factor; r.gradient[c] = orc_copysign1(factor, diff); break; }
+			case ORC_LOSS_HUBER: {
+				const float alpha = 0.1f;
+				float ad = fabsf(diff);
+				float square = 0.5f / alpha * diff * diff;
+				float l = ad > alpha ? (ad - 0.5f * alpha) : square;
+				float g = ad > alpha ? (diff > 0 ? 1.0f : -1.0f) : (diff / alpha);
+				r.loss[c] = l / 5.0f; r.gradient[c] = g / 5.0f; break; }
+			case ORC_LOSS_LOG_L1: {
+				float divisor = fabsf(diff) + 1.0f;
+				r.loss[c] = logf(divisor); r.gradient[c] = orc_copysign1(1.0f / divisor, diff); break; }
+			default: r.loss[c] = diff * diff; r.gradient[c] = 2.0f * diff; break;
+		}
+	}
+	return r;
+}
+
+void orc_loss_and_gradient_export(const float* target, const float* prediction, int loss_type, float* loss, float* grad) {
+	orc_lg r = orc_loss_and_gradient(target, prediction, loss_type);
+	for (int c = 0; c < 3; ++c) { loss[c] = r.loss[c]; grad[c] = r.gradient[c]; }
+}
+
+/* testbed_nerf.cu:1280-1597.  mlp_out: fp16 [sample][mlp_stride] (channels 0..3 = rgb,sigma), coords 7 floats/sample.
+ * Rays are visited in index order so the compacted order is deterministic; the GPU order is not, tests compare per ray
+ * through numsteps_in[i*2+1] (compacted base). */
+void orc_compute_loss(
+	uint32_t n_rays /* rays_per_batch: normalisation + image_idx */, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t max_samples_compacted, uint32_t n_rays_alive /* *rays_counter */, float loss_scale, uint32_t mlp_stride,
+	const float background_color_in[3], int color_space_srgb, int train_with_random_bg_color, int train_in_linear_colors,
+	uint32_t n_training_images, const orc_image_meta* metadata, const uint16_t* network_output, uint32_t* numsteps_counter,
+	const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, uint32_t* numsteps_in, const orc_coord* coords_in_all,
+	orc_coord* coords_out_all, uint16_t* dloss_doutput_all /* [max_samples_compacted][mlp_stride] */, int loss_type,
+	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
+	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
+	float near_distance) {
+	for (uint32_t i = 0; i < n_rays_alive; ++i) {
+		uint32_t numsteps = numsteps_in[i * 2 + 0];
+		uint32_t base = numsteps_in[i * 2 + 1];
+		const orc_coord* coords_in = coords_in_all + base;
+		const uint16_t* no = network_output + (size_t)base * mlp_stride;
+
+		float T = 1.f;
+		const float EPSILON = 1e-4f;
+		float rgb_ray[3] = {0, 0, 0};
+		float depth_ray = 0.f;
+		uint32_t compacted_numsteps = 0;
+		orc_vec3 ray_o = rays_in_unnormalized[i].o;
+		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
+			if (T < EPSILON) break;
+			const uint16_t* lo = no + (size_t)compacted_numsteps * mlp_stride;
+			float rgb[3];
+			for (int c = 0; c < 3; ++c) rgb[c] = orc_network_to_rgb(orc_h2f(lo[c]), rgb_activation);
+			const orc_coord* ci = &coords_in[compacted_numsteps];
+			orc_vec3 pos = orc_unwarp_position(orc_v3(ci->pos[0], ci->pos[1], ci->pos[2]), aabb);
+			float dt = orc_unwarp_dt(ci->dt);
+			float cur_depth = orc_norm(orc_sub(pos, ray_o));
+			float density = orc_network_to_density(orc_h2f(lo[3]), density_activation);
+			float alpha = 1.f - expf(-density * dt);
+			float weight = alpha * T;
+			for (int c = 0; c < 3; ++c) rgb_ray[c] += weight * rgb[c];
+			depth_ray += weight * cur_depth;
+			T *= (1.f - alpha);
+		}
+
+		uint32_t ray_idx = ray_indices_in[i];
+		orc_pcg32 rng = {rng_state, rng_inc};
+		orc_pcg32_advance(&rng, (int64_t)((uint64_t)(uint32_t)(ray_idx * ORC_N_MAX_RANDOM_SAMPLES_PER_RAY)));
+		uint32_t img = ((ray_idx * n_training_images) / n_rays) % n_training_images;
+		const orc_image_meta* md = &metadata[img];
+		float xy[2];
+		orc_nerf_random_image_pos_training(&rng, md->res, snap_to_pixel_centers, xy);
+		float max_level = max_level_rand_training ? (orc_pcg32_next_float(&rng) * 2.0f) : 1.0f;
+
+		float background_color[3] = {background_color_in[0], background_color_in[1], background_color_in[2]};
+		if (train_with_random_bg_color) {
+			for (int c = 0; c < 3; ++c) background_color[c] = orc_pcg32_next_float(&rng);
+		}
+		for (int c = 0; c < 3; ++c) background_color[c] = orc_srgb_to_linear(background_color[c]);
+
+		float exposure_scale[3];
+		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * exposure[img * 3 + c]);
+		float texsamp[4];
+		orc_read_rgba(xy, md->res, md->pixels, md->image_data_type, texsamp);
+
+		float rgbtarget[3];
+		if (train_in_linear_colors || !color_space_srgb) {
+			for (int c = 0; c < 3; ++c) rgbtarget[c] = exposure_scale[c] * texsamp[c] + (1.0f - texsamp[3]) * background_color[c];
+			if (!train_in_linear_colors) {
+				for (int c = 0; c < 3; ++c) { rgbtarget[c] = orc_linear_to_srgb(rgbtarget[c]); background_color[c] = orc_linear_to_srgb(background_color[c]); }
+			}
+		} else {
+			for (int c = 0; c < 3; ++c) background_color[c] = orc_linear_to_srgb(background_color[c]);
+			if (texsamp[3] > 0) {
+				for (int c = 0; c < 3; ++c) rgbtarget[c] = orc_linear_to_srgb(exposure_scale[c] * texsamp[c] / texsamp[3]) * texsamp[3] + (1.0f - texsamp[3]) * background_color[c];
+			} else {
+				for (int c = 0; c < 3; ++c) rgbtarget[c] = background_color[c];
+			}
+		}
+
+		if (compacted_numsteps == numsteps) {
+			for (int c = 0; c < 3; ++c) rgb_ray[c] += T * background_color[c];
+		}
+
+		uint32_t compacted_base = *numsteps_counter; *numsteps_counter += compacted_numsteps;
+		uint32_t room = max_samples_compacted - (max_samples_compacted < compacted_base ? max_samples_compacted : compacted_base);
+		compacted_numsteps = room < compacted_numsteps ? room : compacted_numsteps;
+		numsteps_in[i * 2 + 0] = compacted_numsteps;
+		numsteps_in[i * 2 + 1] = compacted_base;
+		if (compacted_numsteps == 0) continue;
+
+		float* max_level_compacted_ptr = max_level_compacted_ptr_all ? max_level_compacted_ptr_all + compacted_base : NULL;
+		orc_coord* coords_out = coords_out_all + compacted_base;
+		uint16_t* dloss_doutput = dloss_doutput_all + (size_t)compacted_base * mlp_stride;
+
+		orc_lg lg = orc_loss_and_gradient(rgbtarget, rgb_ray, loss_type);
+		/* img_pdf * xy_pdf == 1 without CDF sampling (1448) */
+		float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
+		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
+
+		if (error_map) {
+			float posx = xy[0] * (float)error_map_res[0] - 0.5f, posy = xy[1] * (float)error_map_res[1] - 0.5f;
+			posx = fminf(fmaxf(posx, 0.0f), (float)error_map_res[0] - (1.0f + 1e-4f));
+			posy = fminf(fmaxf(posy, 0.0f), (float)error_map_res[1] - (1.0f + 1e-4f));
+			int pix = (int)posx, piy = (int)posy;
+			float wx = posx - (float)pix, wy = posy - (float)piy;
+			/* 1470: idx = pos_int.cwiseMin(resolution - 2).cwiseMax(0) — `resolution` is the IMAGE resolution there */
+			int ix = pix < md->res[0] - 2 ? pix : md->res[0] - 2; ix = ix > 0 ? ix : 0;
+			int iy = piy < md->res[1] - 2 ? piy : md->res[1] - 2; iy = iy > 0 ? iy : 0;
+			size_t b = (size_t)img * (size_t)error_map_res[0] * (size_t)error_map_res[1];
+			error_map[b + (size_t)iy * error_map_res[0] + ix] += (1 - wx) * (1 - wy) * mean_loss;
+			error_map[b + (size_t)iy * error_map_res[0] + ix + 1] += wx * (1 - wy) * mean_loss;
+			error_map[b + (size_t)(iy + 1) * error_map_res[0] + ix] += (1 - wx) * wy * mean_loss;
+			error_map[b + (size_t)(iy + 1) * error_map_res[0] + ix + 1] += wx * wy * mean_loss;
+		}
+
+		float ls = loss_scale / (float)n_rays;
+		const float output_l2_reg = rgb_activation == ORC_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
+		const float output_l1_reg_density = mean_density < ORC_NERF_MIN_OPTICAL_THICKNESS ? 1e-4f : 0.0f;
+
+		float rgb_ray2[3] = {0.f, 0.f, 0.f};
+		float depth_ray2 = 0.f;
+		T = 1.f;
+		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
+			if (max_level_rand_training && max_level_compacted_ptr) max_level_compacted_ptr[j] = max_level;
+			coords_out[j] = coords_in[j];
+			const orc_coord* ci = &coords_in[j];
+			orc_vec3 pos = orc_unwarp_position(orc_v3(ci->pos[0], ci->pos[1], ci->pos[2]), aabb);
+			float depth = orc_norm(orc_sub(pos, ray_o));
+			float dt = orc_unwarp_dt(ci->dt);
+			const uint16_t* lo = no + (size_t)j * mlp_stride;
+			float lof[4];
+			for (int c = 0; c < 4; ++c) lof[c] = orc_h2f(lo[c]);
+			float rgb[3];
+			for (int c = 0; c < 3; ++c) rgb[c] = orc_network_to_rgb(lof[c], rgb_activation);
+			float density = orc_network_to_density(lof[3], density_activation);
+			float alpha = 1.f - expf(-density * dt);
+			float weight = alpha * T;
+			for (int c = 0; c < 3; ++c) rgb_ray2[c] += weight * rgb[c];
+			depth_ray2 += weight * depth;
+			T *= (1.f - alpha);
+
+			float suffix[3], dloss_by_drgb[3];
+			for (int c = 0; c < 3; ++c) { suffix[c] = rgb_ray[c] - rgb_ray2[c]; dloss_by_drgb[c] = weight * lg.gradient[c]; }
+
+			uint16_t* dl = dloss_doutput + (size_t)j * mlp_stride;
+			for (int c = 0; c < 3; ++c) {
+				dl[c] = orc_f2h(ls * (dloss_by_drgb[c] * orc_network_to_rgb_derivative(lof[c], rgb_activation) + fmaxf(0.0f, output_l2_reg * lof[c])));
+			}
+			float density_derivative = orc_network_to_density_derivative(lof[3], density_activation);
+			/* depth supervision off: depth_loss_gradient == 0 (1450-1452) */
+			float dotv = lg.gradient[0] * (T * rgb[0] - suffix[0]) + lg.gradient[1] * (T * rgb[1] - suffix[1]) + lg.gradient[2] * (T * rgb[2] - suffix[2]);
+			float dloss_by_dmlp = density_derivative * (dt * (dotv + 0.0f));
+			dl[3] = orc_f2h(
+				ls * dloss_by_dmlp +
+				(lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) +
+				(lof[3] > -10.0f && depth < near_distance ? 1e-4f : 0.0f));
+		}
+		(void)depth_ray; (void)depth_ray2;
+	}
+}
+
+/* [tcnn] common_device.h fill_rollover / fill_rollover_and_rescale, call sites testbed_nerf.cu:3314-3322:
+ *   n_input = *n_input_elements_ptr * stride; n_total = n_elements * stride;
+ *   if (i < n_input || i >= n_total || n_input == 0) return;
+ *   fill_rollover:             inout[i] = inout[i % n_input]
+ *   fill_rollover_and_rescale: inout[i] = (T)((float)inout[i % n_input] * n_input / n_total)
+ * i.e. only the wrapped-around copies are rescaled; the kept originals are left untouched. */
+void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout) {
+	size_t total = (size_t)n_elements * stride, avail = (size_t)n_input_elements * stride;
+	if (avail == 0 || avail >= total) return;
+	for (size_t i = avail; i < total; ++i) inout[i] = orc_f2h(orc_h2f(inout[i % avail]) * (float)avail / (float)total);
+}
+void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout) {
+	size_t total = (size_t)n_elements * stride, avail = (size_t)n_input_elements * stride;
+	if (avail == 0 || avail >= total) return;
+	for (size_t i = avail; i < total; ++i) inout[i] = inout[i % avail];
+}

@@ -1,0 +1,328 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see orc_core.h header).
+ * Single-NeRF renderer (Testbed::NerfTracer) + frame accumulation / tonemap.
+ * Follows src/testbed_nerf.cu:612-664 (advance_pos_nerf), 705-765 (generate_next_nerf_network_inputs),
+ * 767-989 (composite_kernel_nerf, Shade mode, no masks/glow), 1748-1781 (shade), 1784-1807 (compact),
+ * 1809-1978 (init rays, Perspective camera), 2140-2267 (trace loop), common_device.cuh:260-317 (pixel_to_ray),
+ * src/render_buffer.cu:235-272 (accumulate), 274-348 + 540-567 (tonemap).
+ */
+#include "ngp_oracle.h"
+#include <stdlib.h>
+
+/* common_device.cuh:260-317 pixel_to_ray (aperture_size == 0, no distortion grid) */
+static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[2], const float focal_length[2], const float* cam /* 3x4 */,
+                                const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, float near_distance,
+                                int lens_mode, const float* lens_params) {
+	float offset[2];
+	orc_ld_random_pixel_offset(snap_to_pixel_centers ? 0 : spp, offset);
+	float u = ((float)px + offset[0]) / (float)res[0];
+	float v = ((float)py + offset[1]) / (float)res[1];
+	orc_vec3 dir = orc_v3(
+		(u - screen_center[0]) * (float)res[0] / focal_length[0],
+		(v - screen_center[1]) * (float)res[1] / focal_length[1],
+		1.0f);
+	if (lens_mode == 1) orc_iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+	orc_vec3 head_pos = orc_v3(parallax_shift[0], parallax_shift[1], 0.f);
+	dir = orc_sub(dir, orc_scale(head_pos, parallax_shift[2]));
+	dir = orc_mat3_mul(cam, dir);
+	orc_vec3 origin = orc_add(orc_mat3_mul(cam, head_pos), orc_col(cam, 3));
+	origin = orc_add(origin, orc_scale(dir, near_distance));
+	orc_ray r = {origin, dir};
+	return r;
+}
+
+/* testbed_nerf.cu:1809-1978 init_rays_with_payload_kernel_nerf, Perspective camera, plane_z >= 0 path, no masks / envmap,
+ * render_aabb_to_local = identity-or-given 3x3 (column-major). */
+void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2],
+                   const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2],
+                   const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local /* 3x3 */,
+                   float near_distance, int lens_mode, const float* lens_params, float* depthbuffer) {
+	for (int y = 0; y < res[1]; ++y) for (int x = 0; x < res[0]; ++x) {
+		uint32_t idx = (uint32_t)x + (uint32_t)res[0] * (uint32_t)y;
+		float u = ((float)x + 0.5f) * (1.f / (float)res[0]);
+		float v = ((float)y + 0.5f) * (1.f / (float)res[1]);
+		float ray_time = rolling_shutter[0] + rolling_shutter[1] * u + rolling_shutter[2] * v + rolling_shutter[3] * orc_ld_random_val(sample_index, idx * 72239731u, 0);
+		float cam[12];
+		for (int k = 0; k < 12; ++k) cam[k] = camera_matrix0[k] * ray_time + camera_matrix1[k] * (1.f - ray_time);
+		orc_ray ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params);
+
+		orc_payload* p = &payloads[idx];
+		p->max_weight = 0.0f;
+		depthbuffer[idx] = 1e10f;
+		ray.d = orc_normalized(ray.d);
+		orc_vec3 lo = orc_mat3_mul(render_aabb_to_local, ray.o), ld = orc_mat3_mul(render_aabb_to_local, ray.d);
+		float tmm[2];
+		orc_aabb_ray_intersect(render_aabb, lo, ld, tmm);
+		float t = fmaxf(tmm[0], 0.0f) + 1e-6f;
+		if (!orc_aabb_contains(render_aabb, orc_mat3_mul(render_aabb_to_local, orc_add(ray.o, orc_scale(ray.d, t))))) {
+			p->origin = ray.o;
+			p->alive = 0;
+			continue;
+		}
+		p->origin = ray.o;
+		p->dir = ray.d;
+		p->t = t;
+		p->idx = idx;
+		p->n_steps = 0;
+		p->alive = 1;
+	}
+}
+
+/* testbed_nerf.cu:612-664 */
+void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index,
+                     orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		orc_payload* p = &payloads[i];
+		if (!p->alive) continue;
+		orc_vec3 origin = p->origin, dir = p->dir;
+		orc_vec3 idir = orc_v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		float cone_angle = cone_angle_constant;
+		float t = p->t;
+		float dt = orc_calc_dt(t, cone_angle);
+		t += orc_ld_random_val(sample_index, i * 786433u, 0) * dt;
+		orc_vec3 pos;
+		while (1) {
+			pos = orc_add(origin, orc_scale(dir, t));
+			if (!orc_aabb_contains(render_aabb, orc_mat3_mul(render_aabb_to_local, pos))) { p->alive = 0; break; }
+			dt = orc_calc_dt(t, cone_angle);
+			uint32_t mip = (uint32_t)orc_mip_from_dt(dt, pos, ORC_NERF_CASCADES - 1);
+			if (mip < min_mip) mip = min_mip;
+			if (!density_grid || orc_density_grid_occupied_at(pos, density_grid, mip)) break;
+			uint32_t res = ORC_NERF_GRIDSIZE >> mip;
+			t = orc_advance_to_next_voxel(t, cone_angle, pos, dir, idir, res);
+		}
+		p->t = t;
+	}
+}
+
+/* testbed_nerf.cu:1784-1807 (sequential => deterministic order) */
+void orc_compact_rays(uint32_t n_elements, const float* src_rgba, const float* src_depth, const orc_payload* src_payloads,
+                      float* dst_rgba, float* dst_depth, orc_payload* dst_payloads,
+                      float* dst_final_rgba, float* dst_final_depth, orc_payload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		if (src_payloads[i].alive) {
+			uint32_t idx = (*counter)++;
+			dst_payloads[idx] = src_payloads[i];
+			memcpy(dst_rgba + 4 * idx, src_rgba + 4 * i, 16);
+			dst_depth[idx] = src_depth[i];
+		} else if (src_rgba[4 * i + 3] > 0.001f) {
+			uint32_t idx = (*final_counter)++;
+			dst_final_payloads[idx] = src_payloads[i];
+			memcpy(dst_final_rgba + 4 * idx, src_rgba + 4 * i, 16);
+			dst_final_depth[idx] = src_depth[i];
+		}
+	}
+}
+
+/* testbed_nerf.cu:705-765; network_input is SoA-strided: sample j of ray i at [i + j*n_elements] */
+void orc_generate_next_inputs(uint32_t n_elements, const orc_aabb* render_aabb, const orc_aabb* train_aabb, orc_payload* payloads,
+                              orc_coord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		orc_payload* p = &payloads[i];
+		if (!p->alive) continue;
+		orc_vec3 origin = p->origin, dir = p->dir;
+		orc_vec3 idir = orc_v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		float cone_angle = cone_angle_constant;
+		float t = p->t;
+		uint32_t j;
+		int done = 0;
+		for (j = 0; j < n_steps; ++j) {
+			orc_vec3 pos;
+			float dt = 0.0f;
+			while (1) {
+				pos = orc_add(origin, orc_scale(dir, t));
+				if (!orc_aabb_contains(render_aabb, pos)) { p->n_steps = (uint16_t)j; done = 1; break; }
+				dt = orc_calc_dt(t, cone_angle);
+				uint32_t mip = (uint32_t)orc_mip_from_dt(dt, pos, ORC_NERF_CASCADES - 1);
+				if (mip < min_mip) mip = min_mip;
+				if (!density_grid || orc_density_grid_occupied_at(pos, density_grid, mip)) break;
+				uint32_t res = ORC_NERF_GRIDSIZE >> mip;
+				t = orc_advance_to_next_voxel(t, cone_angle, pos, dir, idir, res);
+			}
+			if (done) break;
+			orc_coord* c = &network_input[i + (size_t)j * n_elements];
+			orc_vec3 wp = orc_aabb_relative_pos(train_aabb, pos);
+			orc_vec3 wd = orc_warp_direction(dir);
+			c->pos[0] = wp.x; c->pos[1] = wp.y; c->pos[2] = wp.z;
+			c->dt = orc_warp_dt(dt);
+			c->dir[0] = wd.x; c->dir[1] = wd.y; c->dir[2] = wd.z;
+			t += dt;
+		}
+		if (done) continue; /* payload.t is NOT written on the early return (745) */
+		p->t = t;
+		p->n_steps = (uint16_t)n_steps;
+	}
+}
+
+/* testbed_nerf.cu:767-989, ERenderMode::Shade, no masks, no glow, show_accel < 0.
+ * network_output: fp16 rgbsigma for sample j of ray i at (i + j*n_elements), `out_stride` halves apart, channel c at +c
+ * (the reference reads a row-major [channel][sample] matrix, 816-819; same values, different addressing). */
+void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix /* 3x4 */,
+                   float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output,
+                   uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance) {
+	orc_vec3 cam_fwd = orc_col(camera_matrix, 2);
+	orc_vec3 cam_pos = orc_col(camera_matrix, 3);
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		orc_payload* p = &payloads[i];
+		if (!p->alive) continue;
+		float local_rgba[4]; memcpy(local_rgba, rgba + 4 * i, 16);
+		float local_depth = depth[i];
+		uint32_t actual_n_steps = p->n_steps;
+		uint32_t j = 0;
+		for (; j < actual_n_steps; ++j) {
+			const uint16_t* lo = network_output + ((size_t)i + (size_t)j * n_elements) * out_stride;
+			const orc_coord* in = &network_input[i + (size_t)j * n_elements];
+			orc_vec3 pos = orc_unwarp_position(orc_v3(in->pos[0], in->pos[1], in->pos[2]), aabb);
+			float T = 1.f - local_rgba[3];
+			float dt = orc_unwarp_dt(in->dt);
+			float alpha = 1.f - expf(-orc_network_to_density(orc_h2f(lo[3]), density_activation) * dt);
+			float weight = alpha * T;
+			float rgb[3];
+			for (int c = 0; c < 3; ++c) rgb[c] = orc_network_to_rgb(orc_h2f(lo[c]), rgb_activation);
+			for (int c = 0; c < 3; ++c) local_rgba[c] += rgb[c] * weight;
+			local_rgba[3] += weight;
+			if (weight > p->max_weight) {
+				p->max_weight = weight;
+				local_depth = orc_dot(cam_fwd, orc_sub(pos, cam_pos));
+			}
+			if (local_rgba[3] > (1.0f - min_transmittance)) {
+				float w = local_rgba[3];
+				for (int c = 0; c < 4; ++c) local_rgba[c] /= w;
+				break;
+			}
+		}
+		if (j < n_steps) {
+			p->alive = 0;
+			p->n_steps = (uint16_t)(j + current_step);
+		}
+		memcpy(rgba + 4 * i, local_rgba, 16);
+		depth[i] = local_depth;
+	}
+}
+
+/* testbed_nerf.cu:1748-1781 Shade mode */
+void orc_shade(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors,
+               float* frame_buffer, float* depth_buffer) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		float tmp[4]; memcpy(tmp, rgba + 4 * i, 16);
+		if (!train_in_linear_colors) for (int c = 0; c < 3; ++c) tmp[c] = orc_srgb_to_linear(tmp[c]);
+		float* fb = frame_buffer + 4 * (size_t)payloads[i].idx;
+		for (int c = 0; c < 4; ++c) fb[c] = tmp[c] + fb[c] * (1.0f - tmp[3]);
+		if (tmp[3] > 0.2f) depth_buffer[payloads[i].idx] = depth[i];
+	}
+}
+
+/* render_buffer.cu:235-272 (Linear / SRGB colour spaces) */
+void orc_accumulate(const int32_t res[2], const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space_srgb) {
+	size_t n = (size_t)res[0] * res[1];
+	for (size_t idx = 0; idx < n; ++idx) {
+		float color[4]; memcpy(color, frame_buffer + 4 * idx, 16);
+		float* tmp = accumulate_buffer + 4 * idx;
+		if (color_space_srgb) for (int c = 0; c < 3; ++c) color[c] = orc_linear_to_srgb(color[c]);
+		for (int c = 0; c < 3; ++c) tmp[c] = (tmp[c] * sample_count + color[c]) / (sample_count + 1);
+		tmp[3] = (tmp[3] * sample_count + color[3]) / (sample_count + 1);
+	}
+}
+
+/* render_buffer.cu:274-348: ETonemapCurve {Identity, ACES, Hable, Reinhard} (common.h:93-98) */
+static void orc_tonemap_curve(float x[3], int curve) {
+	if (curve == 0) return;
+	for (int c = 0; c < 3; ++c) x[c] = fmaxf(x[c], 0.f);
+	float k0, k1, k2, k3, k4, k5;
+	if (curve == 1) {
+		k0 = 0.6f * 0.6f * 2.51f; k1 = 0.6f * 0.03f; k2 = 0.0f; k3 = 0.6f * 0.6f * 2.43f; k4 = 0.6f * 0.59f; k5 = 0.14f;
+	} else if (curve == 2) {
+		const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+		k0 = A * F - A * E; k1 = C * B * F - B * E; k2 = 0.0f; k3 = A * F; k4 = B * F; k5 = D * F * F;
+		const float W = 11.2f;
+		const float nom = k0 * (W * W) + k1 * W + k2;
+		const float denom = k3 * (W * W) + k4 * W + k5;
+		const float white_scale = denom / nom;
+		k0 = 4.0f * k0 * white_scale; k1 = 2.0f * k1 * white_scale; k2 = k2 * white_scale; k3 = 4.0f * k3; k4 = 2.0f * k4;
+	} else {
+		float Y = 0.2126f * x[0] + 0.7152f * x[1] + 0.0722f * x[2];
+		for (int c = 0; c < 3; ++c) x[c] = x[c] * (1.f / (Y + 1.0f));
+		return;
+	}
+	for (int c = 0; c < 3; ++c) {
+		float sq = x[c] * x[c];
+		float nom = sq * k0 + k1 * x[c] + k2;
+		float denom = k3 * sq + k4 * x[c] + k5;
+		x[c] = nom / denom;
+	}
+}
+
+/* render_buffer.cu:327-348, 540-567 */
+void orc_tonemap(const int32_t res[2], float exposure, const float background_color_in[4], const float* accumulate_buffer,
+                 int color_space_srgb, int output_color_space_srgb, int tonemap_curve, int clamp_output_color, float* surface) {
+	size_t n = (size_t)res[0] * res[1];
+	float bg[4]; memcpy(bg, background_color_in, 16);
+	if (!color_space_srgb) for (int c = 0; c < 3; ++c) bg[c] = orc_srgb_to_linear(bg[c]);
+	for (size_t idx = 0; idx < n; ++idx) {
+		float color[4]; memcpy(color, accumulate_buffer + 4 * idx, 16);
+		float weight = (1 - color[3]) * bg[3];
+		for (int c = 0; c < 3; ++c) color[c] += bg[c] * weight;
+		color[3] += weight;
+		if (color_space_srgb) for (int c = 0; c < 3; ++c) color[c] = orc_srgb_to_linear(color[c]);
+		float e = powf(2.0f, exposure);
+		for (int c = 0; c < 3; ++c) color[c] *= e;
+		orc_tonemap_curve(color, tonemap_curve);
+		if (output_color_space_srgb) for (int c = 0; c < 3; ++c) color[c] = orc_linear_to_srgb(color[c]);
+		if (clamp_output_color) for (int c = 0; c < 4; ++c) color[c] = fminf(fmaxf(color[c], 0.0f), 1.0f);
+		memcpy(surface + 4 * idx, color, 16);
+	}
+}
+
+/* testbed_nerf.cu:2354-2500 render_nerf (Shade) = init_rays_from_camera (2047-2138) + trace (2140-2267) + shade (2478).
+ * Writes into frame_buffer/depth_buffer (cleared by the caller as render_frame does, testbed.cu:2698).
+ * `inference_params` = the EMA copy.  Returns the number of network samples evaluated. */
+uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, uint32_t sample_index, const int32_t res[2],
+                         const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float screen_center[2],
+                         int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb,
+                         float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation,
+                         float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer) {
+	const uint32_t n_pixels = (uint32_t)res[0] * (uint32_t)res[1];
+	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
+	orc_payload* payload[2]; float* rgba[2]; float* depth[2];
+	for (int b = 0; b < 2; ++b) {
+		payload[b] = (orc_payload*)calloc(n_pixels, sizeof(orc_payload));
+		rgba[b] = (float*)calloc((size_t)n_pixels * 4, 4);
+		depth[b] = (float*)calloc(n_pixels, 4);
+	}
+	orc_payload* hit_payload = (orc_payload*)calloc(n_pixels, sizeof(orc_payload));
+	float* hit_rgba = (float*)calloc((size_t)n_pixels * 4, 4);
+	float* hit_depth = (float*)calloc(n_pixels, 4);
+	orc_coord* net_in = (orc_coord*)calloc((size_t)n_pixels * 8, sizeof(orc_coord));
+	uint16_t* net_out = (uint16_t*)calloc((size_t)n_pixels * 8 * 4, 2);
+
+	orc_init_rays(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
+	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer);
+	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant);
+
+	uint32_t n_alive = n_pixels, n_hit = 0, i = 1, dbi = 0;
+	uint64_t n_samples = 0;
+	while (i < 10000) {
+		int cur = (dbi + 1) % 2, tmp = dbi % 2;
+		++dbi;
+		uint32_t alive = 0;
+		orc_compact_rays(n_alive, rgba[tmp], depth[tmp], payload[tmp], rgba[cur], depth[cur], payload[cur], hit_rgba, hit_depth, hit_payload, &alive, &n_hit);
+		n_alive = alive;
+		if (n_alive == 0) break;
+		uint32_t n_steps = n_pixels / n_alive; n_steps = n_steps < 1 ? 1 : (n_steps > 8 ? 8 : n_steps);
+		orc_generate_next_inputs(n_alive, render_aabb, train_aabb, payload[cur], net_in, n_steps, density_grid, 0, cone_angle_constant);
+		/* only slots of alive rays with j < payload.n_steps are consumed by the compositor */
+		for (uint32_t j = 0; j < n_steps; ++j) for (uint32_t r = 0; r < n_alive; ++r) {
+			if (j < payload[cur][r].n_steps) {
+				size_t s = r + (size_t)j * n_alive;
+				orc_nerf_inference(net, inference_params, (const float*)&net_in[s], 7, 1, net_out + s * 4, 4);
+				++n_samples;
+			}
+		}
+		orc_composite(n_alive, i, train_aabb, camera_matrix1, rgba[cur], depth[cur], payload[cur], net_in, net_out, 4, n_steps, rgb_activation, density_activation, min_transmittance);
+		i += n_steps;
+	}
+	orc_shade(n_hit, hit_rgba, hit_depth, hit_payload, train_in_linear_colors, frame_buffer, depth_buffer);
+	for (int b = 0; b < 2; ++b) { free(payload[b]); free(rgba[b]); free(depth[b]); }
+	free(hit_payload); free(hit_rgba); free(hit_depth); free(net_in); free(net_out);
+	return n_samples;
+}

@@ -1,0 +1,47 @@
+"""CPU tests: the C-ABI library loads without a GPU and exports every symbol include/ngp_hip.h declares (no compute calls)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+
+import capi
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(ngp):
+    header = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    declared = set(re.findall(r"\b(ngp_hip_\w+)\s*\(", header))
+    assert len(declared) >= 30
+    nm = subprocess.run(["nm", "-D", "--defined-only", ngp.so_path], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ngp_hip_\w+)", nm))
+    assert declared <= exported, sorted(declared - exported)
+    assert set(ngp.protos) == declared
+    assert ngp.ngp_hip_abi_version() == 1
+
+
+def test_no_torch_or_oracle_in_the_abi(ngp):
+    deps = subprocess.run(["ldd", ngp.so_path], capture_output=True, text=True).stdout
+    assert "torch" not in deps and "oracle" not in deps and "libamdhip64" in deps
+    header = open(os.path.join(ROOT, "include", "ngp_hip.h")).read()
+    assert "torch" not in header and "at::" not in header
+
+
+def test_pod_layouts_match_the_header():
+    src = '#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(NgpAabb), sizeof(NgpRay), sizeof(NgpXForm), sizeof(NgpCoord), sizeof(NgpPayload), sizeof(NgpImageMeta), sizeof(NgpNetDesc));}' % os.path.join(ROOT, "include", "ngp_hip.h")
+    exe = "/tmp/ngp_sizes_%d" % os.getpid()
+    subprocess.run(["gcc", "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
+    sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    os.remove(exe)
+    assert sizes == [capi.AABB.itemsize, capi.RAY.itemsize, capi.XFORM.itemsize, capi.COORD.itemsize, capi.PAYLOAD.itemsize, capi.IMAGE_META.itemsize, capi.NET_DESC.itemsize]
+
+
+def test_host_only_entry_points(ngp):
+    d = H.make_desc(ngp, 15, 16, 1)
+    assert int(d["n_levels"][0]) == 16 and ngp.ngp_hip_net_n_params_host(d.ctypes.data) == 10240 + 2 * int(d["n_grid_entries"][0])
+    assert ngp.ngp_hip_nerf_backward_scratch_bytes(1 << 18) > 480 * (1 << 18) * 2
+    bad = np.zeros(1, H.NET_DESC)
+    assert ngp.ngp_hip_net_make_desc_host(8, 19, 16, H.f32(1.5), bad.ctypes.data) != 0  # only L = 16 is built
+    assert b"n_levels" in ngp.ngp_hip_last_error()

@@ -1,0 +1,164 @@
+"""GPU parity: loss / compositing / compaction kernel (loss.hip) vs the CPU oracle, through the C ABI.
+
+Counts are integers but depend on `T < 1e-4` where T is a product of (1 - alpha), alpha = 1 - exp(-sigma dt): the oracle uses
+libm expf, the kernel v_exp_f32.  Rays whose transmittance passes within 2e-3 (relative) of the threshold are excluded from the
+exact count comparison (reported, must be rare); everything else must match exactly.  Float outputs: rtol 2e-3 (fp16 stores).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from capi import check
+from test_sampling_gpu import _cameras
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(oracle, cuda, n_rays=4096, seed=0, sigma_gain=3.0):
+    imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda)
+    grid = H.blob_density_grid(1)
+    bf, mean = H.oracle_bitfield(oracle, grid, 1)
+    aabb = H.unit_aabb()
+    st, inc = H.pcg32_state(1337)
+    max_samples = n_rays * 64
+    r = dict(rc=np.zeros(1, np.uint32), nc=np.zeros(1, np.uint32), idx=np.zeros(n_rays, np.uint32), rays=np.zeros(n_rays, H.RAY),
+             ns=np.zeros(n_rays * 2, np.uint32), co=np.zeros(max_samples, H.COORD))
+    dres = np.array([32, 32], np.int32)
+    oracle.orc_generate_training_samples(n_rays, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data,
+                                         r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, len(xf), md_host.ctypes.data, xf.ctypes.data,
+                                         bf.ctypes.data, 0, None, 0, 0, H.f32(0.0), None, dres.ctypes.data, 0, n_rays)
+    n_samples = int(r["nc"][0])
+    rs = np.random.RandomState(seed)
+    mlp = np.zeros((n_samples, 4), np.float16)
+    mlp[:, :3] = rs.randn(n_samples, 3).astype(np.float16)
+    mlp[:, 3] = (rs.randn(n_samples) * sigma_gain + 2.0).astype(np.float16)
+    return dict(r=r, mlp=mlp, md_host=md_host, md_dev=md_dev, xf=xf, aabb=aabb, st=st, inc=inc, n_rays=n_rays, n_alive=int(r["rc"][0]), n_samples=n_samples,
+                mean=mean, keep=(imgs, d_imgs))
+
+
+def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=0, rgb_act=2):
+    n_rays, n_alive, ns = I["n_rays"], I["n_alive"], I["n_samples"]
+    bg = np.array([0.2, 0.4, 0.7], np.float32)
+    em_res = np.array([16, 12], np.int32)
+    n_img = len(I["xf"])
+    exposure = np.zeros((n_img, 3), np.float32)
+    # ---- oracle
+    o = dict(cnt=np.zeros(1, np.uint32), ns=I["r"]["ns"].copy(), co=np.zeros(B, H.COORD), dl=np.zeros((B, 4), np.float16), loss=np.zeros(n_rays, np.float32),
+             em=np.zeros(n_img * 16 * 12, np.float32))
+    oracle.orc_compute_loss(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
+                            I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
+                            I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
+                            o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2))
+    # ---- device
+    d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
+             em=H.dev_zeros(n_img * 16 * 12 * 4, cuda))
+    d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
+    d_md, d_mlp, d_idx, d_rays, d_co = (H.to_dev(a, cuda) for a in (I["md_dev"], I["mlp"], I["r"]["idx"], I["r"]["rays"], I["r"]["co"]))
+    d_mean, d_exp = H.to_dev(np.array([I["mean"]], np.float32), cuda), H.to_dev(exposure, cuda)
+    check(ngp.ngp_hip_compute_loss(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
+                                   n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
+                                   d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
+                                   d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2)))
+    g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
+             loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32))
+    return o, g
+
+
+def _borderline_rays(I):
+    """rays whose running transmittance comes within 2e-3 (relative) of EPSILON = 1e-4 at any step (float64 replay)."""
+    ns, mlp, co = I["r"]["ns"], I["mlp"], I["r"]["co"]
+    min_step = np.float64(1.73205080757 / 1024)
+    out = set()
+    for i in range(I["n_alive"]):
+        n, b = int(ns[2 * i]), int(ns[2 * i + 1])
+        dt = co["dt"][b:b + n].astype(np.float64) * (min_step * 128 - min_step) + min_step
+        sigma = np.exp(mlp[b:b + n, 3].astype(np.float64))
+        T = np.cumprod(np.exp(-sigma * dt))
+        if np.any(np.abs(T - 1e-4) < 2e-7):
+            out.add(i)
+    return out
+
+
+@pytest.mark.parametrize("loss_type", [4, 0, 6, 1, 2, 3, 5])  # Huber (configs/nerf/base.json:2-4) first, then the rest of ELossType
+def test_loss_and_compaction_match_oracle(ngp, oracle, cuda, loss_type):
+    I = _inputs(oracle, cuda)
+    B = I["n_samples"] + 128  # no truncation
+    o, g = _run(ngp, oracle, cuda, I, loss_type, B)
+    border = _borderline_rays(I)
+    assert len(border) < 0.01 * I["n_alive"]
+    mism = [i for i in range(I["n_alive"]) if int(o["ns"][2 * i]) != int(g["ns"][2 * i]) and i not in border]
+    assert not mism, mism[:10]
+    if not border:
+        assert int(o["cnt"][0]) == int(g["cnt"][0])
+    # compacted slots tile [0, total)
+    gb = sorted((int(g["ns"][2 * i + 1]), int(g["ns"][2 * i])) for i in range(I["n_alive"]) if int(g["ns"][2 * i]) > 0)
+    pos = 0
+    for b, c in gb:
+        assert b == pos
+        pos += c
+    assert pos == int(g["cnt"][0]) and pos < I["n_samples"]  # compaction actually removed samples
+    worst = 0.0
+    for i in range(I["n_alive"]):
+        if i in border:
+            continue
+        n, bo, bg_ = int(o["ns"][2 * i]), int(o["ns"][2 * i + 1]), int(g["ns"][2 * i + 1])
+        if n == 0:
+            continue
+        assert o["co"][bo:bo + n].tobytes() == g["co"][bg_:bg_ + n].tobytes()
+        a, b = g["dl"][bg_:bg_ + n].astype(np.float32), o["dl"][bo:bo + n].astype(np.float32)
+        np.testing.assert_allclose(a, b, rtol=4e-3, atol=2e-6)
+        worst = max(worst, float(np.abs(a - b).max()))
+    keep = np.array([i for i in range(I["n_alive"]) if i not in border])
+    np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(g["em"], o["em"], rtol=2e-3, atol=1e-6 * max(1.0, float(o["em"].max())))
+    assert np.abs(o["dl"].astype(np.float32)).max() > 1e-4
+
+
+@pytest.mark.parametrize("color_space,linear,random_bg,rgb_act", [(1, 0, 0, 2), (0, 1, 1, 3), (1, 1, 0, 0)])
+def test_loss_colour_space_variants(ngp, oracle, cuda, color_space, linear, random_bg, rgb_act):
+    I = _inputs(oracle, cuda, n_rays=1024, seed=2)
+    B = I["n_samples"] + 128
+    o, g = _run(ngp, oracle, cuda, I, 0, B, random_bg=random_bg, color_space=color_space, linear=linear, rgb_act=rgb_act)
+    border = _borderline_rays(I)
+    keep = np.array([i for i in range(I["n_alive"]) if i not in border])
+    np.testing.assert_array_equal(g["ns"][2 * keep], o["ns"][2 * keep])
+    np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=2e-4, atol=1e-9)
+
+
+def test_compaction_truncates_at_batch_size(ngp, oracle, cuda):
+    """testbed_nerf.cu:1434-1440: a ray straddling B is truncated, rays past B contribute nothing; the counter still counts all."""
+    I = _inputs(oracle, cuda)
+    B = 4096
+    o, g = _run(ngp, oracle, cuda, I, 4, B)
+    total = int(g["cnt"][0])
+    assert total > B
+    kept = 0
+    for i in range(I["n_alive"]):
+        n, b = int(g["ns"][2 * i]), int(g["ns"][2 * i + 1])
+        assert b + n <= B or n == 0
+        kept += n
+    assert kept == B
+
+
+def test_fill_rollover(ngp, oracle, cuda):
+    rs = np.random.RandomState(0)
+    B = 1024
+    for n_in in (0, 1, 300, 1023, 1024, 5000):
+        a = rs.randn(B, 4).astype(np.float16)
+        c = rs.rand(B, 7).astype(np.float32)
+        d_a, d_c, d_n = H.to_dev(a, cuda), H.to_dev(c, cuda), H.to_dev(np.array([n_in], np.uint32), cuda)
+        check(ngp.ngp_hip_fill_rollover_and_rescale_f16(None, B, 4, d_n.data_ptr(), d_a.data_ptr()))
+        check(ngp.ngp_hip_fill_rollover_f32(None, B, 7, d_n.data_ptr(), d_c.data_ptr()))
+        oracle.orc_fill_rollover_and_rescale_f16(B, 4, n_in, a.ctypes.data)
+        oracle.orc_fill_rollover_f32(B, 7, n_in, c.ctypes.data)
+        np.testing.assert_array_equal(H.to_host(d_a, np.float16).reshape(B, 4), a)
+        np.testing.assert_array_equal(H.to_host(d_c, np.float32).reshape(B, 7), c)
+
+
+def test_reduce_sum(ngp, cuda):
+    rs = np.random.RandomState(0)
+    for n in (1, 255, 4096, 262144):
+        x = rs.rand(n).astype(np.float32)
+        d_o = H.dev_zeros(4, cuda)
+        check(ngp.ngp_hip_reduce_sum_f32(None, H.to_dev(x, cuda).data_ptr(), n, d_o.data_ptr()))
+        assert abs(float(H.to_host(d_o, np.float32)[0]) - float(x.astype(np.float64).sum())) <= 1e-5 * n

@@ -1,0 +1,187 @@
+"""GPU parity: fused hash-grid + MFMA MLP kernels (network.hip) vs the CPU oracle, through the C ABI.
+
+Tolerances (fp16 storage, fp32 accumulate; the MFMA sums K in a different order than the oracle's scalar loop):
+  * encoded features / activations: 2 fp16 ulp of the value's magnitude (rtol 2e-3, atol 2e-3 on O(1) values)
+  * network outputs: rtol 1e-2 / atol 1e-2 (5 layers of fp16 rounding)
+  * gradients: fp16 atomic accumulation order is not deterministic -> rtol 3e-2, atol scaled to the gradient norm
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from capi import check
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ngp, cuda, log2=15, seed=0, n=4096, grid_amp=1.0):
+    desc = H.make_desc(ngp, log2_hashmap_size=log2)
+    params = H.random_params(desc, seed=seed, grid_amp=grid_amp)
+    coords = H.random_coords(n, seed=seed + 1)
+    return desc, params, coords, H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(coords, cuda)
+
+
+def test_mfma_operand_layout_asymmetric(ngp, oracle, cuda):
+    """Transpose-detecting check: identity-like W1 rows with an asymmetric grid; any row/col swap in the MFMA operand maps fails."""
+    desc = H.make_desc(ngp, log2_hashmap_size=12)
+    P = np.zeros(H.n_params(desc), dtype=np.float16)
+    W1 = np.zeros((64, 32), dtype=np.float16)
+    for o in range(64):
+        W1[o, (o * 7 + 3) % 32] = 1.0 + o / 64.0  # asymmetric permutation-like matrix
+    W2 = np.zeros((16, 64), dtype=np.float16)
+    W2[0, 5] = 1.0; W2[0, 41] = 0.5; W2[3, 17] = 2.0
+    P[0:2048] = W1.reshape(-1)
+    P[2048:3072] = W2.reshape(-1)
+    rs = np.random.RandomState(5)
+    P[10240:] = rs.uniform(0.1, 1.0, size=P.size - 10240).astype(np.float16)  # positive -> ReLU keeps everything
+    coords = H.random_coords(256, seed=9)
+    d_desc, d_P, d_c = H.to_dev(desc, cuda), H.to_dev(P, cuda), H.to_dev(coords, cuda)
+    out = H.dev_zeros(256 * 2, cuda)
+    check(ngp.ngp_hip_nerf_density(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, 256, out.data_ptr()))
+    got = H.to_host(out, np.float16).astype(np.float32)
+    ref = np.zeros(256, dtype=np.uint16)
+    oracle.orc_nerf_density(desc.ctypes.data, P.ctypes.data, coords.ctypes.data, 7, 256, ref.ctypes.data)
+    ref = ref.view(np.float16).astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("log2,n", [(15, 4096), (19, 2048), (12, 1000)])
+def test_inference_matches_oracle(ngp, oracle, cuda, log2, n):
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=log2, n=n)
+    out = H.dev_zeros(n * 4 * 2, cuda)
+    check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4))
+    got = H.to_host(out, np.float16).reshape(n, 4).astype(np.float32)
+    ref = np.zeros((n, 4), dtype=np.uint16)
+    oracle.orc_nerf_inference(desc.ctypes.data, params.ctypes.data, coords.ctypes.data, 7, n, ref.ctypes.data, 4)
+    ref = ref.view(np.float16).astype(np.float32)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-2)
+    assert np.abs(ref).max() > 0.05  # the comparison is not vacuous
+
+
+def test_inference_ragged_and_empty(ngp, oracle, cuda):
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=33)
+    for n in (0, 1, 31, 33):
+        out = H.dev_zeros(max(n, 1) * 16 * 2, cuda)
+        check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 16))
+        if n == 0:
+            continue
+        got = H.to_host(out, np.float16).reshape(n, 16)[:, :4].astype(np.float32)
+        ref = np.zeros((n, 4), dtype=np.uint16)
+        oracle.orc_nerf_inference(desc.ctypes.data, params.ctypes.data, coords.ctypes.data, 7, n, ref.ctypes.data, 4)
+        np.testing.assert_allclose(got, ref.view(np.float16).astype(np.float32), rtol=1e-2, atol=1e-2)
+
+
+def test_density_matches_oracle(ngp, oracle, cuda):
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=16, n=3000)
+    pos = np.ascontiguousarray(coords["pos"])
+    d_pos = H.to_dev(pos, cuda)
+    out = H.dev_zeros(3000 * 2, cuda)
+    check(ngp.ngp_hip_nerf_density(None, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), 3, 3000, out.data_ptr()))
+    got = H.to_host(out, np.float16).astype(np.float32)
+    ref = np.zeros(3000, dtype=np.uint16)
+    oracle.orc_nerf_density(desc.ctypes.data, params.ctypes.data, pos.ctypes.data, 3, 3000, ref.ctypes.data)
+    np.testing.assert_allclose(got, ref.view(np.float16).astype(np.float32), rtol=5e-3, atol=5e-3)
+
+
+def test_forward_saves_encoding(ngp, oracle, cuda):
+    n = 2048
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=15, n=n)
+    out = H.dev_zeros(n * 4 * 2, cuda)
+    xs = H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    got = H.to_host(xs, np.float16).reshape(n, 32).astype(np.float32)
+    ref = np.zeros((n, 32), dtype=np.uint16)
+    for i in range(n):
+        oracle.orc_grid_encode_one(desc.ctypes.data, params[10240:].ctypes.data, coords["pos"][i].ctypes.data, ref[i].ctypes.data)
+    # the encoding has no MFMA in it: identical fp32 op order => bit-exact up to FMA contraction (1 fp16 ulp)
+    np.testing.assert_allclose(got, ref.view(np.float16).astype(np.float32), rtol=1.5e-3, atol=1e-4)
+
+
+def test_backward_matches_oracle(ngp, oracle, cuda):
+    n = 2048
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=n, grid_amp=0.5)
+    rs = np.random.RandomState(11)
+    dl = (rs.randn(n, 4) * 0.05).astype(np.float16)
+    d_dl = H.to_dev(dl, cuda)
+    out = H.dev_zeros(n * 4 * 2, cuda)
+    xs = H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    np_ = H.n_params(desc)
+    grads = H.to_dev(np.full(np_, 7.0, dtype=np.float16), cuda)  # poison: Overwrite mode must not accumulate into it
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch = H.dev_zeros(sb, cuda)
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                    grads.data_ptr(), scratch.data_ptr(), sb))
+    got = H.to_host(grads, np.float16).astype(np.float64)
+    ref = np.zeros(np_, dtype=np.float64)
+    oracle.orc_nerf_forward_backward(desc.ctypes.data, params.ctypes.data, coords.ctypes.data, 7, n, dl.ctypes.data, None, ref.ctypes.data, None)
+    assert np.isfinite(got).all()
+    # MLP weight gradients: fp32 accumulate on device
+    gm, rm = got[:10240], ref[:10240]
+    scale = np.abs(rm).max()
+    assert scale > 1e-3
+    np.testing.assert_allclose(gm, rm, rtol=3e-2, atol=3e-3 * scale)
+    # grid gradients: fp16 atomics; compare per level with a norm-relative tolerance + check zero pattern
+    gg, rg = got[10240:], ref[10240:]
+    assert np.count_nonzero(gg[rg == 0]) == 0
+    err = np.linalg.norm(gg - rg) / np.linalg.norm(rg)
+    assert err < 2e-2, err
+    np.testing.assert_allclose(gg, rg, rtol=5e-2, atol=5e-3 * np.abs(rg).max())
+
+
+def test_backward_linearity(ngp, cuda):
+    """size-independent property at the full batch size B = 2^18 and the real T = 2^19 table: grads(2*dL) ~= 2*grads(dL)."""
+    n = 1 << 18
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=19, n=n, grid_amp=0.5)
+    rs = np.random.RandomState(3)
+    dl = (rs.randn(n, 4) * 0.01).astype(np.float16)
+    res = []
+    out = H.dev_zeros(n * 4 * 2, cuda)
+    xs = H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch = H.dev_zeros(sb, cuda)
+    for k in (1.0, 2.0):
+        d_dl = H.to_dev((dl.astype(np.float32) * k).astype(np.float16), cuda)
+        grads = H.dev_zeros(H.n_params(desc) * 2, cuda)
+        check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                        grads.data_ptr(), scratch.data_ptr(), sb))
+        res.append(H.to_host(grads, np.float16).astype(np.float64))
+    assert np.isfinite(res[0]).all() and np.isfinite(res[1]).all()
+    num = np.linalg.norm(res[1] - 2.0 * res[0])
+    den = np.linalg.norm(2.0 * res[0])
+    assert den > 0 and num / den < 2e-2, (num, den)
+
+
+def test_init_params_bit_exact(ngp, oracle, cuda):
+    desc = H.make_desc(ngp, log2_hashmap_size=14)
+    np_ = H.n_params(desc)
+    master, p16, inf16 = H.dev_zeros(np_ * 4, cuda), H.dev_zeros(np_ * 2, cuda), H.dev_zeros(np_ * 2, cuda)
+    check(ngp.ngp_hip_nerf_init_params(None, desc.ctypes.data, 1337, master.data_ptr(), p16.data_ptr(), inf16.data_ptr()))
+    ref = np.zeros(np_, dtype=np.float32)
+    oracle.orc_nerf_init_params(desc.ctypes.data, 1337, ref.ctypes.data)
+    np.testing.assert_array_equal(H.to_host(master, np.float32), ref)
+    np.testing.assert_array_equal(H.to_host(p16, np.float16), ref.astype(np.float16))
+    np.testing.assert_array_equal(H.to_host(inf16, np.float16), ref.astype(np.float16))
+
+
+def test_optimizer_step_bit_exact(ngp, oracle, cuda):
+    rs = np.random.RandomState(4)
+    n, nm = 50000, 10240
+    grads = (rs.randn(n) * 0.3).astype(np.float16)
+    grads[rs.rand(n) < 0.3] = 0  # untouched hash slots are skipped
+    master = rs.randn(n).astype(np.float32) * 0.1
+    p16 = master.astype(np.float16)
+    m1 = (rs.randn(n) * 1e-3).astype(np.float32)
+    m2 = (rs.rand(n) * 1e-5).astype(np.float32)
+    ema = master.copy()
+    inf = p16.copy()
+    d = [H.to_dev(a, cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
+    step = 7
+    check(ngp.ngp_hip_optimizer_step(None, n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95),
+                                     d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), d[6].data_ptr()))
+    oracle.orc_adam_ema_step(n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95),
+                             grads.ctypes.data, master.ctypes.data, p16.ctypes.data, m1.ctypes.data, m2.ctypes.data, ema.ctypes.data, inf.ctypes.data)
+    for t, ref, dt in zip(d[1:], (master, p16, m1, m2, ema, inf), (np.float32, np.float16, np.float32, np.float32, np.float32, np.float16)):
+        np.testing.assert_array_equal(H.to_host(t, dt), ref)

@@ -1,0 +1,202 @@
+"""GPU parity: single-NeRF renderer kernels (render.hip) vs the CPU oracle, through the C ABI.
+
+Ray set-up and marching (init_rays, advance_pos, generate_next_inputs) are exact; compositing / shading / tonemapping go through
+exp/pow and are compared with rtol 2e-3 (v_exp_f32 / v_log_f32 based device functions vs libm).
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from capi import check
+
+pytestmark = pytest.mark.gpu
+W, Hh = 80, 48
+
+
+def _camera():
+    cam = H.look_at_xform([1.6, 1.3, 1.1])
+    focal = np.array([70.0, 70.0], np.float32)
+    res = np.array([W, Hh], np.int32)
+    sc = np.array([0.5, 0.5], np.float32)
+    return cam, focal, res, sc
+
+
+def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0):
+    cam, focal, res, sc = _camera()
+    aabb = H.unit_aabb(2 ** (n_cascades - 1))
+    grid = H.blob_density_grid(n_cascades)
+    bf, _ = H.oracle_bitfield(oracle, grid, n_cascades)
+    n = W * Hh
+    ident = np.eye(3, dtype=np.float32).reshape(-1)
+    zero4, zero3 = np.zeros(4, np.float32), np.zeros(3, np.float32)
+    pay = np.zeros(n, H.PAYLOAD)
+    depth = np.zeros(n, np.float32)
+    oracle.orc_init_rays(spp, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
+                         snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data)
+    d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
+    check(ngp.ngp_hip_init_rays(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
+                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr()))
+    g = H.to_host(d_pay, H.PAYLOAD).copy()
+    np.testing.assert_array_equal(g["alive"], pay["alive"])
+    np.testing.assert_array_equal(g["origin"], pay["origin"])
+    al = pay["alive"] == 1
+    assert al.any() and (~al).any() or al.all()
+    for f in ("dir", "t", "idx", "n_steps"):
+        np.testing.assert_array_equal(g[f][al], pay[f][al])
+    np.testing.assert_array_equal(H.to_host(d_depth, np.float32), depth)
+
+    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone))
+    d_bf = H.to_dev(bf, cuda)
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone)))
+    g = H.to_host(d_pay, H.PAYLOAD).copy()
+    np.testing.assert_array_equal(g["alive"], pay["alive"])
+    al = pay["alive"] == 1
+    np.testing.assert_array_equal(g["t"][al], pay["t"][al])
+    return dict(pay=pay, d_pay=d_pay, bf=bf, d_bf=d_bf, aabb=aabb, cam=cam, focal=focal, res=res, sc=sc, n=n)
+
+
+@pytest.mark.parametrize("spp,snap,n_cascades,cone", [(0, 1, 1, 0.0), (3, 0, 1, 0.0), (1, 0, 3, 1.0 / 256.0)])
+def test_init_rays_and_advance_bit_exact(ngp, oracle, cuda, spp, snap, n_cascades, cone):
+    S = _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades, cone)
+    assert (S["pay"]["alive"] == 1).sum() > 50
+
+
+def test_compact_next_inputs_composite(ngp, oracle, cuda):
+    S = _init_and_advance(ngp, oracle, cuda, 0, 1)
+    n = S["n"]
+    # ---- compaction: same SET of alive rays (order is unordered on the GPU as in the reference)
+    rgba0 = np.zeros((n, 4), np.float32)
+    dep0 = np.zeros(n, np.float32)
+    o_pay, o_rgba, o_dep = np.zeros(n, H.PAYLOAD), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    f_pay, f_rgba, f_dep = np.zeros(n, H.PAYLOAD), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    cnt, fcnt = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    oracle.orc_compact_rays(n, rgba0.ctypes.data, dep0.ctypes.data, S["pay"].ctypes.data, o_rgba.ctypes.data, o_dep.ctypes.data, o_pay.ctypes.data,
+                            f_rgba.ctypes.data, f_dep.ctypes.data, f_pay.ctypes.data, cnt.ctypes.data, fcnt.ctypes.data)
+    d = [H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda), H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda), H.dev_zeros(n * 40, cuda),
+         H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda), H.dev_zeros(n * 40, cuda), H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)]
+    check(ngp.ngp_hip_compact_rays(None, n, d[0].data_ptr(), d[1].data_ptr(), S["d_pay"].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                   d[5].data_ptr(), d[6].data_ptr(), d[7].data_ptr(), d[8].data_ptr(), d[9].data_ptr()))
+    n_alive = int(cnt[0])
+    assert int(H.to_host(d[8], np.uint32)[0]) == n_alive and int(H.to_host(d[9], np.uint32)[0]) == int(fcnt[0]) == 0
+    g_pay = H.to_host(d[4], H.PAYLOAD)[:n_alive]
+    assert sorted(g_pay["idx"].tolist()) == sorted(o_pay["idx"][:n_alive].tolist())
+
+    # ---- next inputs on the ORACLE-ordered compacted rays (upload them so both sides see one order)
+    n_steps = 4
+    d_pay2 = H.to_dev(o_pay[:n_alive], cuda)
+    o_in = np.zeros(n_alive * n_steps, H.COORD)
+    oracle.orc_generate_next_inputs(n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, o_pay.ctypes.data, o_in.ctypes.data, n_steps, S["bf"].ctypes.data, 0, H.f32(0.0))
+    d_in = H.dev_zeros(n_alive * n_steps * 28, cuda)
+    check(ngp.ngp_hip_generate_next_inputs(None, n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, d_pay2.data_ptr(), d_in.data_ptr(), n_steps, S["d_bf"].data_ptr(), 0, H.f32(0.0)))
+    g_pay2 = H.to_host(d_pay2, H.PAYLOAD)
+    np.testing.assert_array_equal(g_pay2["n_steps"], o_pay["n_steps"][:n_alive])
+    np.testing.assert_array_equal(g_pay2["t"], o_pay["t"][:n_alive])
+    g_in = H.to_host(d_in, H.COORD)
+    for j in range(n_steps):
+        m = o_pay["n_steps"][:n_alive] > j
+        assert g_in[j * n_alive:(j + 1) * n_alive][m].tobytes() == o_in[j * n_alive:(j + 1) * n_alive][m].tobytes()
+
+    # ---- composite with random network outputs
+    rs = np.random.RandomState(0)
+    out = np.zeros((n_alive * n_steps, 4), np.float16)
+    out[:, :3] = rs.randn(n_alive * n_steps, 3).astype(np.float16)
+    out[:, 3] = (rs.randn(n_alive * n_steps) * 2 + 4).astype(np.float16)
+    o_rgba2, o_dep2 = np.zeros((n_alive, 4), np.float32), np.zeros(n_alive, np.float32)
+    oracle.orc_composite(n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, o_rgba2.ctypes.data, o_dep2.ctypes.data, o_pay.ctypes.data, o_in.ctypes.data,
+                         out.ctypes.data, 4, n_steps, 2, 3, H.f32(0.01))
+    d_rgba2, d_dep2 = H.dev_zeros(n_alive * 16, cuda), H.dev_zeros(n_alive * 4, cuda)
+    check(ngp.ngp_hip_composite(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_rgba2.data_ptr(), d_dep2.data_ptr(), d_pay2.data_ptr(), d_in.data_ptr(),
+                                H.to_dev(out, cuda).data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
+    g_pay3 = H.to_host(d_pay2, H.PAYLOAD)
+    same = g_pay3["alive"] == o_pay["alive"][:n_alive]
+    assert same.mean() > 0.99  # termination is a float threshold; allow a hair of disagreement
+    np.testing.assert_allclose(H.to_host(d_rgba2, np.float32).reshape(n_alive, 4)[same], o_rgba2[same], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(H.to_host(d_dep2, np.float32)[same], o_dep2[same], rtol=2e-3, atol=1e-5)
+    assert (o_pay["alive"][:n_alive] == 0).any() and (o_pay["alive"][:n_alive] == 1).any()
+
+
+def test_shade_accumulate_tonemap(ngp, oracle, cuda):
+    rs = np.random.RandomState(1)
+    n_hit, res = 1500, np.array([64, 32], np.int32)
+    npx = 64 * 32
+    rgba = rs.rand(n_hit, 4).astype(np.float32)
+    depth = rs.rand(n_hit).astype(np.float32)
+    pay = np.zeros(n_hit, H.PAYLOAD)
+    pay["idx"] = rs.permutation(npx)[:n_hit]
+    for linear in (0, 1):
+        fb, db = rs.rand(npx, 4).astype(np.float32), rs.rand(npx).astype(np.float32)
+        d_fb, d_db = H.to_dev(fb, cuda), H.to_dev(db, cuda)
+        oracle.orc_shade(n_hit, rgba.ctypes.data, depth.ctypes.data, pay.ctypes.data, linear, fb.ctypes.data, db.ctypes.data)
+        check(ngp.ngp_hip_shade(None, n_hit, H.to_dev(rgba, cuda).data_ptr(), H.to_dev(depth, cuda).data_ptr(), H.to_dev(pay, cuda).data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr()))
+        np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-4, atol=1e-6)
+        np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
+    for cs in (0, 1):
+        acc = rs.rand(npx, 4).astype(np.float32)
+        d_acc = H.to_dev(acc, cuda)
+        for spp in (0.0, 3.0):
+            oracle.orc_accumulate(res.ctypes.data, fb.ctypes.data, acc.ctypes.data, H.f32(spp), cs)
+            check(ngp.ngp_hip_accumulate(None, res.ctypes.data, H.to_dev(fb, cuda).data_ptr(), d_acc.data_ptr(), H.f32(spp), cs))
+        np.testing.assert_allclose(H.to_host(d_acc, np.float32).reshape(npx, 4), acc, rtol=2e-4, atol=1e-6)
+        bg = np.array([0.1, 0.3, 0.6, 0.8], np.float32)
+        for curve in (0, 1, 2, 3):
+            for out_cs in (0, 1):
+                surf = np.zeros((npx, 4), np.float32)
+                oracle.orc_tonemap(res.ctypes.data, H.f32(0.5), bg.ctypes.data, acc.ctypes.data, cs, out_cs, curve, 1, surf.ctypes.data)
+                d_s = H.dev_zeros(npx * 16, cuda)
+                check(ngp.ngp_hip_tonemap(None, res.ctypes.data, H.f32(0.5), bg.ctypes.data, d_acc.data_ptr(), cs, out_cs, curve, 1, d_s.data_ptr()))
+                np.testing.assert_allclose(H.to_host(d_s, np.float32).reshape(npx, 4), surf, rtol=3e-4, atol=2e-6)
+
+
+def test_full_frame_matches_oracle(ngp, oracle, cuda):
+    """render_nerf (testbed_nerf.cu:2354-2500) driven from Python over the C ABI vs orc_render_nerf on a small frame."""
+    desc = H.make_desc(ngp, log2_hashmap_size=14)
+    params = H.random_params(desc, seed=3, grid_amp=2.0, mlp_gain=2.0)
+    cam, focal, res, sc = _camera()
+    aabb = H.unit_aabb()
+    grid = H.blob_density_grid(1)
+    bf, _ = H.oracle_bitfield(oracle, grid, 1)
+    n = W * Hh
+    ident = np.eye(3, dtype=np.float32).reshape(-1)
+    fb_ref, db_ref = np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    oracle.orc_render_nerf(desc.ctypes.data, params.ctypes.data, 0, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, sc.ctypes.data, 1, aabb.ctypes.data,
+                           ident.ctypes.data, aabb.ctypes.data, H.f32(0.0), bf.ctypes.data, H.f32(0.0), 2, 3, H.f32(0.01), 0, fb_ref.ctypes.data, db_ref.ctypes.data)
+
+    import torch
+    d_desc, d_P, d_bf = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(bf, cuda)
+    zero4, zero3 = np.zeros(4, np.float32), np.zeros(3, np.float32)
+    pay = [H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 40, cuda)]
+    rgba = [H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 16, cuda)]
+    dep = [H.dev_zeros(n * 4, cuda), H.dev_zeros(n * 4, cuda)]
+    hp, hr, hd = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda)
+    net_in, net_out = H.dev_zeros(n * 8 * 28, cuda), H.dev_zeros(n * 8 * 8, cuda)
+    fb, db = H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda)
+    cnt, hcnt = H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)
+    check(ngp.ngp_hip_init_rays(None, 0, pay[0].data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
+                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr()))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0)))
+    n_alive, i, dbi = n, 1, 0
+    while i < 10000:
+        cur, tmp = (dbi + 1) % 2, dbi % 2
+        dbi += 1
+        cnt.zero_()
+        check(ngp.ngp_hip_compact_rays(None, n_alive, rgba[tmp].data_ptr(), dep[tmp].data_ptr(), pay[tmp].data_ptr(), rgba[cur].data_ptr(), dep[cur].data_ptr(), pay[cur].data_ptr(),
+                                       hr.data_ptr(), hd.data_ptr(), hp.data_ptr(), cnt.data_ptr(), hcnt.data_ptr()))
+        n_alive = int(H.to_host(cnt, np.uint32)[0])
+        if n_alive == 0:
+            break
+        n_steps = min(max(n // n_alive, 1), 8)
+        check(ngp.ngp_hip_generate_next_inputs(None, n_alive, aabb.ctypes.data, aabb.ctypes.data, pay[cur].data_ptr(), net_in.data_ptr(), n_steps, d_bf.data_ptr(), 0, H.f32(0.0)))
+        check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), net_in.data_ptr(), 7, n_alive * n_steps, net_out.data_ptr(), 4))
+        check(ngp.ngp_hip_composite(None, n_alive, i, aabb.ctypes.data, cam.ctypes.data, rgba[cur].data_ptr(), dep[cur].data_ptr(), pay[cur].data_ptr(), net_in.data_ptr(),
+                                    net_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
+        i += n_steps
+    n_hit = int(H.to_host(hcnt, np.uint32)[0])
+    check(ngp.ngp_hip_shade(None, n_hit, hr.data_ptr(), hd.data_ptr(), hp.data_ptr(), 0, fb.data_ptr(), db.data_ptr()))
+    torch.cuda.synchronize()
+    got = H.to_host(fb, np.float32).reshape(n, 4)
+    assert (fb_ref[:, 3] > 0.5).sum() > 100  # there is an object in view
+    diff = np.abs(got - fb_ref)
+    # fp16 MLP + early-termination thresholds: demand a tight mean and a small tail
+    assert diff.mean() < 2e-3, diff.mean()
+    assert (diff.max(axis=1) > 0.05).mean() < 0.01
+    np.testing.assert_array_equal(got[:, 3] > 0, fb_ref[:, 3] > 0)

@@ -1,0 +1,190 @@
+"""GPU parity (bit-exact): occupancy-grid maintenance and training ray marching vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import helpers as H
+from capi import check
+
+pytestmark = pytest.mark.gpu
+G3 = 128 ** 3
+
+
+def _cameras(cuda, n_images=6, w=96, h=64, focal=110.0, lens_mode=0, lens_params=None, radius=1.3):
+    imgs = H.make_images(n_images, w, h)
+    d_imgs = H.to_dev(imgs, cuda)
+    ptrs = [d_imgs.data_ptr() + i * w * h * 4 for i in range(n_images)]
+    md_dev = H.make_metadata(ptrs, w, h, focal, lens_mode, lens_params)
+    md_host = H.make_metadata([imgs[i].ctypes.data for i in range(n_images)], w, h, focal, lens_mode, lens_params)
+    xf = H.hemisphere_cameras(n_images, radius=radius)
+    return imgs, d_imgs, md_host, md_dev, xf
+
+
+def test_rng_and_morton_device_host_agree(ngp, oracle, cuda):
+    """pcg32 advance/next_float and morton decode run inside the grid sampler; compare its outputs for a trivial all-pass grid."""
+    grid = np.ones(G3, dtype=np.float32)
+    n = 10000
+    st, inc = H.pcg32_state(99)
+    aabb = H.unit_aabb()
+    ref_pos, ref_idx = np.zeros((n, 3), np.float32), np.zeros(n, np.uint32)
+    oracle.orc_generate_grid_samples_nonuniform(n, st, inc, 3, aabb.ctypes.data, grid.ctypes.data, ref_pos.ctypes.data, ref_idx.ctypes.data, 1, H.f32(-0.01))
+    d_grid, d_pos, d_idx = H.to_dev(grid, cuda), H.dev_zeros(n * 12, cuda), H.dev_zeros(n * 4, cuda)
+    check(ngp.ngp_hip_generate_grid_samples_nonuniform(None, n, st, inc, 3, aabb.ctypes.data, d_grid.data_ptr(), d_pos.data_ptr(), d_idx.data_ptr(), 1, H.f32(-0.01)))
+    np.testing.assert_array_equal(H.to_host(d_idx, np.uint32), ref_idx)
+    np.testing.assert_array_equal(H.to_host(d_pos, np.float32).reshape(n, 3), ref_pos)
+
+
+@pytest.mark.parametrize("n_cascades", [1, 3])
+def test_density_grid_pipeline_bit_exact(ngp, oracle, cuda, n_cascades):
+    """mark_untrained -> sample -> splat -> ema -> mean -> bitfield + 7 pools (update_density_grid_nerf, testbed_nerf.cu:2761-2859)."""
+    imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, radius=1.3 * n_cascades)
+    n_el = G3 * n_cascades
+    grid0 = H.blob_density_grid(n_cascades)
+    aabb = H.unit_aabb(2 ** (n_cascades - 1))
+
+    # --- mark untrained
+    ref = grid0.copy()
+    oracle.orc_mark_untrained_density_grid(n_el, ref.ctypes.data, len(xf), md_host.ctypes.data, xf.ctypes.data, 0)
+    d_grid, d_md, d_xf = H.to_dev(grid0, cuda), H.to_dev(md_dev, cuda), H.to_dev(xf, cuda)
+    check(ngp.ngp_hip_mark_untrained_density_grid(None, n_el, d_grid.data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), 0))
+    np.testing.assert_array_equal(H.to_host(d_grid, np.float32), ref)
+    assert (ref < 0).any() and (ref >= 0).any()
+
+    # --- nonuniform samples at both thresholds (2805-2829)
+    n_s = G3 // 4 * n_cascades
+    st, inc = H.pcg32_state(1337)
+    for thresh in (-0.01, 0.01):
+        ref_pos, ref_idx = np.zeros((n_s, 3), np.float32), np.zeros(n_s, np.uint32)
+        oracle.orc_generate_grid_samples_nonuniform(n_s, st, inc, 5, aabb.ctypes.data, ref.ctypes.data, ref_pos.ctypes.data, ref_idx.ctypes.data, n_cascades, H.f32(thresh))
+        d_pos, d_idx = H.dev_zeros(n_s * 12, cuda), H.dev_zeros(n_s * 4, cuda)
+        check(ngp.ngp_hip_generate_grid_samples_nonuniform(None, n_s, st, inc, 5, aabb.ctypes.data, d_grid.data_ptr(), d_pos.data_ptr(), d_idx.data_ptr(), n_cascades, H.f32(thresh)))
+        np.testing.assert_array_equal(H.to_host(d_idx, np.uint32), ref_idx)
+        np.testing.assert_array_equal(H.to_host(d_pos, np.float32).reshape(n_s, 3), ref_pos)
+
+    # --- splat (atomicMax) with collisions + ema.  Keep logits small so expf == __expf is not the issue: use ReLU activation (exact).
+    rs = np.random.RandomState(0)
+    mlp = (rs.rand(n_s) * 4.0).astype(np.float16)
+    tmp_ref = np.zeros(n_el, np.float32)
+    oracle.orc_splat_grid_samples_max(n_s, ref_idx.ctypes.data, mlp.ctypes.data, tmp_ref.ctypes.data, 1)
+    d_tmp, d_mlp = H.dev_zeros(n_el * 4, cuda), H.to_dev(mlp, cuda)
+    check(ngp.ngp_hip_splat_grid_samples_max(None, n_s, d_idx.data_ptr(), d_mlp.data_ptr(), d_tmp.data_ptr(), 1))
+    np.testing.assert_array_equal(H.to_host(d_tmp, np.float32), tmp_ref)
+    oracle.orc_ema_grid_samples(n_el, H.f32(0.95), ref.ctypes.data, tmp_ref.ctypes.data)
+    check(ngp.ngp_hip_ema_grid_samples(None, n_el, H.f32(0.95), d_grid.data_ptr(), d_tmp.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_grid, np.float32), ref)
+
+    # --- mean (tolerance: reduction order) then bitfield + pooling (bit-exact given the same mean)
+    d_mean = H.dev_zeros(4, cuda)
+    check(ngp.ngp_hip_density_grid_mean(None, d_grid.data_ptr(), G3, d_mean.data_ptr()))
+    mean_ref = oracle.orc_density_grid_mean(ref.ctypes.data, G3)
+    mean_dev = float(H.to_host(d_mean, np.float32)[0])
+    assert abs(mean_dev - mean_ref) <= 1e-5 * abs(mean_ref)
+    bf_ref = np.zeros(G3, np.uint8)
+    oracle.orc_update_bitfield(ref.ctypes.data, n_cascades, H.f32(mean_dev), bf_ref.ctypes.data)
+    d_bf = H.to_dev(np.full(G3, 0xAA, np.uint8), cuda)  # poison
+    check(ngp.ngp_hip_grid_to_bitfield_and_pool(None, d_grid.data_ptr(), n_cascades, d_mean.data_ptr(), d_bf.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_bf, np.uint8), bf_ref)
+    assert 0 < np.unpackbits(bf_ref[: G3 // 8]).mean() < 0.9
+
+
+def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):
+    rs = np.random.RandomState(1)
+    n = 50000
+    idx = rs.randint(0, G3, size=n).astype(np.uint32)
+    mlp = (rs.randn(n) * 3.0).astype(np.float16)
+    ref = np.zeros(G3, np.float32)
+    oracle.orc_splat_grid_samples_max(n, idx.ctypes.data, mlp.ctypes.data, ref.ctypes.data, 3)
+    d_out = H.dev_zeros(G3 * 4, cuda)
+    check(ngp.ngp_hip_splat_grid_samples_max(None, n, H.to_dev(idx, cuda).data_ptr(), H.to_dev(mlp, cuda).data_ptr(), d_out.data_ptr(), 3))
+    np.testing.assert_allclose(H.to_host(d_out, np.float32), ref, rtol=1e-5)  # __expf vs expf
+
+
+def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_mode=0, lens_params=None, snap=0, max_samples=None,
+                       ray_offset=0, n_rays_global=0, distortion=False):
+    imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, lens_mode=lens_mode, lens_params=lens_params, radius=1.3 * 2 ** (n_cascades - 1))
+    grid = H.blob_density_grid(n_cascades)
+    bf, _ = H.oracle_bitfield(oracle, grid, n_cascades)
+    aabb = H.unit_aabb(2 ** (n_cascades - 1))
+    st, inc = H.pcg32_state(1337)
+    max_samples = max_samples or n_rays * 64
+    dist = np.zeros((32, 32, 2), np.float32) if distortion else None
+    dres = np.array([32, 32], np.int32)
+    nrg = n_rays_global or n_rays
+
+    r = dict(rc=np.zeros(1, np.uint32), nc=np.zeros(1, np.uint32), idx=np.zeros(n_rays, np.uint32), rays=np.zeros(n_rays, H.RAY),
+             ns=np.zeros(n_rays * 2, np.uint32), co=np.zeros(max_samples, H.COORD))
+    oracle.orc_generate_training_samples(n_rays, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data,
+                                         r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, len(xf), md_host.ctypes.data, xf.ctypes.data,
+                                         bf.ctypes.data, 0, None, snap, 0, H.f32(cone_angle), H.ptr(dist) if distortion else None, dres.ctypes.data, ray_offset, nrg)
+    d = dict(rc=H.dev_zeros(4, cuda), nc=H.dev_zeros(4, cuda), idx=H.dev_zeros(n_rays * 4, cuda), rays=H.dev_zeros(n_rays * 24, cuda),
+             ns=H.dev_zeros(n_rays * 8, cuda), co=H.dev_zeros(max_samples * 28, cuda))
+    d_md, d_xf, d_bf = H.to_dev(md_dev, cuda), H.to_dev(xf, cuda), H.to_dev(bf, cuda)
+    d_dist = H.to_dev(dist, cuda) if distortion else None
+    check(ngp.ngp_hip_generate_training_samples(None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
+                                                d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
+                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg))
+    g = dict(rc=H.to_host(d["rc"], np.uint32), nc=H.to_host(d["nc"], np.uint32), idx=H.to_host(d["idx"], np.uint32), rays=H.to_host(d["rays"], H.RAY),
+             ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD))
+    return r, g
+
+
+def _compare_per_ray(r, g, exact_rays=True):
+    n_ref, n_got = int(r["rc"][0]), int(g["rc"][0])
+    assert n_got == n_ref and int(g["nc"][0]) == int(r["nc"][0])  # bit-exact ray and sample counts
+    assert n_ref > 0 and int(r["nc"][0]) > n_ref
+    ref_slot = {int(r["idx"][k]): k for k in range(n_ref)}
+    got_slot = {int(g["idx"][k]): k for k in range(n_got)}
+    assert ref_slot.keys() == got_slot.keys()
+    # slots are a permutation: bases must tile [0, total) without overlap
+    gb = sorted((int(g["ns"][2 * k + 1]), int(g["ns"][2 * k])) for k in range(n_got))
+    pos = 0
+    for b, c in gb:
+        assert b == pos
+        pos += c
+    assert pos == int(g["nc"][0])
+    for ray, kr in ref_slot.items():
+        kg = got_slot[ray]
+        nr, br = int(r["ns"][2 * kr]), int(r["ns"][2 * kr + 1])
+        ng, bg = int(g["ns"][2 * kg]), int(g["ns"][2 * kg + 1])
+        assert nr == ng, ray
+        if exact_rays:
+            assert r["rays"][kr].tobytes() == g["rays"][kg].tobytes(), ray
+        assert r["co"][br:br + nr].tobytes() == g["co"][bg:bg + ng].tobytes(), ray
+
+
+def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda):
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True)
+    _compare_per_ray(r, g)
+
+
+def test_training_samples_bit_exact_cascaded_cone(ngp, oracle, cuda):
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=3, cone_angle=1.0 / 256.0, snap=1)
+    _compare_per_ray(r, g)
+
+
+def test_training_samples_opencv_lens(ngp, oracle, cuda):
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=2048, n_cascades=1, cone_angle=0.0, lens_mode=1, lens_params=[0.0578421, -0.0805099, -0.000980296, 0.00015575])
+    _compare_per_ray(r, g)
+
+
+def test_training_samples_sharded_equals_whole(ngp, oracle, cuda):
+    """data-parallel extension: two half-batches with ray offsets reproduce the per-ray results of the full batch."""
+    rf, gf = _run_train_samples(ngp, oracle, cuda, n_rays=2048, n_cascades=1, cone_angle=0.0)
+    whole = {int(gf["idx"][k]): (int(gf["ns"][2 * k]), gf["co"][int(gf["ns"][2 * k + 1]):int(gf["ns"][2 * k + 1]) + int(gf["ns"][2 * k])].tobytes()) for k in range(int(gf["rc"][0]))}
+    seen = {}
+    for off in (0, 1024):
+        r, g = _run_train_samples(ngp, oracle, cuda, n_rays=1024, n_cascades=1, cone_angle=0.0, ray_offset=off, n_rays_global=2048)
+        _compare_per_ray(r, g)
+        for k in range(int(g["rc"][0])):
+            n, b = int(g["ns"][2 * k]), int(g["ns"][2 * k + 1])
+            seen[int(g["idx"][k])] = (n, g["co"][b:b + n].tobytes())
+    assert seen == whole
+
+
+def test_training_samples_overflow_drops_rays(ngp, oracle, cuda):
+    """max_samples smaller than the demand: counts stay consistent (kept rays' runs fit, counter exceeds the budget)."""
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, max_samples=20000)
+    assert int(g["nc"][0]) == int(r["nc"][0]) > 20000  # the counter is bumped before the check (testbed_nerf.cu:1225-1228)
+    n = int(g["rc"][0])
+    assert 0 < n < 4096
+    for k in range(n):
+        assert int(g["ns"][2 * k]) + int(g["ns"][2 * k + 1]) <= 20000
