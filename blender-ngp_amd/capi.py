@@ -94,6 +94,13 @@ def load_ngp_hip():
     """libngp_hip.so with typed entry points; every call returns 0 or raises with ngp_hip_last_error()."""
     global _ngp
     if _ngp is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If torch is going to be used for device
+        # memory in this process it must be loaded FIRST so that libngp_hip.so (NEEDED libamdhip64.so.7) binds to the same
+        # runtime instance; two instances in one process do not both see the GPU (hipErrorNoDevice on the second).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _ngp = CLib(os.path.join(HERE, "lib", "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), "ngp_hip_")
     return _ngp
 

@@ -1,0 +1,178 @@
+// python_api.cpp — the `pyngp` module: same module / class / method / property names as the reference's binding
+// (src/python_api.cu:306-888) for the NeRF train + render path, so scripts/run.py-style drivers run unchanged.
+// Long calls release the GIL like the reference (python_api.cu:546, 566, 594).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "testbed.h"
+
+namespace py = pybind11;
+using namespace ngp;
+
+static Json json_from_py(const py::handle& o) {
+	if (o.is_none()) return Json();
+	if (py::isinstance<py::bool_>(o)) return Json(o.cast<bool>());
+	if (py::isinstance<py::int_>(o)) return Json((double)o.cast<long long>());
+	if (py::isinstance<py::float_>(o)) return Json(o.cast<double>());
+	if (py::isinstance<py::str>(o)) return Json(o.cast<std::string>());
+	if (py::isinstance<py::dict>(o)) {
+		Json j = Json::object();
+		for (auto kv : py::reinterpret_borrow<py::dict>(o)) j[kv.first.cast<std::string>()] = json_from_py(kv.second);
+		return j;
+	}
+	if (py::isinstance<py::list>(o) || py::isinstance<py::tuple>(o)) {
+		Json j = Json::array();
+		for (auto v : o) j.push_back(json_from_py(v));
+		return j;
+	}
+	throw std::runtime_error{"unsupported type in network config json"};
+}
+
+static Mat34 mat34_from_py(const py::array_t<float, py::array::c_style | py::array::forcecast>& a) {
+	auto b = a.request();
+	if (b.ndim != 2 || b.shape[0] < 3 || b.shape[1] != 4) throw std::runtime_error{"expected a 3x4 (or 4x4) matrix"};
+	const float* p = (const float*)b.ptr;
+	Mat34 m;
+	for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m.m[c * 3 + r] = p[r * 4 + c];
+	return m;
+}
+static py::array_t<float> mat34_to_py(const Mat34& m) {
+	py::array_t<float> a({3, 4});
+	auto r = a.mutable_unchecked<2>();
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) r(i, j) = m.m[j * 3 + i];
+	return a;
+}
+
+PYBIND11_MODULE(pyngp, m) {
+	m.doc() = "MI355X-native Instant-NGP NeRF engine behind the blender-ngp `pyngp` API";
+
+	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image).value("Volume", ETestbedMode::Volume).export_values();
+	py::enum_<ERenderMode>(m, "RenderMode").value("AO", ERenderMode::AO).value("Shade", ERenderMode::Shade).value("Normals", ERenderMode::Normals).value("Positions", ERenderMode::Positions)
+		.value("Depth", ERenderMode::Depth).value("Distortion", ERenderMode::Distortion).value("Cost", ERenderMode::Cost).value("Slice", ERenderMode::Slice).export_values();
+	py::enum_<ELossType>(m, "LossType").value("L2", ELossType::L2).value("L1", ELossType::L1).value("Mape", ELossType::Mape).value("Smape", ELossType::Smape)
+		.value("Huber", ELossType::Huber).value("LogL1", ELossType::LogL1).value("RelativeL2", ELossType::RelativeL2).export_values();
+	py::enum_<ENerfActivation>(m, "NerfActivation").value("None", ENerfActivation::None).value("ReLU", ENerfActivation::ReLU).value("Logistic", ENerfActivation::Logistic)
+		.value("Exponential", ENerfActivation::Exponential).export_values();
+	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).export_values();
+	py::enum_<ETonemapCurve>(m, "TonemapCurve").value("Identity", ETonemapCurve::Identity).value("ACES", ETonemapCurve::ACES).value("Hable", ETonemapCurve::Hable)
+		.value("Reinhard", ETonemapCurve::Reinhard).export_values();
+
+	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
+	m.def("device_memory_allocated", []() { return DeviceBuffer::total_allocated(); });
+
+	py::class_<Testbed> testbed(m, "Testbed");
+	testbed
+		.def(py::init<ETestbedMode>(), py::arg("mode") = ETestbedMode::Nerf)
+		.def("load_training_data", &Testbed::load_training_data, py::call_guard<py::gil_scoped_release>(), py::arg("path"))
+		.def("create_empty_nerf_dataset", &Testbed::create_empty_nerf_dataset, py::arg("n_images"), py::arg("aabb_scale") = 1, py::arg("is_hdr") = false)
+		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
+		.def("train", &Testbed::train, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"))
+		.def("reset", &Testbed::reset, py::arg("reset_density_grid") = true)
+		.def("reload_network_from_file", &Testbed::reload_network_from_file, py::arg("path") = "")
+		.def("reload_network_from_json", [](Testbed& t, const py::object& json, const std::string& base) { t.reload_network_from_json(json_from_py(json), base); },
+			py::arg("json"), py::arg("config_base_path") = "")
+		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
+		.def("load_snapshot", &Testbed::load_snapshot, py::arg("path"))
+		.def("n_params", &Testbed::n_params)
+		.def("n_encoding_params", &Testbed::n_encoding_params)
+		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float, float, float, float) {
+				std::vector<float> px;
+				{ py::gil_scoped_release rel; px = t.render_to_cpu(width, height, spp, linear); }
+				py::array_t<float> result({height, width, 4});
+				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				return result;
+			}, py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
+			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& cam) { t.set_nerf_camera_matrix(mat34_from_py(cam)); })
+		.def("reset_camera", &Testbed::reset_camera)
+		.def("reset_accumulation", [](Testbed& t) { t.m_windowless_render_surface.reset_accumulation(); })
+		// data-parallel extension
+		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
+		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c); } return py::make_tuple(c[0], c[1]); }, py::arg("batch_size"))
+		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
+			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
+		.def("training_prep_nerf", &Testbed::training_prep_nerf, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size") = 0)
+		.def("local_loss_sum", &Testbed::local_loss_sum)
+		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })
+		.def("params_ptr", [](Testbed& t) { return (uintptr_t)t.m_params.data(); })
+		.def("sync", &Testbed::sync)
+		.def_readwrite("shall_train", &Testbed::m_train)
+		.def_readwrite("exposure", &Testbed::m_exposure)
+		.def_readwrite("snap_to_pixel_centers", &Testbed::m_snap_to_pixel_centers)
+		.def_readwrite("fov_axis", &Testbed::m_fov_axis)
+		.def_property("fov", &Testbed::fov, &Testbed::set_fov)
+		.def_readwrite("color_space", &Testbed::m_color_space)
+		.def_readwrite("zoom", &Testbed::m_zoom)
+		.def_readwrite("scale", &Testbed::m_scale)
+		.def_readwrite("seed", &Testbed::m_seed)
+		.def_readwrite("training_batch_size", &Testbed::m_training_batch_size)
+		.def_readwrite("max_level_rand_training", &Testbed::m_max_level_rand_training)
+		.def_readwrite("render_near_distance", &Testbed::m_render_near_distance)
+		.def_property("tonemap_curve", [](Testbed& t) { return t.m_windowless_render_surface.tonemap_curve; }, [](Testbed& t, ETonemapCurve c) { t.m_windowless_render_surface.tonemap_curve = c; })
+		.def_property("background_color", [](Testbed& t) { return std::vector<float>(t.m_background_color, t.m_background_color + 4); },
+			[](Testbed& t, const std::vector<float>& c) { if (c.size() != 4) throw std::runtime_error{"background_color needs 4 components"}; for (int i = 0; i < 4; ++i) t.m_background_color[i] = c[i]; })
+		.def_property("screen_center", [](Testbed& t) { return std::vector<float>(t.m_screen_center, t.m_screen_center + 2); },
+			[](Testbed& t, const std::vector<float>& c) { t.m_screen_center[0] = c.at(0); t.m_screen_center[1] = c.at(1); })
+		.def_property("camera_matrix", [](Testbed& t) { return mat34_to_py(t.m_camera); },
+			[](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& cam) { t.m_camera = mat34_from_py(cam); })
+		.def_property_readonly("training_step", &Testbed::training_step)
+		.def_property_readonly("loss", &Testbed::loss)
+		.def_property_readonly("learning_rate", [](Testbed& t) { return t.m_learning_rate; })
+		.def_property_readonly("render_ms", [](Testbed& t) { return t.m_stats.render_ms; })
+		.def_property_readonly("training_ms", [](Testbed& t) { return t.m_stats.training_ms; })
+		.def_property_readonly("training_prep_ms", [](Testbed& t) { return t.m_stats.training_prep_ms; })
+		.def_property_readonly("render_samples_evaluated", [](Testbed& t) { return t.m_render_samples_evaluated; })
+		.def_property_readonly("aabb", [](Testbed& t) { return py::make_tuple(std::vector<float>(t.m_aabb.min, t.m_aabb.min + 3), std::vector<float>(t.m_aabb.max, t.m_aabb.max + 3)); })
+		.def_readonly("nerf", &Testbed::m_nerf);
+
+	py::class_<Nerf> nerf(testbed, "Nerf");
+	nerf
+		.def_readonly("training", &Nerf::training)
+		.def_readwrite("rgb_activation", &Nerf::rgb_activation)
+		.def_readwrite("density_activation", &Nerf::density_activation)
+		.def_readwrite("sharpen", &Nerf::sharpen)
+		.def_readwrite("render_with_lens_distortion", &Nerf::render_with_lens_distortion)
+		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance)
+		.def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
+		.def_readwrite("show_accel", &Nerf::show_accel)
+		.def_readonly("max_cascade", &Nerf::max_cascade)
+		.def("density_grid_bitfield", [](Nerf& n) {
+				py::array_t<uint8_t> a((py::ssize_t)n.density_grid_bitfield.bytes());
+				n.density_grid_bitfield.copy_to_host(a.mutable_data(), n.density_grid_bitfield.bytes());
+				return a;
+			});
+
+	py::class_<NerfTraining> training(nerf, "Training");
+	training
+		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color)
+		.def_readwrite("linear_colors", &NerfTraining::linear_colors)
+		.def_readwrite("loss", &NerfTraining::loss_type)
+		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
+		.def_readwrite("near_distance", &NerfTraining::near_distance)
+		.def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)
+		.def_readwrite("n_images_for_training", &NerfTraining::n_images_for_training)
+		.def_property_readonly("rays_per_batch", [](NerfTraining& t) { return t.counters_rgb.rays_per_batch; })
+		.def_property_readonly("measured_batch_size", [](NerfTraining& t) { return t.counters_rgb.measured_batch_size; })
+		.def_property_readonly("measured_batch_size_before_compaction", [](NerfTraining& t) { return t.counters_rgb.measured_batch_size_before_compaction; })
+		.def_property_readonly("dataset_scale", [](NerfTraining& t) { return t.dataset.scale; })
+		.def("set_dataset_transform", [](NerfTraining& t, float scale, const std::vector<float>& offset) {
+				t.dataset.scale = scale; t.dataset.offset.x = offset.at(0); t.dataset.offset.y = offset.at(1); t.dataset.offset.z = offset.at(2);
+			}, py::arg("scale"), py::arg("offset"), "the `scale` / `offset` keys of transforms.json (nerf_loader.cu:472-474, 499-504)")
+		.def("set_image", [](NerfTraining& t, int frame_idx, const py::array_t<float, py::array::c_style | py::array::forcecast>& img) {
+				auto b = img.request();
+				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error{"image should be (H,W,C) where C=4"};
+				t.set_image(frame_idx, (int)b.shape[1], (int)b.shape[0], (const float*)b.ptr);
+			}, py::arg("frame_idx"), py::arg("img"))
+		.def("set_image_rgba8", [](NerfTraining& t, int frame_idx, const py::array_t<uint8_t, py::array::c_style | py::array::forcecast>& img) {
+				auto b = img.request();
+				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error{"image should be (H,W,C) where C=4"};
+				t.set_image_rgba8(frame_idx, (int)b.shape[1], (int)b.shape[0], (const uint8_t*)b.ptr);
+			}, py::arg("frame_idx"), py::arg("img"))
+		.def("set_camera_extrinsics", [](NerfTraining& t, int frame_idx, const py::array_t<float, py::array::c_style | py::array::forcecast>& m, bool convert_to_ngp) {
+				t.set_camera_extrinsics(frame_idx, mat34_from_py(m), convert_to_ngp);
+			}, py::arg("frame_idx"), py::arg("camera_to_world"), py::arg("convert_to_ngp") = true)
+		.def("get_camera_extrinsics", [](NerfTraining& t, int frame_idx) { return mat34_to_py(t.get_camera_extrinsics(frame_idx)); }, py::arg("frame_idx"))
+		.def("set_camera_intrinsics", &NerfTraining::set_camera_intrinsics, py::arg("frame_idx"), py::arg("fx") = 0.f, py::arg("fy") = 0.f, py::arg("cx") = -0.5f, py::arg("cy") = -0.5f,
+			py::arg("k1") = 0.f, py::arg("k2") = 0.f, py::arg("p1") = 0.f, py::arg("p2") = 0.f);
+}

@@ -1,0 +1,693 @@
+// testbed.cpp — see testbed.h.  Host orchestration only: every device-side computation goes through include/ngp_hip.h.
+#include "testbed.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+
+namespace ngp {
+
+static constexpr uint32_t GRID_CELLS = NGP_NERF_GRID_N_CELLS;
+static constexpr float LOSS_SCALE = 128.0f;                    // testbed.h:272
+static constexpr float NERF_MIN_OPTICAL_THICKNESS = 0.01f;     // testbed_nerf.cu:68
+static constexpr uint32_t BATCH_SIZE_GRANULARITY = 128;        // tcnn::batch_size_granularity
+static constexpr uint32_t OUT_STRIDE = 4;                      // fp16 (r,g,b,sigma) per sample; the reference pads to 16
+static constexpr uint32_t MARCH_ITER = 10000;                  // testbed_nerf.cu:70
+
+static inline uint32_t next_multiple(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+static inline void hip_check(hipError_t e, const char* what) {
+	if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_CHECK_THROW(x) hip_check((x), #x)
+
+// ------------------------------------------------------------------------------------------------ DeviceBuffer
+static std::atomic<size_t> g_total_allocated{0};
+DeviceBuffer::~DeviceBuffer() { try { free(); } catch (...) {} }
+DeviceBuffer& DeviceBuffer::operator=(DeviceBuffer&& o) noexcept {
+	if (this != &o) { try { free(); } catch (...) {} m_ptr = o.m_ptr; m_bytes = o.m_bytes; o.m_ptr = nullptr; o.m_bytes = 0; }
+	return *this;
+}
+void DeviceBuffer::free() {
+	if (m_ptr) { (void)hipFree(m_ptr); g_total_allocated -= m_bytes; m_ptr = nullptr; m_bytes = 0; }
+}
+void DeviceBuffer::resize(size_t bytes) {
+	if (bytes == m_bytes) return;
+	free();
+	if (bytes) { HIP_CHECK_THROW(hipMalloc(&m_ptr, bytes)); m_bytes = bytes; g_total_allocated += bytes; }
+}
+void DeviceBuffer::enlarge(size_t bytes) { if (bytes > m_bytes) resize(bytes); }
+void DeviceBuffer::memset(int value, void* stream) { if (m_bytes) HIP_CHECK_THROW(hipMemsetAsync(m_ptr, value, m_bytes, (hipStream_t)stream)); }
+void DeviceBuffer::copy_from_host(const void* src, size_t bytes, size_t dst_offset) {
+	if (dst_offset + bytes > m_bytes) throw std::runtime_error("DeviceBuffer::copy_from_host out of range");
+	if (bytes) HIP_CHECK_THROW(hipMemcpy((char*)m_ptr + dst_offset, src, bytes, hipMemcpyHostToDevice));
+}
+void DeviceBuffer::copy_to_host(void* dst, size_t bytes, size_t src_offset) const {
+	if (src_offset + bytes > m_bytes) throw std::runtime_error("DeviceBuffer::copy_to_host out of range");
+	if (bytes) HIP_CHECK_THROW(hipMemcpy(dst, (const char*)m_ptr + src_offset, bytes, hipMemcpyDeviceToHost));
+}
+size_t DeviceBuffer::total_allocated() { return g_total_allocated; }
+
+// ------------------------------------------------------------------------------------------------ dataset
+Mat34 NerfDataset::nerf_matrix_to_ngp(const Mat34& in) const {
+	Mat34 r = in;
+	for (int k = 0; k < 3; ++k) { r.m[3 + k] *= -1.f; r.m[6 + k] *= -1.f; }
+	r.m[9] = r.m[9] * scale + offset.x; r.m[10] = r.m[10] * scale + offset.y; r.m[11] = r.m[11] * scale + offset.z;
+	if (from_mitsuba) {
+		for (int k = 0; k < 3; ++k) { r.m[k] *= -1.f; r.m[6 + k] *= -1.f; }
+	} else {
+		// cycle axes xyz <- yzx (rows)
+		for (int c = 0; c < 4; ++c) { float t = r.m[3 * c]; r.m[3 * c] = r.m[3 * c + 1]; r.m[3 * c + 1] = r.m[3 * c + 2]; r.m[3 * c + 2] = t; }
+	}
+	return r;
+}
+Mat34 NerfDataset::ngp_matrix_to_nerf(const Mat34& in) const {
+	Mat34 r = in;
+	if (from_mitsuba) {
+		for (int k = 0; k < 3; ++k) { r.m[k] *= -1.f; r.m[6 + k] *= -1.f; }
+	} else {
+		for (int c = 0; c < 4; ++c) { float t = r.m[3 * c + 2]; r.m[3 * c + 2] = r.m[3 * c + 1]; r.m[3 * c + 1] = r.m[3 * c]; r.m[3 * c] = t; }
+	}
+	for (int k = 0; k < 3; ++k) { r.m[3 + k] *= -1.f; r.m[6 + k] *= -1.f; }
+	r.m[9] = (r.m[9] - offset.x) / scale; r.m[10] = (r.m[10] - offset.y) / scale; r.m[11] = (r.m[11] - offset.z) / scale;
+	return r;
+}
+void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type) {
+	if (frame_idx < 0 || (size_t)frame_idx >= n_images) throw std::runtime_error{"NerfDataset::set_training_image: invalid frame index"};
+	const size_t px = (size_t)w * h;
+	const size_t stride = image_data_type == 1 ? 4 : (image_data_type == 2 ? 8 : 16);
+	pixelmemory[frame_idx].resize(px * stride);
+	pixelmemory[frame_idx].copy_from_host(pixels_host, px * stride);
+	NgpImageMeta& m = metadata[frame_idx];
+	m.pixels = pixelmemory[frame_idx].data();
+	m.image_data_type = image_data_type;
+	m.res[0] = w; m.res[1] = h;
+	update_metadata(frame_idx, frame_idx + 1);
+}
+void NerfDataset::update_metadata(int first, int last) {
+	if (last < 0 || last > (int)n_images) last = (int)n_images;
+	int n = last - first;
+	if (n <= 0) return;
+	metadata_gpu.enlarge(n_images * sizeof(NgpImageMeta));
+	metadata_gpu.copy_from_host(metadata.data() + first, (size_t)n * sizeof(NgpImageMeta), (size_t)first * sizeof(NgpImageMeta));
+}
+
+// ------------------------------------------------------------------------------------------------ training-side setters
+void NerfTraining::set_image(int frame_idx, int w, int h, const float* rgba_host) {
+	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) throw std::runtime_error{"Invalid frame index"};
+	dataset.set_training_image(frame_idx, w, h, rgba_host, 3);
+}
+void NerfTraining::set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host) {
+	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) throw std::runtime_error{"Invalid frame index"};
+	dataset.set_training_image(frame_idx, w, h, rgba_host, 1);
+}
+void NerfTraining::set_camera_extrinsics(int frame_idx, const Mat34& camera_to_world, bool convert_to_ngp) {
+	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) return;
+	Mat34 m = convert_to_ngp ? dataset.nerf_matrix_to_ngp(camera_to_world) : camera_to_world;
+	memcpy(dataset.xforms[frame_idx].start, m.m, sizeof(m.m));
+	memcpy(dataset.xforms[frame_idx].end, m.m, sizeof(m.m));
+	memset(dataset.metadata[frame_idx].rolling_shutter, 0, sizeof(float) * 4);
+	dataset.update_metadata(frame_idx, frame_idx + 1);
+	update_transforms(frame_idx, frame_idx + 1);
+}
+Mat34 NerfTraining::get_camera_extrinsics(int frame_idx) const {
+	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) return Mat34{};
+	Mat34 m; memcpy(m.m, transforms[frame_idx].start, sizeof(m.m));
+	return dataset.ngp_matrix_to_nerf(m);
+}
+void NerfTraining::set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2) {
+	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) return;
+	if (fx <= 0.f) fx = fy;
+	if (fy <= 0.f) fy = fx;
+	NgpImageMeta& m = dataset.metadata[frame_idx];
+	if (cx < 0.f) cx = -cx; else cx = cx / (float)m.res[0];
+	if (cy < 0.f) cy = -cy; else cy = cy / (float)m.res[1];
+	m.lens_mode = (k1 || k2 || p1 || p2) ? 1 : 0;
+	memset(m.lens_params, 0, sizeof(m.lens_params));
+	m.lens_params[0] = k1; m.lens_params[1] = k2; m.lens_params[2] = p1; m.lens_params[3] = p2;
+	m.principal_point[0] = cx; m.principal_point[1] = cy;
+	m.focal_length[0] = fx; m.focal_length[1] = fy;
+	dataset.update_metadata(frame_idx, frame_idx + 1);
+}
+void NerfTraining::update_transforms(int first, int last) {
+	if (last < 0 || last > (int)dataset.n_images) last = (int)dataset.n_images;
+	int n = last - first;
+	if (n <= 0) return;
+	if (transforms.size() < (size_t)last) transforms.resize(last);
+	for (int i = first; i < last; ++i) transforms[i] = dataset.xforms[i];
+	transforms_gpu.enlarge(dataset.n_images * sizeof(NgpXForm));
+	transforms_gpu.copy_from_host(transforms.data() + first, (size_t)n * sizeof(NgpXForm), (size_t)first * sizeof(NgpXForm));
+}
+
+void RenderBuffer::resize(int w, int h) {
+	if (w == res[0] && h == res[1]) return;
+	res[0] = w; res[1] = h;
+	const size_t n = (size_t)w * h;
+	frame_buffer.resize(n * 16); depth_buffer.resize(n * 4); accumulate_buffer.resize(n * 16); surface.resize(n * 16);
+	reset_accumulation();
+}
+
+// ------------------------------------------------------------------------------------------------ Testbed
+Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
+	if (mode != ETestbedMode::Nerf) {
+		throw std::runtime_error{"this build implements the NeRF hot path only (SURVEY.md §8): TestbedMode.Nerf"};
+	}
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+		throw std::runtime_error{"no MI355X / ROCm device visible: the product path has no CPU fallback"};
+	}
+	hipStream_t st;
+	HIP_CHECK_THROW(hipStreamCreate(&st));
+	m_stream = st;
+	m_nerf.training.owner = this;
+	m_rng = Pcg32(m_seed);
+	reset_camera();
+	m_network_config = Json::object();
+}
+
+Testbed::~Testbed() {
+	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
+}
+
+void Testbed::check(int rc, const char* what) {
+	if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + ngp_hip_last_error());
+}
+void Testbed::sync() { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
+
+void Testbed::reset_camera() {  // testbed.cu:283-299
+	m_fov_axis = 1;
+	set_fov(50.625f);
+	m_zoom = 1.f;
+	m_screen_center[0] = m_screen_center[1] = 0.5f;
+	m_scale = 1.5f;
+	const float c[12] = {1, 0, 0, 0, -1, 0, 0, 0, -1, 0.5f, 0.5f, 0.5f};
+	memcpy(m_camera.m, c, sizeof(c));
+	// m_camera.col(3) -= m_scale * view_dir(), view_dir = col(2)
+	for (int k = 0; k < 3; ++k) m_camera.m[9 + k] -= m_scale * m_camera.m[6 + k];
+}
+float Testbed::fov() const { return 2.f * 180.f / 3.14159265358979323846f * atanf(1.0f / (m_relative_focal_length[m_fov_axis] * 2.f)); }
+void Testbed::set_fov(float val) {
+	const float f = 0.5f * 1.0f / tanf(0.5f * val * 3.14159265358979323846f / 180.f);
+	m_relative_focal_length[0] = m_relative_focal_length[1] = f;
+}
+
+void Testbed::load_training_data(const std::string& path) {
+	(void)path;
+	throw std::runtime_error{"load_training_data: the transforms.json / image-decode loader is SURVEY.md §8f row f2 (next); "
+	                         "feed data with create_empty_nerf_dataset + nerf.training.set_image / set_camera_extrinsics"};
+}
+
+void Testbed::create_empty_nerf_dataset(size_t n_images, int aabb_scale, bool is_hdr) {  // testbed_nerf.cu:2635-2641, nerf_loader.cu:175-195
+	NerfDataset& d = m_nerf.training.dataset;
+	d = NerfDataset{};
+	d.n_images = n_images;
+	d.xforms.resize(n_images);
+	d.metadata.assign(n_images, NgpImageMeta{});
+	d.pixelmemory.clear(); d.pixelmemory.resize(n_images);
+	d.aabb_scale = aabb_scale;
+	d.is_hdr = is_hdr;
+	for (size_t i = 0; i < n_images; ++i) {
+		const float ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+		memcpy(d.xforms[i].start, ident, sizeof(ident));
+		memcpy(d.xforms[i].end, ident, sizeof(ident));
+		d.metadata[i].principal_point[0] = d.metadata[i].principal_point[1] = 0.5f;
+		d.metadata[i].focal_length[0] = d.metadata[i].focal_length[1] = 1000.f;
+	}
+	load_nerf_post();
+	m_nerf.training.n_images_for_training = 0;
+	m_training_data_available = true;
+}
+
+void Testbed::load_nerf_post() {
+	NerfTraining& tr = m_nerf.training;
+	m_nerf.rgb_activation = tr.dataset.is_hdr ? ENerfActivation::Exponential : ENerfActivation::Logistic;
+	tr.n_images_for_training = (int)tr.dataset.n_images;
+	tr.dataset.update_metadata();
+	std::vector<float> zeros(std::max<size_t>(tr.dataset.n_images, 1) * 3, 0.f);
+	tr.cam_exposure_gpu.resize(zeros.size() * 4);
+	tr.cam_exposure_gpu.copy_from_host(zeros.data(), zeros.size() * 4);
+	if (tr.dataset.has_rays) tr.near_distance = 0.0f;
+	tr.update_transforms();
+	if (!tr.dataset.metadata.empty()) {
+		m_nerf.render_lens_proxy = tr.dataset.metadata[0];
+		m_screen_center[0] = 1.f - tr.dataset.metadata[0].principal_point[0];
+		m_screen_center[1] = 1.f - tr.dataset.metadata[0].principal_point[1];
+	}
+	const int s = tr.dataset.aabb_scale;
+	if (s <= 0 || (s & (s - 1))) throw std::runtime_error{"NeRF dataset's `aabb_scale` must be a power of two, but is " + std::to_string(s) + "."};
+	const int max_aabb_scale = 1 << (NGP_NERF_CASCADES - 1);
+	if (s > max_aabb_scale) throw std::runtime_error{"NeRF dataset must have `aabb_scale <= " + std::to_string(max_aabb_scale) + "`, but is " + std::to_string(s) + "."};
+	const float half = 0.5f * (float)std::min(max_aabb_scale, s);
+	for (int k = 0; k < 3; ++k) { m_aabb.min[k] = 0.5f - half; m_aabb.max[k] = 0.5f + half; }
+	m_raw_aabb = m_aabb;
+	m_render_aabb = m_aabb;
+	const NgpAabb& ra = tr.dataset.render_aabb;
+	if (!(ra.max[0] < ra.min[0] || ra.max[1] < ra.min[1] || ra.max[2] < ra.min[2])) {
+		for (int k = 0; k < 3; ++k) { m_render_aabb.min[k] = std::max(ra.min[k], m_aabb.min[k]); m_render_aabb.max[k] = std::min(ra.max[k], m_aabb.max[k]); }
+	}
+	m_nerf.max_cascade = 0;
+	while ((1 << m_nerf.max_cascade) < s) ++m_nerf.max_cascade;
+	m_nerf.cone_angle_constant = s <= 1 ? 0.0f : (1.0f / 256.0f);
+}
+
+// ---- network config ---------------------------------------------------------------------------------------------
+Json Testbed::load_network_config(const std::string& path) {  // testbed.cu:120-145 (json only; msgpack snapshots = row f1)
+	Json result = Json::parse_file(path);
+	while (result.contains("parent")) {  // merge_parent_network_config (testbed.cu:77-88)
+		std::string parent = result["parent"].str();
+		std::string base = path.substr(0, path.find_last_of("/\\") + 1);
+		Json p = Json::parse_file(base + parent);
+		result.erase("parent");
+		p.merge_patch(result);
+		result = p;
+	}
+	return result;
+}
+void Testbed::reload_network_from_file(const std::string& path) {
+	if (!path.empty()) m_network_config_path = path;
+	m_network_config = load_network_config(m_network_config_path);
+	reset_network();
+}
+void Testbed::reload_network_from_json(const Json& json, const std::string& config_base_path) {
+	m_network_config_path = config_base_path;
+	m_network_config = json;
+	reset_network();
+}
+
+static ELossType string_to_loss_type(std::string s) {  // testbed.cu:2220-2240
+	std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+	if (s == "l2") return ELossType::L2;
+	if (s == "relativel2") return ELossType::RelativeL2;
+	if (s == "l1") return ELossType::L1;
+	if (s == "mape") return ELossType::Mape;
+	if (s == "smape") return ELossType::Smape;
+	if (s == "huber" || s == "smoothl1") return ELossType::Huber;
+	if (s == "logl1") return ELossType::LogL1;
+	throw std::runtime_error{"Unknown loss type."};
+}
+
+void Testbed::parse_optimizer_config(const Json& opt_in) {
+	// configs/nerf/base.json:5-22: Ema{decay} o ExponentialDecay{decay_start, decay_interval, decay_base} o Adam{...}; any subset of the wrappers
+	m_use_ema = false; m_has_decay = false;
+	m_ema_decay = 0.95f; m_decay_start = 0; m_decay_interval = 1; m_decay_end = 0; m_decay_base = 1.0f;
+	const Json* o = &opt_in;
+	while (true) {
+		std::string otype = o->value("otype", "Adam");
+		std::string lower = otype; std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+		if (lower == "ema") { m_use_ema = true; m_ema_decay = (float)o->value("decay", 0.99); }
+		else if (lower == "exponentialdecay") {
+			m_has_decay = true;
+			m_decay_start = (uint32_t)o->value("decay_start", 0); m_decay_interval = (uint32_t)o->value("decay_interval", 1);
+			m_decay_end = (uint32_t)o->value("decay_end", 0); m_decay_base = (float)o->value("decay_base", 1.0);
+		} else if (lower == "adam") {
+			m_base_learning_rate = (float)o->value("learning_rate", 1e-3);
+			m_beta1 = (float)o->value("beta1", 0.9); m_beta2 = (float)o->value("beta2", 0.999);
+			m_epsilon = (float)o->value("epsilon", 1e-8); m_l2_reg = (float)o->value("l2_reg", 1e-8);
+			break;
+		} else {
+			throw std::runtime_error{"optimizer otype '" + otype + "' is not part of the NeRF hot path (Ema / ExponentialDecay / Adam are)"};
+		}
+		if (!o->contains("nested")) throw std::runtime_error{"optimizer '" + otype + "' needs a nested optimizer"};
+		o = &o->at("nested");
+	}
+	m_learning_rate = m_base_learning_rate;
+}
+
+void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
+	m_rng = Pcg32(m_seed);
+	m_windowless_render_surface.reset_accumulation();
+	NerfTraining& tr = m_nerf.training;
+	tr.counters_rgb.rays_per_batch = 1 << 12;
+	tr.counters_rgb.measured_batch_size_before_compaction = 0;
+	tr.n_steps_since_error_map_update = 0;
+	tr.n_rays_since_error_map_update = 0;
+	tr.n_steps_between_error_map_updates = 128;
+	tr.density_grid_rng = Pcg32(m_rng.next_uint());
+
+	Json config = m_network_config;
+	const Json empty = Json::object();
+	const Json& enc = config.contains("encoding") ? config["encoding"] : empty;
+	tr.loss_type = string_to_loss_type(config.contains("loss") ? config["loss"].value("otype", "L2") : std::string("L2"));
+
+	// the fused kernels implement the base.json family: HashGrid L=16 F=2, 64-wide FullyFusedMLP 1+2 hidden layers, SH degree 4
+	auto require = [](bool ok, const std::string& what) { if (!ok) throw std::runtime_error{"network config not supported by the gfx950 fused kernels: " + what}; };
+	std::string enc_type = enc.value("otype", "HashGrid"); std::transform(enc_type.begin(), enc_type.end(), enc_type.begin(), ::tolower);
+	require(enc_type == "hashgrid", "encoding.otype must be HashGrid");
+	const uint32_t n_features_per_level = (uint32_t)enc.value("n_features_per_level", 2);
+	require(n_features_per_level == 2, "n_features_per_level must be 2");
+	m_num_levels = (uint32_t)enc.value("n_levels", 16);
+	require(m_num_levels == 16, "n_levels must be 16");
+	const uint32_t log2_hashmap_size = (uint32_t)enc.value("log2_hashmap_size", 15);
+	m_base_grid_resolution = (uint32_t)enc.value("base_resolution", 0);
+	if (!m_base_grid_resolution) m_base_grid_resolution = 1u << (log2_hashmap_size / 3);
+	const float desired_resolution = 2048.0f;
+	m_per_level_scale = (float)enc.value("per_level_scale", 0.0);
+	if (m_per_level_scale <= 0.0f && m_num_levels > 1) {
+		m_per_level_scale = std::exp(std::log(desired_resolution * (float)tr.dataset.aabb_scale / (float)m_base_grid_resolution) / (float)(m_num_levels - 1));
+	}
+	if (config.contains("network")) {
+		require(config["network"].value("n_neurons", 64) == 64 && config["network"].value("n_hidden_layers", 1) == 1, "network must be 64 neurons x 1 hidden layer");
+	}
+	if (config.contains("rgb_network")) {
+		require(config["rgb_network"].value("n_neurons", 64) == 64 && config["rgb_network"].value("n_hidden_layers", 2) == 2, "rgb_network must be 64 neurons x 2 hidden layers");
+	}
+	check(ngp_hip_net_make_desc_host(m_num_levels, log2_hashmap_size, m_base_grid_resolution, m_per_level_scale, &m_desc), "ngp_hip_net_make_desc_host");
+	m_n_params = ngp_hip_net_n_params_host(&m_desc);
+	m_desc_gpu.resize(sizeof(NgpNetDesc));
+	m_desc_gpu.copy_from_host(&m_desc, sizeof(NgpNetDesc));
+
+	if (config.contains("optimizer")) parse_optimizer_config(config["optimizer"]);
+	m_optimizer_step = 0;
+
+	m_params.resize(m_n_params * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize(m_n_params * 2);
+	m_master.resize(m_n_params * 4); m_first_moments.resize(m_n_params * 4); m_second_moments.resize(m_n_params * 4); m_ema.resize(m_n_params * 4);
+	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream);
+	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>()), "ngp_hip_nerf_init_params");
+
+	m_distortion_map.resize(32 * 32 * 2 * 4);
+	m_distortion_map.memset(0, m_stream);
+	m_loss_scalar_gpu.resize(4);
+
+	m_training_step = 0;
+	m_loss_scalar = 0.f;
+	if (clear_density_grid) {
+		m_nerf.density_grid.resize((size_t)GRID_CELLS * (m_nerf.max_cascade + 1) * 4);
+		m_nerf.density_grid.memset(0, m_stream);
+		m_nerf.density_grid_bitfield.resize((size_t)GRID_CELLS);  // grid_mip_offset(NERF_CASCADES)/8
+		m_nerf.density_grid_bitfield.memset(0, m_stream);
+		m_nerf.density_grid_mean.resize(4);
+		m_nerf.density_grid_mean.memset(0, m_stream);
+	}
+	sync();
+}
+
+// ---- training ---------------------------------------------------------------------------------------------------
+bool Testbed::frame() {  // testbed.cu:2044-2090 without the GUI: train_and_render(skip_rendering = true)
+	if (m_train) train(m_training_batch_size);
+	return true;
+}
+
+void Testbed::train(uint32_t batch_size) {  // testbed.cu:2527-2587
+	if (!m_training_data_available) { m_train = false; return; }
+	if (m_n_params == 0) throw std::runtime_error{"train(): no network — call reload_network_from_file/json first"};
+	m_windowless_render_surface.reset_accumulation();
+	const uint32_t n_prep_to_skip = std::min(std::max(m_training_step / 16u, 1u), 16u);
+	if (m_training_step % n_prep_to_skip == 0) {
+		auto start = std::chrono::steady_clock::now();
+		training_prep_nerf(batch_size);
+		sync();
+		m_stats.training_prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count() / n_prep_to_skip;
+	}
+	const bool get_loss_scalar = m_training_step % 16 == 0;
+	auto start = std::chrono::steady_clock::now();
+	train_nerf(batch_size, get_loss_scalar);
+	sync();
+	m_stats.training_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
+}
+
+void Testbed::training_prep_nerf(uint32_t) {  // testbed_nerf.cu:3388-3401
+	if (m_nerf.training.n_images_for_training == 0) return;
+	const float alpha = m_nerf.training.density_grid_decay;
+	const uint32_t n_cascades = m_nerf.max_cascade + 1;
+	if (m_training_step < 256) update_density_grid_nerf(alpha, GRID_CELLS * n_cascades, 0);
+	else update_density_grid_nerf(alpha, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
+}
+
+void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {  // testbed_nerf.cu:2761-2842
+	NerfTraining& tr = m_nerf.training;
+	const uint32_t n_elements = GRID_CELLS * (m_nerf.max_cascade + 1);
+	if (m_nerf.density_grid.bytes() != (size_t)n_elements * 4) { m_nerf.density_grid.resize((size_t)n_elements * 4); m_nerf.density_grid.memset(0, m_stream); }
+	const uint32_t n_samples = n_uniform + n_nonuniform;
+	m_grid_positions.enlarge((size_t)n_samples * 12); m_grid_indices.enlarge((size_t)n_samples * 4);
+	m_grid_tmp.enlarge((size_t)n_elements * 4); m_grid_mlp_out.enlarge((size_t)n_samples * 2);
+	float* grid = m_nerf.density_grid.as<float>();
+
+	if (m_training_step == 0 || tr.n_images_for_training != tr.n_images_for_training_prev) {
+		tr.n_images_for_training_prev = tr.n_images_for_training;
+		if (m_training_step == 0) m_nerf.density_grid_ema_step = 0;
+		if (!tr.dataset.has_rays) {
+			check(ngp_hip_mark_untrained_density_grid(m_stream, n_elements, grid, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
+			                                          tr.transforms_gpu.as<NgpXForm>(), m_training_step == 0), "mark_untrained_density_grid");
+		} else {
+			m_nerf.density_grid.memset(0, m_stream);
+		}
+	}
+	HIP_CHECK_THROW(hipMemsetAsync(m_grid_tmp.data(), 0, (size_t)n_elements * 4, (hipStream_t)m_stream));
+	check(ngp_hip_generate_grid_samples_nonuniform(m_stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+	                                               m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f), "generate_grid_samples (uniform)");
+	tr.density_grid_rng.advance();
+	check(ngp_hip_generate_grid_samples_nonuniform(m_stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+	                                               m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
+	                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
+	tr.density_grid_rng.advance();
+	// density pass on the TRAINING weights (use_inference_params = false, testbed_nerf.cu:2833)
+	check(ngp_hip_nerf_density(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>()), "nerf_density");
+	check(ngp_hip_splat_grid_samples_max(m_stream, n_samples, m_grid_indices.as<uint32_t>(), m_grid_mlp_out.as<uint16_t>(), m_grid_tmp.as<float>(), (int)m_nerf.density_activation), "splat");
+	check(ngp_hip_ema_grid_samples(m_stream, n_elements, decay, grid, m_grid_tmp.as<float>()), "ema");
+	++m_nerf.density_grid_ema_step;
+	update_density_grid_mean_and_bitfield();
+}
+
+void Testbed::update_density_grid_mean_and_bitfield() {  // testbed_nerf.cu:2844-2859
+	m_nerf.density_grid_bitfield.enlarge((size_t)GRID_CELLS);
+	m_nerf.density_grid_mean.enlarge(4);
+	check(ngp_hip_density_grid_mean(m_stream, m_nerf.density_grid.as<float>(), GRID_CELLS, m_nerf.density_grid_mean.as<float>()), "density_grid_mean");
+	check(ngp_hip_grid_to_bitfield_and_pool(m_stream, m_nerf.density_grid.as<float>(), m_nerf.max_cascade + 1, m_nerf.density_grid_mean.as<float>(),
+	                                        m_nerf.density_grid_bitfield.as<uint8_t>()), "grid_to_bitfield_and_pool");
+}
+
+void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
+	if (world_size == 0 || rank >= world_size) throw std::runtime_error{"set_distributed: bad rank / world_size"};
+	m_rank = rank; m_world_size = world_size;
+}
+
+void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
+	if (m_nerf.training.n_images_for_training == 0) return;
+	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / all-reduce / train_nerf_dp_end"};
+	uint32_t counters[2];
+	train_nerf_dp_begin(target_batch_size, counters);
+	float loss_sum = get_loss_scalar ? local_loss_sum() : 0.f;
+	train_nerf_dp_end(target_batch_size, counters[0], counters[1], get_loss_scalar, loss_sum);
+}
+
+void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]) {
+	NerfTraining& tr = m_nerf.training;
+	NerfCounters& c = tr.counters_rgb;
+	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)
+	c.numsteps_counter.enlarge(4); c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge((size_t)c.rays_per_batch * 4);
+	c.numsteps_counter.memset(0, m_stream); c.numsteps_counter_compacted.memset(0, m_stream);
+	HIP_CHECK_THROW(hipMemsetAsync(c.loss.data(), 0, (size_t)c.rays_per_batch * 4, (hipStream_t)m_stream));
+	// error map (re)allocation (2933-2939)
+	if (tr.n_steps_since_error_map_update == 0 && !tr.dataset.metadata.empty()) {
+		const uint32_t n_samples_per_image = (tr.n_steps_between_error_map_updates * c.rays_per_batch) / (uint32_t)tr.dataset.n_images;
+		const int r = (int)(std::sqrt(std::sqrt((float)n_samples_per_image)) * 3.5f);
+		tr.error_map_res[0] = std::min(r, tr.dataset.metadata[0].res[0]);
+		tr.error_map_res[1] = std::min(r, tr.dataset.metadata[0].res[1]);
+		tr.error_map_data.resize((size_t)tr.error_map_res[0] * tr.error_map_res[1] * tr.dataset.n_images * 4);
+		tr.error_map_data.memset(0, m_stream);
+	}
+	train_nerf_step(target_batch_size);
+	// update_after_training reads the two counters (2870-2874): blocking 4-byte D2H copies
+	sync();
+	c.numsteps_counter.copy_to_host(&counters_out[0], 4);
+	c.numsteps_counter_compacted.copy_to_host(&counters_out[1], 4);
+}
+
+float Testbed::local_loss_sum() {
+	NerfCounters& c = m_nerf.training.counters_rgb;
+	check(ngp_hip_reduce_sum_f32(m_stream, c.loss.as<float>(), c.rays_per_batch, m_loss_scalar_gpu.as<float>()), "reduce_sum");
+	sync();
+	float v = 0.f;
+	m_loss_scalar_gpu.copy_to_host(&v, 4);
+	return v;
+}
+
+void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
+	++m_optimizer_step;
+	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, NGP_MLP_N_PARAMS, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	                             m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
+	                             m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>()), "optimizer_step");
+	// tcnn ExponentialDecay::step: after the nested step, lr *= decay_base whenever the step count hits start + k * interval
+	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
+		m_learning_rate *= m_decay_base;
+	}
+}
+
+void Testbed::train_nerf_dp_end(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum) {
+	NerfTraining& tr = m_nerf.training;
+	optimizer_step();
+	++m_training_step;
+	update_after_training(target_batch_size, global_measured_before, global_measured, get_loss_scalar, global_loss_sum);
+	const bool zero_records = tr.counters_rgb.measured_batch_size == 0;
+	if (zero_records) {
+		m_loss_scalar = 0.f;
+		fprintf(stderr, "Nerf training generated 0 samples. Aborting training.\n");
+		m_train = false;
+	}
+	// error-map bookkeeping (2971-3023); CDF construction is skipped because sampling from it is off by default (testbed.h:668-669)
+	tr.n_steps_since_error_map_update += 1;
+	if (tr.n_steps_since_error_map_update >= tr.n_steps_between_error_map_updates) {
+		tr.n_steps_since_error_map_update = 0;
+		tr.n_rays_since_error_map_update = 0;
+		tr.n_steps_between_error_map_updates = (uint32_t)(tr.n_steps_between_error_map_updates * 1.5f);
+	}
+}
+
+void Testbed::update_after_training(uint32_t target_batch_size, uint32_t counter, uint32_t compacted_counter, bool get_loss_scalar, float loss_sum) {  // 2870-2894
+	NerfCounters& c = m_nerf.training.counters_rgb;
+	c.measured_batch_size = 0;
+	c.measured_batch_size_before_compaction = 0;
+	if (counter == 0 || compacted_counter == 0) return;
+	// with W ranks the counters are global sums; every rank derives the same per-rank figures
+	c.measured_batch_size_before_compaction = counter / m_world_size;
+	c.measured_batch_size = compacted_counter / m_world_size;
+	if (get_loss_scalar) m_loss_scalar = loss_sum * (float)c.measured_batch_size / (float)target_batch_size;
+	c.rays_per_batch = (uint32_t)((float)c.rays_per_batch * (float)target_batch_size / (float)c.measured_batch_size);
+	c.rays_per_batch = std::min(next_multiple(c.rays_per_batch, BATCH_SIZE_GRANULARITY), 1u << 18);
+}
+
+void Testbed::train_nerf_step(uint32_t target_batch_size) {  // testbed_nerf.cu:3138-3385
+	NerfTraining& tr = m_nerf.training;
+	NerfCounters& c = tr.counters_rgb;
+	if (target_batch_size % 256) throw std::runtime_error{"training batch size must be a multiple of 256"};
+	const uint32_t max_samples = target_batch_size * 16;
+	const uint32_t R = c.rays_per_batch;
+	m_ray_indices.enlarge((size_t)R * 4); m_rays.enlarge((size_t)R * sizeof(NgpRay)); m_numsteps.enlarge((size_t)R * 8);
+	m_coords.enlarge((size_t)max_samples * sizeof(NgpCoord));
+	m_mlp_out.enlarge((size_t)std::max(target_batch_size, max_samples) * OUT_STRIDE * 2);
+	m_dloss.enlarge((size_t)target_batch_size * OUT_STRIDE * 2);
+	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
+	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
+	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes(target_batch_size));
+	m_ray_counter.enlarge(4);
+
+	uint32_t max_inference;
+	if (c.measured_batch_size_before_compaction == 0) {
+		c.measured_batch_size_before_compaction = max_inference = max_samples;
+	} else {
+		max_inference = next_multiple(std::min(c.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
+	}
+	if (m_training_step == 0) c.n_rays_total = 0;
+	c.n_rays_total += R;
+	tr.n_rays_since_error_map_update += R;
+
+	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	const int32_t dist_res[2] = {32, 32};
+	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
+	m_ray_counter.memset(0, m_stream);
+	check(ngp_hip_generate_training_samples(m_stream, R, &m_aabb, max_inference, m_rng.state, m_rng.inc, m_ray_counter.as<uint32_t>(), c.numsteps_counter.as<uint32_t>(),
+	                                        m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training,
+	                                        tr.dataset.metadata_gpu.as<NgpImageMeta>(), tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
+	                                        m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0, m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res,
+	                                        ray_offset, n_rays_global), "generate_training_samples");
+	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256)
+	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
+	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, m_ray_counter.as<uint32_t>(), LOSS_SCALE, OUT_STRIDE, m_background_color,
+	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
+	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
+	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
+	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
+	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance), "compute_loss");
+	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
+	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
+	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
+	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
+	m_rng.advance();
+}
+
+// ---- rendering --------------------------------------------------------------------------------------------------
+std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool linear) {  // python_api.cu:132-190 (no camera path / motion blur)
+	if (m_n_params == 0) throw std::runtime_error{"render(): no network"};
+	RenderBuffer& rb = m_windowless_render_surface;
+	rb.resize(width, height);
+	rb.reset_accumulation();
+	m_render_samples_evaluated = 0;
+	auto start = std::chrono::steady_clock::now();
+	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, rb, !linear);
+	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
+	std::vector<float> out((size_t)width * height * 4);
+	rb.surface.copy_to_host(out.data(), out.size() * 4);
+	return out;
+}
+
+void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb) {  // testbed.cu:2695-2911
+	rb.frame_buffer.memset(0, m_stream);
+	rb.depth_buffer.memset(0, m_stream);
+	const float focal_length[2] = {m_relative_focal_length[0] * (float)rb.res[m_fov_axis] * m_zoom, m_relative_focal_length[1] * (float)rb.res[m_fov_axis] * m_zoom};
+	const float screen_center[2] = {(0.5f - m_screen_center[0]) * m_zoom + 0.5f, (0.5f - m_screen_center[1]) * m_zoom + 0.5f};
+	render_nerf(rb, focal_length, cam0, cam1, screen_center);
+	// CudaRenderBuffer::accumulate / tonemap (render_buffer.cu:609-664)
+	if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);
+	rb.color_space = m_color_space;
+	check(ngp_hip_accumulate(m_stream, rb.res, rb.frame_buffer.as<float>(), rb.accumulate_buffer.as<float>(), (float)rb.spp, (int)rb.color_space), "accumulate");
+	++rb.spp;
+	check(ngp_hip_tonemap(m_stream, rb.res, m_exposure, m_background_color, rb.accumulate_buffer.as<float>(), (int)rb.color_space, to_srgb ? NGP_COLOR_SRGB : NGP_COLOR_LINEAR,
+	                      (int)rb.tonemap_curve, 0, rb.surface.as<float>()), "tonemap");
+	sync();
+}
+
+void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float screen_center[2]) {  // testbed_nerf.cu:2354-2500, 2047-2267
+	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)rb.res[1];
+	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY);
+	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
+	m_tr_hit_payload.enlarge(n_el * sizeof(NgpPayload)); m_tr_hit_rgba.enlarge(n_el * 16); m_tr_hit_depth.enlarge(n_el * 4);
+	m_tr_net_in.enlarge(n_el * 8 * sizeof(NgpCoord)); m_tr_net_out.enlarge(n_el * 8 * OUT_STRIDE * 2);
+	m_tr_counters.enlarge(8);
+	uint32_t* alive_counter = m_tr_counters.as<uint32_t>();
+	uint32_t* hit_counter = alive_counter + 1;
+
+	const bool use_lens = m_nerf.render_with_lens_distortion && m_nerf.render_lens_proxy.lens_mode == 1;
+	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
+	const uint32_t sample_index = rb.spp;
+	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, zero4, screen_center, zero3, m_snap_to_pixel_centers,
+	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, use_lens ? 1 : 0, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>()), "init_rays");
+	HIP_CHECK_THROW(hipMemsetAsync(m_tr_rgba[0].data(), 0, (size_t)n_pixels * 16, (hipStream_t)m_stream));
+	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
+	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;
+	check(ngp_hip_advance_pos(m_stream, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
+	                          min_mip, m_nerf.cone_angle_constant), "advance_pos");
+
+	HIP_CHECK_THROW(hipMemsetAsync(hit_counter, 0, 4, (hipStream_t)m_stream));
+	uint32_t n_alive = n_pixels, i = 1, dbi = 0;
+	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	while (i < MARCH_ITER) {
+		const int cur = (dbi + 1) % 2, tmp = dbi % 2;
+		++dbi;
+		HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, (hipStream_t)m_stream));
+		check(ngp_hip_compact_rays(m_stream, n_alive, m_tr_rgba[tmp].as<float>(), m_tr_depth[tmp].as<float>(), m_tr_payload[tmp].as<NgpPayload>(), m_tr_rgba[cur].as<float>(),
+		                           m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(),
+		                           m_tr_hit_payload.as<NgpPayload>(), alive_counter, hit_counter), "compact_rays");
+		HIP_CHECK_THROW(hipMemcpyAsync(&n_alive, alive_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		sync();
+		if (n_alive == 0) break;
+		const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), 8u);
+		check(ngp_hip_generate_next_inputs(m_stream, n_alive, &m_render_aabb, &m_aabb, m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(), n_steps,
+		                                   m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+		const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
+		// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
+		check(ngp_hip_nerf_inference(m_stream, desc, m_inference_params.as<uint16_t>(), m_tr_net_in.as<float>(), 7, n_elements, m_tr_net_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference (render)");
+		m_render_samples_evaluated += n_elements;
+		check(ngp_hip_composite(m_stream, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(),
+		                        m_tr_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");
+		i += n_steps;
+	}
+	uint32_t n_hit = 0;
+	HIP_CHECK_THROW(hipMemcpyAsync(&n_hit, hit_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+	sync();
+	check(ngp_hip_shade(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
+	                    rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>()), "shade");
+}
+
+void Testbed::save_snapshot(const std::string&, bool) {
+	throw std::runtime_error{"save_snapshot: .msgpack snapshot compatibility is SURVEY.md §8f row f1 (next)"};
+}
+void Testbed::load_snapshot(const std::string&) {
+	throw std::runtime_error{"load_snapshot: .msgpack snapshot compatibility is SURVEY.md §8f row f1 (next)"};
+}
+
+} // namespace ngp

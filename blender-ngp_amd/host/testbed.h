@@ -1,0 +1,289 @@
+// testbed.h — host-side orchestrator: the NeRF part of the reference's `Testbed` (include/neural-graphics-primitives/testbed.h,
+// src/testbed.cu, src/testbed_nerf.cu host functions), re-implemented over the C ABI of libngp_hip.so (include/ngp_hip.h).
+// No Eigen, no tiny-cuda-nn, no CUDA: plain C++17 + the HIP runtime API for memory / streams.
+//
+// Kept from the reference: names and meaning of the public methods / properties that scripts/run.py and the Blender add-on use
+// (src/python_api.cu:540-732), the training schedule (Testbed::train, src/testbed.cu:2527-2587), the step structure
+// (train_nerf / train_nerf_step, src/testbed_nerf.cu:2896-3385), the render loop (NerfTracer, 2047-2267) and error behaviour
+// (std::runtime_error -> Python RuntimeError).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mini_json.h"
+#include "ngp_hip.h"
+
+namespace ngp {
+
+// ---- enums (include/neural-graphics-primitives/common.h:65-160)
+enum class ETestbedMode : int { Nerf, Sdf, Image, Volume };
+enum class ERenderMode : int { AO, Shade, Normals, Positions, Depth, Distortion, Cost, Slice };
+enum class ELossType : int { L2, L1, Mape, Smape, Huber, LogL1, RelativeL2 };
+enum class ENerfActivation : int { None, ReLU, Logistic, Exponential };
+enum class EColorSpace : int { Linear, SRGB, VisPosNeg };
+enum class ETonemapCurve : int { Identity, ACES, Hable, Reinhard };
+enum class ELensMode : int { Perspective, OpenCV, FTheta, LatLong };
+
+struct Vec3 { float x = 0, y = 0, z = 0; };
+struct Mat34 { float m[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; };  // column-major 3x4 (Eigen default)
+
+// ---- RAII device memory (replaces tcnn::GPUMemory / GPUMemoryArena)
+class DeviceBuffer {
+public:
+	DeviceBuffer() = default;
+	~DeviceBuffer();
+	DeviceBuffer(const DeviceBuffer&) = delete;
+	DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+	DeviceBuffer(DeviceBuffer&& o) noexcept { *this = std::move(o); }
+	DeviceBuffer& operator=(DeviceBuffer&& o) noexcept;
+	void resize(size_t bytes);            // reallocates if size differs; contents undefined
+	void enlarge(size_t bytes);           // grows only
+	void free();
+	void memset(int value, void* stream = nullptr);
+	void copy_from_host(const void* src, size_t bytes, size_t dst_offset = 0);
+	void copy_to_host(void* dst, size_t bytes, size_t src_offset = 0) const;
+	template <typename T> T* as() const { return (T*)m_ptr; }
+	void* data() const { return m_ptr; }
+	size_t bytes() const { return m_bytes; }
+	static size_t total_allocated();
+private:
+	void* m_ptr = nullptr;
+	size_t m_bytes = 0;
+};
+
+// host pcg32 (tcnn pcg32.h), same stream as the device one
+struct Pcg32 {
+	uint64_t state = 0x853c49e6748fea9bULL, inc = 0xda3e39cb94b95bdbULL;
+	Pcg32() = default;
+	explicit Pcg32(uint64_t seed) { this->seed(seed, 1); }
+	void seed(uint64_t initstate, uint64_t initseq) { state = 0; inc = (initseq << 1u) | 1u; next_uint(); state += initstate; next_uint(); }
+	uint32_t next_uint() {
+		uint64_t old = state;
+		state = old * 0x5851f42d4c957f2dULL + inc;
+		uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+		return (xs >> rot) | (xs << ((~rot + 1u) & 31));
+	}
+	float next_float() { uint32_t u = (next_uint() >> 9) | 0x3f800000u; float f; memcpy(&f, &u, 4); return f - 1.0f; }
+	void advance(int64_t delta_ = (1ll << 32)) {
+		uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = inc, acc_mult = 1u, acc_plus = 0u, delta = (uint64_t)delta_;
+		while (delta > 0) {
+			if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+			cur_plus = (cur_mult + 1) * cur_plus; cur_mult *= cur_mult; delta /= 2;
+		}
+		state = acc_mult * state + acc_plus;
+	}
+};
+
+// ---- dataset (include/neural-graphics-primitives/nerf_loader.h:47-185)
+struct NerfDataset {
+	size_t n_images = 0;
+	std::vector<NgpXForm> xforms;
+	std::vector<NgpImageMeta> metadata;          // host copy; .pixels are device pointers into pixelmemory
+	std::vector<DeviceBuffer> pixelmemory;
+	DeviceBuffer metadata_gpu;
+	float scale = 1.0f;                          // NERF_SCALE = 1.0 in this fork (nerf_loader.h:28)
+	Vec3 offset;                                 // {0,0,0} (nerf_loader.cu:186)
+	int aabb_scale = 1;
+	bool is_hdr = false;
+	bool from_mitsuba = false;
+	bool has_rays = false;
+	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
+	Vec3 up{0.0f, 1.0f, 0.0f};
+
+	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix) const;   // nerf_loader.h:113-132
+	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix) const;    // nerf_loader.h:134-152
+	void set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type); // nerf_loader.cu:749-
+	void update_metadata(int first = 0, int last = -1);         // nerf_loader.cu:851-867
+};
+
+struct NerfCounters {  // testbed.h:369-381
+	DeviceBuffer numsteps_counter, numsteps_counter_compacted, loss;
+	uint32_t rays_per_batch = 1 << 12;
+	uint32_t n_rays_total = 0;
+	uint32_t measured_batch_size = 0;
+	uint32_t measured_batch_size_before_compaction = 0;
+};
+
+class Testbed;
+
+struct NerfTraining {
+	Testbed* owner = nullptr;
+	NerfDataset dataset;
+	int n_images_for_training = 0;
+	int n_images_for_training_prev = 0;
+	std::vector<NgpXForm> transforms;
+	DeviceBuffer transforms_gpu;
+	DeviceBuffer cam_exposure_gpu;               // zeros: exposure optimisation is off by default (testbed.h:658-662)
+	NerfCounters counters_rgb;
+	Pcg32 density_grid_rng;
+	float near_distance = 0.2f;                  // testbed.h:676
+	float density_grid_decay = 0.95f;            // testbed.h:675
+	bool random_bg_color = true;                 // testbed.h:663
+	bool linear_colors = false;                  // testbed.h:664
+	bool snap_to_pixel_centers = false;          // testbed.h:665
+	ELossType loss_type = ELossType::L2;
+	// error map (always-on accumulation, testbed_nerf.cu:2933-2939, 2971-3023)
+	DeviceBuffer error_map_data;
+	int32_t error_map_res[2] = {0, 0};
+	uint32_t n_steps_since_error_map_update = 0;
+	uint32_t n_steps_between_error_map_updates = 128;
+	uint32_t n_rays_since_error_map_update = 0;
+
+	void set_image(int frame_idx, int w, int h, const float* rgba_host);                 // python_api.cu:53-72 (float RGBA)
+	void set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host);         // Byte images as the PNG loader stores them (nerf_loader.cu:622-623)
+	void set_camera_extrinsics(int frame_idx, const Mat34& camera_to_world, bool convert_to_ngp = true); // testbed_nerf.cu:2539-2541
+	Mat34 get_camera_extrinsics(int frame_idx) const;
+	void set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2); // testbed_nerf.cu:2502-2516
+	void update_transforms(int first = 0, int last = -1);                                // testbed_nerf.cu:2598-2633 (no extrinsic offsets)
+};
+
+struct Nerf {
+	NerfTraining training;
+	DeviceBuffer density_grid;            // fp32 [(max_cascade+1) * 128^3], Morton order
+	DeviceBuffer density_grid_bitfield;   // 8 cascades * 128^3 / 8 bytes
+	DeviceBuffer density_grid_mean;       // 1 float
+	uint32_t max_cascade = 0;
+	uint32_t density_grid_ema_step = 0;
+	ENerfActivation rgb_activation = ENerfActivation::Exponential;   // testbed.h:709
+	ENerfActivation density_activation = ENerfActivation::Exponential; // testbed.h:710
+	float cone_angle_constant = 1.f / 256.f;
+	float render_min_transmittance = 0.01f;  // testbed.h:725
+	bool render_with_lens_distortion = false;
+	float sharpen = 0.f;
+	int show_accel = -1;
+	NgpImageMeta render_lens_proxy{};        // only lens_mode / lens_params are used (render_lens)
+};
+
+// frame / accumulate / output buffers (src/render_buffer.cu CudaRenderBuffer, windowless surface)
+struct RenderBuffer {
+	DeviceBuffer frame_buffer, depth_buffer, accumulate_buffer, surface;
+	int32_t res[2] = {0, 0};
+	uint32_t spp = 0;
+	EColorSpace color_space = EColorSpace::Linear;
+	ETonemapCurve tonemap_curve = ETonemapCurve::Identity;
+	void resize(int w, int h);
+	void reset_accumulation() { spp = 0; }
+};
+
+struct TrainStats { float training_prep_ms = 0, training_ms = 0, render_ms = 0; };
+
+class Testbed {
+public:
+	explicit Testbed(ETestbedMode mode = ETestbedMode::Nerf);
+	~Testbed();
+
+	// ---- data (python_api.cu:546, 619)
+	void load_training_data(const std::string& path);
+	void create_empty_nerf_dataset(size_t n_images, int aabb_scale = 1, bool is_hdr = false);
+	void load_nerf_post();                                             // testbed_nerf.cu:2643-2733
+
+	// ---- network (testbed.cu:120-194, 2249-2470)
+	void reload_network_from_file(const std::string& path = "");
+	void reload_network_from_json(const Json& json, const std::string& config_base_path = "");
+	Json load_network_config(const std::string& path);
+	void reset_network(bool clear_density_grid = true);
+	void reset(bool reset_density_grid = true) { reset_network(reset_density_grid); }
+	size_t n_params() const { return m_n_params; }
+	size_t n_encoding_params() const { return m_n_params - NGP_MLP_N_PARAMS; }
+
+	// ---- training (testbed.cu:2044-2090, 2527-2587; testbed_nerf.cu:2761-3401)
+	bool frame();
+	void train(uint32_t batch_size);
+	void training_prep_nerf(uint32_t batch_size);
+	void update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform);
+	void update_density_grid_mean_and_bitfield();
+	void train_nerf(uint32_t target_batch_size, bool get_loss_scalar);
+	void train_nerf_step(uint32_t target_batch_size);
+	// data-parallel split of train_nerf: begin = everything up to and including backward (gradients ready in
+	// gradients()), end = optimizer step + counter feedback given the GLOBAL (all-rank summed) counters.
+	void set_distributed(uint32_t rank, uint32_t world_size);
+	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]);
+	void train_nerf_dp_end(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
+	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
+	float local_loss_sum();
+
+	// ---- rendering (python_api.cu:132-190; testbed.cu:2695-2911; testbed_nerf.cu:2047-2267, 2354-2500)
+	std::vector<float> render_to_cpu(int width, int height, int spp, bool linear);
+	void render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb);
+	void render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float screen_center[2]);
+	void set_nerf_camera_matrix(const Mat34& cam) { m_camera = m_nerf.training.dataset.nerf_matrix_to_ngp(cam); } // testbed.cu:219-221
+	void reset_camera();
+	float fov() const;
+	void set_fov(float val);
+
+	// ---- snapshots (testbed.cu:3006-3106) — next-row f1, see DESIGN.md
+	void save_snapshot(const std::string& path, bool include_optimizer_state);
+	void load_snapshot(const std::string& path);
+
+	float loss() const { return m_loss_scalar; }
+	uint32_t training_step() const { return m_training_step; }
+	void sync();
+
+	// ---- state (names follow testbed.h)
+	ETestbedMode m_testbed_mode;
+	Nerf m_nerf;
+	bool m_train = false;
+	bool m_training_data_available = false;
+	uint32_t m_training_step = 0;
+	uint32_t m_training_batch_size = 1 << 18;          // testbed.h:909
+	float m_loss_scalar = 0.f;
+	uint64_t m_seed = 1337;                             // testbed.h:567
+	Pcg32 m_rng;
+	NgpAabb m_aabb{}, m_raw_aabb{}, m_render_aabb{};
+	float m_render_aabb_to_local[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	float m_background_color[4] = {0.f, 0.f, 0.f, 1.f}; // testbed.h:875
+	EColorSpace m_color_space = EColorSpace::Linear;
+	float m_exposure = 0.f;
+	bool m_snap_to_pixel_centers = false;
+	float m_render_near_distance = 0.0f;
+	Mat34 m_camera;
+	float m_relative_focal_length[2] = {1.f, 1.f};
+	uint32_t m_fov_axis = 1;
+	float m_zoom = 1.f;
+	float m_screen_center[2] = {0.5f, 0.5f};
+	float m_scale = 1.5f;
+	bool m_max_level_rand_training = false;
+	Json m_network_config;
+	std::string m_network_config_path;
+	TrainStats m_stats;
+	RenderBuffer m_windowless_render_surface;
+	uint64_t m_render_samples_evaluated = 0;          // network samples of the last render_to_cpu (for MP/s + roofline accounting)
+
+	// network + optimizer state
+	NgpNetDesc m_desc{};
+	DeviceBuffer m_desc_gpu, m_params, m_inference_params, m_master, m_first_moments, m_second_moments, m_ema, m_grads;
+	size_t m_n_params = 0;
+	uint32_t m_optimizer_step = 0;
+	float m_learning_rate = 1e-2f, m_base_learning_rate = 1e-2f, m_beta1 = 0.9f, m_beta2 = 0.99f, m_epsilon = 1e-15f, m_l2_reg = 1e-6f;
+	float m_ema_decay = 0.95f;
+	bool m_use_ema = true;
+	uint32_t m_decay_start = 20000, m_decay_interval = 10000, m_decay_end = 0;
+	float m_decay_base = 0.33f;
+	bool m_has_decay = true;
+	float m_per_level_scale = 0.f;
+	uint32_t m_base_grid_resolution = 16, m_num_levels = 16;
+
+	// distributed
+	uint32_t m_rank = 0, m_world_size = 1;
+
+private:
+	void* m_stream = nullptr;
+	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
+	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
+	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
+	DeviceBuffer m_distortion_map;  // 32x32x2 zeros: passed unconditionally to the ray generator
+	DeviceBuffer m_loss_scalar_gpu;
+	// tracer scratch (NerfTracer::enlarge 2270-2295)
+	DeviceBuffer m_tr_payload[2], m_tr_rgba[2], m_tr_depth[2], m_tr_hit_payload, m_tr_hit_rgba, m_tr_hit_depth, m_tr_net_in, m_tr_net_out, m_tr_counters;
+	void check(int rc, const char* what);
+	void optimizer_step();
+	void update_after_training(uint32_t target_batch_size, uint32_t counter, uint32_t compacted_counter, bool get_loss_scalar, float loss_sum);
+	void parse_optimizer_config(const Json& opt);
+};
+
+} // namespace ngp

@@ -159,6 +159,6 @@ def test_reduce_sum(ngp, cuda):
     rs = np.random.RandomState(0)
     for n in (1, 255, 4096, 262144):
         x = rs.rand(n).astype(np.float32)
-        d_o = H.dev_zeros(4, cuda)
-        check(ngp.ngp_hip_reduce_sum_f32(None, H.to_dev(x, cuda).data_ptr(), n, d_o.data_ptr()))
+        d_o, d_x = H.dev_zeros(4, cuda), H.to_dev(x, cuda)
+        check(ngp.ngp_hip_reduce_sum_f32(None, d_x.data_ptr(), n, d_o.data_ptr()))
         assert abs(float(H.to_host(d_o, np.float32)[0]) - float(x.astype(np.float64).sum())) <= 1e-5 * n

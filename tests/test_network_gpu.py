@@ -183,5 +183,7 @@ def test_optimizer_step_bit_exact(ngp, oracle, cuda):
                                      d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), d[6].data_ptr()))
     oracle.orc_adam_ema_step(n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95),
                              grads.ctypes.data, master.ctypes.data, p16.ctypes.data, m1.ctypes.data, m2.ctypes.data, ema.ctypes.data, inf.ctypes.data)
-    for t, ref, dt in zip(d[1:], (master, p16, m1, m2, ema, inf), (np.float32, np.float16, np.float32, np.float32, np.float32, np.float16)):
-        np.testing.assert_array_equal(H.to_host(t, dt), ref)
+    for name, t, ref, dt in zip(("master", "params", "m1", "m2", "ema", "inference"), d[1:], (master, p16, m1, m2, ema, inf), (np.float32, np.float16, np.float32, np.float32, np.float32, np.float16)):
+        got = H.to_host(t, dt)
+        bad = np.nonzero(got != ref)[0]
+        assert bad.size == 0, (name, bad[:5], got[bad[:5]], ref[bad[:5]], H.to_host(d[1], np.float32)[bad[:5]].view(np.uint32), H.to_host(d[5], np.float32)[bad[:5]].view(np.uint32), grads[bad[:5]])

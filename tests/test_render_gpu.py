@@ -105,8 +105,9 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
     oracle.orc_composite(n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, o_rgba2.ctypes.data, o_dep2.ctypes.data, o_pay.ctypes.data, o_in.ctypes.data,
                          out.ctypes.data, 4, n_steps, 2, 3, H.f32(0.01))
     d_rgba2, d_dep2 = H.dev_zeros(n_alive * 16, cuda), H.dev_zeros(n_alive * 4, cuda)
+    d_out = H.to_dev(out, cuda)
     check(ngp.ngp_hip_composite(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_rgba2.data_ptr(), d_dep2.data_ptr(), d_pay2.data_ptr(), d_in.data_ptr(),
-                                H.to_dev(out, cuda).data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
+                                d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
     g_pay3 = H.to_host(d_pay2, H.PAYLOAD)
     same = g_pay3["alive"] == o_pay["alive"][:n_alive]
     assert same.mean() > 0.99  # termination is a float threshold; allow a hair of disagreement
@@ -127,7 +128,8 @@ def test_shade_accumulate_tonemap(ngp, oracle, cuda):
         fb, db = rs.rand(npx, 4).astype(np.float32), rs.rand(npx).astype(np.float32)
         d_fb, d_db = H.to_dev(fb, cuda), H.to_dev(db, cuda)
         oracle.orc_shade(n_hit, rgba.ctypes.data, depth.ctypes.data, pay.ctypes.data, linear, fb.ctypes.data, db.ctypes.data)
-        check(ngp.ngp_hip_shade(None, n_hit, H.to_dev(rgba, cuda).data_ptr(), H.to_dev(depth, cuda).data_ptr(), H.to_dev(pay, cuda).data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr()))
+        d_rgba, d_depth, d_pay = H.to_dev(rgba, cuda), H.to_dev(depth, cuda), H.to_dev(pay, cuda)
+        check(ngp.ngp_hip_shade(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr()))
         np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-4, atol=1e-6)
         np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
     for cs in (0, 1):
@@ -135,7 +137,8 @@ def test_shade_accumulate_tonemap(ngp, oracle, cuda):
         d_acc = H.to_dev(acc, cuda)
         for spp in (0.0, 3.0):
             oracle.orc_accumulate(res.ctypes.data, fb.ctypes.data, acc.ctypes.data, H.f32(spp), cs)
-            check(ngp.ngp_hip_accumulate(None, res.ctypes.data, H.to_dev(fb, cuda).data_ptr(), d_acc.data_ptr(), H.f32(spp), cs))
+            d_fb2 = H.to_dev(fb, cuda)
+            check(ngp.ngp_hip_accumulate(None, res.ctypes.data, d_fb2.data_ptr(), d_acc.data_ptr(), H.f32(spp), cs))
         np.testing.assert_allclose(H.to_host(d_acc, np.float32).reshape(npx, 4), acc, rtol=2e-4, atol=1e-6)
         bg = np.array([0.1, 0.3, 0.6, 0.8], np.float32)
         for curve in (0, 1, 2, 3):
@@ -151,6 +154,7 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     """render_nerf (testbed_nerf.cu:2354-2500) driven from Python over the C ABI vs orc_render_nerf on a small frame."""
     desc = H.make_desc(ngp, log2_hashmap_size=14)
     params = H.random_params(desc, seed=3, grid_amp=2.0, mlp_gain=2.0)
+    params[2048:2048 + 64] *= 6.0  # density logit row of W2: make the blobs opaque enough to terminate rays
     cam, focal, res, sc = _camera()
     aabb = H.unit_aabb()
     grid = H.blob_density_grid(1)

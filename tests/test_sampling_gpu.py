@@ -93,8 +93,8 @@ def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):
     mlp = (rs.randn(n) * 3.0).astype(np.float16)
     ref = np.zeros(G3, np.float32)
     oracle.orc_splat_grid_samples_max(n, idx.ctypes.data, mlp.ctypes.data, ref.ctypes.data, 3)
-    d_out = H.dev_zeros(G3 * 4, cuda)
-    check(ngp.ngp_hip_splat_grid_samples_max(None, n, H.to_dev(idx, cuda).data_ptr(), H.to_dev(mlp, cuda).data_ptr(), d_out.data_ptr(), 3))
+    d_out, d_idx, d_mlp = H.dev_zeros(G3 * 4, cuda), H.to_dev(idx, cuda), H.to_dev(mlp, cuda)  # keep the device buffers referenced
+    check(ngp.ngp_hip_splat_grid_samples_max(None, n, d_idx.data_ptr(), d_mlp.data_ptr(), d_out.data_ptr(), 3))
     np.testing.assert_allclose(H.to_host(d_out, np.float32), ref, rtol=1e-5)  # __expf vs expf
 
 
