@@ -552,10 +552,15 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 		const float eff = lr / (sqrtf(sm) + epsilon);
 		const float nw = w - eff * fm;
 		master[i] = nw;
-		p16 = (half_t)nw;
+		// the fp32 value must be rounded to fp32 BEFORE the fp16 conversion: without the barrier the compiler folds the last
+		// multiply into v_fma_mixlo_f16 (one rounding instead of two) and ties round differently from a plain CPU evaluation
+		float nw_rounded = nw;
+		asm volatile("" : "+v"(nw_rounded));
+		p16 = (half_t)nw_rounded;
 		params[i] = p16;
 	}
-	const float filtered = (ema[i] * ema_decay * ema_debias_old + (float)p16 * (1.0f - ema_decay)) * ema_debias_new;
+	float filtered = (ema[i] * ema_decay * ema_debias_old + (float)p16 * (1.0f - ema_decay)) * ema_debias_new;
+	asm volatile("" : "+v"(filtered));
 	ema[i] = filtered;
 	inference[i] = (half_t)filtered;
 }

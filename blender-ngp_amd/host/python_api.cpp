@@ -97,6 +97,21 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })
 		.def("params_ptr", [](Testbed& t) { return (uintptr_t)t.m_params.data(); })
 		.def("sync", &Testbed::sync)
+		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
+		.def("set_profiling", [](Testbed& t, bool on) { t.m_profile_enabled = on; })
+		.def("reset_profile", &Testbed::reset_profile)
+		.def("profile", [](Testbed& t) {
+				t.sync();
+				t.profile_collect();
+				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep"};
+				py::dict d;
+				for (int k = 0; k < Testbed::PK_COUNT; ++k) {
+					py::dict e;
+					e["ms"] = t.m_prof[k].ms; e["launches"] = t.m_prof[k].launches; e["units"] = t.m_prof[k].units;
+					d[names[k]] = e;
+				}
+				return d;
+			})
 		.def_readwrite("shall_train", &Testbed::m_train)
 		.def_readwrite("exposure", &Testbed::m_exposure)
 		.def_readwrite("snap_to_pixel_centers", &Testbed::m_snap_to_pixel_centers)

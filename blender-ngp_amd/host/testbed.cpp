@@ -178,6 +178,48 @@ void Testbed::check(int rc, const char* what) {
 }
 void Testbed::sync() { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
 
+// ---- live kernel timing ----------------------------------------------------------------------------------------
+void* Testbed::prof_event() {
+	if (!m_prof_event_pool.empty()) { void* e = m_prof_event_pool.back(); m_prof_event_pool.pop_back(); return e; }
+	hipEvent_t e;
+	HIP_CHECK_THROW(hipEventCreate(&e));
+	return e;
+}
+void Testbed::profile_begin(int k) {
+	if (!m_profile_enabled) return;
+	ProfPending p{k, prof_event(), nullptr, 0};
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)m_stream));
+	m_prof_pending.push_back(p);
+}
+void Testbed::profile_end(int k, uint64_t units) {
+	if (!m_profile_enabled) return;
+	for (auto it = m_prof_pending.rbegin(); it != m_prof_pending.rend(); ++it) {
+		if (it->k == k && !it->e1) {
+			it->e1 = prof_event();
+			it->units = units;
+			HIP_CHECK_THROW(hipEventRecord((hipEvent_t)it->e1, (hipStream_t)m_stream));
+			return;
+		}
+	}
+}
+void Testbed::profile_collect() {
+	for (auto& p : m_prof_pending) {
+		if (p.e0 && p.e1) {
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, (hipEvent_t)p.e0, (hipEvent_t)p.e1) == hipSuccess) {
+				m_prof[p.k].ms += ms; m_prof[p.k].launches += 1; m_prof[p.k].units += p.units;
+			}
+		}
+		if (p.e0) m_prof_event_pool.push_back(p.e0);
+		if (p.e1) m_prof_event_pool.push_back(p.e1);
+	}
+	m_prof_pending.clear();
+}
+void Testbed::reset_profile() {
+	profile_collect();
+	for (auto& a : m_prof) a = ProfAccum{};
+}
+
 void Testbed::reset_camera() {  // testbed.cu:283-299
 	m_fov_axis = 1;
 	set_fov(50.625f);
@@ -406,6 +448,7 @@ void Testbed::train(uint32_t batch_size) {  // testbed.cu:2527-2587
 	auto start = std::chrono::steady_clock::now();
 	train_nerf(batch_size, get_loss_scalar);
 	sync();
+	if (m_profile_enabled) profile_collect();
 	m_stats.training_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 }
 
@@ -413,8 +456,11 @@ void Testbed::training_prep_nerf(uint32_t) {  // testbed_nerf.cu:3388-3401
 	if (m_nerf.training.n_images_for_training == 0) return;
 	const float alpha = m_nerf.training.density_grid_decay;
 	const uint32_t n_cascades = m_nerf.max_cascade + 1;
+	profile_begin(PK_GRID_PREP);
+	const uint32_t n_grid_samples = m_training_step < 256 ? GRID_CELLS * n_cascades : GRID_CELLS / 2 * n_cascades;
 	if (m_training_step < 256) update_density_grid_nerf(alpha, GRID_CELLS * n_cascades, 0);
 	else update_density_grid_nerf(alpha, GRID_CELLS / 4 * n_cascades, GRID_CELLS / 4 * n_cascades);
+	profile_end(PK_GRID_PREP, n_grid_samples);
 }
 
 void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {  // testbed_nerf.cu:2761-2842
@@ -508,9 +554,11 @@ float Testbed::local_loss_sum() {
 
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
 	++m_optimizer_step;
+	profile_begin(PK_OPTIMIZER);
 	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, NGP_MLP_N_PARAMS, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
 	                             m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
 	                             m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>()), "optimizer_step");
+	profile_end(PK_OPTIMIZER, m_n_params);
 	// tcnn ExponentialDecay::step: after the nested step, lr *= decay_base whenever the step count hits start + k * interval
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
 		m_learning_rate *= m_decay_base;
@@ -579,24 +627,34 @@ void Testbed::train_nerf_step(uint32_t target_batch_size) {  // testbed_nerf.cu:
 	const int32_t dist_res[2] = {32, 32};
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
 	m_ray_counter.memset(0, m_stream);
+	profile_begin(PK_GEN_SAMPLES);
 	check(ngp_hip_generate_training_samples(m_stream, R, &m_aabb, max_inference, m_rng.state, m_rng.inc, m_ray_counter.as<uint32_t>(), c.numsteps_counter.as<uint32_t>(),
 	                                        m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training,
 	                                        tr.dataset.metadata_gpu.as<NgpImageMeta>(), tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
 	                                        m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0, m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res,
 	                                        ray_offset, n_rays_global), "generate_training_samples");
+	profile_end(PK_GEN_SAMPLES, R);
 	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256)
+	profile_begin(PK_INFERENCE);
 	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
+	profile_end(PK_INFERENCE, max_inference);
+	profile_begin(PK_LOSS);
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, m_ray_counter.as<uint32_t>(), LOSS_SCALE, OUT_STRIDE, m_background_color,
 	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance), "compute_loss");
+	profile_end(PK_LOSS, R);
 	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
 	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
+	profile_begin(PK_FORWARD);
 	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
+	profile_end(PK_FORWARD, target_batch_size);
+	profile_begin(PK_BACKWARD);
 	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
+	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();
 }
 

@@ -254,6 +254,16 @@ public:
 	RenderBuffer m_windowless_render_surface;
 	uint64_t m_render_samples_evaluated = 0;          // network samples of the last render_to_cpu (for MP/s + roofline accounting)
 
+	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
+	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
+	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
+	bool m_profile_enabled = false;
+	ProfAccum m_prof[PK_COUNT];
+	void reset_profile();
+	void profile_begin(int k);
+	void profile_end(int k, uint64_t units);
+	void profile_collect();                            // after a stream sync: fold pending event pairs into m_prof
+
 	// network + optimizer state
 	NgpNetDesc m_desc{};
 	DeviceBuffer m_desc_gpu, m_params, m_inference_params, m_master, m_first_moments, m_second_moments, m_ema, m_grads;
@@ -280,6 +290,10 @@ private:
 	DeviceBuffer m_loss_scalar_gpu;
 	// tracer scratch (NerfTracer::enlarge 2270-2295)
 	DeviceBuffer m_tr_payload[2], m_tr_rgba[2], m_tr_depth[2], m_tr_hit_payload, m_tr_hit_rgba, m_tr_hit_depth, m_tr_net_in, m_tr_net_out, m_tr_counters;
+	struct ProfPending { int k; void* e0; void* e1; uint64_t units; };
+	std::vector<ProfPending> m_prof_pending;
+	std::vector<void*> m_prof_event_pool;
+	void* prof_event();
 	void check(int rc, const char* what);
 	void optimizer_step();
 	void update_after_training(uint32_t target_batch_size, uint32_t counter, uint32_t compacted_counter, bool get_loss_scalar, float loss_sum);

@@ -188,6 +188,12 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
                                double* grads_out, uint16_t* dL_dx_out /* [n][32] or NULL */) {
 	const uint32_t np = orc_net_n_params(net);
 	for (uint32_t k = 0; k < np; ++k) grads_out[k] = 0.0;
+	/* samples are independent; MLP weight gradients are accumulated per thread and merged, grid gradients with atomics
+	 * (double accumulation: the summation order does not matter at the tolerances the tests use) */
+	#pragma omp parallel
+	{
+	double* mlp_acc = (double*)calloc(GRID_OFF, sizeof(double));
+	#pragma omp for schedule(static)
 	for (uint32_t i = 0; i < n; ++i) {
 		const float* coord = coords + (size_t)i * coord_stride_floats;
 		orc_act a;
@@ -208,7 +214,7 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
 
 		/* weight gradients dW[o][i] += dy[o] * x[i] */
 #define WGRAD(OFF, NOUT, NIN, DY, X) \
-		for (uint32_t o = 0; o < (NOUT); ++o) { float dy_ = orc_h2f((DY)[o]); if (dy_ != 0.0f) for (uint32_t k = 0; k < (NIN); ++k) grads_out[(OFF) + o * (NIN) + k] += (double)(dy_ * orc_h2f((X)[k])); }
+		for (uint32_t o = 0; o < (NOUT); ++o) { float dy_ = orc_h2f((DY)[o]); if (dy_ != 0.0f) for (uint32_t k = 0; k < (NIN); ++k) mlp_acc[(OFF) + o * (NIN) + k] += (double)(dy_ * orc_h2f((X)[k])); }
 		WGRAD(W5_OFF, 16, 64, d_out, a.h3)
 		WGRAD(W4_OFF, 64, 64, d_h3, a.h2)
 		WGRAD(W3_OFF, 64, 32, d_h2, a.in_rgb)
@@ -235,10 +241,17 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
 				}
 				uint32_t gi = orc_grid_index(lv, c[0], c[1], c[2]);
 				size_t k = GRID_OFF + 2u * ((size_t)lv->offset + gi);
-				grads_out[k + 0] += (double)orc_rh(w * g0);
-				grads_out[k + 1] += (double)orc_rh(w * g1);
+				const double a0 = (double)orc_rh(w * g0), a1 = (double)orc_rh(w * g1);
+				#pragma omp atomic
+				grads_out[k + 0] += a0;
+				#pragma omp atomic
+				grads_out[k + 1] += a1;
 			}
 		}
+	}
+	#pragma omp critical
+	for (uint32_t k = 0; k < GRID_OFF; ++k) grads_out[k] += mlp_acc[k];
+	free(mlp_acc);
 	}
 }
 
