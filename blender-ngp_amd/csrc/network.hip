@@ -334,6 +334,7 @@ __device__ __forceinline__ void scatter_level(const NgpGridLevel lv, h2* __restr
 }
 
 // Backward kernel: recompute forward from the saved encoding, dgrad chain, grid scatter, plane dump.  n % 32 == 0.
+template <int ABLATE> // dev-only ablation switch (bit0: no scatter, bit1: no plane stores); the product path launches <0>
 __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                             const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                             const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
@@ -374,9 +375,9 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 		h8 dh[4];
 		dh[0] = mask_delta(t0, 0, a.h3[0]); dh[1] = mask_delta(t0, 1, a.h3[1]);
 		dh[2] = mask_delta(t1, 0, a.h3[2]); dh[3] = mask_delta(t1, 1, a.h3[3]);
-		store_plane(planes, n, P_DOUT, MAP_CH, 0, g, s, dout);
+		if (!(ABLATE & 2)) store_plane(planes, n, P_DOUT, MAP_CH, 0, g, s, dout);
 #pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H3, MAP_HID, kb, g, s, a.h3[kb]); store_plane(planes, n, P_DH3, MAP_HID, kb, g, s, dh[kb]); }
+		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H3, MAP_HID, kb, g, s, a.h3[kb]); store_plane(planes, n, P_DH3, MAP_HID, kb, g, s, dh[kb]); } }
 
 		// hidden layer: d_h2 = relu'(h2) * (W4^T d_h3)
 		t0 = zero; t1 = zero;
@@ -388,9 +389,9 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
 		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
 #pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, P_DH2, MAP_HID, kb, g, s, dh[kb]); }
-		store_plane(planes, n, P_RIN, MAP_RGBIN, 0, g, s, a.rin[0]);
-		store_plane(planes, n, P_RIN, MAP_RGBIN, 1, g, s, a.rin[1]);
+		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, P_DH2, MAP_HID, kb, g, s, dh[kb]); } }
+		if (!(ABLATE & 2)) store_plane(planes, n, P_RIN, MAP_RGBIN, 0, g, s, a.rin[0]);
+		if (!(ABLATE & 2)) store_plane(planes, n, P_RIN, MAP_RGBIN, 1, g, s, a.rin[1]);
 
 		// input layer of the rgb net: d_in = W3^T d_h2 (rows 0..15 = density-net output gradient)
 		t0 = zero;
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 #pragma unroll
 		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
 		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
-		store_plane(planes, n, P_DDENS, MAP_RGBIN, 0, g, s, dden);
+		if (!(ABLATE & 2)) store_plane(planes, n, P_DDENS, MAP_RGBIN, 0, g, s, dden);
 
 		// density net: d_h1 = relu'(h1) * (W2^T d_dens);  d_x = W1^T d_h1
 		t0 = NGP_MFMA(lt[(T_W2T + 0) * 64 + lane], dden, zero);
@@ -408,9 +409,9 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
 		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
 #pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, P_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, P_DH1, MAP_HID, kb, g, s, dh[kb]); }
-		store_plane(planes, n, P_X, MAP_ENC, 0, g, s, x0);
-		store_plane(planes, n, P_X, MAP_ENC, 1, g, s, x1);
+		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, P_DH1, MAP_HID, kb, g, s, dh[kb]); } }
+		if (!(ABLATE & 2)) store_plane(planes, n, P_X, MAP_ENC, 0, g, s, x0);
+		if (!(ABLATE & 2)) store_plane(planes, n, P_X, MAP_ENC, 1, g, s, x1);
 
 		t0 = zero;
 #pragma unroll
@@ -423,8 +424,8 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 			const float ga0 = (float)(half_t)t0[4 * q + 0], ga1 = (float)(half_t)t0[4 * q + 1];
 			const float gb0 = (float)(half_t)t0[4 * q + 2], gb1 = (float)(half_t)t0[4 * q + 3];
 			const int lvl = 4 * q + 2 * g;
-			scatter_level(desc->levels[lvl], grid_grad, px, py, pz, ga0, ga1);
-			scatter_level(desc->levels[lvl + 1], grid_grad, px, py, pz, gb0, gb1);
+			if (!(ABLATE & 1)) scatter_level(desc->levels[lvl], grid_grad, px, py, pz, ga0, ga1);
+			if (!(ABLATE & 1)) scatter_level(desc->levels[lvl + 1], grid_grad, px, py, pz, gb0, gb1);
 		}
 	}
 }
@@ -659,8 +660,12 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	float* partials = (float*)((char*)scratch + (uint64_t)N_PLANE_ROWS * n * 2u);
 	// EGradientMode::Overwrite: the scatter target starts from zero every step
 	NGP_HIP_TRY(hipMemsetAsync(grads + NGP_MLP_N_PARAMS, 0, (size_t)desc_host->n_grid_entries * 2u * sizeof(uint16_t), st));
-	hipLaunchKernelGGL(nerf_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n,
-	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, (half_t*)grads, planes);
+	const char* abl = getenv("NGP_HIP_BWD_ABLATE"); // dev-only timing ablations (tools/microbench.py); unset in production
+	const int ablate = abl ? atoi(abl) : 0;
+#define NGP_LAUNCH_BWD(A) hipLaunchKernelGGL(nerf_backward_kernel<A>, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, \
+	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, (half_t*)grads, planes)
+	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
+#undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
