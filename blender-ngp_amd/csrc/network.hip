@@ -319,26 +319,90 @@ __device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8
 	return r;
 }
 
-__device__ __forceinline__ void scatter_level(const NgpGridLevel lv, h2* __restrict__ grid_grad, float px, float py, float pz, float g0, float g1) {
-	const LevelPos p = level_pos(lv, px, py, pz);
+// ----------------------------------------------------------------------------------------------------------------
+// Hash-grid backward WITHOUT global atomics ("owner computes").
+// Measured on MI355X (tools/atomic_probe.hip): scattered global atomics cap at ~21 Gop/s chip-wide whatever the footprint or the
+// XCD locality, LDS atomics reach ~190 Gop/s and cost no HBM traffic.  tcnn's formulation (one atomicAdd(half2) per sample x level x
+// corner, 33.5 M per step) therefore costs ~2.4 ms here.  Instead every workgroup OWNS a slice of one level's table (<= 32768
+// entries = 128 KiB of LDS as half2), scans the samples of its chunk, recomputes the 8 corner indices of its level and
+// accumulates only the corners that fall into its slice with ds_pk_add_f16.  Small (dense) levels, which are heavily contended,
+// are additionally split over sample chunks (K private copies) and summed by grid_combine_kernel.  No global atomic, no memset of
+// the gradient table (every entry is written exactly once by the combine pass).
+constexpr uint32_t GB_SLICE = 32768;       // entries per LDS slice
+constexpr uint32_t GB_ITEMS = 32;          // work items per level (slices x sample chunks)
+
+struct GbSplit { uint32_t n_slices, k_chunks; };
+__host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
+	GbSplit s;
+	s.n_slices = (level_size + GB_SLICE - 1) / GB_SLICE;
+	s.k_chunks = GB_ITEMS / s.n_slices;
+	if (s.k_chunks < 1) s.k_chunks = 1;
+	return s;
+}
+
+// grid (GB_ITEMS, 16 levels), block 1024.  dx planes: [level][sample] half2.  partials: [(level*GB_ITEMS + item)][GB_SLICE] half2.
+__global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                             const h2* __restrict__ dx_planes, h2* __restrict__ partials) {
+	__shared__ h2 slice[GB_SLICE];
+	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	const NgpGridLevel lv = desc->levels[level];
+	const GbSplit sp = gb_split(lv.size);
+	if (item >= sp.n_slices * sp.k_chunks) return;
+	const uint32_t sl = item % sp.n_slices, chunk = item / sp.n_slices;
+	const uint32_t lo = sl * GB_SLICE;
+	const uint32_t cnt = (lv.size - lo) < GB_SLICE ? (lv.size - lo) : GB_SLICE;
+	const h2 zero2 = {(half_t)0.0f, (half_t)0.0f};
+	for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) slice[i] = zero2;
+	__syncthreads();
+	const uint32_t s_begin = (uint32_t)(((uint64_t)n * chunk) / sp.k_chunks), s_end = (uint32_t)(((uint64_t)n * (chunk + 1)) / sp.k_chunks);
+	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
+	for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
+		const h2 gq = dxl[s];
+		const float g0 = (float)gq[0], g1 = (float)gq[1];
+		if (g0 == 0.0f && g1 == 0.0f) continue;  // adding +-0 never changes a sum
+		const float* c = coords + (size_t)s * coord_stride;
+		const LevelPos p = level_pos(lv, c[0], c[1], c[2]);
 #pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		float w = (c & 1) ? p.fx : (1.0f - p.fx);
-		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
-		w *= ((c >> 2) & 1) ? p.fz : (1.0f - p.fz);
-		const uint32_t idx = grid_index(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
-		h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);
-		h2* dst = (h2*)((char*)grid_grad + (size_t)((lv.offset + idx) * 4u));
-		__builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2*)dst, val);
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t idx = grid_index(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1));
+			const uint32_t rel = idx - lo;
+			if (rel < cnt) {
+				float w = (k & 1) ? p.fx : (1.0f - p.fx);
+				w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
+				w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+				h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);   // tcnn kernel_grid_backward: half2(w * dL/dx)
+				__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rel], val);
+			}
+		}
+	}
+	__syncthreads();
+	h2* __restrict__ dst = partials + (size_t)(level * GB_ITEMS + item) * GB_SLICE;
+	for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = slice[i];
+}
+
+// sums the K chunk-copies of every entry in fp32 and writes the fp16 gradient table (each entry exactly once)
+__global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __restrict__ desc, const h2* __restrict__ partials, h2* __restrict__ grid_grad) {
+	const uint32_t level = blockIdx.y;
+	const NgpGridLevel lv = desc->levels[level];
+	const GbSplit sp = gb_split(lv.size);
+	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.size; e += gridDim.x * blockDim.x) {
+		const uint32_t sl = e / GB_SLICE, rel = e % GB_SLICE;
+		float a0 = 0.0f, a1 = 0.0f;
+		for (uint32_t c = 0; c < sp.k_chunks; ++c) {
+			const h2 v = partials[(size_t)(level * GB_ITEMS + c * sp.n_slices + sl) * GB_SLICE + rel];
+			a0 += (float)v[0]; a1 += (float)v[1];
+		}
+		h2 o; o[0] = (half_t)a0; o[1] = (half_t)a1;
+		grid_grad[lv.offset + e] = o;
 	}
 }
 
-// Backward kernel: recompute forward from the saved encoding, dgrad chain, grid scatter, plane dump.  n % 32 == 0.
-template <int ABLATE> // dev-only ablation switch (bit0: no scatter, bit1: no plane stores); the product path launches <0>
+// Backward kernel: recompute forward from the saved encoding, dgrad chain, dL/dx planes + activation planes.  n % 32 == 0.
+template <int ABLATE> // dev-only ablation switch (bit0: no dL/dx store, bit1: no plane stores); the product path launches <0>
 __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                             const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                             const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
-                                                            half_t* __restrict__ grads, half_t* __restrict__ planes) {
+                                                            h2* __restrict__ dx_planes, half_t* __restrict__ planes) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
 
@@ -346,7 +410,6 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 	const uint32_t n_tiles = n / 32;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-	h2* __restrict__ grid_grad = (h2*)(grads + GRID_OFF);
 	const f32x16 zero = {};
 
 	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
@@ -418,14 +481,17 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W1T + kb) * 64 + lane], dh[kb], t0);
 
 		// t0 row = x feature (r&3)+8(r>>2)+4g  =>  this lane owns levels 4q+2g (regs 4q,4q+1) and 4q+2g+1 (regs 4q+2,4q+3), q = 0..3.
-		// tcnn kernel_grid_backward: grad[idx] += half2(w * dL/dx) with dL/dx in fp16.
+		// dL/dx goes out in fp16 as per-level planes [level][sample] (coalesced 128 B per half-wave) for grid_backward_kernel.
+		if (!(ABLATE & 1)) {
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const float ga0 = (float)(half_t)t0[4 * q + 0], ga1 = (float)(half_t)t0[4 * q + 1];
-			const float gb0 = (float)(half_t)t0[4 * q + 2], gb1 = (float)(half_t)t0[4 * q + 3];
-			const int lvl = 4 * q + 2 * g;
-			if (!(ABLATE & 1)) scatter_level(desc->levels[lvl], grid_grad, px, py, pz, ga0, ga1);
-			if (!(ABLATE & 1)) scatter_level(desc->levels[lvl + 1], grid_grad, px, py, pz, gb0, gb1);
+			for (int q = 0; q < 4; ++q) {
+				const int lvl = 4 * q + 2 * g;
+				h2 a, b;
+				a[0] = (half_t)t0[4 * q + 0]; a[1] = (half_t)t0[4 * q + 1];
+				b[0] = (half_t)t0[4 * q + 2]; b[1] = (half_t)t0[4 * q + 3];
+				dx_planes[(size_t)lvl * n + s] = a;
+				dx_planes[(size_t)(lvl + 1) * n + s] = b;
+			}
 		}
 	}
 }
@@ -646,8 +712,12 @@ static uint32_t wgrad_chunks(uint32_t n) {
 	return n / chunk_len;
 }
 
+// scratch layout: [activation planes 480 x n fp16][wgrad partials chunks x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 32 x 32768 half2]
+static uint64_t scratch_off_wgrad(uint32_t n) { return (uint64_t)N_PLANE_ROWS * n * 2u; }
+static uint64_t scratch_off_dx(uint32_t n) { return scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_MLP_N_PARAMS * 4u; }
+static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) {
-	return (uint64_t)N_PLANE_ROWS * n * 2u + (uint64_t)wgrad_chunks(n) * NGP_MLP_N_PARAMS * 4u;
+	return scratch_off_gb(n) + (uint64_t)16 * GB_ITEMS * GB_SLICE * 4u;
 }
 
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
@@ -657,16 +727,24 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
 	half_t* planes = (half_t*)scratch;
-	float* partials = (float*)((char*)scratch + (uint64_t)N_PLANE_ROWS * n * 2u);
-	// EGradientMode::Overwrite: the scatter target starts from zero every step
-	NGP_HIP_TRY(hipMemsetAsync(grads + NGP_MLP_N_PARAMS, 0, (size_t)desc_host->n_grid_entries * 2u * sizeof(uint16_t), st));
+	float* partials = (float*)((char*)scratch + scratch_off_wgrad(n));
+	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
+	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
+	(void)desc_host;
 	const char* abl = getenv("NGP_HIP_BWD_ABLATE"); // dev-only timing ablations (tools/microbench.py); unset in production
 	const int ablate = abl ? atoi(abl) : 0;
 #define NGP_LAUNCH_BWD(A) hipLaunchKernelGGL(nerf_backward_kernel<A>, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, \
-	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, (half_t*)grads, planes)
+	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes)
 	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
 #undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
+	// EGradientMode::Overwrite: the combine pass writes every table entry exactly once (no memset, no global atomics)
+	if (!(ablate & 4)) {
+		hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials);
+		NGP_LAUNCH_CHECK("grid_backward_kernel");
+		hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_MLP_N_PARAMS));
+		NGP_LAUNCH_CHECK("grid_combine_kernel");
+	}
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
