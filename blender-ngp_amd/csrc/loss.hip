@@ -3,7 +3,13 @@
 // tcnn's fill_rollover / fill_rollover_and_rescale (call sites 3314-3322).
 // Default-off branches (envmap, error-map CDF sampling, sharpness, depth supervision, exposure gradient: testbed.h:651-680)
 // are not implemented; the always-on error-map deposit (1465-1491) is.
-// The compaction slot of a ray comes from one wave-aggregated atomic (wave64 scan) instead of one atomic per ray (1434).
+//
+// MI355X mapping: the reference runs ONE THREAD PER RAY walking its samples three times — ~16 k threads on a 131 k-thread
+// chip, every load uncoalesced.  Here ONE WAVE owns a ray: lane j holds sample j (64 per chunk), the transmittance is a
+// wave-wide exclusive prefix PRODUCT, the colour integrals are wave reductions / prefix sums, all sample loads and the
+// compacted stores are coalesced, and the 16 rays of a workgroup share ONE atomic for their compaction slots.
+// The transmittance product is therefore associated as a scan tree instead of left-to-right: counts that hinge on
+// `T < 1e-4` can differ from a sequential evaluation only when T is within rounding of the threshold.
 #include "ngp_device.cuh"
 
 namespace ngp {
@@ -44,40 +50,83 @@ struct LossArgs {
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) compute_loss_kernel(const LossArgs a) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	const bool active = i < *a.rays_counter;
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+// inclusive prefix over the wave: OP 0 = product, 1 = sum
+template <int OP>
+__device__ __forceinline__ float wave_inclusive(float v, uint32_t lane) {
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const float nb = __shfl_up(v, off, 64);
+		if (lane >= (uint32_t)off) v = OP == 0 ? v * nb : v + nb;
+	}
+	return v;
+}
 
-	uint32_t numsteps = 0, base = 0, compacted_numsteps = 0;
-	float T = 1.f;
-	float rgb_ray[3] = {0.f, 0.f, 0.f};
-	v3 ray_o = mk(0, 0, 0);
+constexpr int LOSS_RAYS_PER_BLOCK = 16;
+
+__global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(const LossArgs a) {
+	__shared__ uint32_t s_counts[LOSS_RAYS_PER_BLOCK];
+	__shared__ uint32_t s_block_base;
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t i = blockIdx.x * LOSS_RAYS_PER_BLOCK + w;  // ray slot
+	const bool active = i < *a.rays_counter;                  // wave-uniform
 	const float EPSILON = 1e-4f;
+
+	uint32_t numsteps = 0, base = 0, compacted = 0;
+	float T_final = 1.f;
+	float rgb_ray[3] = {0.f, 0.f, 0.f};
 	if (active) {
 		numsteps = a.numsteps_in[i * 2 + 0];
 		base = a.numsteps_in[i * 2 + 1];
-		ray_o = ld3(a.rays_in[i].o);
-		const NgpCoord* ci = a.coords_in + base;
-		const uint16_t* no = a.network_output + (size_t)base * a.mlp_stride;
-		for (; compacted_numsteps < numsteps; ++compacted_numsteps) {
-			if (T < EPSILON) break;
-			const us4 lo = *(const us4*)(no + (size_t)compacted_numsteps * a.mlp_stride);
-			const float dt = unwarp_dt(ci[compacted_numsteps].dt);
-			const float density = network_to_density(h2f(lo[3]), a.density_activation);
-			const float alpha = 1.f - __expf(-density * dt);
-			const float weight = alpha * T;
-			rgb_ray[0] += weight * network_to_rgb(h2f(lo[0]), a.rgb_activation);
-			rgb_ray[1] += weight * network_to_rgb(h2f(lo[1]), a.rgb_activation);
-			rgb_ray[2] += weight * network_to_rgb(h2f(lo[2]), a.rgb_activation);
-			T *= (1.f - alpha);
+	}
+	const NgpCoord* __restrict__ ci = a.coords_in + base;
+	const uint16_t* __restrict__ no = a.network_output + (size_t)base * a.mlp_stride;
+
+	// ---- pass 1: transmittance, ray colour, number of samples before T < EPSILON (1341-1374)
+	{
+		float T_carry = 1.f;
+		bool done = false;
+		for (uint32_t c0 = 0; c0 < numsteps && !done; c0 += 64) {
+			const uint32_t j = c0 + lane;
+			const bool valid = j < numsteps;
+			float alpha = 0.f, rgb[3] = {0.f, 0.f, 0.f};
+			if (valid) {
+				const us4 lo = *(const us4*)(no + (size_t)j * a.mlp_stride);
+				const float dt = unwarp_dt(ci[j].dt);
+				alpha = 1.f - __expf(-network_to_density(h2f(lo[3]), a.density_activation) * dt);
+				rgb[0] = network_to_rgb(h2f(lo[0]), a.rgb_activation);
+				rgb[1] = network_to_rgb(h2f(lo[1]), a.rgb_activation);
+				rgb[2] = network_to_rgb(h2f(lo[2]), a.rgb_activation);
+			}
+			const float incl = wave_inclusive<0>(1.f - alpha, lane);
+			float excl = __shfl_up(incl, 1, 64);
+			if (lane == 0) excl = 1.f;
+			const float T_before = T_carry * excl;
+			const bool include = valid && !(T_before < EPSILON);
+			const float weight = include ? alpha * T_before : 0.f;
+			rgb_ray[0] += wave_sum(weight * rgb[0]);
+			rgb_ray[1] += wave_sum(weight * rgb[1]);
+			rgb_ray[2] += wave_sum(weight * rgb[2]);
+			const uint32_t n_inc = (uint32_t)__popcll(__ballot(include));
+			const uint32_t n_valid = numsteps - c0 < 64 ? numsteps - c0 : 64;
+			compacted += n_inc;
+			if (n_inc < n_valid) done = true;
+			T_carry = T_carry * __shfl(incl, 63, 64);
 		}
+		T_final = T_carry;
 	}
 
-	// target colour: replay the ray generator's draws (1376-1423)
+	// ---- target colour: replay the ray generator's draws (1376-1423); wave-uniform
 	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f;
 	uint32_t img = 0;
 	int32_t img_res[2] = {1, 1};
+	v3 ray_o = mk(0, 0, 0);
 	if (active) {
+		ray_o = ld3(a.rays_in[i].o);
 		const uint32_t ray_idx = a.ray_indices_in[i];
 		Pcg32 rng = a.rng;
 		rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
@@ -121,88 +170,97 @@ __global__ void __launch_bounds__(256) compute_loss_kernel(const LossArgs a) {
 				for (int c = 0; c < 3; ++c) rgbtarget[c] = bg[c];
 			}
 		}
-		if (compacted_numsteps == numsteps) {
+		if (compacted == numsteps) {
 #pragma unroll
-			for (int c = 0; c < 3; ++c) rgb_ray[c] += T * bg[c];
+			for (int c = 0; c < 3; ++c) rgb_ray[c] += T_final * bg[c];
 		}
 	}
 
-	// compaction slots: one atomic per wave (1434)
-	const uint32_t lane = lane_id();
-	const uint32_t incl = wave_inclusive_scan(compacted_numsteps);
-	const uint32_t wave_total = __shfl(incl, 63, 64);
-	uint32_t wave_base = 0;
-	if (lane == 63 && wave_total) wave_base = atomicAdd(a.numsteps_counter, wave_total);
-	wave_base = __shfl(wave_base, 63, 64);
+	// ---- compaction slots: one atomic per workgroup of 16 rays (1434)
+	if (lane == 0) s_counts[w] = compacted;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (int k = 0; k < LOSS_RAYS_PER_BLOCK; ++k) { const uint32_t c = s_counts[k]; s_counts[k] = total; total += c; }
+		s_block_base = total ? atomicAdd(a.numsteps_counter, total) : 0u;
+	}
+	__syncthreads();
 	if (!active) return;
-	const uint32_t compacted_base = wave_base + incl - compacted_numsteps;
+	const uint32_t compacted_base = s_block_base + s_counts[w];
 	const uint32_t room = a.max_samples_compacted - (a.max_samples_compacted < compacted_base ? a.max_samples_compacted : compacted_base);
-	compacted_numsteps = room < compacted_numsteps ? room : compacted_numsteps;
-	a.numsteps_in[i * 2 + 0] = compacted_numsteps;
-	a.numsteps_in[i * 2 + 1] = compacted_base;
-	if (compacted_numsteps == 0) return;
+	compacted = room < compacted ? room : compacted;
+	if (lane == 0) { a.numsteps_in[i * 2 + 0] = compacted; a.numsteps_in[i * 2 + 1] = compacted_base; }
+	if (compacted == 0) return;
 
 	const LG lg = loss_and_gradient(rgbtarget, rgb_ray, a.loss_type);
-	float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
-	if (a.loss_output) a.loss_output[i] = mean_loss / (float)a.n_rays;
-
-	if (a.error_map) {
-		float posx = xy[0] * (float)a.error_map_res[0] - 0.5f, posy = xy[1] * (float)a.error_map_res[1] - 0.5f;
-		posx = fminf(fmaxf(posx, 0.0f), (float)a.error_map_res[0] - (1.0f + 1e-4f));
-		posy = fminf(fmaxf(posy, 0.0f), (float)a.error_map_res[1] - (1.0f + 1e-4f));
-		const int pix = (int)posx, piy = (int)posy;
-		const float wx = posx - (float)pix, wy = posy - (float)piy;
-		int ix = pix < img_res[0] - 2 ? pix : img_res[0] - 2; ix = ix > 0 ? ix : 0; // 1470 clamps with the IMAGE resolution
-		int iy = piy < img_res[1] - 2 ? piy : img_res[1] - 2; iy = iy > 0 ? iy : 0;
-		float* em = a.error_map + (size_t)img * (size_t)a.error_map_res[0] * (size_t)a.error_map_res[1];
-		atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix], (1 - wx) * (1 - wy) * mean_loss);
-		atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix + 1], wx * (1 - wy) * mean_loss);
-		atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix], (1 - wx) * wy * mean_loss);
-		atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix + 1], wx * wy * mean_loss);
+	const float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
+	if (lane == 0) {
+		if (a.loss_output) a.loss_output[i] = mean_loss / (float)a.n_rays;
+		if (a.error_map) {
+			float posx = xy[0] * (float)a.error_map_res[0] - 0.5f, posy = xy[1] * (float)a.error_map_res[1] - 0.5f;
+			posx = fminf(fmaxf(posx, 0.0f), (float)a.error_map_res[0] - (1.0f + 1e-4f));
+			posy = fminf(fmaxf(posy, 0.0f), (float)a.error_map_res[1] - (1.0f + 1e-4f));
+			const int pix = (int)posx, piy = (int)posy;
+			const float wx = posx - (float)pix, wy = posy - (float)piy;
+			int ix = pix < img_res[0] - 2 ? pix : img_res[0] - 2; ix = ix > 0 ? ix : 0; // 1470 clamps with the IMAGE resolution
+			int iy = piy < img_res[1] - 2 ? piy : img_res[1] - 2; iy = iy > 0 ? iy : 0;
+			float* em = a.error_map + (size_t)img * (size_t)a.error_map_res[0] * (size_t)a.error_map_res[1];
+			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix], (1 - wx) * (1 - wy) * mean_loss);
+			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix + 1], wx * (1 - wy) * mean_loss);
+			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix], (1 - wx) * wy * mean_loss);
+			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix + 1], wx * wy * mean_loss);
+		}
 	}
 
+	// ---- pass 2: gradients + compacted copies (1498-1556), lanes = samples
 	const float ls = a.loss_scale / (float)a.n_rays;
 	const float output_l2_reg = a.rgb_activation == NGP_ACT_EXPONENTIAL ? 1e-4f : 0.0f;
 	const float output_l1_reg_density = *a.mean_density < MIN_OPTICAL_THICKNESS() ? 1e-4f : 0.0f;
-
-	const NgpCoord* ci = a.coords_in + base;
-	NgpCoord* co = a.coords_out + compacted_base;
-	const uint16_t* no = a.network_output + (size_t)base * a.mlp_stride;
-	uint16_t* dl = a.dloss_doutput + (size_t)compacted_base * a.dl_stride;
-	float rgb_ray2[3] = {0.f, 0.f, 0.f};
-	T = 1.f;
-	for (uint32_t j = 0; j < compacted_numsteps; ++j) {
-		if (a.max_level_rand_training) a.max_level_compacted[compacted_base + j] = max_level;
-		const NgpCoord cin = ci[j];
-		co[j] = cin;
-		const v3 pos = unwarp_position(mk(cin.pos[0], cin.pos[1], cin.pos[2]), a.aabb);
-		const float depth = norm(pos - ray_o);
-		const float dt = unwarp_dt(cin.dt);
-		const us4 lo = *(const us4*)(no + (size_t)j * a.mlp_stride);
-		const float lof[4] = {h2f(lo[0]), h2f(lo[1]), h2f(lo[2]), h2f(lo[3])};
-		float rgb[3];
+	NgpCoord* __restrict__ co = a.coords_out + compacted_base;
+	uint16_t* __restrict__ dl = a.dloss_doutput + (size_t)compacted_base * a.dl_stride;
+	float T_carry = 1.f, acc_carry[3] = {0.f, 0.f, 0.f};
+	for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
+		const uint32_t j = c0 + lane;
+		const bool valid = j < compacted;
+		float alpha = 0.f, rgb[3] = {0.f, 0.f, 0.f}, lof[4] = {0.f, 0.f, 0.f, 0.f}, dt = 0.f, depth = 0.f;
+		if (valid) {
+			const NgpCoord cin = ci[j];
+			co[j] = cin;
+			if (a.max_level_rand_training) a.max_level_compacted[compacted_base + j] = max_level;
+			const v3 pos = unwarp_position(mk(cin.pos[0], cin.pos[1], cin.pos[2]), a.aabb);
+			depth = norm(pos - ray_o);
+			dt = unwarp_dt(cin.dt);
+			const us4 lo = *(const us4*)(no + (size_t)j * a.mlp_stride);
+			lof[0] = h2f(lo[0]); lof[1] = h2f(lo[1]); lof[2] = h2f(lo[2]); lof[3] = h2f(lo[3]);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) rgb[c] = network_to_rgb(lof[c], a.rgb_activation);
-		const float density = network_to_density(lof[3], a.density_activation);
-		const float alpha = 1.f - __expf(-density * dt);
-		const float weight = alpha * T;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) rgb_ray2[c] += weight * rgb[c];
-		T *= (1.f - alpha);
-		float suffix[3];
-#pragma unroll
-		for (int c = 0; c < 3; ++c) suffix[c] = rgb_ray[c] - rgb_ray2[c];
-		us4 out;
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			const float dloss_by_drgb = weight * lg.grad[c];
-			out[c] = f2h(ls * (dloss_by_drgb * network_to_rgb_derivative(lof[c], a.rgb_activation) + fmaxf(0.0f, output_l2_reg * lof[c])));
+			for (int c = 0; c < 3; ++c) rgb[c] = network_to_rgb(lof[c], a.rgb_activation);
+			alpha = 1.f - __expf(-network_to_density(lof[3], a.density_activation) * dt);
 		}
-		const float density_derivative = network_to_density_derivative(lof[3], a.density_activation);
-		const float dotv = lg.grad[0] * (T * rgb[0] - suffix[0]) + lg.grad[1] * (T * rgb[1] - suffix[1]) + lg.grad[2] * (T * rgb[2] - suffix[2]);
-		const float dloss_by_dmlp = density_derivative * (dt * (dotv + 0.0f));
-		out[3] = f2h(ls * dloss_by_dmlp + (lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) + (lof[3] > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f));
-		*(us4*)(dl + (size_t)j * a.dl_stride) = out;
+		const float incl = wave_inclusive<0>(1.f - alpha, lane);
+		float excl = __shfl_up(incl, 1, 64);
+		if (lane == 0) excl = 1.f;
+		const float T_before = T_carry * excl;
+		const float weight = alpha * T_before;
+		const float T = T_before * (1.f - alpha);  // transmittance after this sample (1522)
+		float rgb_ray2[3];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) rgb_ray2[c] = acc_carry[c] + wave_inclusive<1>(weight * rgb[c], lane);
+		if (valid) {
+			us4 out;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float dloss_by_drgb = weight * lg.grad[c];
+				out[c] = f2h(ls * (dloss_by_drgb * network_to_rgb_derivative(lof[c], a.rgb_activation) + fmaxf(0.0f, output_l2_reg * lof[c])));
+			}
+			const float density_derivative = network_to_density_derivative(lof[3], a.density_activation);
+			const float dotv = lg.grad[0] * (T * rgb[0] - (rgb_ray[0] - rgb_ray2[0])) + lg.grad[1] * (T * rgb[1] - (rgb_ray[1] - rgb_ray2[1])) + lg.grad[2] * (T * rgb[2] - (rgb_ray[2] - rgb_ray2[2]));
+			const float dloss_by_dmlp = density_derivative * (dt * (dotv + 0.0f));
+			out[3] = f2h(ls * dloss_by_dmlp + (lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) + (lof[3] > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f));
+			*(us4*)(dl + (size_t)j * a.dl_stride) = out;
+		}
+		T_carry = T_carry * __shfl(incl, 63, 64);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) acc_carry[c] = __shfl(rgb_ray2[c], 63, 64);
 	}
 }
 
@@ -254,7 +312,8 @@ int ngp_hip_compute_loss(
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;
-	hipLaunchKernelGGL(compute_loss_kernel, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
+	// n_rays upper-bounds *rays_counter (the number of ray slots the generator filled); one wave per slot
+	hipLaunchKernelGGL(compute_loss_kernel, dim3(div_up(n_rays, LOSS_RAYS_PER_BLOCK)), dim3(LOSS_RAYS_PER_BLOCK * 64), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("compute_loss_kernel");
 	return 0;
 }

@@ -8,8 +8,12 @@
 // identical to the reference's; only the slot order differs (it is unordered in the reference as well).
 // Index / count arithmetic is exact (-ffp-contract=off): bit-exact against the CPU oracle.
 #include "ngp_device.cuh"
+#include <stdlib.h>
 
 namespace ngp {
+
+// occupied runs a ray may have before the write pass falls back to a serial re-march (LDS: 6 B x 256 threads per run slot)
+#define NGP_MAX_RUNS 24
 
 struct TrainSampleArgs {
 	uint32_t n_rays; Aabb aabb; uint32_t max_samples; Pcg32 rng;
@@ -17,12 +21,18 @@ struct TrainSampleArgs {
 	uint32_t n_training_images; const NgpImageMeta* metadata; const NgpXForm* xforms; const uint8_t* density_grid;
 	int max_level_rand_training; float* max_level_ptr; int snap_to_pixel_centers; int train_envmap; float cone_angle_constant;
 	const float* distortion_data; int32_t distortion_res[2]; uint32_t ray_offset; uint32_t n_rays_global;
+	int dev_variant; // dev-only timing variants (NGP_HIP_GEN_VARIANT): 0 product path, 2 no sample writes, 3 no march
 };
 
 __global__ void __launch_bounds__(256) generate_training_samples_kernel(const TrainSampleArgs a) {
 	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
 	const bool in_range = li < a.n_rays;
 	const uint32_t i = li + a.ray_offset;
+
+	constexpr uint32_t MAX_RUNS = NGP_MAX_RUNS;
+	__shared__ float s_run_t[MAX_RUNS][256];
+	__shared__ uint16_t s_run_n[MAX_RUNS][256];
+	uint32_t n_runs = 0;
 
 	// ---- per-ray setup (dead lanes keep numsteps = 0 and take part in the wave scan)
 	uint32_t numsteps = 0;
@@ -78,15 +88,34 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 			startt += calc_dt(startt, cone_angle) * rng.next_float();
 			idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
 
-			// pass 1: count occupied steps (1204-1219)
+			// pass 1: count occupied steps (1204-1219).  The march is a serial, latency-bound chain (one dependent bitfield byte per
+			// iteration); instead of repeating it for the write pass, the occupied RUNS (start t, length) are recorded in LDS: inside a
+			// run the reference's second pass is exactly `emit at t; t += dt`, so replaying the runs reproduces it bit for bit.
 			uint32_t j = 0;
 			float t = startt;
 			v3 pos;
+			if (a.dev_variant == 3) t = 3.0e38f;
+			uint32_t run_len = 0;   // length of the open run (registers only; LDS is touched once per run)
+			float run_t0 = 0.f;
 			while (aabb_contains(a.aabb, pos = ro + rd * t) && j < NGP_NERF_STEPS) {
 				const float dt = calc_dt(t, cone_angle);
 				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
-				if (density_grid_occupied_at(pos, a.density_grid, mip)) { ++j; t += dt; }
-				else t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+				if (density_grid_occupied_at(pos, a.density_grid, mip)) {
+					if (run_len == 0) run_t0 = t;
+					++run_len;
+					++j; t += dt;
+				} else {
+					if (run_len) {
+						if (n_runs < MAX_RUNS) { s_run_t[n_runs][threadIdx.x] = run_t0; s_run_n[n_runs][threadIdx.x] = (uint16_t)run_len; }
+						++n_runs;
+						run_len = 0;
+					}
+					t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+				}
+			}
+			if (run_len) {
+				if (n_runs < MAX_RUNS) { s_run_t[n_runs][threadIdx.x] = run_t0; s_run_n[n_runs][threadIdx.x] = (uint16_t)run_len; }
+				++n_runs;
 			}
 			numsteps = j;
 			keep = !(j == 0 && !a.train_envmap);
@@ -118,13 +147,77 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 	a.numsteps_out[ray_idx * 2 + 0] = numsteps;
 	a.numsteps_out[ray_idx * 2 + 1] = base;
 
-	// pass 2: write the samples (1239-1253)
+	// pass 2 is a separate, wave-per-ray kernel (expand_training_samples_kernel): this thread only leaves the recipe — start t,
+	// number of runs and the (t0, length) pairs — in the first bytes of the ray's own output slots, which that kernel reads
+	// before it overwrites them.  Every run has >= 1 sample, so the 28 B x numsteps of slots always hold 8 B + 8 B x n_runs.
+	if (numsteps == 0) return;
+	uint32_t* stash = (uint32_t*)(a.coords_out + base);
+	stash[0] = n_runs;
+	stash[1] = __float_as_uint(startt);
+	const uint32_t n_store = n_runs <= MAX_RUNS ? n_runs : 0;
+	for (uint32_t r = 0; r < n_store; ++r) {
+		stash[2 + 2 * r] = __float_as_uint(s_run_t[r][threadIdx.x]);
+		stash[3 + 2 * r] = s_run_n[r][threadIdx.x];
+	}
+	if (a.max_level_rand_training) {
+		float* ml = a.max_level_ptr + base;
+		for (uint32_t j = 0; j < numsteps; ++j) ml[j] = max_level;
+	}
+}
+
+// Pass 2 (testbed_nerf.cu:1239-1253) with one WAVE per kept ray: lane k of a 64-sample chunk rebuilds t_k by the same sequence
+// of `t += calc_dt(t)` additions the reference performs (bit-identical), and the 28-byte records of consecutive samples are
+// written by consecutive lanes (coalesced) instead of one lane dribbling out its whole ray.
+__global__ void __launch_bounds__(256) expand_training_samples_kernel(const TrainSampleArgs a) {
+	constexpr uint32_t MAX_RUNS = NGP_MAX_RUNS;
+	__shared__ float s_t[4][MAX_RUNS];
+	__shared__ uint32_t s_n[4][MAX_RUNS];
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t slot = blockIdx.x * 4 + w;
+	if (slot >= *a.ray_counter) return;
+	const uint32_t numsteps = a.numsteps_out[slot * 2 + 0], base = a.numsteps_out[slot * 2 + 1];
+	if (numsteps == 0) return;
 	NgpCoord* co = a.coords_out + base;
+	const uint32_t* stash = (const uint32_t*)co;
+	const uint32_t n_runs = stash[0];
+	const float startt = __uint_as_float(stash[1]);
+	// lane r fetches run r of the recipe into LDS before any lane overwrites the slots (n_runs <= numsteps, so it always fits)
+	if (n_runs <= MAX_RUNS && lane < n_runs) { s_t[w][lane] = __uint_as_float(stash[2 + 2 * lane]); s_n[w][lane] = stash[3 + 2 * lane]; }
+	const NgpRay ray = a.rays_out[slot];
+	const v3 ro = ld3(ray.o), rd = normalized(ld3(ray.d));
 	const v3 warped_dir = warp_direction(rd);
+	const float cone_angle = a.cone_angle_constant;
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the recipe is out of the slots before any lane overwrites them
+
+	if (n_runs <= MAX_RUNS) {
+		uint32_t j0 = 0;
+		for (uint32_t r = 0; r < n_runs; ++r) {
+			const uint32_t cnt = s_n[w][r];
+			float t_chunk = s_t[w][r];
+			for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+				float t = t_chunk;
+				for (uint32_t k = 0; k < lane; ++k) t += calc_dt(t, cone_angle);
+				const float dt = calc_dt(t, cone_angle);
+				if (c0 + lane < cnt) {
+					const v3 wp = aabb_relative_pos(a.aabb, ro + rd * t);
+					NgpCoord c;
+					c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
+					c.dir[0] = warped_dir.x; c.dir[1] = warped_dir.y; c.dir[2] = warped_dir.z;
+					co[j0 + c0 + lane] = c;
+				}
+				t_chunk = __shfl(t + dt, 63, 64);
+			}
+			j0 += cnt;
+		}
+		return;
+	}
+	// more runs than recipe slots (very fragmented occupancy): the reference's full second march, one lane
+	if (lane != 0) return;
+	const v3 idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
 	float t = startt;
-	uint32_t j = 0;
 	v3 pos;
-	while (aabb_contains(a.aabb, pos = ro + rd * t) && j < numsteps) {
+	uint32_t j = 0;
+	while (j < numsteps && aabb_contains(a.aabb, pos = ro + rd * t)) {
 		const float dt = calc_dt(t, cone_angle);
 		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		if (density_grid_occupied_at(pos, a.density_grid, mip)) {
@@ -138,10 +231,6 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 		} else {
 			t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
-	}
-	if (a.max_level_rand_training) {
-		float* ml = a.max_level_ptr + base;
-		for (j = 0; j < numsteps; ++j) ml[j] = max_level;
 	}
 }
 
@@ -166,7 +255,13 @@ extern "C" int ngp_hip_generate_training_samples(
 	a.distortion_res[0] = distortion_resolution_host ? distortion_resolution_host[0] : 0;
 	a.distortion_res[1] = distortion_resolution_host ? distortion_resolution_host[1] : 0;
 	a.ray_offset = ray_offset; a.n_rays_global = n_rays_global ? n_rays_global : n_rays;
+	const char* var = getenv("NGP_HIP_GEN_VARIANT");
+	a.dev_variant = var ? atoi(var) : 0;
 	hipLaunchKernelGGL(generate_training_samples_kernel, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("generate_training_samples_kernel");
+	if (a.dev_variant != 2) {
+		hipLaunchKernelGGL(expand_training_samples_kernel, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, a);
+		NGP_LAUNCH_CHECK("expand_training_samples_kernel");
+	}
 	return 0;
 }

@@ -97,6 +97,19 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })
 		.def("params_ptr", [](Testbed& t) { return (uintptr_t)t.m_params.data(); })
 		.def("sync", &Testbed::sync)
+		.def("debug_pointers", [](Testbed& t) {  // dev tooling (tools/microbench.py): device addresses of the training inputs
+				py::dict d;
+				d["bitfield"] = (uintptr_t)t.m_nerf.density_grid_bitfield.data();
+				d["metadata"] = (uintptr_t)t.m_nerf.training.dataset.metadata_gpu.data();
+				d["xforms"] = (uintptr_t)t.m_nerf.training.transforms_gpu.data();
+				d["n_images"] = t.m_nerf.training.n_images_for_training;
+				d["rng_state"] = t.m_rng.state; d["rng_inc"] = t.m_rng.inc;
+				d["rays_per_batch"] = t.m_nerf.training.counters_rgb.rays_per_batch;
+				d["cone_angle_constant"] = t.m_nerf.cone_angle_constant;
+				d["desc"] = (uintptr_t)t.m_desc_gpu.data();
+				d["params"] = (uintptr_t)t.m_params.data();
+				return d;
+			})
 		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
 		.def("set_profiling", [](Testbed& t, bool on) { t.m_profile_enabled = on; })
 		.def("reset_profile", &Testbed::reset_profile)

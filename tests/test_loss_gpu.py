@@ -106,7 +106,9 @@ def test_loss_and_compaction_match_oracle(ngp, oracle, cuda, loss_type):
             continue
         assert o["co"][bo:bo + n].tobytes() == g["co"][bg_:bg_ + n].tobytes()
         a, b = g["dl"][bg_:bg_ + n].astype(np.float32), o["dl"][bo:bo + n].astype(np.float32)
-        np.testing.assert_allclose(a, b, rtol=4e-3, atol=2e-6)
+        # atol: the kernel sums colour / transmittance as wave scans (tree order), the oracle left to right; the `rgb_ray - rgb_ray2`
+        # suffix cancels to ~1e-7 differently and is amplified by d(sigma)/d(logit) -> a few 1e-6 on gradients of magnitude ~1e-3
+        np.testing.assert_allclose(a, b, rtol=4e-3, atol=6e-6)
         worst = max(worst, float(np.abs(a - b).max()))
     keep = np.array([i for i in range(I["n_alive"]) if i not in border])
     np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
