@@ -342,9 +342,9 @@ __host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
 
 // grid (GB_ITEMS, 16 levels), block 1024.  dx planes: [level][sample] half2.  partials: [(level*GB_ITEMS + item)][GB_SLICE] half2.
 __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                             const h2* __restrict__ dx_planes, h2* __restrict__ partials) {
+                                                             const h2* __restrict__ dx_planes, h2* __restrict__ partials, uint32_t level_base) {
 	__shared__ h2 slice[GB_SLICE];
-	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	const uint32_t level = blockIdx.y + level_base, item = blockIdx.x;
 	const NgpGridLevel lv = desc->levels[level];
 	const GbSplit sp = gb_split(lv.size);
 	if (item >= sp.n_slices * sp.k_chunks) return;
@@ -356,22 +356,103 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 	__syncthreads();
 	const uint32_t s_begin = (uint32_t)(((uint64_t)n * chunk) / sp.k_chunks), s_end = (uint32_t)(((uint64_t)n * (chunk + 1)) / sp.k_chunks);
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
-		const h2 gq = dxl[s];
-		const float g0 = (float)gq[0], g1 = (float)gq[1];
-		if (g0 == 0.0f && g1 == 0.0f) continue;  // adding +-0 never changes a sum
-		const float* c = coords + (size_t)s * coord_stride;
-		const LevelPos p = level_pos(lv, c[0], c[1], c[2]);
+	const bool dense = (uint64_t)lv.resolution * lv.resolution * lv.resolution <= (uint64_t)lv.size;
+	if (dense) {
+		// Dense (coarse) levels: tens of consecutive ray samples share a cell, i.e. the same 8 corner keys.  Every thread walks GB_RUN
+		// CONSECUTIVE samples, sums their contributions in fp32 registers while the cell stays the same and issues one LDS atomic per
+		// in-slice corner when it changes (tcnn adds half2(w * dL/dx) per sample; the run is summed in fp32 first).
+		constexpr uint32_t GB_RUN = 8;
+		for (uint32_t s0 = s_begin + threadIdx.x * GB_RUN; s0 < s_end; s0 += blockDim.x * GB_RUN) {
+			uint32_t cgx = 0xffffffffu, cgy = 0, cgz = 0, rels[8];
+			uint32_t mask = 0;       // corners of the open cell that fall into this slice
+			float a0[8], a1[8];
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint32_t idx = grid_index(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1));
-			const uint32_t rel = idx - lo;
-			if (rel < cnt) {
-				float w = (k & 1) ? p.fx : (1.0f - p.fx);
-				w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
-				w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
-				h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);   // tcnn kernel_grid_backward: half2(w * dL/dx)
-				__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rel], val);
+			for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; rels[k] = 0; }
+			auto flush = [&]() {
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					if (mask & (1u << k)) {
+						h2 val; val[0] = (half_t)a0[k]; val[1] = (half_t)a1[k];
+						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rels[k]], val);
+					}
+				}
+			};
+			// fetch the whole run first (independent loads in flight), then walk it
+			h2 gqs[GB_RUN];
+			float pxs[GB_RUN], pys[GB_RUN], pzs[GB_RUN];
+#pragma unroll
+			for (uint32_t u = 0; u < GB_RUN; ++u) {
+				const uint32_t sc = s0 + u < s_end ? s0 + u : s_begin;
+				gqs[u] = dxl[sc];
+				const float* c = coords + (size_t)sc * coord_stride;
+				pxs[u] = c[0]; pys[u] = c[1]; pzs[u] = c[2];
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < GB_RUN; ++u) {
+				const float g0 = (float)gqs[u][0], g1 = (float)gqs[u][1];
+				if (s0 + u >= s_end || (g0 == 0.0f && g1 == 0.0f)) continue;  // adding +-0 never changes a sum
+				const LevelPos p = level_pos(lv, pxs[u], pys[u], pzs[u]);
+				if (p.gx != cgx || p.gy != cgy || p.gz != cgz) {
+					if (mask) flush();
+					cgx = p.gx; cgy = p.gy; cgz = p.gz;
+					mask = 0;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						const uint32_t rel = grid_index(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1)) - lo;
+						rels[k] = rel;
+						if (rel < cnt) mask |= 1u << k;
+						a0[k] = 0.f; a1[k] = 0.f;
+					}
+				}
+				if (mask) {
+#pragma unroll
+					for (int k = 0; k < 8; ++k) {
+						float w = (k & 1) ? p.fx : (1.0f - p.fx);
+						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
+						w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+						a0[k] += w * g0; a1[k] += w * g1;
+					}
+				}
+			}
+			if (mask) flush();
+		}
+	} else {
+		// Hashed (fine) levels: no two samples share keys, and only ~1/16 of the corners land in this slice.  The scan is a chain of
+		// dependent global loads, so every thread first fetches GB_UNROLL samples (coalesced across lanes).  The level size is a power
+		// of two here, so a corner index is (x ^ y*P1 ^ z*P2) & (size-1) with the three products shared by the 8 corners.
+		constexpr uint32_t GB_UNROLL = 8;
+		const uint32_t hmask = lv.size - 1;
+		for (uint32_t s0 = s_begin + threadIdx.x; s0 < s_end; s0 += blockDim.x * GB_UNROLL) {
+			h2 gq[GB_UNROLL];
+			float px[GB_UNROLL], py[GB_UNROLL], pz[GB_UNROLL];
+#pragma unroll
+			for (uint32_t u = 0; u < GB_UNROLL; ++u) {
+				const uint32_t s = s0 + u * blockDim.x;
+				const uint32_t sc = s < s_end ? s : s_begin;   // clamp: the load is always in range, the result is masked below
+				gq[u] = dxl[sc];
+				const float* c = coords + (size_t)sc * coord_stride;
+				px[u] = c[0]; py[u] = c[1]; pz[u] = c[2];
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < GB_UNROLL; ++u) {
+				const uint32_t s = s0 + u * blockDim.x;
+				const float g0 = (float)gq[u][0], g1 = (float)gq[u][1];
+				if (s >= s_end || (g0 == 0.0f && g1 == 0.0f)) continue;  // adding +-0 never changes a sum
+				const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
+				const uint32_t hx[2] = {p.gx, p.gx + 1u};
+				const uint32_t hy[2] = {p.gy * 2654435761u, (p.gy + 1u) * 2654435761u};
+				const uint32_t hz[2] = {p.gz * 805459861u, (p.gz + 1u) * 805459861u};
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const uint32_t rel = ((hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[(k >> 2) & 1]) & hmask) - lo;
+					if (rel < cnt) {
+						float w = (k & 1) ? p.fx : (1.0f - p.fx);
+						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
+						w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+						h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);   // tcnn kernel_grid_backward: half2(w * dL/dx)
+						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rel], val);
+					}
+				}
 			}
 		}
 	}
@@ -740,7 +821,11 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
 	// EGradientMode::Overwrite: the combine pass writes every table entry exactly once (no memset, no global atomics)
 	if (!(ablate & 4)) {
-		hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials);
+		if (getenv("NGP_HIP_GB_SPLIT")) {  // dev-only: one launch per level so a kernel trace shows per-level times
+			for (uint32_t l = 0; l < 16; ++l) hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 1), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, l);
+		} else {
+			hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
+		}
 		NGP_LAUNCH_CHECK("grid_backward_kernel");
 		hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_MLP_N_PARAMS));
 		NGP_LAUNCH_CHECK("grid_combine_kernel");
