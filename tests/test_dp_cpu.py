@@ -1,0 +1,175 @@
+"""CPU tests (gloo, world_size 2) of the data-parallel path.
+
+No GPU here, so the per-rank compute is done by the oracle; what is under test is the PARTITIONING CONTRACT that bench.py /
+Testbed.train_nerf_dp_* rely on:
+  * rank r marches global rays [r*R, (r+1)*R) of a step of W*R rays (ray_offset / n_rays_global arguments),
+  * the loss is normalised by the GLOBAL ray count, so all_reduce(SUM) of the rank gradients == the full-batch gradient,
+  * counters and the loss scalar are summed with the same collective, every rank ends up with identical values,
+and the control flow of bench.dp_step (prep schedule, begin -> all-reduce -> end) with a recording fake Testbed.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(orc, ngp):
+    n_img, w, h = 4, 48, 32
+    imgs = H.make_images(n_img, w, h, masked_fraction=0.0)
+    md = H.make_metadata([imgs[i].ctypes.data for i in range(n_img)], w, h, 55.0)
+    xf = H.hemisphere_cameras(n_img)
+    grid = H.blob_density_grid(1)
+    bf, mean = H.oracle_bitfield(orc, grid, 1)
+    desc = H.make_desc(ngp, log2_hashmap_size=10)
+    params = H.random_params(desc, seed=1, grid_amp=0.5)
+    return dict(imgs=imgs, md=md, xf=xf, bf=bf, mean=mean, desc=desc, params=params, n_img=n_img)
+
+
+def _rank_gradient(orc, S, n_rays_local, ray_offset, n_rays_global):
+    """one rank's share of a training step, oracle only: march -> inference -> loss (global normalisation) -> backward"""
+    aabb = H.unit_aabb()
+    st, inc = H.pcg32_state(1337)
+    max_samples = n_rays_local * 256
+    r = dict(rc=np.zeros(1, np.uint32), nc=np.zeros(1, np.uint32), idx=np.zeros(n_rays_local, np.uint32), rays=np.zeros(n_rays_local, H.RAY),
+             ns=np.zeros(n_rays_local * 2, np.uint32), co=np.zeros(max_samples, H.COORD))
+    dres = np.array([0, 0], np.int32)
+    orc.orc_generate_training_samples(n_rays_local, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data, r["rays"].ctypes.data,
+                                      r["ns"].ctypes.data, r["co"].ctypes.data, S["n_img"], S["md"].ctypes.data, S["xf"].ctypes.data, S["bf"].ctypes.data, 0, None, 0, 0,
+                                      H.f32(0.0), None, dres.ctypes.data, ray_offset, n_rays_global)
+    n_alive, n_samples = int(r["rc"][0]), int(r["nc"][0])
+    out = np.zeros((max(n_samples, 1), 4), np.uint16)
+    orc.orc_nerf_inference(S["desc"].ctypes.data, S["params"].ctypes.data, r["co"].ctypes.data, 7, n_samples, out.ctypes.data, 4)
+    B = n_samples + 8
+    cnt = np.zeros(1, np.uint32)
+    co_c, dl, loss = np.zeros(B, H.COORD), np.zeros((B, 4), np.float16), np.zeros(n_rays_global, np.float32)
+    bg = np.zeros(3, np.float32)
+    em_res = np.array([8, 8], np.int32)
+    em = np.zeros(S["n_img"] * 64, np.float32)
+    exposure = np.zeros((S["n_img"], 3), np.float32)
+    orc.orc_compute_loss(n_rays_global, aabb.ctypes.data, st, inc, B, n_alive, H.f32(128.0), 4, bg.ctypes.data, 0, 1, 0, S["n_img"], S["md"].ctypes.data, out.ctypes.data,
+                         cnt.ctypes.data, r["idx"].ctypes.data, r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, co_c.ctypes.data, dl.ctypes.data, 4,
+                         loss.ctypes.data, 0, None, 2, 3, 0, em.ctypes.data, em_res.ctypes.data, H.f32(S["mean"]), exposure.ctypes.data, H.f32(0.2))
+    n_c = int(cnt[0])
+    grads = np.zeros(H.n_params(S["desc"]), np.float64)
+    if n_c:
+        orc.orc_nerf_forward_backward(S["desc"].ctypes.data, S["params"].ctypes.data, co_c.ctypes.data, 7, n_c, dl.ctypes.data, None, grads.ctypes.data, None)
+    return grads, np.array([n_samples, n_c, float(loss.sum())])
+
+
+def _worker(rank, world, port, result_path):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "blender-ngp_amd"), os.path.join(ROOT, "tests")]
+    import capi
+    import helpers as Hh
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    orc, ngp = Hh.load_oracle(), capi.load_ngp_hip()
+    S = _scene(orc, ngp)
+    R = 256  # rays per rank
+    g, c = _rank_gradient(orc, S, R, rank * R, world * R)
+    tg, tc = torch.from_numpy(g), torch.from_numpy(c)
+    dist.all_reduce(tg)
+    dist.all_reduce(tc)
+    if rank == 0:
+        full_g, full_c = _rank_gradient(orc, S, world * R, 0, world * R)
+        np.savez(result_path, summed=tg.numpy(), full=full_g, counters=tc.numpy(), full_counters=full_c)
+    # every rank holds the same reduced counters
+    gathered = [torch.zeros_like(tc) for _ in range(world)]
+    dist.all_gather(gathered, tc)
+    assert all(torch.equal(gathered[0], x) for x in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gradients_sum_to_full_batch(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    # the two shards together see exactly the rays of the full batch: identical sample / compaction counts and loss
+    np.testing.assert_array_equal(r["counters"][:2], r["full_counters"][:2])
+    assert r["counters"][0] > 0 and r["counters"][1] > 0
+    np.testing.assert_allclose(r["counters"][2], r["full_counters"][2], rtol=1e-5)
+    scale = np.abs(r["full"]).max()
+    assert scale > 0
+    np.testing.assert_allclose(r["summed"], r["full"], rtol=1e-9, atol=1e-12 * scale)
+
+
+class _FakeTestbed:
+    """records the call sequence of bench.dp_step; mimics the pyngp extension API used by it"""
+    def __init__(self, step, counters):
+        self.training_step = step
+        self.calls = []
+        self._c = counters
+
+    def training_prep_nerf(self, B):
+        self.calls.append("prep")
+
+    def train_nerf_dp_begin(self, B):
+        self.calls.append("begin")
+        return self._c
+
+    def local_loss_sum(self):
+        self.calls.append("loss")
+        return 0.5
+
+    def train_nerf_dp_end(self, B, before, after, get_loss, loss_sum):
+        self.calls.append(("end", before, after, get_loss, round(loss_sum, 6)))
+        self.training_step += 1
+
+
+def _dp_step_worker(rank, world, port, result_path):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT]
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    log = []
+    for step in (0, 16, 17, 300, 512):
+        tb = _FakeTestbed(step, (1000 + rank, 400 + 10 * rank))
+        grads = torch.full((8,), float(rank + 1), dtype=torch.float16)
+        scratch = torch.zeros(3, dtype=torch.float64)
+        bench.dp_step(tb, torch, dist, 1 << 18, grads, scratch)
+        log.append((step, tb.calls, grads.tolist()))
+    if rank == 0:
+        import pickle
+        pickle.dump(log, open(result_path, "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_step_control_flow(tmp_path):
+    import pickle
+    import torch.multiprocessing as mp
+    port = _free_port()
+    out = str(tmp_path / "flow.pkl")
+    mp.spawn(_dp_step_worker, args=(2, port, out), nprocs=2, join=True)
+    log = pickle.load(open(out, "rb"))
+    by_step = {s: (calls, g) for s, calls, g in log}
+    # prep schedule of Testbed::train (testbed.cu:2538): every step until 32, then every step//16-th (capped at 16)
+    assert by_step[0][0][0] == "prep" and by_step[16][0][0] == "prep"
+    assert by_step[17][0][0] == "prep"            # n_prep_to_skip = clamp(17 // 16, 1, 16) = 1
+    assert by_step[300][0][0] == "begin"          # n_prep_to_skip = 16 and 300 % 16 != 0
+    assert by_step[512][0][0] == "prep"           # 512 % 16 == 0
+    for s, (calls, g) in by_step.items():
+        end = calls[-1]
+        assert end[0] == "end" and end[1] == 2001 and end[2] == 810   # summed over the two ranks
+        assert end[3] == (s % 16 == 0)
+        assert end[4] == (1.0 if s % 16 == 0 else 0.0)
+        assert g == [3.0] * 8                                          # gradient buffer was all-reduced in place
+        assert calls.index("begin") < len(calls) - 1
