@@ -47,9 +47,10 @@ def dp_step(tb, torch, dist, B, grads, scratch):
     get_loss = step % 16 == 0
     scratch[0], scratch[1] = c0, c1
     scratch[2] = tb.local_loss_sum() if get_loss else 0.0
+    dist.all_reduce(scratch)    # 2 counters + loss scalar: every rank derives the same rays_per_batch for the next step
+    tb.train_nerf_dp_backward(B, int(scratch[0].item()), int(scratch[1].item()), get_loss, float(scratch[2].item()))
     dist.all_reduce(grads)      # RCCL over xGMI, fp16 sum of the loss-scaled gradients (24.4 MB for lego)
-    dist.all_reduce(scratch)    # 2 counters + loss scalar
-    tb.train_nerf_dp_end(B, int(scratch[0].item()), int(scratch[1].item()), get_loss, float(scratch[2].item()))
+    tb.train_nerf_dp_end()
     return c1
 
 

@@ -90,8 +90,11 @@ PYBIND11_MODULE(pyngp, m) {
 		// data-parallel extension
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
 		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c); } return py::make_tuple(c[0], c[1]); }, py::arg("batch_size"))
-		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
+		.def("train_nerf_dp_backward", &Testbed::train_nerf_dp_backward, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
+		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())
+		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
+		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
 		.def("training_prep_nerf", &Testbed::training_prep_nerf, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size") = 0)
 		.def("local_loss_sum", &Testbed::local_loss_sum)
 		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })

@@ -98,15 +98,18 @@ void NerfDataset::update_metadata(int first, int last) {
 
 // ------------------------------------------------------------------------------------------------ training-side setters
 void NerfTraining::set_image(int frame_idx, int w, int h, const float* rgba_host) {
+	if (owner) owner->invalidate_training_inputs();
 	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) throw std::runtime_error{"Invalid frame index"};
 	dataset.set_training_image(frame_idx, w, h, rgba_host, 3);
 }
 void NerfTraining::set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host) {
+	if (owner) owner->invalidate_training_inputs();
 	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) throw std::runtime_error{"Invalid frame index"};
 	dataset.set_training_image(frame_idx, w, h, rgba_host, 1);
 }
 void NerfTraining::set_camera_extrinsics(int frame_idx, const Mat34& camera_to_world, bool convert_to_ngp) {
 	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) return;
+	if (owner) owner->invalidate_training_inputs();
 	Mat34 m = convert_to_ngp ? dataset.nerf_matrix_to_ngp(camera_to_world) : camera_to_world;
 	memcpy(dataset.xforms[frame_idx].start, m.m, sizeof(m.m));
 	memcpy(dataset.xforms[frame_idx].end, m.m, sizeof(m.m));
@@ -121,6 +124,7 @@ Mat34 NerfTraining::get_camera_extrinsics(int frame_idx) const {
 }
 void NerfTraining::set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2) {
 	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) return;
+	if (owner) owner->invalidate_training_inputs();
 	if (fx <= 0.f) fx = fy;
 	if (fy <= 0.f) fy = fx;
 	NgpImageMeta& m = dataset.metadata[frame_idx];
@@ -160,9 +164,10 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
 		throw std::runtime_error{"no MI355X / ROCm device visible: the product path has no CPU fallback"};
 	}
-	hipStream_t st;
+	hipStream_t st, st_b;
 	HIP_CHECK_THROW(hipStreamCreate(&st));
-	m_stream = st;
+	HIP_CHECK_THROW(hipStreamCreate(&st_b));
+	m_stream = st; m_stream_b = st_b;
 	m_nerf.training.owner = this;
 	m_rng = Pcg32(m_seed);
 	reset_camera();
@@ -170,6 +175,7 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
 
@@ -177,6 +183,7 @@ void Testbed::check(int rc, const char* what) {
 	if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + ngp_hip_last_error());
 }
 void Testbed::sync() { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
+void Testbed::invalidate_training_inputs() { drop_prefetch(); ++m_state_version; }
 
 // ---- live kernel timing ----------------------------------------------------------------------------------------
 void* Testbed::prof_event() {
@@ -185,19 +192,19 @@ void* Testbed::prof_event() {
 	HIP_CHECK_THROW(hipEventCreate(&e));
 	return e;
 }
-void Testbed::profile_begin(int k) {
+void Testbed::profile_begin(int k, void* stream) {
 	if (!m_profile_enabled) return;
 	ProfPending p{k, prof_event(), nullptr, 0};
-	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)m_stream));
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)(stream ? stream : m_stream)));
 	m_prof_pending.push_back(p);
 }
-void Testbed::profile_end(int k, uint64_t units) {
+void Testbed::profile_end(int k, uint64_t units, void* stream) {
 	if (!m_profile_enabled) return;
 	for (auto it = m_prof_pending.rbegin(); it != m_prof_pending.rend(); ++it) {
 		if (it->k == k && !it->e1) {
 			it->e1 = prof_event();
 			it->units = units;
-			HIP_CHECK_THROW(hipEventRecord((hipEvent_t)it->e1, (hipStream_t)m_stream));
+			HIP_CHECK_THROW(hipEventRecord((hipEvent_t)it->e1, (hipStream_t)(stream ? stream : m_stream)));
 			return;
 		}
 	}
@@ -205,6 +212,7 @@ void Testbed::profile_end(int k, uint64_t units) {
 void Testbed::profile_collect() {
 	for (auto& p : m_prof_pending) {
 		if (p.e0 && p.e1) {
+			(void)hipEventSynchronize((hipEvent_t)p.e1);
 			float ms = 0.f;
 			if (hipEventElapsedTime(&ms, (hipEvent_t)p.e0, (hipEvent_t)p.e1) == hipSuccess) {
 				m_prof[p.k].ms += ms; m_prof[p.k].launches += 1; m_prof[p.k].units += p.units;
@@ -360,6 +368,8 @@ void Testbed::parse_optimizer_config(const Json& opt_in) {
 }
 
 void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
+	drop_prefetch();
+	++m_state_version;
 	m_rng = Pcg32(m_seed);
 	m_windowless_render_surface.reset_accumulation();
 	NerfTraining& tr = m_nerf.training;
@@ -464,6 +474,8 @@ void Testbed::training_prep_nerf(uint32_t) {  // testbed_nerf.cu:3388-3401
 }
 
 void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {  // testbed_nerf.cu:2761-2842
+	drop_prefetch();     // the bitfield is about to change: samples marched ahead against the old one are void
+	++m_state_version;
 	NerfTraining& tr = m_nerf.training;
 	const uint32_t n_elements = GRID_CELLS * (m_nerf.max_cascade + 1);
 	if (m_nerf.density_grid.bytes() != (size_t)n_elements * 4) { m_nerf.density_grid.resize((size_t)n_elements * 4); m_nerf.density_grid.memset(0, m_stream); }
@@ -508,38 +520,146 @@ void Testbed::update_density_grid_mean_and_bitfield() {  // testbed_nerf.cu:2844
 
 void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
 	if (world_size == 0 || rank >= world_size) throw std::runtime_error{"set_distributed: bad rank / world_size"};
+	drop_prefetch();
+	++m_state_version;
 	m_rank = rank; m_world_size = world_size;
 }
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
-	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / all-reduce / train_nerf_dp_end"};
+	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / _dp_backward / _dp_end around the all-reduces"};
 	uint32_t counters[2];
 	train_nerf_dp_begin(target_batch_size, counters);
-	float loss_sum = get_loss_scalar ? local_loss_sum() : 0.f;
-	train_nerf_dp_end(target_batch_size, counters[0], counters[1], get_loss_scalar, loss_sum);
+	const float loss_sum = get_loss_scalar ? local_loss_sum() : 0.f;
+	train_nerf_dp_backward(target_batch_size, counters[0], counters[1], get_loss_scalar, loss_sum);
+	train_nerf_dp_end();
+}
+
+// ---- sample generation, possibly one step ahead on a second stream ----------------------------------------------------------
+// The DDA march (generate_training_samples) is a serial, latency-bound kernel that keeps < 25 % of the SIMDs busy, and it depends
+// only on the occupancy bitfield, the rng and rays_per_batch — not on the weights.  Once the counters of step n are known (after
+// its loss kernel) the march of step n+1 is therefore launched on a second HIP stream and overlaps step n's forward / backward /
+// optimizer.  Same inputs, same kernels, same results as the in-order schedule; skipped whenever an occupancy-grid update is due
+// before step n+1 and discarded if any input changed in the meantime.
+uint32_t Testbed::next_max_inference(uint32_t target_batch_size) const {  // testbed_nerf.cu:3185-3190
+	const uint32_t max_samples = target_batch_size * 16;
+	const NerfCounters& c = m_nerf.training.counters_rgb;
+	if (c.measured_batch_size_before_compaction == 0) return max_samples;
+	return next_multiple(std::min(c.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
+}
+
+void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng) {
+	NerfTraining& tr = m_nerf.training;
+	m_ray_indices.enlarge((size_t)R * 4); m_rays.enlarge((size_t)R * sizeof(NgpRay)); m_numsteps.enlarge((size_t)R * 8);
+	m_gen_counters.enlarge(16);
+	uint32_t* counters = m_gen_counters.as<uint32_t>() + 2 * slot;  // [0] ray counter, [1] numsteps counter
+	HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
+	const int32_t dist_res[2] = {32, 32};
+	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
+	profile_begin(PK_GEN_SAMPLES, stream);
+	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
+	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
+	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
+	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global), "generate_training_samples");
+	profile_end(PK_GEN_SAMPLES, R, stream);
+}
+
+void Testbed::drop_prefetch() {
+	if (m_prefetch.valid) {
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream_b));
+		m_prefetch.valid = false;
+	}
+}
+
+void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
+	if (!m_enable_prefetch || !m_train_continues) return;
+	const uint32_t next_step = m_training_step + 1;
+	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
+	if (next_step % n_prep_to_skip == 0) return;  // an occupancy-grid update (new bitfield) precedes that step
+	NerfCounters& c = m_nerf.training.counters_rgb;
+	Pcg32 rng = m_rng;   // m_rng was already advanced for the next step (3380)
+	PrefetchedSamples p;
+	p.valid = true; p.step = next_step; p.R = c.rays_per_batch; p.max_inference = next_max_inference(target_batch_size); p.rng_state = rng.state;
+	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
+	// stream B may only start once stream A has consumed this step's rays / coords (the loss kernel): A is synchronised at this point
+	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng);
+	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_prefetch_event = e; }
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
+	m_prefetch = p;
 }
 
 void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]) {
 	NerfTraining& tr = m_nerf.training;
 	NerfCounters& c = tr.counters_rgb;
+	if (target_batch_size % 256) throw std::runtime_error{"training batch size must be a multiple of 256"};
+	const uint32_t max_samples = target_batch_size * 16;
+	const uint32_t R = c.rays_per_batch;
+	m_coords.enlarge((size_t)max_samples * sizeof(NgpCoord));
+	m_mlp_out.enlarge((size_t)std::max(target_batch_size, max_samples) * OUT_STRIDE * 2);
+	m_dloss.enlarge((size_t)target_batch_size * OUT_STRIDE * 2);
+	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
+	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
+	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes(target_batch_size));
+
 	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)
-	c.numsteps_counter.enlarge(4); c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge((size_t)c.rays_per_batch * 4);
-	c.numsteps_counter.memset(0, m_stream); c.numsteps_counter_compacted.memset(0, m_stream);
-	HIP_CHECK_THROW(hipMemsetAsync(c.loss.data(), 0, (size_t)c.rays_per_batch * 4, (hipStream_t)m_stream));
+	c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge((size_t)R * 4);
+	c.numsteps_counter_compacted.memset(0, m_stream);
+	HIP_CHECK_THROW(hipMemsetAsync(c.loss.data(), 0, (size_t)R * 4, (hipStream_t)m_stream));
 	// error map (re)allocation (2933-2939)
 	if (tr.n_steps_since_error_map_update == 0 && !tr.dataset.metadata.empty()) {
-		const uint32_t n_samples_per_image = (tr.n_steps_between_error_map_updates * c.rays_per_batch) / (uint32_t)tr.dataset.n_images;
+		const uint32_t n_samples_per_image = (tr.n_steps_between_error_map_updates * R) / (uint32_t)tr.dataset.n_images;
 		const int r = (int)(std::sqrt(std::sqrt((float)n_samples_per_image)) * 3.5f);
 		tr.error_map_res[0] = std::min(r, tr.dataset.metadata[0].res[0]);
 		tr.error_map_res[1] = std::min(r, tr.dataset.metadata[0].res[1]);
 		tr.error_map_data.resize((size_t)tr.error_map_res[0] * tr.error_map_res[1] * tr.dataset.n_images * 4);
 		tr.error_map_data.memset(0, m_stream);
 	}
-	train_nerf_step(target_batch_size);
-	// update_after_training reads the two counters (2870-2874): blocking 4-byte D2H copies
+
+	// ---- train_nerf_step, first half (3138-3312): samples, inference on all of them, loss + compaction
+	uint32_t max_inference;
+	if (c.measured_batch_size_before_compaction == 0) {
+		c.measured_batch_size_before_compaction = max_inference = max_samples;
+	} else {
+		max_inference = next_max_inference(target_batch_size);
+	}
+	if (m_training_step == 0) c.n_rays_total = 0;
+	c.n_rays_total += R;
+	tr.n_rays_since_error_map_update += R;
+
+	const bool hit = m_prefetch.valid && m_prefetch.step == m_training_step && m_prefetch.R == R && m_prefetch.max_inference == max_inference && m_prefetch.rng_state == m_rng.state &&
+	                 m_prefetch.version == m_state_version && m_prefetch.n_images == tr.n_images_for_training && m_prefetch.batch == target_batch_size;
+	if (hit) {
+		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_prefetch_event, 0));
+		m_gen_slot = m_prefetch.slot;
+		m_prefetch.valid = false;
+		++m_prefetch_hits;
+	} else {
+		drop_prefetch();
+		launch_generate(m_stream, m_gen_slot, R, max_inference, m_rng);
+	}
+	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 2 * m_gen_slot;
+	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	const uint32_t n_rays_global = R * m_world_size;
+	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256)
+	profile_begin(PK_INFERENCE);
+	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
+	profile_end(PK_INFERENCE, max_inference);
+	profile_begin(PK_LOSS);
+	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
+	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
+	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
+	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
+	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
+	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance), "compute_loss");
+	profile_end(PK_LOSS, R);
+	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
+	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
+	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
+
+	// NerfCounters::update_after_training reads the two counters (2870-2874): blocking 4-byte D2H copies.  Moved here (they are
+	// final once the loss kernel ran) so that the next step's march can start while this step's backward is still running.
 	sync();
-	c.numsteps_counter.copy_to_host(&counters_out[0], 4);
+	HIP_CHECK_THROW(hipMemcpy(&counters_out[0], gen_counters + 1, 4, hipMemcpyDeviceToHost));
 	c.numsteps_counter_compacted.copy_to_host(&counters_out[1], 4);
 }
 
@@ -550,6 +670,23 @@ float Testbed::local_loss_sum() {
 	float v = 0.f;
 	m_loss_scalar_gpu.copy_to_host(&v, 4);
 	return v;
+}
+
+void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum) {
+	// counter feedback first: it fixes the next step's rays_per_batch, which the prefetch needs
+	update_after_training(target_batch_size, global_measured_before, global_measured, get_loss_scalar, global_loss_sum);
+	m_train_continues = m_nerf.training.counters_rgb.measured_batch_size != 0;
+	maybe_prefetch_next(target_batch_size);
+	// ---- train_nerf_step, second half (3324-3332): forward on the compacted batch, backward (gradients overwrite)
+	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	profile_begin(PK_FORWARD);
+	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
+	profile_end(PK_FORWARD, target_batch_size);
+	profile_begin(PK_BACKWARD);
+	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
+	profile_end(PK_BACKWARD, target_batch_size);
+	if (m_world_size > 1) sync();  // the gradient all-reduce runs on another stream / library
 }
 
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
@@ -565,11 +702,10 @@ void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE)
 	}
 }
 
-void Testbed::train_nerf_dp_end(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum) {
+void Testbed::train_nerf_dp_end() {
 	NerfTraining& tr = m_nerf.training;
 	optimizer_step();
 	++m_training_step;
-	update_after_training(target_batch_size, global_measured_before, global_measured, get_loss_scalar, global_loss_sum);
 	const bool zero_records = tr.counters_rgb.measured_batch_size == 0;
 	if (zero_records) {
 		m_loss_scalar = 0.f;
@@ -596,66 +732,6 @@ void Testbed::update_after_training(uint32_t target_batch_size, uint32_t counter
 	if (get_loss_scalar) m_loss_scalar = loss_sum * (float)c.measured_batch_size / (float)target_batch_size;
 	c.rays_per_batch = (uint32_t)((float)c.rays_per_batch * (float)target_batch_size / (float)c.measured_batch_size);
 	c.rays_per_batch = std::min(next_multiple(c.rays_per_batch, BATCH_SIZE_GRANULARITY), 1u << 18);
-}
-
-void Testbed::train_nerf_step(uint32_t target_batch_size) {  // testbed_nerf.cu:3138-3385
-	NerfTraining& tr = m_nerf.training;
-	NerfCounters& c = tr.counters_rgb;
-	if (target_batch_size % 256) throw std::runtime_error{"training batch size must be a multiple of 256"};
-	const uint32_t max_samples = target_batch_size * 16;
-	const uint32_t R = c.rays_per_batch;
-	m_ray_indices.enlarge((size_t)R * 4); m_rays.enlarge((size_t)R * sizeof(NgpRay)); m_numsteps.enlarge((size_t)R * 8);
-	m_coords.enlarge((size_t)max_samples * sizeof(NgpCoord));
-	m_mlp_out.enlarge((size_t)std::max(target_batch_size, max_samples) * OUT_STRIDE * 2);
-	m_dloss.enlarge((size_t)target_batch_size * OUT_STRIDE * 2);
-	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
-	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
-	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes(target_batch_size));
-	m_ray_counter.enlarge(4);
-
-	uint32_t max_inference;
-	if (c.measured_batch_size_before_compaction == 0) {
-		c.measured_batch_size_before_compaction = max_inference = max_samples;
-	} else {
-		max_inference = next_multiple(std::min(c.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
-	}
-	if (m_training_step == 0) c.n_rays_total = 0;
-	c.n_rays_total += R;
-	tr.n_rays_since_error_map_update += R;
-
-	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
-	const int32_t dist_res[2] = {32, 32};
-	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
-	m_ray_counter.memset(0, m_stream);
-	profile_begin(PK_GEN_SAMPLES);
-	check(ngp_hip_generate_training_samples(m_stream, R, &m_aabb, max_inference, m_rng.state, m_rng.inc, m_ray_counter.as<uint32_t>(), c.numsteps_counter.as<uint32_t>(),
-	                                        m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training,
-	                                        tr.dataset.metadata_gpu.as<NgpImageMeta>(), tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
-	                                        m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0, m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res,
-	                                        ray_offset, n_rays_global), "generate_training_samples");
-	profile_end(PK_GEN_SAMPLES, R);
-	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256)
-	profile_begin(PK_INFERENCE);
-	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
-	profile_end(PK_INFERENCE, max_inference);
-	profile_begin(PK_LOSS);
-	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, m_ray_counter.as<uint32_t>(), LOSS_SCALE, OUT_STRIDE, m_background_color,
-	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
-	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
-	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
-	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
-	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance), "compute_loss");
-	profile_end(PK_LOSS, R);
-	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
-	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
-	profile_begin(PK_FORWARD);
-	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
-	profile_end(PK_FORWARD, target_batch_size);
-	profile_begin(PK_BACKWARD);
-	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
-	profile_end(PK_BACKWARD, target_batch_size);
-	m_rng.advance();
 }
 
 // ---- rendering --------------------------------------------------------------------------------------------------

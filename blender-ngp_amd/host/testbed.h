@@ -198,12 +198,18 @@ public:
 	void update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform);
 	void update_density_grid_mean_and_bitfield();
 	void train_nerf(uint32_t target_batch_size, bool get_loss_scalar);
-	void train_nerf_step(uint32_t target_batch_size);
 	// data-parallel split of train_nerf: begin = everything up to and including backward (gradients ready in
 	// gradients()), end = optimizer step + counter feedback given the GLOBAL (all-rank summed) counters.
 	void set_distributed(uint32_t rank, uint32_t world_size);
+	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
+	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)
+	//      -> [all-reduce gradients] -> end (optimizer, bookkeeping)
 	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]);
-	void train_nerf_dp_end(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
+	void train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
+	void train_nerf_dp_end();
+	void invalidate_training_inputs();
+	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
+	uint64_t m_prefetch_hits = 0;
 	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
 	float local_loss_sum();
 
@@ -260,8 +266,8 @@ public:
 	bool m_profile_enabled = false;
 	ProfAccum m_prof[PK_COUNT];
 	void reset_profile();
-	void profile_begin(int k);
-	void profile_end(int k, uint64_t units);
+	void profile_begin(int k, void* stream = nullptr);
+	void profile_end(int k, uint64_t units, void* stream = nullptr);
 	void profile_collect();                            // after a stream sync: fold pending event pairs into m_prof
 
 	// network + optimizer state
@@ -283,6 +289,18 @@ public:
 
 private:
 	void* m_stream = nullptr;
+	void* m_stream_b = nullptr;                        // second stream: sample generation one step ahead
+	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };
+	PrefetchedSamples m_prefetch;
+	void* m_prefetch_event = nullptr;
+	int m_gen_slot = 0;
+	uint64_t m_state_version = 0;
+	bool m_train_continues = true;
+	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter}
+	uint32_t next_max_inference(uint32_t target_batch_size) const;
+	void launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng);
+	void maybe_prefetch_next(uint32_t target_batch_size);
+	void drop_prefetch();
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
 	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;

@@ -128,8 +128,11 @@ class _FakeTestbed:
         self.calls.append("loss")
         return 0.5
 
-    def train_nerf_dp_end(self, B, before, after, get_loss, loss_sum):
-        self.calls.append(("end", before, after, get_loss, round(loss_sum, 6)))
+    def train_nerf_dp_backward(self, B, before, after, get_loss, loss_sum):
+        self.calls.append(("backward", before, after, get_loss, round(loss_sum, 6)))
+
+    def train_nerf_dp_end(self):
+        self.calls.append("end")
         self.training_step += 1
 
 
@@ -167,9 +170,10 @@ def test_dp_step_control_flow(tmp_path):
     assert by_step[300][0][0] == "begin"          # n_prep_to_skip = 16 and 300 % 16 != 0
     assert by_step[512][0][0] == "prep"           # 512 % 16 == 0
     for s, (calls, g) in by_step.items():
-        end = calls[-1]
-        assert end[0] == "end" and end[1] == 2001 and end[2] == 810   # summed over the two ranks
-        assert end[3] == (s % 16 == 0)
-        assert end[4] == (1.0 if s % 16 == 0 else 0.0)
+        assert calls[-1] == "end"
+        bwd = calls[-2]
+        assert bwd[0] == "backward" and bwd[1] == 2001 and bwd[2] == 810   # counters summed over the two ranks
+        assert bwd[3] == (s % 16 == 0)
+        assert bwd[4] == (1.0 if s % 16 == 0 else 0.0)
         assert g == [3.0] * 8                                          # gradient buffer was all-reduced in place
-        assert calls.index("begin") < len(calls) - 1
+        assert calls.index("begin") < len(calls) - 2
