@@ -37,19 +37,57 @@ class CudaArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def dp_step(tb, torch, dist, B, grads, scratch):
-    """Testbed::train (testbed.cu:2527-2587) with the gradient exchange between backward and optimizer."""
+class DpState:
+    """per-rank buffers of the data-parallel step: the gradient view, a 3-word scratch tensor and the stream the collectives are
+    ordered on (the Testbed's own HIP stream wrapped as a torch ExternalStream; None on CPU / gloo)"""
+    def __init__(self, torch, grads, device, comm_stream=None, ctl_group=None, ctl_stream=None):
+        self.grads = grads
+        self.ctl_group = ctl_group     # process group of the 24-byte counter exchange (high-priority RCCL stream on GPU)
+        self.ctl_stream = ctl_stream   # high-priority torch stream for its H2D / D2H copies
+        self.scratch = torch.zeros(3, dtype=torch.float64, device=device)
+        self.host = torch.zeros(3, dtype=torch.float64)
+        if torch.device(device).type == "cuda":
+            self.host = self.host.pin_memory()
+        self.comm_stream = comm_stream
+        self._torch = torch
+
+    def on_comm_stream(self):
+        import contextlib
+        return self._torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else contextlib.nullcontext()
+
+    def on_ctl_stream(self):
+        import contextlib
+        return self._torch.cuda.stream(self.ctl_stream) if self.ctl_stream is not None else contextlib.nullcontext()
+
+
+def make_dp_state(torch, dist, tb, grads, dev):
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    ctl_group = dist.new_group(backend="nccl", pg_options=opts)
+    ctl_stream = torch.cuda.Stream(device=dev, priority=-1)
+    return DpState(torch, grads, dev, torch.cuda.ExternalStream(tb.stream_ptr(), device=dev), ctl_group, ctl_stream)
+
+
+def dp_step(tb, torch, dist, B, st):
+    """Testbed::train (testbed.cu:2527-2587) with the two exchanges of the data-parallel step:
+    counters (+ loss) right after the loss kernel, gradients between backward and optimizer."""
     step = tb.training_step
     n_prep_to_skip = min(max(step // 16, 1), 16)
     if step % n_prep_to_skip == 0:
         tb.training_prep_nerf(B)  # replicated: same params + same rng on every rank => bit-identical grids, no collective
-    c0, c1 = tb.train_nerf_dp_begin(B)
     get_loss = step % 16 == 0
-    scratch[0], scratch[1] = c0, c1
-    scratch[2] = tb.local_loss_sum() if get_loss else 0.0
-    dist.all_reduce(scratch)    # 2 counters + loss scalar: every rank derives the same rays_per_batch for the next step
-    tb.train_nerf_dp_backward(B, int(scratch[0].item()), int(scratch[1].item()), get_loss, float(scratch[2].item()))
-    dist.all_reduce(grads)      # RCCL over xGMI, fp16 sum of the loss-scaled gradients (24.4 MB for lego)
+    c0, c1 = tb.train_nerf_dp_begin(B, get_loss)   # returns once the loss kernel ran; forward / backward are already queued
+    st.host[0], st.host[1], st.host[2] = c0, c1, (tb.local_loss_sum() if get_loss else 0.0)
+    with st.on_ctl_stream():
+        # 24 bytes on high-priority streams so that it is not queued behind backward: every rank derives the same rays_per_batch
+        st.scratch.copy_(st.host, non_blocking=True)
+        dist.all_reduce(st.scratch, group=st.ctl_group)
+        st.host.copy_(st.scratch)
+    n0, n1, loss_sum = st.host.tolist()
+    tb.train_nerf_dp_backward(B, int(n0), int(n1), get_loss, float(loss_sum))   # feedback + next step's march on stream B
+    with st.on_comm_stream():
+        # RCCL over xGMI, fp16 sum of the loss-scaled gradients (24.4 MB for lego), stream-ordered: after backward, before Adam
+        dist.all_reduce(st.grads)
     tb.train_nerf_dp_end()
     return c1
 
@@ -120,17 +158,17 @@ def main():
     ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
     tb = scene.build_testbed(ds)
     tb.set_distributed(rank, world)
-    grads = scratch = None
+    dp = None
     if use_dp:
         grads = torch.as_tensor(CudaArray(tb.gradients_ptr(), tb.n_params(), "<f2"), device=dev)
         assert grads.data_ptr() == tb.gradients_ptr()
-        scratch = torch.zeros(3, dtype=torch.float64, device=dev)
+        dp = make_dp_state(torch, dist, tb, grads, dev)
 
     def one_step():
         if not use_dp:
             tb.frame()
             return tb.nerf.training.measured_batch_size
-        dp_step(tb, torch, dist, B, grads, scratch)
+        dp_step(tb, torch, dist, B, dp)
         return tb.nerf.training.measured_batch_size
 
     for _ in range(a.warmup):

@@ -181,6 +181,19 @@ int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out
 	return 0;
 }
 
+__global__ void gather_words_kernel(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst) {
+	if (threadIdx.x == 0) {
+		dst[0] = a ? *a : 0u; dst[1] = b ? *b : 0u; dst[2] = c ? *c : 0u; dst[3] = d ? *d : 0u;
+		__threadfence_system();
+	}
+}
+
+int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst4) {
+	hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, d, dst4);
+	NGP_LAUNCH_CHECK("gather_words_kernel");
+	return 0;
+}
+
 int ngp_hip_grid_to_bitfield_and_pool(void* stream, const float* grid, uint32_t n_cascades_used, const float* mean_density, uint8_t* bitfield) {
 	const uint32_t n = NGP_NERF_GRID_N_CELLS;
 	hipLaunchKernelGGL(grid_to_bitfield_kernel, dim3(div_up(n / 8 * NGP_NERF_CASCADES, 256)), dim3(256), 0, (hipStream_t)stream, n / 8 * NGP_NERF_CASCADES, n / 8 * n_cascades_used, grid, bitfield, mean_density);

@@ -89,7 +89,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("reset_accumulation", [](Testbed& t) { t.m_windowless_render_surface.reset_accumulation(); })
 		// data-parallel extension
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
-		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c); } return py::make_tuple(c[0], c[1]); }, py::arg("batch_size"))
+		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss); } return py::make_tuple(c[0], c[1]); },
+			py::arg("batch_size"), py::arg("get_loss_scalar") = false)
 		.def("train_nerf_dp_backward", &Testbed::train_nerf_dp_backward, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
 		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())
@@ -100,6 +101,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })
 		.def("params_ptr", [](Testbed& t) { return (uintptr_t)t.m_params.data(); })
 		.def("sync", &Testbed::sync)
+		.def("stream_ptr", [](Testbed& t) { return (uintptr_t)t.stream(); })  // hipStream_t of the training stream (torch.cuda.ExternalStream)
 		.def("debug_pointers", [](Testbed& t) {  // dev tooling (tools/microbench.py): device addresses of the training inputs
 				py::dict d;
 				d["bitfield"] = (uintptr_t)t.m_nerf.density_grid_bitfield.data();

@@ -175,6 +175,10 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	(void)hipDeviceSynchronize();
+	if (m_host_words) (void)hipHostFree(m_host_words);
+	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
+	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
@@ -529,7 +533,7 @@ void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  //
 	if (m_nerf.training.n_images_for_training == 0) return;
 	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / _dp_backward / _dp_end around the all-reduces"};
 	uint32_t counters[2];
-	train_nerf_dp_begin(target_batch_size, counters);
+	train_nerf_dp_begin(target_batch_size, counters, get_loss_scalar);
 	const float loss_sum = get_loss_scalar ? local_loss_sum() : 0.f;
 	train_nerf_dp_backward(target_batch_size, counters[0], counters[1], get_loss_scalar, loss_sum);
 	train_nerf_dp_end();
@@ -550,7 +554,8 @@ uint32_t Testbed::next_max_inference(uint32_t target_batch_size) const {  // tes
 
 void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng) {
 	NerfTraining& tr = m_nerf.training;
-	m_ray_indices.enlarge((size_t)R * 4); m_rays.enlarge((size_t)R * sizeof(NgpRay)); m_numsteps.enlarge((size_t)R * 8);
+	const size_t r_cap = std::max<size_t>(R, 1u << 18);  // rays_per_batch is capped at 2^18 (2893): size once, no reallocation under a running step
+	m_ray_indices.enlarge(r_cap * 4); m_rays.enlarge(r_cap * sizeof(NgpRay)); m_numsteps.enlarge(r_cap * 8);
 	m_gen_counters.enlarge(16);
 	uint32_t* counters = m_gen_counters.as<uint32_t>() + 2 * slot;  // [0] ray counter, [1] numsteps counter
 	HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
@@ -581,14 +586,14 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	PrefetchedSamples p;
 	p.valid = true; p.step = next_step; p.R = c.rays_per_batch; p.max_inference = next_max_inference(target_batch_size); p.rng_state = rng.state;
 	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
-	// stream B may only start once stream A has consumed this step's rays / coords (the loss kernel): A is synchronised at this point
+	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the counters event has fired by now
 	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
 	m_prefetch = p;
 }
 
-void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]) {
+void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar) {
 	NerfTraining& tr = m_nerf.training;
 	NerfCounters& c = tr.counters_rgb;
 	if (target_batch_size % 256) throw std::runtime_error{"training batch size must be a multiple of 256"};
@@ -602,7 +607,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes(target_batch_size));
 
 	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)
-	c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge((size_t)R * 4);
+	c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge(std::max<size_t>(R, 1u << 18) * 4);
 	c.numsteps_counter_compacted.memset(0, m_stream);
 	HIP_CHECK_THROW(hipMemsetAsync(c.loss.data(), 0, (size_t)R * 4, (hipStream_t)m_stream));
 	// error map (re)allocation (2933-2939)
@@ -654,31 +659,23 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	profile_end(PK_LOSS, R);
 	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
 	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
-	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
+	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
+	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
+	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
+	// march can be launched (stream B) while they run.
+	const float* loss_sum_dev = nullptr;
+	if (get_loss_scalar) {
+		check(ngp_hip_reduce_sum_f32(m_stream, c.loss.as<float>(), R, m_loss_scalar_gpu.as<float>()), "reduce_sum");
+		loss_sum_dev = m_loss_scalar_gpu.as<float>();
+	}
+	if (!m_host_words) {
+		HIP_CHECK_THROW(hipHostMalloc(&m_host_words, 16, hipHostMallocMapped | hipHostMallocCoherent));
+		hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_counters_event = e;
+	}
+	check(ngp_hip_gather_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, nullptr, (uint32_t*)m_host_words), "gather_words");
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 
-	// NerfCounters::update_after_training reads the two counters (2870-2874): blocking 4-byte D2H copies.  Moved here (they are
-	// final once the loss kernel ran) so that the next step's march can start while this step's backward is still running.
-	sync();
-	HIP_CHECK_THROW(hipMemcpy(&counters_out[0], gen_counters + 1, 4, hipMemcpyDeviceToHost));
-	c.numsteps_counter_compacted.copy_to_host(&counters_out[1], 4);
-}
-
-float Testbed::local_loss_sum() {
-	NerfCounters& c = m_nerf.training.counters_rgb;
-	check(ngp_hip_reduce_sum_f32(m_stream, c.loss.as<float>(), c.rays_per_batch, m_loss_scalar_gpu.as<float>()), "reduce_sum");
-	sync();
-	float v = 0.f;
-	m_loss_scalar_gpu.copy_to_host(&v, 4);
-	return v;
-}
-
-void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum) {
-	// counter feedback first: it fixes the next step's rays_per_batch, which the prefetch needs
-	update_after_training(target_batch_size, global_measured_before, global_measured, get_loss_scalar, global_loss_sum);
-	m_train_continues = m_nerf.training.counters_rgb.measured_batch_size != 0;
-	maybe_prefetch_next(target_batch_size);
 	// ---- train_nerf_step, second half (3324-3332): forward on the compacted batch, backward (gradients overwrite)
-	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	profile_begin(PK_FORWARD);
 	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
 	profile_end(PK_FORWARD, target_batch_size);
@@ -686,7 +683,24 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
 	profile_end(PK_BACKWARD, target_batch_size);
-	if (m_world_size > 1) sync();  // the gradient all-reduce runs on another stream / library
+	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
+
+	HIP_CHECK_THROW(hipEventSynchronize((hipEvent_t)m_counters_event));
+	const volatile uint32_t* w = (const volatile uint32_t*)m_host_words;
+	counters_out[0] = w[0]; counters_out[1] = w[1];
+	uint32_t bits = w[2];
+	memcpy(&m_local_loss_sum, &bits, 4);
+}
+
+float Testbed::local_loss_sum() { return m_local_loss_sum; }  // of the step begun last, if it was begun with get_loss_scalar
+
+void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum) {
+	// counter feedback (it fixes the next step's rays_per_batch), then the next step's march on stream B
+	update_after_training(target_batch_size, global_measured_before, global_measured, get_loss_scalar, global_loss_sum);
+	m_train_continues = m_nerf.training.counters_rgb.measured_batch_size != 0;
+	maybe_prefetch_next(target_batch_size);
+	// the gradient all-reduce must be ordered on stream() after this point (and the optimizer after it): bench.py wraps the stream
+	// as a torch ExternalStream; a caller without stream ordering calls sync() before and after its collective instead
 }
 
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)

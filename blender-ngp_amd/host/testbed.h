@@ -204,10 +204,11 @@ public:
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
 	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)
 	//      -> [all-reduce gradients] -> end (optimizer, bookkeeping)
-	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2]);
+	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar = false);
 	void train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
 	void train_nerf_dp_end();
 	void invalidate_training_inputs();
+	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	uint64_t m_prefetch_hits = 0;
 	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
@@ -293,6 +294,9 @@ private:
 	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };
 	PrefetchedSamples m_prefetch;
 	void* m_prefetch_event = nullptr;
+	void* m_counters_event = nullptr;
+	void* m_host_words = nullptr;                      // 4 pinned, device-mapped words: {numsteps, numsteps_compacted, loss sum, -}
+	float m_local_loss_sum = 0.f;
 	int m_gen_slot = 0;
 	uint64_t m_state_version = 0;
 	bool m_train_continues = true;

@@ -151,6 +151,10 @@ int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uin
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);
 /* tcnn reduce_sum(float*) as used for the loss scalar (:2887): sum of n floats into out (zeroed inside). */
 int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out);
+/* NerfCounters::update_after_training (:2870-2874) reads its counters with blocking 4-byte copies.  This gathers up to four
+ * 32-bit device words (NULL -> 0) into dst4[0..3] in stream order; dst4 may be device memory or host-mapped pinned memory, so the
+ * host can pick the step's counters up from an event instead of draining the stream. */
+int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst4);
 
 /* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,

@@ -120,7 +120,7 @@ class _FakeTestbed:
     def training_prep_nerf(self, B):
         self.calls.append("prep")
 
-    def train_nerf_dp_begin(self, B):
+    def train_nerf_dp_begin(self, B, get_loss=False):
         self.calls.append("begin")
         return self._c
 
@@ -146,8 +146,7 @@ def _dp_step_worker(rank, world, port, result_path):
     for step in (0, 16, 17, 300, 512):
         tb = _FakeTestbed(step, (1000 + rank, 400 + 10 * rank))
         grads = torch.full((8,), float(rank + 1), dtype=torch.float16)
-        scratch = torch.zeros(3, dtype=torch.float64)
-        bench.dp_step(tb, torch, dist, 1 << 18, grads, scratch)
+        bench.dp_step(tb, torch, dist, 1 << 18, bench.DpState(torch, grads, "cpu"))
         log.append((step, tb.calls, grads.tolist()))
     if rank == 0:
         import pickle
