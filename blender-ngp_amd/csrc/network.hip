@@ -136,14 +136,34 @@ __device__ __forceinline__ LevelPos level_pos(const NgpGridLevel& lv, float px, 
 	return p;
 }
 
+// PAIR: the two corners that differ in x only sit in one aligned 8-byte pair whenever their indices differ in bit 0 alone (always for
+// a hashed level at even x, because the x term of the hash is x itself; for a dense level at even index).  One 8-byte load then
+// replaces two 4-byte loads of the same cache line, the second of which would otherwise queue behind the pending miss of the first.
+template <bool PAIR = false>
 __device__ __forceinline__ void encode_level(const NgpGridLevel lv, const h2* __restrict__ grid, float px, float py, float pz, half_t& o0, half_t& o1) {
 	const LevelPos p = level_pos(lv, px, py, pz);
 	h2 v[8];
+	if (!PAIR) {
 #pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		const uint32_t idx = grid_index(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
-		// uniform base + 32-bit per-lane byte offset (the whole table is < 4 GiB): saddr-form global_load_dword
-		v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
+		for (int c = 0; c < 8; ++c) {
+			const uint32_t idx = grid_index(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
+			// uniform base + 32-bit per-lane byte offset (the whole table is < 4 GiB): saddr-form global_load_dword
+			v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
+		}
+	} else {
+#pragma unroll
+		for (int c = 0; c < 8; c += 2) {
+			const uint32_t i0 = grid_index(lv, p.gx, p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
+			const uint32_t i1 = grid_index(lv, p.gx + 1, p.gy + ((c >> 1) & 1), p.gz + ((c >> 2) & 1));
+			if ((i0 ^ i1) == 1u) {   // lv.offset is a multiple of 8 entries: the pair is 8-byte aligned
+				const uint2 pr = *(const uint2*)((const char*)grid + (size_t)((lv.offset + (i0 & ~1u)) * 4u));
+				const uint32_t w0 = (i0 & 1u) ? pr.y : pr.x, w1 = (i0 & 1u) ? pr.x : pr.y;
+				v[c] = __builtin_bit_cast(h2, w0); v[c + 1] = __builtin_bit_cast(h2, w1);
+			} else {
+				v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + i0) * 4u));
+				v[c + 1] = *(const h2*)((const char*)grid + (size_t)((lv.offset + i1) * 4u));
+			}
+		}
 	}
 	float r0 = 0.0f, r1 = 0.0f;
 #pragma unroll
@@ -158,18 +178,20 @@ __device__ __forceinline__ void encode_level(const NgpGridLevel lv, const h2* __
 	o0 = (half_t)r0; o1 = (half_t)r1;
 }
 
+// (measured: 8-byte pair loads cost the fused kernels 15-20 % — more instructions at 2 waves/SIMD — and gain the stand-alone encode 16 %)
+#define NGP_FUSED_PAIR false
 // lane (j, g) encodes levels 8g..8g+7 of its sample: x0 = levels 8g..8g+3, x1 = levels 8g+4..8g+7  (MAP_ENC)
 __device__ __forceinline__ void encode_half(const NgpNetDesc* __restrict__ desc, const h2* __restrict__ grid, int g, float px, float py, float pz, h8& x0, h8& x1) {
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
 		half_t a, b;
-		encode_level(desc->levels[8 * g + m], grid, px, py, pz, a, b);
+		encode_level<NGP_FUSED_PAIR>(desc->levels[8 * g + m], grid, px, py, pz, a, b);
 		x0[2 * m] = a; x0[2 * m + 1] = b;
 	}
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
 		half_t a, b;
-		encode_level(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
+		encode_level<NGP_FUSED_PAIR>(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
 		x1[2 * m] = a; x1[2 * m + 1] = b;
 	}
 }
@@ -248,10 +270,13 @@ __device__ __forceinline__ void mlp_forward(const h8* __restrict__ lt, int lane,
 // ----------------------------------------------------------------------------------------------------------------
 // Fused forward kernel: hash encode -> density MLP -> SH -> rgb MLP.  MODE 0 inference (rgb sigma), 1 density only,
 // 2 training forward (also stores the encoded features for backward).
-template <int MODE>
-__global__ void __launch_bounds__(256, 2) nerf_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
+// PRE = false: fully fused (gathers inside).  PRE = true: the features were produced by encode_planes_kernel into
+// x_planes[level][n_pad] (half2 per sample); the kernel is then the MLP alone and runs at twice the occupancy.
+template <int MODE, bool PRE>
+__global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                            const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                           half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved) {
+                                                           half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved,
+                                                           const h2* __restrict__ x_planes, uint32_t n_pad) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_FWD_TILES * 64];
 	stage_weights(lds_tiles, params, 0, MODE == 1 ? T_W3 : N_FWD_TILES);
 
@@ -265,9 +290,18 @@ __global__ void __launch_bounds__(256, 2) nerf_forward_kernel(const NgpNetDesc* 
 		const uint32_t s = tile * 32 + j;
 		const bool valid = s < n;
 		const float* c = coords + (size_t)(valid ? s : 0) * coord_stride;
-		const float px = c[0], py = c[1], pz = c[2];
 		h8 x0, x1;
-		encode_half(desc, grid, g, px, py, pz, x0, x1);
+		if (PRE) {
+			const h2* xp = x_planes + (size_t)(8 * g) * n_pad + (valid ? s : 0);
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				const h2 a = xp[(size_t)m * n_pad], b = xp[(size_t)(4 + m) * n_pad];
+				x0[2 * m] = a[0]; x0[2 * m + 1] = a[1];
+				x1[2 * m] = b[0]; x1[2 * m + 1] = b[1];
+			}
+		} else {
+			encode_half(desc, grid, g, c[0], c[1], c[2], x0, x1);
+		}
 		if (MODE == 2 && valid) {
 			h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
 			dst[0] = x0; dst[1] = x1;
@@ -285,6 +319,88 @@ __global__ void __launch_bounds__(256, 2) nerf_forward_kernel(const NgpNetDesc* 
 				typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 				h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = (half_t)dd[0];
 				*(h4*)(out + (size_t)s * out_stride) = o;
+			}
+		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// XCD-affine hash encode.  The 11 hashed levels are 2 MiB each (22 MiB together), the L2 of one XCD is 4 MiB: in the fused
+// kernel every XCD touches every level and 60 % of the L2 requests miss (rocprof: TCC_MISS / TCC_REQ), i.e. go over the
+// fabric, whose random-64-B-request rate (~75 G/s chip-wide, tools/gather_probe.hip) is 3.6x below the L2-hit rate (~270 G/s).
+// Here work items are (level, 1024-sample chunk); the level-major item list is cut into 8 cost-balanced queues (hashed level =
+// 2 units, dense = 1), one per XCD, and a persistent workgroup pulls from the queue of the XCD it RUNS on (HW_REG_XCC_ID), so
+// that one XCD walks at most two tables in sequence and its L2 holds them.  Empty queue => steal from the next one.  The
+// placement only affects speed; any block may process any item.
+constexpr uint32_t ENC_CHUNK = 1024;
+constexpr uint32_t ENC_ITEMS_PER_CLAIM = 2;
+constexpr uint32_t ENC_QUEUE_STRIDE = 64;   // uint32 words between the 8 queue counters
+constexpr uint32_t ENC_QUEUE_BYTES = 8 * ENC_QUEUE_STRIDE * 4;
+
+__device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
+
+__global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
+                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues) {
+	__shared__ uint32_t s_first[9];
+	__shared__ uint32_t s_item;
+	const uint32_t n_chunks = (n + ENC_CHUNK - 1) / ENC_CHUNK;
+	if (threadIdx.x < 9) {
+		// queue k = items [first[k], first[k+1]) of the level-major list, cut where the running cost passes k/8 of the total
+		uint32_t cost[16], total = 0;
+		for (int l = 0; l < 16; ++l) {
+			const NgpGridLevel lv = desc->levels[l];
+			const uint64_t dense = (uint64_t)lv.resolution * lv.resolution * lv.resolution;
+			cost[l] = dense > lv.size ? 2u : 1u;
+			total += cost[l] * n_chunks;
+		}
+		const uint32_t target = (uint32_t)((uint64_t)total * threadIdx.x / 8u);
+		uint32_t first = 16u * n_chunks, run = 0;
+		for (int l = 0; l < 16; ++l) {
+			const uint32_t span = cost[l] * n_chunks;
+			if (target < run + span) { first = l * n_chunks + (target - run + cost[l] - 1) / cost[l]; break; }
+			run += span;
+		}
+		s_first[threadIdx.x] = first;
+	}
+	__syncthreads();
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	const uint32_t home = xcc_id();
+	for (uint32_t q = 0; q < 8; ++q) {
+		const uint32_t k = (home + q) & 7u;
+		const uint32_t begin = s_first[k], end = s_first[k + 1];
+		uint32_t* counter = queues + k * ENC_QUEUE_STRIDE;  // one counter per 256-B line: same-address atomics serialise at the memory side
+		const uint32_t n_claims = (end - begin + ENC_ITEMS_PER_CLAIM - 1) / ENC_ITEMS_PER_CLAIM;
+		for (;;) {
+			if (threadIdx.x == 0) {
+				// stealing (q > 0) looks before it claims, so that the 2048 x 7 visits of drained queues stay plain loads
+				uint32_t claim = n_claims;
+				if (q == 0 || __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_claims) claim = atomicAdd(counter, 1u);
+				s_item = claim;
+			}
+			__syncthreads();
+			const uint32_t claim = __builtin_amdgcn_readfirstlane(s_item);
+			__syncthreads();
+			if (claim >= n_claims) break;
+			const uint32_t item0 = begin + claim * ENC_ITEMS_PER_CLAIM;
+			const uint32_t item1 = item0 + ENC_ITEMS_PER_CLAIM < end ? item0 + ENC_ITEMS_PER_CLAIM : end;
+			for (uint32_t item = item0; item < item1; ++item) {
+				const uint32_t level = item / n_chunks, chunk = item - level * n_chunks;
+				const NgpGridLevel lv = desc->levels[level];
+				h2* __restrict__ dst = planes + (size_t)level * n_pad;
+				constexpr int PER_THREAD = ENC_CHUNK / 256;
+				half_t a[PER_THREAD], b[PER_THREAD];
+#pragma unroll
+				for (int u = 0; u < PER_THREAD; ++u) {
+					const uint32_t smp = chunk * ENC_CHUNK + u * 256 + threadIdx.x;
+					const float* c = coords + (size_t)(smp < n ? smp : 0) * coord_stride;
+					encode_level<true>(lv, grid, c[0], c[1], c[2], a[u], b[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < PER_THREAD; ++u) {
+					const uint32_t smp = chunk * ENC_CHUNK + u * 256 + threadIdx.x;
+					h2 v; v[0] = a[u]; v[1] = b[u];
+					if (smp < n) dst[smp] = v;
+				}
 			}
 		}
 	}
@@ -713,6 +829,8 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 	inference[i] = (half_t)filtered;
 }
 
+static uint32_t next_multiple_u32(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
 static int fwd_grid(uint32_t n) {
 	uint32_t tiles = div_up(n, 32);
 	uint32_t blocks = div_up(tiles, 4);
@@ -765,14 +883,14 @@ int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint1
                            uint32_t n, uint16_t* out, uint32_t out_stride) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	hipLaunchKernelGGL(nerf_forward_kernel<0>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr);
+	hipLaunchKernelGGL((nerf_forward_kernel<0, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0>");
 	return 0;
 }
 
 int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0) {
 	if (n == 0) return 0;
-	hipLaunchKernelGGL(nerf_forward_kernel<1>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr);
+	hipLaunchKernelGGL((nerf_forward_kernel<1, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<1>");
 	return 0;
 }
@@ -781,8 +899,58 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
                          uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	hipLaunchKernelGGL(nerf_forward_kernel<2>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
+	hipLaunchKernelGGL((nerf_forward_kernel<2, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
+	return 0;
+}
+
+// ---- two-kernel variants: XCD-affine encode into level planes (workspace), then the MLP kernel
+uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n) { return ENC_QUEUE_BYTES + (uint64_t)16 * next_multiple_u32(n, ENC_CHUNK) * 4u; }
+
+static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, void* workspace, uint64_t workspace_bytes,
+                         const h2** planes_out, uint32_t* n_pad_out, const char* who) {
+	if (!workspace || workspace_bytes < ngp_hip_nerf_encode_workspace_bytes(n)) { set_last_error(who, hipErrorInvalidValue); return -1; }
+	const uint32_t n_pad = next_multiple_u32(n, ENC_CHUNK);
+	uint32_t* queues = (uint32_t*)workspace;
+	h2* planes = (h2*)((char*)workspace + ENC_QUEUE_BYTES);
+	NGP_HIP_TRY(hipMemsetAsync(queues, 0, ENC_QUEUE_BYTES, (hipStream_t)stream));
+	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
+	const uint32_t blocks = items < 2048u ? items : 2048u;  // persistent: 8 workgroups per CU
+	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues);
+	NGP_LAUNCH_CHECK("encode_planes_kernel");
+	*planes_out = planes; *n_pad_out = n_pad;
+	return 0;
+}
+
+int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	const h2* planes; uint32_t n_pad;
+	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_inference_ws: workspace too small")) return -1;
+	hipLaunchKernelGGL((nerf_forward_kernel<0, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, planes, n_pad);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<0, pre>");
+	return 0;
+}
+
+int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0,
+                            void* workspace, uint64_t workspace_bytes) {
+	if (n == 0) return 0;
+	const h2* planes; uint32_t n_pad;
+	if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_density_ws: workspace too small")) return -1;
+	hipLaunchKernelGGL((nerf_forward_kernel<1, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, planes, n_pad);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<1, pre>");
+	return 0;
+}
+
+int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	const h2* planes; uint32_t n_pad;
+	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_forward_ws: workspace too small")) return -1;
+	hipLaunchKernelGGL((nerf_forward_kernel<2, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad);
+	NGP_LAUNCH_CHECK("nerf_forward_kernel<2, pre>");
 	return 0;
 }
 

@@ -507,7 +507,8 @@ void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t
 	                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
 	tr.density_grid_rng.advance();
 	// density pass on the TRAINING weights (use_inference_params = false, testbed_nerf.cu:2833)
-	check(ngp_hip_nerf_density(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>()), "nerf_density");
+	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_samples));
+	check(ngp_hip_nerf_density_ws(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes()), "nerf_density");
 	check(ngp_hip_splat_grid_samples_max(m_stream, n_samples, m_grid_indices.as<uint32_t>(), m_grid_mlp_out.as<uint16_t>(), m_grid_tmp.as<float>(), (int)m_nerf.density_activation), "splat");
 	check(ngp_hip_ema_grid_samples(m_stream, n_elements, decay, grid, m_grid_tmp.as<float>()), "ema");
 	++m_nerf.density_grid_ema_step;
@@ -605,6 +606,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
 	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
 	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes(target_batch_size));
+	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(target_batch_size, next_max_inference(target_batch_size))));
 
 	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)
 	c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge(std::max<size_t>(R, 1u << 18) * 4);
@@ -818,7 +820,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		                                   m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
 		const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 		// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
-		check(ngp_hip_nerf_inference(m_stream, desc, m_inference_params.as<uint16_t>(), m_tr_net_in.as<float>(), 7, n_elements, m_tr_net_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference (render)");
+		m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_elements));
+		check(ngp_hip_nerf_inference_ws(m_stream, desc, m_inference_params.as<uint16_t>(), m_tr_net_in.as<float>(), 7, n_elements, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (render)");
 		m_render_samples_evaluated += n_elements;
 		check(ngp_hip_composite(m_stream, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(),
 		                        m_tr_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");

@@ -307,6 +307,7 @@ private:
 	void drop_prefetch();
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
 	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
+	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
 	DeviceBuffer m_distortion_map;  // 32x32x2 zeros: passed unconditionally to the ray generator
 	DeviceBuffer m_loss_scalar_gpu;

@@ -95,6 +95,17 @@ int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_
  * encoded features x_saved [n][32] fp16 that backward consumes (the tcnn ForwardContext). */
 int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                          uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+/* Two-kernel variants of the three forward passes above (same results, bit for bit): an XCD-affine hash-encode kernel writes the
+ * 32 features of every sample into level planes inside `workspace` (each XCD of the MI355X walks at most two 2-MiB level tables,
+ * so its 4-MiB L2 holds them), then the MLP kernel reads the planes.  Faster whenever n is large enough to fill the chip
+ * (training, occupancy-grid update, render passes); the single-kernel entry points need no workspace. */
+uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n);
+int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes);
+int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
+                            uint32_t n, uint16_t* out0, void* workspace, uint64_t workspace_bytes);
+int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
+                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes);
 
 /* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only. */
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);

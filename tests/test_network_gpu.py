@@ -187,3 +187,38 @@ def test_optimizer_step_bit_exact(ngp, oracle, cuda):
         got = H.to_host(t, dt)
         bad = np.nonzero(got != ref)[0]
         assert bad.size == 0, (name, bad[:5], got[bad[:5]], ref[bad[:5]], H.to_host(d[1], np.float32)[bad[:5]].view(np.uint32), H.to_host(d[5], np.float32)[bad[:5]].view(np.uint32), grads[bad[:5]])
+
+
+# ---- two-kernel (XCD-affine encode + MLP) variants: bit-identical to the single-kernel entry points -------------------------
+@pytest.mark.parametrize("log2,n", [(19, 70001), (15, 4096), (12, 1), (14, 1025)])
+def test_ws_variants_bit_identical(ngp, cuda, log2, n):
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=log2, n=n)
+    ws_bytes = ngp.ngp_hip_nerf_encode_workspace_bytes(n)
+    assert ws_bytes >= 256 + 64 * n
+    ws = H.dev_zeros(ws_bytes, cuda)
+    # inference
+    a, b = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 8, cuda)
+    check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, a.data_ptr(), 4))
+    check(ngp.ngp_hip_nerf_inference_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, b.data_ptr(), 4, ws.data_ptr(), ws_bytes))
+    np.testing.assert_array_equal(H.to_host(a, np.uint16), H.to_host(b, np.uint16))
+    assert H.to_host(a, np.uint16).any()
+    # density only
+    a, b = H.dev_zeros(n * 2 + 2, cuda), H.dev_zeros(n * 2 + 2, cuda)
+    check(ngp.ngp_hip_nerf_density(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, a.data_ptr()))
+    check(ngp.ngp_hip_nerf_density_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, b.data_ptr(), ws.data_ptr(), ws_bytes))
+    np.testing.assert_array_equal(H.to_host(a, np.uint16), H.to_host(b, np.uint16))
+    # training forward: outputs and the saved encoded features
+    a, b = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 8, cuda)
+    xa, xb = H.dev_zeros(n * 64, cuda), H.dev_zeros(n * 64, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, a.data_ptr(), 4, xa.data_ptr()))
+    check(ngp.ngp_hip_nerf_forward_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, b.data_ptr(), 4, xb.data_ptr(), ws.data_ptr(), ws_bytes))
+    np.testing.assert_array_equal(H.to_host(a, np.uint16), H.to_host(b, np.uint16))
+    np.testing.assert_array_equal(H.to_host(xa, np.uint16), H.to_host(xb, np.uint16))
+
+
+def test_ws_rejects_small_workspace(ngp, cuda):
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=12, n=2048)
+    ws = H.dev_zeros(1024, cuda)
+    out = H.dev_zeros(2048 * 8, cuda)
+    assert ngp.ngp_hip_nerf_inference_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, 2048, out.data_ptr(), 4, ws.data_ptr(), 1024) != 0
+    assert b"workspace" in ngp.ngp_hip_last_error()

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Fold two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE, collected separately with --kernel-trace only, CSV output) into
+profiles/pmc_traffic.json: HBM bytes per C-ABI call of each step stage, per the gfx950 recipe in MI355X_MICROARCH.md §HBM
+(unit = KiB; FETCH_SIZE doubled because this rocprofv3 tallies 128-B read requests at 64 B).
+
+usage: pmc_traffic.py <dir with *counter_collection.csv of the FETCH pass> <dir of the WRITE pass> <out.json>
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+# kernel-name substring -> stage (one stage = one ngp_hip_* entry point as bench.py times it)
+STAGES = [("nerf_forward_kernel<0", "nerf_inference"), ("nerf_forward_kernel<2", "nerf_forward"), ("nerf_forward_kernel<1", "nerf_density"),
+          ("nerf_backward_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
+          ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema_kernel", "optimizer_step"),
+          ("generate_training_samples_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
+          ("compute_loss_kernel", "compute_loss")]
+
+
+def per_kernel(d, counter):
+    tot, cnt = {}, {}
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, "no counter_collection.csv under " + d
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            k = row["Kernel_Name"]
+            tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
+            cnt[k] = cnt.get(k, 0) + 1
+    return tot, cnt
+
+
+def main():
+    fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out, detail = {}, {}
+    launches = {}
+    for k in sorted(set(fetch) | set(write)):
+        stage = next((s for sub, s in STAGES if sub in k), None)
+        f_kib = fetch.get(k, 0.0) / max(nf.get(k, 1), 1)
+        w_kib = write.get(k, 0.0) / max(nw.get(k, 1), 1)
+        detail[k[:90]] = {"dispatches": nf.get(k, nw.get(k, 0)), "FETCH_SIZE_KiB_avg": round(f_kib, 1), "WRITE_SIZE_KiB_avg": round(w_kib, 1), "stage": stage}
+        if stage is None:
+            continue
+        # kernels launched once per entry-point call add up; (grid_backward may be launched per level under a dev switch — not in bench runs)
+        out[stage] = out.get(stage, 0.0) + (2.0 * f_kib + w_kib) * 1024.0
+        launches[stage] = launches.get(stage, 0) + 1
+    res = {s: round(v) for s, v in out.items()}
+    res["_method"] = "per call: sum over the stage's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 B, dispatch averages; separate --pmc passes"
+    res["_kernels"] = detail
+    json.dump(res, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
