@@ -182,7 +182,8 @@ __device__ __forceinline__ float distance_to_next_voxel(v3 pos, v3 dir, v3 idir,
 	float ty = (floorf(p.y + 0.5f + 0.5f * signf1(dir.y)) - p.y) * idir.y;
 	float tz = (floorf(p.z + 0.5f + 0.5f * signf1(dir.z)) - p.z) * idir.z;
 	float t = fminf(fminf(tx, ty), tz);
-	return fmaxf(t / r, 0.0f);
+	// r is a power of two (128 >> mip): its reciprocal is exact and built from the exponent bits; t * (1/r) == t / r bit for bit
+	return fmaxf(t * __uint_as_float(0x7f000000u - __float_as_uint(r)), 0.0f);
 }
 __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, v3 pos, v3 dir, v3 idir, uint32_t res) {
 	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
@@ -199,17 +200,9 @@ __device__ __forceinline__ float unwarp_dt(float dt) {
 }
 __device__ __forceinline__ v3 warp_direction(v3 d) { return mk((d.x + 1.0f) * 0.5f, (d.y + 1.0f) * 0.5f, (d.z + 1.0f) * 0.5f); }
 
-// exponent e of frexpf(x) = m * 2^e, m in [0.5, 1), by bit inspection (x >= 0 here); frexp(0) -> 0.
-__device__ __forceinline__ int frexp_exponent(float x) {
-	uint32_t u = __float_as_uint(x) & 0x7fffffffu;
-	if (u == 0) return 0;
-	int e = (int)(u >> 23);
-	if (e == 0) { // subnormal
-		int lz = __clz(u) - 8;
-		return -126 - lz;
-	}
-	return e - 126;
-}
+// exponent e of frexpf(x) = m * 2^e, m in [0.5, 1) (x >= 0 and finite here); frexp(0) -> 0.  v_frexp_exp_i32_f32 is exactly that
+// (f32 denormals are kept in hipcc's default kernel mode).
+__device__ __forceinline__ int frexp_exponent(float x) { return __builtin_amdgcn_frexp_expf(x); }
 __device__ __forceinline__ uint32_t cascaded_grid_idx_at(v3 pos, uint32_t mip) {
 	float mip_scale = __uint_as_float((127u - mip) << 23); // scalbnf(1, -mip)
 	pos.x -= 0.5f; pos.y -= 0.5f; pos.z -= 0.5f;
@@ -221,6 +214,16 @@ __device__ __forceinline__ uint32_t cascaded_grid_idx_at(v3 pos, uint32_t mip) {
 __device__ __forceinline__ bool density_grid_occupied_at(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
 	uint32_t idx = cascaded_grid_idx_at(pos, mip);
 	return bitfield[idx / 8 + (NGP_NERF_GRID_N_CELLS * mip) / 8] & (1u << (idx % 8));
+}
+// The bitfield is in Morton order, so 64 consecutive bits are one 4x4x4 brick of cells.  A marching ray stays inside a brick for
+// several lookups (a brick is ~18 minimum steps across); keeping the last brick in two registers turns most of the dependent
+// 1-byte loads of the serial march into a compare.  Same bit as density_grid_occupied_at, always.
+struct OccBrick { uint32_t id = 0xffffffffu; uint64_t bits = 0; };
+__device__ __forceinline__ bool density_grid_occupied_at(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, OccBrick& cache) {
+	const uint32_t idx = cascaded_grid_idx_at(pos, mip);
+	const uint32_t brick = (idx >> 6) + (NGP_NERF_GRID_N_CELLS / 64u) * mip;
+	if (brick != cache.id) { cache.id = brick; cache.bits = ((const uint64_t*)bitfield)[brick]; }
+	return (cache.bits >> (idx & 63u)) & 1ull;
 }
 __device__ __forceinline__ int mip_from_pos(v3 pos, uint32_t max_cascade = NGP_NERF_CASCADES - 1) {
 	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));

@@ -65,13 +65,14 @@ __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 
 	float dt = calc_dt(t, cone_angle);
 	t += ld_random_val(sample_index, i * 786433u) * dt;
 	v3 pos;
+	OccBrick occ;
 	while (1) {
 		pos = origin + dir * t;
 		if (!aabb_contains(render_aabb, mat3_mul(to_local.m, pos))) { payload.alive = 0; break; }
 		dt = calc_dt(t, cone_angle);
 		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		mip = mip < min_mip ? min_mip : mip;
-		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip)) break;
+		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
 		t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 	}
 	payload.t = t;
@@ -121,6 +122,7 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 	const v3 wd = warp_direction(dir);
 	const float cone_angle = cone_angle_constant;
 	float t = payload.t;
+	OccBrick occ;
 	for (uint32_t j = 0; j < n_steps; ++j) {
 		v3 pos;
 		float dt = 0.0f;
@@ -130,7 +132,7 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 			dt = calc_dt(t, cone_angle);
 			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 			mip = mip < min_mip ? min_mip : mip;
-			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip)) break;
+			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
 			t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
 		const v3 wp = aabb_relative_pos(train_aabb, pos);

@@ -97,10 +97,11 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 			if (a.dev_variant == 3) t = 3.0e38f;
 			uint32_t run_len = 0;   // length of the open run (registers only; LDS is touched once per run)
 			float run_t0 = 0.f;
+			OccBrick occ;
 			while (aabb_contains(a.aabb, pos = ro + rd * t) && j < NGP_NERF_STEPS) {
 				const float dt = calc_dt(t, cone_angle);
 				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
-				if (density_grid_occupied_at(pos, a.density_grid, mip)) {
+				if (density_grid_occupied_at(pos, a.density_grid, mip, occ)) {
 					if (run_len == 0) run_t0 = t;
 					++run_len;
 					++j; t += dt;
@@ -217,10 +218,11 @@ __global__ void __launch_bounds__(256) expand_training_samples_kernel(const Trai
 	float t = startt;
 	v3 pos;
 	uint32_t j = 0;
+	OccBrick occ;
 	while (j < numsteps && aabb_contains(a.aabb, pos = ro + rd * t)) {
 		const float dt = calc_dt(t, cone_angle);
 		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
-		if (density_grid_occupied_at(pos, a.density_grid, mip)) {
+		if (density_grid_occupied_at(pos, a.density_grid, mip, occ)) {
 			const v3 wp = aabb_relative_pos(a.aabb, pos);
 			NgpCoord c;
 			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
