@@ -816,15 +816,23 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		sync();
 		if (n_alive == 0) break;
 		const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), 8u);
+		static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: pass structure on stderr
+		double t_stage[4] = {0, 0, 0, 0};
+		auto stamp = [&](int k) { if (trace) { sync(); t_stage[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
+		stamp(0);
 		check(ngp_hip_generate_next_inputs(m_stream, n_alive, &m_render_aabb, &m_aabb, m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(), n_steps,
 		                                   m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+		stamp(1);
 		const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 		// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
 		m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_elements));
 		check(ngp_hip_nerf_inference_ws(m_stream, desc, m_inference_params.as<uint16_t>(), m_tr_net_in.as<float>(), 7, n_elements, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (render)");
+		stamp(2);
 		m_render_samples_evaluated += n_elements;
 		check(ngp_hip_composite(m_stream, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(),
 		                        m_tr_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");
+		stamp(3);
+		if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u  next_inputs %.0f us  inference %.0f us  composite %.0f us\n", i, n_alive, n_steps, t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2]);
 		i += n_steps;
 	}
 	uint32_t n_hit = 0;
