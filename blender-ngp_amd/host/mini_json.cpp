@@ -1,4 +1,8 @@
 #include "mini_json.h"
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <climits>
 
 #include <cmath>
 #include <cstdio>
@@ -56,7 +60,10 @@ private:
 		char* end = nullptr;
 		double v = std::strtod(start, &end);
 		if (end == start) fail("invalid value");
+		bool integral = true;
+		for (const char* c = start; c < end; ++c) if (*c == '.' || *c == 'e' || *c == 'E') integral = false;
 		p += (size_t)(end - start);
+		if (integral && std::fabs(v) < 9.0e15) return Json((long long)v);
 		return Json(v);
 	}
 	std::string parse_string() {
@@ -177,8 +184,165 @@ std::string Json::dump() const {
 			out += "}";
 			break;
 		}
+		case Binary: out = "\"<binary " + std::to_string(m_bin->size()) + " bytes>\""; break;
 	}
 	return out;
+}
+
+// ---- MessagePack -------------------------------------------------------------------------------------------------------------
+// Writer choices follow nlohmann::json::to_msgpack (what the reference calls): smallest integer format, float32 when the value
+// survives the round trip through float, str8/16/32, bin8/16/32 without ext subtype, maps in key order (std::map, like nlohmann).
+namespace {
+void put_be(std::string& o, uint64_t v, int n) { for (int i = n - 1; i >= 0; --i) o += (char)((v >> (8 * i)) & 0xff); }
+void write_mp(const Json& j, std::string& o);
+void write_str(const std::string& s, std::string& o) {
+	const size_t n = s.size();
+	if (n <= 31) o += (char)(0xa0 | n);
+	else if (n <= 0xff) { o += (char)0xd9; put_be(o, n, 1); }
+	else if (n <= 0xffff) { o += (char)0xda; put_be(o, n, 2); }
+	else { o += (char)0xdb; put_be(o, n, 4); }
+	o += s;
+}
+void write_mp(const Json& j, std::string& o) {
+	switch (j.type()) {
+		case Json::Null: o += (char)0xc0; break;
+		case Json::Bool: o += (char)(j.boolean() ? 0xc3 : 0xc2); break;
+		case Json::Number: {
+			const double d = j.number();
+			if (j.is_integer()) {
+				if (d >= 0) {
+					const uint64_t u = (uint64_t)d;
+					if (u < 128) o += (char)u;
+					else if (u <= 0xff) { o += (char)0xcc; put_be(o, u, 1); }
+					else if (u <= 0xffff) { o += (char)0xcd; put_be(o, u, 2); }
+					else if (u <= 0xffffffffull) { o += (char)0xce; put_be(o, u, 4); }
+					else { o += (char)0xcf; put_be(o, u, 8); }
+				} else {
+					const int64_t i = (int64_t)d;
+					if (i >= -32) o += (char)(int8_t)i;
+					else if (i >= INT8_MIN) { o += (char)0xd0; put_be(o, (uint64_t)i, 1); }
+					else if (i >= INT16_MIN) { o += (char)0xd1; put_be(o, (uint64_t)i, 2); }
+					else if (i >= INT32_MIN) { o += (char)0xd2; put_be(o, (uint64_t)i, 4); }
+					else { o += (char)0xd3; put_be(o, (uint64_t)i, 8); }
+				}
+			} else {
+				const float f = (float)d;
+				if ((double)f == d) { uint32_t u; memcpy(&u, &f, 4); o += (char)0xca; put_be(o, u, 4); }
+				else { uint64_t u; memcpy(&u, &d, 8); o += (char)0xcb; put_be(o, u, 8); }
+			}
+			break;
+		}
+		case Json::String: write_str(j.str(), o); break;
+		case Json::Binary: {
+			const auto& b = j.bin();
+			const size_t n = b.size();
+			if (n <= 0xff) { o += (char)0xc4; put_be(o, n, 1); }
+			else if (n <= 0xffff) { o += (char)0xc5; put_be(o, n, 2); }
+			else if (n <= 0xffffffffull) { o += (char)0xc6; put_be(o, n, 4); }
+			else throw std::runtime_error("msgpack: binary value larger than 4 GiB");
+			o.append((const char*)b.data(), n);
+			break;
+		}
+		case Json::Array: {
+			const size_t n = j.size();
+			if (n <= 15) o += (char)(0x90 | n);
+			else if (n <= 0xffff) { o += (char)0xdc; put_be(o, n, 2); }
+			else { o += (char)0xdd; put_be(o, n, 4); }
+			for (const Json& e : j.elements()) write_mp(e, o);
+			break;
+		}
+		case Json::Object: {
+			const size_t n = j.size();
+			if (n <= 15) o += (char)(0x80 | n);
+			else if (n <= 0xffff) { o += (char)0xde; put_be(o, n, 2); }
+			else { o += (char)0xdf; put_be(o, n, 4); }
+			for (const auto& kv : j.items()) { write_str(kv.first, o); write_mp(kv.second, o); }
+			break;
+		}
+	}
+}
+
+struct MpReader {
+	const uint8_t* d; size_t n, p = 0;
+	void need(size_t k) const { if (p + k > n) throw std::runtime_error("msgpack: unexpected end of input"); }
+	uint64_t be(int k) { need(k); uint64_t v = 0; for (int i = 0; i < k; ++i) v = (v << 8) | d[p++]; return v; }
+	std::string str(size_t k) { need(k); std::string s((const char*)d + p, k); p += k; return s; }
+	Json bin(size_t k) { need(k); Json j = Json::binary(d + p, k); p += k; return j; }
+	Json arr(size_t k) { Json j = Json::array(); for (size_t i = 0; i < k; ++i) j.push_back(value()); return j; }
+	Json map(size_t k) {
+		Json j = Json::object();
+		for (size_t i = 0; i < k; ++i) {
+			Json key = value();
+			if (!key.is_string()) throw std::runtime_error("msgpack: map key is not a string");
+			j[key.str()] = value();
+		}
+		return j;
+	}
+	Json value() {
+		need(1);
+		const uint8_t c = d[p++];
+		if (c <= 0x7f) return Json((long long)c);
+		if (c >= 0xe0) return Json((long long)(int8_t)c);
+		if ((c & 0xf0) == 0x80) return map(c & 0x0f);
+		if ((c & 0xf0) == 0x90) return arr(c & 0x0f);
+		if ((c & 0xe0) == 0xa0) return Json(str(c & 0x1f));
+		switch (c) {
+			case 0xc0: return Json();
+			case 0xc2: return Json(false);
+			case 0xc3: return Json(true);
+			case 0xc4: return bin(be(1));
+			case 0xc5: return bin(be(2));
+			case 0xc6: return bin(be(4));
+			case 0xca: { uint32_t u = (uint32_t)be(4); float f; memcpy(&f, &u, 4); return Json((double)f); }
+			case 0xcb: { uint64_t u = be(8); double f; memcpy(&f, &u, 8); return Json(f); }
+			case 0xcc: return Json((long long)be(1));
+			case 0xcd: return Json((long long)be(2));
+			case 0xce: return Json((long long)be(4));
+			case 0xcf: return Json((unsigned long long)be(8));
+			case 0xd0: return Json((long long)(int8_t)be(1));
+			case 0xd1: return Json((long long)(int16_t)be(2));
+			case 0xd2: return Json((long long)(int32_t)be(4));
+			case 0xd3: return Json((long long)(int64_t)be(8));
+			case 0xd9: return Json(str(be(1)));
+			case 0xda: return Json(str(be(2)));
+			case 0xdb: return Json(str(be(4)));
+			case 0xdc: return arr(be(2));
+			case 0xdd: return arr(be(4));
+			case 0xde: return map(be(2));
+			case 0xdf: return map(be(4));
+			default: throw std::runtime_error("msgpack: unsupported type byte (ext / reserved)");
+		}
+	}
+};
+} // namespace
+
+std::string Json::to_msgpack() const { std::string o; write_mp(*this, o); return o; }
+
+Json Json::from_msgpack(const void* data, size_t n_bytes) {
+	MpReader r{(const uint8_t*)data, n_bytes};
+	Json j = r.value();
+	if (r.p != n_bytes) throw std::runtime_error("msgpack: trailing bytes after the top-level value");
+	return j;
+}
+
+Json Json::from_msgpack_file(const std::string& path) {
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) throw std::runtime_error("cannot open " + path);
+	std::string buf;
+	char tmp[1 << 16];
+	size_t k;
+	while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.append(tmp, k);
+	fclose(f);
+	return from_msgpack(buf.data(), buf.size());
+}
+
+void Json::to_msgpack_file(const std::string& path) const {
+	const std::string o = to_msgpack();
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) throw std::runtime_error("cannot write " + path);
+	const size_t k = fwrite(o.data(), 1, o.size(), f);
+	fclose(f);
+	if (k != o.size()) throw std::runtime_error("short write to " + path);
 }
 
 void Json::merge_patch(const Json& patch) {

@@ -1,7 +1,9 @@
 // mini_json — the small JSON subset the host needs (the reference takes nlohmann::json from inside tiny-cuda-nn's dependencies,
-// which are absent).  Supports // and /* */ comments like load_network_config (src/testbed.cu:120-145)
-// and RFC 7386 merge_patch for the recursive "parent" inheritance (src/testbed.cu:77-88).
+// which are absent).  Supports // and /* */ comments like load_network_config (src/testbed.cu:120-145),
+// RFC 7386 merge_patch for the recursive "parent" inheritance (src/testbed.cu:77-88), binary values and the MessagePack
+// encoding that `.msgpack` snapshots use (json::to_msgpack / from_msgpack, src/testbed.cu:3041, 139).
 #pragma once
+#include <cstdint>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -12,15 +14,32 @@ namespace ngp {
 
 class Json {
 public:
-	enum Type { Null, Bool, Number, String, Array, Object };
+	enum Type { Null, Bool, Number, String, Array, Object, Binary };
 	Json() : m_type(Null) {}
 	Json(bool b) : m_type(Bool), m_bool(b) {}
 	Json(double d) : m_type(Number), m_num(d) {}
-	Json(int d) : m_type(Number), m_num(d) {}
+	Json(int d) : m_type(Number), m_num(d), m_is_int(true) {}
+	Json(unsigned d) : m_type(Number), m_num(d), m_is_int(true) {}
+	Json(long d) : m_type(Number), m_num((double)d), m_is_int(true) {}
+	Json(unsigned long d) : m_type(Number), m_num((double)d), m_is_int(true) {}
+	Json(long long d) : m_type(Number), m_num((double)d), m_is_int(true) {}
+	Json(unsigned long long d) : m_type(Number), m_num((double)d), m_is_int(true) {}
 	Json(const std::string& s) : m_type(String), m_str(s) {}
 	Json(const char* s) : m_type(String), m_str(s) {}
 	static Json array() { Json j; j.m_type = Array; return j; }
 	static Json object() { Json j; j.m_type = Object; return j; }
+	static Json binary(const void* data, size_t n_bytes) {
+		Json j; j.m_type = Binary;
+		j.m_bin = std::make_shared<std::vector<uint8_t>>((const uint8_t*)data, (const uint8_t*)data + n_bytes);
+		return j;
+	}
+	static Json integer(long long v) { return Json(v); }
+
+	// MessagePack (the subset nlohmann::json emits: nil, bool, ints, float32/64, str, bin, array, map with string keys)
+	std::string to_msgpack() const;
+	static Json from_msgpack(const void* data, size_t n_bytes);
+	static Json from_msgpack_file(const std::string& path);
+	void to_msgpack_file(const std::string& path) const;
 
 	static Json parse(const std::string& text);
 	static Json parse_file(const std::string& path);
@@ -33,6 +52,9 @@ public:
 	bool is_number() const { return m_type == Number; }
 	bool is_string() const { return m_type == String; }
 	bool is_bool() const { return m_type == Bool; }
+	bool is_binary() const { return m_type == Binary; }
+	bool is_integer() const { return m_type == Number && m_is_int; }
+	const std::vector<uint8_t>& bin() const { if (m_type != Binary) throw std::runtime_error("json: not a binary value"); return *m_bin; }
 
 	bool contains(const std::string& key) const { return m_type == Object && m_obj.count(key) > 0; }
 	Json& operator[](const std::string& key) { if (m_type == Null) m_type = Object; if (m_type != Object) throw std::runtime_error("json: not an object"); return m_obj[key]; }
@@ -62,6 +84,8 @@ private:
 	Type m_type;
 	bool m_bool = false;
 	double m_num = 0.0;
+	bool m_is_int = false;   // written as a MessagePack integer / parsed from an integer literal
+	std::shared_ptr<std::vector<uint8_t>> m_bin;
 	std::string m_str;
 	std::vector<Json> m_arr;
 	std::map<std::string, Json> m_obj;

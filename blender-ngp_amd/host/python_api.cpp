@@ -6,6 +6,7 @@
 #include <pybind11/stl.h>
 
 #include "testbed.h"
+#include "snapshot.h"
 
 namespace py = pybind11;
 using namespace ngp;
@@ -13,9 +14,10 @@ using namespace ngp;
 static Json json_from_py(const py::handle& o) {
 	if (o.is_none()) return Json();
 	if (py::isinstance<py::bool_>(o)) return Json(o.cast<bool>());
-	if (py::isinstance<py::int_>(o)) return Json((double)o.cast<long long>());
+	if (py::isinstance<py::int_>(o)) return Json(o.cast<long long>());
 	if (py::isinstance<py::float_>(o)) return Json(o.cast<double>());
 	if (py::isinstance<py::str>(o)) return Json(o.cast<std::string>());
+	if (py::isinstance<py::bytes>(o)) { const std::string b = o.cast<std::string>(); return Json::binary(b.data(), b.size()); }
 	if (py::isinstance<py::dict>(o)) {
 		Json j = Json::object();
 		for (auto kv : py::reinterpret_borrow<py::dict>(o)) j[kv.first.cast<std::string>()] = json_from_py(kv.second);
@@ -27,6 +29,18 @@ static Json json_from_py(const py::handle& o) {
 		return j;
 	}
 	throw std::runtime_error{"unsupported type in network config json"};
+}
+
+static py::object json_to_py(const Json& j) {
+	switch (j.type()) {
+		case Json::Null: return py::none();
+		case Json::Bool: return py::bool_(j.boolean());
+		case Json::Number: if (j.is_integer()) return py::int_((long long)j.number()); return py::float_(j.number());
+		case Json::String: return py::str(j.str());
+		case Json::Binary: return py::bytes((const char*)j.bin().data(), j.bin().size());
+		case Json::Array: { py::list l; for (const Json& e : j.elements()) l.append(json_to_py(e)); return l; }
+		default: { py::dict d; for (const auto& kv : j.items()) d[py::str(kv.first)] = json_to_py(kv.second); return d; }
+	}
 }
 
 static Mat34 mat34_from_py(const py::array_t<float, py::array::c_style | py::array::forcecast>& a) {
@@ -58,6 +72,19 @@ PYBIND11_MODULE(pyngp, m) {
 	py::enum_<ETonemapCurve>(m, "TonemapCurve").value("Identity", ETonemapCurve::Identity).value("ACES", ETonemapCurve::ACES).value("Hable", ETonemapCurve::Hable)
 		.value("Reinhard", ETonemapCurve::Reinhard).export_values();
 
+	// MessagePack codec of the snapshot files (json::to_msgpack / from_msgpack in the reference): exposed for tests and tooling
+	m.def("json_to_msgpack", [](const py::object& o) { const std::string b = json_from_py(o).to_msgpack(); return py::bytes(b); });
+	m.def("msgpack_to_json", [](const py::bytes& b) { const std::string s = b; return json_to_py(Json::from_msgpack(s.data(), s.size())); });
+	m.def("float_to_half_bits", [](const py::array_t<float, py::array::c_style | py::array::forcecast>& a) {
+		py::array_t<uint16_t> r(a.size());
+		for (py::ssize_t i = 0; i < a.size(); ++i) r.mutable_data()[i] = float_to_half_bits(a.data()[i]);
+		return r;
+	});
+	m.def("half_bits_to_float", [](const py::array_t<uint16_t, py::array::c_style | py::array::forcecast>& a) {
+		py::array_t<float> r(a.size());
+		for (py::ssize_t i = 0; i < a.size(); ++i) r.mutable_data()[i] = half_bits_to_float(a.data()[i]);
+		return r;
+	});
 	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
 	m.def("device_memory_allocated", []() { return DeviceBuffer::total_allocated(); });
 

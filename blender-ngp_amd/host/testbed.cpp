@@ -1,5 +1,6 @@
 // testbed.cpp — see testbed.h.  Host orchestration only: every device-side computation goes through include/ngp_hip.h.
 #include "testbed.h"
+#include "snapshot.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -309,17 +310,8 @@ void Testbed::load_nerf_post() {
 }
 
 // ---- network config ---------------------------------------------------------------------------------------------
-Json Testbed::load_network_config(const std::string& path) {  // testbed.cu:120-145 (json only; msgpack snapshots = row f1)
-	Json result = Json::parse_file(path);
-	while (result.contains("parent")) {  // merge_parent_network_config (testbed.cu:77-88)
-		std::string parent = result["parent"].str();
-		std::string base = path.substr(0, path.find_last_of("/\\") + 1);
-		Json p = Json::parse_file(base + parent);
-		result.erase("parent");
-		p.merge_patch(result);
-		result = p;
-	}
-	return result;
+Json Testbed::load_network_config(const std::string& path) {  // testbed.cu:120-145
+	return load_config_or_snapshot(path);
 }
 void Testbed::reload_network_from_file(const std::string& path) {
 	if (!path.empty()) m_network_config_path = path;
@@ -842,11 +834,154 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	                    rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>()), "shade");
 }
 
-void Testbed::save_snapshot(const std::string&, bool) {
-	throw std::runtime_error{"save_snapshot: .msgpack snapshot compatibility is SURVEY.md §8f row f1 (next)"};
+// ---- snapshots (testbed.cu:3006-3106; schema in snapshot.h) ---------------------------------------------------------------
+static Json buffer_to_json_binary(const DeviceBuffer& b, size_t bytes) {
+	std::vector<uint8_t> host(bytes);
+	if (bytes) b.copy_to_host(host.data(), bytes);
+	return Json::binary(host.data(), host.size());
 }
-void Testbed::load_snapshot(const std::string&) {
-	throw std::runtime_error{"load_snapshot: .msgpack snapshot compatibility is SURVEY.md §8f row f1 (next)"};
+
+void Testbed::save_snapshot(const std::string& path, bool include_optimizer_state) {
+	if (m_n_params == 0) throw std::runtime_error{"save_snapshot: no network"};
+	drop_prefetch();
+	sync();
+	Json snapshot = Json::object();
+	// Trainer::serialize [tcnn]: the inference (EMA) weights in the network precision
+	snapshot["n_params"] = Json((unsigned long long)m_n_params);
+	snapshot["params_type"] = Json("__half");
+	snapshot["params_binary"] = buffer_to_json_binary(m_inference_params, m_n_params * 2);
+	if (include_optimizer_state) {
+		// Ema o ExponentialDecay o Adam, nested like the config (configs/nerf/base.json:5-22)
+		Json adam = Json::object();
+		adam["otype"] = Json("Adam");
+		adam["current_step"] = Json(m_optimizer_step);
+		adam["base_learning_rate"] = Json((double)m_base_learning_rate);
+		adam["first_moments_binary"] = buffer_to_json_binary(m_first_moments, m_n_params * 4);
+		adam["second_moments_binary"] = buffer_to_json_binary(m_second_moments, m_n_params * 4);
+		Json decay = Json::object();
+		decay["otype"] = Json("ExponentialDecay");
+		decay["learning_rate"] = Json((double)m_learning_rate);
+		decay["nested"] = adam;
+		Json ema = Json::object();
+		ema["otype"] = Json("Ema");
+		ema["ema_step"] = Json(m_optimizer_step);
+		ema["ema_binary"] = buffer_to_json_binary(m_ema, m_n_params * 4);
+		ema["nested"] = decay;
+		// full-precision master weights and the training (non-EMA) fp16 weights, so that a resumed run continues exactly
+		ema["params_full_precision_binary"] = buffer_to_json_binary(m_master, m_n_params * 4);
+		snapshot["optimizer"] = ema;
+	}
+	snapshot["version"] = Json(1);
+	snapshot["density_grid_size"] = Json((unsigned)NGP_NERF_GRIDSIZE);
+	{
+		const size_t n_cells = m_nerf.density_grid.bytes() / 4;
+		std::vector<float> grid(n_cells);
+		if (n_cells) m_nerf.density_grid.copy_to_host(grid.data(), n_cells * 4);
+		std::vector<uint16_t> grid_fp16(n_cells);
+		for (size_t i = 0; i < n_cells; ++i) grid_fp16[i] = float_to_half_bits(grid[i]);
+		snapshot["density_grid_binary"] = Json::binary(grid_fp16.data(), n_cells * 2);
+	}
+	Json nerf = Json::object();
+	nerf["aabb_scale"] = Json(m_nerf.training.dataset.aabb_scale);
+	Json rgb = Json::object();
+	const NerfCounters& c = m_nerf.training.counters_rgb;
+	rgb["rays_per_batch"] = Json(c.rays_per_batch);
+	rgb["measured_batch_size"] = Json(c.measured_batch_size);
+	rgb["measured_batch_size_before_compaction"] = Json(c.measured_batch_size_before_compaction);
+	nerf["rgb"] = rgb;
+	nerf["dataset"] = dataset_to_json(m_nerf.training.dataset);
+	snapshot["nerf"] = nerf;
+	snapshot["training_step"] = Json(m_training_step);
+	snapshot["loss"] = Json((double)m_loss_scalar);
+	snapshot["aabb"] = aabb_to_json(m_aabb);
+	snapshot["bounding_radius"] = Json((double)m_bounding_radius);
+
+	m_network_config["snapshot"] = snapshot;
+	m_network_config_path = path;
+	m_network_config.to_msgpack_file(path);
+}
+
+void Testbed::load_snapshot(const std::string& path) {
+	Json config = load_network_config(path);
+	if (!config.contains("snapshot")) throw std::runtime_error{"File " + path + " does not contain a snapshot."};
+	const Json& snapshot = config["snapshot"];
+	if (snapshot.value("version", 0) < 1) throw std::runtime_error{"Snapshot uses an old format."};
+	if (snapshot.contains("aabb")) m_aabb = aabb_from_json(snapshot["aabb"]);
+	m_bounding_radius = (float)snapshot.value("bounding_radius", (double)m_bounding_radius);
+	if ((uint32_t)snapshot.at("density_grid_size").number() != NGP_NERF_GRIDSIZE) throw std::runtime_error{"Incompatible grid size."};
+
+	NerfTraining& tr = m_nerf.training;
+	NerfCounters& c = tr.counters_rgb;
+	const Json& rgb = snapshot.at("nerf").at("rgb");
+	const uint32_t rays_per_batch = (uint32_t)rgb.at("rays_per_batch").number();
+	const uint32_t measured = (uint32_t)rgb.at("measured_batch_size").number();
+	const uint32_t measured_before = (uint32_t)rgb.at("measured_batch_size_before_compaction").number();
+
+	// without a dataset of our own, take the metadata from the snapshot and render from that alone (3071-3078)
+	if (!m_training_data_available && snapshot["nerf"].contains("dataset")) {
+		dataset_from_json(snapshot["nerf"]["dataset"], tr.dataset);
+	} else if (snapshot["nerf"].contains("aabb_scale")) {
+		tr.dataset.aabb_scale = (int)snapshot["nerf"]["aabb_scale"].number();
+	}
+	load_nerf_post();
+	if (!m_training_data_available) { tr.n_images_for_training = 0; m_train = false; }  // metadata only: no pixels to train on
+
+	std::vector<float> grid;
+	snapshot_read_density_grid(snapshot, grid);
+	const size_t expected = (size_t)GRID_CELLS * (m_nerf.max_cascade + 1);
+	if (grid.size() != expected && !grid.empty()) throw std::runtime_error{"Incompatible number of grid cascades."};
+
+	m_network_config_path = path;
+	m_network_config = config;
+	reset_network(false);
+	c.rays_per_batch = rays_per_batch; c.measured_batch_size = measured; c.measured_batch_size_before_compaction = measured_before;
+
+	m_nerf.density_grid.resize(expected * 4);
+	m_nerf.density_grid_bitfield.resize((size_t)GRID_CELLS);
+	m_nerf.density_grid_mean.resize(4);
+	if (!grid.empty()) {
+		m_nerf.density_grid.copy_from_host(grid.data(), grid.size() * 4);
+		update_density_grid_mean_and_bitfield();
+	} else {
+		m_nerf.density_grid.memset(0, m_stream); m_nerf.density_grid_bitfield.memset(0, m_stream); m_nerf.density_grid_mean.memset(0, m_stream);
+	}
+
+	m_training_step = (uint32_t)snapshot.at("training_step").number();
+	m_loss_scalar = (float)snapshot.at("loss").number();
+
+	// Trainer::deserialize [tcnn]
+	std::vector<uint16_t> p16; std::vector<float> p32;
+	snapshot_read_params(snapshot, p16, p32);
+	if (p16.size() != m_n_params) throw std::runtime_error{"Snapshot has " + std::to_string(p16.size()) + " parameters, the network config needs " + std::to_string(m_n_params) + "."};
+	m_params.copy_from_host(p16.data(), m_n_params * 2);
+	m_inference_params.copy_from_host(p16.data(), m_n_params * 2);
+	m_master.copy_from_host(p32.data(), m_n_params * 4);
+	if (snapshot.contains("optimizer")) {
+		const Json* o = &snapshot["optimizer"];
+		while (true) {
+			const std::string otype = o->value("otype", "");
+			if (otype == "Ema") {
+				if (o->contains("ema_binary") && o->at("ema_binary").bin().size() == m_n_params * 4) m_ema.copy_from_host(o->at("ema_binary").bin().data(), m_n_params * 4);
+				if (o->contains("params_full_precision_binary") && o->at("params_full_precision_binary").bin().size() == m_n_params * 4) {
+					const std::vector<uint8_t>& mb = o->at("params_full_precision_binary").bin();
+					m_master.copy_from_host(mb.data(), m_n_params * 4);
+					std::vector<uint16_t> train16(m_n_params);
+					const float* mf = (const float*)mb.data();
+					for (size_t i = 0; i < m_n_params; ++i) train16[i] = float_to_half_bits(mf[i]);
+					m_params.copy_from_host(train16.data(), m_n_params * 2);
+				}
+			} else if (otype == "ExponentialDecay") {
+				m_learning_rate = (float)o->value("learning_rate", (double)m_learning_rate);
+			} else if (otype == "Adam") {
+				m_optimizer_step = (uint32_t)o->value("current_step", 0);
+				if (o->contains("first_moments_binary") && o->at("first_moments_binary").bin().size() == m_n_params * 4) m_first_moments.copy_from_host(o->at("first_moments_binary").bin().data(), m_n_params * 4);
+				if (o->contains("second_moments_binary") && o->at("second_moments_binary").bin().size() == m_n_params * 4) m_second_moments.copy_from_host(o->at("second_moments_binary").bin().data(), m_n_params * 4);
+			}
+			if (!o->contains("nested")) break;
+			o = &o->at("nested");
+		}
+	}
+	sync();
 }
 
 } // namespace ngp

@@ -83,6 +83,7 @@ struct Pcg32 {
 struct NerfDataset {
 	size_t n_images = 0;
 	std::vector<NgpXForm> xforms;
+	std::vector<std::string> paths;              // image paths, carried through snapshots (json_binding.h:133)
 	std::vector<NgpImageMeta> metadata;          // host copy; .pixels are device pointers into pixelmemory
 	std::vector<DeviceBuffer> pixelmemory;
 	DeviceBuffer metadata_gpu;
@@ -242,6 +243,7 @@ public:
 	uint64_t m_seed = 1337;                             // testbed.h:567
 	Pcg32 m_rng;
 	NgpAabb m_aabb{}, m_raw_aabb{}, m_render_aabb{};
+	float m_bounding_radius = 1.0f;                    // testbed.h:556 (snapshot field)
 	float m_render_aabb_to_local[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	float m_background_color[4] = {0.f, 0.f, 0.f, 1.f}; // testbed.h:875
 	EColorSpace m_color_space = EColorSpace::Linear;
