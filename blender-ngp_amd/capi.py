@@ -123,5 +123,19 @@ IMAGE_META = np.dtype([
 GRID_LEVEL = np.dtype([("scale", "<f4"), ("resolution", "<u4"), ("offset", "<u4"), ("size", "<u4")])
 NET_DESC = np.dtype([("n_levels", "<u4"), ("n_grid_entries", "<u4"), ("levels", GRID_LEVEL, 16)])
 
+# Blender multi-NeRF renderer records (include/ngp_hip.h)
+GLOBAL_RAY = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("rgba", "<f4", 4), ("idx", "<u4"), ("depth", "<f4"), ("alive", "u1"), ("pad", "u1", 3)])
+PROXY_RAY = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("t", "<f4"), ("idx", "<u4"), ("n_steps", "<u2"), ("alive", "u1"), ("active", "u1"), ("mask_alpha", "<f4")])
+MASK3D = np.dtype([("mode", "<i4"), ("shape", "<i4"), ("transform", "<f4", 16), ("itransform", "<f4", 16), ("config", "<f4", 6), ("feather", "<f4"), ("opacity", "<f4")])
+NERF_PROPS = np.dtype([
+    ("transform", "<f4", 16), ("itransform", "<f4", 16), ("density_grid_bitfield", "<u8"), ("grid_size", "<u4"), ("grid_volume", "<u4"),
+    ("render_aabb", AABB), ("train_aabb", AABB), ("masks", "<u8"), ("n_masks", "<u4"), ("cone_angle", "<f4"), ("min_cone_stepsize", "<f4"),
+    ("max_cone_stepsize", "<f4"), ("nerf_cascades", "<u4"), ("opacity", "<f4")], align=True)
+DOWNSAMPLE_INFO = np.dtype([("max_res", "<i4", 2), ("scaled_res", "<i4", 2), ("skip", "<i4", 2), ("max_pixels", "<u4"), ("scaled_pixels", "<u4")])
+RENDER_CAMERA = np.dtype([("transform", "<f4", 12), ("model", "<i4"), ("focal_length", "<f4"), ("sq_width", "<f4"), ("sq_height", "<f4"), ("sq_curvature", "<f4"),
+                          ("qh_front", "<f4", 12), ("qh_back", "<f4", 12), ("near_distance", "<f4"), ("aperture_size", "<f4"), ("focus_z", "<f4")])
+assert GLOBAL_RAY.itemsize == 52 and PROXY_RAY.itemsize == 40 and MASK3D.itemsize == 168 and NERF_PROPS.itemsize == 224
+assert DOWNSAMPLE_INFO.itemsize == 32 and RENDER_CAMERA.itemsize == 176
+
 assert AABB.itemsize == 24 and RAY.itemsize == 24 and XFORM.itemsize == 96 and COORD.itemsize == 28 and PAYLOAD.itemsize == 40
 assert NET_DESC.itemsize == 8 + 16 * 16

@@ -1,0 +1,513 @@
+// multi_render.hip — the Blender add-on's multi-NeRF renderer kernels for gfx950.
+// Replaces src/nerf_renderer.cu:17-563 (init_global_rays, init_proxy_rays, hit_test_and_march, compact_rays, march_active_rays,
+// march_proxy_rays_and_generate_next_network_inputs, cull_global_rays_and_set_proxy_rays_active, composite_proxy_ray_colors,
+// shade_buffer_with_rays), src/nerf_utils.cu (runtime-parameter marching helpers), include/.../nerf/mask_3D.cuh (SDF masks) and
+// include/.../camera_models.cuh (perspective / spherical-quadrilateral / quadrilateral-hexahedron cameras).
+// One thread per ray like the reference; compaction uses wave64 ballots (one atomic per wave and counter).
+#include "ngp_device.cuh"
+
+namespace ngp {
+
+// ---- 4x4 column-major helpers (Eigen: M * p.homogeneous() accumulates column by column)
+__device__ __forceinline__ v3 xform_point(const float* m, v3 p) {
+	return mk(((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12], ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13], ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14]);
+}
+__device__ __forceinline__ v3 xform_dir(const float* m, v3 d) {
+	return mk((m[0] * d.x + m[4] * d.y) + m[8] * d.z, (m[1] * d.x + m[5] * d.y) + m[9] * d.z, (m[2] * d.x + m[6] * d.y) + m[10] * d.z);
+}
+__device__ __forceinline__ Aabb aabb_of(const NgpAabb& a) { Aabb b; b.mn = ld3(a.min); b.mx = ld3(a.max); return b; }
+
+// ---- nerf_utils.cu
+__device__ __forceinline__ float get_dt(float t, float cone_angle, float min_step, float max_step) { return clampf(t * cone_angle, min_step, max_step); }
+__device__ __forceinline__ int get_mip_from_dt(float dt, v3 pos, uint32_t grid_size, uint32_t max_cascade) {
+	int mip = mip_from_pos(pos, max_cascade);
+	dt *= (float)(2u * grid_size);
+	if (dt < 1.f) return mip;
+	const int e = frexp_exponent(dt);
+	const int m = e > mip ? e : mip;
+	return (int)max_cascade < m ? (int)max_cascade : m;
+}
+__device__ __forceinline__ uint32_t get_cascaded_grid_idx_at(v3 pos, uint32_t mip, uint32_t grid_size) {
+	const float mip_scale = __uint_as_float((127u - mip) << 23);
+	pos.x -= 0.5f; pos.y -= 0.5f; pos.z -= 0.5f;
+	pos.x *= mip_scale; pos.y *= mip_scale; pos.z *= mip_scale;
+	pos.x += 0.5f; pos.y += 0.5f; pos.z += 0.5f;
+	const float g = (float)grid_size;
+	const int ix = (int)(pos.x * g), iy = (int)(pos.y * g), iz = (int)(pos.z * g);
+	const int hi = (int)grid_size - 1;
+	return morton3D((uint32_t)clampi(ix, 0, hi), (uint32_t)clampi(iy, 0, hi), (uint32_t)clampi(iz, 0, hi));
+}
+__device__ __forceinline__ bool get_is_occupied(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, uint32_t grid_size, uint32_t grid_volume) {
+	const uint32_t idx = get_cascaded_grid_idx_at(pos, mip, grid_size);
+	return bitfield[idx / 8 + (grid_volume * mip) / 8] & (1u << (idx % 8));
+}
+__device__ __forceinline__ float get_t_advanced_to_next_voxel(float t, float cone_angle, v3 pos, v3 dir, v3 idir, uint32_t res, float min_step, float max_step) {
+	const float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
+	do { t += get_dt(t, cone_angle, min_step, max_step); } while (t < t_target);
+	return t;
+}
+__device__ __forceinline__ float get_warped_dt(float dt, float min_step, uint32_t nerf_cascades) {
+	const float max_stepsize = min_step * (float)(1u << (nerf_cascades - 1));
+	return (dt - min_step) / (max_stepsize - min_step);
+}
+__device__ __forceinline__ float get_unwarped_dt(float dt, float min_step, uint32_t nerf_cascades) {
+	const float max_stepsize = min_step * (float)(1u << (nerf_cascades - 1));
+	return dt * (max_stepsize - min_step) + min_step;
+}
+
+// ---- mask_3D.cuh
+__device__ __forceinline__ float sdf_box(v3 p, v3 b) {
+	const v3 d = mk(fabsf(p.x) - 0.5f * b.x, fabsf(p.y) - 0.5f * b.y, fabsf(p.z) - 0.5f * b.z);
+	const v3 dm = mk(fmaxf(d.x, 0.0f), fmaxf(d.y, 0.0f), fmaxf(d.z, 0.0f));
+	return norm(dm) + fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f);
+}
+__device__ __forceinline__ float sdf_cylinder(v3 p, float r, float h) {
+	const float dx = fabsf(sqrtf(p.y * p.y + p.x * p.x)) - r, dy = fabsf(p.z) - 0.5f * h;
+	const float mx = fmaxf(dx, 0.0f), my = fmaxf(dy, 0.0f);
+	return sqrtf(mx * mx + my * my) + fminf(fmaxf(dx, dy), 0.0f);
+}
+__device__ __forceinline__ float mask_signed_distance(const NgpMask3D& m, v3 p) {
+	const v3 pl = xform_point(m.itransform, p);
+	float d = 0.0f;
+	switch (m.shape) {
+		case 0: d = sdf_box(pl, mk(m.config[0], m.config[1], m.config[2])); break;
+		case 1: d = sdf_cylinder(pl, m.config[0], m.config[1]); break;
+		case 2: d = norm(pl) - m.config[0]; break;
+		default: d = -1.0f; break;
+	}
+	return d * (m.mode == 0 ? 1.0f : -1.0f);
+}
+__device__ __forceinline__ float mask_sample(const NgpMask3D& m, v3 p) {
+	const float k = m.mode == 0 ? 1.0f : -1.0f;
+	if (m.shape == 3) return k;
+	const float d = mask_signed_distance(m, p);
+	float alpha;
+	if (m.feather == 0.0f) alpha = d < 0.0f ? 1.0f : 0.0f;
+	else alpha = clampf(0.5f - d / m.feather, 0.0f, 1.0f);
+	return m.opacity * alpha * k;
+}
+__device__ __forceinline__ bool ray_intersects_box(v3 o, v3 d, v3 size) {
+	const v3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const v3 t0 = mk((-0.5f * size.x - o.x) * inv.x, (-0.5f * size.y - o.y) * inv.y, (-0.5f * size.z - o.z) * inv.z);
+	const v3 t1 = mk((0.5f * size.x - o.x) * inv.x, (0.5f * size.y - o.y) * inv.y, (0.5f * size.z - o.z) * inv.z);
+	const float tmin = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+	const float tmax = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+	return tmin <= tmax;
+}
+__device__ __forceinline__ bool ray_intersects_sphere(v3 o, v3 d, float radius) {
+	const float od = dot(d, o);
+	const float a = od * od;   // powf(x, 2)
+	const float b = dot(o, o) - radius * radius;
+	return !((a - b) < 0.0f);
+}
+__device__ __forceinline__ bool intersect_plane_ray(v3 o, v3 d, v3 n, v3 p, float& t) {
+	const float denom = dot(n, d);
+	if (denom > 1e-6f) { t = dot(p - o, n) / denom; return t >= 0.0f; }
+	return false;
+}
+__device__ __forceinline__ bool ray_intersects_cylinder(v3 o, v3 d, float radius, float height) {
+	const float a = d.x * d.x + d.y * d.y;
+	const float b = 2.0f * (d.x * o.x + d.y * o.y);
+	const float c = (o.x * o.x + o.y * o.y) - radius * radius;
+	const float disc = b * b - 4.0f * a * c;
+	if (disc < 0.0f) return false;
+	const float d_sqrt = sqrtf(disc), a2 = 2.0f * a, h_2 = 0.5f * height;
+	if (a2 > 1e-6f) {
+		const float t0 = (-b - d_sqrt) / a2, t1 = (-b + d_sqrt) / a2;
+		const float z0 = o.z + t0 * d.z, z1 = o.z + t1 * d.z;
+		if ((z0 >= -h_2 && z0 <= h_2) || (z1 >= -h_2 && z1 <= h_2)) return true;
+	}
+	float t = 0.0f;
+	if (intersect_plane_ray(o, d, mk(0.0f, 0.0f, 1.0f), mk(0.0f, 0.0f, h_2), t)) {
+		const v3 p = o + d * t;
+		if (p.x * p.x + p.y * p.y <= radius * radius) return true;
+	}
+	if (intersect_plane_ray(o, d, mk(0.0f, 0.0f, -1.0f), mk(0.0f, 0.0f, -h_2), t)) {
+		const v3 p = o + d * t;
+		if (p.x * p.x + p.y * p.y <= radius * radius) return true;
+	}
+	return false;
+}
+__device__ __forceinline__ bool mask_intersects_ray(const NgpMask3D& m, v3 ro, v3 rd) {
+	if (m.mode == 1) return true;        // subtract masks have infinite additive area around them
+	if (m.shape == 3) return m.mode == 0;
+	const v3 ol = xform_point(m.itransform, ro);
+	const v3 dl = normalized(xform_dir(m.itransform, rd));
+	const float f = 0.5f * m.feather;
+	switch (m.shape) {
+		case 0: return ray_intersects_box(ol, dl, mk(m.config[0] + f, m.config[1] + f, m.config[2] + f));
+		case 1: return ray_intersects_cylinder(ol, dl, m.config[0] + f, m.config[1] + f);
+		case 2: return ray_intersects_sphere(ol, dl, m.config[0] + f);
+		default: return true;
+	}
+}
+
+// ---- camera_models.cuh
+__device__ __forceinline__ void square2disk_shirley(float a, float b, float& ox, float& oy) {  // random_val.cuh:109-125
+	const float PI = 3.14159265358979323846f;
+	float phi, r;
+	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
+	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
+	ox = r * cosf(phi); oy = r * sinf(phi);
+}
+__device__ __forceinline__ void apply_aperture(uint32_t spp, uint32_t px, uint32_t py, const float* cam, float aperture_size, float focus_z, v3& origin, v3& dir) {
+	if (aperture_size > 0.0f) {
+		const v3 lookat = origin + dir * focus_z;
+		const uint32_t seed = px * 19349663u + py * 96925573u;
+		const float r0 = ld_random_val(spp, seed, 0) * 2.0f - 1.0f, r1 = ld_random_val(spp, seed, 1) * 2.0f - 1.0f;
+		float bx, by;
+		square2disk_shirley(r0, r1, bx, by);
+		bx *= aperture_size; by *= aperture_size;
+		origin = origin + mk(cam[0] * bx + cam[3] * by, cam[1] * bx + cam[4] * by, cam[2] * bx + cam[5] * by);
+		dir = mk((lookat.x - origin.x) / focus_z, (lookat.y - origin.y) / focus_z, (lookat.z - origin.z) / focus_z);
+	}
+}
+__device__ __forceinline__ v3 lerp3(const float* a, const float* b, float t) { return mk(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])); }
+
+__global__ void __launch_bounds__(128) init_global_rays_kernel(uint32_t sample_index, NgpGlobalRay* __restrict__ rays, float* __restrict__ depthbuffer, const NgpDownsampleInfo ds, const NgpRenderCamera cam) {
+	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	const uint32_t idx = x + (uint32_t)ds.scaled_res[0] * y;
+	x *= (uint32_t)ds.skip[0]; y *= (uint32_t)ds.skip[1];
+	if (x >= (uint32_t)ds.max_res[0] || y >= (uint32_t)ds.max_res[1]) return;
+	const float rx = (float)ds.max_res[0], ry = (float)ds.max_res[1];
+	v3 origin = mk(0.f, 0.f, 0.f), dir = mk(0.f, 0.f, 1.f);
+	const float* c = cam.transform;
+	if (cam.model == 0) {  // perspective_pixel_to_ray (camera_models.cuh:206-241)
+		float ox, oy;
+		ld_random_pixel_offset(sample_index, ox, oy);
+		const float u = ((float)x + ox) / rx, v = ((float)y + oy) / ry;
+		dir = mk((u - 0.5f) * rx / cam.focal_length, (v - 0.5f) * ry / cam.focal_length, 1.0f);
+		dir = mat3_mul(c, dir);
+		origin = mat3_mul(c, mk(0.f, 0.f, 0.f)) + col(c, 3);
+		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
+		origin = origin + dir * cam.near_distance;
+	} else if (cam.model == 2) {  // spherical_quadrilateral_pixel_to_ray (162-203)
+		const float PI = 3.14159265358979323846f;
+		const float max_linear_len = sqrtf(cam.sq_width * cam.sq_width + cam.sq_height * cam.sq_height);
+		const float ux = 2.0f * (((float)x + 0.5f) / rx - 0.5f), uy = 2.0f * (((float)y + 0.5f) / ry - 0.5f);
+		const float qx = cam.sq_width * ux, qy = cam.sq_height * uy;
+		const float a = atan2f(qy, qx), r = sqrtf(qx * qx + qy * qy);
+		// walk_along_sphere -> walk_along_circle (133-160)
+		float wx = 0.0f, wz = 0.0f;
+		const float arc_t = r / (2.0f * max_linear_len);
+		if (!(arc_t == 0.0f || max_linear_len == 0.0f)) {
+			if (cam.sq_curvature == 0.0f) { wx = max_linear_len * arc_t; wz = 0.0f; }
+			else {
+				const float tpc = 2.0f * PI * cam.sq_curvature;
+				const float s_tpc = max_linear_len / tpc;
+				wx = s_tpc * sinf(tpc * arc_t); wz = s_tpc * (1.0f - cosf(tpc * arc_t));
+			}
+		}
+		origin = mk(wx * cosf(a), wx * sinf(a), wz);
+		dir = mk(0.0f, 0.0f, 1.0f);
+		if (cam.sq_curvature != 0.0f) {
+			const v3 sc = mk(0.0f, 0.0f, max_linear_len / (2.0f * PI * cam.sq_curvature));
+			const float k = cam.sq_curvature > 0.0f ? 1.0f : -1.0f;
+			dir = normalized(sc - origin) * k;
+		}
+		origin = mat3_mul(c, origin) + col(c, 3);
+		dir = mat3_mul(c, dir);
+		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
+		origin = origin + dir * cam.near_distance;
+	} else {  // quadrilateral_hexahedron_pixel_to_ray (80-118)
+		const float u = ((float)x + 0.5f) / rx, v = ((float)y + 0.5f) / ry;
+		const float *f = cam.qh_front, *b = cam.qh_back;
+		const v3 f_ab = lerp3(f + 0, f + 3, u), f_dc = lerp3(f + 6, f + 9, u);
+		const v3 front_p = f_ab + (f_dc - f_ab) * v;
+		const v3 b_ab = lerp3(b + 0, b + 3, u), b_dc = lerp3(b + 6, b + 9, u);
+		const v3 back_p = b_ab + (b_dc - b_ab) * v;
+		dir = front_p - back_p;
+		dir = mk(dir.x / dir.z, dir.y / dir.z, dir.z / dir.z);
+		origin = mat3_mul(c, back_p) + col(c, 3);
+		dir = mat3_mul(c, dir);
+		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
+		origin = origin + dir * cam.near_distance;
+	}
+	depthbuffer[idx] = 1e10f;
+	NgpGlobalRay ray;
+	dir = normalized(dir);
+	ray.origin[0] = origin.x; ray.origin[1] = origin.y; ray.origin[2] = origin.z;
+	ray.dir[0] = dir.x; ray.dir[1] = dir.y; ray.dir[2] = dir.z;
+	ray.rgba[0] = ray.rgba[1] = ray.rgba[2] = ray.rgba[3] = 0.0f;
+	ray.idx = idx; ray.depth = 0.0f; ray.alive = 1; ray.pad_[0] = ray.pad_[1] = ray.pad_[2] = 0;
+	rays[idx] = ray;
+}
+
+__global__ void init_proxy_rays_kernel(uint32_t n_elements, const NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, const NgpNerfProps* __restrict__ props) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const NgpGlobalRay& g = global_rays[i];
+	NgpProxyRay& p = proxy_rays[g.idx];
+	if (!g.alive) { p.alive = 0; p.origin[0] = p.origin[1] = p.origin[2] = 0.0f; return; }
+	const Aabb render_aabb = aabb_of(props->render_aabb);
+	const v3 origin = xform_point(props->itransform, ld3(g.origin));
+	const v3 dir = normalized(xform_dir(props->itransform, normalized(ld3(g.dir))));
+	p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
+	float tmin, tmax;
+	aabb_ray_intersect(render_aabb, origin, dir, tmin, tmax);
+	const float t = fmaxf(tmin, 0.0f) + 1e-5f;
+	if (!aabb_contains(render_aabb, origin + dir * t)) { p.alive = 0; return; }
+	bool hits = props->n_masks == 0;
+	if (!hits) {
+		for (uint32_t k = 0; k < props->n_masks; ++k) {
+			if (mask_intersects_ray(props->masks[k], origin, dir)) { hits = true; break; }
+		}
+	}
+	p.active = 1;
+	p.alive = hits ? 1 : 0;
+	p.idx = g.idx;
+	p.t = 0.0f;
+	p.n_steps = 0;
+	const v3 o2 = origin + dir * t;
+	p.origin[0] = o2.x; p.origin[1] = o2.y; p.origin[2] = o2.z;
+}
+
+// nerf_renderer.cu:148-208.  The mask test inside the loop is unreachable in the reference (a `break` precedes it), so occupancy alone decides.
+__device__ __forceinline__ bool hit_test_and_march(v3 origin, v3 dir, v3 idir, float proxy_t, const NgpNerfProps* __restrict__ props, float* t_out, float* dt_out) {
+	const Aabb render_aabb = aabb_of(props->render_aabb);
+	const float cone = props->cone_angle, mn = props->min_cone_stepsize, mx = props->max_cone_stepsize;
+	const uint8_t* __restrict__ bitfield = props->density_grid_bitfield;
+	const uint32_t grid_size = props->grid_size, grid_volume = props->grid_volume, max_cascade = props->nerf_cascades - 1;
+	float t = proxy_t, dt = 0.0f, prev_t = t;
+	while (1) {
+		const v3 pos = origin + dir * t;
+		if (!aabb_contains(render_aabb, pos)) {
+			if (t_out) *t_out = prev_t;
+			if (dt_out) *dt_out = dt;
+			return false;
+		}
+		dt = get_dt(t, cone, mn, mx);
+		int mipi = get_mip_from_dt(dt, pos, grid_size, max_cascade);
+		const uint32_t mip = (uint32_t)(mipi < 0 ? 0 : mipi);
+		if (!bitfield) break;
+		if (get_is_occupied(pos, bitfield, mip, grid_size, grid_volume)) break;
+		const uint32_t res = grid_size >> mip;
+		prev_t = t;
+		t = get_t_advanced_to_next_voxel(t, cone, pos, dir, idir, res, mn, mx);
+	}
+	if (t_out) *t_out = t;
+	if (dt_out) *dt_out = dt;
+	return true;
+}
+
+__global__ void multi_compact_rays_kernel(uint32_t n_elements, const NgpGlobalRay* __restrict__ g_src, NgpGlobalRay* __restrict__ g_dst, const NgpProxyRay* __restrict__ p_src,
+                                          NgpProxyRay* __restrict__ p_dst, uint32_t n_nerfs, uint32_t stride, NgpGlobalRay* __restrict__ g_final, uint32_t* alive_counter, uint32_t* final_counter) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const bool in = i < n_elements;
+	NgpGlobalRay g;
+	bool alive = false, fin = false;
+	if (in) { g = g_src[i]; alive = g.alive != 0; fin = !alive && g.rgba[3] > 0.001f; }
+	const uint64_t m_alive = __ballot(alive), m_fin = __ballot(fin);
+	const uint32_t lane = lane_id();
+	uint32_t base_a = 0, base_f = 0;
+	if (lane == 0) {
+		if (m_alive) base_a = atomicAdd(alive_counter, (uint32_t)__popcll(m_alive));
+		if (m_fin) base_f = atomicAdd(final_counter, (uint32_t)__popcll(m_fin));
+	}
+	base_a = __shfl(base_a, 0, 64); base_f = __shfl(base_f, 0, 64);
+	const uint64_t below = (1ull << lane) - 1ull;
+	if (alive) {
+		const uint32_t idx = base_a + (uint32_t)__popcll(m_alive & below);
+		g_dst[idx] = g;
+		for (uint32_t n = 0; n < n_nerfs; ++n) p_dst[idx + n * stride] = p_src[i + n * stride];
+	} else if (fin) {
+		g_final[base_f + (uint32_t)__popcll(m_fin & below)] = g;
+	}
+}
+
+__global__ void march_active_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs, const NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, uint32_t stride,
+                                         const NgpNerfProps* __restrict__ props) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_rays_alive) return;
+	if (!global_rays[i].alive) return;
+	for (uint32_t n = 0; n < n_nerfs; ++n) {
+		NgpProxyRay& p = proxy_rays[i + n * stride];
+		if (!p.alive || !p.active) continue;
+		const v3 origin = ld3(p.origin), dir = ld3(p.dir);
+		const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		float t = p.t;
+		p.alive = hit_test_and_march(origin, dir, idir, t, props + n, &t, nullptr) ? 1 : 0;
+		p.t = t;
+	}
+}
+
+__global__ void cull_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, uint32_t stride, v3 cam_pos,
+                                 const NgpNerfProps* __restrict__ props) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_rays_alive) return;
+	NgpGlobalRay& g = global_rays[i];
+	if (!g.alive) return;
+	float min_d2 = 0.0f;
+	int32_t active_idx = -1;
+	uint32_t n_proxy_alive = 0;
+	for (uint32_t n = 0; n < n_nerfs; ++n) {
+		const uint32_t pi = i + n * stride;
+		NgpProxyRay& p = proxy_rays[pi];
+		if (!p.alive) continue;
+		++n_proxy_alive;
+		const v3 pw = xform_point(props[n].transform, ld3(p.origin) + ld3(p.dir) * p.t);
+		const v3 dlt = pw - cam_pos;
+		const float d2 = dot(dlt, dlt);
+		if (d2 < min_d2 || active_idx == -1) { min_d2 = d2; active_idx = (int32_t)pi; }
+		p.active = 0;
+	}
+	if (active_idx >= 0) proxy_rays[active_idx].active = 1;
+	if (n_proxy_alive == 0) g.alive = 0;
+}
+
+__global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, NgpCoord* __restrict__ network_input,
+                                                  uint32_t n_steps, const NgpNerfProps* __restrict__ props) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	if (!global_rays[i].alive) return;
+	NgpProxyRay& p = proxy_rays[i];
+	if (!p.active) return;
+	const v3 origin = ld3(p.origin), dir = ld3(p.dir);
+	const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	const Aabb train_aabb = aabb_of(props->train_aabb);
+	const v3 wd = warp_direction(dir);
+	float t = p.t;
+	float dt = get_dt(t, props->cone_angle, props->min_cone_stepsize, props->max_cone_stepsize);
+	for (uint32_t j = 0; j < n_steps; ++j) {
+		const v3 pos = origin + dir * t;
+		const v3 wp = aabb_relative_pos(train_aabb, pos);
+		NgpCoord c;
+		c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z;
+		c.dt = get_warped_dt(dt, props->min_cone_stepsize, props->nerf_cascades);
+		c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+		network_input[i + (size_t)j * n_elements] = c;
+		if (!hit_test_and_march(origin, dir, idir, t, props, &t, &dt)) { p.n_steps = (uint16_t)j; return; }
+		t += dt;
+	}
+	p.t = t;
+	p.n_steps = (uint16_t)n_steps;
+}
+
+typedef uint16_t us4m __attribute__((ext_vector_type(4)));
+
+__global__ void multi_composite_kernel(uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays,
+                                       const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride, uint32_t n_steps,
+                                       int rgb_activation, int density_activation, float min_transmittance, const NgpNerfProps* __restrict__ props) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_global_rays) return;
+	NgpGlobalRay& g = global_rays[i];
+	if (!g.alive) return;
+	NgpProxyRay& p = proxy_rays[i];
+	if (!p.alive || !p.active) return;
+	float r = g.rgba[0], gg = g.rgba[1], b = g.rgba[2], a = g.rgba[3];
+	const Aabb train_aabb = aabb_of(props->train_aabb);
+	const uint32_t actual_n_steps = p.n_steps;
+	uint32_t j = 0;
+	for (; j < actual_n_steps; ++j) {
+		const size_t e = i + (size_t)j * n_global_rays;
+		const us4m o = *(const us4m*)(network_output + e * out_stride);
+		const NgpCoord& in = network_input[e];
+		const v3 pos = unwarp_position(ld3(in.pos), train_aabb);
+		const float T = 1.f - a;
+		const float dt = get_unwarped_dt(in.dt, props->min_cone_stepsize, props->nerf_cascades);
+		const float alpha = 1.f - __expf(-network_to_density(h2f(o[3]), density_activation) * dt);
+		float weight = alpha * T;
+		const float cr = network_to_rgb(h2f(o[0]), rgb_activation), cg = network_to_rgb(h2f(o[1]), rgb_activation), cb = network_to_rgb(h2f(o[2]), rgb_activation);
+		float mask_weight = 1.f;
+		for (uint32_t k = 0; k < props->n_masks; ++k) mask_weight = clampf(mask_weight + mask_sample(props->masks[k], pos), 0.0f, 1.0f);
+		weight *= mask_weight;
+		weight *= props->opacity;
+		r += cr * weight; gg += cg * weight; b += cb * weight; a += weight;
+		if (a > (1.0f - min_transmittance)) { r /= a; gg /= a; b /= a; a /= a; break; }
+	}
+	if (j < n_steps) { p.alive = 0; p.n_steps = (uint16_t)(j + current_step); }
+	g.rgba[0] = r; g.rgba[1] = gg; g.rgba[2] = b; g.rgba[3] = a;
+}
+
+__global__ void multi_shade_kernel(uint32_t n_rays, const NgpGlobalRay* __restrict__ rays, bool train_in_linear_colors, float4* __restrict__ frame_buffer, float* __restrict__ depth_buffer,
+                                   const NgpDownsampleInfo ds, bool flip_y) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_rays) return;
+	const NgpGlobalRay& ray = rays[i];
+	const uint32_t x = (uint32_t)ds.skip[0] * (ray.idx % (uint32_t)ds.scaled_res[0]);
+	uint32_t y = (uint32_t)ds.skip[1] * (ray.idx / (uint32_t)ds.scaled_res[0]);
+	if (flip_y) y = (uint32_t)ds.max_res[1] - y - 1;
+	float4 tmp = make_float4(ray.rgba[0], ray.rgba[1], ray.rgba[2], ray.rgba[3]);
+	if (!train_in_linear_colors) { tmp.x = srgb_to_linear(tmp.x); tmp.y = srgb_to_linear(tmp.y); tmp.z = srgb_to_linear(tmp.z); }
+	for (uint32_t u = 0; u < (uint32_t)ds.skip[0]; ++u) {
+		for (uint32_t v = 0; v < (uint32_t)ds.skip[1]; ++v) {
+			const uint32_t idx = (x + u) + (y + v) * (uint32_t)ds.max_res[0];
+			if (idx >= ds.max_pixels) continue;
+			const float4 f = frame_buffer[idx];
+			const float k = 1.0f - tmp.w;
+			frame_buffer[idx] = make_float4(tmp.x + f.x * k, tmp.y + f.y * k, tmp.z + f.z * k, tmp.w + f.w * k);
+			if (tmp.w > 0.2f) depth_buffer[idx] = ray.depth;
+		}
+	}
+}
+
+} // namespace ngp
+
+using namespace ngp;
+
+extern "C" {
+
+int ngp_hip_multi_init_global_rays(void* stream, uint32_t sample_index, NgpGlobalRay* rays, float* depthbuffer, const NgpDownsampleInfo* ds, const NgpRenderCamera* camera) {
+	if (ds->scaled_res[0] <= 0 || ds->scaled_res[1] <= 0) return 0;
+	const dim3 threads(16, 8, 1), blocks(div_up((uint32_t)ds->scaled_res[0], 16u), div_up((uint32_t)ds->scaled_res[1], 8u), 1);
+	hipLaunchKernelGGL(init_global_rays_kernel, blocks, threads, 0, (hipStream_t)stream, sample_index, rays, depthbuffer, *ds, *camera);
+	NGP_LAUNCH_CHECK("init_global_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_init_proxy_rays(void* stream, uint32_t n_elements, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, const NgpNerfProps* props) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(init_proxy_rays_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, global_rays, proxy_rays, props);
+	NGP_LAUNCH_CHECK("init_proxy_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_compact_rays(void* stream, uint32_t n_elements, const NgpGlobalRay* global_src, NgpGlobalRay* global_dst, const NgpProxyRay* proxy_src, NgpProxyRay* proxy_dst,
+                               uint32_t n_nerfs, uint32_t stride, NgpGlobalRay* global_final, uint32_t* alive_counter, uint32_t* final_counter) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(multi_compact_rays_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, global_src, global_dst, proxy_src, proxy_dst, n_nerfs, stride,
+	                   global_final, alive_counter, final_counter);
+	NGP_LAUNCH_CHECK("multi_compact_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_march_active_rays(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, uint32_t stride, const NgpNerfProps* props) {
+	if (!n_rays_alive) return 0;
+	hipLaunchKernelGGL(march_active_rays_kernel, dim3(div_up(n_rays_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_alive, n_nerfs, global_rays, proxy_rays, stride, props);
+	NGP_LAUNCH_CHECK("march_active_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_cull_rays(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, uint32_t stride, const float* cam_pos, const NgpNerfProps* props) {
+	if (!n_rays_alive) return 0;
+	v3 cp; cp.x = cam_pos[0]; cp.y = cam_pos[1]; cp.z = cam_pos[2];
+	hipLaunchKernelGGL(cull_rays_kernel, dim3(div_up(n_rays_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_alive, n_nerfs, global_rays, proxy_rays, stride, cp, props);
+	NGP_LAUNCH_CHECK("cull_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_generate_next_inputs(void* stream, uint32_t n_elements, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, NgpCoord* network_input, uint32_t n_steps, const NgpNerfProps* props) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(multi_generate_next_inputs_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, global_rays, proxy_rays, network_input, n_steps, props);
+	NGP_LAUNCH_CHECK("multi_generate_next_inputs_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_composite(void* stream, uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, const NgpCoord* network_input,
+                            const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, const NgpNerfProps* props) {
+	if (!n_global_rays) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_multi_composite: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(multi_composite_kernel, dim3(div_up(n_global_rays, 128)), dim3(128), 0, (hipStream_t)stream, n_global_rays, current_step, global_rays, proxy_rays, network_input,
+	                   network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, props);
+	NGP_LAUNCH_CHECK("multi_composite_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer, const NgpDownsampleInfo* ds, int flip_y) {
+	if (!n_rays) return 0;
+	hipLaunchKernelGGL(multi_shade_kernel, dim3(div_up(n_rays, 128)), dim3(128), 0, (hipStream_t)stream, n_rays, rays, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer, *ds, flip_y != 0);
+	NGP_LAUNCH_CHECK("multi_shade_kernel");
+	return 0;
+}
+
+} // extern "C"

@@ -190,6 +190,63 @@ int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame
 int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
                     int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */
 
+/* ============================ Blender multi-NeRF renderer (src/nerf_renderer.cu:17-563, include/.../nerf/ headers) ============================
+ * One GLOBAL ray per output pixel (world space) and one PROXY ray per (pixel, NeRF) in that NeRF's local frame; per pass the nearest alive
+ * proxy of every pixel is marched, evaluated by its own network and composited into the global ray.  4x4 matrices are column-major. */
+typedef struct {                                                     /* render_data_workspace.cuh:13-20 NerfGlobalRay */
+	float origin[3]; float dir[3]; float rgba[4]; uint32_t idx; float depth; uint8_t alive; uint8_t pad_[3];
+} NgpGlobalRay;                                                      /* 52 B */
+typedef struct {                                                     /* render_data_workspace.cuh:22-31 NerfProxyRay */
+	float origin[3]; float dir[3]; float t; uint32_t idx; uint16_t n_steps; uint8_t alive; uint8_t active; float mask_alpha;
+} NgpProxyRay;                                                       /* 40 B */
+typedef struct {                                                     /* mask_3D.cuh:129-255 Mask3D */
+	int32_t mode;             /* EMaskMode: 0 Add, 1 Subtract */
+	int32_t shape;            /* EMaskShape: 0 Box, 1 Cylinder, 2 Sphere, 3 All */
+	float transform[16], itransform[16];
+	float config[6];          /* box: dims xyz; cylinder: radius, height; sphere: radius */
+	float feather, opacity;
+} NgpMask3D;
+typedef struct {                                                     /* nerf_props.cuh:14-48 NerfProps */
+	float transform[16], itransform[16];
+	const uint8_t* density_grid_bitfield;   /* device, 8 cascades, max-pooled (may be NULL) */
+	uint32_t grid_size, grid_volume;        /* 128, 128^3 */
+	NgpAabb render_aabb, train_aabb;
+	const NgpMask3D* masks;                 /* device */
+	uint32_t n_masks;
+	float cone_angle, min_cone_stepsize, max_cone_stepsize;
+	uint32_t nerf_cascades;
+	float opacity;
+} NgpNerfProps;
+typedef struct { int32_t max_res[2], scaled_res[2], skip[2]; uint32_t max_pixels, scaled_pixels; } NgpDownsampleInfo;   /* common.h:337-355 MakeFromMip */
+typedef struct {                                                     /* render_request.cuh:55-103 RenderCameraProperties */
+	float transform[12];      /* 3x4 column-major camera-to-world */
+	int32_t model;            /* camera_models.cuh:27-31: 0 Perspective, 1 QuadrilateralHexahedron, 2 SphericalQuadrilateral */
+	float focal_length;
+	float sq_width, sq_height, sq_curvature;          /* SphericalQuadrilateral */
+	float qh_front[12], qh_back[12];                  /* QuadrilateralHexahedron: tl, tr, bl, br of each face */
+	float near_distance, aperture_size, focus_z;
+} NgpRenderCamera;
+
+int ngp_hip_multi_init_global_rays(void* stream, uint32_t sample_index, NgpGlobalRay* rays, float* depthbuffer, const NgpDownsampleInfo* ds_host,
+                                   const NgpRenderCamera* camera_host);                                                        /* nerf_renderer.cu:17-94 */
+int ngp_hip_multi_init_proxy_rays(void* stream, uint32_t n_elements, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays,
+                                  const NgpNerfProps* nerf_props_dev);                                                         /* :96-146 */
+int ngp_hip_multi_compact_rays(void* stream, uint32_t n_elements, const NgpGlobalRay* global_src, NgpGlobalRay* global_dst, const NgpProxyRay* proxy_src,
+                               NgpProxyRay* proxy_dst, uint32_t n_nerfs, uint32_t proxy_stride_between_nerfs, NgpGlobalRay* global_final,
+                               uint32_t* alive_counter, uint32_t* final_counter);                                              /* :237-268 */
+int ngp_hip_multi_march_active_rays(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays,
+                                    uint32_t proxy_stride_between_nerfs, const NgpNerfProps* nerf_props_dev);                  /* :272-316 (hit_test_and_march :148-208) */
+int ngp_hip_multi_cull_rays(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays,
+                            uint32_t proxy_stride_between_nerfs, const float* cam_pos_host, const NgpNerfProps* nerf_props_dev); /* :378-428 */
+int ngp_hip_multi_generate_next_inputs(void* stream, uint32_t n_elements, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays_of_nerf,
+                                       NgpCoord* network_input, uint32_t n_steps, const NgpNerfProps* nerf_props_of_nerf_dev);  /* :318-375 */
+/* network_output is fp16 [n][out_stride] (r, g, b, sigma first), i.e. the layout ngp_hip_nerf_inference writes */
+int ngp_hip_multi_composite(void* stream, uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays_of_nerf,
+                            const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                            int density_activation, float min_transmittance, const NgpNerfProps* nerf_props_of_nerf_dev);      /* :431-510 */
+int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
+                        const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
+
 #ifdef __cplusplus
 }
 #endif

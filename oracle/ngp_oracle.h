@@ -91,6 +91,20 @@ void orc_accumulate(const int32_t res[2], const float* frame_buffer, float* accu
 void orc_tonemap(const int32_t res[2], float exposure, const float background_color_in[4], const float* accumulate_buffer, int color_space_srgb, int output_color_space_srgb, int tonemap_curve, int clamp_output_color, float* surface);
 uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, uint32_t sample_index, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float screen_center[2], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb, float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation, float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer);
 
+/* orc_multi.c — Blender multi-NeRF renderer (src/nerf_renderer.cu) */
+float orc_mask_sample(const orc_mask3d* m, const float p[3]);
+int orc_mask_intersects_ray(const orc_mask3d* m, const float ro[3], const float rd[3]);
+void orc_downsample_info_from_mip(const int32_t resolution[2], uint32_t mip, orc_downsample_info* ds);
+void orc_multi_init_global_rays(uint32_t sample_index, orc_global_ray* rays, float* depthbuffer, const orc_downsample_info* ds, const orc_render_camera* cam);
+void orc_multi_init_proxy_rays(uint32_t n_elements, const orc_global_ray* global_rays, orc_proxy_ray* proxy_rays, const orc_nerf_props* props);
+void orc_multi_compact_rays(uint32_t n_elements, const orc_global_ray* g_src, orc_global_ray* g_dst, const orc_proxy_ray* p_src, orc_proxy_ray* p_dst, uint32_t n_nerfs, uint32_t stride, orc_global_ray* g_final, uint32_t* alive_counter, uint32_t* final_counter);
+void orc_multi_march_active_rays(uint32_t n_rays_alive, uint32_t n_nerfs, const orc_global_ray* global_rays, orc_proxy_ray* proxy_rays, uint32_t stride, const orc_nerf_props* props);
+void orc_multi_cull_rays(uint32_t n_rays_alive, uint32_t n_nerfs, orc_global_ray* global_rays, orc_proxy_ray* proxy_rays, uint32_t stride, const float cam_pos[3], const orc_nerf_props* props);
+void orc_multi_generate_next_inputs(uint32_t n_elements, const orc_global_ray* global_rays, orc_proxy_ray* proxy_rays, orc_coord* network_input, uint32_t n_steps, const orc_nerf_props* props);
+void orc_multi_composite(uint32_t n_global_rays, uint32_t current_step, orc_global_ray* global_rays, orc_proxy_ray* proxy_rays, const orc_coord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, const orc_nerf_props* props);
+void orc_multi_shade(uint32_t n_rays, const orc_global_ray* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer, const orc_downsample_info* ds, int flip_y);
+uint64_t orc_multi_render(uint32_t n_nerfs, const orc_net* const* nets, const uint16_t* const* params, const orc_nerf_props* props, const int* rgb_activation, const int* density_activation, const float* min_transmittance, const orc_downsample_info* ds, const orc_render_camera* cam, int flip_y, float* frame_buffer, float* depth_buffer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,27 @@ typedef struct {
 	uint8_t pad_;
 } orc_payload;
 
+/* ---- Blender multi-NeRF renderer records (same byte layout as include/ngp_hip.h so that test buffers can be shared) ---- */
+typedef struct { float origin[3]; float dir[3]; float rgba[4]; uint32_t idx; float depth; uint8_t alive; uint8_t pad_[3]; } orc_global_ray;     /* render_data_workspace.cuh:13-20 */
+typedef struct { float origin[3]; float dir[3]; float t; uint32_t idx; uint16_t n_steps; uint8_t alive; uint8_t active; float mask_alpha; } orc_proxy_ray; /* :22-31 */
+typedef struct { int32_t mode; int32_t shape; float transform[16], itransform[16]; float config[6]; float feather, opacity; } orc_mask3d;       /* mask_3D.cuh:129-137 */
+typedef struct {                                                                                                                               /* nerf_props.cuh:14-30 */
+	float transform[16], itransform[16];
+	const uint8_t* density_grid_bitfield;
+	uint32_t grid_size, grid_volume;
+	orc_aabb render_aabb, train_aabb;
+	const orc_mask3d* masks;
+	uint32_t n_masks;
+	float cone_angle, min_cone_stepsize, max_cone_stepsize;
+	uint32_t nerf_cascades;
+	float opacity;
+} orc_nerf_props;
+typedef struct { int32_t max_res[2], scaled_res[2], skip[2]; uint32_t max_pixels, scaled_pixels; } orc_downsample_info;                          /* common.h:300-355 */
+typedef struct {                                                                                                                               /* render_request.cuh:55-103 */
+	float transform[12]; int32_t model; float focal_length; float sq_width, sq_height, sq_curvature; float qh_front[12], qh_back[12];
+	float near_distance, aperture_size, focus_z;
+} orc_render_camera;
+
 /* ------------------------------------------------------------------ */
 /* fp16 <-> fp32 (IEEE binary16, round-to-nearest-even)                */
 /* ------------------------------------------------------------------ */
