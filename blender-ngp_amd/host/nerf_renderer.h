@@ -1,0 +1,129 @@
+// nerf_renderer.h — host side of the Blender add-on's multi-NeRF renderer: the request schema that crosses pybind11
+// (include/neural-graphics-primitives/nerf/render_request.cuh, nerf_descriptor.cuh, render_modifiers*.cuh, mask_3D.cuh,
+// camera_models.cuh, common.h:300-355), one NeuralRadianceField per snapshot path (neural_radiance_field.cuh) and the render loop
+// (src/nerf_renderer.cu:565-791) over the ngp_hip_multi_* kernels.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ngp_hip.h"
+#include "testbed.h"
+
+namespace ngp {
+
+struct Mat4 {  // column-major 4x4 (Eigen::Matrix4f)
+	float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+	Mat4 inverse() const;
+	Mat4 operator*(const Mat4& o) const;
+};
+
+struct BoundingBox {  // bounding_box.cuh:43-268 (the members the request schema and the add-on use)
+	Vec3 min{1e30f, 1e30f, 1e30f}, max{-1e30f, -1e30f, -1e30f};
+	BoundingBox() = default;
+	BoundingBox(const Vec3& a, const Vec3& b) : min(a), max(b) {}
+	Vec3 center() const { return Vec3{0.5f * (min.x + max.x), 0.5f * (min.y + max.y), 0.5f * (min.z + max.z)}; }
+	Vec3 diag() const { return Vec3{max.x - min.x, max.y - min.y, max.z - min.z}; }
+	bool contains(const Vec3& p) const { return p.x >= min.x && p.x <= max.x && p.y >= min.y && p.y <= max.y && p.z >= min.z && p.z <= max.z; }
+	void enlarge(const Vec3& p);
+	void enlarge(const BoundingBox& o) { enlarge(o.min); enlarge(o.max); }
+	void inflate(float amount);
+	Vec3 relative_pos(const Vec3& p) const;
+	NgpAabb pod() const { return NgpAabb{{min.x, min.y, min.z}, {max.x, max.y, max.z}}; }
+};
+
+enum class EMaskMode : int { Add, Subtract };
+enum class EMaskShape : int { Box, Cylinder, Sphere, All };
+enum class ECameraModel : int { Perspective, QuadrilateralHexahedron, SphericalQuadrilateral };  // camera_models.cuh:27-31
+
+struct Mask3D {  // mask_3D.cuh:129-255
+	NgpMask3D pod{};
+	Mask3D() { pod.mode = 0; pod.shape = 0; Mat4 id; memcpy(pod.transform, id.m, 64); memcpy(pod.itransform, id.m, 64); }
+	Mask3D(EMaskShape shape, const Mat4& transform, EMaskMode mode, const float config[6], float feather, float opacity);
+	static Mask3D All(EMaskMode mode);
+	static Mask3D Box(const Vec3& dims, const Mat4& transform, EMaskMode mode, float feather, float opacity);
+	static Mask3D Cylinder(float radius, float height, const Mat4& transform, EMaskMode mode, float feather, float opacity);
+	static Mask3D Sphere(float radius, const Mat4& transform, EMaskMode mode, float feather, float opacity);
+	Mask3D transformed_by(const Mat4& matrix) const;
+};
+
+struct RenderModifiersDescriptor { std::vector<Mask3D> masks; };  // render_modifiers_descriptor.cuh
+
+struct DownsampleInfo {  // common.h:300-355
+	NgpDownsampleInfo pod{};
+	static DownsampleInfo MakeFromMip(int res_x, int res_y, uint32_t mip);
+};
+
+struct Quadrilateral3D { Vec3 tl, tr, bl, br; Vec3 center() const; };
+struct QuadrilateralHexahedron { Quadrilateral3D front, back; Vec3 center() const; };
+struct SphericalQuadrilateral { float width = 0, height = 0, curvature = 0; };
+
+struct RenderOutputProperties {  // render_request.cuh:17-52
+	int32_t resolution[2] = {0, 0};
+	DownsampleInfo ds;
+	uint32_t spp = 1;
+	EColorSpace color_space = EColorSpace::Linear;
+	ETonemapCurve tonemap_curve = ETonemapCurve::Identity;
+	float exposure = 0.f;
+	float background_color[4] = {0, 0, 0, 0};
+	bool flip_y = false;
+};
+
+struct RenderCameraProperties {  // render_request.cuh:55-103
+	Mat34 transform;
+	ECameraModel model = ECameraModel::Perspective;
+	float focal_length = 1.f;
+	SphericalQuadrilateral spherical_quadrilateral;
+	QuadrilateralHexahedron quadrilateral_hexahedron;
+	float near_distance = 0.f, aperture_size = 0.f, focus_z = 1.f;
+	bool operator==(const RenderCameraProperties& o) const;
+	bool operator!=(const RenderCameraProperties& o) const { return !(*this == o); }
+	NgpRenderCamera pod() const;
+};
+
+struct NerfDescriptor {  // nerf_descriptor.cuh:15-35
+	std::string snapshot_path;
+	BoundingBox aabb;
+	Mat4 transform;
+	RenderModifiersDescriptor modifiers;
+	float opacity = 1.f;
+};
+
+struct RenderRequest {  // render_request.cuh:105-125
+	RenderOutputProperties output;
+	RenderCameraProperties camera;
+	RenderModifiersDescriptor modifiers;
+	std::vector<NerfDescriptor> nerfs;
+	BoundingBox aabb;
+};
+
+// one trained field per snapshot file, loaded lazily and kept across requests (render_data.cuh:38-93)
+class NeuralRadianceField {
+public:
+	explicit NeuralRadianceField(const std::string& path) : snapshot_path(path) {}
+	void load_snapshot(void* stream);  // neural_radiance_field.cuh:153-298 + nerf_data.cu:61-88
+	std::string snapshot_path;
+	bool is_loaded = false;
+	NgpNetDesc desc{};
+	DeviceBuffer desc_gpu, params, density_grid, density_grid_bitfield, density_grid_mean;
+	NgpAabb train_aabb{{0, 0, 0}, {1, 1, 1}};
+	uint32_t grid_size = 128, max_cascade = 0, num_cascades = 8, aabb_scale = 1;
+	float cone_angle_constant = 1.0f / 256.0f;
+	float min_transmittance = 0.01f;
+	ENerfActivation rgb_activation = ENerfActivation::Logistic, density_activation = ENerfActivation::Exponential;
+	float min_cone_step_size() const { return 1.73205080757f / 1024.0f; }                                             // :66-72
+	float max_cone_step_size() const { return min_cone_step_size() * (float)(1u << (num_cascades - 1)) * 1024.0f / (float)grid_size; }
+};
+
+class NerfRenderer {
+public:
+	// returns the number of network samples evaluated; rb.frame_buffer / depth_buffer must be cleared by the caller (bl_render_frame)
+	uint64_t render(RenderBuffer& rb, const RenderRequest& request, void* stream);
+	size_t n_loaded_fields() const { return m_fields.size(); }
+private:
+	std::vector<std::unique_ptr<NeuralRadianceField>> m_fields;
+	DeviceBuffer m_global[2], m_proxy[2], m_hit, m_net_in, m_net_out, m_counters, m_props_gpu, m_masks_gpu, m_enc_ws;
+};
+
+} // namespace ngp

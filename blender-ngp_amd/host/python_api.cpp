@@ -7,6 +7,7 @@
 
 #include "testbed.h"
 #include "snapshot.h"
+#include "nerf_renderer.h"
 
 namespace py = pybind11;
 using namespace ngp;
@@ -58,6 +59,21 @@ static py::array_t<float> mat34_to_py(const Mat34& m) {
 	return a;
 }
 
+static Vec3 vec3_from_py(const py::object& o) {
+	const std::vector<float> v = o.cast<std::vector<float>>();
+	if (v.size() != 3) throw std::runtime_error{"expected a 3-vector"};
+	return Vec3{v[0], v[1], v[2]};
+}
+static py::array_t<float> vec3_to_py(const Vec3& v) { py::array_t<float> a(3); a.mutable_data()[0] = v.x; a.mutable_data()[1] = v.y; a.mutable_data()[2] = v.z; return a; }
+static Mat4 mat4_from_py(const py::array_t<float, py::array::c_style | py::array::forcecast>& a) {
+	auto b = a.request();
+	if (b.ndim != 2 || b.shape[0] != 4 || b.shape[1] != 4) throw std::runtime_error{"expected a 4x4 matrix"};
+	const float* p = (const float*)b.ptr;
+	Mat4 m;
+	for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m.m[c * 4 + r] = p[r * 4 + c];
+	return m;
+}
+
 PYBIND11_MODULE(pyngp, m) {
 	m.doc() = "MI355X-native Instant-NGP NeRF engine behind the blender-ngp `pyngp` API";
 
@@ -88,6 +104,86 @@ PYBIND11_MODULE(pyngp, m) {
 	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
 	m.def("device_memory_allocated", []() { return DeviceBuffer::total_allocated(); });
 
+	// ---- Blender add-on request schema (python_api.cu:392-538)
+	py::enum_<ECameraModel>(m, "CameraModel").value("Perspective", ECameraModel::Perspective).value("SphericalQuadrilateral", ECameraModel::SphericalQuadrilateral)
+		.value("QuadrilateralHexahedron", ECameraModel::QuadrilateralHexahedron).export_values();
+	py::enum_<EMaskMode>(m, "MaskMode").value("Add", EMaskMode::Add).value("Subtract", EMaskMode::Subtract).export_values();
+	py::enum_<EMaskShape>(m, "MaskShape").value("Box", EMaskShape::Box).value("Cylinder", EMaskShape::Cylinder).value("Sphere", EMaskShape::Sphere).export_values();
+
+	py::class_<BoundingBox>(m, "BoundingBox")
+		.def(py::init<>())
+		.def(py::init([](const py::object& a, const py::object& b) { return BoundingBox(vec3_from_py(a), vec3_from_py(b)); }))
+		.def("center", [](const BoundingBox& b) { return vec3_to_py(b.center()); })
+		.def("contains", [](const BoundingBox& b, const py::object& p) { return b.contains(vec3_from_py(p)); })
+		.def("diag", [](const BoundingBox& b) { return vec3_to_py(b.diag()); })
+		.def("enlarge", [](BoundingBox& b, const py::object& p) { if (py::isinstance<BoundingBox>(p)) b.enlarge(p.cast<BoundingBox>()); else b.enlarge(vec3_from_py(p)); })
+		.def("inflate", &BoundingBox::inflate)
+		.def("relative_pos", [](const BoundingBox& b, const py::object& p) { return vec3_to_py(b.relative_pos(vec3_from_py(p))); })
+		.def_property("min", [](const BoundingBox& b) { return vec3_to_py(b.min); }, [](BoundingBox& b, const py::object& v) { b.min = vec3_from_py(v); })
+		.def_property("max", [](const BoundingBox& b) { return vec3_to_py(b.max); }, [](BoundingBox& b, const py::object& v) { b.max = vec3_from_py(v); });
+
+	py::class_<Quadrilateral3D>(m, "Quadrilateral3D")
+		.def_static("Zero", []() { return Quadrilateral3D{}; })
+		.def(py::init([](const py::object& tl, const py::object& tr, const py::object& bl, const py::object& br) { return Quadrilateral3D{vec3_from_py(tl), vec3_from_py(tr), vec3_from_py(bl), vec3_from_py(br)}; }),
+			py::arg("tl"), py::arg("tr"), py::arg("bl"), py::arg("br"))
+		.def("center", [](const Quadrilateral3D& q) { return vec3_to_py(q.center()); });
+	py::class_<QuadrilateralHexahedron>(m, "QuadrilateralHexahedronConfig")
+		.def_static("Zero", []() { return QuadrilateralHexahedron{}; })
+		.def(py::init([](const Quadrilateral3D& f, const Quadrilateral3D& b) { return QuadrilateralHexahedron{f, b}; }), py::arg("front"), py::arg("back"))
+		.def("center", [](const QuadrilateralHexahedron& q) { return vec3_to_py(q.center()); });
+	py::class_<SphericalQuadrilateral>(m, "SphericalQuadrilateralConfig")
+		.def_static("Zero", []() { return SphericalQuadrilateral{}; })
+		.def(py::init([](float w, float h, float c) { return SphericalQuadrilateral{w, h, c}; }), py::arg("width"), py::arg("height"), py::arg("curvature"));
+
+	py::class_<Mask3D>(m, "Mask3D")
+		.def_static("Box", [](const py::object& dims, const py::array_t<float, py::array::c_style | py::array::forcecast>& t, EMaskMode mode, float feather, float opacity) {
+				return Mask3D::Box(vec3_from_py(dims), mat4_from_py(t), mode, feather, opacity); }, py::arg("dims"), py::arg("transform"), py::arg("mode"), py::arg("feather"), py::arg("opacity"))
+		.def_static("Cylinder", [](float radius, float height, const py::array_t<float, py::array::c_style | py::array::forcecast>& t, EMaskMode mode, float feather, float opacity) {
+				return Mask3D::Cylinder(radius, height, mat4_from_py(t), mode, feather, opacity); }, py::arg("radius"), py::arg("height"), py::arg("transform"), py::arg("mode"), py::arg("feather"), py::arg("opacity"))
+		.def_static("Sphere", [](float radius, const py::array_t<float, py::array::c_style | py::array::forcecast>& t, EMaskMode mode, float feather, float opacity) {
+				return Mask3D::Sphere(radius, mat4_from_py(t), mode, feather, opacity); }, py::arg("radius"), py::arg("transform"), py::arg("mode"), py::arg("feather"), py::arg("opacity"));
+
+	py::class_<DownsampleInfo>(m, "DownsampleInfo")
+		.def_static("MakeFromMip", [](const std::vector<int>& res, uint32_t mip) { if (res.size() != 2) throw std::runtime_error{"resolution must have 2 entries"}; return DownsampleInfo::MakeFromMip(res[0], res[1], mip); },
+			py::arg("resolution"), py::arg("mip"));
+
+	py::class_<RenderOutputProperties>(m, "RenderOutputProperties")
+		.def(py::init([](const std::vector<int>& res, const DownsampleInfo& ds, uint32_t spp, EColorSpace cs, ETonemapCurve tc, float exposure, const std::vector<float>& bg, bool flip_y) {
+				if (res.size() != 2 || bg.size() != 4) throw std::runtime_error{"resolution needs 2 entries, background_color 4"};
+				RenderOutputProperties o;
+				o.resolution[0] = res[0]; o.resolution[1] = res[1]; o.ds = ds; o.spp = spp; o.color_space = cs; o.tonemap_curve = tc; o.exposure = exposure;
+				for (int i = 0; i < 4; ++i) o.background_color[i] = bg[i];
+				o.flip_y = flip_y;
+				return o;
+			}), py::arg("resolution"), py::arg("ds"), py::arg("spp"), py::arg("color_space"), py::arg("tonemap_curve"), py::arg("exposure"), py::arg("background_color"), py::arg("flip_y"));
+
+	py::class_<RenderModifiersDescriptor>(m, "RenderModifiers")
+		.def(py::init([](const std::vector<Mask3D>& masks) { return RenderModifiersDescriptor{masks}; }), py::arg("masks"));
+
+	py::class_<RenderCameraProperties>(m, "RenderCameraProperties")
+		.def(py::init([](const py::array_t<float, py::array::c_style | py::array::forcecast>& transform, ECameraModel model, float focal_length, float near_distance, float aperture_size, float focus_z,
+		                 const SphericalQuadrilateral& sq, const QuadrilateralHexahedron& qh) {
+				RenderCameraProperties c;
+				c.transform = mat34_from_py(transform); c.model = model; c.focal_length = focal_length; c.near_distance = near_distance; c.aperture_size = aperture_size; c.focus_z = focus_z;
+				c.spherical_quadrilateral = sq; c.quadrilateral_hexahedron = qh;
+				return c;
+			}), py::arg("transform"), py::arg("model"), py::arg("focal_length"), py::arg("near_distance"), py::arg("aperture_size"), py::arg("focus_z"), py::arg("spherical_quadrilateral"),
+			py::arg("quadrilateral_hexahedron"))
+		.def("__eq__", [](const RenderCameraProperties& a, const RenderCameraProperties& b) { return a == b; })
+		.def("__ne__", [](const RenderCameraProperties& a, const RenderCameraProperties& b) { return a != b; });
+
+	py::class_<NerfDescriptor>(m, "NerfDescriptor")
+		.def(py::init([](const std::string& path, const BoundingBox& aabb, const py::array_t<float, py::array::c_style | py::array::forcecast>& transform, const RenderModifiersDescriptor& mods, float opacity) {
+				NerfDescriptor d;
+				d.snapshot_path = path; d.aabb = aabb; d.transform = mat4_from_py(transform); d.modifiers = mods; d.opacity = opacity;
+				return d;
+			}), py::arg("snapshot_path_str"), py::arg("aabb"), py::arg("transform"), py::arg("modifiers"), py::arg("opacity"));
+
+	py::class_<RenderRequest>(m, "RenderRequest")
+		.def(py::init([](const RenderOutputProperties& output, const RenderCameraProperties& camera, const RenderModifiersDescriptor& modifiers, const std::vector<NerfDescriptor>& nerfs, const BoundingBox& aabb) {
+				return RenderRequest{output, camera, modifiers, nerfs, aabb};
+			}), py::arg("output"), py::arg("camera"), py::arg("modifiers"), py::arg("nerfs"), py::arg("aabb"));
+
 	py::class_<Testbed> testbed(m, "Testbed");
 	testbed
 		.def(py::init<ETestbedMode>(), py::arg("mode") = ETestbedMode::Nerf)
@@ -111,6 +207,44 @@ PYBIND11_MODULE(pyngp, m) {
 				return result;
 			}, py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
 			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		.def("request_nerf_render_sync", [](Testbed& t, const RenderRequest& req) {  // python_api.cu:233-260, 581
+				std::vector<float> px;
+				{ py::gil_scoped_release rel; px = t.bl_request_nerf_render_sync(req); }
+				py::array_t<float> result({req.output.resolution[1], req.output.resolution[0], 4});
+				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				return result;
+			}, "Requests a nerf render frame.", py::arg("render_request"))
+		.def("request_nerf_render_async", [](Testbed& t, const RenderRequest& req, const py::function& callback) {  // python_api.cu:192-231, 577
+				if (!t.bl_try_begin_render()) return;   // a render is already in flight: the request is dropped (:218-220)
+				if (t.m_render_thread.joinable()) { py::gil_scoped_release rel; t.m_render_thread.join(); }
+				auto cb = std::make_shared<py::function>(callback);
+				t.m_render_thread = std::thread([&t, req, cb]() mutable {
+					std::vector<float> px;
+					std::string error;
+					try {
+						RenderBuffer& rb = t.m_bl_render_surface;
+						rb.resize(req.output.resolution[0], req.output.resolution[1]);
+						rb.reset_accumulation();
+						t.bl_render_frame(rb, req);
+						px.resize((size_t)req.output.resolution[0] * req.output.resolution[1] * 4);
+						rb.surface.copy_to_host(px.data(), px.size() * 4);
+					} catch (const std::exception& e) { error = e.what(); }
+					t.bl_end_render();   // before the callback, so that it may queue the next request
+					py::gil_scoped_acquire acquire;
+					try {
+						if (error.empty()) {
+							py::array_t<float> result({req.output.resolution[1], req.output.resolution[0], 4});
+							memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+							(*cb)(result);
+						} else {
+							fprintf(stderr, "request_nerf_render_async failed: %s\n", error.c_str());
+						}
+					} catch (py::error_already_set& e) { fprintf(stderr, "render callback raised: %s\n", e.what()); }
+					cb.reset();   // drop the Python reference while the GIL is held
+				});
+			}, "Requests a nerf render frame.", py::arg("render_request"), py::arg("callback"))
+		.def("wait_for_render", [](Testbed& t) { py::gil_scoped_release rel; if (t.m_render_thread.joinable()) t.m_render_thread.join(); })
+		.def_readonly("bl_render_samples", &Testbed::m_bl_render_samples)
 		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& cam) { t.set_nerf_camera_matrix(mat34_from_py(cam)); })
 		.def("reset_camera", &Testbed::reset_camera)
 		.def("reset_accumulation", [](Testbed& t) { t.m_windowless_render_surface.reset_accumulation(); })

@@ -1,6 +1,7 @@
 // testbed.cpp — see testbed.h.  Host orchestration only: every device-side computation goes through include/ngp_hip.h.
 #include "testbed.h"
 #include "snapshot.h"
+#include "nerf_renderer.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -176,6 +177,7 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	if (m_render_thread.joinable()) m_render_thread.join();
 	(void)hipDeviceSynchronize();
 	if (m_host_words) (void)hipHostFree(m_host_words);
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
@@ -832,6 +834,40 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	sync();
 	check(ngp_hip_shade(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
 	                    rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>()), "shade");
+}
+
+// ---- Blender multi-NeRF requests -------------------------------------------------------------------------------------------
+void Testbed::bl_render_frame(RenderBuffer& rb, const RenderRequest& request) {  // testbed.cu:2675-2693
+	if (!m_renderer) m_renderer.reset(new NerfRenderer());
+	rb.frame_buffer.memset(0, m_stream);   // CudaRenderBuffer::clear_frame
+	rb.depth_buffer.memset(0, m_stream);
+	m_bl_render_samples = m_renderer->render(rb, request, m_stream);
+	rb.color_space = request.output.color_space;
+	rb.tonemap_curve = request.output.tonemap_curve;
+	if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);
+	check(ngp_hip_accumulate(m_stream, rb.res, rb.frame_buffer.as<float>(), rb.accumulate_buffer.as<float>(), (float)rb.spp, (int)rb.color_space), "accumulate");
+	++rb.spp;
+	check(ngp_hip_tonemap(m_stream, rb.res, request.output.exposure, request.output.background_color, rb.accumulate_buffer.as<float>(), (int)rb.color_space,
+	                      (int)request.output.color_space, (int)rb.tonemap_curve, 0, rb.surface.as<float>()), "tonemap");
+	sync();
+}
+
+bool Testbed::bl_try_begin_render() { bool expected = false; return m_currently_rendering.compare_exchange_strong(expected, true); }
+void Testbed::bl_end_render() { m_currently_rendering.store(false); }
+
+std::vector<float> Testbed::bl_request_nerf_render_sync(const RenderRequest& request) {  // python_api.cu:233-260
+	const int w = request.output.resolution[0], h = request.output.resolution[1];
+	std::vector<float> out((size_t)w * h * 4, 0.f);
+	if (!bl_try_begin_render()) return out;   // the reference returns the untouched array while another render is in flight (:235-237)
+	try {
+		RenderBuffer& rb = m_bl_render_surface;
+		rb.resize(w, h);
+		rb.reset_accumulation();
+		bl_render_frame(rb, request);
+		rb.surface.copy_to_host(out.data(), out.size() * 4);
+	} catch (...) { bl_end_render(); throw; }
+	bl_end_render();
+	return out;
 }
 
 // ---- snapshots (testbed.cu:3006-3106; schema in snapshot.h) ---------------------------------------------------------------

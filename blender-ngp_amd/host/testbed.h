@@ -8,11 +8,13 @@
 // (std::runtime_error -> Python RuntimeError).
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mini_json.h"
@@ -173,6 +175,9 @@ struct RenderBuffer {
 
 struct TrainStats { float training_prep_ms = 0, training_ms = 0, render_ms = 0; };
 
+class NerfRenderer;
+struct RenderRequest;
+
 class Testbed {
 public:
 	explicit Testbed(ETestbedMode mode = ETestbedMode::Nerf);
@@ -209,6 +214,14 @@ public:
 	void train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
 	void train_nerf_dp_end();
 	void invalidate_training_inputs();
+	// ---- Blender multi-NeRF requests (python_api.cu:192-260, testbed.cu:2675-2693)
+	void bl_render_frame(RenderBuffer& rb, const RenderRequest& request);
+	std::vector<float> bl_request_nerf_render_sync(const RenderRequest& request);      // H*W*4 floats; zeros while another render is running
+	bool bl_try_begin_render();                                                        // false if a render is already in flight
+	void bl_end_render();
+	uint64_t m_bl_render_samples = 0;
+	RenderBuffer m_bl_render_surface;
+	std::thread m_render_thread;                       // request_nerf_render_async worker (joined before the next request / on destruction)
 	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	uint64_t m_prefetch_hits = 0;
@@ -291,6 +304,8 @@ public:
 	uint32_t m_rank = 0, m_world_size = 1;
 
 private:
+	std::unique_ptr<NerfRenderer> m_renderer;
+	std::atomic<bool> m_currently_rendering{false};
 	void* m_stream = nullptr;
 	void* m_stream_b = nullptr;                        // second stream: sample generation one step ahead
 	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };

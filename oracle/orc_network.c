@@ -158,7 +158,7 @@ void orc_nerf_forward_one(const orc_net* net, const uint16_t* params, const floa
  * With out_stride >= 16 all 16 padded rgb-net outputs are written like the reference's AoS matrix. */
 void orc_nerf_inference(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                         uint32_t n, uint16_t* out, uint32_t out_stride) {
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for schedule(static) if (n >= 512)
 	for (uint32_t i = 0; i < n; ++i) {
 		orc_act a;
 		orc_nerf_forward_one(net, params, coords + (size_t)i * coord_stride_floats, &a);
@@ -169,7 +169,7 @@ void orc_nerf_inference(const orc_net* net, const uint16_t* params, const float*
 
 /* nerf_network.h:268-284 density(): pos (3 floats, stride given) -> 16 fp16 density-net outputs; channel 0 is the density logit */
 void orc_nerf_density(const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0) {
-	#pragma omp parallel for schedule(static)
+	#pragma omp parallel for schedule(static) if (n >= 512)
 	for (uint32_t i = 0; i < n; ++i) {
 		uint16_t x[32], h1[64], d[16];
 		orc_grid_encode_one(net, params + GRID_OFF, pos + (size_t)i * pos_stride_floats, x);
