@@ -1,0 +1,33 @@
+// nerf_loader.h — transforms.json + image ingest (src/nerf_loader.cu:197-747, Testbed::load_nerf at src/testbed_nerf.cu:2735-2759).
+// Host-only first stage (JSON keys, path resolution, frame ordering / culling, PNG decode, RGBA8 fix-ups of convert_rgba32), so that it can be
+// tested without a GPU; Testbed::load_training_data uploads the result.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ngp_hip.h"
+#include "testbed.h"
+
+namespace ngp {
+
+struct LoadedNerfData {
+	size_t n_images = 0;
+	std::vector<std::string> paths;                 // as written in the json (NerfDataset::paths)
+	std::vector<NgpXForm> xforms;                   // already in the NGP convention (nerf_matrix_to_ngp)
+	std::vector<NgpImageMeta> metadata;             // .pixels unset
+	std::vector<std::vector<uint8_t>> pixels;       // RGBA8 per image (EImageDataType::Byte)
+	float scale = 1.0f;                             // NERF_SCALE (nerf_loader.h:28)
+	Vec3 offset{0.f, 0.f, 0.f};
+	int aabb_scale = 1;
+	bool from_mitsuba = false, is_hdr = false, wants_importance_sampling = true;
+	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
+	Vec3 up{0.0f, 1.0f, 0.0f};
+};
+
+// a .json file, or a directory (every *.json in it), like Testbed::load_nerf
+std::vector<std::string> resolve_nerf_json_paths(const std::string& data_path);
+LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float sharpen_amount = 0.f);
+// convert_rgba32 (nerf_loader.cu:59-81) on the host
+void convert_rgba32_host(size_t n_pixels, uint8_t* rgba, bool white_transparent, bool black_transparent, uint32_t mask_color);
+
+} // namespace ngp

@@ -1,0 +1,130 @@
+#include "png_reader.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace ngp {
+
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static int paeth(int a, int b, int c) {
+	const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+	if (pa <= pb && pa <= pc) return a;
+	if (pb <= pc) return b;
+	return c;
+}
+
+void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<uint8_t>& out) {
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+	if (n < 8 || memcmp(d, sig, 8) != 0) {
+		if (n >= 2 && d[0] == 0xff && d[1] == 0xd8) throw std::runtime_error("JPEG decoding is not part of this build (PNG only)");
+		throw std::runtime_error("not a PNG file");
+	}
+	size_t p = 8;
+	int depth = 0, ctype = 0, interlace = 0;
+	bool have_ihdr = false;
+	std::vector<uint8_t> idat, palette, trns;
+	while (p + 12 <= n) {
+		const uint32_t len = be32(d + p);
+		const uint8_t* type = d + p + 4;
+		const uint8_t* body = d + p + 8;
+		if (p + 12 + (size_t)len > n) throw std::runtime_error("PNG: truncated chunk");
+		if (!memcmp(type, "IHDR", 4)) {
+			if (len < 13) throw std::runtime_error("PNG: bad IHDR");
+			w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+			have_ihdr = true;
+		} else if (!memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
+		else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+		else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+		else if (!memcmp(type, "IEND", 4)) break;
+		p += 12 + (size_t)len;
+	}
+	if (!have_ihdr || w <= 0 || h <= 0) throw std::runtime_error("PNG: missing IHDR");
+	if (interlace) throw std::runtime_error("PNG: Adam7 interlacing is not supported");
+	int channels;
+	switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: throw std::runtime_error("PNG: bad colour type"); }
+	if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw std::runtime_error("PNG: unsupported bit depth");
+	if (ctype == 3 && palette.empty()) throw std::runtime_error("PNG: palette image without PLTE");
+	const size_t row_bytes = ((size_t)w * channels * depth + 7) / 8;
+	const size_t bpp = std::max<size_t>(1, (size_t)channels * depth / 8);
+	std::vector<uint8_t> raw((row_bytes + 1) * (size_t)h);
+	uLongf raw_len = (uLongf)raw.size();
+	const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+	if (zr != Z_OK || raw_len != raw.size()) throw std::runtime_error("PNG: zlib stream is corrupt or has the wrong size");
+	// unfilter in place (PNG spec 9.2)
+	std::vector<uint8_t> prev(row_bytes, 0);
+	for (int y = 0; y < h; ++y) {
+		uint8_t* row = raw.data() + (size_t)y * (row_bytes + 1);
+		const int f = row[0];
+		uint8_t* cur = row + 1;
+		for (size_t i = 0; i < row_bytes; ++i) {
+			const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+			int v = cur[i];
+			switch (f) {
+				case 0: break;
+				case 1: v += a; break;
+				case 2: v += b; break;
+				case 3: v += (a + b) >> 1; break;
+				case 4: v += paeth(a, b, c); break;
+				default: throw std::runtime_error("PNG: bad filter type");
+			}
+			cur[i] = (uint8_t)v;
+		}
+		memcpy(prev.data(), cur, row_bytes);
+	}
+	// to RGBA8
+	out.assign((size_t)w * h * 4, 255);
+	for (int y = 0; y < h; ++y) {
+		const uint8_t* cur = raw.data() + (size_t)y * (row_bytes + 1) + 1;
+		uint8_t* o = out.data() + (size_t)y * w * 4;
+		for (int x = 0; x < w; ++x, o += 4) {
+			auto sample = [&](int c) -> uint32_t {   // raw sample value of channel c at pixel x (not scaled)
+				if (depth == 8) return cur[(size_t)x * channels + c];
+				if (depth == 16) return ((uint32_t)cur[((size_t)x * channels + c) * 2] << 8) | cur[((size_t)x * channels + c) * 2 + 1];
+				const size_t bit = (size_t)x * depth;
+				return (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+			};
+			auto to8 = [&](uint32_t v) -> uint8_t { if (depth == 16) return (uint8_t)(v >> 8); if (depth == 8) return (uint8_t)v; return (uint8_t)(v * (255u / ((1u << depth) - 1u))); };
+			switch (ctype) {
+				case 0: {
+					const uint32_t g = sample(0);
+					o[0] = o[1] = o[2] = to8(g);
+					if (trns.size() >= 2 && g == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
+					break;
+				}
+				case 2: {
+					const uint32_t r = sample(0), g = sample(1), b = sample(2);
+					o[0] = to8(r); o[1] = to8(g); o[2] = to8(b);
+					if (trns.size() >= 6 && r == (((uint32_t)trns[0] << 8) | trns[1]) && g == (((uint32_t)trns[2] << 8) | trns[3]) && b == (((uint32_t)trns[4] << 8) | trns[5])) o[3] = 0;
+					break;
+				}
+				case 3: {
+					const uint32_t i = sample(0);
+					if ((size_t)i * 3 + 2 >= palette.size()) throw std::runtime_error("PNG: palette index out of range");
+					o[0] = palette[i * 3]; o[1] = palette[i * 3 + 1]; o[2] = palette[i * 3 + 2];
+					if (i < trns.size()) o[3] = trns[i];
+					break;
+				}
+				case 4: o[0] = o[1] = o[2] = to8(sample(0)); o[3] = to8(sample(1)); break;
+				default: o[0] = to8(sample(0)); o[1] = to8(sample(1)); o[2] = to8(sample(2)); o[3] = to8(sample(3)); break;
+			}
+		}
+	}
+}
+
+void read_png_rgba8(const std::string& path, int& w, int& h, std::vector<uint8_t>& pixels) {
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) throw std::runtime_error("Could not open image file: " + path);
+	std::vector<uint8_t> buf;
+	uint8_t tmp[1 << 16];
+	size_t k;
+	while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+	fclose(f);
+	try { decode_png_rgba8(buf.data(), buf.size(), w, h, pixels); }
+	catch (const std::runtime_error& e) { throw std::runtime_error("Could not open image file " + path + ": " + e.what()); }
+}
+
+} // namespace ngp

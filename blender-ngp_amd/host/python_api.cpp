@@ -8,6 +8,8 @@
 #include "testbed.h"
 #include "snapshot.h"
 #include "nerf_renderer.h"
+#include "nerf_loader.h"
+#include "png_reader.h"
 
 namespace py = pybind11;
 using namespace ngp;
@@ -100,6 +102,40 @@ PYBIND11_MODULE(pyngp, m) {
 		py::array_t<float> r(a.size());
 		for (py::ssize_t i = 0; i < a.size(); ++i) r.mutable_data()[i] = half_bits_to_float(a.data()[i]);
 		return r;
+	});
+	// host stage of the transforms.json loader (no GPU needed): exposed for tests and tooling
+	m.def("decode_png", [](const std::string& path) {
+		int w = 0, h = 0; std::vector<uint8_t> px;
+		read_png_rgba8(path, w, h, px);
+		py::array_t<uint8_t> a({h, w, 4});
+		memcpy(a.mutable_data(), px.data(), px.size());
+		return a;
+	});
+	m.def("load_nerf_host", [](const std::string& data_path) {
+		const LoadedNerfData d = load_nerf_host(resolve_nerf_json_paths(data_path));
+		py::dict out;
+		out["n_images"] = d.n_images; out["paths"] = d.paths; out["scale"] = d.scale; out["aabb_scale"] = d.aabb_scale; out["from_mitsuba"] = d.from_mitsuba;
+		out["offset"] = std::vector<float>{d.offset.x, d.offset.y, d.offset.z};
+		out["up"] = std::vector<float>{d.up.x, d.up.y, d.up.z};
+		out["render_aabb"] = std::vector<float>{d.render_aabb.min[0], d.render_aabb.min[1], d.render_aabb.min[2], d.render_aabb.max[0], d.render_aabb.max[1], d.render_aabb.max[2]};
+		py::list xf, meta, px;
+		for (size_t i = 0; i < d.n_images; ++i) {
+			Mat34 s, e; memcpy(s.m, d.xforms[i].start, sizeof(s.m)); memcpy(e.m, d.xforms[i].end, sizeof(e.m));
+			xf.append(py::make_tuple(mat34_to_py(s), mat34_to_py(e)));
+			const NgpImageMeta& m = d.metadata[i];
+			py::dict mj;
+			mj["resolution"] = std::vector<int>{m.res[0], m.res[1]};
+			mj["focal_length"] = std::vector<float>{m.focal_length[0], m.focal_length[1]};
+			mj["principal_point"] = std::vector<float>{m.principal_point[0], m.principal_point[1]};
+			mj["rolling_shutter"] = std::vector<float>(m.rolling_shutter, m.rolling_shutter + 4);
+			mj["lens_mode"] = m.lens_mode; mj["lens_params"] = std::vector<float>(m.lens_params, m.lens_params + 7);
+			meta.append(mj);
+			py::array_t<uint8_t> a({m.res[1], m.res[0], 4});
+			memcpy(a.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
+			px.append(a);
+		}
+		out["xforms"] = xf; out["metadata"] = meta; out["pixels"] = px;
+		return out;
 	});
 	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
 	m.def("device_memory_allocated", []() { return DeviceBuffer::total_allocated(); });
@@ -367,6 +403,26 @@ PYBIND11_MODULE(pyngp, m) {
 				t.set_camera_extrinsics(frame_idx, mat34_from_py(m), convert_to_ngp);
 			}, py::arg("frame_idx"), py::arg("camera_to_world"), py::arg("convert_to_ngp") = true)
 		.def("get_camera_extrinsics", [](NerfTraining& t, int frame_idx) { return mat34_to_py(t.get_camera_extrinsics(frame_idx)); }, py::arg("frame_idx"))
+		.def("get_image_metadata", [](NerfTraining& t, int i) {   // what the kernels see for training image i (TrainingImageMetadata, nerf_loader.h:30-45)
+				if (i < 0 || (size_t)i >= t.dataset.n_images) throw std::runtime_error{"Invalid frame index"};
+				const NgpImageMeta& m = t.dataset.metadata[i];
+				py::dict d;
+				d["resolution"] = std::vector<int>{m.res[0], m.res[1]};
+				d["focal_length"] = std::vector<float>{m.focal_length[0], m.focal_length[1]};
+				d["principal_point"] = std::vector<float>{m.principal_point[0], m.principal_point[1]};
+				d["rolling_shutter"] = std::vector<float>(m.rolling_shutter, m.rolling_shutter + 4);
+				d["lens_mode"] = m.lens_mode; d["lens_params"] = std::vector<float>(m.lens_params, m.lens_params + 7);
+				d["image_data_type"] = m.image_data_type;
+				return d;
+			}, py::arg("frame_idx"))
+		.def("get_image_rgba8", [](NerfTraining& t, int i) {      // device copy of a Byte-typed training image
+				if (i < 0 || (size_t)i >= t.dataset.n_images) throw std::runtime_error{"Invalid frame index"};
+				const NgpImageMeta& m = t.dataset.metadata[i];
+				if (m.image_data_type != 1) throw std::runtime_error{"image is not RGBA8"};
+				py::array_t<uint8_t> a({m.res[1], m.res[0], 4});
+				t.dataset.pixelmemory[i].copy_to_host(a.mutable_data(), (size_t)m.res[0] * m.res[1] * 4);
+				return a;
+			}, py::arg("frame_idx"))
 		.def("set_camera_intrinsics", &NerfTraining::set_camera_intrinsics, py::arg("frame_idx"), py::arg("fx") = 0.f, py::arg("fy") = 0.f, py::arg("cx") = -0.5f, py::arg("cy") = -0.5f,
 			py::arg("k1") = 0.f, py::arg("k2") = 0.f, py::arg("p1") = 0.f, py::arg("p2") = 0.f);
 }

@@ -1,6 +1,7 @@
 // testbed.cpp — see testbed.h.  Host orchestration only: every device-side computation goes through include/ngp_hip.h.
 #include "testbed.h"
 #include "snapshot.h"
+#include "nerf_loader.h"
 #include "nerf_renderer.h"
 
 #include <hip/hip_runtime_api.h>
@@ -252,10 +253,22 @@ void Testbed::set_fov(float val) {
 	m_relative_focal_length[0] = m_relative_focal_length[1] = f;
 }
 
-void Testbed::load_training_data(const std::string& path) {
-	(void)path;
-	throw std::runtime_error{"load_training_data: the transforms.json / image-decode loader is SURVEY.md §8f row f2 (next); "
-	                         "feed data with create_empty_nerf_dataset + nerf.training.set_image / set_camera_extrinsics"};
+void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:196-218 (Nerf mode) -> Testbed::load_nerf (testbed_nerf.cu:2735-2759)
+	drop_prefetch();
+	++m_state_version;
+	if (data_path.size() > 8 && data_path.substr(data_path.size() - 8) == ".msgpack") { load_snapshot(data_path); m_train = false; return; }
+	const LoadedNerfData data = load_nerf_host(resolve_nerf_json_paths(data_path), m_nerf.sharpen);
+	NerfDataset& d = m_nerf.training.dataset;
+	d = NerfDataset{};
+	d.n_images = data.n_images;
+	d.paths = data.paths; d.xforms = data.xforms; d.metadata = data.metadata;
+	d.pixelmemory.clear(); d.pixelmemory.resize(d.n_images);
+	d.scale = data.scale; d.offset = data.offset; d.aabb_scale = data.aabb_scale; d.from_mitsuba = data.from_mitsuba; d.is_hdr = data.is_hdr;
+	d.render_aabb = data.render_aabb; d.up = data.up;
+	for (size_t i = 0; i < d.n_images; ++i) d.set_training_image((int)i, data.metadata[i].res[0], data.metadata[i].res[1], data.pixels[i].data(), 1);
+	m_data_path = data_path;
+	load_nerf_post();
+	m_training_data_available = true;
 }
 
 void Testbed::create_empty_nerf_dataset(size_t n_images, int aabb_scale, bool is_hdr) {  // testbed_nerf.cu:2635-2641, nerf_loader.cu:175-195

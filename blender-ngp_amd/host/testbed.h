@@ -272,6 +272,7 @@ public:
 	bool m_max_level_rand_training = false;
 	Json m_network_config;
 	std::string m_network_config_path;
+	std::string m_data_path;
 	TrainStats m_stats;
 	RenderBuffer m_windowless_render_surface;
 	uint64_t m_render_samples_evaluated = 0;          // network samples of the last render_to_cpu (for MP/s + roofline accounting)

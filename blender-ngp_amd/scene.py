@@ -204,3 +204,23 @@ if __name__ == "__main__":
     print("trained %d steps in %.1fs (%.2f ms/step)" % (a.steps, dt, 1000 * dt / a.steps), flush=True)
     psnr, ssim, per = eval_test_views(tb, ds, spp=a.spp)
     print("PSNR=%.2f SSIM=%.4f per-view=%s render_ms=%.1f" % (psnr, ssim, ["%.1f" % p for p in per], tb.render_ms))
+
+
+def write_dataset(ds, directory):
+    """Write a dataset of make_dataset() in the nerf-synthetic on-disk layout (transforms_train.json + train/r_%03d.png, RGBA8): what
+    `Testbed.load_training_data` ingests (src/nerf_loader.cu).  Returns the path of transforms_train.json."""
+    import json
+    from PIL import Image
+    os.makedirs(os.path.join(directory, "train"), exist_ok=True)
+    frames = []
+    for i, (img, pose) in enumerate(zip(ds["train_images"], ds["train_poses"])):
+        name = "train/r_%03d" % i
+        Image.fromarray(np.ascontiguousarray(img), "RGBA").save(os.path.join(directory, name + ".png"))
+        m = np.eye(4); m[:3, :4] = np.asarray(pose)[:3, :4]
+        frames.append({"file_path": "./" + name, "transform_matrix": m.tolist()})
+    meta = {"fl_x": float(np.float32(ds["focal"])), "fl_y": float(np.float32(ds["focal"])), "cx": 0.5 * ds["res"], "cy": 0.5 * ds["res"], "w": ds["res"], "h": ds["res"],
+            "camera_angle_x": ds["camera_angle_x"], "aabb_scale": ds["aabb_scale"], "scale": ds["scale"], "offset": list(ds["offset"]), "frames": frames}
+    path = os.path.join(directory, "transforms_train.json")
+    with open(path, "w") as f:
+        json.dump(meta, f)
+    return path
