@@ -12,7 +12,8 @@ import os
 import sys
 
 # kernel-name substring -> stage (one stage = one ngp_hip_* entry point as bench.py times it)
-STAGES = [("nerf_forward_kernel<0", "nerf_inference"), ("nerf_forward_kernel<2", "nerf_forward"), ("nerf_forward_kernel<1", "nerf_density"),
+STAGES = [("nerf_forward_kernelILi0ELb0E", "nerf_inference"), ("nerf_forward_kernelILi2ELb0E", "nerf_forward"), ("nerf_forward_kernelILi1E", "density_grid_prep"),
+          ("encode_planes_kernel", "density_grid_prep"),
           ("nerf_backward_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema_kernel", "optimizer_step"),
           ("generate_training_samples_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
