@@ -108,11 +108,9 @@ __global__ void grid_to_bitfield_kernel(uint32_t n_elements, uint32_t n_nonzero_
 	bitfield[i] = bits;
 }
 
-// one thread per output BYTE of the next level is not possible (bits of one byte come from 8 different threads in the
-// reference: `next_level[morton] |= bits` with morton of the coarse cell == byte index).  Here: thread i owns coarse cell i's
-// 8 children bytes -> 1 bit... the reference writes a whole byte per thread: i indexes a group of 8 prev bytes (= 64 fine
-// cells = 8 coarse cells = one coarse BYTE), and the target byte index is morton3D(x+16, y+16, z+16) of that byte's cell
-// coordinates.  Target bytes are distinct across threads, so a plain read-modify-write is race-free.
+// testbed_nerf.cu:589-610.  Thread i reads 8 bytes of the finer level (64 cells = 8 coarse cells) and produces ONE byte of the coarser
+// level: bit j is set if fine byte j has any cell set.  The target is the byte whose (x, y, z) byte-coordinates are those of i shifted
+// by 16 (the finer cascade covers the central half of the coarser one); targets are distinct across threads, so the `|=` is race-free.
 __global__ void bitfield_max_pool_kernel(uint32_t n_elements, const uint8_t* __restrict__ prev_level, uint8_t* __restrict__ next_level) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;

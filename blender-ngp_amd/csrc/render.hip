@@ -1,7 +1,7 @@
 // render.hip — single-NeRF renderer kernels (Testbed::NerfTracer) + frame accumulate / tonemap for gfx950.
 // Replaces src/testbed_nerf.cu:612-664 (advance_pos_nerf), 705-765 (generate_next_nerf_network_inputs), 767-989
 // (composite_kernel_nerf; Shade mode, no masks / glow), 1748-1781 (shade_kernel_nerf), 1784-1807 (compact_kernel_nerf),
-// 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective camera) and src/render_buffer.cu:235-272, 274-348, 540-567.
+// 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective / OpenCV / FTheta / LatLong lenses) and src/render_buffer.cu:235-272, 274-348, 540-567.
 // Compaction uses wave64 ballots: one atomic per wave per counter instead of one per ray.
 #include "ngp_device.cuh"
 
@@ -27,13 +27,26 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	float ox, oy;
 	ld_random_pixel_offset(a.snap_to_pixel_centers ? 0 : a.sample_index, ox, oy);
 	const float pu = ((float)x + ox) / (float)a.res[0], pv = ((float)y + oy) / (float)a.res[1];
-	v3 dir = mk((pu - a.screen_center[0]) * (float)a.res[0] / a.focal_length[0], (pv - a.screen_center[1]) * (float)a.res[1] / a.focal_length[1], 1.0f);
-	if (a.lens_mode == 1) iterative_opencv_lens_undistortion(a.lens_params, dir.x, dir.y);
-	const v3 head_pos = mk(a.parallax_shift[0], a.parallax_shift[1], 0.f);
-	dir = dir - head_pos * a.parallax_shift[2];
-	dir = mat3_mul(cam, dir);
-	v3 origin = mat3_mul(cam, head_pos) + col(cam, 3);
-	origin = origin + dir * a.near_distance;
+	v3 dir, origin;
+	bool outside = false;
+	if (a.lens_mode == 2) {          // FTheta
+		dir = f_theta_undistortion(pu - a.screen_center[0], pv - a.screen_center[1], a.lens_params, mk(1000.f, 0.f, 0.f));
+		outside = dir.x == 1000.f;   // the reference returns a ray from (1000, 0, 0): outside the aabb, the pixel is not rendered
+	} else if (a.lens_mode == 3) {   // LatLong
+		dir = latlong_to_dir(pu, pv);
+	} else {
+		dir = mk((pu - a.screen_center[0]) * (float)a.res[0] / a.focal_length[0], (pv - a.screen_center[1]) * (float)a.res[1] / a.focal_length[1], 1.0f);
+		if (a.lens_mode == 1) iterative_opencv_lens_undistortion(a.lens_params, dir.x, dir.y);
+	}
+	if (outside) {
+		origin = mk(1000.f, 0.f, 0.f); dir = mk(0.f, 0.f, 1.f);
+	} else {
+		const v3 head_pos = mk(a.parallax_shift[0], a.parallax_shift[1], 0.f);
+		dir = dir - head_pos * a.parallax_shift[2];
+		dir = mat3_mul(cam, dir);
+		origin = mat3_mul(cam, head_pos) + col(cam, 3);
+		origin = origin + dir * a.near_distance;
+	}
 
 	NgpPayload p = a.payloads[idx];
 	p.max_weight = 0.0f;

@@ -214,6 +214,9 @@ static inline void orc_pcg32_advance(orc_pcg32* r, int64_t delta_) {
 /* LK-scrambled Sobol: random_val.cuh:148-288                          */
 /* ------------------------------------------------------------------ */
 uint32_t orc_sobol(uint32_t index, uint32_t dim);
+/* lens models shared by the training sampler and the renderer (common_device.cuh:145-200); defined in orc_sampling.c */
+orc_vec3 orc_f_theta_undistortion(float uvx, float uvy, const float* params, orc_vec3 error_direction);
+orc_vec3 orc_latlong_to_dir(float u, float v);
 static inline uint32_t orc_hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
 static inline uint32_t orc_reverse_bits(uint32_t x) {
 	x = (((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1));

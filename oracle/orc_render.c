@@ -17,11 +17,19 @@ static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[
 	orc_ld_random_pixel_offset(snap_to_pixel_centers ? 0 : spp, offset);
 	float u = ((float)px + offset[0]) / (float)res[0];
 	float v = ((float)py + offset[1]) / (float)res[1];
-	orc_vec3 dir = orc_v3(
-		(u - screen_center[0]) * (float)res[0] / focal_length[0],
-		(v - screen_center[1]) * (float)res[1] / focal_length[1],
-		1.0f);
-	if (lens_mode == 1) orc_iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+	orc_vec3 dir;
+	if (lens_mode == 2) {          /* FTheta (:281-285) */
+		dir = orc_f_theta_undistortion(u - screen_center[0], v - screen_center[1], lens_params, orc_v3(1000.f, 0.f, 0.f));
+		if (dir.x == 1000.f) { orc_ray out = {orc_v3(1000.f, 0.f, 0.f), orc_v3(0.f, 0.f, 1.f)}; return out; }   /* a point outside the aabb: pixel not rendered */
+	} else if (lens_mode == 3) {   /* LatLong (:286-287) */
+		dir = orc_latlong_to_dir(u, v);
+	} else {
+		dir = orc_v3(
+			(u - screen_center[0]) * (float)res[0] / focal_length[0],
+			(v - screen_center[1]) * (float)res[1] / focal_length[1],
+			1.0f);
+		if (lens_mode == 1) orc_iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+	}
 	orc_vec3 head_pos = orc_v3(parallax_shift[0], parallax_shift[1], 0.f);
 	dir = orc_sub(dir, orc_scale(head_pos, parallax_shift[2]));
 	dir = orc_mat3_mul(cam, dir);

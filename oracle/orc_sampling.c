@@ -262,7 +262,7 @@ void orc_iterative_opencv_lens_undistortion(const float* params, float* u, float
 }
 
 /* common_device.cuh:236-249 */
-static orc_vec3 orc_f_theta_undistortion(float uvx, float uvy, const float* params, orc_vec3 error_direction) {
+orc_vec3 orc_f_theta_undistortion(float uvx, float uvy, const float* params, orc_vec3 error_direction) {
 	float xpix = uvx * params[5], ypix = uvy * params[6];
 	float norm = sqrtf(xpix * xpix + ypix * ypix);
 	float alpha = params[0] + norm * (params[1] + norm * (params[2] + norm * (params[3] + norm * params[4])));
@@ -272,7 +272,7 @@ static orc_vec3 orc_f_theta_undistortion(float uvx, float uvy, const float* para
 	return orc_v3(sin_alpha * xpix, sin_alpha * ypix, cos_alpha);
 }
 /* common_device.cuh:251-258 */
-static orc_vec3 orc_latlong_to_dir(float u, float v) {
+orc_vec3 orc_latlong_to_dir(float u, float v) {
 	const float PI = 3.14159265358979323846f;
 	float theta = (v - 0.5f) * PI, phi = (u - 0.5f) * PI * 2.0f;
 	float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);

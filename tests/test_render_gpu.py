@@ -204,3 +204,41 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     assert diff.mean() < 2e-3, diff.mean()
     assert (diff.max(axis=1) > 0.05).mean() < 0.01
     np.testing.assert_array_equal(got[:, 3] > 0, fb_ref[:, 3] > 0)
+
+
+@pytest.mark.parametrize("lens_mode,params", [
+    (1, [0.05, -0.01, 0.001, -0.002, 0, 0, 0]),                       # OpenCV k1 k2 p1 p2
+    (2, [0.0, 1.1e-3 * 48, 0.0, 2e-9, 0.0, 48.0, 36.0]),              # FTheta p0..p4, w, h (alpha = p1 * r: ~equidistant fisheye)
+    (3, [0, 0, 0, 0, 0, 0, 0]),                                       # LatLong
+])
+def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
+    """render lenses of pixel_to_ray (common_device.cuh:260-317) beyond Perspective; sinf / cosf differ by ulps between libm and the device"""
+    cam, focal, res, sc = _camera()
+    aabb = H.unit_aabb(2)
+    n = W * Hh
+    ident = np.eye(3, dtype=np.float32).reshape(-1)
+    zero4, zero3 = np.zeros(4, np.float32), np.zeros(3, np.float32)
+    lp = np.array(params, np.float32)
+    if lens_mode == 2:
+        lp[5], lp[6] = W, Hh
+    pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
+    oracle.orc_init_rays(2, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data)
+    d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
+    check(ngp.ngp_hip_init_rays(None, 2, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
+                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr()))
+    g = H.to_host(d_pay, H.PAYLOAD)
+    same = g["alive"] == pay["alive"]
+    assert same.mean() > 0.995                      # a ray grazing the box may flip with a 1-ulp different direction
+    al = (pay["alive"] == 1) & same
+    assert al.sum() > 100
+    tol = 0 if lens_mode == 1 else 2e-6
+    np.testing.assert_allclose(g["dir"][al], pay["dir"][al], rtol=0, atol=tol)
+    np.testing.assert_allclose(g["origin"][al], pay["origin"][al], rtol=0, atol=tol)
+    np.testing.assert_allclose(g["t"][al], pay["t"][al], rtol=0, atol=1e-5 if lens_mode != 1 else 0)
+    # the lens actually bends the rays: directions differ from the pinhole ones
+    pin = np.zeros(n, H.PAYLOAD)
+    oracle.orc_init_rays(2, pin.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), 0, None, depth.ctypes.data)
+    both = al & (pin["alive"] == 1)
+    assert both.sum() > 50 and np.abs(pin["dir"][both] - pay["dir"][both]).max() > 1e-3
