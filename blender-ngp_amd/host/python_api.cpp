@@ -364,6 +364,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("sharpen", &Nerf::sharpen)
 		.def_readwrite("render_with_lens_distortion", &Nerf::render_with_lens_distortion)
 		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance)
+		.def_readwrite("render_max_steps_per_pass", &Nerf::render_max_steps_per_pass)
+		.def_readwrite("render_n_streams", &Nerf::render_n_streams)
 		.def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
 		.def_readwrite("show_accel", &Nerf::show_accel)
 		.def_readonly("max_cascade", &Nerf::max_cascade)

@@ -178,6 +178,9 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	for (void* st : m_render_streams) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
+	if (m_render_host_words) (void)hipHostFree(m_render_host_words);
+	if (m_render_event) (void)hipEventDestroy((hipEvent_t)m_render_event);
 	if (m_render_thread.joinable()) m_render_thread.join();
 	(void)hipDeviceSynchronize();
 	if (m_host_words) (void)hipHostFree(m_host_words);
@@ -794,9 +797,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
 	m_tr_hit_payload.enlarge(n_el * sizeof(NgpPayload)); m_tr_hit_rgba.enlarge(n_el * 16); m_tr_hit_depth.enlarge(n_el * 4);
 	m_tr_net_in.enlarge(n_el * 8 * sizeof(NgpCoord)); m_tr_net_out.enlarge(n_el * 8 * OUT_STRIDE * 2);
-	m_tr_counters.enlarge(8);
-	uint32_t* alive_counter = m_tr_counters.as<uint32_t>();
-	uint32_t* hit_counter = alive_counter + 1;
+	m_tr_counters.enlarge((2 + 8) * 4);
+	uint32_t* hit_counter = m_tr_counters.as<uint32_t>() + 1;
 
 	const int lens_mode = m_nerf.render_with_lens_distortion ? m_nerf.render_lens_proxy.lens_mode : 0;   // testbed_nerf.cu:2381
 	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
@@ -810,37 +812,78 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	                          min_mip, m_nerf.cone_angle_constant), "advance_pos");
 
 	HIP_CHECK_THROW(hipMemsetAsync(hit_counter, 0, 4, (hipStream_t)m_stream));
-	uint32_t n_alive = n_pixels, i = 1, dbi = 0;
+
+	// NerfTracer::trace (2140-2267).  The reference walks all rays of the frame in lock step on one stream: compact -> read n_alive back ->
+	// march n_steps -> network -> composite, ~40 times per frame, and every pass pays a host round trip plus a march that is bound by the
+	// latency of its longest ray.  Rays are independent, so the frame CAN be cut into K contiguous pixel ranges, each with its own stream and
+	// counters (while the host waits for one range's compaction result, the other ranges' passes run; same per-ray arithmetic, same image).
+	// Measured on MI355X / ROCm 7.0 the cross-queue scheduling costs more than the overlap buys (K = 1: 16.1 ms, 2: 27.5 ms, 3: 31.9 ms
+	// per 800x800 frame), so K defaults to 1 and the knob stays for re-measurement.
+	const uint32_t K = std::max(1u, std::min(m_nerf.render_n_streams, 8u));
+	while (m_render_streams.size() < K) { hipStream_t st; HIP_CHECK_THROW(hipStreamCreate(&st)); m_render_streams.push_back(st); }
+	if (!m_render_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_render_event = e; }
+	if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocDefault));
+	m_tr_counters.enlarge((2 + 8) * 4);
+	while (m_tr_enc_ws.size() < K) m_tr_enc_ws.emplace_back();
+	struct Part { uint32_t start, count, n_alive, i, dbi; bool done; };
+	std::vector<Part> parts(K);
+	const uint32_t per_part = next_multiple((n_pixels + K - 1) / K, BATCH_SIZE_GRANULARITY);
+	for (uint32_t p = 0; p < K; ++p) {
+		const uint32_t start = std::min(p * per_part, n_pixels);
+		parts[p] = Part{start, std::min(per_part, n_pixels - start), 0, 1, 0, false};
+		parts[p].n_alive = parts[p].count;
+		parts[p].done = parts[p].count == 0;
+	}
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_render_event, (hipStream_t)m_stream));
+	for (uint32_t p = 0; p < K; ++p) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_render_streams[p], (hipEvent_t)m_render_event, 0));
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
-	while (i < MARCH_ITER) {
-		const int cur = (dbi + 1) % 2, tmp = dbi % 2;
-		++dbi;
-		HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, (hipStream_t)m_stream));
-		check(ngp_hip_compact_rays(m_stream, n_alive, m_tr_rgba[tmp].as<float>(), m_tr_depth[tmp].as<float>(), m_tr_payload[tmp].as<NgpPayload>(), m_tr_rgba[cur].as<float>(),
-		                           m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(),
-		                           m_tr_hit_payload.as<NgpPayload>(), alive_counter, hit_counter), "compact_rays");
-		HIP_CHECK_THROW(hipMemcpyAsync(&n_alive, alive_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
-		sync();
-		if (n_alive == 0) break;
-		const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), 8u);
-		static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: pass structure on stderr
-		double t_stage[4] = {0, 0, 0, 0};
-		auto stamp = [&](int k) { if (trace) { sync(); t_stage[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
-		stamp(0);
-		check(ngp_hip_generate_next_inputs(m_stream, n_alive, &m_render_aabb, &m_aabb, m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(), n_steps,
-		                                   m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
-		stamp(1);
-		const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
-		// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
-		m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_elements));
-		check(ngp_hip_nerf_inference_ws(m_stream, desc, m_inference_params.as<uint16_t>(), m_tr_net_in.as<float>(), 7, n_elements, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (render)");
-		stamp(2);
-		m_render_samples_evaluated += n_elements;
-		check(ngp_hip_composite(m_stream, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), m_tr_payload[cur].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>(),
-		                        m_tr_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");
-		stamp(3);
-		if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u  next_inputs %.0f us  inference %.0f us  composite %.0f us\n", i, n_alive, n_steps, t_stage[1] - t_stage[0], t_stage[2] - t_stage[1], t_stage[3] - t_stage[2]);
-		i += n_steps;
+	uint32_t* alive_counters = m_tr_counters.as<uint32_t>() + 2;
+	volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
+	static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: pass structure on stderr
+	auto buf = [&](DeviceBuffer& b, size_t elem_bytes, uint32_t start) { return (char*)b.data() + (size_t)start * elem_bytes; };
+	bool any = true;
+	while (any) {
+		// stage A: queue the compaction of every active range and the read-back of its alive count
+		for (uint32_t p = 0; p < K; ++p) {
+			Part& pt = parts[p];
+			if (pt.done) continue;
+			hipStream_t st = (hipStream_t)m_render_streams[p];
+			const int cur = (pt.dbi + 1) % 2, tmp = pt.dbi % 2;
+			HIP_CHECK_THROW(hipMemsetAsync(alive_counters + p, 0, 4, st));
+			check(ngp_hip_compact_rays(st, pt.n_alive, (float*)buf(m_tr_rgba[tmp], 16, pt.start), (float*)buf(m_tr_depth[tmp], 4, pt.start), (NgpPayload*)buf(m_tr_payload[tmp], sizeof(NgpPayload), pt.start),
+			                           (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), (NgpPayload*)buf(m_tr_payload[cur], sizeof(NgpPayload), pt.start),
+			                           m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), alive_counters + p, hit_counter), "compact_rays");
+			HIP_CHECK_THROW(hipMemcpyAsync((void*)(host_alive + p), alive_counters + p, 4, hipMemcpyDeviceToHost, st));
+		}
+		// stage B: per range, wait for its count only, then queue its march / network / composite
+		any = false;
+		for (uint32_t p = 0; p < K; ++p) {
+			Part& pt = parts[p];
+			if (pt.done) continue;
+			hipStream_t st = (hipStream_t)m_render_streams[p];
+			HIP_CHECK_THROW(hipStreamSynchronize(st));
+			const int cur = (pt.dbi + 1) % 2;
+			++pt.dbi;
+			pt.n_alive = host_alive[p];
+			if (pt.n_alive == 0 || pt.i >= MARCH_ITER) { pt.done = true; continue; }
+			any = true;
+			// NerfTracer::trace (2231): clamp(n_rays_initialized / n_alive, 1, 8).  The per-ray sample sequence does not depend on how it is cut
+			// into passes and n_alive * n_steps <= n_rays keeps every buffer as sized for 8, so the cap is raised once few rays are left.
+			const uint32_t n_steps = std::min(std::max(pt.count / pt.n_alive, 1u), m_nerf.render_max_steps_per_pass);
+			if (trace) fprintf(stderr, "render pass part=%u i=%u n_alive=%u n_steps=%u\n", p, pt.i, pt.n_alive, n_steps);
+			NgpPayload* payloads = (NgpPayload*)buf(m_tr_payload[cur], sizeof(NgpPayload), pt.start);
+			NgpCoord* net_in = (NgpCoord*)buf(m_tr_net_in, 8 * sizeof(NgpCoord), pt.start);
+			uint16_t* net_out = (uint16_t*)buf(m_tr_net_out, 8 * OUT_STRIDE * 2, pt.start);
+			check(ngp_hip_generate_next_inputs(st, pt.n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+			const uint32_t n_elements = next_multiple(pt.n_alive * n_steps, BATCH_SIZE_GRANULARITY);
+			// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
+			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
+			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
+			m_render_samples_evaluated += n_elements;
+			check(ngp_hip_composite(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
+			                        (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");
+			pt.i += n_steps;
+		}
 	}
 	uint32_t n_hit = 0;
 	HIP_CHECK_THROW(hipMemcpyAsync(&n_hit, hit_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));

@@ -156,6 +156,8 @@ struct Nerf {
 	ENerfActivation density_activation = ENerfActivation::Exponential; // testbed.h:710
 	float cone_angle_constant = 1.f / 256.f;
 	float render_min_transmittance = 0.01f;  // testbed.h:725
+	uint32_t render_n_streams = 1;           // >1 traces the frame as independent pixel ranges on separate streams (measured slower on ROCm 7.0: 16 -> 28 ms at 2)
+	uint32_t render_max_steps_per_pass = 64; // the reference's m_max_steps_inbetween_compactions is 8 (testbed.h NerfTracer)
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
@@ -330,6 +332,10 @@ private:
 	DeviceBuffer m_distortion_map;  // 32x32x2 zeros: passed unconditionally to the ray generator
 	DeviceBuffer m_loss_scalar_gpu;
 	// tracer scratch (NerfTracer::enlarge 2270-2295)
+	std::vector<void*> m_render_streams;
+	void* m_render_event = nullptr;
+	void* m_render_host_words = nullptr;
+	std::vector<DeviceBuffer> m_tr_enc_ws;
 	DeviceBuffer m_tr_payload[2], m_tr_rgba[2], m_tr_depth[2], m_tr_hit_payload, m_tr_hit_rgba, m_tr_hit_depth, m_tr_net_in, m_tr_net_out, m_tr_counters;
 	struct ProfPending { int k; void* e0; void* e1; uint64_t units; };
 	std::vector<ProfPending> m_prof_pending;

@@ -116,3 +116,14 @@ def test_load_snapshot_errors(trained, tmp_path):
     open(p2, "wb").write(msgpack.packb(cfg, use_bin_type=True))
     with pytest.raises(RuntimeError, match="old format"):
         t.load_snapshot(p2)
+
+
+def test_render_schedule_does_not_change_the_image(trained):
+    """the tracer's pass structure (steps per compaction, number of independent pixel ranges / streams) is a schedule, not arithmetic"""
+    ds, tb, d = trained
+    tb.nerf.render_n_streams, tb.nerf.render_max_steps_per_pass = 1, 8          # the reference's schedule (testbed_nerf.cu:2231)
+    ref = _render(tb, ds)
+    for streams, cap in [(1, 64), (2, 8), (3, 64), (8, 64)]:
+        tb.nerf.render_n_streams, tb.nerf.render_max_steps_per_pass = streams, cap
+        np.testing.assert_array_equal(_render(tb, ds), ref)
+    assert ref[..., 3].max() > 0.5

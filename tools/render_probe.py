@@ -11,6 +11,10 @@ scene.train(tb, int(sys.argv[1]) if len(sys.argv) > 1 else 1000)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 psnr, ssim, per = scene.eval_test_views(tb, ds, spp=1, max_views=1)
 res = ds["res"]
+if os.environ.get("NGP_RENDER_STREAMS"):
+    tb.nerf.render_n_streams = int(os.environ["NGP_RENDER_STREAMS"])
+if os.environ.get("NGP_RENDER_CAP"):
+    tb.nerf.render_max_steps_per_pass = int(os.environ["NGP_RENDER_CAP"])
 tb.render(res, res, 1, True)
 t0 = time.perf_counter()
 for _ in range(n):
