@@ -354,6 +354,27 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("training_prep_ms", [](Testbed& t) { return t.m_stats.training_prep_ms; })
 		.def_property_readonly("render_samples_evaluated", [](Testbed& t) { return t.m_render_samples_evaluated; })
 		.def_property_readonly("aabb", [](Testbed& t) { return py::make_tuple(std::vector<float>(t.m_aabb.min, t.m_aabb.min + 3), std::vector<float>(t.m_aabb.max, t.m_aabb.max + 3)); })
+		// names scripts/run.py and the add-on touch on the NeRF path (python_api.cu:650-732); state that only the GUI consumes is stored as is
+		.def_readwrite("camera_smoothing", &Testbed::m_camera_smoothing)
+		.def_readwrite("loop_animation", &Testbed::m_loop_animation)
+		.def_readwrite("dynamic_res", &Testbed::m_dynamic_res)
+		.def_property("render_aabb", [](Testbed& t) { return BoundingBox(Vec3{t.m_render_aabb.min[0], t.m_render_aabb.min[1], t.m_render_aabb.min[2]}, Vec3{t.m_render_aabb.max[0], t.m_render_aabb.max[1], t.m_render_aabb.max[2]}); },
+			[](Testbed& t, const BoundingBox& b) { t.m_render_aabb = b.pod(); })
+		.def_property_readonly("raw_aabb", [](Testbed& t) { return BoundingBox(Vec3{t.m_raw_aabb.min[0], t.m_raw_aabb.min[1], t.m_raw_aabb.min[2]}, Vec3{t.m_raw_aabb.max[0], t.m_raw_aabb.max[1], t.m_raw_aabb.max[2]}); })
+		.def_property("up_dir", [](Testbed& t) { return vec3_to_py(t.m_up_dir); }, [](Testbed& t, const py::object& v) { t.m_up_dir = vec3_from_py(v); })
+		.def_property("render_mode", [](Testbed&) { return ERenderMode::Shade; }, [](Testbed&, ERenderMode m) {
+				if (m != ERenderMode::Shade) throw std::runtime_error{"only RenderMode.Shade is implemented on this build (the visualisation modes are GUI features)"}; })
+		.def("set_camera_to_training_view", [](Testbed& t, int i) {   // testbed_nerf.cu: camera <- training view i (already in NGP convention)
+				if (i < 0 || (size_t)i >= t.m_nerf.training.dataset.n_images) throw std::runtime_error{"Invalid training view"};
+				memcpy(t.m_camera.m, t.m_nerf.training.transforms[i].start, sizeof(t.m_camera.m));   // testbed.cu:273-281 (rolling shutter time 0)
+				const NgpImageMeta& m = t.m_nerf.training.dataset.metadata[i];
+				t.m_relative_focal_length[0] = m.focal_length[0] / (float)m.res[t.m_fov_axis]; t.m_relative_focal_length[1] = m.focal_length[1] / (float)m.res[t.m_fov_axis];
+				t.m_nerf.render_with_lens_distortion = true;
+				t.m_nerf.render_lens_proxy = m;
+				const NgpImageMeta& m0 = t.m_nerf.training.dataset.metadata[0];
+				t.m_screen_center[0] = 1.f - m0.principal_point[0]; t.m_screen_center[1] = 1.f - m0.principal_point[1];
+			}, py::arg("trainview"))
+		.def("clear_training_data", [](Testbed& t) { t.m_training_data_available = false; t.m_nerf.training.n_images_for_training = 0; })
 		.def_readonly("nerf", &Testbed::m_nerf);
 
 	py::class_<Nerf> nerf(testbed, "Nerf");
@@ -364,6 +385,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("sharpen", &Nerf::sharpen)
 		.def_readwrite("render_with_lens_distortion", &Nerf::render_with_lens_distortion)
 		.def_readwrite("render_min_transmittance", &Nerf::render_min_transmittance)
+		.def_readwrite("rendering_min_transmittance", &Nerf::render_min_transmittance)      // the name scripts/run.py uses (python_api.cu:751)
+		.def_readwrite("render_with_camera_distortion", &Nerf::render_with_lens_distortion)  // legacy name (python_api.cu:747)
 		.def_readwrite("render_max_steps_per_pass", &Nerf::render_max_steps_per_pass)
 		.def_readwrite("render_n_streams", &Nerf::render_n_streams)
 		.def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
@@ -380,6 +403,14 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("random_bg_color", &NerfTraining::random_bg_color)
 		.def_readwrite("linear_colors", &NerfTraining::linear_colors)
 		.def_readwrite("loss", &NerfTraining::loss_type)
+		.def_readwrite("loss_type", &NerfTraining::loss_type)
+		.def_property_readonly("n_images", [](NerfTraining& t) { return t.dataset.n_images; })
+		.def_property_readonly("aabb_scale", [](NerfTraining& t) { return t.dataset.aabb_scale; })
+		.def_property_readonly("is_hdr", [](NerfTraining& t) { return t.dataset.is_hdr; })
+		.def_property_readonly("from_mitsuba", [](NerfTraining& t) { return t.dataset.from_mitsuba; })
+		.def_property_readonly("paths", [](NerfTraining& t) { return t.dataset.paths; })
+		.def_property_readonly("scale", [](NerfTraining& t) { return t.dataset.scale; })
+		.def_property_readonly("offset", [](NerfTraining& t) { return vec3_to_py(t.dataset.offset); })
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
 		.def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)

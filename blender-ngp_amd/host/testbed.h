@@ -266,6 +266,8 @@ public:
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
 	Mat34 m_camera;
+	bool m_camera_smoothing = false, m_loop_animation = false, m_dynamic_res = false;   // GUI-side state kept for script compatibility
+	Vec3 m_up_dir{0.f, 1.f, 0.f};
 	float m_relative_focal_length[2] = {1.f, 1.f};
 	uint32_t m_fov_axis = 1;
 	float m_zoom = 1.f;

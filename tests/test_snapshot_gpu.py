@@ -127,3 +127,31 @@ def test_render_schedule_does_not_change_the_image(trained):
         tb.nerf.render_n_streams, tb.nerf.render_max_steps_per_pass = streams, cap
         np.testing.assert_array_equal(_render(tb, ds), ref)
     assert ref[..., 3].max() > 0.5
+
+
+def test_script_facing_properties(trained):
+    """names scripts/run.py and the add-on read / write on the NeRF path (python_api.cu:650-761)"""
+    import pyngp
+    ds, tb, d = trained
+    tb.nerf.rendering_min_transmittance = 1e-4
+    assert tb.nerf.render_min_transmittance == pytest.approx(1e-4)
+    tb.nerf.render_with_camera_distortion = True
+    assert tb.nerf.render_with_lens_distortion
+    tb.camera_smoothing = False; tb.loop_animation = False; tb.dynamic_res = False
+    assert tb.nerf.training.n_images == 8 and tb.nerf.training.aabb_scale == 1 and not tb.nerf.training.is_hdr
+    assert tb.nerf.training.loss_type == tb.nerf.training.loss
+    bb = tb.render_aabb
+    assert np.allclose(bb.min, [0, 0, 0]) and np.allclose(bb.max, [1, 1, 1]) and np.allclose(tb.raw_aabb.max, [1, 1, 1])
+    tb.render_mode = pyngp.RenderMode.Shade
+    with pytest.raises(RuntimeError):
+        tb.render_mode = pyngp.RenderMode.Normals
+    tb.set_camera_to_training_view(3)
+    tb.shall_train = False
+    tb.background_color = [0.0, 0.0, 0.0, 0.0]
+    img = tb.render(64, 64, 1, True)
+    ref = ds["train_images"][3]
+    ref = np.asarray(ref.cpu().numpy() if hasattr(ref, "cpu") else ref).astype(np.float32) / 255.0
+    # rendered from the training pose with the training intrinsics, the picture correlates with the training image's alpha
+    a, b = img[..., 3].reshape(-1), ref[..., 3].reshape(-1)
+    assert a.std() > 0 and b.std() > 0, (float(a.min()), float(a.max()), float(b.min()), float(b.max()), ref.shape)
+    assert np.corrcoef(a, b)[0, 1] > 0.5
