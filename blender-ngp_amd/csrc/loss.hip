@@ -283,6 +283,87 @@ __global__ void fill_rollover_f32_kernel(uint32_t n_elements, uint32_t stride, c
 	inout[i] = inout[i % n_input];
 }
 
+
+// ---- plumbing configs P1 / P2: tcnn losses driven by Trainer::training_step, sample generation of Testbed::train_image ----------------
+// [tcnn] losses/{l2,relative_l2,l1,mape}.h: per element i of the (padded) prediction matrix, n_total = n * dims,
+//   value = f(d) / n_total, gradient = loss_scale * f'(d) / n_total with d = prediction - target.  Padding channels get zero gradient.
+__global__ void loss_and_gradient_kernel(int loss_type, uint32_t n, uint32_t dims, float loss_scale, const half_t* __restrict__ predictions, uint32_t pred_stride,
+                                         const float* __restrict__ targets, float* __restrict__ values, half_t* __restrict__ gradients, uint32_t grad_stride) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n * 4u) return;
+	const uint32_t s = i >> 2, c = i & 3u;
+	if (c >= dims) { gradients[(size_t)s * grad_stride + c] = (half_t)0.0f; return; }
+	const float n_total = (float)(n * dims);
+	const float prediction = (float)predictions[(size_t)s * pred_stride + c];
+	const float target = targets[(size_t)s * dims + c];
+	const float difference = prediction - target;
+	float value, gradient;
+	switch (loss_type) {
+		case NGP_LOSS_L2: value = difference * difference; gradient = 2.0f * difference; break;
+		case NGP_LOSS_RELATIVE_L2: { const float pn = prediction * prediction + 0.01f; value = difference * difference / pn; gradient = 2.0f * difference / pn; break; }
+		case NGP_LOSS_L1: value = fabsf(difference); gradient = copysignf(1.0f, difference); break;
+		default: { const float sc = 1.0f / (fabsf(target) + 0.01f); value = fabsf(difference) * sc; gradient = copysignf(sc, difference); break; }   // MAPE
+	}
+	values[(size_t)s * dims + c] = value / n_total;
+	float gs = loss_scale * gradient / n_total;
+	asm volatile("" : "+v"(gs));   // one rounding to fp16 of the fp32 product (no fused multiply-convert)
+	gradients[(size_t)s * grad_stride + c] = (half_t)gs;
+}
+
+// [tcnn] generate_random_uniform: element k is the k-th next_float() of the generator (each thread advances to its own offset)
+__global__ void random_uniform_kernel(uint32_t n_elements, Pcg32 rng, float* __restrict__ out) {
+	const uint32_t i = (threadIdx.x + blockIdx.x * blockDim.x) * 4u;
+	if (i >= n_elements) return;
+	rng.advance(i);
+#pragma unroll
+	for (uint32_t j = 0; j < 4; ++j) { if (i + j < n_elements) out[i + j] = rng.next_float(); }
+}
+
+// testbed_image.cu:62-77 stratify2_kernel
+__global__ void stratify2_kernel(uint32_t n_elements, uint32_t log2_batch_size, float2* __restrict__ inout) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const uint32_t log2_size = log2_batch_size / 2, size = 1u << log2_size;
+	const uint32_t in_batch_index = i & ((1u << log2_batch_size) - 1u);
+	const uint32_t x = in_batch_index & ((1u << log2_size) - 1u), y = in_batch_index >> log2_size;
+	const float2 val = inout[i];
+	inout[i] = make_float2(val.x / (float)size + ((float)x / (float)size), val.y / (float)size + ((float)y / (float)size));
+}
+
+// testbed_image.cu:172-218 eval_image_kernel_and_snap<T, stride>: bilinear target lookup (or nearest + snap of the position)
+template <typename T>
+__global__ void eval_image_and_snap_kernel(uint32_t n_elements, const T* __restrict__ texture, float2* __restrict__ positions, int rx, int ry, float* __restrict__ result, uint32_t stride,
+                                           bool snap_to_pixel_centers, bool linear_colors) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	float2 pos = positions[i];
+	auto read_val = [&](int x, int y, float* o) {
+		const T* t = texture + ((size_t)y * rx + x) * 4;
+		o[0] = (float)t[0]; o[1] = (float)t[1]; o[2] = (float)t[2]; o[3] = (float)t[3];
+		if (!linear_colors) { o[0] = linear_to_srgb(o[0]); o[1] = linear_to_srgb(o[1]); o[2] = linear_to_srgb(o[2]); }
+	};
+	float val[4];
+	if (snap_to_pixel_centers) {
+		int px = (int)floorf(pos.x * (float)rx), py = (int)floorf(pos.y * (float)ry);
+		positions[i] = make_float2(((float)px + 0.5f) / (float)rx, ((float)py + 0.5f) / (float)ry);
+		px = px < 0 ? 0 : (px > rx - 1 ? rx - 1 : px); py = py < 0 ? 0 : (py > ry - 1 ? ry - 1 : py);
+		read_val(px, py, val);
+	} else {
+		pos.x = fminf(fmaxf(pos.x * (float)rx - 0.5f, 0.0f), (float)rx - (1.0f + 1e-4f));
+		pos.y = fminf(fmaxf(pos.y * (float)ry - 0.5f, 0.0f), (float)ry - (1.0f + 1e-4f));
+		const int ix = (int)pos.x, iy = (int)pos.y;
+		const float wx = pos.x - (float)ix, wy = pos.y - (float)iy;
+		const int x0 = ix < rx - 2 ? (ix < 0 ? 0 : ix) : (rx - 2 < 0 ? 0 : rx - 2), y0 = iy < ry - 2 ? (iy < 0 ? 0 : iy) : (ry - 2 < 0 ? 0 : ry - 2);
+		float a[4], b[4], c[4], d[4];
+		read_val(x0, y0, a); read_val(x0 + 1, y0, b); read_val(x0, y0 + 1, c); read_val(x0 + 1, y0 + 1, d);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) val[k] = ((((1 - wx) * (1 - wy)) * a[k] + ((wx) * (1 - wy)) * b[k]) + ((1 - wx) * (wy)) * c[k]) + ((wx) * (wy)) * d[k];
+	}
+	float* r = result + (size_t)i * stride;
+	r[0] = val[0]; r[1] = val[1]; r[2] = val[2];
+	for (uint32_t k = 3; k < stride; ++k) r[k] = 1.0f;
+}
+
 } // namespace ngp
 
 using namespace ngp;
@@ -328,6 +409,45 @@ int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(fill_rollover_f32_kernel, dim3(div_up(n_elements * stride, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, stride, n_input_elements, inout);
 	NGP_LAUNCH_CHECK("fill_rollover_f32_kernel");
+	return 0;
+}
+
+int ngp_hip_loss_and_gradient(void* stream, int loss_type, uint32_t n, uint32_t dims, float loss_scale, const uint16_t* predictions, uint32_t pred_stride, const float* targets,
+                              float* values, uint16_t* gradients, uint32_t grad_stride) {
+	if (!n) return 0;
+	if (dims < 1 || dims > 4 || pred_stride < dims || grad_stride < 4) { set_last_error("ngp_hip_loss_and_gradient: 1 <= dims <= 4, pred_stride >= dims, grad_stride >= 4", hipErrorInvalidValue); return -1; }
+	if (loss_type != NGP_LOSS_L2 && loss_type != NGP_LOSS_RELATIVE_L2 && loss_type != NGP_LOSS_L1 && loss_type != NGP_LOSS_MAPE) { set_last_error("ngp_hip_loss_and_gradient: loss must be L2, RelativeL2, L1 or MAPE", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(loss_and_gradient_kernel, dim3(div_up(n * 4u, 256)), dim3(256), 0, (hipStream_t)stream, loss_type, n, dims, loss_scale, (const half_t*)predictions, pred_stride, targets, values,
+	                   (half_t*)gradients, grad_stride);
+	NGP_LAUNCH_CHECK("loss_and_gradient_kernel");
+	return 0;
+}
+
+int ngp_hip_generate_random_uniform(void* stream, uint64_t rng_state, uint64_t rng_inc, uint32_t n_elements, float* out) {
+	if (!n_elements) return 0;
+	Pcg32 rng; rng.state = rng_state; rng.inc = rng_inc;
+	hipLaunchKernelGGL(random_uniform_kernel, dim3(div_up(div_up(n_elements, 4u), 256)), dim3(256), 0, (hipStream_t)stream, n_elements, rng, out);
+	NGP_LAUNCH_CHECK("random_uniform_kernel");
+	return 0;
+}
+
+int ngp_hip_image_stratify2(void* stream, uint32_t n_elements, uint32_t log2_batch_size, float* inout_xy) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(stratify2_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, log2_batch_size, (float2*)inout_xy);
+	NGP_LAUNCH_CHECK("stratify2_kernel");
+	return 0;
+}
+
+int ngp_hip_image_eval_and_snap(void* stream, uint32_t n_elements, const void* texture, int image_data_type, float* positions_xy, const int32_t* resolution_host, float* result,
+                                uint32_t stride, int snap_to_pixel_centers, int linear_colors) {
+	if (!n_elements) return 0;
+	if (stride < 3) { set_last_error("ngp_hip_image_eval_and_snap: stride must be >= 3", hipErrorInvalidValue); return -1; }
+	if (image_data_type == 2) hipLaunchKernelGGL(eval_image_and_snap_kernel<half_t>, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, (const half_t*)texture, (float2*)positions_xy,
+	                                            resolution_host[0], resolution_host[1], result, stride, snap_to_pixel_centers != 0, linear_colors != 0);
+	else if (image_data_type == 3) hipLaunchKernelGGL(eval_image_and_snap_kernel<float>, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, (const float*)texture, (float2*)positions_xy,
+	                                                 resolution_host[0], resolution_host[1], result, stride, snap_to_pixel_centers != 0, linear_colors != 0);
+	else { set_last_error("ngp_hip_image_eval_and_snap: image_data_type must be 2 (half4) or 3 (float4)", hipErrorInvalidValue); return -1; }
+	NGP_LAUNCH_CHECK("eval_image_and_snap_kernel");
 	return 0;
 }
 

@@ -69,6 +69,23 @@ constexpr int T_W2T = 38; // + mt          (2)   A[i = h1 feat][slot = density-o
 constexpr int T_W1T = 40; // + kb          (4)   A[i = x feat][slot = h1 feat]
 constexpr int N_ALL_TILES = 44;
 
+// one A-operand tile of a row-major [n_out][n_in] weight matrix at P + w_off: element (i = mt*32 + lane&31, K-slot (kb, lane>>5, e))
+__device__ __forceinline__ h8 gather_tile_spec(const half_t* __restrict__ P, int w_off, int n_out, int n_in, int mt, int kb, int map, bool transposed, int lane) {
+	const int i32 = lane & 31, g = lane >> 5;
+	const half_t* W = P + w_off;
+	const int i = mt * 32 + i32;
+	h8 r;
+#pragma unroll
+	for (int e = 0; e < 8; ++e) {
+		const int f = slot_feature(map, kb, g, e);
+		half_t v = (half_t)0.0f;
+		if (!transposed) { if (i < n_out && f < n_in) v = W[i * n_in + f]; }     // A[i = out][slot = in feature f]
+		else             { if (f < n_out && i < n_in) v = W[f * n_in + i]; }     // A[i = in][slot = out feature f]
+		r[e] = v;
+	}
+	return r;
+}
+
 // element of forward tile: W[row i][col slot_feature]
 __device__ __forceinline__ h8 gather_tile(const half_t* __restrict__ P, int tile, int lane) {
 	const int i32 = lane & 31, g = lane >> 5;
@@ -122,6 +139,18 @@ __device__ __forceinline__ uint32_t grid_index(const NgpGridLevel& lv, uint32_t 
 	if (stride <= lv.size) { index += y * stride; stride *= lv.resolution;
 		if (stride <= lv.size) { index += z * stride; stride *= lv.resolution; } }
 	if (lv.size < stride) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+	if ((lv.size & (lv.size - 1)) == 0) return index & (lv.size - 1);
+	return index >= lv.size ? index % lv.size : index;
+}
+
+// tcnn grid_index<N_DIMS>: dense strides while they fit the table, else the spatial hash of the first N_DIMS primes {1, 2654435761, 805459861}
+template <int D>
+__device__ __forceinline__ uint32_t grid_index_nd(const NgpGridLevel& lv, uint32_t x, uint32_t y, uint32_t z) {
+	if (D == 3) return grid_index(lv, x, y, z);
+	uint32_t stride = 1, index = 0;
+	if (stride <= lv.size) { index += x * stride; stride *= lv.resolution;
+		if (stride <= lv.size) { index += y * stride; stride *= lv.resolution; } }
+	if (lv.size < stride) index = (x * 1u) ^ (y * 2654435761u);
 	if ((lv.size & (lv.size - 1)) == 0) return index & (lv.size - 1);
 	return index >= lv.size ? index % lv.size : index;
 }
@@ -457,8 +486,10 @@ __host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
 }
 
 // grid (GB_ITEMS, 16 levels), block 1024.  dx planes: [level][sample] half2.  partials: [(level*GB_ITEMS + item)][GB_SLICE] half2.
+template <int D>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z term)
 __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                              const h2* __restrict__ dx_planes, h2* __restrict__ partials, uint32_t level_base) {
+	constexpr int NC = 1 << D;
 	__shared__ h2 slice[GB_SLICE];
 	const uint32_t level = blockIdx.y + level_base, item = blockIdx.x;
 	const NgpGridLevel lv = desc->levels[level];
@@ -472,7 +503,7 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 	__syncthreads();
 	const uint32_t s_begin = (uint32_t)(((uint64_t)n * chunk) / sp.k_chunks), s_end = (uint32_t)(((uint64_t)n * (chunk + 1)) / sp.k_chunks);
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	const bool dense = (uint64_t)lv.resolution * lv.resolution * lv.resolution <= (uint64_t)lv.size;
+	const bool dense = (D == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
 	if (dense) {
 		// Dense (coarse) levels: tens of consecutive ray samples share a cell, i.e. the same 8 corner keys.  Every thread walks GB_RUN
 		// CONSECUTIVE samples, sums their contributions in fp32 registers while the cell stays the same and issues one LDS atomic per
@@ -486,7 +517,7 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 			for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; rels[k] = 0; }
 			auto flush = [&]() {
 #pragma unroll
-				for (int k = 0; k < 8; ++k) {
+				for (int k = 0; k < NC; ++k) {
 					if (mask & (1u << k)) {
 						h2 val; val[0] = (half_t)a0[k]; val[1] = (half_t)a1[k];
 						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rels[k]], val);
@@ -501,7 +532,7 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				const uint32_t sc = s0 + u < s_end ? s0 + u : s_begin;
 				gqs[u] = dxl[sc];
 				const float* c = coords + (size_t)sc * coord_stride;
-				pxs[u] = c[0]; pys[u] = c[1]; pzs[u] = c[2];
+				pxs[u] = c[0]; pys[u] = c[1]; pzs[u] = D == 3 ? c[2] : 0.f;
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < GB_RUN; ++u) {
@@ -513,8 +544,8 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 					cgx = p.gx; cgy = p.gy; cgz = p.gz;
 					mask = 0;
 #pragma unroll
-					for (int k = 0; k < 8; ++k) {
-						const uint32_t rel = grid_index(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1)) - lo;
+					for (int k = 0; k < NC; ++k) {
+						const uint32_t rel = grid_index_nd<D>(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1)) - lo;
 						rels[k] = rel;
 						if (rel < cnt) mask |= 1u << k;
 						a0[k] = 0.f; a1[k] = 0.f;
@@ -522,10 +553,10 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				}
 				if (mask) {
 #pragma unroll
-					for (int k = 0; k < 8; ++k) {
+					for (int k = 0; k < NC; ++k) {
 						float w = (k & 1) ? p.fx : (1.0f - p.fx);
 						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
-						w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+						if (D == 3) w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
 						a0[k] += w * g0; a1[k] += w * g1;
 					}
 				}
@@ -547,7 +578,7 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				const uint32_t sc = s < s_end ? s : s_begin;   // clamp: the load is always in range, the result is masked below
 				gq[u] = dxl[sc];
 				const float* c = coords + (size_t)sc * coord_stride;
-				px[u] = c[0]; py[u] = c[1]; pz[u] = c[2];
+				px[u] = c[0]; py[u] = c[1]; pz[u] = D == 3 ? c[2] : 0.f;
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < GB_UNROLL; ++u) {
@@ -557,14 +588,14 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
 				const uint32_t hx[2] = {p.gx, p.gx + 1u};
 				const uint32_t hy[2] = {p.gy * 2654435761u, (p.gy + 1u) * 2654435761u};
-				const uint32_t hz[2] = {p.gz * 805459861u, (p.gz + 1u) * 805459861u};
+				const uint32_t hz[2] = {D == 3 ? p.gz * 805459861u : 0u, D == 3 ? (p.gz + 1u) * 805459861u : 0u};
 #pragma unroll
-				for (int k = 0; k < 8; ++k) {
+				for (int k = 0; k < NC; ++k) {
 					const uint32_t rel = ((hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[(k >> 2) & 1]) & hmask) - lo;
 					if (rel < cnt) {
 						float w = (k & 1) ? p.fx : (1.0f - p.fx);
 						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
-						w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+						if (D == 3) w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
 						h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);   // tcnn kernel_grid_backward: half2(w * dL/dx)
 						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rel], val);
 					}
@@ -693,13 +724,200 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 	}
 }
 
+
+// ================================================================================================================
+// Plumbing configs P1 / P2: ONE grid encoding (2-D or 3-D, 16 levels x 2 features) -> ONE FullyFusedMLP 32 -> 64 -> 64 -> 16
+// (tcnn NetworkWithInputEncoding as built by Testbed::reset_network for Image / Sdf mode, src/testbed.cu:2397-2445; configs/image/base.json,
+// configs/sdf/base.json).  Parameter order: MLP (input 64x32, hidden 64x64, output 16x64 = 7168), then the grid.  Same wave-owns-32-samples
+// MFMA chaining as the NeRF kernels; the topology equals the NeRF colour network fed by the encoding instead of [density | SH].
+constexpr uint32_t GM_L0_OFF = 0, GM_L1_OFF = 64 * 32, GM_L2_OFF = GM_L1_OFF + 64 * 64, GM_GRID_OFF = GM_L2_OFF + 16 * 64;   // 7168
+static_assert(GM_GRID_OFF == NGP_GRIDMLP_N_PARAMS, "GridMLP parameter count");
+constexpr int G_L0 = 0;    // + mt*2 + kb (4)   [64][32], K slots = encoding features (MAP_ENC)
+constexpr int G_L1 = 4;    // + mt*4 + kb (8)   [64][64]
+constexpr int G_L2 = 12;   // + kb        (4)   [16][64]
+constexpr int GM_FWD_TILES = 16;
+constexpr int G_L2T = 16;  // + mt        (2)   A[i = h2 feat][slot = channel]
+constexpr int G_L1T = 18;  // + mt*4 + kb (8)   A[i = h1 feat][slot = h2 feat]
+constexpr int G_L0T = 26;  // + kb        (4)   A[i = x feat][slot = h1 feat]
+constexpr int GM_ALL_TILES = 30;
+
+__device__ __forceinline__ h8 gm_gather_tile(const half_t* __restrict__ P, int tile, int lane) {
+	if (tile < G_L1)  return gather_tile_spec(P, GM_L0_OFF, 64, 32, (tile - G_L0) >> 1, (tile - G_L0) & 1, MAP_ENC, false, lane);
+	if (tile < G_L2)  return gather_tile_spec(P, GM_L1_OFF, 64, 64, (tile - G_L1) >> 2, (tile - G_L1) & 3, MAP_HID, false, lane);
+	if (tile < G_L2T) return gather_tile_spec(P, GM_L2_OFF, 16, 64, 0, tile - G_L2, MAP_HID, false, lane);
+	if (tile < G_L1T) return gather_tile_spec(P, GM_L2_OFF, 16, 64, tile - G_L2T, 0, MAP_CH, true, lane);
+	if (tile < G_L0T) return gather_tile_spec(P, GM_L1_OFF, 64, 64, (tile - G_L1T) >> 2, (tile - G_L1T) & 3, MAP_HID, true, lane);
+	return gather_tile_spec(P, GM_L0_OFF, 64, 32, 0, tile - G_L0T, MAP_HID, true, lane);
+}
+__device__ __forceinline__ void gm_stage_weights(h8* lds_tiles, const half_t* __restrict__ params, int n_tiles) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	for (int t = w; t < n_tiles; t += nw) lds_tiles[t * 64 + lane] = gm_gather_tile(params, t, lane);
+	__syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void encode_level_nd(const NgpGridLevel lv, const h2* __restrict__ grid, float px, float py, float pz, half_t& o0, half_t& o1) {
+	if (D == 3) { encode_level<false>(lv, grid, px, py, pz, o0, o1); return; }
+	const LevelPos p = level_pos(lv, px, py, 0.0f);
+	h2 v[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t idx = grid_index_nd<2>(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), 0u);
+		v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
+	}
+	float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float w = (c & 1) ? p.fx : (1.0f - p.fx);
+		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
+		r0 += w * (float)v[c][0];
+		r1 += w * (float)v[c][1];
+	}
+	o0 = (half_t)r0; o1 = (half_t)r1;
+}
+
+struct GmActs { h8 h1[4]; h8 h2[4]; };
+template <bool KEEP>
+__device__ __forceinline__ void gm_mlp_forward(const h8* __restrict__ lt, int lane, const h8& x0, const h8& x1, f32x16& oo, GmActs* acts) {
+	const f32x16 zero = {};
+	f32x16 a0 = NGP_MFMA(lt[(G_L0 + 0) * 64 + lane], x0, zero);
+	a0 = NGP_MFMA(lt[(G_L0 + 1) * 64 + lane], x1, a0);
+	f32x16 a1 = NGP_MFMA(lt[(G_L0 + 2) * 64 + lane], x0, zero);
+	a1 = NGP_MFMA(lt[(G_L0 + 3) * 64 + lane], x1, a1);
+	h8 h[4];
+	d_to_b<true>(a0, h[0], h[1]);
+	d_to_b<true>(a1, h[2], h[3]);
+	if (KEEP) { for (int k = 0; k < 4; ++k) acts->h1[k] = h[k]; }
+	a0 = zero; a1 = zero;
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) {
+		a0 = NGP_MFMA(lt[(G_L1 + kb) * 64 + lane], h[kb], a0);
+		a1 = NGP_MFMA(lt[(G_L1 + 4 + kb) * 64 + lane], h[kb], a1);
+	}
+	d_to_b<true>(a0, h[0], h[1]);
+	d_to_b<true>(a1, h[2], h[3]);
+	if (KEEP) { for (int k = 0; k < 4; ++k) acts->h2[k] = h[k]; }
+	oo = zero;
+#pragma unroll
+	for (int kb = 0; kb < 4; ++kb) oo = NGP_MFMA(lt[(G_L2 + kb) * 64 + lane], h[kb], oo);
+}
+
+// forward: out[s*out_stride + 0..3] = network outputs 0..3 (fp16; 3 used by the image config, 1 by the SDF config); x_saved optional
+template <int D>
+__global__ void __launch_bounds__(256, 2) gridmlp_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ pos, uint32_t pos_stride,
+                                                                 uint32_t n, half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_FWD_TILES * 64];
+	gm_stage_weights(lds_tiles, params, GM_FWD_TILES);
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+	const uint32_t n_tiles = (n + 31) / 32;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const h2* __restrict__ grid = (const h2*)(params + GM_GRID_OFF);
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 32 + j;
+		const bool valid = s < n;
+		const float* c = pos + (size_t)(valid ? s : 0) * pos_stride;
+		const float px = c[0], py = c[1], pz = D == 3 ? c[2] : 0.0f;
+		h8 x0, x1;
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			half_t a, b;
+			encode_level_nd<D>(desc->levels[8 * g + m], grid, px, py, pz, a, b);
+			x0[2 * m] = a; x0[2 * m + 1] = b;
+			encode_level_nd<D>(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
+			x1[2 * m] = a; x1[2 * m + 1] = b;
+		}
+		if (x_saved && valid) { h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g); dst[0] = x0; dst[1] = x1; }
+		f32x16 oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off));
+		gm_mlp_forward<false>(lds_tiles + lt_off, lane, x0, x1, oo, nullptr);
+		if (valid && g == 0) {
+			typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+			h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = (half_t)oo[3];
+			*(h4*)(out + (size_t)s * out_stride) = o;
+		}
+	}
+}
+
+// activation / delta planes of the GridMLP backward: [row][sample] fp16
+constexpr int GP_DOUT = 0, GP_H2 = 16, GP_DH2 = 80, GP_H1 = 144, GP_DH1 = 208, GP_X = 272, GM_PLANE_ROWS = 304;
+
+// backward: recompute the MLP from the saved encoding, dgrad chain (channels 0..3 of dL_dout), planes for the weight gradients, dL/dx planes
+__global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* __restrict__ params, uint32_t n, const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout,
+                                                                  uint32_t dl_stride, h2* __restrict__ dx_planes, half_t* __restrict__ planes) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_ALL_TILES * 64];
+	gm_stage_weights(lds_tiles, params, GM_ALL_TILES);
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+	const uint32_t n_tiles = n / 32;
+	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const f32x16 zero = {};
+	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+		const uint32_t s = tile * 32 + j;
+		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
+		const h8 x0 = xs[0], x1 = xs[1];
+		GmActs a;
+		f32x16 oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off));
+		const h8* lt = lds_tiles + lt_off;
+		gm_mlp_forward<true>(lt, lane, x0, x1, oo, &a);
+		const half_t* dl = dL_dout + (size_t)s * dl_stride;
+		h8 dout = {};
+		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; dout[3] = dl[3]; }
+		// output layer: d_h2 = relu'(h2) * (L2^T dout)
+		f32x16 t0 = NGP_MFMA(lt[(G_L2T + 0) * 64 + lane], dout, zero);
+		f32x16 t1 = NGP_MFMA(lt[(G_L2T + 1) * 64 + lane], dout, zero);
+		h8 dh[4];
+		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
+		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
+		store_plane(planes, n, GP_DOUT, MAP_CH, 0, g, s, dout);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, GP_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, GP_DH2, MAP_HID, kb, g, s, dh[kb]); }
+		// hidden layer: d_h1 = relu'(h1) * (L1^T d_h2)
+		t0 = zero; t1 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) {
+			t0 = NGP_MFMA(lt[(G_L1T + kb) * 64 + lane], dh[kb], t0);
+			t1 = NGP_MFMA(lt[(G_L1T + 4 + kb) * 64 + lane], dh[kb], t1);
+		}
+		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
+		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, GP_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, GP_DH1, MAP_HID, kb, g, s, dh[kb]); }
+		store_plane(planes, n, GP_X, MAP_ENC, 0, g, s, x0);
+		store_plane(planes, n, GP_X, MAP_ENC, 1, g, s, x1);
+		// input layer: d_x = L0^T d_h1
+		t0 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(G_L0T + kb) * 64 + lane], dh[kb], t0);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {   // same row -> level mapping as nerf_backward_kernel
+			const int lvl = 4 * q + 2 * g;
+			h2 u, v;
+			u[0] = (half_t)t0[4 * q + 0]; u[1] = (half_t)t0[4 * q + 1];
+			v[0] = (half_t)t0[4 * q + 2]; v[1] = (half_t)t0[4 * q + 3];
+			dx_planes[(size_t)lvl * n + s] = u;
+			dx_planes[(size_t)(lvl + 1) * n + s] = v;
+		}
+	}
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Weight gradients: dW[o][i] = sum_s dY[o][s] * H[i][s].  Contraction over samples: both operands are read straight from
 // the [row][sample] planes (64 B per lane per 64-sample step, a full 128-B line per row), K-slot <-> sample mapping is
 // identical for A and B so it never has to be made explicit.  6 balanced jobs (2 output tiles, 3 operand row groups each):
 //   0: W4 rows 0..31   1: W4 rows 32..63   2: W5   3: W2   4: W3 (both row tiles)   5: W1 (both row tiles)
 struct WgradJob { int dy_row, dy_rows, h_row, h_rows, w_off, n_in, two_mt; int mt0; };
+template <int NET>
 __device__ __forceinline__ WgradJob wgrad_job(int job) {
+	if (NET == 1) {   // GridMLP: 0/1: hidden layer rows 0..31 / 32..63, 2: output layer, 3: input layer (both row tiles)
+		switch (job) {
+			case 0: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 0};
+			case 1: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 1};
+			case 2: return {GP_DOUT, 16, GP_H2, 64, (int)GM_L2_OFF, 64, 0, 0};
+			default: return {GP_DH1, 64, GP_X, 32, (int)GM_L0_OFF, 32, 1, 0};
+		}
+	}
 	switch (job) {
 		case 0: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 0};
 		case 1: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 1};
@@ -711,10 +929,12 @@ __device__ __forceinline__ WgradJob wgrad_job(int job) {
 }
 
 // grid (n_chunks, 6); block 256 = 4 waves; wave w handles samples [chunk*chunk_len + w*chunk_len/4, ...) in steps of 64.
-__global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restrict__ planes, uint32_t n, uint32_t chunk_len, float* __restrict__ partials /* [n_chunks][10240] */) {
+template <int NET>
+__global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restrict__ planes, uint32_t n, uint32_t chunk_len, float* __restrict__ partials /* [n_chunks][n_mlp_params] */) {
+	constexpr uint32_t N_MLP = NET == 1 ? NGP_GRIDMLP_N_PARAMS : NGP_MLP_N_PARAMS;
 	__shared__ float red[4][2][16][64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, g = lane >> 5;
-	const WgradJob jb = wgrad_job(blockIdx.y);
+	const WgradJob jb = wgrad_job<NET>(blockIdx.y);
 	const uint32_t per_wave = chunk_len / 4;
 	const uint32_t s_begin = blockIdx.x * chunk_len + w * per_wave, s_end = s_begin + per_wave;
 
@@ -750,7 +970,7 @@ __global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restric
 #pragma unroll
 	for (int r = 0; r < 16; ++r) { red[w][0][r][lane] = acc0[r]; red[w][1][r][lane] = acc1[r]; }
 	__syncthreads();
-	float* dst = partials + (size_t)blockIdx.x * NGP_MLP_N_PARAMS + jb.w_off;
+	float* dst = partials + (size_t)blockIdx.x * N_MLP + jb.w_off;
 	for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
 		const int t = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
 		const float v = red[0][t][r][l] + red[1][t][r][l] + red[2][t][r][l] + red[3][t][r][l];
@@ -765,22 +985,22 @@ __global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restric
 
 // sums the per-chunk partial weight gradients.  64 parameters x 4 chunk groups per block; every thread keeps 8 independent loads in
 // flight (the straightforward one-thread-per-parameter loop is a chain of n_chunks dependent L2 latencies: 40 us for 5 MB)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads, uint32_t n_mlp_params) {
 	__shared__ float red[4][64];
 	const uint32_t p = threadIdx.x & 63u, q = threadIdx.x >> 6;
 	const uint32_t i = blockIdx.x * 64u + p;
 	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-	if (i < NGP_MLP_N_PARAMS) {
+	if (i < n_mlp_params) {
 		uint32_t c = q;
 		for (; c + 28 < n_chunks; c += 32) {
 #pragma unroll
-			for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(c + 4 * u) * NGP_MLP_N_PARAMS + i];
+			for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(c + 4 * u) * n_mlp_params + i];
 		}
-		for (int u = 0; c < n_chunks; c += 4, ++u) acc[u & 7] += partials[(size_t)c * NGP_MLP_N_PARAMS + i];
+		for (int u = 0; c < n_chunks; c += 4, ++u) acc[u & 7] += partials[(size_t)c * n_mlp_params + i];
 	}
 	red[q][p] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 	__syncthreads();
-	if (q == 0 && i < NGP_MLP_N_PARAMS) grads[i] = (half_t)((red[0][p] + red[1][p]) + (red[2][p] + red[3][p]));
+	if (q == 0 && i < n_mlp_params) grads[i] = (half_t)((red[0][p] + red[1][p]) + (red[2][p] + red[3][p]));
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -796,6 +1016,26 @@ __global__ void init_params_kernel(uint32_t n_params, uint64_t seed_state, uint6
 	else if (k < W4_OFF) scale = sqrtf(6.0f / (float)(64 + 32));
 	else if (k < W5_OFF) scale = sqrtf(6.0f / (float)(64 + 64));
 	else if (k < GRID_OFF) scale = sqrtf(6.0f / (float)(16 + 64));
+	else scale = 1e-4f;
+	float v;
+	{
+#pragma clang fp contract(off)
+		v = rng.next_float() * (scale - (-scale)) + (-scale);
+	}
+	master[k] = v;
+	params[k] = (half_t)v;
+	inference[k] = (half_t)v;
+}
+
+__global__ void gridmlp_init_params_kernel(uint32_t n_params, uint64_t seed_state, uint64_t seed_inc, float* __restrict__ master, half_t* __restrict__ params, half_t* __restrict__ inference) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_params) return;
+	Pcg32 rng; rng.state = seed_state; rng.inc = seed_inc;
+	rng.advance(k);
+	float scale;
+	if (k < GM_L1_OFF) scale = sqrtf(6.0f / (float)(64 + 32));
+	else if (k < GM_L2_OFF) scale = sqrtf(6.0f / (float)(64 + 64));
+	else if (k < GM_GRID_OFF) scale = sqrtf(6.0f / (float)(16 + 64));
 	else scale = 1e-4f;
 	float v;
 	{
@@ -1002,18 +1242,95 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	// EGradientMode::Overwrite: the combine pass writes every table entry exactly once (no memset, no global atomics)
 	if (!(ablate & 4)) {
 		if (getenv("NGP_HIP_GB_SPLIT")) {  // dev-only: one launch per level so a kernel trace shows per-level times
-			for (uint32_t l = 0; l < 16; ++l) hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 1), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, l);
+			for (uint32_t l = 0; l < 16; ++l) hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 1), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, l);
 		} else {
-			hipLaunchKernelGGL(grid_backward_kernel, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
+			hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
 		}
 		NGP_LAUNCH_CHECK("grid_backward_kernel");
 		hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_MLP_N_PARAMS));
 		NGP_LAUNCH_CHECK("grid_combine_kernel");
 	}
 	const uint32_t n_chunks = wgrad_chunks(n);
-	hipLaunchKernelGGL(nerf_wgrad_kernel, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
+	hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads);
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
+	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	return 0;
+}
+
+// ---- plumbing configs: grid encoding -> one MLP (P1 image, P2 sdf)
+int ngp_hip_gridmlp_make_desc_host(uint32_t n_dims, uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* d) {
+	if (n_levels != 16 || !d || (n_dims != 2 && n_dims != 3)) { set_last_error("ngp_hip_gridmlp_make_desc_host: n_levels must be 16 and n_dims 2 or 3", hipErrorInvalidValue); return -1; }
+	uint32_t offset = 0;
+	const float log2_pls = log2f(per_level_scale);
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		const float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+		const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+		uint64_t dense = 1;
+		for (uint32_t k = 0; k < n_dims; ++k) dense *= res;
+		const uint32_t max_params = 0xffffffffu / 2u;
+		uint32_t cnt = dense > max_params ? max_params : (uint32_t)dense;
+		cnt = (cnt + 7u) / 8u * 8u;
+		const uint32_t hashmap = 1u << log2_hashmap_size;
+		const uint32_t size = cnt < hashmap ? cnt : hashmap;
+		d->levels[l].scale = scale; d->levels[l].resolution = res; d->levels[l].offset = offset; d->levels[l].size = size;
+		offset += size;
+	}
+	d->n_levels = n_levels;
+	d->n_grid_entries = offset;
+	return 0;
+}
+
+uint32_t ngp_hip_gridmlp_n_params_host(const NgpNetDesc* d) { return NGP_GRIDMLP_N_PARAMS + 2u * d->n_grid_entries; }
+
+int ngp_hip_gridmlp_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params) {
+	uint64_t state = 0u, inc = (1ull << 1u) | 1u;
+	state = state * 0x5851f42d4c957f2dULL + inc;
+	state += seed;
+	state = state * 0x5851f42d4c957f2dULL + inc;
+	const uint32_t n = ngp_hip_gridmlp_n_params_host(desc_host);
+	hipLaunchKernelGGL(gridmlp_init_params_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, state, inc, master, (half_t*)params, (half_t*)inference_params);
+	NGP_LAUNCH_CHECK("gridmlp_init_params_kernel");
+	return 0;
+}
+
+int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                            uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_gridmlp_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	if (n_dims == 2) hipLaunchKernelGGL(gridmlp_forward_kernel<2>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
+	else if (n_dims == 3) hipLaunchKernelGGL(gridmlp_forward_kernel<3>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
+	else { set_last_error("ngp_hip_gridmlp_forward: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
+	NGP_LAUNCH_CHECK("gridmlp_forward_kernel");
+	return 0;
+}
+
+static uint64_t gm_scratch_off_wgrad(uint32_t n) { return (uint64_t)GM_PLANE_ROWS * n * 2u; }
+static uint64_t gm_scratch_off_dx(uint32_t n) { return gm_scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_GRIDMLP_N_PARAMS * 4u; }
+static uint64_t gm_scratch_off_gb(uint32_t n) { return gm_scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
+uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n) { return gm_scratch_off_gb(n) + (uint64_t)16 * GB_ITEMS * GB_SLICE * 4u; }
+
+int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                             const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_gridmlp_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (n_dims != 2 && n_dims != 3) { set_last_error("ngp_hip_gridmlp_backward: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_gridmlp_backward_scratch_bytes(n)) { set_last_error("ngp_hip_gridmlp_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	half_t* planes = (half_t*)scratch;
+	float* partials = (float*)((char*)scratch + gm_scratch_off_wgrad(n));
+	h2* dx_planes = (h2*)((char*)scratch + gm_scratch_off_dx(n));
+	h2* gb_partials = (h2*)((char*)scratch + gm_scratch_off_gb(n));
+	hipLaunchKernelGGL(gridmlp_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes);
+	NGP_LAUNCH_CHECK("gridmlp_backward_kernel");
+	if (n_dims == 2) hipLaunchKernelGGL(grid_backward_kernel<2>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
+	else hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
+	NGP_LAUNCH_CHECK("grid_backward_kernel");
+	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_GRIDMLP_N_PARAMS));
+	NGP_LAUNCH_CHECK("grid_combine_kernel");
+	const uint32_t n_chunks = wgrad_chunks(n);
+	hipLaunchKernelGGL(nerf_wgrad_kernel<1>, dim3(n_chunks, 4), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
+	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	return 0;
 }

@@ -32,6 +32,7 @@ extern "C" {
 #define NGP_NERF_CASCADES 8u
 #define NGP_NERF_STEPS 1024u
 #define NGP_N_MAX_RANDOM_SAMPLES_PER_RAY 8u
+#define NGP_GRIDMLP_N_PARAMS 7168u /* plumbing configs: one MLP 32->64->64->16 (configs/image/base.json, configs/sdf/base.json) */
 #define NGP_MLP_N_PARAMS 10240u /* density 32->64->16 (3072) + rgb 32->64->64->16 (7168): configs/nerf/base.json:30-36,52-58 */
 
 /* ---- PODs ---- */
@@ -189,6 +190,32 @@ int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const fl
 int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space); /* render_buffer.cu:235 */
 int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
                     int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */
+
+/* ============================ plumbing configs P1 (2-D image) / P2 (SDF): grid encoding -> one FullyFusedMLP ============================
+ * tcnn NetworkWithInputEncoding as Testbed::reset_network builds it for Image / Sdf mode (src/testbed.cu:2397-2445): HashGrid (16 levels x 2
+ * features over n_dims = 2 or 3) -> 64 -> 64 -> 16 (ReLU, no output activation).  Parameters: [input 64x32 | hidden 64x64 | output 16x64 | grid].
+ * Training step = forward, ngp_hip_loss_and_gradient, backward, ngp_hip_optimizer_step(n_params, 7168, ...)  (Trainer::training_step +
+ * optimizer_step(128): src/testbed_image.cu:277-288, src/testbed_sdf.cu:1229-1252). */
+int ngp_hip_gridmlp_make_desc_host(uint32_t n_dims, uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* out);
+uint32_t ngp_hip_gridmlp_n_params_host(const NgpNetDesc* desc_host);
+int ngp_hip_gridmlp_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params);
+/* out: fp16, sample i at out[i*out_stride + 0..3] = network outputs 0..3; x_saved: NULL (inference) or [n][32] fp16 for backward */
+int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
+                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n);
+/* dL_dout: fp16 [n][dl_stride], channels 0..3 consumed; grads: fp16 [n_params], overwritten.  n must be a multiple of 256. */
+int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
+                             uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes);
+/* [tcnn] L2 / RelativeL2 / L1 / MAPE losses as Trainer::training_step applies them: predictions fp16 [n][pred_stride] (first `dims` channels), targets
+ * fp32 [n][dims]; values fp32 [n][dims] (each already divided by n*dims: their sum is Trainer::loss); gradients fp16 [n][grad_stride], channels 0..3 written. */
+int ngp_hip_loss_and_gradient(void* stream, int loss_type, uint32_t n, uint32_t dims, float loss_scale, const uint16_t* predictions, uint32_t pred_stride,
+                              const float* targets, float* values, uint16_t* gradients, uint32_t grad_stride);
+/* [tcnn] generate_random_uniform (call site src/testbed_image.cu:236): out[k] = k-th next_float() of pcg32{state, inc}; the host then advances by n_elements */
+int ngp_hip_generate_random_uniform(void* stream, uint64_t rng_state, uint64_t rng_inc, uint32_t n_elements, float* out);
+int ngp_hip_image_stratify2(void* stream, uint32_t n_elements, uint32_t log2_batch_size, float* inout_xy);                         /* src/testbed_image.cu:62-77 */
+/* eval_image_kernel_and_snap<T, stride> (src/testbed_image.cu:172-218): texture = H*W texels of 4 x T, image_data_type 2 = half, 3 = float */
+int ngp_hip_image_eval_and_snap(void* stream, uint32_t n_elements, const void* texture, int image_data_type, float* positions_xy, const int32_t* resolution_host,
+                                float* result, uint32_t stride, int snap_to_pixel_centers, int linear_colors);
 
 /* ============================ Blender multi-NeRF renderer (src/nerf_renderer.cu:17-563, include/.../nerf/ headers) ============================
  * One GLOBAL ray per output pixel (world space) and one PROXY ray per (pixel, NeRF) in that NeRF's local frame; per pass the nearest alive

@@ -67,6 +67,18 @@ void orc_f32_to_f16(const float* in, uint16_t* out, uint32_t n);
 void orc_f16_to_f32(const uint16_t* in, float* out, uint32_t n);
 void orc_adam_ema_step(uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float base_lr_after_decay, float beta1, float beta2, float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads_fp16, float* master, uint16_t* params_fp16, float* m1, float* m2, float* ema_fp32, uint16_t* inference_fp16);
 
+/* orc_network.c — plumbing configs P1 / P2 (grid encoding -> one MLP) */
+void orc_gridmlp_make_levels(uint32_t n_dims, uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, orc_grid_level* levels, uint32_t* n_grid_entries);
+uint32_t orc_gridmlp_n_params(const orc_net* net);
+void orc_grid_encode_nd(uint32_t n_dims, const orc_net* net, const uint16_t* grid, const float* pos_in, uint16_t* out);
+void orc_gridmlp_inference(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out, uint32_t out_stride);
+void orc_gridmlp_forward_backward(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dout, uint16_t* out4, double* grads_out, uint16_t* dL_dx_out);
+void orc_gridmlp_init_params(const orc_net* net, uint64_t seed, float* params_fp32);
+void orc_tcnn_loss_and_gradient(int loss_type, uint32_t n, uint32_t dims, float loss_scale, const uint16_t* predictions, uint32_t pred_stride, const float* targets, float* values, uint16_t* gradients, uint32_t grad_stride);
+void orc_generate_random_uniform(uint64_t rng_state, uint64_t rng_inc, uint32_t n_elements, float* out);
+void orc_image_stratify2(uint32_t n_elements, uint32_t log2_batch_size, float* inout_xy);
+void orc_image_eval_and_snap(uint32_t n_elements, const void* texture, int image_data_type, float* positions_xy, const int32_t res[2], float* result, uint32_t stride, int snap_to_pixel_centers, int linear_colors);
+
 /* orc_loss.c */
 void orc_loss_and_gradient_export(const float* target, const float* prediction, int loss_type, float* loss, float* grad);
 void orc_compute_loss(

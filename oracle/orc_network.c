@@ -308,3 +308,235 @@ void orc_adam_ema_step(uint32_t n_params, uint32_t n_matrix_params, uint32_t ste
 		inference_fp16[i] = orc_f2h(filtered);
 	}
 }
+
+/* ================================================================================================================================
+ * Plumbing configs P1 (2-D image) / P2 (SDF): tcnn NetworkWithInputEncoding = HashGrid(n_dims in {2,3}, L=16, F=2) -> FullyFusedMLP
+ * 32 -> 64 -> 64 -> 16 (ReLU, no output activation), as Testbed::reset_network builds it for Image / Sdf mode (src/testbed.cu:2397-2445,
+ * configs/image/base.json, configs/sdf/base.json).  Parameter order [tcnn NetworkWithInputEncoding::set_params]: network, then encoding.
+ * Training = Trainer::training_step (forward, loss, backward) + optimizer_step(128) (src/testbed_image.cu:277-288, src/testbed_sdf.cu:1229-1252). */
+#define GM_L0_OFF 0u
+#define GM_L1_OFF (64u * 32u)
+#define GM_L2_OFF (GM_L1_OFF + 64u * 64u)
+#define GM_GRID_OFF (GM_L2_OFF + 16u * 64u)   /* 7168 */
+
+void orc_gridmlp_make_levels(uint32_t n_dims, uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale,
+                             orc_grid_level* levels, uint32_t* n_grid_entries) {
+	uint32_t offset = 0;
+	float log2_pls = log2f(per_level_scale);
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		float scale = exp2f((float)l * log2_pls) * (float)base_resolution - 1.0f;
+		uint32_t res = (uint32_t)ceilf(scale) + 1u;
+		uint64_t dense = 1;
+		for (uint32_t d = 0; d < n_dims; ++d) dense *= res;
+		uint32_t max_params = 0xffffffffu / 2u;
+		uint32_t n = dense > max_params ? max_params : (uint32_t)dense;
+		n = (n + 7u) / 8u * 8u;
+		uint32_t hashmap = 1u << log2_hashmap_size;
+		uint32_t size = n < hashmap ? n : hashmap;
+		levels[l].scale = scale; levels[l].resolution = res; levels[l].offset = offset; levels[l].size = size;
+		offset += size;
+	}
+	*n_grid_entries = offset;
+}
+uint32_t orc_gridmlp_n_params(const orc_net* net) { return GM_GRID_OFF + 2u * net->n_grid_entries; }
+
+/* [tcnn] grid_index<N_DIMS> with the primes {1, 2654435761, 805459861} */
+static inline uint32_t orc_grid_index_nd(uint32_t n_dims, const orc_grid_level* lv, const uint32_t p[3]) {
+	static const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+	uint32_t stride = 1, index = 0;
+	for (uint32_t d = 0; d < n_dims && stride <= lv->size; ++d) { index += p[d] * stride; stride *= lv->resolution; }
+	if (lv->size < stride) { index = 0; for (uint32_t d = 0; d < n_dims; ++d) index ^= p[d] * primes[d]; }
+	return index % lv->size;
+}
+
+void orc_grid_encode_nd(uint32_t n_dims, const orc_net* net, const uint16_t* grid, const float* pos_in, uint16_t* out) {
+	for (uint32_t l = 0; l < net->n_levels; ++l) {
+		const orc_grid_level* lv = &net->levels[l];
+		float pos[3] = {0, 0, 0}; uint32_t pg[3] = {0, 0, 0};
+		for (uint32_t d = 0; d < n_dims; ++d) {
+			float p = pos_in[d] * lv->scale + 0.5f;
+			float fl = floorf(p);
+			pg[d] = (uint32_t)(int)fl;
+			pos[d] = p - fl;
+		}
+		float r0 = 0.0f, r1 = 0.0f;
+		for (uint32_t idx = 0; idx < (1u << n_dims); ++idx) {
+			float w = 1.0f; uint32_t c[3] = {0, 0, 0};
+			for (uint32_t d = 0; d < n_dims; ++d) {
+				if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; c[d] = pg[d]; }
+				else { w *= pos[d]; c[d] = pg[d] + 1; }
+			}
+			const uint16_t* v = grid + 2u * ((size_t)lv->offset + orc_grid_index_nd(n_dims, lv, c));
+			r0 += w * orc_h2f(v[0]);
+			r1 += w * orc_h2f(v[1]);
+		}
+		out[2 * l + 0] = orc_f2h(r0);
+		out[2 * l + 1] = orc_f2h(r1);
+	}
+}
+
+typedef struct { uint16_t x[32], h1[64], h2[64], out[16]; } orc_gm_act;
+static void orc_gridmlp_forward_one(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos, orc_gm_act* a) {
+	orc_grid_encode_nd(n_dims, net, params + GM_GRID_OFF, pos, a->x);
+	orc_dense(params + GM_L0_OFF, 64, 32, a->x, a->h1, 1);
+	orc_dense(params + GM_L1_OFF, 64, 64, a->h1, a->h2, 1);
+	orc_dense(params + GM_L2_OFF, 16, 64, a->h2, a->out, 0);
+}
+
+void orc_gridmlp_inference(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out, uint32_t out_stride) {
+	#pragma omp parallel for schedule(static) if (n >= 512)
+	for (uint32_t i = 0; i < n; ++i) {
+		orc_gm_act a;
+		orc_gridmlp_forward_one(n_dims, net, params, pos + (size_t)i * pos_stride_floats, &a);
+		for (uint32_t c = 0; c < 4; ++c) out[(size_t)i * out_stride + c] = a.out[c];
+	}
+}
+
+/* forward + backward over n samples; dL_dout fp16 [n][4]; grads_out double [n_params]; optional per-sample outputs / encodings / dL/dx */
+void orc_gridmlp_forward_backward(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dout,
+                                  uint16_t* out4 /* [n][4] or NULL */, double* grads_out, uint16_t* dL_dx_out /* [n][32] or NULL */) {
+	const uint32_t np = orc_gridmlp_n_params(net);
+	for (uint32_t k = 0; k < np; ++k) grads_out[k] = 0.0;
+	#pragma omp parallel
+	{
+	double* mlp_acc = (double*)calloc(GM_GRID_OFF, sizeof(double));
+	#pragma omp for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		const float* pos_in = pos_all + (size_t)i * pos_stride_floats;
+		orc_gm_act a;
+		orc_gridmlp_forward_one(n_dims, net, params, pos_in, &a);
+		if (out4) for (int c = 0; c < 4; ++c) out4[(size_t)i * 4 + c] = a.out[c];
+		uint16_t d_out[16]; memset(d_out, 0, sizeof(d_out));
+		for (int c = 0; c < 4; ++c) d_out[c] = dL_dout[(size_t)i * 4 + c];
+		uint16_t d_h2[64], d_h1[64], d_x[32];
+		orc_dense_bwd_input(params + GM_L2_OFF, 16, 64, d_out, a.h2, d_h2);
+		orc_dense_bwd_input(params + GM_L1_OFF, 64, 64, d_h2, a.h1, d_h1);
+		orc_dense_bwd_input(params + GM_L0_OFF, 64, 32, d_h1, NULL, d_x);
+		if (dL_dx_out) memcpy(dL_dx_out + (size_t)i * 32, d_x, sizeof(d_x));
+#define WGRAD(OFF, NOUT, NIN, DY, X) \
+		for (uint32_t o = 0; o < (NOUT); ++o) { float dy_ = orc_h2f((DY)[o]); if (dy_ != 0.0f) for (uint32_t k = 0; k < (NIN); ++k) mlp_acc[(OFF) + o * (NIN) + k] += (double)(dy_ * orc_h2f((X)[k])); }
+		WGRAD(GM_L2_OFF, 16, 64, d_out, a.h2)
+		WGRAD(GM_L1_OFF, 64, 64, d_h2, a.h1)
+		WGRAD(GM_L0_OFF, 64, 32, d_h1, a.x)
+#undef WGRAD
+		for (uint32_t l = 0; l < net->n_levels; ++l) {
+			const orc_grid_level* lv = &net->levels[l];
+			float pos[3] = {0, 0, 0}; uint32_t pg[3] = {0, 0, 0};
+			for (uint32_t d = 0; d < n_dims; ++d) {
+				float p = pos_in[d] * lv->scale + 0.5f;
+				float fl = floorf(p);
+				pg[d] = (uint32_t)(int)fl;
+				pos[d] = p - fl;
+			}
+			float g0 = orc_h2f(d_x[2 * l]), g1 = orc_h2f(d_x[2 * l + 1]);
+			for (uint32_t idx = 0; idx < (1u << n_dims); ++idx) {
+				float w = 1.0f; uint32_t c[3] = {0, 0, 0};
+				for (uint32_t d = 0; d < n_dims; ++d) {
+					if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; c[d] = pg[d]; }
+					else { w *= pos[d]; c[d] = pg[d] + 1; }
+				}
+				size_t k = GM_GRID_OFF + 2u * ((size_t)lv->offset + orc_grid_index_nd(n_dims, lv, c));
+				const double a0 = (double)orc_rh(w * g0), a1 = (double)orc_rh(w * g1);
+				#pragma omp atomic
+				grads_out[k + 0] += a0;
+				#pragma omp atomic
+				grads_out[k + 1] += a1;
+			}
+		}
+	}
+	#pragma omp critical
+	for (uint32_t k = 0; k < GM_GRID_OFF; ++k) grads_out[k] += mlp_acc[k];
+	free(mlp_acc);
+	}
+}
+
+void orc_gridmlp_init_params(const orc_net* net, uint64_t seed, float* params_fp32) {
+	orc_pcg32 rng = orc_pcg32_make(seed);
+	const uint32_t dims[3][2] = {{64, 32}, {64, 64}, {16, 64}};
+	uint32_t off = 0;
+	for (int m = 0; m < 3; ++m) {
+		float scale = sqrtf(6.0f / (float)(dims[m][0] + dims[m][1]));
+		uint32_t cnt = dims[m][0] * dims[m][1];
+		for (uint32_t k = 0; k < cnt; ++k) params_fp32[off + k] = orc_pcg32_next_float(&rng) * (scale - (-scale)) + (-scale);
+		off += cnt;
+	}
+	uint32_t ng = 2u * net->n_grid_entries;
+	for (uint32_t k = 0; k < ng; ++k) params_fp32[off + k] = orc_pcg32_next_float(&rng) * (1e-4f - (-1e-4f)) + (-1e-4f);
+}
+
+/* [tcnn] losses/{l2, relative_l2, l1, mape}.h (unverified recall): n_total = n * dims; value = f(d) / n_total; gradient = loss_scale * f'(d) / n_total */
+void orc_tcnn_loss_and_gradient(int loss_type, uint32_t n, uint32_t dims, float loss_scale, const uint16_t* predictions, uint32_t pred_stride, const float* targets,
+                           float* values, uint16_t* gradients, uint32_t grad_stride) {
+	const float n_total = (float)(n * dims);
+	for (uint32_t s = 0; s < n; ++s) for (uint32_t c = 0; c < 4; ++c) {
+		if (c >= dims) { gradients[(size_t)s * grad_stride + c] = 0; continue; }
+		float prediction = orc_h2f(predictions[(size_t)s * pred_stride + c]);
+		float target = targets[(size_t)s * dims + c];
+		float difference = prediction - target, value, gradient;
+		switch (loss_type) {
+			case ORC_LOSS_L2: value = difference * difference; gradient = 2.0f * difference; break;
+			case ORC_LOSS_RELATIVE_L2: { float pn = prediction * prediction + 0.01f; value = difference * difference / pn; gradient = 2.0f * difference / pn; break; }
+			case ORC_LOSS_L1: value = fabsf(difference); gradient = copysignf(1.0f, difference); break;
+			default: { float sc = 1.0f / (fabsf(target) + 0.01f); value = fabsf(difference) * sc; gradient = copysignf(sc, difference); break; }
+		}
+		values[(size_t)s * dims + c] = value / n_total;
+		gradients[(size_t)s * grad_stride + c] = orc_f2h(loss_scale * gradient / n_total);
+	}
+}
+
+/* [tcnn] generate_random_uniform: element k = k-th next_float() */
+void orc_generate_random_uniform(uint64_t rng_state, uint64_t rng_inc, uint32_t n_elements, float* out) {
+	orc_pcg32 rng; rng.state = rng_state; rng.inc = rng_inc;
+	for (uint32_t k = 0; k < n_elements; ++k) out[k] = orc_pcg32_next_float(&rng);
+}
+
+/* src/testbed_image.cu:62-77 */
+void orc_image_stratify2(uint32_t n_elements, uint32_t log2_batch_size, float* inout_xy) {
+	uint32_t log2_size = log2_batch_size / 2, size = 1u << log2_size;
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		uint32_t in_batch_index = i & ((1u << log2_batch_size) - 1u);
+		uint32_t x = in_batch_index & ((1u << log2_size) - 1u), y = in_batch_index >> log2_size;
+		float vx = inout_xy[2 * i], vy = inout_xy[2 * i + 1];
+		inout_xy[2 * i] = vx / (float)size + ((float)x / (float)size);
+		inout_xy[2 * i + 1] = vy / (float)size + ((float)y / (float)size);
+	}
+}
+
+/* src/testbed_image.cu:172-218 eval_image_kernel_and_snap<T, stride>; image_data_type 2 = fp16 RGBA, 3 = fp32 RGBA */
+void orc_image_eval_and_snap(uint32_t n_elements, const void* texture, int image_data_type, float* positions_xy, const int32_t res[2], float* result, uint32_t stride,
+                             int snap_to_pixel_centers, int linear_colors) {
+	const int rx = res[0], ry = res[1];
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		float px = positions_xy[2 * i], py = positions_xy[2 * i + 1];
+		float val[4] = {0, 0, 0, 0};
+		float texel[4][4];
+		int coords[4][2], n_tex;
+		float wts[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+		if (snap_to_pixel_centers) {
+			int ix = (int)floorf(px * (float)rx), iy = (int)floorf(py * (float)ry);
+			positions_xy[2 * i] = ((float)ix + 0.5f) / (float)rx; positions_xy[2 * i + 1] = ((float)iy + 0.5f) / (float)ry;
+			ix = ix < 0 ? 0 : (ix > rx - 1 ? rx - 1 : ix); iy = iy < 0 ? 0 : (iy > ry - 1 ? ry - 1 : iy);
+			coords[0][0] = ix; coords[0][1] = iy; wts[0] = 1.0f; n_tex = 1;
+		} else {
+			px = fminf(fmaxf(px * (float)rx - 0.5f, 0.0f), (float)rx - (1.0f + 1e-4f));
+			py = fminf(fmaxf(py * (float)ry - 0.5f, 0.0f), (float)ry - (1.0f + 1e-4f));
+			int ix = (int)px, iy = (int)py;
+			float wx = px - (float)ix, wy = py - (float)iy;
+			int x0 = ix < rx - 2 ? ix : rx - 2; if (x0 < 0) x0 = 0;
+			int y0 = iy < ry - 2 ? iy : ry - 2; if (y0 < 0) y0 = 0;
+			coords[0][0] = x0; coords[0][1] = y0; coords[1][0] = x0 + 1; coords[1][1] = y0; coords[2][0] = x0; coords[2][1] = y0 + 1; coords[3][0] = x0 + 1; coords[3][1] = y0 + 1;
+			wts[0] = (1 - wx) * (1 - wy); wts[1] = wx * (1 - wy); wts[2] = (1 - wx) * wy; wts[3] = wx * wy;
+			n_tex = 4;
+		}
+		for (int t = 0; t < n_tex; ++t) {
+			size_t e = ((size_t)coords[t][1] * rx + coords[t][0]) * 4;
+			for (int k = 0; k < 4; ++k) texel[t][k] = image_data_type == 2 ? orc_h2f(((const uint16_t*)texture)[e + k]) : ((const float*)texture)[e + k];
+			if (!linear_colors) for (int k = 0; k < 3; ++k) texel[t][k] = orc_linear_to_srgb(texel[t][k]);
+		}
+		if (n_tex == 1) { for (int k = 0; k < 4; ++k) val[k] = texel[0][k]; }
+		else for (int k = 0; k < 4; ++k) val[k] = ((wts[0] * texel[0][k] + wts[1] * texel[1][k]) + wts[2] * texel[2][k]) + wts[3] * texel[3][k];
+		float* r = result + (size_t)i * stride;
+		r[0] = val[0]; r[1] = val[1]; r[2] = val[2];
+		for (uint32_t k = 3; k < stride; ++k) r[k] = 1.0f;
+	}
+}
