@@ -364,6 +364,56 @@ __global__ void eval_image_and_snap_kernel(uint32_t n_elements, const T* __restr
 	for (uint32_t k = 3; k < stride; ++k) r[k] = 1.0f;
 }
 
+// testbed_image.cu:79-108 init_image_coords (pixel_to_image_uv, common_device.cuh:397-417)
+__global__ void init_image_coords_kernel(float2* __restrict__ positions, int rx, int ry, int irx, int iry, float view_dist, float ipx, float ipy, float scx, float scy, bool snap, uint32_t sample_index) {
+	const uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= (uint32_t)rx || y >= (uint32_t)ry) return;
+	float jx, jy;
+	ld_random_pixel_offset(snap ? 0 : sample_index, jx, jy);
+	const float ox = scx * (float)rx + jx, oy = scy * (float)ry + jy;
+	const float y_scale = view_dist, x_scale = y_scale * (float)rx / (float)ry;
+	positions[x + (size_t)rx * y] = make_float2(((x_scale * ((float)x + ox)) / (float)rx - view_dist * ipx) / (float)irx * (float)iry, (y_scale * ((float)y + oy)) / (float)ry - view_dist * ipy);
+}
+
+// testbed_image.cu:139-170 shade_kernel_image; colours come as the network's fp16 outputs (channels 0..2 of `color_stride` halves per pixel)
+__global__ void shade_image_kernel(int rx, int ry, const float2* __restrict__ positions, const half_t* __restrict__ colors, uint32_t color_stride, float4* __restrict__ frame_buffer,
+                                   float* __restrict__ depth_buffer, bool linear_colors) {
+	const uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	if (x >= (uint32_t)rx || y >= (uint32_t)ry) return;
+	const size_t idx = x + (size_t)rx * y;
+	const float2 uv = positions[idx];
+	if (uv.x < 0.0f || uv.x > 1.0f || uv.y < 0.0f || uv.y > 1.0f) { frame_buffer[idx] = make_float4(0.f, 0.f, 0.f, 0.f); depth_buffer[idx] = 1e10f; return; }
+	float r = (float)colors[idx * color_stride + 0], g = (float)colors[idx * color_stride + 1], b = (float)colors[idx * color_stride + 2];
+	if (!linear_colors) { r = srgb_to_linear(r); g = srgb_to_linear(g); b = srgb_to_linear(b); }
+	frame_buffer[idx] = make_float4(r, g, b, 1.0f);
+	depth_buffer[idx] = 1.0f;
+}
+
+// testbed_image.cu:436-446
+__global__ void image_coords_from_idx_kernel(uint32_t n_elements, uint32_t offset, float2* __restrict__ pos, int rx, int ry) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	const uint32_t idx = i + offset;
+	int x = (int)(idx % (uint32_t)rx), y = (int)(idx / (uint32_t)rx);
+	x = x < 0 ? 0 : (x > rx - 1 ? rx - 1 : x); y = y < 0 ? 0 : (y > ry - 1 ? ry - 1 : y);
+	pos[i] = make_float2(((float)x + 0.5f) / (float)rx, ((float)y + 0.5f) / (float)ry);
+}
+
+// testbed_image.cu:448-460 image_mse_kernel; prediction = fp16 network outputs
+__global__ void image_mse_kernel(uint32_t n_elements, const float* __restrict__ target, const half_t* __restrict__ prediction, uint32_t pred_stride, float* __restrict__ result, bool quantize_to_byte) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_elements) return;
+	float acc = 0.0f;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		float p = (float)prediction[(size_t)i * pred_stride + c];
+		if (quantize_to_byte) { int q = (int)(p * 255.0f + 0.5f); q = q < 0 ? 0 : (q > 255 ? 255 : q); p = (float)q / 255.0f; }
+		const float d = target[(size_t)i * 3 + c] - p;
+		acc += d * d;
+	}
+	result[i] = acc / 3.0f;
+}
+
 } // namespace ngp
 
 using namespace ngp;
@@ -448,6 +498,39 @@ int ngp_hip_image_eval_and_snap(void* stream, uint32_t n_elements, const void* t
 	                                                 resolution_host[0], resolution_host[1], result, stride, snap_to_pixel_centers != 0, linear_colors != 0);
 	else { set_last_error("ngp_hip_image_eval_and_snap: image_data_type must be 2 (half4) or 3 (float4)", hipErrorInvalidValue); return -1; }
 	NGP_LAUNCH_CHECK("eval_image_and_snap_kernel");
+	return 0;
+}
+
+int ngp_hip_image_init_coords(void* stream, float* positions_xy, const int32_t* res_host, const int32_t* image_res_host, float view_dist, const float* image_pos_host,
+                              const float* screen_center_host, int snap_to_pixel_centers, uint32_t sample_index) {
+	if (res_host[0] <= 0 || res_host[1] <= 0) return 0;
+	const dim3 threads(16, 8, 1), blocks(div_up((uint32_t)res_host[0], 16u), div_up((uint32_t)res_host[1], 8u), 1);
+	hipLaunchKernelGGL(init_image_coords_kernel, blocks, threads, 0, (hipStream_t)stream, (float2*)positions_xy, res_host[0], res_host[1], image_res_host[0], image_res_host[1], view_dist,
+	                   image_pos_host[0], image_pos_host[1], screen_center_host[0], screen_center_host[1], snap_to_pixel_centers != 0, sample_index);
+	NGP_LAUNCH_CHECK("init_image_coords_kernel");
+	return 0;
+}
+
+int ngp_hip_image_shade(void* stream, const int32_t* res_host, const float* positions_xy, const uint16_t* colors, uint32_t color_stride, float* frame_buffer, float* depth_buffer, int linear_colors) {
+	if (res_host[0] <= 0 || res_host[1] <= 0) return 0;
+	const dim3 threads(16, 8, 1), blocks(div_up((uint32_t)res_host[0], 16u), div_up((uint32_t)res_host[1], 8u), 1);
+	hipLaunchKernelGGL(shade_image_kernel, blocks, threads, 0, (hipStream_t)stream, res_host[0], res_host[1], (const float2*)positions_xy, (const half_t*)colors, color_stride, (float4*)frame_buffer,
+	                   depth_buffer, linear_colors != 0);
+	NGP_LAUNCH_CHECK("shade_image_kernel");
+	return 0;
+}
+
+int ngp_hip_image_coords_from_idx(void* stream, uint32_t n_elements, uint32_t offset, float* positions_xy, const int32_t* res_host) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(image_coords_from_idx_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, offset, (float2*)positions_xy, res_host[0], res_host[1]);
+	NGP_LAUNCH_CHECK("image_coords_from_idx_kernel");
+	return 0;
+}
+
+int ngp_hip_image_mse(void* stream, uint32_t n_elements, const float* target, const uint16_t* prediction, uint32_t pred_stride, float* result, int quantize_to_byte) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(image_mse_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, target, (const half_t*)prediction, pred_stride, result, quantize_to_byte != 0);
+	NGP_LAUNCH_CHECK("image_mse_kernel");
 	return 0;
 }
 

@@ -243,6 +243,36 @@ PYBIND11_MODULE(pyngp, m) {
 				return result;
 			}, py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
 			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
+		// plumbing configs
+		.def("set_image_data", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& img) {
+				auto b = img.request();
+				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error{"image should be (H,W,4) float32"};
+				t.set_image_data((int)b.shape[1], (int)b.shape[0], (const float*)b.ptr);
+			}, py::arg("img"), "Image mode: fit this linear RGBA float image (what load_exr_image leaves on the device)")
+		.def("compute_image_mse", &Testbed::compute_image_mse, py::call_guard<py::gil_scoped_release>(), py::arg("quantize") = false)   // python_api.cu:600
+		.def("override_sdf_training_data", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& points, const py::array_t<float, py::array::c_style | py::array::forcecast>& distances) {
+				auto pb = points.request(), db = distances.request();
+				if (pb.ndim != 2 || db.ndim != 1 || pb.shape[0] != db.shape[0] || pb.shape[1] != 3) throw std::runtime_error{"Invalid Points<->Distances data"};
+				t.override_sdf_training_data((const float*)pb.ptr, (const float*)db.ptr, (size_t)pb.shape[0]);
+			}, "Override the training data for learning a signed distance function")                                                  // python_api.cu:605
+		.def("gridmlp_inference", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& pos) {   // tooling / tests: network outputs 0..3 at the given positions
+				auto b = pos.request();
+				const uint32_t n_dims = t.gridmlp_n_dims();
+				if (b.ndim != 2 || (uint32_t)b.shape[1] != n_dims) throw std::runtime_error{"positions must be (N, n_dims)"};
+				const uint32_t n = (uint32_t)b.shape[0];
+				DeviceBuffer d_pos, d_out;
+				d_pos.resize((size_t)n * n_dims * 4); d_out.resize((size_t)n * 8);
+				d_pos.copy_from_host(b.ptr, (size_t)n * n_dims * 4);
+				if (ngp_hip_gridmlp_forward(t.stream(), n_dims, t.m_desc_gpu.as<NgpNetDesc>(), t.m_inference_params.as<uint16_t>(), d_pos.as<float>(), n_dims, n, d_out.as<uint16_t>(), 4, nullptr))
+					throw std::runtime_error{ngp_hip_last_error()};
+				t.sync();
+				std::vector<uint16_t> h((size_t)n * 4);
+				d_out.copy_to_host(h.data(), h.size() * 2);
+				py::array_t<float> out({(py::ssize_t)n, (py::ssize_t)4});
+				for (size_t i = 0; i < h.size(); ++i) out.mutable_data()[i] = half_bits_to_float(h[i]);
+				return out;
+			}, py::arg("positions"))
+		.def_property_readonly("image_resolution", [](Testbed& t) { return std::vector<int>{t.m_image.resolution[0], t.m_image.resolution[1]}; })
 		.def("request_nerf_render_sync", [](Testbed& t, const RenderRequest& req) {  // python_api.cu:233-260, 581
 				std::vector<float> px;
 				{ py::gil_scoped_release rel; px = t.bl_request_nerf_render_sync(req); }

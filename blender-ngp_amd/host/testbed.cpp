@@ -160,8 +160,8 @@ void RenderBuffer::resize(int w, int h) {
 
 // ------------------------------------------------------------------------------------------------ Testbed
 Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
-	if (mode != ETestbedMode::Nerf) {
-		throw std::runtime_error{"this build implements the NeRF hot path only (SURVEY.md §8): TestbedMode.Nerf"};
+	if (mode == ETestbedMode::Volume) {
+		throw std::runtime_error{"TestbedMode.Volume is outside the scope of this build (SURVEY.md §8): Nerf, and the plumbing configs Image / Sdf"};
 	}
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
@@ -257,6 +257,8 @@ void Testbed::set_fov(float val) {
 }
 
 void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:196-218 (Nerf mode) -> Testbed::load_nerf (testbed_nerf.cu:2735-2759)
+	if (m_testbed_mode == ETestbedMode::Image) { load_image(data_path); return; }
+	if (m_testbed_mode == ETestbedMode::Sdf) throw std::runtime_error{"mesh loading (OBJ/STL + BVH) is outside the scope of this build: feed (position, distance) pairs with override_sdf_training_data"};
 	drop_prefetch();
 	++m_state_version;
 	if (data_path.size() > 8 && data_path.substr(data_path.size() - 8) == ".msgpack") { load_snapshot(data_path); m_train = false; return; }
@@ -382,8 +384,10 @@ void Testbed::parse_optimizer_config(const Json& opt_in) {
 }
 
 void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
+	if (m_testbed_mode != ETestbedMode::Nerf) { reset_network_gridmlp(); return; }
 	drop_prefetch();
 	++m_state_version;
+	m_n_matrix_params = NGP_MLP_N_PARAMS;
 	m_rng = Pcg32(m_seed);
 	m_windowless_render_surface.reset_accumulation();
 	NerfTraining& tr = m_nerf.training;
@@ -459,6 +463,15 @@ bool Testbed::frame() {  // testbed.cu:2044-2090 without the GUI: train_and_rend
 
 void Testbed::train(uint32_t batch_size) {  // testbed.cu:2527-2587
 	if (!m_training_data_available) { m_train = false; return; }
+	if (m_testbed_mode != ETestbedMode::Nerf) {
+		if (m_n_params == 0) throw std::runtime_error{"train(): no network — call reload_network_from_file/json first"};
+		const bool get_loss = m_training_step % 16 == 0;
+		auto t0 = std::chrono::steady_clock::now();
+		if (m_testbed_mode == ETestbedMode::Image) train_image(batch_size, get_loss); else train_sdf(batch_size, get_loss);
+		sync();
+		m_stats.training_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		return;
+	}
 	if (m_n_params == 0) throw std::runtime_error{"train(): no network — call reload_network_from_file/json first"};
 	m_windowless_render_surface.reset_accumulation();
 	const uint32_t n_prep_to_skip = std::min(std::max(m_training_step / 16u, 1u), 16u);
@@ -718,7 +731,7 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
 	++m_optimizer_step;
 	profile_begin(PK_OPTIMIZER);
-	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, NGP_MLP_N_PARAMS, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
 	                             m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
 	                             m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>()), "optimizer_step");
 	profile_end(PK_OPTIMIZER, m_n_params);
@@ -778,6 +791,18 @@ std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool l
 void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb) {  // testbed.cu:2695-2911
 	rb.frame_buffer.memset(0, m_stream);
 	rb.depth_buffer.memset(0, m_stream);
+	if (m_testbed_mode == ETestbedMode::Image) {
+		render_image(rb);
+		if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);
+		rb.color_space = m_color_space;
+		check(ngp_hip_accumulate(m_stream, rb.res, rb.frame_buffer.as<float>(), rb.accumulate_buffer.as<float>(), (float)rb.spp, (int)rb.color_space), "accumulate");
+		++rb.spp;
+		check(ngp_hip_tonemap(m_stream, rb.res, m_exposure, m_background_color, rb.accumulate_buffer.as<float>(), (int)rb.color_space, to_srgb ? NGP_COLOR_SRGB : NGP_COLOR_LINEAR,
+		                      (int)rb.tonemap_curve, 0, rb.surface.as<float>()), "tonemap");
+		sync();
+		return;
+	}
+	if (m_testbed_mode == ETestbedMode::Sdf) throw std::runtime_error{"rendering an SDF (sphere tracing, testbed_sdf.cu) is outside the scope of this build; P2 covers the training step"};
 	const float focal_length[2] = {m_relative_focal_length[0] * (float)rb.res[m_fov_axis] * m_zoom, m_relative_focal_length[1] * (float)rb.res[m_fov_axis] * m_zoom};
 	const float screen_center[2] = {(0.5f - m_screen_center[0]) * m_zoom + 0.5f, (0.5f - m_screen_center[1]) * m_zoom + 0.5f};
 	render_nerf(rb, focal_length, cam0, cam1, screen_center);

@@ -197,7 +197,7 @@ public:
 	void reset_network(bool clear_density_grid = true);
 	void reset(bool reset_density_grid = true) { reset_network(reset_density_grid); }
 	size_t n_params() const { return m_n_params; }
-	size_t n_encoding_params() const { return m_n_params - NGP_MLP_N_PARAMS; }
+	size_t n_encoding_params() const { return m_n_params - m_n_matrix_params; }
 
 	// ---- training (testbed.cu:2044-2090, 2527-2587; testbed_nerf.cu:2761-3401)
 	bool frame();
@@ -216,6 +216,33 @@ public:
 	void train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
 	void train_nerf_dp_end();
 	void invalidate_training_inputs();
+	// ---- plumbing configs: 2-D image fitting and SDF fitting through one grid -> MLP network (host/plumbing.cpp)
+	struct ImageState {   // testbed.h Image (m_image)
+		DeviceBuffer data, positions, targets, render_coords, render_out, se;
+		int32_t resolution[2] = {0, 0};
+		int type = 0;                  // 2 = half4, 3 = float4 (EDataType)
+		float pos[2] = {0.f, 0.f};
+		bool snap_to_pixel_centers = false, linear_colors = false;   // m_image.training.*
+		bool stratified = true;        // ERandomMode::Stratified (testbed.h default)
+	} m_image;
+	struct SdfState {     // the part of m_sdf that override_sdf_training_data feeds (python_api.cu:74-100)
+		DeviceBuffer positions, distances;
+		uint32_t n_samples = 0, cursor = 0;
+		float mesh_scale = 1.0f;
+	} m_sdf;
+	void load_image(const std::string& path);                                         // testbed_image.cu:362-434 (.bin: int32 h, int32 w, fp16 RGBA)
+	void set_image_data(int w, int h, const float* rgba_host);                        // fp32 RGBA (what load_exr_image / load_stbi_image leave on the device)
+	void override_sdf_training_data(const float* points, const float* distances, size_t n);
+	void reset_network_gridmlp();
+	void train_image(uint32_t batch_size, bool get_loss_scalar);                      // testbed_image.cu:220-291
+	void train_sdf(uint32_t batch_size, bool get_loss_scalar);                        // testbed_sdf.cu:1229-1252 on user-provided (pos, distance) pairs
+	void render_image(RenderBuffer& rb);                                              // testbed_image.cu:293-360
+	float compute_image_mse(bool quantize_to_byte);                                   // testbed_image.cu:461-523
+	uint32_t gridmlp_n_dims() const { return m_testbed_mode == ETestbedMode::Image ? 2u : 3u; }
+	void gridmlp_training_step(const float* pos, uint32_t n_dims, const float* targets, uint32_t dims, uint32_t n, bool get_loss_scalar);
+	uint32_t m_n_matrix_params = NGP_MLP_N_PARAMS;     // parameters that get weight decay (the MLPs): 10240 NeRF, 7168 grid -> MLP
+	DeviceBuffer m_gm_out, m_gm_values;
+
 	// ---- Blender multi-NeRF requests (python_api.cu:192-260, testbed.cu:2675-2693)
 	void bl_render_frame(RenderBuffer& rb, const RenderRequest& request);
 	std::vector<float> bl_request_nerf_render_sync(const RenderRequest& request);      // H*W*4 floats; zeros while another render is running

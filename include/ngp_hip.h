@@ -216,6 +216,13 @@ int ngp_hip_image_stratify2(void* stream, uint32_t n_elements, uint32_t log2_bat
 /* eval_image_kernel_and_snap<T, stride> (src/testbed_image.cu:172-218): texture = H*W texels of 4 x T, image_data_type 2 = half, 3 = float */
 int ngp_hip_image_eval_and_snap(void* stream, uint32_t n_elements, const void* texture, int image_data_type, float* positions_xy, const int32_t* resolution_host,
                                 float* result, uint32_t stride, int snap_to_pixel_centers, int linear_colors);
+int ngp_hip_image_init_coords(void* stream, float* positions_xy, const int32_t* res_host, const int32_t* image_res_host, float view_dist, const float* image_pos_host,
+                              const float* screen_center_host, int snap_to_pixel_centers, uint32_t sample_index);                                 /* src/testbed_image.cu:79-108 */
+/* colours / predictions are the network's fp16 outputs ([n][stride], channels 0..2) instead of the reference's float3 matrices */
+int ngp_hip_image_shade(void* stream, const int32_t* res_host, const float* positions_xy, const uint16_t* colors, uint32_t color_stride, float* frame_buffer,
+                        float* depth_buffer, int linear_colors);                                                                               /* :139-170 */
+int ngp_hip_image_coords_from_idx(void* stream, uint32_t n_elements, uint32_t offset, float* positions_xy, const int32_t* res_host);              /* :436-446 */
+int ngp_hip_image_mse(void* stream, uint32_t n_elements, const float* target, const uint16_t* prediction, uint32_t pred_stride, float* result, int quantize_to_byte); /* :448-460 */
 
 /* ============================ Blender multi-NeRF renderer (src/nerf_renderer.cu:17-563, include/.../nerf/ headers) ============================
  * One GLOBAL ray per output pixel (world space) and one PROXY ray per (pixel, NeRF) in that NeRF's local frame; per pass the nearest alive
