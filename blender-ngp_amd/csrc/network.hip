@@ -155,6 +155,10 @@ __device__ __forceinline__ uint32_t grid_index_nd(const NgpGridLevel& lv, uint32
 	return index >= lv.size ? index % lv.size : index;
 }
 
+// position of one sample as ONE memory request (global_load_dwordx3; the record is only 4-byte aligned) instead of three
+typedef float f3_t __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f3_t load_pos3(const float* __restrict__ c) { f3_t v; __builtin_memcpy(&v, c, 12); return v; }
+
 struct LevelPos { uint32_t gx, gy, gz; float fx, fy, fz; };
 __device__ __forceinline__ LevelPos level_pos(const NgpGridLevel& lv, float px, float py, float pz) {
 	LevelPos p;
@@ -473,8 +477,8 @@ __device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8
 // accumulates only the corners that fall into its slice with ds_pk_add_f16.  Small (dense) levels, which are heavily contended,
 // are additionally split over sample chunks (K private copies) and summed by grid_combine_kernel.  No global atomic, no memset of
 // the gradient table (every entry is written exactly once by the combine pass).
-constexpr uint32_t GB_SLICE = 32768;       // entries per LDS slice
-constexpr uint32_t GB_ITEMS = 32;          // work items per level (slices x sample chunks)
+constexpr uint32_t GB_SLICE = 16384;       // half2 entries per LDS slice of the float fallback (64 KiB: two workgroups per CU)
+constexpr uint32_t GB_ITEMS = 64;          // its work items per level (slices x sample chunks)
 
 struct GbSplit { uint32_t n_slices, k_chunks; };
 __host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
@@ -485,14 +489,349 @@ __host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
 	return s;
 }
 
-// grid (GB_ITEMS, 16 levels), block 1024.  dx planes: [level][sample] half2.  partials: [(level*GB_ITEMS + item)][GB_SLICE] half2.
-template <int D>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z term)
-__global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                             const h2* __restrict__ dx_planes, h2* __restrict__ partials, uint32_t level_base) {
+// Hashed levels: BIN, then accumulate in FIXED POINT.
+//  * tools/lds_atomic_probe.hip on MI355X: LDS float atomics (ds_pk_add_f16, ds_add_f32) run at ~200 G/s chip-wide whatever the bank pattern,
+//    integer ones at ~3100 G/s (u32) / ~2400 G/s (u64) on random addresses.  Every fp16 term is an integer multiple of 2^-24 below 2^16, so
+//    term * 2^24 is an exact 41-bit integer and a 64-bit accumulator per feature holds the EXACT sum of up to 2^22 terms: no scale to choose,
+//    no overflow, no dependence on the order of the adds; the sum is rounded to fp16 once (tcnn rounds after every atomicAdd(half2)).
+//  * "owner computes" makes every slice owner scan every sample; with 16-byte entries a slice is 8192 entries, i.e. 64 owners per level, and the
+//    scan (not the atomics) becomes the cost.  The x term of the hash is x itself, so the slice of a corner is fixed by its (y, z) pair: a
+//    counting sort by slice of the (sample, pair) items — count, exclusive scan, scatter; LDS integer atomics for the histograms — hands every
+//    owner exactly its ~n/16 items, and the owner writes its 8192 final fp16 gradients directly (no partial copies, no combine pass).
+constexpr uint32_t GB_FX_SLICE = GB_SLICE / 4;   // 4096 entries x 16 B = the same 64 KiB of LDS
+constexpr uint32_t GB_FX_MAX_SLICES = 256;       // tables up to 2^20 entries
+constexpr uint32_t GB_FX_CHUNK = 2048;           // samples per binning workgroup
+__host__ __device__ __forceinline__ bool gb_uses_fx(uint32_t level_size, uint32_t resolution, bool dense) {
+	return !dense && (level_size & (level_size - 1)) == 0 && level_size >= GB_FX_SLICE && level_size / GB_FX_SLICE <= GB_FX_MAX_SLICES && resolution < GB_FX_SLICE;
+}
+// scratch of the binned path: per level and slice {total, cursor, start} u32, then the item lists (one u32 per (sample, pair))
+struct GbFxCounters { uint32_t totals[16][GB_FX_MAX_SLICES], cursors[16][GB_FX_MAX_SLICES], starts[16][GB_FX_MAX_SLICES]; };
+constexpr uint32_t GB_FX_COUNTER_BYTES = 65536;
+
+template <int D>
+__device__ __forceinline__ bool level_is_dense(const NgpGridLevel& lv) {
+	return (D == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
+}
+
+// one term of tcnn's kernel_grid_backward, half(w * dL/dx), as an exact multiple of 2^-24 (integer part * 2^24 + fraction * 2^24, both native
+// fp32 -> int32 conversions); inf / nan terms (a step the loss scaler is about to skip) would poison the integer sums and are dropped
+__device__ __forceinline__ long long gb_term_fixed(float w_times_g) {
+	const float t = (float)(half_t)w_times_g;
+	if (!(fabsf(t) < 65520.0f)) return 0ll;
+	const float fl = floorf(t);
+	return (long long)(int)fl * 16777216ll + (long long)(uint32_t)((t - fl) * 16777216.0f);
+}
+// exact fixed-point sum -> fp16 with ONE rounding: round to odd at 24 bits, then nearest-even to 11
+__device__ __forceinline__ half_t gb_fixed_to_half(unsigned long long bits) {
+	const long long a = (long long)bits;
+	const unsigned long long m = a < 0 ? 0ull - (unsigned long long)a : (unsigned long long)a;
+	float f;
+	if (m < (1ull << 24)) f = (float)(uint32_t)m;
+	else {
+		const int sh = 40 - __builtin_clzll(m);
+		unsigned long long top = m >> sh;
+		if (m & ((1ull << sh) - 1ull)) top |= 1ull;
+		f = ldexpf((float)(uint32_t)top, sh);
+	}
+	f *= 1.0f / 16777216.0f;
+	return (half_t)(a < 0 ? -f : f);
+}
+
+// Dense (coarse) levels are binned too, by (slice, sample chunk): K private copies of a small table keep enough owners busy and
+// grid_combine_kernel sums them.  Tens of consecutive ray samples share a cell there, i.e. the same 8 entries: the binning pass sums such
+// runs itself (same exact 2^-24 fixed point) and emits one record {entry, sum0, sum1} per run and corner.  The owners of dense levels then
+// add several times fewer, already merged, records and read them coalesced; the merging is spread over all the binning workgroups.
+constexpr uint32_t GB_D_ITEMS = 16;            // owners per dense level (slices x sample chunks) while the level has fewer slices
+__host__ __device__ __forceinline__ GbSplit gb_dense_split(uint32_t level_size) {
+	GbSplit s;
+	s.n_slices = (level_size + GB_FX_SLICE - 1) / GB_FX_SLICE;
+	s.k_chunks = GB_D_ITEMS / s.n_slices;
+	if (s.k_chunks < 1) s.k_chunks = 1;   // then the owner writes the final fp16 values itself
+	return s;
+}
+constexpr uint32_t GB_PARTIAL_LEVEL_BYTES = GB_ITEMS * GB_SLICE * 4u;   // private copies of one level: 4 MiB (dense: 16 x 64 KiB fixed point; fallback: 64 x 64 KiB half2)
+static_assert(GB_D_ITEMS * GB_FX_SLICE * 16u <= GB_PARTIAL_LEVEL_BYTES, "partials");
+constexpr uint32_t GB_ITEMS_PER_SAMPLE = 8;    // list stride per level: n * 8 items (hashed: 4 (y, z) pairs, dense: at most 8 records)
+
+// passes 1 and 3 of the counting sort.  grid (ceil(n / GB_FX_CHUNK), 16 levels), block 256.  SCATTER = false: per-bin totals;
+// SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
+// hashed level: item = sample << 3 | (y, z) pair, bin = slice.
+template <int D, bool SCATTER>
+__device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, const NgpGridLevel& lv, uint32_t level,
+                                              const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
+                                              GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items) {
+	constexpr int NI = D == 3 ? 4 : 2;
+	constexpr int PER = GB_FX_CHUNK / 256;
+	const uint32_t hmask = lv.size - 1;
+	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
+	uint32_t code[PER][NI];   // bin << 16 | rank inside this workgroup, or ~0
+	h2 gq[PER]; float px[PER], py[PER], pz[PER];
+#pragma unroll
+	for (int u = 0; u < PER; ++u) {
+		const uint32_t s = blockIdx.x * GB_FX_CHUNK + u * 256 + threadIdx.x;
+		const uint32_t sc = s < n ? s : 0;
+		gq[u] = dxl[sc];
+		const float* c = coords + (size_t)sc * coord_stride;
+		if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
+	}
+#pragma unroll
+	for (int u = 0; u < PER; ++u) {
+		const uint32_t s = blockIdx.x * GB_FX_CHUNK + u * 256 + threadIdx.x;
+		const uint32_t bits = __builtin_bit_cast(uint32_t, gq[u]) & 0x7fff7fffu;
+		const bool live = s < n && bits != 0;   // adding +-0 never changes a sum
+		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
+		const uint32_t hy[2] = {p.gy * 2654435761u, (p.gy + 1u) * 2654435761u};
+		const uint32_t hz[2] = {D == 3 ? p.gz * 805459861u : 0u, D == 3 ? (p.gz + 1u) * 805459861u : 0u};
+#pragma unroll
+		for (int m = 0; m < NI; ++m) {
+			const uint32_t bin = ((hy[m & 1] ^ hz[m >> 1]) & hmask) / GB_FX_SLICE;
+			code[u][m] = live ? ((bin << 16) | atomicAdd(&hist[bin], 1u)) : 0xffffffffu;
+		}
+	}
+	__syncthreads();
+	if (!SCATTER) {
+		if (threadIdx.x < GB_FX_MAX_SLICES && hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
+		return;
+	}
+	if (threadIdx.x < GB_FX_MAX_SLICES) base[threadIdx.x] = hist[threadIdx.x] ? ctr->starts[level][threadIdx.x] + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	__syncthreads();
+	uint32_t* __restrict__ out = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE;
+#pragma unroll
+	for (int u = 0; u < PER; ++u) {
+		const uint32_t s = blockIdx.x * GB_FX_CHUNK + u * 256 + threadIdx.x;
+#pragma unroll
+		for (int m = 0; m < NI; ++m) {
+			const uint32_t c = code[u][m];
+			if (c != 0xffffffffu) out[base[c >> 16] + (c & 0xffffu)] = (s << 3) | (uint32_t)m;
+		}
+	}
+}
+
+// dense level: record = {entry inside its slice, two fixed-point run sums}, bin = slice + n_slices * sample chunk.  The workgroup stages its
+// 2048 samples in LDS (coalesced loads), then every thread walks 8 CONSECUTIVE samples and sums the 8 corner terms in registers while the
+// cell stays the same; a record per corner leaves when the cell changes.  (Padded LDS index i + i/8: the walk is bank-conflict free.)
+constexpr uint32_t GB_STAGE = GB_FX_CHUNK + GB_FX_CHUNK / 8;
+template <int D, bool WRITE>
+__device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, const float* __restrict__ s_px, const float* __restrict__ s_py, const float* __restrict__ s_pz,
+                                              uint32_t* __restrict__ counter, const NgpGridLevel& lv, uint32_t chunk_bin0, uint32_t n_live,
+                                              uint32_t* __restrict__ out_e, ulonglong2* __restrict__ out_v) {
 	constexpr int NC = 1 << D;
-	__shared__ h2 slice[GB_SLICE];
-	const uint32_t level = blockIdx.y + level_base, item = blockIdx.x;
+	constexpr uint32_t RUN = GB_FX_CHUNK / 256;
+	uint32_t cgx = 0xffffffffu, cgy = 0, cgz = 0;
+	long long a0[NC], a1[NC];
+#pragma unroll
+	for (int k = 0; k < NC; ++k) { a0[k] = 0; a1[k] = 0; }
+	auto flush = [&]() {
+#pragma unroll
+		for (int k = 0; k < NC; ++k) {
+			const uint32_t idx = grid_index_nd<D>(lv, cgx + (k & 1), cgy + ((k >> 1) & 1), cgz + ((k >> 2) & 1));
+			const uint32_t pos = atomicAdd(&counter[chunk_bin0 + idx / GB_FX_SLICE], 1u);
+			if (WRITE) { out_e[pos] = idx % GB_FX_SLICE; out_v[pos] = make_ulonglong2((unsigned long long)a0[k], (unsigned long long)a1[k]); }
+		}
+	};
+#pragma unroll
+	for (uint32_t u = 0; u < RUN; ++u) {
+		const uint32_t i = threadIdx.x * RUN + u, ip = i + (i >> 3);
+		const uint32_t gbits = s_g[ip];
+		if (i >= n_live || (gbits & 0x7fff7fffu) == 0) continue;   // adding +-0 never changes a sum
+		const LevelPos p = level_pos(lv, s_px[ip], s_py[ip], D == 3 ? s_pz[ip] : 0.f);
+		if (p.gx != cgx || p.gy != cgy || p.gz != cgz) {
+			if (cgx != 0xffffffffu) flush();
+			cgx = p.gx; cgy = p.gy; cgz = p.gz;
+#pragma unroll
+			for (int k = 0; k < NC; ++k) { a0[k] = 0; a1[k] = 0; }
+		}
+		if (WRITE) {
+			const h2 g = __builtin_bit_cast(h2, gbits);
+			const float g0 = (float)g[0], g1 = (float)g[1];
+#pragma unroll
+			for (int k = 0; k < NC; ++k) {
+				float w = (k & 1) ? p.fx : (1.0f - p.fx);
+				w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
+				if (D == 3) w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
+				a0[k] += gb_term_fixed(w * g0); a1[k] += gb_term_fixed(w * g1);
+			}
+		}
+	}
+	if (cgx != 0xffffffffu) flush();
+}
+
+template <int D, bool SCATTER>
+__device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, uint32_t* __restrict__ stage, const NgpGridLevel& lv, uint32_t level,
+                                             const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
+                                             GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums) {
+	constexpr int PER = GB_FX_CHUNK / 256;
+	const GbSplit sp = gb_dense_split(lv.size);
+	const uint32_t chunk_bin0 = (uint32_t)(((uint64_t)blockIdx.x * sp.k_chunks) / gridDim.x) * sp.n_slices;
+	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
+	uint32_t* s_g = stage;
+	float* s_px = (float*)(stage + GB_STAGE); float* s_py = (float*)(stage + 2 * GB_STAGE); float* s_pz = (float*)(stage + 3 * GB_STAGE);
+	const uint32_t s_first = blockIdx.x * GB_FX_CHUNK;
+	const uint32_t n_live = n - s_first < GB_FX_CHUNK ? n - s_first : GB_FX_CHUNK;
+#pragma unroll
+	for (int u = 0; u < PER; ++u) {
+		const uint32_t i = u * 256 + threadIdx.x, ip = i + (i >> 3);
+		const uint32_t sc = i < n_live ? s_first + i : s_first;
+		const float* c = coords + (size_t)sc * coord_stride;
+		s_g[ip] = __builtin_bit_cast(uint32_t, dxl[sc]);
+		if (D == 3) { const f3_t v = load_pos3(c); s_px[ip] = v.x; s_py[ip] = v.y; s_pz[ip] = v.z; } else { s_px[ip] = c[0]; s_py[ip] = c[1]; }
+	}
+	__syncthreads();
+	gb_dense_walk<D, false>(s_g, s_px, s_py, s_pz, hist, lv, chunk_bin0, n_live, nullptr, nullptr);
+	__syncthreads();
+	if (!SCATTER) {
+		if (threadIdx.x < GB_FX_MAX_SLICES && hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
+		return;
+	}
+	// reserve the ranges (base[] then serves as the running cursor of each bin), walk again with the sums
+	if (threadIdx.x < GB_FX_MAX_SLICES) base[threadIdx.x] = hist[threadIdx.x] ? ctr->starts[level][threadIdx.x] + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	__syncthreads();
+	gb_dense_walk<D, true>(s_g, s_px, s_py, s_pz, base, lv, chunk_bin0, n_live, items + (size_t)level * n * GB_ITEMS_PER_SAMPLE, sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
+}
+
+template <int D, bool SCATTER>
+__global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums) {
+	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
+	const uint32_t level = blockIdx.y;
 	const NgpGridLevel lv = desc->levels[level];
+	const bool dense = level_is_dense<D>(lv);
+	const bool fx = gb_uses_fx(lv.size, lv.resolution, dense);
+	if (!fx && !dense) return;   // float fallback: no binning
+	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[4 * GB_STAGE];
+	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
+	__syncthreads();
+	if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums);
+	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, items);
+}
+
+// pass 2: exclusive scan of the per-slice totals of every level (16 x 64 counters: one wave per level)
+__global__ void __launch_bounds__(64) gb_fx_scan_kernel(GbFxCounters* __restrict__ ctr) {
+	const uint32_t level = blockIdx.x, lane = threadIdx.x;
+	uint32_t carry = 0;
+	for (uint32_t b = 0; b < GB_FX_MAX_SLICES; b += 64) {
+		const uint32_t v = ctr->totals[level][b + lane];
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += o; }
+		ctr->starts[level][b + lane] = carry + incl - v;
+		carry += __shfl(incl, 63, 64);
+	}
+}
+
+// pass 4: the owner of (level, slice) adds its items into 8192 x 2 64-bit fixed-point words in LDS and writes the final fp16 gradients
+template <int D>
+__device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t sl,
+                                                 const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
+                                                 const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, h2* __restrict__ grid_grad) {
+	if (sl >= lv.size / GB_FX_SLICE) return;
+	h2* __restrict__ dst = grid_grad + lv.offset + (size_t)sl * GB_FX_SLICE;
+	const uint32_t count = ctr->totals[level][sl];
+	if (count == 0) {
+		const h2 z2 = {(half_t)0.0f, (half_t)0.0f};
+		for (uint32_t i = threadIdx.x; i < GB_FX_SLICE; i += blockDim.x) dst[i] = z2;
+		return;
+	}
+	for (uint32_t i = threadIdx.x; i < 2 * GB_FX_SLICE; i += blockDim.x) slice64[i] = 0ull;
+	__syncthreads();
+	const uint32_t hmask = lv.size - 1;
+	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
+	const uint32_t* __restrict__ my = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE + ctr->starts[level][sl];
+	constexpr uint32_t UN = 8;
+	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
+		uint32_t it[UN]; h2 gq[UN]; float px[UN], py[UN], pz[UN];
+#pragma unroll
+		for (uint32_t u = 0; u < UN; ++u) { const uint32_t i = i0 + u * blockDim.x; it[u] = my[i < count ? i : 0]; }
+#pragma unroll
+		for (uint32_t u = 0; u < UN; ++u) {
+			const uint32_t s = it[u] >> 3;
+			gq[u] = dxl[s];
+			const float* c = coords + (size_t)s * coord_stride;
+			if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < UN; ++u) {
+			if (i0 + u * blockDim.x >= count) continue;
+			const uint32_t m = it[u] & 3u;
+			const float g0 = (float)gq[u][0], g1 = (float)gq[u][1];
+			const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
+			const uint32_t yb = m & 1u, zb = m >> 1;
+			const uint32_t base = ((p.gy + yb) * 2654435761u) ^ (D == 3 ? (p.gz + zb) * 805459861u : 0u);
+			const float wy = yb ? p.fy : (1.0f - p.fy), wz = zb ? p.fz : (1.0f - p.fz);
+#pragma unroll
+			for (uint32_t xb = 0; xb < 2; ++xb) {
+				const uint32_t idx = (base ^ (p.gx + xb)) & hmask;
+				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
+				if (D == 3) w *= wz;
+				// tcnn kernel_grid_backward adds half2(w * dL/dx): the terms are rounded to fp16 like there, their sum is exact
+				const long long v0 = gb_term_fixed(w * g0), v1 = gb_term_fixed(w * g1);
+				const uint32_t e = idx & (GB_FX_SLICE - 1);
+				if (v0) atomicAdd(&slice64[2 * e], (unsigned long long)v0);
+				if (v1) atomicAdd(&slice64[2 * e + 1], (unsigned long long)v1);
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < GB_FX_SLICE; i += blockDim.x) {
+		h2 o; o[0] = gb_fixed_to_half(slice64[2 * i]); o[1] = gb_fixed_to_half(slice64[2 * i + 1]);
+		dst[i] = o;
+	}
+}
+
+// Dense (coarse) levels: the owner of (slice, sample chunk) adds its merged records (see gb_bin_dense)
+__device__ __forceinline__ void gb_dense_owner(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t bin, uint32_t n,
+                                               const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums,
+                                               unsigned long long* __restrict__ partials, h2* __restrict__ grid_grad) {
+	const GbSplit sp = gb_dense_split(lv.size);
+	if (bin >= sp.n_slices * sp.k_chunks) return;
+	const uint32_t sl = bin % sp.n_slices;
+	const uint32_t lo = sl * GB_FX_SLICE;
+	const uint32_t cnt = (lv.size - lo) < GB_FX_SLICE ? (lv.size - lo) : GB_FX_SLICE;
+	const uint32_t count = ctr->totals[level][bin];
+	for (uint32_t i = threadIdx.x; i < 2 * cnt; i += blockDim.x) slice64[i] = 0ull;
+	__syncthreads();
+	const size_t first = (size_t)level * n * GB_ITEMS_PER_SAMPLE + ctr->starts[level][bin];
+	const uint32_t* __restrict__ my_e = items + first;
+	const ulonglong2* __restrict__ my_v = sums + first;
+	constexpr uint32_t UN = 4;
+	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
+		uint32_t e[UN]; ulonglong2 v[UN];
+#pragma unroll
+		for (uint32_t u = 0; u < UN; ++u) { const uint32_t i = i0 + u * blockDim.x; const uint32_t ic = i < count ? i : 0; e[u] = my_e[ic]; v[u] = my_v[ic]; }
+#pragma unroll
+		for (uint32_t u = 0; u < UN; ++u) {
+			if (i0 + u * blockDim.x >= count) continue;
+			if (v[u].x) atomicAdd(&slice64[2 * e[u]], v[u].x);
+			if (v[u].y) atomicAdd(&slice64[2 * e[u] + 1], v[u].y);
+		}
+	}
+	__syncthreads();
+	if (sp.k_chunks == 1) {
+		h2* __restrict__ dst = grid_grad + lv.offset + lo;
+		for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { h2 o; o[0] = gb_fixed_to_half(slice64[2 * i]); o[1] = gb_fixed_to_half(slice64[2 * i + 1]); dst[i] = o; }
+	} else {
+		unsigned long long* __restrict__ dst = partials + (size_t)(level * GB_D_ITEMS + bin) * (2 * GB_FX_SLICE);
+		for (uint32_t i = threadIdx.x; i < 2 * cnt; i += blockDim.x) dst[i] = slice64[i];
+	}
+}
+
+// grid (GB_FX_MAX_SLICES, 16 levels), block 1024, 64 KiB of LDS (two workgroups per CU hide each other's load -> atomics -> store chain).  dx planes: [level][sample] half2.  One launch serves the three kinds of level so
+// that their workgroups overlap: binned fixed-point owners (hashed, power-of-two tables), dense owners, and the float fallback for hashed
+// levels whose resolution exceeds the slice (the x term then reaches the slice bits).
+// partials (GB_PARTIAL_LEVEL_BYTES per level): dense [bin][GB_FX_SLICE][2] fixed point, fallback [item][GB_SLICE] half2.
+template <int D>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z term)
+__global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                             const h2* __restrict__ dx_planes, void* __restrict__ partials_raw,
+                                                             const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask) {
+	constexpr int NC = 1 << D;
+	__shared__ unsigned long long slice64[2 * GB_FX_SLICE];
+	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation (tools/gb_level_probe.py); all ones in production
+	const NgpGridLevel lv = desc->levels[level];
+	const bool dense = level_is_dense<D>(lv);
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, coords, coord_stride, n, dx_planes, ctr, items, grid_grad); return; }
+	if (dense) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad); return; }
+	h2* __restrict__ slice = (h2*)slice64;
+	h2* __restrict__ partials = (h2*)partials_raw;
 	const GbSplit sp = gb_split(lv.size);
 	if (item >= sp.n_slices * sp.k_chunks) return;
 	const uint32_t sl = item % sp.n_slices, chunk = item / sp.n_slices;
@@ -503,71 +842,12 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 	__syncthreads();
 	const uint32_t s_begin = (uint32_t)(((uint64_t)n * chunk) / sp.k_chunks), s_end = (uint32_t)(((uint64_t)n * (chunk + 1)) / sp.k_chunks);
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	const bool dense = (D == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
-	if (dense) {
-		// Dense (coarse) levels: tens of consecutive ray samples share a cell, i.e. the same 8 corner keys.  Every thread walks GB_RUN
-		// CONSECUTIVE samples, sums their contributions in fp32 registers while the cell stays the same and issues one LDS atomic per
-		// in-slice corner when it changes (tcnn adds half2(w * dL/dx) per sample; the run is summed in fp32 first).
-		constexpr uint32_t GB_RUN = 8;
-		for (uint32_t s0 = s_begin + threadIdx.x * GB_RUN; s0 < s_end; s0 += blockDim.x * GB_RUN) {
-			uint32_t cgx = 0xffffffffu, cgy = 0, cgz = 0, rels[8];
-			uint32_t mask = 0;       // corners of the open cell that fall into this slice
-			float a0[8], a1[8];
-#pragma unroll
-			for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; rels[k] = 0; }
-			auto flush = [&]() {
-#pragma unroll
-				for (int k = 0; k < NC; ++k) {
-					if (mask & (1u << k)) {
-						h2 val; val[0] = (half_t)a0[k]; val[1] = (half_t)a1[k];
-						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rels[k]], val);
-					}
-				}
-			};
-			// fetch the whole run first (independent loads in flight), then walk it
-			h2 gqs[GB_RUN];
-			float pxs[GB_RUN], pys[GB_RUN], pzs[GB_RUN];
-#pragma unroll
-			for (uint32_t u = 0; u < GB_RUN; ++u) {
-				const uint32_t sc = s0 + u < s_end ? s0 + u : s_begin;
-				gqs[u] = dxl[sc];
-				const float* c = coords + (size_t)sc * coord_stride;
-				pxs[u] = c[0]; pys[u] = c[1]; pzs[u] = D == 3 ? c[2] : 0.f;
-			}
-#pragma unroll
-			for (uint32_t u = 0; u < GB_RUN; ++u) {
-				const float g0 = (float)gqs[u][0], g1 = (float)gqs[u][1];
-				if (s0 + u >= s_end || (g0 == 0.0f && g1 == 0.0f)) continue;  // adding +-0 never changes a sum
-				const LevelPos p = level_pos(lv, pxs[u], pys[u], pzs[u]);
-				if (p.gx != cgx || p.gy != cgy || p.gz != cgz) {
-					if (mask) flush();
-					cgx = p.gx; cgy = p.gy; cgz = p.gz;
-					mask = 0;
-#pragma unroll
-					for (int k = 0; k < NC; ++k) {
-						const uint32_t rel = grid_index_nd<D>(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1)) - lo;
-						rels[k] = rel;
-						if (rel < cnt) mask |= 1u << k;
-						a0[k] = 0.f; a1[k] = 0.f;
-					}
-				}
-				if (mask) {
-#pragma unroll
-					for (int k = 0; k < NC; ++k) {
-						float w = (k & 1) ? p.fx : (1.0f - p.fx);
-						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
-						if (D == 3) w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
-						a0[k] += w * g0; a1[k] += w * g1;
-					}
-				}
-			}
-			if (mask) flush();
-		}
-	} else {
-		// Hashed (fine) levels: no two samples share keys, and only ~1/16 of the corners land in this slice.  The scan is a chain of
+	{
+		// Every slice owner scans its chunk of samples; only ~1/n_slices of the corners land in its slice.  The scan is a chain of
 		// dependent global loads, so every thread first fetches GB_UNROLL samples (coalesced across lanes).  The level size is a power
 		// of two here, so a corner index is (x ^ y*P1 ^ z*P2) & (size-1) with the three products shared by the 8 corners.
 		constexpr uint32_t GB_UNROLL = 8;
+		const bool pow2 = (lv.size & (lv.size - 1)) == 0;
 		const uint32_t hmask = lv.size - 1;
 		for (uint32_t s0 = s_begin + threadIdx.x; s0 < s_end; s0 += blockDim.x * GB_UNROLL) {
 			h2 gq[GB_UNROLL];
@@ -578,7 +858,7 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				const uint32_t sc = s < s_end ? s : s_begin;   // clamp: the load is always in range, the result is masked below
 				gq[u] = dxl[sc];
 				const float* c = coords + (size_t)sc * coord_stride;
-				px[u] = c[0]; py[u] = c[1]; pz[u] = D == 3 ? c[2] : 0.f;
+				if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
 			}
 #pragma unroll
 			for (uint32_t u = 0; u < GB_UNROLL; ++u) {
@@ -591,7 +871,8 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 				const uint32_t hz[2] = {D == 3 ? p.gz * 805459861u : 0u, D == 3 ? (p.gz + 1u) * 805459861u : 0u};
 #pragma unroll
 				for (int k = 0; k < NC; ++k) {
-					const uint32_t rel = ((hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[(k >> 2) & 1]) & hmask) - lo;
+					const uint32_t h = hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[(k >> 2) & 1];
+					const uint32_t rel = (pow2 ? (h & hmask) : (h % lv.size)) - lo;
 					if (rel < cnt) {
 						float w = (k & 1) ? p.fx : (1.0f - p.fx);
 						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
@@ -604,20 +885,39 @@ __global__ void __launch_bounds__(1024) grid_backward_kernel(const NgpNetDesc* _
 		}
 	}
 	__syncthreads();
-	h2* __restrict__ dst = partials + (size_t)(level * GB_ITEMS + item) * GB_SLICE;
+	h2* __restrict__ dst = partials + (size_t)level * (GB_PARTIAL_LEVEL_BYTES / 4u) + (size_t)item * GB_SLICE;
 	for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = slice[i];
 }
 
 // sums the K chunk-copies of every entry in fp32 and writes the fp16 gradient table (each entry exactly once)
-__global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __restrict__ desc, const h2* __restrict__ partials, h2* __restrict__ grid_grad) {
+__global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __restrict__ desc, const void* __restrict__ partials_raw, h2* __restrict__ grid_grad, uint32_t dims) {
 	const uint32_t level = blockIdx.y;
 	const NgpGridLevel lv = desc->levels[level];
+	const bool dense = (dims == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) return;   // written directly by the owners
+	if (dense) {
+		const GbSplit sp = gb_dense_split(lv.size);
+		if (sp.k_chunks == 1) return;                        // likewise
+		const ulonglong2* __restrict__ partials = (const ulonglong2*)partials_raw;
+		for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.size; e += gridDim.x * blockDim.x) {
+			const uint32_t sl = e / GB_FX_SLICE, rel = e % GB_FX_SLICE;
+			unsigned long long a0 = 0ull, a1 = 0ull;   // two's-complement sums of the K private copies: still exact
+			for (uint32_t c = 0; c < sp.k_chunks; ++c) {
+				const ulonglong2 v = partials[(size_t)(level * GB_D_ITEMS + c * sp.n_slices + sl) * GB_FX_SLICE + rel];
+				a0 += v.x; a1 += v.y;
+			}
+			h2 o; o[0] = gb_fixed_to_half(a0); o[1] = gb_fixed_to_half(a1);
+			grid_grad[lv.offset + e] = o;
+		}
+		return;
+	}
+	const h2* __restrict__ partials = (const h2*)partials_raw;
 	const GbSplit sp = gb_split(lv.size);
 	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.size; e += gridDim.x * blockDim.x) {
 		const uint32_t sl = e / GB_SLICE, rel = e % GB_SLICE;
 		float a0 = 0.0f, a1 = 0.0f;
 		for (uint32_t c = 0; c < sp.k_chunks; ++c) {
-			const h2 v = partials[(size_t)(level * GB_ITEMS + c * sp.n_slices + sl) * GB_SLICE + rel];
+			const h2 v = partials[(size_t)level * (GB_PARTIAL_LEVEL_BYTES / 4u) + (size_t)(c * sp.n_slices + sl) * GB_SLICE + rel];
 			a0 += (float)v[0]; a1 += (float)v[1];
 		}
 		h2 o; o[0] = (half_t)a0; o[1] = (half_t)a1;
@@ -1090,6 +1390,30 @@ static int fwd_grid(uint32_t n) {
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
+// hash-grid backward for all 16 levels: binned fixed-point path for the hashed levels, LDS owner-computes path for the dense ones
+template <int D>
+static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad) {
+	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
+	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
+	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
+	ulonglong2* sums = (ulonglong2*)((char*)items + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 4u);
+	const char* lm = getenv("NGP_HIP_GB_LEVELS");   // dev-only timing ablation; unset in production
+	const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xffffu;
+	NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
+	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
+	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
+	hipLaunchKernelGGL(gb_fx_scan_kernel, dim3(16), dim3(64), 0, st, ctr);
+	NGP_LAUNCH_CHECK("gb_fx_scan_kernel");
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
+	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
+	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(1024), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
+	NGP_LAUNCH_CHECK("grid_backward_kernel");
+	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const void*)gb_partials, grid_grad, (uint32_t)D);
+	NGP_LAUNCH_CHECK("grid_combine_kernel");
+	return 0;
+}
+
 } // namespace ngp
 
 using namespace ngp;
@@ -1213,13 +1537,13 @@ static uint32_t wgrad_chunks(uint32_t n) {
 	return n / chunk_len;
 }
 
-// scratch layout: [activation planes 480 x n fp16][wgrad partials chunks x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 32 x 32768 half2]
+// scratch layout: [activation planes 480 x n fp16][wgrad partials chunks x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 4 MiB][binned path: counters, item lists, run sums]
 static uint64_t scratch_off_wgrad(uint32_t n) { return (uint64_t)N_PLANE_ROWS * n * 2u; }
 static uint64_t scratch_off_dx(uint32_t n) { return scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_MLP_N_PARAMS * 4u; }
 static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
-uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) {
-	return scratch_off_gb(n) + (uint64_t)16 * GB_ITEMS * GB_SLICE * 4u;
-}
+static uint64_t gb_fx_bytes(uint32_t n) { return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u); }   // counters + item lists + run sums of the binned path
+static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
+uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx(n) + gb_fx_bytes(n); }
 
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
@@ -1239,16 +1563,9 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
 #undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
-	// EGradientMode::Overwrite: the combine pass writes every table entry exactly once (no memset, no global atomics)
+	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (!(ablate & 4)) {
-		if (getenv("NGP_HIP_GB_SPLIT")) {  // dev-only: one launch per level so a kernel trace shows per-level times
-			for (uint32_t l = 0; l < 16; ++l) hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 1), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, l);
-		} else {
-			hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
-		}
-		NGP_LAUNCH_CHECK("grid_backward_kernel");
-		hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_MLP_N_PARAMS));
-		NGP_LAUNCH_CHECK("grid_combine_kernel");
+		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS))) return -1;
 	}
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
@@ -1308,7 +1625,8 @@ int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* des
 static uint64_t gm_scratch_off_wgrad(uint32_t n) { return (uint64_t)GM_PLANE_ROWS * n * 2u; }
 static uint64_t gm_scratch_off_dx(uint32_t n) { return gm_scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_GRIDMLP_N_PARAMS * 4u; }
 static uint64_t gm_scratch_off_gb(uint32_t n) { return gm_scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
-uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n) { return gm_scratch_off_gb(n) + (uint64_t)16 * GB_ITEMS * GB_SLICE * 4u; }
+static uint64_t gm_scratch_off_fx(uint32_t n) { return gm_scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
+uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n) { return gm_scratch_off_fx(n) + gb_fx_bytes(n); }
 
 int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n,
                              const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
@@ -1322,11 +1640,8 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 	h2* gb_partials = (h2*)((char*)scratch + gm_scratch_off_gb(n));
 	hipLaunchKernelGGL(gridmlp_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes);
 	NGP_LAUNCH_CHECK("gridmlp_backward_kernel");
-	if (n_dims == 2) hipLaunchKernelGGL(grid_backward_kernel<2>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
-	else hipLaunchKernelGGL(grid_backward_kernel<3>, dim3(GB_ITEMS, 16), dim3(1024), 0, st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, 0u);
-	NGP_LAUNCH_CHECK("grid_backward_kernel");
-	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const h2*)gb_partials, (h2*)(grads + NGP_GRIDMLP_N_PARAMS));
-	NGP_LAUNCH_CHECK("grid_combine_kernel");
+	if (n_dims == 2) { if (launch_grid_backward<2>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS))) return -1; }
+	else { if (launch_grid_backward<3>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS))) return -1; }
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel<1>, dim3(n_chunks, 4), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");
