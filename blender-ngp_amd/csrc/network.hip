@@ -162,7 +162,8 @@ __device__ __forceinline__ f3_t load_pos3(const float* __restrict__ c) { f3_t v;
 struct LevelPos { uint32_t gx, gy, gz; float fx, fy, fz; };
 __device__ __forceinline__ LevelPos level_pos(const NgpGridLevel& lv, float px, float py, float pz) {
 	LevelPos p;
-	float x = px * lv.scale + 0.5f, y = py * lv.scale + 0.5f, z = pz * lv.scale + 0.5f;
+	// [tcnn] pos_fract: fmaf(scale, input, 0.5f) — one rounding, spelled out so that it does not depend on the contraction mode
+	float x = __builtin_fmaf(lv.scale, px, 0.5f), y = __builtin_fmaf(lv.scale, py, 0.5f), z = __builtin_fmaf(lv.scale, pz, 0.5f);
 	float flx = floorf(x), fly = floorf(y), flz = floorf(z);
 	p.gx = (uint32_t)(int)flx; p.gy = (uint32_t)(int)fly; p.gz = (uint32_t)(int)flz;
 	p.fx = x - flx; p.fy = y - fly; p.fz = z - flz;
@@ -468,6 +469,9 @@ __device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8
 	return r;
 }
 
+// The gradient terms must round like tcnn's (T)(weight * grad): fp32 product, THEN fp16; no contraction anywhere in this section.
+#pragma clang fp contract(off)
+
 // ----------------------------------------------------------------------------------------------------------------
 // Hash-grid backward WITHOUT global atomics ("owner computes").
 // Measured on MI355X (tools/atomic_probe.hip): scattered global atomics cap at ~21 Gop/s chip-wide whatever the footprint or the
@@ -516,6 +520,9 @@ __device__ __forceinline__ bool level_is_dense(const NgpGridLevel& lv) {
 // one term of tcnn's kernel_grid_backward, half(w * dL/dx), as an exact multiple of 2^-24 (integer part * 2^24 + fraction * 2^24, both native
 // fp32 -> int32 conversions); inf / nan terms (a step the loss scaler is about to skip) would poison the integer sums and are dropped
 __device__ __forceinline__ long long gb_term_fixed(float w_times_g) {
+	// tcnn: (T)(weight * grad) = fp32 product, THEN fp16.  The compiler would fold the caller's multiply into v_fma_mixlo_f16, which rounds
+	// the exact product once; the empty asm keeps the fp32 rounding
+	asm("" : "+v"(w_times_g));
 	const float t = (float)(half_t)w_times_g;
 	if (!(fabsf(t) < 65520.0f)) return 0ll;
 	const float fl = floorf(t);
@@ -877,7 +884,9 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 						float w = (k & 1) ? p.fx : (1.0f - p.fx);
 						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
 						if (D == 3) w *= ((k >> 2) & 1) ? p.fz : (1.0f - p.fz);
-						h2 val; val[0] = (half_t)(w * g0); val[1] = (half_t)(w * g1);   // tcnn kernel_grid_backward: half2(w * dL/dx)
+						float t0 = w * g0, t1 = w * g1;
+						asm("" : "+v"(t0), "+v"(t1));                     // fp32 product first, like tcnn's half2(w * dL/dx)
+						h2 val; val[0] = (half_t)t0; val[1] = (half_t)t1;
 						__builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2*)&slice[rel], val);
 					}
 				}
@@ -924,6 +933,8 @@ __global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __r
 		grid_grad[lv.offset + e] = o;
 	}
 }
+
+#pragma clang fp contract(fast)
 
 // Backward kernel: recompute forward from the saved encoding, dgrad chain, dL/dx planes + activation planes.  n % 32 == 0.
 template <int ABLATE> // dev-only ablation switch (bit0: no dL/dx store, bit1: no plane stores); the product path launches <0>
@@ -1573,6 +1584,20 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	return 0;
+}
+
+// ---- hash-grid backward on its own (tcnn kernel_grid_backward): scratch = [partials 16 x 4 MiB][binned path]
+uint64_t ngp_hip_grid_backward_scratch_bytes(uint32_t n) { return (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES + gb_fx_bytes(n); }
+int ngp_hip_grid_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                          const uint16_t* dL_dx_planes, uint16_t* grid_grad, void* scratch, uint64_t scratch_bytes) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_grid_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (n_dims != 2 && n_dims != 3) { set_last_error("ngp_hip_grid_backward: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_grid_backward_scratch_bytes(n)) { set_last_error("ngp_hip_grid_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	h2* gb_partials = (h2*)scratch;
+	void* fx = (char*)scratch + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES;
+	if (n_dims == 2) return launch_grid_backward<2>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dL_dx_planes, gb_partials, fx, (h2*)grid_grad);
+	return launch_grid_backward<3>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dL_dx_planes, gb_partials, fx, (h2*)grid_grad);
 }
 
 // ---- plumbing configs: grid encoding -> one MLP (P1 image, P2 sdf)

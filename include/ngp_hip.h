@@ -191,6 +191,16 @@ int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame
 int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
                     int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */
 
+/* [tcnn] GridEncodingTemplated::backward_impl -> kernel_grid_backward (tiny-cuda-nn encodings/grid.h; the reference reaches it through
+ * m_network->backward, src/testbed_nerf.cu:3331): grid_grad[entry][f] = sum over samples and corners of half(w * dL/dx[level][f]),
+ * EGradientMode::Overwrite.  dL_dx_planes: fp16 [16 levels][n] x 2 features (level-major planes, the layout ngp_hip_nerf_backward produces
+ * internally); grid_grad: fp16 [n_grid_entries][2], every entry written.  Levels that are dense or hashed with a power-of-two table and a
+ * resolution below 4096 are summed EXACTLY (64-bit fixed point, one rounding to fp16, independent of the order of the adds); tcnn rounds
+ * after every atomicAdd(half2), so results agree to fp16 accumulation noise, not bit for bit.  n must be a multiple of 256. */
+uint64_t ngp_hip_grid_backward_scratch_bytes(uint32_t n);
+int ngp_hip_grid_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                          const uint16_t* dL_dx_planes, uint16_t* grid_grad, void* scratch, uint64_t scratch_bytes);
+
 /* ============================ plumbing configs P1 (2-D image) / P2 (SDF): grid encoding -> one FullyFusedMLP ============================
  * tcnn NetworkWithInputEncoding as Testbed::reset_network builds it for Image / Sdf mode (src/testbed.cu:2397-2445): HashGrid (16 levels x 2
  * features over n_dims = 2 or 3) -> 64 -> 64 -> 16 (ReLU, no output activation).  Parameters: [input 64x32 | hidden 64x64 | output 16x64 | grid].

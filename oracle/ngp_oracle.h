@@ -72,6 +72,8 @@ void orc_gridmlp_make_levels(uint32_t n_dims, uint32_t n_levels, uint32_t log2_h
 uint32_t orc_gridmlp_n_params(const orc_net* net);
 void orc_grid_encode_nd(uint32_t n_dims, const orc_net* net, const uint16_t* grid, const float* pos_in, uint16_t* out);
 void orc_gridmlp_inference(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out, uint32_t out_stride);
+/* [tcnn] kernel_grid_backward with the sum taken exactly: out[entry][f] = fp16( sum of half(w * dL/dx) ), ONE rounding.  dL_dx_planes fp16 [n_levels][n][2]. */
+void orc_grid_backward_exact(uint32_t n_dims, const orc_net* net, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dx_planes, uint16_t* grid_grad);
 void orc_gridmlp_forward_backward(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dout, uint16_t* out4, double* grads_out, uint16_t* dL_dx_out);
 void orc_gridmlp_init_params(const orc_net* net, uint64_t seed, float* params_fp32);
 void orc_tcnn_loss_and_gradient(int loss_type, uint32_t n, uint32_t dims, float loss_scale, const uint16_t* predictions, uint32_t pred_stride, const float* targets, float* values, uint16_t* gradients, uint32_t grad_stride);

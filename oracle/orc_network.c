@@ -7,7 +7,7 @@
  * The arithmetic of GridEncoding / FullyFusedMLP / SphericalHarmonics / Adam / Ema lives in
  * NVlabs/tiny-cuda-nn (submodule, .gitmodules:16-18, UNPINNED commit, sources absent) and is restated
  * from that library's published algorithm [tcnn]:
- *   grid:  scale_l = exp2(l*log2(b))*N_min - 1; res_l = ceil(scale_l)+1; pos = x*scale+0.5; floor/fract;
+ *   grid:  scale_l = exp2(l*log2(b))*N_min - 1; res_l = ceil(scale_l)+1; pos = fma(scale, x, 0.5) (one rounding); floor/fract;
  *          dense index = x + y*res + z*res^2 (stride stops growing once > level size), hashed index =
  *          x*1 ^ y*2654435761 ^ z*805459861; index %= level size; trilinear weights; fp16 features.
  *   mlp:   row-major [out][in] fp16 weights, fp32 accumulate, ReLU on hidden layers, fp16 activations.
@@ -65,7 +65,7 @@ void orc_grid_encode_one(const orc_net* net, const uint16_t* grid /* fp16 [entri
 		const orc_grid_level* lv = &net->levels[l];
 		float pos[3]; uint32_t pg[3];
 		for (int d = 0; d < 3; ++d) {
-			float p = pos_in[d] * lv->scale + 0.5f;
+			float p = fmaf(lv->scale, pos_in[d], 0.5f);   /* [tcnn] pos_fract: fmaf(scale, input, 0.5f) */
 			float fl = floorf(p);
 			pg[d] = (uint32_t)(int)fl;
 			pos[d] = p - fl;
@@ -227,7 +227,7 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
 			const orc_grid_level* lv = &net->levels[l];
 			float pos[3]; uint32_t pg[3];
 			for (int d = 0; d < 3; ++d) {
-				float p = coord[d] * lv->scale + 0.5f;
+				float p = fmaf(lv->scale, coord[d], 0.5f);   /* [tcnn] pos_fract: fmaf(scale, input, 0.5f) */
 				float fl = floorf(p);
 				pg[d] = (uint32_t)(int)fl;
 				pos[d] = p - fl;
@@ -354,7 +354,7 @@ void orc_grid_encode_nd(uint32_t n_dims, const orc_net* net, const uint16_t* gri
 		const orc_grid_level* lv = &net->levels[l];
 		float pos[3] = {0, 0, 0}; uint32_t pg[3] = {0, 0, 0};
 		for (uint32_t d = 0; d < n_dims; ++d) {
-			float p = pos_in[d] * lv->scale + 0.5f;
+			float p = fmaf(lv->scale, pos_in[d], 0.5f);   /* [tcnn] pos_fract: fmaf(scale, input, 0.5f) */
 			float fl = floorf(p);
 			pg[d] = (uint32_t)(int)fl;
 			pos[d] = p - fl;
@@ -392,6 +392,59 @@ void orc_gridmlp_inference(uint32_t n_dims, const orc_net* net, const uint16_t* 
 	}
 }
 
+/* [tcnn] kernel_grid_backward (encodings/grid.h), restated with an exact sum: every term half(w * dL/dx) is a multiple of 2^-24 below 2^16,
+ * so a 64-bit integer holds the sum of all terms of an entry exactly; it is rounded to fp16 once (nearest even).  tcnn itself rounds after
+ * every atomicAdd(half2) in whatever order the GPU schedules them, which no restatement can pin; this is the order-independent answer those
+ * sums scatter around.  Non-finite terms are dropped (the device does the same; such a step is skipped by the loss scaler anyway). */
+static uint16_t orc_fixed24_to_half(long long a) {
+	/* exact integer a * 2^-24 -> fp16: round to odd at 24 significant bits, then orc_f2h rounds nearest-even to 11 */
+	unsigned long long m = a < 0 ? 0ull - (unsigned long long)a : (unsigned long long)a;
+	float f;
+	if (m < (1ull << 24)) f = (float)(uint32_t)m;
+	else {
+		int top_bit = 63; while (!((m >> top_bit) & 1ull)) --top_bit;
+		const int sh = top_bit - 23;
+		unsigned long long top = m >> sh;
+		if (m & ((1ull << sh) - 1ull)) top |= 1ull;
+		f = ldexpf((float)(uint32_t)top, sh);
+	}
+	f *= 1.0f / 16777216.0f;
+	return orc_f2h(a < 0 ? -f : f);
+}
+
+void orc_grid_backward_exact(uint32_t n_dims, const orc_net* net, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dx_planes, uint16_t* grid_grad) {
+	const orc_grid_level* last = &net->levels[net->n_levels - 1];
+	const size_t n_entries = (size_t)last->offset + last->size;
+	long long* acc = (long long*)calloc(2 * n_entries, sizeof(long long));
+	for (uint32_t l = 0; l < net->n_levels; ++l) {
+		const orc_grid_level* lv = &net->levels[l];
+		for (uint32_t i = 0; i < n; ++i) {
+			const float* pos_in = pos_all + (size_t)i * pos_stride_floats;
+			float pos[3] = {0, 0, 0}; uint32_t pg[3] = {0, 0, 0};
+			for (uint32_t d = 0; d < n_dims; ++d) {
+				float p = fmaf(lv->scale, pos_in[d], 0.5f);   /* [tcnn] pos_fract: fmaf(scale, input, 0.5f) */
+				float fl = floorf(p);
+				pg[d] = (uint32_t)(int)fl;
+				pos[d] = p - fl;
+			}
+			const float g0 = orc_h2f(dL_dx_planes[((size_t)l * n + i) * 2]), g1 = orc_h2f(dL_dx_planes[((size_t)l * n + i) * 2 + 1]);
+			for (uint32_t idx = 0; idx < (1u << n_dims); ++idx) {
+				float w = 1.0f; uint32_t c[3] = {0, 0, 0};
+				for (uint32_t d = 0; d < n_dims; ++d) {
+					if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; c[d] = pg[d]; }
+					else { w *= pos[d]; c[d] = pg[d] + 1; }
+				}
+				const size_t k = 2u * ((size_t)lv->offset + orc_grid_index_nd(n_dims, lv, c));
+				const float t0 = orc_rh(w * g0), t1 = orc_rh(w * g1);
+				if (fabsf(t0) < 65520.0f) acc[k] += (long long)((double)t0 * 16777216.0);
+				if (fabsf(t1) < 65520.0f) acc[k + 1] += (long long)((double)t1 * 16777216.0);
+			}
+		}
+	}
+	for (size_t k = 0; k < 2 * n_entries; ++k) grid_grad[k] = orc_fixed24_to_half(acc[k]);
+	free(acc);
+}
+
 /* forward + backward over n samples; dL_dout fp16 [n][4]; grads_out double [n_params]; optional per-sample outputs / encodings / dL/dx */
 void orc_gridmlp_forward_backward(uint32_t n_dims, const orc_net* net, const uint16_t* params, const float* pos_all, uint32_t pos_stride_floats, uint32_t n, const uint16_t* dL_dout,
                                   uint16_t* out4 /* [n][4] or NULL */, double* grads_out, uint16_t* dL_dx_out /* [n][32] or NULL */) {
@@ -423,7 +476,7 @@ void orc_gridmlp_forward_backward(uint32_t n_dims, const orc_net* net, const uin
 			const orc_grid_level* lv = &net->levels[l];
 			float pos[3] = {0, 0, 0}; uint32_t pg[3] = {0, 0, 0};
 			for (uint32_t d = 0; d < n_dims; ++d) {
-				float p = pos_in[d] * lv->scale + 0.5f;
+				float p = fmaf(lv->scale, pos_in[d], 0.5f);   /* [tcnn] pos_fract: fmaf(scale, input, 0.5f) */
 				float fl = floorf(p);
 				pg[d] = (uint32_t)(int)fl;
 				pos[d] = p - fl;

