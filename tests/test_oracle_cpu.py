@@ -219,3 +219,51 @@ def test_oracle_network_gradients_finite_difference(oracle, ngp):
     fd = loss(p_plus) - loss(p_minus)
     an = float((grads * actual_dir).sum())
     assert abs(fd - an) <= 0.05 * abs(an) + 0.05, (fd, an)
+
+
+def test_exact_grid_backward_is_the_rounded_rational_sum(oracle, ngp):
+    """orc_grid_backward_exact against an independent restatement in exact rational arithmetic (Fraction), and its one-rounding conversion
+    against numpy's correctly rounded float64 -> float16 on sums that fit a double exactly."""
+    from fractions import Fraction
+    n = 256
+    desc = H.make_desc(ngp, log2_hashmap_size=10)
+    rs = np.random.RandomState(3)
+    pos = rs.rand(n, 3).astype(np.float32)
+    pos[:32] = pos[0] + (np.arange(32)[:, None] * 1e-4).astype(np.float32)     # a run of samples inside one coarse cell
+    pl = (rs.randn(16, n, 2) * 0.05).astype(np.float16)
+    pl[2, 3, 0] = np.float16(np.inf)                                             # dropped
+    pl[5, 4] = np.float16(6.0e-8)                                                # subnormal terms
+    n_entries = int(desc["n_grid_entries"][0])
+    got = np.zeros(2 * n_entries, np.uint16)
+    oracle.orc_grid_backward_exact(3, desc.ctypes.data, pos.ctypes.data, 3, n, pl.view(np.uint16).ctypes.data, got.ctypes.data)
+    acc = {}
+    lv = desc["levels"][0]
+    primes = (1, 2654435761, 805459861)
+    for l in range(16):
+        scale, res, size, off = np.float32(lv[l]["scale"]), int(lv[l]["resolution"]), int(lv[l]["size"]), int(lv[l]["offset"])
+        for i in range(n):
+            p = np.array([np.float32(float(Fraction(float(scale)) * Fraction(float(x)) + Fraction(1, 2))) for x in pos[i]], np.float32)   # fma: one rounding
+            fl = np.floor(p)
+            fr = (p - fl).astype(np.float32)
+            pg = fl.astype(np.int64)
+            for c in range(8):
+                w = np.float32(1.0)
+                cc = []
+                for d in range(3):
+                    w = np.float32(w * (fr[d] if (c >> d) & 1 else np.float32(np.float32(1.0) - fr[d])))
+                    cc.append(int(pg[d]) + ((c >> d) & 1))
+                if res ** 3 <= size:
+                    idx = (cc[0] + cc[1] * res + cc[2] * res * res) % size
+                else:
+                    idx = (((cc[0] * primes[0]) ^ (cc[1] * primes[1]) ^ (cc[2] * primes[2])) & 0xffffffff) % size
+                for f in range(2):
+                    with np.errstate(over="ignore", invalid="ignore"):
+                        t = np.float16(np.float32(w * np.float32(pl[l, i, f])))
+                    if np.isfinite(t):
+                        k = 2 * (off + idx) + f
+                        acc[k] = acc.get(k, Fraction(0)) + Fraction(float(t))
+    ref = np.zeros(2 * n_entries, np.float16)
+    for k, v in acc.items():
+        ref[k] = np.float16(float(v))        # sums of < 2^12 terms of 41-bit fixed point fit a double exactly; numpy rounds to nearest even
+    np.testing.assert_array_equal(got, ref.view(np.uint16))
+    assert (got != 0).sum() > 10000
