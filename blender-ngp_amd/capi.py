@@ -131,6 +131,7 @@ NERF_PROPS = np.dtype([
     ("transform", "<f4", 16), ("itransform", "<f4", 16), ("density_grid_bitfield", "<u8"), ("grid_size", "<u4"), ("grid_volume", "<u4"),
     ("render_aabb", AABB), ("train_aabb", AABB), ("masks", "<u8"), ("n_masks", "<u4"), ("cone_angle", "<f4"), ("min_cone_stepsize", "<f4"),
     ("max_cone_stepsize", "<f4"), ("nerf_cascades", "<u4"), ("opacity", "<f4")], align=True)
+ERROR_MAP_CDF = np.dtype([("cdf_x_cond_y", np.uint64), ("cdf_y", np.uint64), ("cdf_img", np.uint64), ("res", np.int32, 2)], align=True)   # NgpErrorMapCdf
 DOWNSAMPLE_INFO = np.dtype([("max_res", "<i4", 2), ("scaled_res", "<i4", 2), ("skip", "<i4", 2), ("max_pixels", "<u4"), ("scaled_pixels", "<u4")])
 RENDER_CAMERA = np.dtype([("transform", "<f4", 12), ("model", "<i4"), ("focal_length", "<f4"), ("sq_width", "<f4"), ("sq_height", "<f4"), ("sq_curvature", "<f4"),
                           ("qh_front", "<f4", 12), ("qh_back", "<f4", 12), ("near_distance", "<f4"), ("aperture_size", "<f4"), ("focus_z", "<f4")])

@@ -46,6 +46,7 @@ struct LossArgs {
 	const NgpRay* rays_in; uint32_t* numsteps_in; const NgpCoord* coords_in; NgpCoord* coords_out; uint16_t* dloss_doutput; uint32_t dl_stride;
 	int loss_type; float* loss_output; int max_level_rand_training; float* max_level_compacted; int rgb_activation; int density_activation;
 	int snap_to_pixel_centers; float* error_map; int32_t error_map_res[2]; const float* mean_density; const float* exposure; float near_distance;
+	ErrorMapCdf cdf;
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	}
 
 	// ---- target colour: replay the ray generator's draws (1376-1423); wave-uniform
-	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f;
+	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f;
 	uint32_t img = 0;
 	int32_t img_res[2] = {1, 1};
 	v3 ray_o = mk(0, 0, 0);
@@ -130,18 +131,12 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		const uint32_t ray_idx = a.ray_indices_in[i];
 		Pcg32 rng = a.rng;
 		rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
-		img = ((ray_idx * a.n_training_images) / a.n_rays) % a.n_training_images;
+		float img_pdf = 1.0f, xy_pdf = 1.0f;
+		img = image_idx(ray_idx, a.n_rays, a.n_training_images, a.cdf.cdf_img, &img_pdf);
 		const NgpImageMeta& md = a.metadata[img];
 		img_res[0] = md.res[0]; img_res[1] = md.res[1];
-		xy[0] = rng.next_float(); xy[1] = rng.next_float();
-		if (a.snap_to_pixel_centers) {
-#pragma unroll
-			for (int k = 0; k < 2; ++k) {
-				int p = (int)(xy[k] * (float)md.res[k]);
-				p = p > 0 ? p : 0; p = p < md.res[k] - 1 ? p : md.res[k] - 1;
-				xy[k] = ((float)p + 0.5f) / (float)md.res[k];
-			}
-		}
+		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, xy[0], xy[1], &xy_pdf);
+		sample_pdf = img_pdf * xy_pdf;
 		max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
 		float bg[3] = {a.background_color[0], a.background_color[1], a.background_color[2]};
 		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
@@ -193,7 +188,8 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	if (compacted == 0) return;
 
 	const LG lg = loss_and_gradient(rgbtarget, rgb_ray, a.loss_type);
-	const float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
+	// lg.loss /= img_pdf * xy_pdf (1448): the reported loss and the error map are importance-weighted, the gradient deliberately is not (1454-1458)
+	const float mean_loss = (lg.loss[0] / sample_pdf + lg.loss[1] / sample_pdf + lg.loss[2] / sample_pdf) / 3.0f;
 	if (lane == 0) {
 		if (a.loss_output) a.loss_output[i] = mean_loss / (float)a.n_rays;
 		if (a.error_map) {
@@ -416,9 +412,50 @@ __global__ void image_mse_kernel(uint32_t n_elements, const float* __restrict__ 
 
 } // namespace ngp
 
+// ---- error-map CDFs (testbed_nerf.cu:1982-2037).  One thread per (image, row) / per image like the reference: the running sums are
+// sequential fp32 additions whose order is part of the result.
+namespace ngp {
+constexpr float MIN_PDF = 0.01f;
+__global__ void construct_cdf_2d_kernel(uint32_t n_images, uint32_t height, uint32_t width, const float* __restrict__ data, float* __restrict__ cdf_x_cond_y, float* __restrict__ cdf_y) {
+	const uint32_t y = threadIdx.x + blockIdx.x * blockDim.x;
+	const uint32_t img = threadIdx.y + blockIdx.y * blockDim.y;
+	if (y >= height || img >= n_images) return;
+	const size_t off = ((size_t)img * height + y) * width;
+	data += off; cdf_x_cond_y += off;
+	float cum = 0;
+	for (uint32_t x = 0; x < width; ++x) { cum += data[x] + 1e-10f; cdf_x_cond_y[x] = cum; }
+	cdf_y[(size_t)img * height + y] = cum;
+	const float norm = 1.0f / cum;   // __frcp_rn
+	for (uint32_t x = 0; x < width; ++x) cdf_x_cond_y[x] = (1.0f - MIN_PDF) * cdf_x_cond_y[x] * norm + MIN_PDF * (float)(x + 1) / (float)width;
+}
+__global__ void construct_cdf_1d_kernel(uint32_t n_images, uint32_t height, float* __restrict__ cdf_y, float* __restrict__ cdf_img) {
+	const uint32_t img = threadIdx.x + blockIdx.x * blockDim.x;
+	if (img >= n_images) return;
+	cdf_y += (size_t)img * height;
+	float cum = 0;
+	for (uint32_t y = 0; y < height; ++y) { cum += cdf_y[y]; cdf_y[y] = cum; }
+	cdf_img[img] = cum;
+	const float norm = 1.0f / cum;
+	for (uint32_t y = 0; y < height; ++y) cdf_y[y] = (1.0f - MIN_PDF) * cdf_y[y] * norm + MIN_PDF * (float)(y + 1) / (float)height;
+}
+}  // namespace ngp
+
 using namespace ngp;
 
 extern "C" {
+
+int ngp_hip_construct_cdf_2d(void* stream, uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y) {
+	if (!n_images || !height || !width) return 0;
+	hipLaunchKernelGGL(construct_cdf_2d_kernel, dim3(div_up(height, 16), div_up(n_images, 8)), dim3(16, 8), 0, (hipStream_t)stream, n_images, height, width, data, cdf_x_cond_y, cdf_y);
+	NGP_LAUNCH_CHECK("construct_cdf_2d_kernel");
+	return 0;
+}
+int ngp_hip_construct_cdf_1d(void* stream, uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img) {
+	if (!n_images || !height) return 0;
+	hipLaunchKernelGGL(construct_cdf_1d_kernel, dim3(div_up(n_images, 128)), dim3(128), 0, (hipStream_t)stream, n_images, height, cdf_y, cdf_img);
+	NGP_LAUNCH_CHECK("construct_cdf_1d_kernel");
+	return 0;
+}
 
 int ngp_hip_compute_loss(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
@@ -428,7 +465,7 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance) {
+	float near_distance, const NgpErrorMapCdf* cdf_host) {
 	if (!n_rays) return 0;
 	if ((mlp_stride & 3) || (dl_stride & 3)) { set_last_error("ngp_hip_compute_loss: strides must be multiples of 4 halves", hipErrorInvalidValue); return -1; }
 	LossArgs a;
@@ -440,6 +477,7 @@ int ngp_hip_compute_loss(
 	a.ray_indices_in = ray_indices_in; a.rays_in = rays_in_unnormalized; a.numsteps_in = numsteps_in; a.coords_in = coords_in; a.coords_out = coords_out;
 	a.dloss_doutput = dloss_doutput; a.dl_stride = dl_stride; a.loss_type = loss_type; a.loss_output = loss_output;
 	a.max_level_rand_training = max_level_rand_training; a.max_level_compacted = max_level_compacted; a.rgb_activation = rgb_activation;
+	a.cdf = make_error_map_cdf(cdf_host);
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;

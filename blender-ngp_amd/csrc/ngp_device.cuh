@@ -127,6 +127,69 @@ __device__ __forceinline__ void ld_random_pixel_offset(uint32_t spp, float& ox, 
 	oy = 0.5f - a1 + b1; oy = oy - floorf(oy);
 }
 
+// ---- error-map importance sampling (testbed_nerf.cu:991-1083; off by default, testbed.h:668-669)
+struct ErrorMapCdf { const float* cdf_x_cond_y; const float* cdf_y; const float* cdf_img; int32_t res[2]; };
+// common.h:201-224
+__device__ __forceinline__ uint32_t binary_search(float val, const float* __restrict__ data, uint32_t length) {
+	if (length == 0) return 0;
+	uint32_t first = 0, count = length;
+	while (count > 0) {
+		const uint32_t step = count / 2, it = first + step;
+		if (data[it] < val) { first = it + 1; count -= step + 1; }
+		else count = step;
+	}
+	return first < length - 1 ? first : length - 1;
+}
+// image_idx (1062-1083)
+__device__ __forceinline__ uint32_t image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_training_images, const float* __restrict__ cdf, float* pdf) {
+	if (cdf) {
+		const float sample = ld_random_val(base_idx, 0xdeadbeefu);
+		const uint32_t img = binary_search(sample, cdf, n_training_images);
+		if (pdf) { const float prev = img > 0 ? cdf[img - 1] : 0.0f; *pdf = (cdf[img] - prev) * (float)n_training_images; }
+		return img;
+	}
+	if (pdf) *pdf = 1.0f;
+	return ((base_idx * n_training_images) / n_rays) % n_training_images;   // neighbouring rays read the same image
+}
+// sample_cdf_2d (991-1022): half of the samples stay uniform
+__device__ __forceinline__ void sample_cdf_2d(float& sx, float& sy, uint32_t img, const int32_t res[2], const float* __restrict__ cdf_x_cond_y, const float* __restrict__ cdf_y, float* pdf) {
+	constexpr float UNIFORM_SAMPLING_FRACTION = 0.5f;
+	if (sx < UNIFORM_SAMPLING_FRACTION) { sx /= UNIFORM_SAMPLING_FRACTION; return; }
+	sx = (sx - UNIFORM_SAMPLING_FRACTION) / (1.0f - UNIFORM_SAMPLING_FRACTION);
+	cdf_y += (size_t)img * res[1];
+	const uint32_t y = binary_search(sy, cdf_y, (uint32_t)res[1]);
+	float prev = y > 0 ? cdf_y[y - 1] : 0.0f;
+	const float pmf_y = cdf_y[y] - prev;
+	sy = (sy - prev) / pmf_y;
+	cdf_x_cond_y += (size_t)img * res[1] * res[0] + (size_t)y * res[0];
+	const uint32_t x = binary_search(sx, cdf_x_cond_y, (uint32_t)res[0]);
+	prev = x > 0 ? cdf_x_cond_y[x - 1] : 0.0f;
+	const float pmf_x = cdf_x_cond_y[x] - prev;
+	sx = (sx - prev) / pmf_x;
+	if (pdf) *pdf = pmf_x * pmf_y * (float)(res[0] * res[1]);
+	sx = ((float)x + sx) / (float)res[0];
+	sy = ((float)y + sy) / (float)res[1];
+}
+// nerf_random_image_pos_training (1047-1060)
+__device__ __forceinline__ void nerf_random_image_pos_training(Pcg32& rng, const int32_t res[2], int snap_to_pixel_centers, const ErrorMapCdf& cdf, uint32_t img, float& u, float& v, float* pdf) {
+	u = rng.next_float(); v = rng.next_float();
+	if (pdf) *pdf = 1.0f;
+	if (cdf.cdf_x_cond_y) sample_cdf_2d(u, v, img, cdf.res, cdf.cdf_x_cond_y, cdf.cdf_y, pdf);
+	if (snap_to_pixel_centers) {
+		int px = (int)(u * (float)res[0]), py = (int)(v * (float)res[1]);
+		px = px > 0 ? px : 0; px = px < res[0] - 1 ? px : res[0] - 1;
+		py = py > 0 ? py : 0; py = py < res[1] - 1 ? py : res[1] - 1;
+		u = ((float)px + 0.5f) / (float)res[0];
+		v = ((float)py + 0.5f) / (float)res[1];
+	}
+}
+__host__ inline ErrorMapCdf make_error_map_cdf(const NgpErrorMapCdf* h) {
+	ErrorMapCdf c; c.cdf_x_cond_y = nullptr; c.cdf_y = nullptr; c.cdf_img = nullptr; c.res[0] = c.res[1] = 0;
+	if (h) { c.cdf_x_cond_y = h->cdf_x_cond_y; c.cdf_y = h->cdf_y; c.cdf_img = h->cdf_img; c.res[0] = h->res[0]; c.res[1] = h->res[1]; }
+	return c;
+}
+
+
 // ---------------------------------------------------------------- morton (tcnn common_device.h)
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
 	v = (v * 0x00010001u) & 0xFF0000FFu;

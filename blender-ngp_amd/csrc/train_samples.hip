@@ -20,7 +20,7 @@ struct TrainSampleArgs {
 	uint32_t* ray_counter; uint32_t* numsteps_counter; uint32_t* ray_indices_out; NgpRay* rays_out; uint32_t* numsteps_out; NgpCoord* coords_out;
 	uint32_t n_training_images; const NgpImageMeta* metadata; const NgpXForm* xforms; const uint8_t* density_grid;
 	int max_level_rand_training; float* max_level_ptr; int snap_to_pixel_centers; int train_envmap; float cone_angle_constant;
-	const float* distortion_data; int32_t distortion_res[2]; uint32_t ray_offset; uint32_t n_rays_global;
+	const float* distortion_data; int32_t distortion_res[2]; uint32_t ray_offset; uint32_t n_rays_global; ErrorMapCdf cdf;
 	int dev_variant; // dev-only timing variants (NGP_HIP_GEN_VARIANT): 0 product path, 2 no sample writes, 3 no march
 };
 
@@ -41,18 +41,12 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 	v3 ro = mk(0, 0, 0), rd_unnorm = mk(0, 0, 1), rd = mk(0, 0, 1), idir = mk(1, 1, 1);
 
 	if (in_range) {
-		const uint32_t img = ((i * a.n_training_images) / a.n_rays_global) % a.n_training_images; // image_idx, no CDF (1082)
+		const uint32_t img = image_idx(i, a.n_rays_global, a.n_training_images, a.cdf.cdf_img, nullptr);
 		const NgpImageMeta& md = a.metadata[img];
 		Pcg32 rng = a.rng;
 		rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
-		float u = rng.next_float(), v = rng.next_float();
-		if (a.snap_to_pixel_centers) {
-			int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
-			px = px > 0 ? px : 0; px = px < md.res[0] - 1 ? px : md.res[0] - 1;
-			py = py > 0 ? py : 0; py = py < md.res[1] - 1 ? py : md.res[1] - 1;
-			u = ((float)px + 0.5f) / (float)md.res[0];
-			v = ((float)py + 0.5f) / (float)md.res[1];
-		}
+		float u, v;
+		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, u, v, nullptr);
 		if (!pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) {
 			max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
 			const float motionblur_time = rng.next_float();
@@ -245,9 +239,11 @@ extern "C" int ngp_hip_generate_training_samples(
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
-	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global) {
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
+	const NgpErrorMapCdf* cdf_host) {
 	if (!n_rays) return 0;
 	TrainSampleArgs a;
+	a.cdf = make_error_map_cdf(cdf_host);
 	a.n_rays = n_rays; a.aabb = aabb_from_host(aabb_host); a.max_samples = max_samples; a.rng.state = rng_state; a.rng.inc = rng_inc;
 	a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out; a.rays_out = rays_out_unnormalized;
 	a.numsteps_out = numsteps_out; a.coords_out = coords_out; a.n_training_images = n_training_images; a.metadata = metadata; a.xforms = xforms;

@@ -443,6 +443,26 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("offset", [](NerfTraining& t) { return vec3_to_py(t.dataset.offset); })
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
+		.def_readwrite("sample_focal_plane_proportional_to_error", &NerfTraining::sample_focal_plane_proportional_to_error)   // python_api.cu:817
+		.def_readwrite("sample_image_proportional_to_error", &NerfTraining::sample_image_proportional_to_error)               // python_api.cu:818
+		.def_readwrite("n_steps_between_error_map_updates", &NerfTraining::n_steps_between_error_map_updates)
+		.def_readonly("n_steps_since_error_map_update", &NerfTraining::n_steps_since_error_map_update)
+		.def_property_readonly("is_cdf_valid", [](NerfTraining& t) { return t.is_cdf_valid; })
+		.def("get_error_map", [](NerfTraining& t) {               // [n_images][res_y][res_x] fp32, as accumulated since the last CDF update
+				py::array_t<float> a({(py::ssize_t)t.dataset.n_images, (py::ssize_t)t.error_map_res[1], (py::ssize_t)t.error_map_res[0]});
+				if (a.size()) t.error_map_data.copy_to_host(a.mutable_data(), (size_t)a.size() * 4);
+				return a;
+			})
+		.def("get_error_map_cdfs", [](NerfTraining& t) {          // (cdf_x_cond_y [n][h][w], cdf_y [n][h], cdf_img [n], pmf_img [n])
+				if (!t.is_cdf_valid) throw std::runtime_error{"the error-map CDFs have not been built yet"};
+				const py::ssize_t n = (py::ssize_t)t.dataset.n_images, h = t.cdf_res[1], w = t.cdf_res[0];
+				py::array_t<float> x({n, h, w}), y({n, h}), im({n}), pm({n});
+				t.cdf_x_cond_y.copy_to_host(x.mutable_data(), (size_t)x.size() * 4);
+				t.cdf_y.copy_to_host(y.mutable_data(), (size_t)y.size() * 4);
+				t.cdf_img.copy_to_host(im.mutable_data(), (size_t)im.size() * 4);
+				for (py::ssize_t i = 0; i < n; ++i) pm.mutable_data()[i] = t.pmf_img_cpu[(size_t)i];
+				return py::make_tuple(x, y, im, pm);
+			})
 		.def_readwrite("density_grid_decay", &NerfTraining::density_grid_decay)
 		.def_readwrite("n_images_for_training", &NerfTraining::n_images_for_training)
 		.def_property_readonly("rays_per_batch", [](NerfTraining& t) { return t.counters_rgb.rays_per_batch; })

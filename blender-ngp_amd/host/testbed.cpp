@@ -585,11 +585,12 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
 	const int32_t dist_res[2] = {32, 32};
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
+	NgpErrorMapCdf cdf_storage;
 	profile_begin(PK_GEN_SAMPLES, stream);
 	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
-	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global), "generate_training_samples");
+	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage)), "generate_training_samples");
 	profile_end(PK_GEN_SAMPLES, R, stream);
 }
 
@@ -610,6 +611,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	PrefetchedSamples p;
 	p.valid = true; p.step = next_step; p.R = c.rays_per_batch; p.max_inference = next_max_inference(target_batch_size); p.rng_state = rng.state;
 	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
+	p.cdf_mode = m_nerf.training.cdf_mode();
 	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the counters event has fired by now
 	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_prefetch_event = e; }
@@ -657,7 +659,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	tr.n_rays_since_error_map_update += R;
 
 	const bool hit = m_prefetch.valid && m_prefetch.step == m_training_step && m_prefetch.R == R && m_prefetch.max_inference == max_inference && m_prefetch.rng_state == m_rng.state &&
-	                 m_prefetch.version == m_state_version && m_prefetch.n_images == tr.n_images_for_training && m_prefetch.batch == target_batch_size;
+	                 m_prefetch.version == m_state_version && m_prefetch.n_images == tr.n_images_for_training && m_prefetch.batch == target_batch_size &&
+	                 m_prefetch.cdf_mode == tr.cdf_mode();
 	if (hit) {
 		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_prefetch_event, 0));
 		m_gen_slot = m_prefetch.slot;
@@ -675,12 +678,14 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
 	profile_end(PK_INFERENCE, max_inference);
 	profile_begin(PK_LOSS);
+	NgpErrorMapCdf cdf_storage;
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
 	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
-	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance), "compute_loss");
+	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
+	                           tr.error_map_cdf(cdf_storage)), "compute_loss");
 	profile_end(PK_LOSS, R);
 	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
 	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
@@ -751,13 +756,45 @@ void Testbed::train_nerf_dp_end() {
 		fprintf(stderr, "Nerf training generated 0 samples. Aborting training.\n");
 		m_train = false;
 	}
-	// error-map bookkeeping (2971-3023); CDF construction is skipped because sampling from it is off by default (testbed.h:668-669)
+	// error map -> CDFs (2971-3023): low-overhead enough to be always on in the reference; sampling from them is a separate switch
 	tr.n_steps_since_error_map_update += 1;
-	if (tr.n_steps_since_error_map_update >= tr.n_steps_between_error_map_updates) {
+	if (tr.n_steps_since_error_map_update >= tr.n_steps_between_error_map_updates && tr.error_map_res[0] > 0 && tr.dataset.n_images > 0) {
+		const uint32_t n_img = (uint32_t)tr.dataset.n_images, W = (uint32_t)tr.error_map_res[0], H = (uint32_t)tr.error_map_res[1];
+		tr.cdf_res[0] = tr.error_map_res[0]; tr.cdf_res[1] = tr.error_map_res[1];
+		tr.cdf_x_cond_y.resize((size_t)W * H * n_img * 4); tr.cdf_y.resize((size_t)H * n_img * 4); tr.cdf_img.resize((size_t)n_img * 4);
+		check(ngp_hip_construct_cdf_2d(m_stream, n_img, H, W, tr.error_map_data.as<float>(), tr.cdf_x_cond_y.as<float>(), tr.cdf_y.as<float>()), "construct_cdf_2d");
+		check(ngp_hip_construct_cdf_1d(m_stream, n_img, H, tr.cdf_y.as<float>(), tr.cdf_img.as<float>()), "construct_cdf_1d");
+		// image CDF on the CPU ("single-threaded anyway", 2999-3015)
+		tr.pmf_img_cpu.resize(n_img);
+		HIP_CHECK_THROW(hipMemcpyAsync(tr.pmf_img_cpu.data(), tr.cdf_img.data(), (size_t)n_img * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
+		std::vector<float> cdf_img_cpu = tr.pmf_img_cpu;
+		float cum = 0;
+		for (float& f : cdf_img_cpu) { cum += f; f = cum; }
+		const float norm = 1.0f / cum;
+		for (size_t i = 0; i < cdf_img_cpu.size(); ++i) {
+			constexpr float MIN_PMF = 0.1f;
+			tr.pmf_img_cpu[i] = (1.0f - MIN_PMF) * tr.pmf_img_cpu[i] * norm + MIN_PMF / (float)n_img;
+			cdf_img_cpu[i] = (1.0f - MIN_PMF) * cdf_img_cpu[i] * norm + MIN_PMF * (float)(i + 1) / (float)n_img;
+		}
+		HIP_CHECK_THROW(hipMemcpyAsync(tr.cdf_img.data(), cdf_img_cpu.data(), (size_t)n_img * 4, hipMemcpyHostToDevice, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));   // cdf_img_cpu goes out of scope
 		tr.n_steps_since_error_map_update = 0;
 		tr.n_rays_since_error_map_update = 0;
+		tr.is_cdf_valid = true;
 		tr.n_steps_between_error_map_updates = (uint32_t)(tr.n_steps_between_error_map_updates * 1.5f);
+		if (tr.cdf_mode()) ++m_state_version;   // a march that ran ahead used the previous CDFs
 	}
+}
+
+const NgpErrorMapCdf* NerfTraining::error_map_cdf(NgpErrorMapCdf& storage) const {
+	const uint32_t mode = cdf_mode();
+	if (!mode) return nullptr;
+	storage.cdf_x_cond_y = (mode & 1u) ? cdf_x_cond_y.as<float>() : nullptr;
+	storage.cdf_y = (mode & 1u) ? cdf_y.as<float>() : nullptr;
+	storage.cdf_img = (mode & 2u) ? cdf_img.as<float>() : nullptr;
+	storage.res[0] = cdf_res[0]; storage.res[1] = cdf_res[1];
+	return &storage;
 }
 
 void Testbed::update_after_training(uint32_t target_batch_size, uint32_t counter, uint32_t compacted_counter, bool get_loss_scalar, float loss_sum) {  // 2870-2894

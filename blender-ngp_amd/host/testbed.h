@@ -136,6 +136,15 @@ struct NerfTraining {
 	uint32_t n_steps_since_error_map_update = 0;
 	uint32_t n_steps_between_error_map_updates = 128;
 	uint32_t n_rays_since_error_map_update = 0;
+	// CDFs built from the error map every n_steps_between_error_map_updates steps (2973-3023); sampling from them is off by default
+	DeviceBuffer cdf_x_cond_y, cdf_y, cdf_img;
+	int32_t cdf_res[2] = {0, 0};
+	std::vector<float> pmf_img_cpu;
+	bool is_cdf_valid = false;
+	bool sample_focal_plane_proportional_to_error = false;   // testbed.h:668
+	bool sample_image_proportional_to_error = false;         // testbed.h:669
+	uint32_t cdf_mode() const { return is_cdf_valid ? (sample_focal_plane_proportional_to_error ? 1u : 0u) | (sample_image_proportional_to_error ? 2u : 0u) : 0u; }
+	const NgpErrorMapCdf* error_map_cdf(NgpErrorMapCdf& storage) const;   // NULL when both switches are off (3211-3212, 3243-3245)
 
 	void set_image(int frame_idx, int w, int h, const float* rgba_host);                 // python_api.cu:53-72 (float RGBA)
 	void set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host);         // Byte images as the PNG loader stores them (nerf_loader.cu:622-623)
@@ -340,7 +349,7 @@ private:
 	std::atomic<bool> m_currently_rendering{false};
 	void* m_stream = nullptr;
 	void* m_stream_b = nullptr;                        // second stream: sample generation one step ahead
-	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };
+	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0, cdf_mode = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };
 	PrefetchedSamples m_prefetch;
 	void* m_prefetch_event = nullptr;
 	void* m_counters_event = nullptr;

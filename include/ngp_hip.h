@@ -55,6 +55,12 @@ typedef struct {                                                     /* nerf_loa
 	const float* depth;       /* device or NULL */
 	const NgpRay* rays;       /* device or NULL */
 } NgpImageMeta;
+typedef struct {                                                     /* testbed.h:603-616 ErrorMap CDFs as the kernels take them (testbed_nerf.cu:3243-3245) */
+	const float* cdf_x_cond_y; /* device [n_images][res[1]][res[0]] or NULL (sample_focal_plane_proportional_to_error off) */
+	const float* cdf_y;        /* device [n_images][res[1]]         or NULL (same switch) */
+	const float* cdf_img;      /* device [n_images]                 or NULL (sample_image_proportional_to_error off) */
+	int32_t res[2];
+} NgpErrorMapCdf;
 typedef struct { float scale; uint32_t resolution; uint32_t offset; uint32_t size; } NgpGridLevel;
 typedef struct {                                                     /* tcnn GridEncoding geometry (HashGrid, F=2, 3-D) */
 	uint32_t n_levels;        /* must be 16 (configs/nerf/base.json:23-29) */
@@ -146,7 +152,15 @@ int ngp_hip_generate_training_samples(
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
-	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global);
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
+	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */);
+
+/* ============================ error-map CDFs (src/testbed_nerf.cu:1982-2037, 2971-3024) ============================ */
+/* construct_cdf_2d: per image and row, running sum of (error + 1e-10) over x, normalised and blended with MIN_PDF = 0.01 of uniform;
+ * cdf_y[img][y] receives the row totals.  construct_cdf_1d: the same over the row totals, cdf_img[img] receives the image total (the
+ * host turns those into the image CDF with MIN_PMF = 0.1, :3000-3015).  Both overwrite their outputs. */
+int ngp_hip_construct_cdf_2d(void* stream, uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y);
+int ngp_hip_construct_cdf_1d(void* stream, uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img);
 
 /* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================ */
 int ngp_hip_compute_loss(
@@ -157,7 +171,7 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance);
+	float near_distance, const NgpErrorMapCdf* cdf_host /* NULL: uniform; must be what ngp_hip_generate_training_samples got */);
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);

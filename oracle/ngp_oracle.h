@@ -42,14 +42,19 @@ void orc_update_bitfield(const float* grid, uint32_t n_cascades_used, float mean
 void orc_iterative_opencv_lens_undistortion(const float* params, float* u, float* v);
 void orc_get_xform_given_rolling_shutter(const orc_xform* xf, const float rs[4], float u, float v, float motionblur_time, float out[12]);
 void orc_read_rgba(const float xy[2], const int32_t res[2], const void* pixels, int type, float out[4]);
-void orc_nerf_random_image_pos_training(orc_pcg32* rng, const int32_t res[2], int snap_to_pixel_centers, float xy[2]);
+void orc_nerf_random_image_pos_training(orc_pcg32* rng, const int32_t res[2], int snap_to_pixel_centers, const orc_error_map_cdf* cdf, uint32_t img, float xy[2], float* pdf);
+uint32_t orc_image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_training_images, const float* cdf, float* pdf);
+uint32_t orc_binary_search(float val, const float* data, uint32_t length);
+void orc_construct_cdf_2d(uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y);
+void orc_construct_cdf_1d(uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img);
+void orc_image_cdf_host(uint32_t n_images, const float* pmf_unnormalized, float* pmf_out, float* cdf_out);
 void orc_generate_training_samples(
 	uint32_t n_rays, const orc_aabb* aabb, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, orc_ray* rays_out_unnormalized,
 	uint32_t* numsteps_out, orc_coord* coords_out, uint32_t n_training_images, const orc_image_meta* metadata,
 	const orc_xform* xforms, const uint8_t* density_grid, int max_level_rand_training, float* max_level_ptr,
 	int snap_to_pixel_centers, int train_envmap, float cone_angle_constant, const float* distortion_data,
-	const int32_t distortion_resolution[2], uint32_t ray_offset, uint32_t n_rays_global);
+	const int32_t distortion_resolution[2], uint32_t ray_offset, uint32_t n_rays_global, const orc_error_map_cdf* cdf /* NULL: uniform */);
 
 /* orc_network.c */
 void orc_net_make_levels(uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, orc_grid_level* levels, uint32_t* n_grid_entries);
@@ -90,7 +95,7 @@ void orc_compute_loss(
 	uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, uint32_t* numsteps_in,
 	const orc_coord* coords_in_all, orc_coord* coords_out_all, uint16_t* dloss_doutput_all, int loss_type, float* loss_output,
 	int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation, int snap_to_pixel_centers,
-	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance);
+	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);
 void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout);
 

@@ -454,4 +454,7 @@ static inline float orc_network_to_density_derivative(float val, int act) {
 #ifdef __cplusplus
 }
 #endif
+/* error-map CDFs (testbed_nerf.cu:3243-3245: each pointer may be NULL on its own) */
+typedef struct { const float* cdf_x_cond_y; const float* cdf_y; const float* cdf_img; int32_t res[2]; } orc_error_map_cdf;
+
 #endif

@@ -62,7 +62,7 @@ void orc_compute_loss(
 	orc_coord* coords_out_all, uint16_t* dloss_doutput_all /* [max_samples_compacted][mlp_stride] */, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
-	float near_distance) {
+	float near_distance, const orc_error_map_cdf* cdf) {
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		uint32_t numsteps = numsteps_in[i * 2 + 0];
 		uint32_t base = numsteps_in[i * 2 + 1];
@@ -95,10 +95,11 @@ void orc_compute_loss(
 		uint32_t ray_idx = ray_indices_in[i];
 		orc_pcg32 rng = {rng_state, rng_inc};
 		orc_pcg32_advance(&rng, (int64_t)((uint64_t)(uint32_t)(ray_idx * ORC_N_MAX_RANDOM_SAMPLES_PER_RAY)));
-		uint32_t img = ((ray_idx * n_training_images) / n_rays) % n_training_images;
+		float img_pdf = 1.0f, xy_pdf = 1.0f;
+		uint32_t img = orc_image_idx(ray_idx, n_rays, n_training_images, cdf ? cdf->cdf_img : NULL, &img_pdf);
 		const orc_image_meta* md = &metadata[img];
 		float xy[2];
-		orc_nerf_random_image_pos_training(&rng, md->res, snap_to_pixel_centers, xy);
+		orc_nerf_random_image_pos_training(&rng, md->res, snap_to_pixel_centers, cdf, img, xy, &xy_pdf);
 		float max_level = max_level_rand_training ? (orc_pcg32_next_float(&rng) * 2.0f) : 1.0f;
 
 		float background_color[3] = {background_color_in[0], background_color_in[1], background_color_in[2]};
@@ -143,7 +144,7 @@ void orc_compute_loss(
 		uint16_t* dloss_doutput = dloss_doutput_all + (size_t)compacted_base * mlp_stride;
 
 		orc_lg lg = orc_loss_and_gradient(rgbtarget, rgb_ray, loss_type);
-		/* img_pdf * xy_pdf == 1 without CDF sampling (1448) */
+		{ const float pdf = img_pdf * xy_pdf; for (int c = 0; c < 3; ++c) lg.loss[c] /= pdf; }   /* 1448; == 1 without CDF sampling */
 		float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
 		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
 

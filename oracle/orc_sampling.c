@@ -370,10 +370,44 @@ void orc_read_rgba(const float xy[2], const int32_t res[2], const void* pixels, 
 	}
 }
 
-/* testbed_nerf.cu:1047-1060 (no CDF: error-map sampling is default-off, testbed.h:668-669) */
-void orc_nerf_random_image_pos_training(orc_pcg32* rng, const int32_t res[2], int snap_to_pixel_centers, float xy[2]) {
+/* common.h:201-224 */
+uint32_t orc_binary_search(float val, const float* data, uint32_t length) {
+	if (length == 0) return 0;
+	uint32_t first = 0, count = length;
+	while (count > 0) {
+		uint32_t step = count / 2, it = first + step;
+		if (data[it] < val) { first = it + 1; count -= step + 1; }
+		else count = step;
+	}
+	return first < length - 1 ? first : length - 1;
+}
+
+/* testbed_nerf.cu:991-1022 sample_cdf_2d (UNIFORM_SAMPLING_FRACTION = 0.5) */
+static void orc_sample_cdf_2d(float xy[2], uint32_t img, const int32_t res[2], const float* cdf_x_cond_y, const float* cdf_y, float* pdf) {
+	const float UNIFORM = 0.5f;
+	if (xy[0] < UNIFORM) { xy[0] /= UNIFORM; return; }   /* the reference leaves *pdf untouched (1.0) on this branch */
+	xy[0] = (xy[0] - UNIFORM) / (1.0f - UNIFORM);
+	cdf_y += (size_t)img * res[1];
+	uint32_t y = orc_binary_search(xy[1], cdf_y, (uint32_t)res[1]);
+	float prev = y > 0 ? cdf_y[y - 1] : 0.0f;
+	float pmf_y = cdf_y[y] - prev;
+	xy[1] = (xy[1] - prev) / pmf_y;
+	cdf_x_cond_y += (size_t)img * res[1] * res[0] + (size_t)y * res[0];
+	uint32_t x = orc_binary_search(xy[0], cdf_x_cond_y, (uint32_t)res[0]);
+	prev = x > 0 ? cdf_x_cond_y[x - 1] : 0.0f;
+	float pmf_x = cdf_x_cond_y[x] - prev;
+	xy[0] = (xy[0] - prev) / pmf_x;
+	if (pdf) *pdf = pmf_x * pmf_y * (float)(res[0] * res[1]);
+	xy[0] = ((float)x + xy[0]) / (float)res[0];
+	xy[1] = ((float)y + xy[1]) / (float)res[1];
+}
+
+/* testbed_nerf.cu:1047-1060; cdf may be NULL (error-map sampling is default-off, testbed.h:668-669) */
+void orc_nerf_random_image_pos_training(orc_pcg32* rng, const int32_t res[2], int snap_to_pixel_centers, const orc_error_map_cdf* cdf, uint32_t img, float xy[2], float* pdf) {
 	xy[0] = orc_pcg32_next_float(rng);
 	xy[1] = orc_pcg32_next_float(rng);
+	if (pdf) *pdf = 1.0f;
+	if (cdf && cdf->cdf_x_cond_y) orc_sample_cdf_2d(xy, img, cdf->res, cdf->cdf_x_cond_y, cdf->cdf_y, pdf);
 	if (snap_to_pixel_centers) {
 		for (int k = 0; k < 2; ++k) {
 			int p = (int)(xy[k] * (float)res[k]);
@@ -383,9 +417,50 @@ void orc_nerf_random_image_pos_training(orc_pcg32* rng, const int32_t res[2], in
 	}
 }
 
-/* testbed_nerf.cu:1062-1083 (cdf == nullptr branch) */
-static inline uint32_t orc_image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_training_images) {
+/* testbed_nerf.cu:1062-1083 */
+uint32_t orc_image_idx(uint32_t base_idx, uint32_t n_rays, uint32_t n_training_images, const float* cdf, float* pdf) {
+	if (cdf) {
+		float sample = orc_ld_random_val(base_idx, 0xdeadbeefu, 0);
+		uint32_t img = orc_binary_search(sample, cdf, n_training_images);
+		if (pdf) { float prev = img > 0 ? cdf[img - 1] : 0.0f; *pdf = (cdf[img] - prev) * (float)n_training_images; }
+		return img;
+	}
+	if (pdf) *pdf = 1.0f;
 	return ((base_idx * n_training_images) / n_rays) % n_training_images;
+}
+
+/* testbed_nerf.cu:1982-2037 construct_cdf_2d / construct_cdf_1d (MIN_PDF = 0.01; __frcp_rn = correctly rounded 1/x) */
+void orc_construct_cdf_2d(uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y) {
+	const float MIN_PDF = 0.01f;
+	for (uint32_t img = 0; img < n_images; ++img) for (uint32_t y = 0; y < height; ++y) {
+		const size_t off = ((size_t)img * height + y) * width;
+		float cum = 0;
+		for (uint32_t x = 0; x < width; ++x) { cum += data[off + x] + 1e-10f; cdf_x_cond_y[off + x] = cum; }
+		cdf_y[(size_t)img * height + y] = cum;
+		const float norm = 1.0f / cum;
+		for (uint32_t x = 0; x < width; ++x) cdf_x_cond_y[off + x] = (1.0f - MIN_PDF) * cdf_x_cond_y[off + x] * norm + MIN_PDF * (float)(x + 1) / (float)width;
+	}
+}
+void orc_construct_cdf_1d(uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img) {
+	const float MIN_PDF = 0.01f;
+	for (uint32_t img = 0; img < n_images; ++img) {
+		float* c = cdf_y + (size_t)img * height;
+		float cum = 0;
+		for (uint32_t y = 0; y < height; ++y) { cum += c[y]; c[y] = cum; }
+		cdf_img[img] = cum;
+		const float norm = 1.0f / cum;
+		for (uint32_t y = 0; y < height; ++y) c[y] = (1.0f - MIN_PDF) * c[y] * norm + MIN_PDF * (float)(y + 1) / (float)height;
+	}
+}
+/* testbed_nerf.cu:3000-3015: host-side image CDF from the per-image sums (MIN_PMF = 0.1) */
+void orc_image_cdf_host(uint32_t n_images, const float* pmf_unnormalized, float* pmf_out, float* cdf_out) {
+	float cum = 0;
+	for (uint32_t i = 0; i < n_images; ++i) { cum += pmf_unnormalized[i]; cdf_out[i] = cum; }
+	const float norm = 1.0f / cum, MIN_PMF = 0.1f;
+	for (uint32_t i = 0; i < n_images; ++i) {
+		pmf_out[i] = (1.0f - MIN_PMF) * pmf_unnormalized[i] * norm + MIN_PMF / (float)n_images;
+		cdf_out[i] = (1.0f - MIN_PMF) * cdf_out[i] * norm + MIN_PMF * (float)(i + 1) / (float)n_images;
+	}
 }
 
 /* ------------------------------------------------------------------ */
@@ -403,15 +478,15 @@ void orc_generate_training_samples(
 	uint32_t* numsteps_out, orc_coord* coords_out, uint32_t n_training_images, const orc_image_meta* metadata,
 	const orc_xform* xforms, const uint8_t* density_grid, int max_level_rand_training, float* max_level_ptr,
 	int snap_to_pixel_centers, int train_envmap, float cone_angle_constant, const float* distortion_data,
-	const int32_t distortion_resolution[2], uint32_t ray_offset, uint32_t n_rays_global) {
+	const int32_t distortion_resolution[2], uint32_t ray_offset, uint32_t n_rays_global, const orc_error_map_cdf* cdf) {
 	for (uint32_t li = 0; li < n_rays; ++li) {
 		const uint32_t i = li + ray_offset;
-		uint32_t img = orc_image_idx(i, n_rays_global, n_training_images);
+		uint32_t img = orc_image_idx(i, n_rays_global, n_training_images, cdf ? cdf->cdf_img : NULL, NULL);
 		const orc_image_meta* md = &metadata[img];
 		orc_pcg32 rng = {rng_state, rng_inc};
 		orc_pcg32_advance(&rng, (int64_t)((uint64_t)(uint32_t)(i * ORC_N_MAX_RANDOM_SAMPLES_PER_RAY)));
 		float xy[2];
-		orc_nerf_random_image_pos_training(&rng, md->res, snap_to_pixel_centers, xy);
+		orc_nerf_random_image_pos_training(&rng, md->res, snap_to_pixel_centers, cdf, img, xy, NULL);
 
 		float texel[4];
 		orc_read_rgba(xy, md->res, md->pixels, md->image_data_type, texel);

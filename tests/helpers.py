@@ -191,3 +191,26 @@ def to_host(t, dtype, count=None):
     a = t.cpu().numpy().view(np.uint8)
     out = a.view(dtype)
     return out if count is None else out[:count]
+
+
+def make_error_map_cdfs(oracle, n_img, w, h, seed=7):
+    """random error map -> the three CDFs through the oracle (construct_cdf_2d / _1d + host image CDF).  Returns host arrays."""
+    rs = np.random.RandomState(seed)
+    em = (rs.rand(n_img, h, w) ** 4).astype(np.float32)
+    em[:, : h // 3] *= 20.0                        # make the distribution visibly non-uniform
+    em[0] *= 5.0
+    x = np.zeros((n_img, h, w), np.float32)
+    y = np.zeros((n_img, h), np.float32)
+    im = np.zeros(n_img, np.float32)
+    oracle.orc_construct_cdf_2d(n_img, h, w, em.ctypes.data, x.ctypes.data, y.ctypes.data)
+    oracle.orc_construct_cdf_1d(n_img, h, y.ctypes.data, im.ctypes.data)
+    pmf, cdf = np.zeros(n_img, np.float32), np.zeros(n_img, np.float32)
+    oracle.orc_image_cdf_host(n_img, im.ctypes.data, pmf.ctypes.data, cdf.ctypes.data)
+    return dict(em=em, x=x, y=y, img_sums=im, pmf=pmf, img=cdf, res=(w, h))
+
+
+def error_map_cdf_struct(x_ptr, y_ptr, img_ptr, res):
+    c = np.zeros(1, dtype=capi.ERROR_MAP_CDF)
+    c["cdf_x_cond_y"], c["cdf_y"], c["cdf_img"] = x_ptr or 0, y_ptr or 0, img_ptr or 0
+    c["res"][0] = res
+    return c

@@ -14,7 +14,7 @@ from test_sampling_gpu import _cameras
 pytestmark = pytest.mark.gpu
 
 
-def _inputs(oracle, cuda, n_rays=4096, seed=0, sigma_gain=3.0):
+def _inputs(oracle, cuda, n_rays=4096, seed=0, sigma_gain=3.0, cdf_mode=0):
     imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda)
     grid = H.blob_density_grid(1)
     bf, mean = H.oracle_bitfield(oracle, grid, 1)
@@ -24,16 +24,18 @@ def _inputs(oracle, cuda, n_rays=4096, seed=0, sigma_gain=3.0):
     r = dict(rc=np.zeros(1, np.uint32), nc=np.zeros(1, np.uint32), idx=np.zeros(n_rays, np.uint32), rays=np.zeros(n_rays, H.RAY),
              ns=np.zeros(n_rays * 2, np.uint32), co=np.zeros(max_samples, H.COORD))
     dres = np.array([32, 32], np.int32)
+    C = H.make_error_map_cdfs(oracle, len(xf), 20, 14) if cdf_mode else None
+    c_host = H.error_map_cdf_struct(C["x"].ctypes.data if cdf_mode & 1 else 0, C["y"].ctypes.data if cdf_mode & 1 else 0, C["img"].ctypes.data if cdf_mode & 2 else 0, C["res"]) if cdf_mode else None
     oracle.orc_generate_training_samples(n_rays, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data,
                                          r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, len(xf), md_host.ctypes.data, xf.ctypes.data,
-                                         bf.ctypes.data, 0, None, 0, 0, H.f32(0.0), None, dres.ctypes.data, 0, n_rays)
+                                         bf.ctypes.data, 0, None, 0, 0, H.f32(0.0), None, dres.ctypes.data, 0, n_rays, c_host.ctypes.data if cdf_mode else None)
     n_samples = int(r["nc"][0])
     rs = np.random.RandomState(seed)
     mlp = np.zeros((n_samples, 4), np.float16)
     mlp[:, :3] = rs.randn(n_samples, 3).astype(np.float16)
     mlp[:, 3] = (rs.randn(n_samples) * sigma_gain + 2.0).astype(np.float16)
     return dict(r=r, mlp=mlp, md_host=md_host, md_dev=md_dev, xf=xf, aabb=aabb, st=st, inc=inc, n_rays=n_rays, n_alive=int(r["rc"][0]), n_samples=n_samples,
-                mean=mean, keep=(imgs, d_imgs))
+                mean=mean, keep=(imgs, d_imgs), cdf_mode=cdf_mode, C=C, c_host=c_host)
 
 
 def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=0, rgb_act=2):
@@ -48,17 +50,22 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     oracle.orc_compute_loss(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
                             I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
-                            o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2))
+                            o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None)
     # ---- device
     d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
              em=H.dev_zeros(n_img * 16 * 12 * 4, cuda))
     d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
     d_md, d_mlp, d_idx, d_rays, d_co = (H.to_dev(a, cuda) for a in (I["md_dev"], I["mlp"], I["r"]["idx"], I["r"]["rays"], I["r"]["co"]))
     d_mean, d_exp = H.to_dev(np.array([I["mean"]], np.float32), cuda), H.to_dev(exposure, cuda)
+    c_dev = None
+    if I.get("cdf_mode"):
+        m, C = I["cdf_mode"], I["C"]
+        d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
+        c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if m & 1 else 0, d_cy.data_ptr() if m & 1 else 0, d_ci.data_ptr() if m & 2 else 0, C["res"])
     check(ngp.ngp_hip_compute_loss(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
-                                   d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2)))
+                                   d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None))
     g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
              loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32))
     return o, g
@@ -114,6 +121,29 @@ def test_loss_and_compaction_match_oracle(ngp, oracle, cuda, loss_type):
     np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(g["em"], o["em"], rtol=2e-3, atol=1e-6 * max(1.0, float(o["em"].max())))
     assert np.abs(o["dl"].astype(np.float32)).max() > 1e-4
+
+
+@pytest.mark.parametrize("cdf_mode", [1, 3])
+def test_loss_with_error_map_importance_sampling(ngp, oracle, cuda, cdf_mode):
+    """the loss kernel replays image_idx / nerf_random_image_pos_training with the CDFs and divides the reported loss (and the error-map
+    deposit) by img_pdf * xy_pdf, not the gradient (testbed_nerf.cu:1381-1386, 1448-1458)"""
+    I = _inputs(oracle, cuda, cdf_mode=cdf_mode)
+    B = I["n_samples"] + 128
+    o, g = _run(ngp, oracle, cuda, I, 0, B)
+    border = _borderline_rays(I)
+    keep = np.array([i for i in range(I["n_alive"]) if i not in border])
+    np.testing.assert_array_equal(o["ns"].reshape(-1, 2)[keep, 0], g["ns"].reshape(-1, 2)[keep, 0])
+    np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(g["em"], o["em"], rtol=2e-3, atol=1e-6 * max(1.0, float(o["em"].max())))
+    for i in keep[:400]:
+        n, bo, bg_ = int(o["ns"][2 * i]), int(o["ns"][2 * i + 1]), int(g["ns"][2 * i + 1])
+        if n:
+            # same summation-order noise as in test_loss_and_compaction_match_oracle (a cancelling suffix sum), other rays: atol 1e-5
+            np.testing.assert_allclose(g["dl"][bg_:bg_ + n].astype(np.float32), o["dl"][bo:bo + n].astype(np.float32), rtol=4e-3, atol=1e-5)
+    # the weighting is really there: the same rays without the CDFs report different losses
+    I0 = dict(I); I0["cdf_mode"] = 0
+    o0 = _run(ngp, oracle, cuda, I0, 0, B)[0]
+    assert not np.allclose(o0["loss"][keep], o["loss"][keep], rtol=1e-3)
 
 
 @pytest.mark.parametrize("color_space,linear,random_bg,rgb_act", [(1, 0, 0, 2), (0, 1, 1, 3), (1, 1, 0, 0)])

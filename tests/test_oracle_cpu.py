@@ -157,7 +157,7 @@ def test_marching_constants_and_helpers(oracle):
                  co=np.zeros(max_samples, H.COORD))
         oracle.orc_generate_training_samples(n_rays, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data, r["rays"].ctypes.data,
                                              r["ns"].ctypes.data, r["co"].ctypes.data, 2, md.ctypes.data, xf.ctypes.data, bitfield.ctypes.data, 0, None, 0, 0, H.f32(0.0), None,
-                                             dres.ctypes.data, 0, n_rays)
+                                             dres.ctypes.data, 0, n_rays, None)
         return r
 
     empty = run(np.zeros(128 ** 3, np.uint8))

@@ -99,7 +99,7 @@ def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):
 
 
 def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_mode=0, lens_params=None, snap=0, max_samples=None,
-                       ray_offset=0, n_rays_global=0, distortion=False):
+                       ray_offset=0, n_rays_global=0, distortion=False, cdf_mode=0):
     imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, lens_mode=lens_mode, lens_params=lens_params, radius=1.3 * 2 ** (n_cascades - 1))
     grid = H.blob_density_grid(n_cascades)
     bf, _ = H.oracle_bitfield(oracle, grid, n_cascades)
@@ -109,19 +109,26 @@ def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_m
     dist = np.zeros((32, 32, 2), np.float32) if distortion else None
     dres = np.array([32, 32], np.int32)
     nrg = n_rays_global or n_rays
+    # error-map importance sampling (off by default): bit 0 = pixel CDFs, bit 1 = image CDF
+    C = H.make_error_map_cdfs(oracle, len(xf), 20, 14) if cdf_mode else None
+    c_host = H.error_map_cdf_struct(C["x"].ctypes.data if cdf_mode & 1 else 0, C["y"].ctypes.data if cdf_mode & 1 else 0, C["img"].ctypes.data if cdf_mode & 2 else 0, C["res"]) if cdf_mode else None
 
     r = dict(rc=np.zeros(1, np.uint32), nc=np.zeros(1, np.uint32), idx=np.zeros(n_rays, np.uint32), rays=np.zeros(n_rays, H.RAY),
              ns=np.zeros(n_rays * 2, np.uint32), co=np.zeros(max_samples, H.COORD))
     oracle.orc_generate_training_samples(n_rays, aabb.ctypes.data, max_samples, st, inc, r["rc"].ctypes.data, r["nc"].ctypes.data, r["idx"].ctypes.data,
                                          r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, len(xf), md_host.ctypes.data, xf.ctypes.data,
-                                         bf.ctypes.data, 0, None, snap, 0, H.f32(cone_angle), H.ptr(dist) if distortion else None, dres.ctypes.data, ray_offset, nrg)
+                                         bf.ctypes.data, 0, None, snap, 0, H.f32(cone_angle), H.ptr(dist) if distortion else None, dres.ctypes.data, ray_offset, nrg,
+                                         c_host.ctypes.data if cdf_mode else None)
     d = dict(rc=H.dev_zeros(4, cuda), nc=H.dev_zeros(4, cuda), idx=H.dev_zeros(n_rays * 4, cuda), rays=H.dev_zeros(n_rays * 24, cuda),
              ns=H.dev_zeros(n_rays * 8, cuda), co=H.dev_zeros(max_samples * 28, cuda))
     d_md, d_xf, d_bf = H.to_dev(md_dev, cuda), H.to_dev(xf, cuda), H.to_dev(bf, cuda)
     d_dist = H.to_dev(dist, cuda) if distortion else None
+    if cdf_mode:
+        d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
+        c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if cdf_mode & 1 else 0, d_cy.data_ptr() if cdf_mode & 1 else 0, d_ci.data_ptr() if cdf_mode & 2 else 0, C["res"])
     check(ngp.ngp_hip_generate_training_samples(None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
                                                 d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
-                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg))
+                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None))
     g = dict(rc=H.to_host(d["rc"], np.uint32), nc=H.to_host(d["nc"], np.uint32), idx=H.to_host(d["idx"], np.uint32), rays=H.to_host(d["rays"], H.RAY),
              ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD))
     return r, g
@@ -159,6 +166,32 @@ def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda):
 def test_training_samples_bit_exact_cascaded_cone(ngp, oracle, cuda):
     r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=3, cone_angle=1.0 / 256.0, snap=1)
     _compare_per_ray(r, g)
+
+
+@pytest.mark.parametrize("cdf_mode", [1, 2, 3])
+def test_training_samples_error_map_importance_sampling(ngp, oracle, cuda, cdf_mode):
+    """sample_focal_plane_proportional_to_error / sample_image_proportional_to_error (testbed_nerf.cu:991-1083): same rays, bit for bit"""
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, snap=cdf_mode == 3, cdf_mode=cdf_mode)
+    _compare_per_ray(r, g)
+    # ... and they are not the uniform rays
+    r0, _ = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, snap=cdf_mode == 3)
+    assert r0["rays"].tobytes() != r["rays"].tobytes()
+
+
+def test_error_map_cdf_construction_bit_exact(ngp, oracle, cuda):
+    """construct_cdf_2d / construct_cdf_1d (testbed_nerf.cu:1982-2037): sequential fp32 running sums, same order -> same bits"""
+    n_img, w, h = 7, 37, 23
+    C = H.make_error_map_cdfs(oracle, n_img, w, h)
+    d_em = H.to_dev(C["em"], cuda)
+    d_x, d_y, d_i = H.dev_zeros(n_img * h * w * 4, cuda), H.dev_zeros(n_img * h * 4, cuda), H.dev_zeros(n_img * 4, cuda)
+    check(ngp.ngp_hip_construct_cdf_2d(None, n_img, h, w, d_em.data_ptr(), d_x.data_ptr(), d_y.data_ptr()))
+    check(ngp.ngp_hip_construct_cdf_1d(None, n_img, h, d_y.data_ptr(), d_i.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_x, np.float32).reshape(n_img, h, w), C["x"])
+    np.testing.assert_array_equal(H.to_host(d_y, np.float32).reshape(n_img, h), C["y"])
+    np.testing.assert_array_equal(H.to_host(d_i, np.float32), C["img_sums"])
+    # CDFs end at 1 and increase
+    assert np.allclose(C["x"][:, :, -1], 1.0, atol=1e-5) and np.allclose(C["y"][:, -1], 1.0, atol=1e-5) and abs(C["img"][-1] - 1.0) < 1e-5
+    assert (np.diff(C["x"], axis=2) > 0).all() and (np.diff(C["y"], axis=1) > 0).all() and (np.diff(C["img"]) > 0).all()
 
 
 def test_training_samples_opencv_lens(ngp, oracle, cuda):
