@@ -47,6 +47,7 @@ struct LossArgs {
 	int loss_type; float* loss_output; int max_level_rand_training; float* max_level_compacted; int rgb_activation; int density_activation;
 	int snap_to_pixel_centers; float* error_map; int32_t error_map_res[2]; const float* mean_density; const float* exposure; float near_distance;
 	ErrorMapCdf cdf;
+	const uint16_t* encoded_in; uint16_t* encoded_out;   // optional: [sample][32] fp16 encoding rows carried through the compaction
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -222,6 +223,12 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		if (valid) {
 			const NgpCoord cin = ci[j];
 			co[j] = cin;
+			if (a.encoded_in) {
+				const uint4* src = (const uint4*)(a.encoded_in + (size_t)(base + j) * 32);
+				uint4* dst = (uint4*)(a.encoded_out + (size_t)(compacted_base + j) * 32);
+				const uint4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+				dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+			}
 			if (a.max_level_rand_training) a.max_level_compacted[compacted_base + j] = max_level;
 			const v3 pos = unwarp_position(mk(cin.pos[0], cin.pos[1], cin.pos[2]), a.aabb);
 			depth = norm(pos - ray_o);
@@ -465,8 +472,9 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host) {
+	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out) {
 	if (!n_rays) return 0;
+	if ((encoded_in == nullptr) != (encoded_out == nullptr)) { set_last_error("ngp_hip_compute_loss: encoded_in and encoded_out go together", hipErrorInvalidValue); return -1; }
 	if ((mlp_stride & 3) || (dl_stride & 3)) { set_last_error("ngp_hip_compute_loss: strides must be multiples of 4 halves", hipErrorInvalidValue); return -1; }
 	LossArgs a;
 	a.n_rays = n_rays; a.aabb = aabb_from_host(aabb_host); a.rng.state = rng_state; a.rng.inc = rng_inc; a.max_samples_compacted = max_samples_compacted;
@@ -477,7 +485,7 @@ int ngp_hip_compute_loss(
 	a.ray_indices_in = ray_indices_in; a.rays_in = rays_in_unnormalized; a.numsteps_in = numsteps_in; a.coords_in = coords_in; a.coords_out = coords_out;
 	a.dloss_doutput = dloss_doutput; a.dl_stride = dl_stride; a.loss_type = loss_type; a.loss_output = loss_output;
 	a.max_level_rand_training = max_level_rand_training; a.max_level_compacted = max_level_compacted; a.rgb_activation = rgb_activation;
-	a.cdf = make_error_map_cdf(cdf_host);
+	a.cdf = make_error_map_cdf(cdf_host); a.encoded_in = encoded_in; a.encoded_out = encoded_out;
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;

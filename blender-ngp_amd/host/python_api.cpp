@@ -322,6 +322,7 @@ PYBIND11_MODULE(pyngp, m) {
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
 		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
+		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
 		.def("training_prep_nerf", &Testbed::training_prep_nerf, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size") = 0)
 		.def("local_loss_sum", &Testbed::local_loss_sum)

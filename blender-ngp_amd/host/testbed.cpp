@@ -673,9 +673,12 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 2 * m_gen_slot;
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	const uint32_t n_rays_global = R * m_world_size;
-	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256)
+	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256).  The pass also stores every sample's encoding
+	// (64 B): the loss kernel carries the rows of the kept samples through the compaction, which replaces the reference's second network
+	// pass over the compacted batch (3330) — its only product that backward consumes is that encoding (ngp_hip.h "Forward pass").
+	m_x_all.enlarge((size_t)max_inference * 32 * 2);
 	profile_begin(PK_INFERENCE);
-	check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference");
+	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
 	profile_end(PK_INFERENCE, max_inference);
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
@@ -685,10 +688,11 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
-	                           tr.error_map_cdf(cdf_storage)), "compute_loss");
+	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>()), "compute_loss");
 	profile_end(PK_LOSS, R);
 	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
 	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
+	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 16, c.numsteps_counter_compacted.as<uint32_t>(), m_x_saved.as<float>()), "fill_rollover(encoding)");
 	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
 	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
@@ -705,10 +709,13 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	check(ngp_hip_gather_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, nullptr, (uint32_t*)m_host_words), "gather_words");
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 
-	// ---- train_nerf_step, second half (3324-3332): forward on the compacted batch, backward (gradients overwrite)
-	profile_begin(PK_FORWARD);
-	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
-	profile_end(PK_FORWARD, target_batch_size);
+	// ---- train_nerf_step, second half (3324-3332): backward on the compacted batch (gradients overwrite).  The reference's forward over
+	// the compacted batch is the encoding that arrived with the compaction above; m_separate_forward restores the second pass (same bits).
+	if (m_separate_forward) {
+		profile_begin(PK_FORWARD);
+		check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
+		profile_end(PK_FORWARD, target_batch_size);
+	}
 	profile_begin(PK_BACKWARD);
 	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");

@@ -262,6 +262,7 @@ public:
 	std::thread m_render_thread;                       // request_nerf_render_async worker (joined before the next request / on destruction)
 	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
+	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
 	uint64_t m_prefetch_hits = 0;
 	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
 	float local_loss_sum();
@@ -365,6 +366,7 @@ private:
 	void drop_prefetch();
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
 	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
+	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
 	DeviceBuffer m_distortion_map;  // 32x32x2 zeros: passed unconditionally to the ray generator

@@ -162,7 +162,13 @@ int ngp_hip_generate_training_samples(
 int ngp_hip_construct_cdf_2d(void* stream, uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y);
 int ngp_hip_construct_cdf_1d(void* stream, uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img);
 
-/* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================ */
+/* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================
+ * Forward pass.  The reference runs inference on all samples (:3256), compacts, then runs m_network->forward on the compacted batch
+ * (:3330) only to rebuild the activations backward needs; the network outputs of that second pass are never read.  ngp_hip_nerf_backward
+ * recomputes the MLPs from the saved encoding, so all it needs from "forward" is x_saved — a pure function of the sample position.  A
+ * host may therefore run ngp_hip_nerf_forward instead of ngp_hip_nerf_inference on the uncompacted samples and let ngp_hip_compute_loss
+ * carry each kept sample's 64-byte encoding row along with its coordinates (encoded_in / encoded_out), then roll it over like the
+ * coordinates (ngp_hip_fill_rollover_f32 with stride 16): same bits as the second pass would produce, one gather pass less. */
 int ngp_hip_compute_loss(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
 	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
@@ -171,7 +177,9 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host /* NULL: uniform; must be what ngp_hip_generate_training_samples got */);
+	float near_distance, const NgpErrorMapCdf* cdf_host /* NULL: uniform; must be what ngp_hip_generate_training_samples got */,
+	const uint16_t* encoded_in, uint16_t* encoded_out /* both NULL, or: row i of encoded_in ([n_samples][32] fp16, the x_saved that
+	ngp_hip_nerf_forward wrote for coords_in) is copied next to coords_out — see "forward pass" below */);
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);

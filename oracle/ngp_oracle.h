@@ -95,7 +95,8 @@ void orc_compute_loss(
 	uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, uint32_t* numsteps_in,
 	const orc_coord* coords_in_all, orc_coord* coords_out_all, uint16_t* dloss_doutput_all, int loss_type, float* loss_output,
 	int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation, int snap_to_pixel_centers,
-	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */);
+	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */,
+	const uint16_t* encoded_in, uint16_t* encoded_out /* optional [sample][32] fp16 rows carried through the compaction */);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);
 void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout);
 

@@ -62,7 +62,7 @@ void orc_compute_loss(
 	orc_coord* coords_out_all, uint16_t* dloss_doutput_all /* [max_samples_compacted][mlp_stride] */, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
-	float near_distance, const orc_error_map_cdf* cdf) {
+	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out) {
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		uint32_t numsteps = numsteps_in[i * 2 + 0];
 		uint32_t base = numsteps_in[i * 2 + 1];
@@ -174,6 +174,7 @@ void orc_compute_loss(
 		for (uint32_t j = 0; j < compacted_numsteps; ++j) {
 			if (max_level_rand_training && max_level_compacted_ptr) max_level_compacted_ptr[j] = max_level;
 			coords_out[j] = coords_in[j];
+			if (encoded_in) memcpy(encoded_out + ((size_t)compacted_base + j) * 32, encoded_in + ((size_t)base + j) * 32, 64);   /* see ngp_hip.h "Forward pass" */
 			const orc_coord* ci = &coords_in[j];
 			orc_vec3 pos = orc_unwarp_position(orc_v3(ci->pos[0], ci->pos[1], ci->pos[2]), aabb);
 			float depth = orc_norm(orc_sub(pos, ray_o));

@@ -46,14 +46,16 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     exposure = np.zeros((n_img, 3), np.float32)
     # ---- oracle
     o = dict(cnt=np.zeros(1, np.uint32), ns=I["r"]["ns"].copy(), co=np.zeros(B, H.COORD), dl=np.zeros((B, 4), np.float16), loss=np.zeros(n_rays, np.float32),
-             em=np.zeros(n_img * 16 * 12, np.float32))
+             em=np.zeros(n_img * 16 * 12, np.float32), enc=np.zeros((B, 32), np.uint16))
     oracle.orc_compute_loss(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
                             I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
-                            o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None)
+                            o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None,
+                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None)
     # ---- device
     d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
-             em=H.dev_zeros(n_img * 16 * 12 * 4, cuda))
+             em=H.dev_zeros(n_img * 16 * 12 * 4, cuda), enc=H.dev_zeros(B * 64, cuda))
+    d_enc_in = H.to_dev(I["enc"], cuda) if "enc" in I else None
     d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
     d_md, d_mlp, d_idx, d_rays, d_co = (H.to_dev(a, cuda) for a in (I["md_dev"], I["mlp"], I["r"]["idx"], I["r"]["rays"], I["r"]["co"]))
     d_mean, d_exp = H.to_dev(np.array([I["mean"]], np.float32), cuda), H.to_dev(exposure, cuda)
@@ -65,9 +67,10 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     check(ngp.ngp_hip_compute_loss(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
-                                   d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None))
+                                   d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None,
+                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None))
     g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
-             loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32))
+             loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"])
     return o, g
 
 
@@ -121,6 +124,43 @@ def test_loss_and_compaction_match_oracle(ngp, oracle, cuda, loss_type):
     np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(g["em"], o["em"], rtol=2e-3, atol=1e-6 * max(1.0, float(o["em"].max())))
     assert np.abs(o["dl"].astype(np.float32)).max() > 1e-4
+
+
+def test_compaction_carries_the_saved_encoding(ngp, oracle, cuda):
+    """ngp_hip.h "Forward pass": the encoding rows that ngp_hip_nerf_forward wrote for the uncompacted samples, carried through the
+    compaction, are bit for bit what a second ngp_hip_nerf_forward over the compacted coordinates writes (testbed_nerf.cu:3330)."""
+    I = _inputs(oracle, cuda)
+    n_s = I["n_samples"]
+    n_pad = (n_s + 255) // 256 * 256
+    desc = H.make_desc(ngp, 19)
+    P = H.random_params(desc, 3, grid_amp=1.0)
+    d_desc, d_P = H.to_dev(desc, cuda), H.to_dev(P, cuda)
+    co_pad = np.zeros(n_pad, H.COORD); co_pad[:n_s] = I["r"]["co"][:n_s]
+    d_co = H.to_dev(co_pad, cuda)
+    out, xs = H.dev_zeros(n_pad * 8, cuda), H.dev_zeros(n_pad * 64, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_co.data_ptr(), 7, n_pad, out.data_ptr(), 4, xs.data_ptr()))
+    I["enc"] = H.to_host(xs, np.uint16).reshape(n_pad, 32)
+    B = n_pad + 256
+    o, g = _run(ngp, oracle, cuda, I, 0, B)
+    n_c = int(g["cnt"][0])
+    assert 0 < n_c < n_s
+    # device: carried rows == second pass over the compacted coordinates
+    n_c_pad = (n_c + 255) // 256 * 256
+    out2, xs2 = H.dev_zeros(n_c_pad * 8, cuda), H.dev_zeros(n_c_pad * 64, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), g["d_co"].data_ptr(), 7, n_c_pad, out2.data_ptr(), 4, xs2.data_ptr()))
+    np.testing.assert_array_equal(g["enc"][:n_c], H.to_host(xs2, np.uint16).reshape(n_c_pad, 32)[:n_c])
+    assert (g["enc"][:n_c] != 0).any()
+    # oracle: the same rows, ray by ray (slot order differs between the two)
+    border = _borderline_rays(I)
+    for i in range(I["n_alive"]):
+        n, bo, bg_ = int(o["ns"][2 * i]), int(o["ns"][2 * i + 1]), int(g["ns"][2 * i + 1])
+        if i in border or n == 0 or n != int(g["ns"][2 * i]):
+            continue
+        np.testing.assert_array_equal(g["enc"][bg_:bg_ + n], o["enc"][bo:bo + n])
+    # the two pointers go together
+    assert ngp.ngp_hip_compute_loss(None, 1, I["aabb"].ctypes.data, 0, 1, 256, out.data_ptr(), H.f32(128.0), 4, np.zeros(3, np.float32).ctypes.data, 0, 0, 0, 1, out.data_ptr(),
+                                    out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), 4, 0, None, 0, None,
+                                    2, 3, 0, None, None, out.data_ptr(), out.data_ptr(), H.f32(0.2), None, xs.data_ptr(), None) != 0
 
 
 @pytest.mark.parametrize("cdf_mode", [1, 3])
