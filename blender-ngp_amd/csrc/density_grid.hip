@@ -186,6 +186,21 @@ __global__ void gather_words_kernel(const uint32_t* a, const uint32_t* b, const 
 	}
 }
 
+__global__ void post_words_kernel(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst, uint32_t* zero2) {
+	if (threadIdx.x == 0) {
+		dst[0] = a ? *a : 0u; dst[1] = b ? *b : 0u; dst[2] = c ? *c : 0u;
+		if (zero2) { zero2[0] = 0u; zero2[1] = 0u; }
+		__threadfence_system();
+		__hip_atomic_store(&dst[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2) {
+	hipLaunchKernelGGL(post_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, tag, dst4, zero2);
+	NGP_LAUNCH_CHECK("post_words_kernel");
+	return 0;
+}
+
 int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst4) {
 	hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, d, dst4);
 	NGP_LAUNCH_CHECK("gather_words_kernel");

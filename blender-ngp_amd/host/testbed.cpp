@@ -582,7 +582,8 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	m_ray_indices.enlarge(r_cap * 4); m_rays.enlarge(r_cap * sizeof(NgpRay)); m_numsteps.enlarge(r_cap * 8);
 	m_gen_counters.enlarge(16);
 	uint32_t* counters = m_gen_counters.as<uint32_t>() + 2 * slot;  // [0] ray counter, [1] numsteps counter
-	HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
+	if (m_next_slot_zeroed == slot) m_next_slot_zeroed = -1;   // cleared by the previous step's post_words launch
+	else HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
 	const int32_t dist_res[2] = {32, 32};
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
 	NgpErrorMapCdf cdf_storage;
@@ -690,9 +691,6 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
 	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>()), "compute_loss");
 	profile_end(PK_LOSS, R);
-	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
-	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
-	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 16, c.numsteps_counter_compacted.as<uint32_t>(), m_x_saved.as<float>()), "fill_rollover(encoding)");
 	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
 	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
@@ -706,8 +704,17 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		HIP_CHECK_THROW(hipHostMalloc(&m_host_words, 16, hipHostMallocMapped | hipHostMallocCoherent));
 		hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_counters_event = e;
 	}
-	check(ngp_hip_gather_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, nullptr, (uint32_t*)m_host_words), "gather_words");
+	// the same launch clears the other slot's march counters: its last reader (the previous step's loss kernel) is long done, and the
+	// march that will bump them is launched after the host has seen this step's counters
+	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
+	m_next_slot_zeroed = m_gen_slot ^ 1;
+	check(ngp_hip_post_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
+	                         m_gen_counters.as<uint32_t>() + 2 * (m_gen_slot ^ 1)), "post_words");
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
+	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
+	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
+	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
+	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 16, c.numsteps_counter_compacted.as<uint32_t>(), m_x_saved.as<float>()), "fill_rollover(encoding)");
 
 	// ---- train_nerf_step, second half (3324-3332): backward on the compacted batch (gradients overwrite).  The reference's forward over
 	// the compacted batch is the encoding that arrived with the compaction above; m_separate_forward restores the second pass (same bits).
@@ -722,8 +729,18 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
 
-	HIP_CHECK_THROW(hipEventSynchronize((hipEvent_t)m_counters_event));
+	// poll the host-mapped words (a couple of microseconds after the kernel's store; an event wake-up costs 10-20); the event is the fallback
 	const volatile uint32_t* w = (const volatile uint32_t*)m_host_words;
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		uint32_t spins = 0;
+		while (__atomic_load_n((const uint32_t*)&w[3], __ATOMIC_ACQUIRE) != m_post_tag) {
+			if ((++spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+				HIP_CHECK_THROW(hipEventSynchronize((hipEvent_t)m_counters_event));   // also surfaces a failed kernel instead of spinning forever
+				break;
+			}
+		}
+	}
 	counters_out[0] = w[0]; counters_out[1] = w[1];
 	uint32_t bits = w[2];
 	memcpy(&m_local_loss_sum, &bits, 4);

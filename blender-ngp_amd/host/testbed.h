@@ -357,6 +357,8 @@ private:
 	void* m_host_words = nullptr;                      // 4 pinned, device-mapped words: {numsteps, numsteps_compacted, loss sum, -}
 	float m_local_loss_sum = 0.f;
 	int m_gen_slot = 0;
+	int m_next_slot_zeroed = -1;                       // slot whose march counters the last post_words launch cleared
+	uint32_t m_post_tag = 0;
 	uint64_t m_state_version = 0;
 	bool m_train_continues = true;
 	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter}

@@ -189,6 +189,10 @@ int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out
  * 32-bit device words (NULL -> 0) into dst4[0..3] in stream order; dst4 may be device memory or host-mapped pinned memory, so the
  * host can pick the step's counters up from an event instead of draining the stream. */
 int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst4);
+/* Same for a host that POLLS host-mapped memory instead of waiting on an event: dst4[0..2] = *a, *b, *c (NULL -> 0), then — after a
+ * system-scope fence — dst4[3] = tag, so a reader that sees the tag sees the three words.  zero2 (optional) gets two words cleared in
+ * the same launch (the next march's counters, which would otherwise cost a memset on the counter -> march chain). */
+int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2);
 
 /* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
