@@ -37,27 +37,77 @@ class CudaArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+class ShmCounters:
+    """all-reduce (sum) of three numbers per step between the ranks of ONE node through POSIX shared memory: every rank owns a 64-byte
+    slot per step parity, writes {values, step tag} and spins until all slots carry the tag.  A rank can be at most one step ahead of
+    the slowest one (it needs everybody's values to proceed), so two parities are enough."""
+    def __init__(self, rank, world, key):
+        from multiprocessing import shared_memory
+        import numpy as np
+        self.rank, self.world, self.np = rank, world, np
+        name = "ngp_dp_%s" % key
+        size = 2 * world * 64
+        if rank == 0:
+            try:
+                old = shared_memory.SharedMemory(name=name)
+                old.close(); old.unlink()
+            except FileNotFoundError:
+                pass
+            self.mem = shared_memory.SharedMemory(name=name, create=True, size=size)
+            self.mem.buf[:size] = bytes(size)
+        self.name, self.size = name, size
+
+    def attach(self):   # after a barrier that follows rank 0's constructor
+        from multiprocessing import shared_memory
+        if self.rank != 0:
+            self.mem = shared_memory.SharedMemory(name=self.name)
+        self.a = self.np.ndarray((2, self.world, 8), dtype=self.np.float64, buffer=self.mem.buf)
+
+    def all_sum(self, step, v0, v1, v2):
+        a = self.a[step & 1]
+        mine = a[self.rank]
+        mine[0], mine[1], mine[2] = v0, v1, v2
+        mine[3] = float(step + 1)           # tag last (x86 stores are not reordered with older stores)
+        tags = a[:, 3]
+        want = float(step + 1)
+        t0 = time.perf_counter()
+        while not (tags == want).all():
+            if time.perf_counter() - t0 > 60.0:
+                raise RuntimeError("shared-memory counter exchange timed out at step %d (tags %s)" % (step, tags.tolist()))
+        return float(a[:, 0].sum()), float(a[:, 1].sum()), float(a[:, 2].sum())
+
+    def close(self):
+        self.a = None
+        self.mem.close()
+        if self.rank == 0:
+            self.mem.unlink()
+
+
 class DpState:
-    """per-rank buffers of the data-parallel step: the gradient view, a 3-word scratch tensor and the stream the collectives are
-    ordered on (the Testbed's own HIP stream wrapped as a torch ExternalStream; None on CPU / gloo)"""
-    def __init__(self, torch, grads, device, comm_stream=None, ctl_group=None, ctl_stream=None):
+    """per-rank buffers of the data-parallel step: the gradient view (split into its MLP and hash-grid parts), a 3-double scratch
+    tensor for the counter exchange and the streams the collectives are ordered on.  On CPU / gloo (tests) everything is None and the
+    exchanges are plain blocking all-reduces."""
+    def __init__(self, torch, grads, device, train_stream=None, ctl_group=None, ctl_stream=None, grid_stream=None, n_mlp=0):
         self.grads = grads
+        self.n_mlp = n_mlp
         self.ctl_group = ctl_group     # process group of the 24-byte counter exchange (high-priority RCCL stream on GPU)
-        self.ctl_stream = ctl_stream   # high-priority torch stream for its H2D / D2H copies
+        self.ctl_stream = ctl_stream   # high-priority torch stream the exchange is ordered on
+        self.grid_stream = grid_stream # side stream of the hash-grid gradient all-reduce (starts while the MLP weight gradients are computed)
         self.scratch = torch.zeros(3, dtype=torch.float64, device=device)
         self.host = torch.zeros(3, dtype=torch.float64)
-        if torch.device(device).type == "cuda":
+        self.on_gpu = torch.device(device).type == "cuda"
+        # counter exchange: "shm" (single node: host shared memory, microseconds), "device" (RCCL, stream-ordered), "host" (RCCL after a host hop)
+        self.ctl_mode = os.environ.get("BENCH_DP_CTL", "shm")
+        # "1": all-reduce the hash-grid gradients on a side stream while the MLP weight gradients are computed.  Measured on one rank the
+        # cross-stream event hops cost more (~90 us) than the overlap can win back (~85 us), so it is off by default
+        self.bucketed = os.environ.get("BENCH_DP_BUCKET", "0") == "1"
+        self.shm = None
+        if self.on_gpu:
             self.host = self.host.pin_memory()
-        self.comm_stream = comm_stream
+            self.ctl_done = torch.cuda.Event()
+            self.grid_done = torch.cuda.Event()
+        self.train_stream = train_stream   # the Testbed's own HIP stream as a torch ExternalStream
         self._torch = torch
-
-    def on_comm_stream(self):
-        import contextlib
-        return self._torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else contextlib.nullcontext()
-
-    def on_ctl_stream(self):
-        import contextlib
-        return self._torch.cuda.stream(self.ctl_stream) if self.ctl_stream is not None else contextlib.nullcontext()
 
 
 def make_dp_state(torch, dist, tb, grads, dev):
@@ -65,7 +115,16 @@ def make_dp_state(torch, dist, tb, grads, dev):
     opts.is_high_priority_stream = True
     ctl_group = dist.new_group(backend="nccl", pg_options=opts)
     ctl_stream = torch.cuda.Stream(device=dev, priority=-1)
-    return DpState(torch, grads, dev, torch.cuda.ExternalStream(tb.stream_ptr(), device=dev), ctl_group, ctl_stream)
+    st = DpState(torch, grads, dev, torch.cuda.ExternalStream(tb.stream_ptr(), device=dev), ctl_group, ctl_stream, torch.cuda.Stream(device=dev), int(tb.n_mlp_params))
+    tb.set_dp_counter_buffer(st.scratch.data_ptr())   # every step's post kernel leaves {samples, compacted samples, loss sum} there
+    world, rank = dist.get_world_size(), dist.get_rank()
+    single_node = int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world
+    if st.ctl_mode == "shm" and single_node:
+        st.shm = ShmCounters(rank, world, os.environ.get("MASTER_PORT", "0"))
+        dist.barrier()
+        st.shm.attach()
+        dist.barrier()
+    return st
 
 
 def dp_step(tb, torch, dist, B, st):
@@ -76,17 +135,50 @@ def dp_step(tb, torch, dist, B, st):
     if step % n_prep_to_skip == 0:
         tb.training_prep_nerf(B)  # replicated: same params + same rng on every rank => bit-identical grids, no collective
     get_loss = step % 16 == 0
-    c0, c1 = tb.train_nerf_dp_begin(B, get_loss)   # returns once the loss kernel ran; forward / backward are already queued
-    st.host[0], st.host[1], st.host[2] = c0, c1, (tb.local_loss_sum() if get_loss else 0.0)
-    with st.on_ctl_stream():
-        # 24 bytes on high-priority streams so that it is not queued behind backward: every rank derives the same rays_per_batch
-        st.scratch.copy_(st.host, non_blocking=True)
-        dist.all_reduce(st.scratch, group=st.ctl_group)
-        st.host.copy_(st.scratch)
+    if st.on_gpu and st.ctl_mode == "shm" and st.shm is not None:
+        # single node: the host polls its own counters (host-mapped memory) and the ranks exchange them through shared memory
+        c0, c1 = tb.train_nerf_dp_begin(B, get_loss)
+        n0, n1, loss_sum = st.shm.all_sum(step, c0, c1, tb.local_loss_sum() if get_loss else 0.0)
+        st.host[0], st.host[1], st.host[2] = n0, n1, loss_sum
+    elif st.on_gpu and st.ctl_mode == "device":
+        # the whole step is queued; the counters land in st.scratch (device) in stream order.  24 bytes are all-reduced on
+        # high-priority streams right behind the loss kernel (not behind backward), one host wait for the summed values
+        tb.train_nerf_dp_begin(B, get_loss, False)
+        tb.stream_wait_counters(st.ctl_stream.cuda_stream)
+        with torch.cuda.stream(st.ctl_stream):
+            dist.all_reduce(st.scratch, group=st.ctl_group)
+            st.host.copy_(st.scratch, non_blocking=True)
+            st.ctl_done.record()
+        st.ctl_done.synchronize()
+        c1 = 0
+    elif st.on_gpu:
+        c0, c1 = tb.train_nerf_dp_begin(B, get_loss)   # returns once the loss kernel ran; backward is already queued
+        st.host[0], st.host[1], st.host[2] = c0, c1, (tb.local_loss_sum() if get_loss else 0.0)
+        with torch.cuda.stream(st.ctl_stream):
+            st.scratch.copy_(st.host, non_blocking=True)
+            dist.all_reduce(st.scratch, group=st.ctl_group)
+            st.host.copy_(st.scratch)
+    else:
+        c0, c1 = tb.train_nerf_dp_begin(B, get_loss)
+        st.host[0], st.host[1], st.host[2] = c0, c1, (tb.local_loss_sum() if get_loss else 0.0)
+        dist.all_reduce(st.host, group=st.ctl_group)
     n0, n1, loss_sum = st.host.tolist()
     tb.train_nerf_dp_backward(B, int(n0), int(n1), get_loss, float(loss_sum))   # feedback + next step's march on stream B
-    with st.on_comm_stream():
-        # RCCL over xGMI, fp16 sum of the loss-scaled gradients (24.4 MB for lego), stream-ordered: after backward, before Adam
+    if st.on_gpu and st.bucketed:
+        # RCCL over xGMI, fp16 sums of the loss-scaled gradients.  The hash-grid part (24 MB for lego) is final before the MLP weight
+        # gradients are computed: its all-reduce starts there on a side stream; the 20 KB MLP part follows on the training stream,
+        # which then waits for the side stream — both are complete before Adam
+        tb.stream_wait_grid_gradients(st.grid_stream.cuda_stream)
+        with torch.cuda.stream(st.grid_stream):
+            dist.all_reduce(st.grads[st.n_mlp:])
+            st.grid_done.record()
+        with torch.cuda.stream(st.train_stream):
+            dist.all_reduce(st.grads[:st.n_mlp])
+            st.train_stream.wait_event(st.grid_done)
+    elif st.on_gpu:
+        with torch.cuda.stream(st.train_stream):
+            dist.all_reduce(st.grads)
+    else:
         dist.all_reduce(st.grads)
     tb.train_nerf_dp_end()
     return c1
@@ -205,6 +297,8 @@ def main():
     if rank != 0:
         if use_dp:
             dist.barrier()
+            if dp.shm is not None:
+                dp.shm.close()
             dist.destroy_process_group()
         return
 
@@ -257,6 +351,8 @@ def main():
     print(json.dumps(line), flush=True)
     if use_dp:
         dist.barrier()
+        if dp.shm is not None:
+            dp.shm.close()
         dist.destroy_process_group()
 
 

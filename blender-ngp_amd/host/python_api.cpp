@@ -316,8 +316,12 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("reset_accumulation", [](Testbed& t) { t.m_windowless_render_surface.reset_accumulation(); })
 		// data-parallel extension
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
-		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss); } return py::make_tuple(c[0], c[1]); },
-			py::arg("batch_size"), py::arg("get_loss_scalar") = false)
+		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss, bool wait) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss, wait); } return py::make_tuple(c[0], c[1]); },
+			py::arg("batch_size"), py::arg("get_loss_scalar") = false, py::arg("wait_for_counters") = true)
+		.def("set_dp_counter_buffer", [](Testbed& t, uintptr_t p) { t.set_dp_counter_buffer((void*)p); })                 // 3 doubles on the device
+		.def("stream_wait_counters", [](Testbed& t, uintptr_t stream) { t.stream_wait_counters((void*)stream); })         // hipStreamWaitEvent(stream, counters posted)
+		.def("stream_wait_grid_gradients", [](Testbed& t, uintptr_t stream) { t.stream_wait_grid_gradients((void*)stream); })
+		.def_property_readonly("n_mlp_params", [](Testbed& t) { return t.m_n_matrix_params; })   // the gradient vector is [MLP | grid]
 		.def("train_nerf_dp_backward", &Testbed::train_nerf_dp_backward, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
 		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())

@@ -620,7 +620,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	m_prefetch = p;
 }
 
-void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar) {
+void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar, bool wait_for_counters) {
 	NerfTraining& tr = m_nerf.training;
 	NerfCounters& c = tr.counters_rgb;
 	if (target_batch_size % 256) throw std::runtime_error{"training batch size must be a multiple of 256"};
@@ -709,7 +709,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
 	m_next_slot_zeroed = m_gen_slot ^ 1;
 	check(ngp_hip_post_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
-	                         m_gen_counters.as<uint32_t>() + 2 * (m_gen_slot ^ 1)), "post_words");
+	                         m_gen_counters.as<uint32_t>() + 2 * (m_gen_slot ^ 1), (double*)m_dp_counters_dev), "post_words");
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
 	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
@@ -724,11 +724,13 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		profile_end(PK_FORWARD, target_batch_size);
 	}
 	profile_begin(PK_BACKWARD);
-	check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes()), "nerf_backward");
+	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_grid_grad_event = e; }
+	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_grid_grad_event), "nerf_backward");
 	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
 
+	if (!wait_for_counters) { counters_out[0] = counters_out[1] = 0; return; }   // the caller reduces m_dp_counters_dev in stream order instead
 	// poll the host-mapped words (a couple of microseconds after the kernel's store; an event wake-up costs 10-20); the event is the fallback
 	const volatile uint32_t* w = (const volatile uint32_t*)m_host_words;
 	{
@@ -744,6 +746,15 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	counters_out[0] = w[0]; counters_out[1] = w[1];
 	uint32_t bits = w[2];
 	memcpy(&m_local_loss_sum, &bits, 4);
+}
+
+void Testbed::stream_wait_counters(void* other_stream) {
+	if (!m_counters_event) throw std::runtime_error{"stream_wait_counters: no step has been begun"};
+	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_counters_event, 0));
+}
+void Testbed::stream_wait_grid_gradients(void* other_stream) {
+	if (!m_grid_grad_event) throw std::runtime_error{"stream_wait_grid_gradients: no step has been begun"};
+	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_grid_grad_event, 0));
 }
 
 float Testbed::local_loss_sum() { return m_local_loss_sum; }  // of the step begun last, if it was begun with get_loss_scalar

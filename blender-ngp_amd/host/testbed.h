@@ -221,7 +221,12 @@ public:
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
 	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)
 	//      -> [all-reduce gradients] -> end (optimizer, bookkeeping)
-	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar = false);
+	void train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_out[2], bool get_loss_scalar = false, bool wait_for_counters = true);
+	// data-parallel hooks: a device buffer of 3 doubles that receives {samples, compacted samples, loss sum} of every step begun (the
+	// operand of the host's counter all-reduce), and stream-order waits on "counters posted" / "grid gradients final"
+	void set_dp_counter_buffer(void* three_doubles_dev) { m_dp_counters_dev = three_doubles_dev; }
+	void stream_wait_counters(void* other_stream);
+	void stream_wait_grid_gradients(void* other_stream);
 	void train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global_measured_before, uint32_t global_measured, bool get_loss_scalar, float global_loss_sum);
 	void train_nerf_dp_end();
 	void invalidate_training_inputs();
@@ -359,6 +364,8 @@ private:
 	int m_gen_slot = 0;
 	int m_next_slot_zeroed = -1;                       // slot whose march counters the last post_words launch cleared
 	uint32_t m_post_tag = 0;
+	void* m_dp_counters_dev = nullptr;
+	void* m_grid_grad_event = nullptr;
 	uint64_t m_state_version = 0;
 	bool m_train_continues = true;
 	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter}

@@ -123,6 +123,12 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes);
+/* Same; additionally records `grid_gradients_event` (a hipEvent_t, may be NULL) on the stream once the hash-grid part of `grads`
+ * (everything behind the first 10240 MLP parameters) is final — the MLP weight gradients follow.  A data-parallel host starts the
+ * all-reduce of the 24 MB grid slice on another stream at that point instead of after the whole call. */
+int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                             uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event);
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */
@@ -192,7 +198,8 @@ int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, con
 /* Same for a host that POLLS host-mapped memory instead of waiting on an event: dst4[0..2] = *a, *b, *c (NULL -> 0), then — after a
  * system-scope fence — dst4[3] = tag, so a reader that sees the tag sees the three words.  zero2 (optional) gets two words cleared in
  * the same launch (the next march's counters, which would otherwise cost a memset on the counter -> march chain). */
-int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2);
+int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2,
+                       double* sum3_dev /* optional DEVICE copy {(double)*a, (double)*b, (double)(float)*c}: the operand of a data-parallel host's counter all-reduce */);
 
 /* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,

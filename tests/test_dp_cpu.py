@@ -176,3 +176,26 @@ def test_dp_step_control_flow(tmp_path):
         assert bwd[4] == (1.0 if s % 16 == 0 else 0.0)
         assert g == [3.0] * 8                                          # gradient buffer was all-reduced in place
         assert calls.index("begin") < len(calls) - 2
+
+
+def _shm_worker(rank, world, port):
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT]
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = bench.ShmCounters(rank, world, "t%d" % port)
+    dist.barrier()
+    s.attach()
+    dist.barrier()
+    for step in range(300):
+        got = s.all_sum(step, rank + step, 10 * rank, 0.5)
+        assert got == (sum(k + step for k in range(world)), 10.0 * sum(range(world)), 0.5 * world), (step, got)
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+def test_shared_memory_counter_exchange():
+    """bench.ShmCounters: the single-node counter all-reduce of the data-parallel step (two ranks, 300 back-to-back steps)"""
+    import torch.multiprocessing as mp
+    mp.spawn(_shm_worker, args=(2, _free_port()), nprocs=2, join=True)
