@@ -234,3 +234,27 @@ def test_reduce_sum(ngp, cuda):
         d_o, d_x = H.dev_zeros(4, cuda), H.to_dev(x, cuda)
         check(ngp.ngp_hip_reduce_sum_f32(None, d_x.data_ptr(), n, d_o.data_ptr()))
         assert abs(float(H.to_host(d_o, np.float32)[0]) - float(x.astype(np.float64).sum())) <= 1e-5 * n
+
+
+def test_counter_posting_kernels(ngp, cuda):
+    """ngp_hip_gather_words / ngp_hip_post_words: the step's counters leave the device in stream order (pinned host memory in the
+    Testbed; plain device memory here), tag last, optional clears and the double-precision copy for a data-parallel all-reduce"""
+    import torch
+    a = torch.tensor([123456], dtype=torch.int32, device=cuda)
+    b = torch.tensor([7890], dtype=torch.int32, device=cuda)
+    c = torch.tensor([0.375], dtype=torch.float32, device=cuda)
+    dst = torch.full((4,), -1, dtype=torch.int32, device=cuda)
+    check(ngp.ngp_hip_gather_words(None, a.data_ptr(), b.data_ptr(), None, c.data_ptr(), dst.data_ptr()))
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == [123456, 7890, 0, int(np.float32(0.375).view(np.int32))]
+    dst.fill_(-1)
+    z = torch.tensor([5, 6, 7], dtype=torch.int32, device=cuda)
+    s3 = torch.zeros(3, dtype=torch.float64, device=cuda)
+    check(ngp.ngp_hip_post_words(None, a.data_ptr(), b.data_ptr(), c.data_ptr(), 42, dst.data_ptr(), z.data_ptr(), s3.data_ptr()))
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == [123456, 7890, int(np.float32(0.375).view(np.int32)), 42]
+    assert z.cpu().tolist() == [0, 0, 7]
+    assert s3.cpu().tolist() == [123456.0, 7890.0, 0.375]
+    check(ngp.ngp_hip_post_words(None, None, None, None, 43, dst.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == [0, 0, 0, 43]
