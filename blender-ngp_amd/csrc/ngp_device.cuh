@@ -248,9 +248,14 @@ __device__ __forceinline__ float distance_to_next_voxel(v3 pos, v3 dir, v3 idir,
 	// r is a power of two (128 >> mip): its reciprocal is exact and built from the exponent bits; t * (1/r) == t / r bit for bit
 	return fmaxf(t * __uint_as_float(0x7f000000u - __float_as_uint(r)), 0.0f);
 }
+// CONST_DT: cone_angle == 0 (aabb_scale 1), where calc_dt(t, 0) = clamp(t * 0, MIN, MAX) is MIN_CONE_STEPSIZE for every finite t — the same
+// value without the three instructions per step
+template <bool CONST_DT>
+__device__ __forceinline__ float calc_dt_t(float t, float cone_angle) { return CONST_DT ? MIN_CONE_STEPSIZE() : calc_dt(t, cone_angle); }
+template <bool CONST_DT = false>
 __device__ __forceinline__ float advance_to_next_voxel(float t, float cone_angle, v3 pos, v3 dir, v3 idir, uint32_t res) {
 	float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
-	do { t += calc_dt(t, cone_angle); } while (t < t_target);
+	do { t += calc_dt_t<CONST_DT>(t, cone_angle); } while (t < t_target);
 	return t;
 }
 __device__ __forceinline__ float warp_dt(float dt) {

@@ -24,6 +24,7 @@ struct TrainSampleArgs {
 	int dev_variant; // dev-only timing variants (NGP_HIP_GEN_VARIANT): 0 product path, 2 no sample writes, 3 no march
 };
 
+template <bool CONST_DT>
 __global__ void __launch_bounds__(256) generate_training_samples_kernel(const TrainSampleArgs a) {
 	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
 	const bool in_range = li < a.n_rays;
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 			float run_t0 = 0.f;
 			OccBrick occ;
 			while (aabb_contains(a.aabb, pos = ro + rd * t) && j < NGP_NERF_STEPS) {
-				const float dt = calc_dt(t, cone_angle);
+				const float dt = calc_dt_t<CONST_DT>(t, cone_angle);
 				const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 				if (density_grid_occupied_at(pos, a.density_grid, mip, occ)) {
 					if (run_len == 0) run_t0 = t;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 						++n_runs;
 						run_len = 0;
 					}
-					t = advance_to_next_voxel(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+					t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
 				}
 			}
 			if (run_len) {
@@ -191,7 +192,9 @@ __global__ void __launch_bounds__(256) expand_training_samples_kernel(const Trai
 			float t_chunk = s_t[w][r];
 			for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
 				float t = t_chunk;
-				for (uint32_t k = 0; k < lane; ++k) t += calc_dt(t, cone_angle);
+				// lane k replays k additions; lanes past the end of the run replay none (runs are short: the wave loops max(k) times)
+				const uint32_t n_add = c0 + lane < cnt ? lane : 0u;
+				for (uint32_t k = 0; k < n_add; ++k) t += calc_dt(t, cone_angle);
 				const float dt = calc_dt(t, cone_angle);
 				if (c0 + lane < cnt) {
 					const v3 wp = aabb_relative_pos(a.aabb, ro + rd * t);
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256) expand_training_samples_kernel(const Trai
 					c.dir[0] = warped_dir.x; c.dir[1] = warped_dir.y; c.dir[2] = warped_dir.z;
 					co[j0 + c0 + lane] = c;
 				}
-				t_chunk = __shfl(t + dt, 63, 64);
+				t_chunk = __shfl(t + dt, 63, 64);   // only read when the run continues, i.e. when lane 63 was inside it
 			}
 			j0 += cnt;
 		}
@@ -255,7 +258,8 @@ extern "C" int ngp_hip_generate_training_samples(
 	a.ray_offset = ray_offset; a.n_rays_global = n_rays_global ? n_rays_global : n_rays;
 	const char* var = getenv("NGP_HIP_GEN_VARIANT");
 	a.dev_variant = var ? atoi(var) : 0;
-	hipLaunchKernelGGL(generate_training_samples_kernel, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_training_samples_kernel<true>, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL(generate_training_samples_kernel<false>, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("generate_training_samples_kernel");
 	if (a.dev_variant != 2) {
 		hipLaunchKernelGGL(expand_training_samples_kernel, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, a);
