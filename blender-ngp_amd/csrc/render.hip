@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	a.payloads[idx] = p;
 }
 
+template <bool CONST_DT>   // cone_angle == 0: see calc_dt_t
 __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
                                    const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -82,11 +83,11 @@ __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 
 	while (1) {
 		pos = origin + dir * t;
 		if (!aabb_contains(render_aabb, mat3_mul(to_local.m, pos))) { payload.alive = 0; break; }
-		dt = calc_dt(t, cone_angle);
+		dt = calc_dt_t<CONST_DT>(t, cone_angle);
 		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		mip = mip < min_mip ? min_mip : mip;
 		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
-		t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+		t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 	}
 	payload.t = t;
 }
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(256) compact_rays_kernel(uint32_t n_elements, 
 	}
 }
 
+template <bool CONST_DT>
 __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aabb, Aabb train_aabb, NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input,
                                             uint32_t n_steps, const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
@@ -142,11 +144,11 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 		while (1) {
 			pos = origin + dir * t;
 			if (!aabb_contains(render_aabb, pos)) { payload.n_steps = (uint16_t)j; return; }
-			dt = calc_dt(t, cone_angle);
+			dt = calc_dt_t<CONST_DT>(t, cone_angle);
 			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 			mip = mip < min_mip ? min_mip : mip;
 			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
-			t = advance_to_next_voxel(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+			t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
 		const v3 wp = aabb_relative_pos(train_aabb, pos);
 		NgpCoord c;
@@ -304,7 +306,8 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host, uint32_t sample_index,
                         NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
 	if (!n_elements) return 0;
-	hipLaunchKernelGGL(advance_pos_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
+	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
 	NGP_LAUNCH_CHECK("advance_pos_kernel");
 	return 0;
 }
@@ -321,7 +324,8 @@ int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgb
 int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host, NgpPayload* payloads, NgpCoord* network_input,
                                  uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
 	if (!n_elements) return 0;
-	hipLaunchKernelGGL(generate_next_inputs_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_next_inputs_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
+	else hipLaunchKernelGGL(generate_next_inputs_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
 	NGP_LAUNCH_CHECK("generate_next_inputs_kernel");
 	return 0;
 }
