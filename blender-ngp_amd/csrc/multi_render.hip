@@ -143,25 +143,6 @@ __device__ __forceinline__ bool mask_intersects_ray(const NgpMask3D& m, v3 ro, v
 }
 
 // ---- camera_models.cuh
-__device__ __forceinline__ void square2disk_shirley(float a, float b, float& ox, float& oy) {  // random_val.cuh:109-125
-	const float PI = 3.14159265358979323846f;
-	float phi, r;
-	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
-	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
-	ox = r * cosf(phi); oy = r * sinf(phi);
-}
-__device__ __forceinline__ void apply_aperture(uint32_t spp, uint32_t px, uint32_t py, const float* cam, float aperture_size, float focus_z, v3& origin, v3& dir) {
-	if (aperture_size > 0.0f) {
-		const v3 lookat = origin + dir * focus_z;
-		const uint32_t seed = px * 19349663u + py * 96925573u;
-		const float r0 = ld_random_val(spp, seed, 0) * 2.0f - 1.0f, r1 = ld_random_val(spp, seed, 1) * 2.0f - 1.0f;
-		float bx, by;
-		square2disk_shirley(r0, r1, bx, by);
-		bx *= aperture_size; by *= aperture_size;
-		origin = origin + mk(cam[0] * bx + cam[3] * by, cam[1] * bx + cam[4] * by, cam[2] * bx + cam[5] * by);
-		dir = mk((lookat.x - origin.x) / focus_z, (lookat.y - origin.y) / focus_z, (lookat.z - origin.z) / focus_z);
-	}
-}
 __device__ __forceinline__ v3 lerp3(const float* a, const float* b, float t) { return mk(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])); }
 
 __global__ void __launch_bounds__(128) init_global_rays_kernel(uint32_t sample_index, NgpGlobalRay* __restrict__ rays, float* __restrict__ depthbuffer, const NgpDownsampleInfo ds, const NgpRenderCamera cam) {

@@ -127,6 +127,27 @@ __device__ __forceinline__ void ld_random_pixel_offset(uint32_t spp, float& ox, 
 	oy = 0.5f - a1 + b1; oy = oy - floorf(oy);
 }
 
+// ---- depth of field (shared by the stock renderer and the Blender camera models)
+__device__ __forceinline__ void square2disk_shirley(float a, float b, float& ox, float& oy) {  // random_val.cuh:109-125
+	const float PI = 3.14159265358979323846f;
+	float phi, r;
+	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
+	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
+	ox = r * cosf(phi); oy = r * sinf(phi);
+}
+__device__ __forceinline__ void apply_aperture(uint32_t spp, uint32_t px, uint32_t py, const float* cam, float aperture_size, float focus_z, v3& origin, v3& dir) {
+	if (aperture_size > 0.0f) {
+		const v3 lookat = origin + dir * focus_z;
+		const uint32_t seed = px * 19349663u + py * 96925573u;
+		const float r0 = ld_random_val(spp, seed, 0) * 2.0f - 1.0f, r1 = ld_random_val(spp, seed, 1) * 2.0f - 1.0f;
+		float bx, by;
+		square2disk_shirley(r0, r1, bx, by);
+		bx *= aperture_size; by *= aperture_size;
+		origin = origin + mk(cam[0] * bx + cam[3] * by, cam[1] * bx + cam[4] * by, cam[2] * bx + cam[5] * by);
+		dir = mk((lookat.x - origin.x) / focus_z, (lookat.y - origin.y) / focus_z, (lookat.z - origin.z) / focus_z);
+	}
+}
+
 // ---- error-map importance sampling (testbed_nerf.cu:991-1083; off by default, testbed.h:668-669)
 struct ErrorMapCdf { const float* cdf_x_cond_y; const float* cdf_y; const float* cdf_img; int32_t res[2]; };
 // common.h:201-224

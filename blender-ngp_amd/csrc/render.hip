@@ -1,7 +1,7 @@
 // render.hip — single-NeRF renderer kernels (Testbed::NerfTracer) + frame accumulate / tonemap for gfx950.
 // Replaces src/testbed_nerf.cu:612-664 (advance_pos_nerf), 705-765 (generate_next_nerf_network_inputs), 767-989
 // (composite_kernel_nerf; Shade mode, no masks / glow), 1748-1781 (shade_kernel_nerf), 1784-1807 (compact_kernel_nerf),
-// 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective / OpenCV / FTheta / LatLong lenses) and src/render_buffer.cu:235-272, 274-348, 540-567.
+// 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective / OpenCV / FTheta / LatLong lenses, rolling shutter, depth of field, slice plane) and src/render_buffer.cu:235-272, 274-348, 540-567.
 // Compaction uses wave64 ballots: one atomic per wave per counter instead of one per ray.
 #include "ngp_device.cuh"
 
@@ -10,7 +10,7 @@ namespace ngp {
 struct InitRaysArgs {
 	uint32_t sample_index; NgpPayload* payloads; int32_t res[2]; float focal_length[2]; Mat34 cam0, cam1; float rolling_shutter[4];
 	float screen_center[2]; float parallax_shift[3]; int snap_to_pixel_centers; Aabb render_aabb; Mat33 to_local; float near_distance;
-	int lens_mode; float lens_params[7]; float* depthbuffer;
+	int lens_mode; float lens_params[7]; float* depthbuffer; float plane_z, aperture_size;
 };
 
 __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 #pragma unroll
 	for (int k = 0; k < 12; ++k) cam[k] = a.cam0.m[k] * ray_time + a.cam1.m[k] * (1.f - ray_time);
 
-	// pixel_to_ray (common_device.cuh:260-317), aperture_size == 0, no distortion grid
+	// pixel_to_ray (common_device.cuh:260-317), no distortion grid
+	const float aperture_size = a.plane_z < 0 ? 0.0f : a.aperture_size;   // 1849-1851
 	float ox, oy;
 	ld_random_pixel_offset(a.snap_to_pixel_centers ? 0 : a.sample_index, ox, oy);
 	const float pu = ((float)x + ox) / (float)a.res[0], pv = ((float)y + oy) / (float)a.res[1];
@@ -45,11 +46,22 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 		dir = dir - head_pos * a.parallax_shift[2];
 		dir = mat3_mul(cam, dir);
 		origin = mat3_mul(cam, head_pos) + col(cam, 3);
+		apply_aperture(a.sample_index, x, y, cam, aperture_size, a.plane_z, origin, dir);   // depth of field (307-312)
 		origin = origin + dir * a.near_distance;
 	}
 
 	NgpPayload p = a.payloads[idx];
 	p.max_weight = 0.0f;
+	if (a.plane_z < 0) {   // slice plane (1913-1923): the ray stops at depth -plane_z along the view axis
+		const float n = norm(dir);
+		const v3 dn = dir * (1.0f / n);
+		p.origin[0] = origin.x; p.origin[1] = origin.y; p.origin[2] = origin.z;
+		p.dir[0] = dn.x; p.dir[1] = dn.y; p.dir[2] = dn.z;
+		p.t = -a.plane_z * n; p.idx = idx; p.n_steps = 0; p.alive = 0;
+		a.depthbuffer[idx] = -a.plane_z;
+		a.payloads[idx] = p;
+		return;
+	}
 	a.depthbuffer[idx] = 1e10f;
 	dir = normalized(dir);
 	float tmin, tmax;
@@ -284,8 +296,10 @@ extern "C" {
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
-                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer) {
+                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
+                      float plane_z, float aperture_size) {
 	InitRaysArgs a;
+	a.plane_z = plane_z; a.aperture_size = aperture_size;
 	a.sample_index = sample_index; a.payloads = payloads; a.res[0] = res_host[0]; a.res[1] = res_host[1];
 	a.focal_length[0] = focal_length_host[0]; a.focal_length[1] = focal_length_host[1];
 	a.cam0 = mat34_from_host(camera_matrix0_host); a.cam1 = mat34_from_host(camera_matrix1_host);

@@ -325,6 +325,12 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("train_nerf_dp_backward", &Testbed::train_nerf_dp_backward, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
 		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())
+		.def_readwrite("slice_plane_z", &Testbed::m_slice_plane_z)          // python_api.cu:662-666
+		.def_readwrite("dof", &Testbed::m_aperture_size)
+		.def_readwrite("aperture_size", &Testbed::m_aperture_size)
+		.def_readwrite("autofocus", &Testbed::m_autofocus)
+		.def_property("autofocus_target", [](Testbed& t) { py::array_t<float> a(3); for (int i = 0; i < 3; ++i) a.mutable_data()[i] = t.m_autofocus_target[i]; return a; },
+			[](Testbed& t, const std::vector<float>& v) { if (v.size() != 3) throw std::runtime_error{"autofocus_target takes 3 floats"}; for (int i = 0; i < 3; ++i) t.m_autofocus_target[i] = v[i]; })
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
 		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)

@@ -852,12 +852,23 @@ std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool l
 	rb.resize(width, height);
 	rb.reset_accumulation();
 	m_render_samples_evaluated = 0;
+	if (m_autofocus) autofocus();   // python_api.cu:174-176
 	auto start = std::chrono::steady_clock::now();
 	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, rb, !linear);
 	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	std::vector<float> out((size_t)width * height * 4);
 	rb.surface.copy_to_host(out.data(), out.size() * 4);
 	return out;
+}
+
+void Testbed::autofocus() {  // testbed.cu:2933-2941: focus on m_autofocus_target
+	const float* c = m_camera.m;   // column-major 3x4: view dir = column 2, position = column 3
+	const float d = c[6] * (m_autofocus_target[0] - c[9]) + c[7] * (m_autofocus_target[1] - c[10]) + c[8] * (m_autofocus_target[2] - c[11]);
+	const float new_slice_plane_z = std::max(d, 0.1f) - m_scale;
+	if (new_slice_plane_z != m_slice_plane_z) {
+		m_slice_plane_z = new_slice_plane_z;
+		if (m_aperture_size != 0.0f) m_windowless_render_surface.reset_accumulation();
+	}
 }
 
 void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb) {  // testbed.cu:2695-2911
@@ -901,7 +912,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
 	const uint32_t sample_index = rb.spp;
 	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, zero4, screen_center, zero3, m_snap_to_pixel_centers,
-	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>()), "init_rays");
+	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
+	                        m_slice_plane_z + m_scale /* plane_z (2355); the Slice render mode, which negates it, is not built */, m_aperture_size), "init_rays");
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_rgba[0].data(), 0, (size_t)n_pixels * 16, (hipStream_t)m_stream));
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;

@@ -307,6 +307,11 @@ public:
 	float m_exposure = 0.f;
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
+	float m_aperture_size = 0.0f;                      // depth of field: radius of the lens disk (testbed.h m_aperture_size; python `dof` / `aperture_size`)
+	float m_slice_plane_z = 0.0f;                      // focus distance is m_slice_plane_z + m_scale (testbed_nerf.cu:2355)
+	bool m_autofocus = false;
+	float m_autofocus_target[3] = {0.5f, 0.5f, 0.5f};
+	void autofocus();                                  // testbed.cu:2933-2941
 	Mat34 m_camera;
 	bool m_camera_smoothing = false, m_loop_animation = false, m_dynamic_res = false;   // GUI-side state kept for script compatibility
 	Vec3 m_up_dir{0.f, 1.f, 0.f};

@@ -206,7 +206,7 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
                       const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host,
-                      float* depthbuffer);                                                                                     /* :1809 */
+                      float* depthbuffer, float plane_z /* focus distance; < 0: slice plane at -plane_z */, float aperture_size /* 0: pinhole */);   /* :1809 */
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
                         uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant); /* :612 */
 int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,

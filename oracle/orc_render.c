@@ -9,10 +9,19 @@
 #include "ngp_oracle.h"
 #include <stdlib.h>
 
-/* common_device.cuh:260-317 pixel_to_ray (aperture_size == 0, no distortion grid) */
+/* random_val.cuh:109-125 */
+static void orc_square2disk_shirley(float a, float b, float* ox, float* oy) {
+	const float PI = 3.14159265358979323846f;
+	float phi, r;
+	if (a * a > b * b) { r = a; phi = (PI / 4.0f) * (b / a); }
+	else { r = b; phi = (PI / 2.0f) - (PI / 4.0f) * (a / b); }
+	*ox = r * cosf(phi); *oy = r * sinf(phi);
+}
+
+/* common_device.cuh:260-317 pixel_to_ray (no distortion grid) */
 static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[2], const float focal_length[2], const float* cam /* 3x4 */,
                                 const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, float near_distance,
-                                int lens_mode, const float* lens_params) {
+                                int lens_mode, const float* lens_params, float focus_z, float aperture_size) {
 	float offset[2];
 	orc_ld_random_pixel_offset(snap_to_pixel_centers ? 0 : spp, offset);
 	float u = ((float)px + offset[0]) / (float)res[0];
@@ -34,17 +43,27 @@ static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[
 	dir = orc_sub(dir, orc_scale(head_pos, parallax_shift[2]));
 	dir = orc_mat3_mul(cam, dir);
 	orc_vec3 origin = orc_add(orc_mat3_mul(cam, head_pos), orc_col(cam, 3));
+	if (aperture_size > 0.0f) {   /* depth of field (:307-312): jitter the origin on the lens disk, keep the point at focus_z fixed */
+		orc_vec3 lookat = orc_add(origin, orc_scale(dir, focus_z));
+		float rv[2], bx, by;
+		orc_ld_random_val_2d(spp, (uint32_t)px * 19349663u + (uint32_t)py * 96925573u, rv);
+		orc_square2disk_shirley(rv[0] * 2.0f - 1.0f, rv[1] * 2.0f - 1.0f, &bx, &by);
+		bx *= aperture_size; by *= aperture_size;
+		origin = orc_add(origin, orc_v3(cam[0] * bx + cam[3] * by, cam[1] * bx + cam[4] * by, cam[2] * bx + cam[5] * by));
+		dir = orc_v3((lookat.x - origin.x) / focus_z, (lookat.y - origin.y) / focus_z, (lookat.z - origin.z) / focus_z);
+	}
 	origin = orc_add(origin, orc_scale(dir, near_distance));
 	orc_ray r = {origin, dir};
 	return r;
 }
 
-/* testbed_nerf.cu:1809-1978 init_rays_with_payload_kernel_nerf, Perspective camera, plane_z >= 0 path, no masks / envmap,
+/* testbed_nerf.cu:1809-1978 init_rays_with_payload_kernel_nerf, Perspective camera model, no masks / envmap / quilting,
  * render_aabb_to_local = identity-or-given 3x3 (column-major). */
 void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2],
                    const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2],
                    const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local /* 3x3 */,
-                   float near_distance, int lens_mode, const float* lens_params, float* depthbuffer) {
+                   float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size) {
+	if (plane_z < 0) aperture_size = 0.0f;   /* :1849-1851 */
 	for (int y = 0; y < res[1]; ++y) for (int x = 0; x < res[0]; ++x) {
 		uint32_t idx = (uint32_t)x + (uint32_t)res[0] * (uint32_t)y;
 		float u = ((float)x + 0.5f) * (1.f / (float)res[0]);
@@ -52,10 +71,21 @@ void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t r
 		float ray_time = rolling_shutter[0] + rolling_shutter[1] * u + rolling_shutter[2] * v + rolling_shutter[3] * orc_ld_random_val(sample_index, idx * 72239731u, 0);
 		float cam[12];
 		for (int k = 0; k < 12; ++k) cam[k] = camera_matrix0[k] * ray_time + camera_matrix1[k] * (1.f - ray_time);
-		orc_ray ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params);
+		orc_ray ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params, plane_z, aperture_size);
 
 		orc_payload* p = &payloads[idx];
 		p->max_weight = 0.0f;
+		if (plane_z < 0) {   /* slice plane (:1913-1923): the ray stops at depth -plane_z along the view axis */
+			float n = orc_norm(ray.d);
+			p->origin = ray.o;
+			p->dir = orc_scale(ray.d, 1.0f / n);
+			p->t = -plane_z * n;
+			p->idx = idx;
+			p->n_steps = 0;
+			p->alive = 0;
+			depthbuffer[idx] = -plane_z;
+			continue;
+		}
 		depthbuffer[idx] = 1e10f;
 		ray.d = orc_normalized(ray.d);
 		orc_vec3 lo = orc_mat3_mul(render_aabb_to_local, ray.o), ld = orc_mat3_mul(render_aabb_to_local, ray.d);
@@ -304,7 +334,7 @@ uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, u
 	uint16_t* net_out = (uint16_t*)calloc((size_t)n_pixels * 8 * 4, 2);
 
 	orc_init_rays(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
-	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer);
+	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f);
 	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant);
 
 	uint32_t n_alive = n_pixels, n_hit = 0, i = 1, dbi = 0;

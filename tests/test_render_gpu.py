@@ -21,7 +21,7 @@ def _camera():
     return cam, focal, res, sc
 
 
-def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0):
+def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plane_z=1.0, aperture=0.0, exact=True):
     cam, focal, res, sc = _camera()
     aabb = H.unit_aabb(2 ** (n_cascades - 1))
     grid = H.blob_density_grid(n_cascades)
@@ -32,18 +32,29 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0):
     pay = np.zeros(n, H.PAYLOAD)
     depth = np.zeros(n, np.float32)
     oracle.orc_init_rays(spp, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data)
+                         snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(plane_z), H.f32(aperture))
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr()))
+                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(plane_z), H.f32(aperture)))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
+    if not exact:   # depth of field: the lens-disk sample goes through cosf / sinf (device intrinsics vs libm)
+        same = g["alive"] == pay["alive"]
+        assert same.mean() > 0.995
+        al = (pay["alive"] == 1) & same
+        np.testing.assert_allclose(g["origin"][al], pay["origin"][al], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(g["dir"][al], pay["dir"][al], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(g["t"][al], pay["t"][al], rtol=0, atol=1e-5)
+        return dict(pay=pay, g=g, al=al, cam=cam)
     np.testing.assert_array_equal(g["alive"], pay["alive"])
     np.testing.assert_array_equal(g["origin"], pay["origin"])
     al = pay["alive"] == 1
-    assert al.any() and (~al).any() or al.all()
+    assert plane_z < 0 or (al.any() and (~al).any() or al.all())
     for f in ("dir", "t", "idx", "n_steps"):
         np.testing.assert_array_equal(g[f][al], pay[f][al])
     np.testing.assert_array_equal(H.to_host(d_depth, np.float32), depth)
+    if plane_z < 0:
+        np.testing.assert_array_equal(g["dir"], pay["dir"])
+        return dict(pay=pay, g=g, depth=depth)
 
     oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone))
     d_bf = H.to_dev(bf, cuda)
@@ -59,6 +70,32 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0):
 def test_init_rays_and_advance_bit_exact(ngp, oracle, cuda, spp, snap, n_cascades, cone):
     S = _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades, cone)
     assert (S["pay"]["alive"] == 1).sum() > 50
+
+
+def test_init_rays_depth_of_field(ngp, oracle, cuda):
+    """pixel_to_ray with aperture_size > 0 (common_device.cuh:307-312): origins jittered on the lens disk, the point at focus_z fixed"""
+    S = _init_and_advance(ngp, oracle, cuda, 5, 0, plane_z=1.7, aperture=0.03, exact=False)
+    P0 = _init_and_advance(ngp, oracle, cuda, 5, 0)["pay"]          # pinhole rays of the same pixels
+    al = S["al"] & (P0["alive"] == 1)
+    assert al.sum() > 100
+    o, d = S["pay"]["origin"][al], S["pay"]["dir"][al]
+    o0, d0 = P0["origin"][al], P0["dir"][al]
+    off = np.linalg.norm(o - o0, axis=1)
+    assert off.max() > 0.01 and off.max() <= 0.03 + 1e-6            # inside the lens disk, and actually spread over it
+    # both rays pass through the same point of the focal plane: origin0 + dir0_unnormalised * focus_z
+    cam = S["cam"].reshape(4, 3)                                    # column-major 3x4
+    fwd = cam[2]
+    tz0 = 1.7 / (d0 @ fwd)
+    tz = ((o0 + d0 * tz0[:, None] - o) @ fwd) / (d @ fwd)
+    np.testing.assert_allclose(o + d * tz[:, None], o0 + d0 * tz0[:, None], atol=2e-5)
+
+
+def test_init_rays_slice_plane(ngp, oracle, cuda):
+    """plane_z < 0 (the Slice render mode, testbed_nerf.cu:1913-1923): no ray is alive, depth = -plane_z, t at the plane; DOF is off"""
+    S = _init_and_advance(ngp, oracle, cuda, 2, 0, plane_z=-0.8, aperture=0.05)
+    assert (S["g"]["alive"] == 0).all() and (S["depth"] == np.float32(0.8)).all()
+    np.testing.assert_array_equal(S["g"]["t"], S["pay"]["t"])
+    assert (S["g"]["t"] >= 0.8 - 1e-6).all()
 
 
 def test_compact_next_inputs_composite(ngp, oracle, cuda):
@@ -176,7 +213,7 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     fb, db = H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda)
     cnt, hcnt = H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)
     check(ngp.ngp_hip_init_rays(None, 0, pay[0].data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr()))
+                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0)))
     check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0)))
     n_alive, i, dbi = n, 1, 0
     while i < 10000:
@@ -223,10 +260,10 @@ def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
         lp[5], lp[6] = W, Hh
     pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
     oracle.orc_init_rays(2, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data)
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data, H.f32(1.0), H.f32(0.0))
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, 2, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr()))
+                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0)))
     g = H.to_host(d_pay, H.PAYLOAD)
     same = g["alive"] == pay["alive"]
     assert same.mean() > 0.995                      # a ray grazing the box may flip with a 1-ulp different direction
@@ -239,6 +276,34 @@ def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
     # the lens actually bends the rays: directions differ from the pinhole ones
     pin = np.zeros(n, H.PAYLOAD)
     oracle.orc_init_rays(2, pin.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), 0, None, depth.ctypes.data)
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0))
     both = al & (pin["alive"] == 1)
     assert both.sum() > 50 and np.abs(pin["dir"][both] - pay["dir"][both]).max() > 1e-3
+
+
+def test_pyngp_depth_of_field_and_autofocus(cuda):
+    """python_api.cu:662-666: `aperture_size` / `dof`, `slice_plane_z`, `autofocus`, `autofocus_target` drive the stock renderer"""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=48, device=cuda)
+    t = scene.build_testbed(ds)
+    scene.train(t, 80)
+    t.shall_train = False
+    t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    sharp = t.render(48, 48, 4, True)
+    t.autofocus_target = [0.5, 0.5, 0.5]
+    t.autofocus = True
+    t.aperture_size = 0.06
+    assert t.dof == np.float32(0.06)
+    blurred = t.render(48, 48, 4, True)
+    cam = np.asarray(t.camera_matrix, np.float32)
+    want = max(float(cam[:, 2] @ (np.array([0.5, 0.5, 0.5], np.float32) - cam[:, 3])), 0.1) - t.scale
+    assert abs(t.slice_plane_z - want) < 1e-5
+    assert np.isfinite(blurred).all() and blurred[..., 3].max() > 0.5
+    assert np.abs(blurred - sharp).mean() > 2e-3          # the lens blur is visible
+    # gradients across pixels are weaker in the blurred image away from the focal plane
+    def sharpness(img):
+        return float(np.abs(np.diff(img[..., :3], axis=0)).mean() + np.abs(np.diff(img[..., :3], axis=1)).mean())
+    assert sharpness(blurred) < sharpness(sharp)
+    t.aperture_size = 0.0
+    again = t.render(48, 48, 4, True)
+    np.testing.assert_allclose(again, sharp, atol=1e-6)
