@@ -37,9 +37,13 @@ __device__ __forceinline__ uint32_t get_cascaded_grid_idx_at(v3 pos, uint32_t mi
 	const int hi = (int)grid_size - 1;
 	return morton3D((uint32_t)clampi(ix, 0, hi), (uint32_t)clampi(iy, 0, hi), (uint32_t)clampi(iz, 0, hi));
 }
-__device__ __forceinline__ bool get_is_occupied(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, uint32_t grid_size, uint32_t grid_volume) {
+// same bit as bitfield[idx / 8 + grid_volume * mip / 8] & (1 << idx % 8), read through the last 4x4x4 Morton brick (64 consecutive bits)
+// kept in two registers: consecutive steps of a ray mostly stay inside one brick, and the march is a chain of dependent loads otherwise
+__device__ __forceinline__ bool get_is_occupied(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, uint32_t grid_size, uint32_t grid_volume, OccBrick& cache) {
 	const uint32_t idx = get_cascaded_grid_idx_at(pos, mip, grid_size);
-	return bitfield[idx / 8 + (grid_volume * mip) / 8] & (1u << (idx % 8));
+	const uint32_t brick = (idx >> 6) + (grid_volume / 64u) * mip;
+	if (brick != cache.id) { cache.id = brick; cache.bits = ((const uint64_t*)bitfield)[brick]; }
+	return (cache.bits >> (idx & 63u)) & 1ull;
 }
 __device__ __forceinline__ float get_t_advanced_to_next_voxel(float t, float cone_angle, v3 pos, v3 dir, v3 idir, uint32_t res, float min_step, float max_step) {
 	const float t_target = t + distance_to_next_voxel(pos, dir, idir, res);
@@ -244,7 +248,7 @@ __global__ void init_proxy_rays_kernel(uint32_t n_elements, const NgpGlobalRay* 
 }
 
 // nerf_renderer.cu:148-208.  The mask test inside the loop is unreachable in the reference (a `break` precedes it), so occupancy alone decides.
-__device__ __forceinline__ bool hit_test_and_march(v3 origin, v3 dir, v3 idir, float proxy_t, const NgpNerfProps* __restrict__ props, float* t_out, float* dt_out) {
+__device__ __forceinline__ bool hit_test_and_march(v3 origin, v3 dir, v3 idir, float proxy_t, const NgpNerfProps* __restrict__ props, float* t_out, float* dt_out, OccBrick& occ) {
 	const Aabb render_aabb = aabb_of(props->render_aabb);
 	const float cone = props->cone_angle, mn = props->min_cone_stepsize, mx = props->max_cone_stepsize;
 	const uint8_t* __restrict__ bitfield = props->density_grid_bitfield;
@@ -261,7 +265,7 @@ __device__ __forceinline__ bool hit_test_and_march(v3 origin, v3 dir, v3 idir, f
 		int mipi = get_mip_from_dt(dt, pos, grid_size, max_cascade);
 		const uint32_t mip = (uint32_t)(mipi < 0 ? 0 : mipi);
 		if (!bitfield) break;
-		if (get_is_occupied(pos, bitfield, mip, grid_size, grid_volume)) break;
+		if (get_is_occupied(pos, bitfield, mip, grid_size, grid_volume, occ)) break;
 		const uint32_t res = grid_size >> mip;
 		prev_t = t;
 		t = get_t_advanced_to_next_voxel(t, cone, pos, dir, idir, res, mn, mx);
@@ -307,7 +311,8 @@ __global__ void march_active_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs
 		const v3 origin = ld3(p.origin), dir = ld3(p.dir);
 		const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 		float t = p.t;
-		p.alive = hit_test_and_march(origin, dir, idir, t, props + n, &t, nullptr) ? 1 : 0;
+		OccBrick occ;
+		p.alive = hit_test_and_march(origin, dir, idir, t, props + n, &t, nullptr, occ) ? 1 : 0;
 		p.t = t;
 	}
 }
@@ -349,16 +354,39 @@ __global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const Ngp
 	const v3 wd = warp_direction(dir);
 	float t = p.t;
 	float dt = get_dt(t, props->cone_angle, props->min_cone_stepsize, props->max_cone_stepsize);
-	for (uint32_t j = 0; j < n_steps; ++j) {
+	// The reference emits sample j, then calls hit_test_and_march (march until occupied or out of the box) and steps.  Flattened into one
+	// loop of single DDA iterations per ray — same per-ray sequence, same bits — so that a lane walking ~150 empty voxels to the box
+	// boundary does not hold the rest of its wave at every step (see generate_next_inputs_kernel in render.hip).
+	const Aabb render_aabb = aabb_of(props->render_aabb);
+	const float cone = props->cone_angle, mn = props->min_cone_stepsize, mx = props->max_cone_stepsize;
+	const uint8_t* __restrict__ bitfield = props->density_grid_bitfield;
+	const uint32_t grid_size = props->grid_size, grid_volume = props->grid_volume, max_cascade = props->nerf_cascades - 1, n_cascades = props->nerf_cascades;
+	OccBrick occ;
+	uint32_t j = 0;
+	bool emit = true;
+	while (j < n_steps) {
+		if (emit) {
+			const v3 wp = aabb_relative_pos(train_aabb, origin + dir * t);
+			NgpCoord c;
+			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z;
+			c.dt = get_warped_dt(dt, mn, n_cascades);
+			c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+			network_input[i + (size_t)j * n_elements] = c;
+			emit = false;
+		}
+		// one iteration of hit_test_and_march (nerf_renderer.cu:148-208)
 		const v3 pos = origin + dir * t;
-		const v3 wp = aabb_relative_pos(train_aabb, pos);
-		NgpCoord c;
-		c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z;
-		c.dt = get_warped_dt(dt, props->min_cone_stepsize, props->nerf_cascades);
-		c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
-		network_input[i + (size_t)j * n_elements] = c;
-		if (!hit_test_and_march(origin, dir, idir, t, props, &t, &dt)) { p.n_steps = (uint16_t)j; return; }
-		t += dt;
+		if (!aabb_contains(render_aabb, pos)) { p.n_steps = (uint16_t)j; return; }
+		dt = get_dt(t, cone, mn, mx);
+		const int mipi = get_mip_from_dt(dt, pos, grid_size, max_cascade);
+		const uint32_t mip = (uint32_t)(mipi < 0 ? 0 : mipi);
+		if (!bitfield || get_is_occupied(pos, bitfield, mip, grid_size, grid_volume, occ)) {
+			t += dt;
+			++j;
+			emit = true;
+		} else {
+			t = get_t_advanced_to_next_voxel(t, cone, pos, dir, idir, grid_size >> mip, mn, mx);
+		}
 	}
 	p.t = t;
 	p.n_steps = (uint16_t)n_steps;

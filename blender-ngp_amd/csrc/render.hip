@@ -137,6 +137,10 @@ __global__ void __launch_bounds__(256) compact_rays_kernel(uint32_t n_elements, 
 	}
 }
 
+// One flat loop per ray instead of the reference's "for every step: march until occupied": every iteration is one DDA iteration — emit a
+// sample and step, or skip an empty voxel.  The per-ray sequence (and so every bit of the output) is the same, but a lane that leaves
+// the object and walks ~150 empty voxels to the box boundary no longer holds the other 63 lanes of its wave at every one of the
+// n_steps steps: the wave runs max-over-lanes(n_steps + skips) iterations, not sum-over-steps(max-over-lanes skips).
 template <bool CONST_DT>
 __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aabb, Aabb train_aabb, NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input,
                                             uint32_t n_steps, const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
@@ -150,23 +154,23 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 	const float cone_angle = cone_angle_constant;
 	float t = payload.t;
 	OccBrick occ;
-	for (uint32_t j = 0; j < n_steps; ++j) {
-		v3 pos;
-		float dt = 0.0f;
-		while (1) {
-			pos = origin + dir * t;
-			if (!aabb_contains(render_aabb, pos)) { payload.n_steps = (uint16_t)j; return; }
-			dt = calc_dt_t<CONST_DT>(t, cone_angle);
-			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
-			mip = mip < min_mip ? min_mip : mip;
-			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
+	uint32_t j = 0;
+	while (j < n_steps) {
+		const v3 pos = origin + dir * t;
+		if (!aabb_contains(render_aabb, pos)) { payload.n_steps = (uint16_t)j; return; }
+		const float dt = calc_dt_t<CONST_DT>(t, cone_angle);
+		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+		mip = mip < min_mip ? min_mip : mip;
+		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) {
+			const v3 wp = aabb_relative_pos(train_aabb, pos);
+			NgpCoord c;
+			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt); c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+			network_input[i + (size_t)j * n_elements] = c;
+			t += dt;
+			++j;
+		} else {
 			t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
-		const v3 wp = aabb_relative_pos(train_aabb, pos);
-		NgpCoord c;
-		c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt); c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
-		network_input[i + (size_t)j * n_elements] = c;
-		t += dt;
 	}
 	payload.t = t;
 	payload.n_steps = (uint16_t)n_steps;
