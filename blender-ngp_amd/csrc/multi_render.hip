@@ -317,14 +317,12 @@ __global__ void march_active_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs
 	}
 }
 
-__global__ void cull_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, uint32_t stride, v3 cam_pos,
-                                 const NgpNerfProps* __restrict__ props) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_rays_alive) return;
+// nerf_renderer.cu:210-262; returns the index of the NeRF whose proxy ray is nearest to the camera (it samples in this pass), or -1
+__device__ __forceinline__ int32_t cull_one_ray(uint32_t i, uint32_t n_nerfs, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, uint32_t stride, v3 cam_pos,
+                                                const NgpNerfProps* __restrict__ props) {
 	NgpGlobalRay& g = global_rays[i];
-	if (!g.alive) return;
 	float min_d2 = 0.0f;
-	int32_t active_idx = -1;
+	int32_t active_idx = -1, active_nerf = -1;
 	uint32_t n_proxy_alive = 0;
 	for (uint32_t n = 0; n < n_nerfs; ++n) {
 		const uint32_t pi = i + n * stride;
@@ -334,17 +332,43 @@ __global__ void cull_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlo
 		const v3 pw = xform_point(props[n].transform, ld3(p.origin) + ld3(p.dir) * p.t);
 		const v3 dlt = pw - cam_pos;
 		const float d2 = dot(dlt, dlt);
-		if (d2 < min_d2 || active_idx == -1) { min_d2 = d2; active_idx = (int32_t)pi; }
+		if (d2 < min_d2 || active_idx == -1) { min_d2 = d2; active_idx = (int32_t)pi; active_nerf = (int32_t)n; }
 		p.active = 0;
 	}
 	if (active_idx >= 0) proxy_rays[active_idx].active = 1;
 	if (n_proxy_alive == 0) g.alive = 0;
+	return active_nerf;
 }
 
-__global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, NgpCoord* __restrict__ network_input,
-                                                  uint32_t n_steps, const NgpNerfProps* __restrict__ props) {
+__global__ void cull_rays_kernel(uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays, uint32_t stride, v3 cam_pos,
+                                 const NgpNerfProps* __restrict__ props, uint32_t* __restrict__ active_lists, uint32_t* __restrict__ active_counts) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_elements) return;
+	int32_t active_nerf = -1;
+	if (i < n_rays_alive && global_rays[i].alive) active_nerf = cull_one_ray(i, n_nerfs, global_rays, proxy_rays, stride, cam_pos, props);
+	if (!active_lists) return;
+	// per-NeRF lists of the rays that sample it in this pass: one atomic per wave and NeRF present in it
+	const uint32_t lane = lane_id();
+	uint64_t todo = __ballot(active_nerf >= 0);
+	while (todo) {
+		const int leader = __ffsll((unsigned long long)todo) - 1;
+		const int32_t nerf = __shfl(active_nerf, leader, 64);
+		const uint64_t same = __ballot(active_nerf == nerf);
+		uint32_t base = 0;
+		if ((int)lane == leader) base = atomicAdd(&active_counts[nerf], (uint32_t)__popcll(same));
+		base = __shfl(base, leader, 64);
+		if (active_nerf == nerf) active_lists[(size_t)nerf * stride + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+		todo &= ~same;
+	}
+}
+
+
+// `list` (optional): thread k handles ray list[k] and the network batch holds only those n_elements rays (element k + j * n_elements);
+// without it thread k handles ray k as in the reference, inactive rays leaving holes that the network evaluates anyway
+__global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const uint32_t* __restrict__ list, const NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays,
+                                                  NgpCoord* __restrict__ network_input, uint32_t n_steps, const NgpNerfProps* __restrict__ props) {
+	const uint32_t k = threadIdx.x + blockIdx.x * blockDim.x;
+	if (k >= n_elements) return;
+	const uint32_t i = list ? list[k] : k;
 	if (!global_rays[i].alive) return;
 	NgpProxyRay& p = proxy_rays[i];
 	if (!p.active) return;
@@ -371,7 +395,7 @@ __global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const Ngp
 			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z;
 			c.dt = get_warped_dt(dt, mn, n_cascades);
 			c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
-			network_input[i + (size_t)j * n_elements] = c;
+			network_input[k + (size_t)j * n_elements] = c;
 			emit = false;
 		}
 		// one iteration of hit_test_and_march (nerf_renderer.cu:148-208)
@@ -394,11 +418,12 @@ __global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const Ngp
 
 typedef uint16_t us4m __attribute__((ext_vector_type(4)));
 
-__global__ void multi_composite_kernel(uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays,
+__global__ void multi_composite_kernel(uint32_t n_global_rays, const uint32_t* __restrict__ list, uint32_t current_step, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays,
                                        const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride, uint32_t n_steps,
                                        int rgb_activation, int density_activation, float min_transmittance, const NgpNerfProps* __restrict__ props) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_global_rays) return;
+	const uint32_t k = threadIdx.x + blockIdx.x * blockDim.x;
+	if (k >= n_global_rays) return;
+	const uint32_t i = list ? list[k] : k;
 	NgpGlobalRay& g = global_rays[i];
 	if (!g.alive) return;
 	NgpProxyRay& p = proxy_rays[i];
@@ -408,7 +433,7 @@ __global__ void multi_composite_kernel(uint32_t n_global_rays, uint32_t current_
 	const uint32_t actual_n_steps = p.n_steps;
 	uint32_t j = 0;
 	for (; j < actual_n_steps; ++j) {
-		const size_t e = i + (size_t)j * n_global_rays;
+		const size_t e = k + (size_t)j * n_global_rays;
 		const us4m o = *(const us4m*)(network_output + e * out_stride);
 		const NgpCoord& in = network_input[e];
 		const v3 pos = unwarp_position(ld3(in.pos), train_aabb);
@@ -490,23 +515,43 @@ int ngp_hip_multi_march_active_rays(void* stream, uint32_t n_rays_alive, uint32_
 int ngp_hip_multi_cull_rays(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, uint32_t stride, const float* cam_pos, const NgpNerfProps* props) {
 	if (!n_rays_alive) return 0;
 	v3 cp; cp.x = cam_pos[0]; cp.y = cam_pos[1]; cp.z = cam_pos[2];
-	hipLaunchKernelGGL(cull_rays_kernel, dim3(div_up(n_rays_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_alive, n_nerfs, global_rays, proxy_rays, stride, cp, props);
+	hipLaunchKernelGGL(cull_rays_kernel, dim3(div_up(n_rays_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_alive, n_nerfs, global_rays, proxy_rays, stride, cp, props, (uint32_t*)nullptr, (uint32_t*)nullptr);
+	NGP_LAUNCH_CHECK("cull_rays_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_cull_rays_collect(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, uint32_t stride, const float* cam_pos, const NgpNerfProps* props,
+                                    uint32_t* active_lists, uint32_t* active_counts) {
+	if (!active_lists || !active_counts) { set_last_error("ngp_hip_multi_cull_rays_collect: active_lists / active_counts missing", hipErrorInvalidValue); return -1; }
+	NGP_HIP_TRY(hipMemsetAsync(active_counts, 0, (size_t)n_nerfs * 4, (hipStream_t)stream));
+	if (!n_rays_alive) return 0;
+	v3 cp; cp.x = cam_pos[0]; cp.y = cam_pos[1]; cp.z = cam_pos[2];
+	hipLaunchKernelGGL(cull_rays_kernel, dim3(div_up(n_rays_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_alive, n_nerfs, global_rays, proxy_rays, stride, cp, props, active_lists, active_counts);
 	NGP_LAUNCH_CHECK("cull_rays_kernel");
 	return 0;
 }
 
 int ngp_hip_multi_generate_next_inputs(void* stream, uint32_t n_elements, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, NgpCoord* network_input, uint32_t n_steps, const NgpNerfProps* props) {
+	return ngp_hip_multi_generate_next_inputs_list(stream, n_elements, nullptr, global_rays, proxy_rays, network_input, n_steps, props);
+}
+int ngp_hip_multi_generate_next_inputs_list(void* stream, uint32_t n_elements, const uint32_t* list, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, NgpCoord* network_input, uint32_t n_steps,
+                                            const NgpNerfProps* props) {
 	if (!n_elements) return 0;
-	hipLaunchKernelGGL(multi_generate_next_inputs_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, global_rays, proxy_rays, network_input, n_steps, props);
+	hipLaunchKernelGGL(multi_generate_next_inputs_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, list, global_rays, proxy_rays, network_input, n_steps, props);
 	NGP_LAUNCH_CHECK("multi_generate_next_inputs_kernel");
 	return 0;
 }
 
 int ngp_hip_multi_composite(void* stream, uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, const NgpCoord* network_input,
                             const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, const NgpNerfProps* props) {
+	return ngp_hip_multi_composite_list(stream, n_global_rays, nullptr, current_step, global_rays, proxy_rays, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation,
+	                                    min_transmittance, props);
+}
+int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uint32_t* list, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, const NgpCoord* network_input,
+                                 const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, const NgpNerfProps* props) {
 	if (!n_global_rays) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_multi_composite: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	hipLaunchKernelGGL(multi_composite_kernel, dim3(div_up(n_global_rays, 128)), dim3(128), 0, (hipStream_t)stream, n_global_rays, current_step, global_rays, proxy_rays, network_input,
+	hipLaunchKernelGGL(multi_composite_kernel, dim3(div_up(n_global_rays, 128)), dim3(128), 0, (hipStream_t)stream, n_global_rays, list, current_step, global_rays, proxy_rays, network_input,
 	                   network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, props);
 	NGP_LAUNCH_CHECK("multi_composite_kernel");
 	return 0;

@@ -242,13 +242,16 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 	const uint32_t n_pixels = ds.scaled_pixels;
 	if (n_pixels == 0) return 0;
 	const uint32_t stride = (n_pixels + 127u) / 128u * 128u;
-	const uint32_t max_steps = 8, OUT_STRIDE = 4;
+	// nerf_renderer.cu marches clamp(n_rays / n_alive, 1, 8) steps per pass.  The per-ray sample sequence does not depend on how it is cut
+	// into passes and n_alive * n_steps <= n_pixels keeps every buffer as sized for one step per pixel, so the cap is raised: fewer passes
+	// (each costs a host round trip and 3-5 launches per NeRF) once few rays are left — same image (tests/test_bl_render_gpu.py).
+	const uint32_t max_steps = 64, OUT_STRIDE = 4;
 	for (int b = 0; b < 2; ++b) { m_global[b].enlarge((size_t)stride * sizeof(NgpGlobalRay)); m_proxy[b].enlarge((size_t)stride * n_nerfs * sizeof(NgpProxyRay)); }
 	m_hit.enlarge((size_t)stride * sizeof(NgpGlobalRay));
-	m_net_in.enlarge((size_t)stride * max_steps * sizeof(NgpCoord));
-	m_net_out.enlarge((size_t)stride * max_steps * OUT_STRIDE * 2);
+	m_net_in.enlarge((size_t)stride * 8 * sizeof(NgpCoord));
+	m_net_out.enlarge((size_t)stride * 8 * OUT_STRIDE * 2);
 	m_counters.enlarge(8);
-	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(stride * max_steps));
+	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(stride * 8));
 	uint32_t* alive_counter = m_counters.as<uint32_t>();
 	uint32_t* hit_counter = alive_counter + 1;
 
@@ -278,18 +281,26 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 		NgpGlobalRay* g = m_global[cur].as<NgpGlobalRay>();
 		NgpProxyRay* px = m_proxy[cur].as<NgpProxyRay>();
 		check(ngp_hip_multi_march_active_rays(stream, n_alive, n_nerfs, g, px, stride, props_dev), "multi_march_active_rays");
-		check(ngp_hip_multi_cull_rays(stream, n_alive, n_nerfs, g, px, stride, cam_pos, props_dev), "multi_cull_rays");
+		// cull + per-NeRF lists of the rays that sample each NeRF in this pass (a ray samples at most one): the network then runs on
+		// exactly those rays instead of on every alive ray for every NeRF as nerf_renderer.cu:735-768 does
+		m_active_lists.enlarge((size_t)stride * n_nerfs * 4); m_active_counts.enlarge((size_t)n_nerfs * 4);
+		check(ngp_hip_multi_cull_rays_collect(stream, n_alive, n_nerfs, g, px, stride, cam_pos, props_dev, m_active_lists.as<uint32_t>(), m_active_counts.as<uint32_t>()), "multi_cull_rays");
+		std::vector<uint32_t> n_active(n_nerfs);
+		HIP_TRY(hipMemcpyAsync(n_active.data(), m_active_counts.data(), (size_t)n_nerfs * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
 		const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), max_steps);
-		const uint32_t n_network_elements = (n_alive * n_steps + 127u) / 128u * 128u;
 		for (uint32_t n = 0; n < n_nerfs; ++n) {
+			if (n_active[n] == 0) continue;
 			const NeuralRadianceField& f = *field_of[n];
 			NgpProxyRay* pn = px + (size_t)n * stride;
-			check(ngp_hip_multi_generate_next_inputs(stream, n_alive, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
+			const uint32_t* list = m_active_lists.as<uint32_t>() + (size_t)n * stride;
+			const uint32_t n_network_elements = (n_active[n] * n_steps + 127u) / 128u * 128u;
+			check(ngp_hip_multi_generate_next_inputs_list(stream, n_active[n], list, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
 			check(ngp_hip_nerf_inference_ws(stream, f.desc_gpu.as<NgpNetDesc>(), f.params.as<uint16_t>(), m_net_in.as<float>(), 7, n_network_elements, m_net_out.as<uint16_t>(), OUT_STRIDE,
 			                                m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (multi)");
 			n_samples += n_network_elements;
-			check(ngp_hip_multi_composite(stream, n_alive, i, g, pn, m_net_in.as<NgpCoord>(), m_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)f.rgb_activation, (int)f.density_activation,
-			                              f.min_transmittance, props_dev + n), "multi_composite");
+			check(ngp_hip_multi_composite_list(stream, n_active[n], list, i, g, pn, m_net_in.as<NgpCoord>(), m_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)f.rgb_activation, (int)f.density_activation,
+			                                   f.min_transmittance, props_dev + n), "multi_composite");
 		}
 		i += n_steps;
 	}

@@ -123,7 +123,7 @@ public:
 	size_t n_loaded_fields() const { return m_fields.size(); }
 private:
 	std::vector<std::unique_ptr<NeuralRadianceField>> m_fields;
-	DeviceBuffer m_global[2], m_proxy[2], m_hit, m_net_in, m_net_out, m_counters, m_props_gpu, m_masks_gpu, m_enc_ws;
+	DeviceBuffer m_global[2], m_proxy[2], m_hit, m_net_in, m_net_out, m_counters, m_props_gpu, m_masks_gpu, m_enc_ws, m_active_lists, m_active_counts;
 };
 
 } // namespace ngp

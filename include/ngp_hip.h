@@ -321,6 +321,16 @@ int ngp_hip_multi_generate_next_inputs(void* stream, uint32_t n_elements, const 
 int ngp_hip_multi_composite(void* stream, uint32_t n_global_rays, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays_of_nerf,
                             const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
                             int density_activation, float min_transmittance, const NgpNerfProps* nerf_props_of_nerf_dev);      /* :431-510 */
+/* Sparse variants (not in the reference, which evaluates every alive ray's slots for every NeRF): ngp_hip_multi_cull_rays_collect also
+ * appends ray i to active_lists[nerf * stride + ...] of the NeRF whose proxy ray it activated (active_counts[n_nerfs], zeroed inside);
+ * the _list kernels then run thread k on ray list[k] with a network batch of exactly those n rays (element k + j * n).  Same pixels. */
+int ngp_hip_multi_cull_rays_collect(void* stream, uint32_t n_rays_alive, uint32_t n_nerfs, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, uint32_t stride, const float* cam_pos,
+                                    const NgpNerfProps* props, uint32_t* active_lists, uint32_t* active_counts);
+int ngp_hip_multi_generate_next_inputs_list(void* stream, uint32_t n_elements, const uint32_t* list, const NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays, NgpCoord* network_input,
+                                            uint32_t n_steps, const NgpNerfProps* props);
+int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uint32_t* list, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays,
+                                 const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation,
+                                 float min_transmittance, const NgpNerfProps* props);
 int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                         const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
 
