@@ -48,6 +48,7 @@ struct LossArgs {
 	int snap_to_pixel_centers; float* error_map; int32_t error_map_res[2]; const float* mean_density; const float* exposure; float near_distance;
 	ErrorMapCdf cdf;
 	const uint16_t* encoded_in; uint16_t* encoded_out;   // optional: [sample][32] fp16 encoding rows carried through the compaction
+	float depth_supervision_lambda; int depth_loss_type;  // testbed.h:654, 680 (off by default)
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -80,7 +81,8 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 
 	uint32_t numsteps = 0, base = 0, compacted = 0;
 	float T_final = 1.f;
-	float rgb_ray[3] = {0.f, 0.f, 0.f};
+	float rgb_ray[3] = {0.f, 0.f, 0.f}, depth_ray = 0.f;
+	const v3 ray_o_early = active ? ld3(a.rays_in[i].o) : mk(0.f, 0.f, 0.f);
 	if (active) {
 		numsteps = a.numsteps_in[i * 2 + 0];
 		base = a.numsteps_in[i * 2 + 1];
@@ -113,6 +115,14 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			rgb_ray[0] += wave_sum(weight * rgb[0]);
 			rgb_ray[1] += wave_sum(weight * rgb[1]);
 			rgb_ray[2] += wave_sum(weight * rgb[2]);
+			if (a.depth_supervision_lambda > 0.0f) {   // depth_ray += weight * cur_depth (1366-1368)
+				float cur_depth = 0.f;
+				if (valid) {
+					const NgpCoord cc = ci[j];
+					cur_depth = norm(unwarp_position(mk(cc.pos[0], cc.pos[1], cc.pos[2]), a.aabb) - ray_o_early);
+				}
+				depth_ray += wave_sum(weight * cur_depth);
+			}
 			const uint32_t n_inc = (uint32_t)__popcll(__ballot(include));
 			const uint32_t n_valid = numsteps - c0 < 64 ? numsteps - c0 : 64;
 			compacted += n_inc;
@@ -189,6 +199,22 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	if (compacted == 0) return;
 
 	const LG lg = loss_and_gradient(rgbtarget, rgb_ray, a.loss_type);
+	// depth supervision (1450-1452): target = |d| * depth image at the ray's pixel, loss on the expected termination depth
+	float depth_loss_gradient = 0.0f;
+	if (a.depth_supervision_lambda > 0.0f) {
+		const NgpImageMeta& mdd = a.metadata[img];
+		float dval = -1.0f;
+		if (mdd.depth) {
+			int px = (int)(xy[0] * (float)mdd.res[0]), py = (int)(xy[1] * (float)mdd.res[1]);
+			px = px > 0 ? px : 0; px = px < mdd.res[0] - 1 ? px : mdd.res[0] - 1;
+			py = py > 0 ? py : 0; py = py < mdd.res[1] - 1 ? py : mdd.res[1] - 1;
+			dval = mdd.depth[(size_t)px + (size_t)py * (size_t)mdd.res[0]];
+		}
+		const float target_depth = norm(ld3(a.rays_in[i].d)) * dval;
+		const float t3[3] = {target_depth, target_depth, target_depth}, p3[3] = {depth_ray, depth_ray, depth_ray};
+		const LG lgd = loss_and_gradient(t3, p3, a.depth_loss_type);
+		depth_loss_gradient = target_depth > 0.0f ? a.depth_supervision_lambda * lgd.grad[0] : 0.0f;
+	}
 	// lg.loss /= img_pdf * xy_pdf (1448): the reported loss and the error map are importance-weighted, the gradient deliberately is not (1454-1458)
 	const float mean_loss = (lg.loss[0] / sample_pdf + lg.loss[1] / sample_pdf + lg.loss[2] / sample_pdf) / 3.0f;
 	if (lane == 0) {
@@ -215,7 +241,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	const float output_l1_reg_density = *a.mean_density < MIN_OPTICAL_THICKNESS() ? 1e-4f : 0.0f;
 	NgpCoord* __restrict__ co = a.coords_out + compacted_base;
 	uint16_t* __restrict__ dl = a.dloss_doutput + (size_t)compacted_base * a.dl_stride;
-	float T_carry = 1.f, acc_carry[3] = {0.f, 0.f, 0.f};
+	float T_carry = 1.f, acc_carry[3] = {0.f, 0.f, 0.f}, depth_carry = 0.f;
 	for (uint32_t c0 = 0; c0 < compacted; c0 += 64) {
 		const uint32_t j = c0 + lane;
 		const bool valid = j < compacted;
@@ -248,6 +274,8 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		float rgb_ray2[3];
 #pragma unroll
 		for (int c = 0; c < 3; ++c) rgb_ray2[c] = acc_carry[c] + wave_inclusive<1>(weight * rgb[c], lane);
+		float depth_ray2 = 0.f;
+		if (a.depth_supervision_lambda > 0.0f) depth_ray2 = depth_carry + wave_inclusive<1>(weight * depth, lane);
 		if (valid) {
 			us4 out;
 #pragma unroll
@@ -257,13 +285,15 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			}
 			const float density_derivative = network_to_density_derivative(lof[3], a.density_activation);
 			const float dotv = lg.grad[0] * (T * rgb[0] - (rgb_ray[0] - rgb_ray2[0])) + lg.grad[1] * (T * rgb[1] - (rgb_ray[1] - rgb_ray2[1])) + lg.grad[2] * (T * rgb[2] - (rgb_ray[2] - rgb_ray2[2]));
-			const float dloss_by_dmlp = density_derivative * (dt * (dotv + 0.0f));
+			const float depth_supervision = depth_loss_gradient * (T * depth - (depth_ray - depth_ray2));   // 1536-1537; 0 when switched off
+			const float dloss_by_dmlp = density_derivative * (dt * (dotv + depth_supervision));
 			out[3] = f2h(ls * dloss_by_dmlp + (lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) + (lof[3] > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f));
 			*(us4*)(dl + (size_t)j * a.dl_stride) = out;
 		}
 		T_carry = T_carry * __shfl(incl, 63, 64);
 #pragma unroll
 		for (int c = 0; c < 3; ++c) acc_carry[c] = __shfl(rgb_ray2[c], 63, 64);
+		depth_carry = __shfl(depth_ray2, 63, 64);
 	}
 }
 
@@ -472,7 +502,7 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out) {
+	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type) {
 	if (!n_rays) return 0;
 	if ((encoded_in == nullptr) != (encoded_out == nullptr)) { set_last_error("ngp_hip_compute_loss: encoded_in and encoded_out go together", hipErrorInvalidValue); return -1; }
 	if ((mlp_stride & 3) || (dl_stride & 3)) { set_last_error("ngp_hip_compute_loss: strides must be multiples of 4 halves", hipErrorInvalidValue); return -1; }
@@ -486,6 +516,7 @@ int ngp_hip_compute_loss(
 	a.dloss_doutput = dloss_doutput; a.dl_stride = dl_stride; a.loss_type = loss_type; a.loss_output = loss_output;
 	a.max_level_rand_training = max_level_rand_training; a.max_level_compacted = max_level_compacted; a.rgb_activation = rgb_activation;
 	a.cdf = make_error_map_cdf(cdf_host); a.encoded_in = encoded_in; a.encoded_out = encoded_out;
+	a.depth_supervision_lambda = depth_supervision_lambda; a.depth_loss_type = depth_loss_type;
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;

@@ -454,6 +454,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("offset", [](NerfTraining& t) { return vec3_to_py(t.dataset.offset); })
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
+		.def_readwrite("depth_loss_type", &NerfTraining::depth_loss_type)                       // python_api.cu:809
+		.def_readwrite("depth_supervision_lambda", &NerfTraining::depth_supervision_lambda)     // python_api.cu:828
 		.def_readwrite("sample_focal_plane_proportional_to_error", &NerfTraining::sample_focal_plane_proportional_to_error)   // python_api.cu:817
 		.def_readwrite("sample_image_proportional_to_error", &NerfTraining::sample_image_proportional_to_error)               // python_api.cu:818
 		.def_readwrite("n_steps_between_error_map_updates", &NerfTraining::n_steps_between_error_map_updates)
@@ -483,11 +485,18 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("set_dataset_transform", [](NerfTraining& t, float scale, const std::vector<float>& offset) {
 				t.dataset.scale = scale; t.dataset.offset.x = offset.at(0); t.dataset.offset.y = offset.at(1); t.dataset.offset.z = offset.at(2);
 			}, py::arg("scale"), py::arg("offset"), "the `scale` / `offset` keys of transforms.json (nerf_loader.cu:472-474, 499-504)")
-		.def("set_image", [](NerfTraining& t, int frame_idx, const py::array_t<float, py::array::c_style | py::array::forcecast>& img) {
+		.def("set_image", [](NerfTraining& t, int frame_idx, const py::array_t<float, py::array::c_style | py::array::forcecast>& img,
+		                     const py::array_t<float, py::array::c_style | py::array::forcecast>& depth_img, float depth_scale) {
 				auto b = img.request();
 				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error{"image should be (H,W,C) where C=4"};
-				t.set_image(frame_idx, (int)b.shape[1], (int)b.shape[0], (const float*)b.ptr);
-			}, py::arg("frame_idx"), py::arg("img"))
+				auto d = depth_img.request();
+				const float* depth = nullptr;
+				if (d.size > 0) {
+					if (d.size != b.shape[0] * b.shape[1]) throw std::runtime_error{"depth image should be (H,W)"};
+					depth = (const float*)d.ptr;
+				}
+				t.set_image(frame_idx, (int)b.shape[1], (int)b.shape[0], (const float*)b.ptr, depth, depth_scale);
+			}, py::arg("frame_idx"), py::arg("img"), py::arg("depth_img") = py::array_t<float>(), py::arg("depth_scale") = -1.f)   // python_api.cu:53-72, 786-791
 		.def("set_image_rgba8", [](NerfTraining& t, int frame_idx, const py::array_t<uint8_t, py::array::c_style | py::array::forcecast>& img) {
 				auto b = img.request();
 				if (b.ndim != 3 || b.shape[2] != 4) throw std::runtime_error{"image should be (H,W,C) where C=4"};

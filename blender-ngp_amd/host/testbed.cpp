@@ -79,7 +79,7 @@ Mat34 NerfDataset::ngp_matrix_to_nerf(const Mat34& in) const {
 	r.m[9] = (r.m[9] - offset.x) / scale; r.m[10] = (r.m[10] - offset.y) / scale; r.m[11] = (r.m[11] - offset.z) / scale;
 	return r;
 }
-void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type) {
+void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type, const float* depth_host, float depth_scale) {
 	if (frame_idx < 0 || (size_t)frame_idx >= n_images) throw std::runtime_error{"NerfDataset::set_training_image: invalid frame index"};
 	const size_t px = (size_t)w * h;
 	const size_t stride = image_data_type == 1 ? 4 : (image_data_type == 2 ? 8 : 16);
@@ -89,6 +89,18 @@ void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pi
 	m.pixels = pixelmemory[frame_idx].data();
 	m.image_data_type = image_data_type;
 	m.res[0] = w; m.res[1] = h;
+	// depth (nerf_loader.cu:785-802, copy_depth 91-100): stored pre-multiplied by depth_scale; scale < 0 frees it, no data or scale 0 zeroes it
+	if (depthmemory.size() < n_images) depthmemory.resize(n_images);
+	if (depth_scale >= 0.f) {
+		std::vector<float> scaled(px, 0.f);
+		if (depth_host && depth_scale > 0.f) for (size_t k = 0; k < px; ++k) scaled[k] = depth_host[k] * depth_scale;
+		depthmemory[frame_idx].resize(px * 4);
+		depthmemory[frame_idx].copy_from_host(scaled.data(), px * 4);
+		m.depth = depthmemory[frame_idx].as<float>();
+	} else {
+		depthmemory[frame_idx] = DeviceBuffer{};
+		m.depth = nullptr;
+	}
 	update_metadata(frame_idx, frame_idx + 1);
 }
 void NerfDataset::update_metadata(int first, int last) {
@@ -100,10 +112,10 @@ void NerfDataset::update_metadata(int first, int last) {
 }
 
 // ------------------------------------------------------------------------------------------------ training-side setters
-void NerfTraining::set_image(int frame_idx, int w, int h, const float* rgba_host) {
+void NerfTraining::set_image(int frame_idx, int w, int h, const float* rgba_host, const float* depth_host, float depth_scale) {
 	if (owner) owner->invalidate_training_inputs();
 	if (frame_idx < 0 || (size_t)frame_idx >= dataset.n_images) throw std::runtime_error{"Invalid frame index"};
-	dataset.set_training_image(frame_idx, w, h, rgba_host, 3);
+	dataset.set_training_image(frame_idx, w, h, rgba_host, 3, depth_host, depth_scale);
 }
 void NerfTraining::set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host) {
 	if (owner) owner->invalidate_training_inputs();
@@ -689,7 +701,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
-	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>()), "compute_loss");
+	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type), "compute_loss");
 	profile_end(PK_LOSS, R);
 	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory

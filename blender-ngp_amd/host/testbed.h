@@ -88,6 +88,7 @@ struct NerfDataset {
 	std::vector<std::string> paths;              // image paths, carried through snapshots (json_binding.h:133)
 	std::vector<NgpImageMeta> metadata;          // host copy; .pixels are device pointers into pixelmemory
 	std::vector<DeviceBuffer> pixelmemory;
+	std::vector<DeviceBuffer> depthmemory;       // fp32 per pixel, already multiplied by depth_scale (nerf_loader.cu:785-802); empty = no depth
 	DeviceBuffer metadata_gpu;
 	float scale = 1.0f;                          // NERF_SCALE = 1.0 in this fork (nerf_loader.h:28)
 	Vec3 offset;                                 // {0,0,0} (nerf_loader.cu:186)
@@ -100,7 +101,7 @@ struct NerfDataset {
 
 	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix) const;   // nerf_loader.h:113-132
 	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix) const;    // nerf_loader.h:134-152
-	void set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type); // nerf_loader.cu:749-
+	void set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type, const float* depth_host = nullptr, float depth_scale = -1.f); // nerf_loader.cu:749-
 	void update_metadata(int first = 0, int last = -1);         // nerf_loader.cu:851-867
 };
 
@@ -130,6 +131,8 @@ struct NerfTraining {
 	bool linear_colors = false;                  // testbed.h:664
 	bool snap_to_pixel_centers = false;          // testbed.h:665
 	ELossType loss_type = ELossType::L2;
+	ELossType depth_loss_type = ELossType::L1;   // testbed.h:654
+	float depth_supervision_lambda = 0.f;        // testbed.h:680
 	// error map (always-on accumulation, testbed_nerf.cu:2933-2939, 2971-3023)
 	DeviceBuffer error_map_data;
 	int32_t error_map_res[2] = {0, 0};
@@ -146,7 +149,7 @@ struct NerfTraining {
 	uint32_t cdf_mode() const { return is_cdf_valid ? (sample_focal_plane_proportional_to_error ? 1u : 0u) | (sample_image_proportional_to_error ? 2u : 0u) : 0u; }
 	const NgpErrorMapCdf* error_map_cdf(NgpErrorMapCdf& storage) const;   // NULL when both switches are off (3211-3212, 3243-3245)
 
-	void set_image(int frame_idx, int w, int h, const float* rgba_host);                 // python_api.cu:53-72 (float RGBA)
+	void set_image(int frame_idx, int w, int h, const float* rgba_host, const float* depth_host = nullptr, float depth_scale = -1.f);   // python_api.cu:53-72 (float RGBA, optional float depth)
 	void set_image_rgba8(int frame_idx, int w, int h, const uint8_t* rgba_host);         // Byte images as the PNG loader stores them (nerf_loader.cu:622-623)
 	void set_camera_extrinsics(int frame_idx, const Mat34& camera_to_world, bool convert_to_ngp = true); // testbed_nerf.cu:2539-2541
 	Mat34 get_camera_extrinsics(int frame_idx) const;

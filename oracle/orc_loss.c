@@ -62,7 +62,7 @@ void orc_compute_loss(
 	orc_coord* coords_out_all, uint16_t* dloss_doutput_all /* [max_samples_compacted][mlp_stride] */, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
-	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out) {
+	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type) {
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		uint32_t numsteps = numsteps_in[i * 2 + 0];
 		uint32_t base = numsteps_in[i * 2 + 1];
@@ -144,6 +144,21 @@ void orc_compute_loss(
 		uint16_t* dloss_doutput = dloss_doutput_all + (size_t)compacted_base * mlp_stride;
 
 		orc_lg lg = orc_loss_and_gradient(rgbtarget, rgb_ray, loss_type);
+		/* depth supervision (1450-1452) */
+		float depth_loss_gradient = 0.0f;
+		if (depth_supervision_lambda > 0.0f) {
+			float dval = -1.0f;
+			if (md->depth) {
+				int px = (int)(xy[0] * (float)md->res[0]), py = (int)(xy[1] * (float)md->res[1]);
+				px = px > 0 ? px : 0; px = px < md->res[0] - 1 ? px : md->res[0] - 1;
+				py = py > 0 ? py : 0; py = py < md->res[1] - 1 ? py : md->res[1] - 1;
+				dval = md->depth[(size_t)px + (size_t)py * (size_t)md->res[0]];
+			}
+			const float target_depth = orc_norm(rays_in_unnormalized[i].d) * dval;
+			const float t3[3] = {target_depth, target_depth, target_depth}, p3[3] = {depth_ray, depth_ray, depth_ray};
+			orc_lg lgd = orc_loss_and_gradient(t3, p3, depth_loss_type);
+			depth_loss_gradient = target_depth > 0.0f ? depth_supervision_lambda * lgd.gradient[0] : 0.0f;
+		}
 		{ const float pdf = img_pdf * xy_pdf; for (int c = 0; c < 3; ++c) lg.loss[c] /= pdf; }   /* 1448; == 1 without CDF sampling */
 		float mean_loss = (lg.loss[0] + lg.loss[1] + lg.loss[2]) / 3.0f;
 		if (loss_output) loss_output[i] = mean_loss / (float)n_rays;
@@ -199,15 +214,14 @@ void orc_compute_loss(
 				dl[c] = orc_f2h(ls * (dloss_by_drgb[c] * orc_network_to_rgb_derivative(lof[c], rgb_activation) + fmaxf(0.0f, output_l2_reg * lof[c])));
 			}
 			float density_derivative = orc_network_to_density_derivative(lof[3], density_activation);
-			/* depth supervision off: depth_loss_gradient == 0 (1450-1452) */
 			float dotv = lg.gradient[0] * (T * rgb[0] - suffix[0]) + lg.gradient[1] * (T * rgb[1] - suffix[1]) + lg.gradient[2] * (T * rgb[2] - suffix[2]);
-			float dloss_by_dmlp = density_derivative * (dt * (dotv + 0.0f));
+			const float depth_supervision = depth_loss_gradient * (T * depth - (depth_ray - depth_ray2));   /* 1536-1537 */
+			float dloss_by_dmlp = density_derivative * (dt * (dotv + depth_supervision));
 			dl[3] = orc_f2h(
 				ls * dloss_by_dmlp +
 				(lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) +
 				(lof[3] > -10.0f && depth < near_distance ? 1e-4f : 0.0f));
 		}
-		(void)depth_ray; (void)depth_ray2;
 	}
 }
 

@@ -38,3 +38,31 @@ def test_testbed_builds_cdfs_and_trains_with_importance_sampling(cuda, oracle):
     scene.train(t, 46)                    # trains UP TO step 46
     assert t.training_step == 46 and np.isfinite(t.loss) and t.loss < loss_before
     assert tr.measured_batch_size > 0
+
+
+def test_testbed_depth_supervision(cuda):
+    """nerf.training.set_image(frame, img, depth_img, depth_scale) + depth_supervision_lambda (python_api.cu:53-72, 809, 828): the depth
+    term pulls the expected termination depth of the training rays towards the supplied depth maps"""
+    import scene
+    import pyngp
+    ds = scene.make_dataset(n_train=6, n_test=1, res=48, device=cuda)
+    imgs = [np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x) for x in ds["train_images"]]
+
+    def run(lam):
+        t = scene.build_testbed(ds)
+        tr = t.nerf.training
+        for i, im in enumerate(imgs):
+            rgba = im.astype(np.float32) / 255.0 if im.dtype == np.uint8 else im.astype(np.float32)
+            rgba = rgba.copy(); rgba[..., :3] = np.where(rgba[..., :3] <= 0.04045, rgba[..., :3] / 12.92, ((rgba[..., :3] + 0.055) / 1.055) ** 2.4) * rgba[..., 3:4]
+            tr.set_image(i, rgba, np.full(rgba.shape[:2], 0.25, np.float32), 1.0)     # a (wrong) constant depth of 0.25 for every pixel
+        assert tr.depth_loss_type == pyngp.LossType.L1 and tr.depth_supervision_lambda == 0.0
+        tr.depth_supervision_lambda = lam
+        scene.train(t, 60)
+        assert np.isfinite(t.loss)
+        t.shall_train = False
+        t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+        return t.render(32, 32, 1, True)
+
+    free, pulled = run(0.0), run(5.0)
+    # with a strong pull towards a surface 0.25 in front of every camera the reconstruction differs visibly
+    assert np.abs(free - pulled).mean() > 5e-3

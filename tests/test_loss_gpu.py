@@ -51,7 +51,7 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
                             I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
                             o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None,
-                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None)
+                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2))
     # ---- device
     d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
              em=H.dev_zeros(n_img * 16 * 12 * 4, cuda), enc=H.dev_zeros(B * 64, cuda))
@@ -68,7 +68,7 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
                                    d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None,
-                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None))
+                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2)))
     g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
              loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"])
     return o, g
@@ -160,7 +160,44 @@ def test_compaction_carries_the_saved_encoding(ngp, oracle, cuda):
     # the two pointers go together
     assert ngp.ngp_hip_compute_loss(None, 1, I["aabb"].ctypes.data, 0, 1, 256, out.data_ptr(), H.f32(128.0), 4, np.zeros(3, np.float32).ctypes.data, 0, 0, 0, 1, out.data_ptr(),
                                     out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), 4, 0, None, 0, None,
-                                    2, 3, 0, None, None, out.data_ptr(), out.data_ptr(), H.f32(0.2), None, xs.data_ptr(), None) != 0
+                                    2, 3, 0, None, None, out.data_ptr(), out.data_ptr(), H.f32(0.2), None, xs.data_ptr(), None, H.f32(0.0), 2) != 0
+
+
+@pytest.mark.parametrize("depth_loss", [1, 0])
+def test_loss_with_depth_supervision(ngp, oracle, cuda, depth_loss):
+    """depth_supervision_lambda > 0 (testbed_nerf.cu:1450-1452, 1536-1541): extra density gradient from the expected termination depth vs
+    the depth image; images without depth (pointer NULL) are unaffected"""
+    I = _inputs(oracle, cuda)
+    n_img = len(I["xf"])
+    w, h = int(I["md_host"]["res"][0][0]), int(I["md_host"]["res"][0][1])
+    rs = np.random.RandomState(4)
+    depth = (0.4 + 1.5 * rs.rand(n_img, h, w)).astype(np.float32)
+    d_depth = H.to_dev(depth, cuda)
+    mh, mdv = I["md_host"].copy(), I["md_dev"].copy()
+    for k in range(n_img - 1):                       # the last image has no depth
+        mh["depth"][k] = depth[k].ctypes.data
+        mdv["depth"][k] = d_depth.data_ptr() + k * w * h * 4
+    I["md_host"], I["md_dev"] = mh, mdv
+    B = I["n_samples"] + 128
+    I["depth_lambda"], I["depth_loss"] = 0.0, depth_loss
+    o0, g0 = _run(ngp, oracle, cuda, I, 0, B)
+    I["depth_lambda"] = 0.7
+    o, g = _run(ngp, oracle, cuda, I, 0, B)
+    border = _borderline_rays(I)
+    keep = [i for i in range(I["n_alive"]) if i not in border and int(o["ns"][2 * i]) == int(g["ns"][2 * i]) and int(o["ns"][2 * i]) > 0]
+    changed = unchanged = 0
+    for i in keep[::max(1, len(keep) // 600)]:            # rays are ordered by image: sample all of them
+        n, bo, bg_ = int(o["ns"][2 * i]), int(o["ns"][2 * i + 1]), int(g["ns"][2 * i + 1])
+        a, b = g["dl"][bg_:bg_ + n].astype(np.float32), o["dl"][bo:bo + n].astype(np.float32)
+        np.testing.assert_allclose(a, b, rtol=4e-3, atol=1e-5)
+        b0 = o0["dl"][int(o0["ns"][2 * i + 1]):int(o0["ns"][2 * i + 1]) + n].astype(np.float32)
+        np.testing.assert_array_equal(b[:, :3], b0[:, :3])          # colour gradients do not see the depth term
+        img = (int(I["r"]["idx"][i]) * n_img // I["n_rays"]) % n_img
+        if img == n_img - 1:
+            np.testing.assert_array_equal(b[:, 3], b0[:, 3]); unchanged += 1
+        elif not np.array_equal(b[:, 3], b0[:, 3]):
+            changed += 1
+    assert changed > 100 and unchanged > 10
 
 
 @pytest.mark.parametrize("cdf_mode", [1, 3])
