@@ -147,7 +147,6 @@ __device__ __forceinline__ bool mask_intersects_ray(const NgpMask3D& m, v3 ro, v
 }
 
 // ---- camera_models.cuh
-__device__ __forceinline__ v3 lerp3(const float* a, const float* b, float t) { return mk(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])); }
 
 __global__ void __launch_bounds__(128) init_global_rays_kernel(uint32_t sample_index, NgpGlobalRay* __restrict__ rays, float* __restrict__ depthbuffer, const NgpDownsampleInfo ds, const NgpRenderCamera cam) {
 	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
@@ -166,47 +165,10 @@ __global__ void __launch_bounds__(128) init_global_rays_kernel(uint32_t sample_i
 		origin = mat3_mul(c, mk(0.f, 0.f, 0.f)) + col(c, 3);
 		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
 		origin = origin + dir * cam.near_distance;
-	} else if (cam.model == 2) {  // spherical_quadrilateral_pixel_to_ray (162-203)
-		const float PI = 3.14159265358979323846f;
-		const float max_linear_len = sqrtf(cam.sq_width * cam.sq_width + cam.sq_height * cam.sq_height);
-		const float ux = 2.0f * (((float)x + 0.5f) / rx - 0.5f), uy = 2.0f * (((float)y + 0.5f) / ry - 0.5f);
-		const float qx = cam.sq_width * ux, qy = cam.sq_height * uy;
-		const float a = atan2f(qy, qx), r = sqrtf(qx * qx + qy * qy);
-		// walk_along_sphere -> walk_along_circle (133-160)
-		float wx = 0.0f, wz = 0.0f;
-		const float arc_t = r / (2.0f * max_linear_len);
-		if (!(arc_t == 0.0f || max_linear_len == 0.0f)) {
-			if (cam.sq_curvature == 0.0f) { wx = max_linear_len * arc_t; wz = 0.0f; }
-			else {
-				const float tpc = 2.0f * PI * cam.sq_curvature;
-				const float s_tpc = max_linear_len / tpc;
-				wx = s_tpc * sinf(tpc * arc_t); wz = s_tpc * (1.0f - cosf(tpc * arc_t));
-			}
-		}
-		origin = mk(wx * cosf(a), wx * sinf(a), wz);
-		dir = mk(0.0f, 0.0f, 1.0f);
-		if (cam.sq_curvature != 0.0f) {
-			const v3 sc = mk(0.0f, 0.0f, max_linear_len / (2.0f * PI * cam.sq_curvature));
-			const float k = cam.sq_curvature > 0.0f ? 1.0f : -1.0f;
-			dir = normalized(sc - origin) * k;
-		}
-		origin = mat3_mul(c, origin) + col(c, 3);
-		dir = mat3_mul(c, dir);
-		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
-		origin = origin + dir * cam.near_distance;
-	} else {  // quadrilateral_hexahedron_pixel_to_ray (80-118)
-		const float u = ((float)x + 0.5f) / rx, v = ((float)y + 0.5f) / ry;
-		const float *f = cam.qh_front, *b = cam.qh_back;
-		const v3 f_ab = lerp3(f + 0, f + 3, u), f_dc = lerp3(f + 6, f + 9, u);
-		const v3 front_p = f_ab + (f_dc - f_ab) * v;
-		const v3 b_ab = lerp3(b + 0, b + 3, u), b_dc = lerp3(b + 6, b + 9, u);
-		const v3 back_p = b_ab + (b_dc - b_ab) * v;
-		dir = front_p - back_p;
-		dir = mk(dir.x / dir.z, dir.y / dir.z, dir.z / dir.z);
-		origin = mat3_mul(c, back_p) + col(c, 3);
-		dir = mat3_mul(c, dir);
-		apply_aperture(sample_index, x, y, c, cam.aperture_size, cam.focus_z, origin, dir);
-		origin = origin + dir * cam.near_distance;
+	} else if (cam.model == 2) {
+		spherical_quadrilateral_pixel_to_ray(sample_index, x, y, rx, ry, c, cam.sq_width, cam.sq_height, cam.sq_curvature, cam.near_distance, cam.focus_z, cam.aperture_size, origin, dir);
+	} else {
+		quadrilateral_hexahedron_pixel_to_ray(sample_index, x, y, rx, ry, c, cam.qh_front, cam.qh_back, cam.near_distance, cam.focus_z, cam.aperture_size, origin, dir);
 	}
 	depthbuffer[idx] = 1e10f;
 	NgpGlobalRay ray;

@@ -148,6 +148,55 @@ __device__ __forceinline__ void apply_aperture(uint32_t spp, uint32_t px, uint32
 	}
 }
 
+// ---- the fork's extra camera models (camera_models.cuh), shared by the stock renderer and the Blender renderer.  c = 3x4 column-major
+// camera-to-world, (x, y) = pixel, (rx, ry) = resolution
+__device__ __forceinline__ v3 lerp3(const float* a, const float* b, float t) { return mk(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])); }
+// spherical_quadrilateral_pixel_to_ray (camera_models.cuh:162-203) with walk_along_sphere / walk_along_circle (133-160)
+__device__ __forceinline__ void spherical_quadrilateral_pixel_to_ray(uint32_t spp, uint32_t x, uint32_t y, float rx, float ry, const float* c, float sq_width, float sq_height, float sq_curvature,
+                                                                     float near_distance, float focus_z, float aperture_size, v3& origin, v3& dir) {
+	const float PI = 3.14159265358979323846f;
+	const float max_linear_len = sqrtf(sq_width * sq_width + sq_height * sq_height);
+	const float ux = 2.0f * (((float)x + 0.5f) / rx - 0.5f), uy = 2.0f * (((float)y + 0.5f) / ry - 0.5f);
+	const float qx = sq_width * ux, qy = sq_height * uy;
+	const float a = atan2f(qy, qx), r = sqrtf(qx * qx + qy * qy);
+	float wx = 0.0f, wz = 0.0f;
+	const float arc_t = r / (2.0f * max_linear_len);
+	if (!(arc_t == 0.0f || max_linear_len == 0.0f)) {
+		if (sq_curvature == 0.0f) { wx = max_linear_len * arc_t; wz = 0.0f; }
+		else {
+			const float tpc = 2.0f * PI * sq_curvature;
+			const float s_tpc = max_linear_len / tpc;
+			wx = s_tpc * sinf(tpc * arc_t); wz = s_tpc * (1.0f - cosf(tpc * arc_t));
+		}
+	}
+	origin = mk(wx * cosf(a), wx * sinf(a), wz);
+	dir = mk(0.0f, 0.0f, 1.0f);
+	if (sq_curvature != 0.0f) {
+		const v3 sc = mk(0.0f, 0.0f, max_linear_len / (2.0f * PI * sq_curvature));
+		const float k = sq_curvature > 0.0f ? 1.0f : -1.0f;
+		dir = normalized(sc - origin) * k;
+	}
+	origin = mat3_mul(c, origin) + col(c, 3);
+	dir = mat3_mul(c, dir);
+	apply_aperture(spp, x, y, c, aperture_size, focus_z, origin, dir);
+	origin = origin + dir * near_distance;
+}
+// quadrilateral_hexahedron_pixel_to_ray (camera_models.cuh:80-118): front / back = tl, tr, bl, br corners of the two faces
+__device__ __forceinline__ void quadrilateral_hexahedron_pixel_to_ray(uint32_t spp, uint32_t x, uint32_t y, float rx, float ry, const float* c, const float* f, const float* b,
+                                                                      float near_distance, float focus_z, float aperture_size, v3& origin, v3& dir) {
+	const float u = ((float)x + 0.5f) / rx, v = ((float)y + 0.5f) / ry;
+	const v3 f_ab = lerp3(f + 0, f + 3, u), f_dc = lerp3(f + 6, f + 9, u);
+	const v3 front_p = f_ab + (f_dc - f_ab) * v;
+	const v3 b_ab = lerp3(b + 0, b + 3, u), b_dc = lerp3(b + 6, b + 9, u);
+	const v3 back_p = b_ab + (b_dc - b_ab) * v;
+	dir = front_p - back_p;
+	dir = mk(dir.x / dir.z, dir.y / dir.z, dir.z / dir.z);
+	origin = mat3_mul(c, back_p) + col(c, 3);
+	dir = mat3_mul(c, dir);
+	apply_aperture(spp, x, y, c, aperture_size, focus_z, origin, dir);
+	origin = origin + dir * near_distance;
+}
+
 // ---- error-map importance sampling (testbed_nerf.cu:991-1083; off by default, testbed.h:668-669)
 struct ErrorMapCdf { const float* cdf_x_cond_y; const float* cdf_y; const float* cdf_img; int32_t res[2]; };
 // common.h:201-224

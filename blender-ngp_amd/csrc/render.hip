@@ -11,6 +11,7 @@ struct InitRaysArgs {
 	uint32_t sample_index; NgpPayload* payloads; int32_t res[2]; float focal_length[2]; Mat34 cam0, cam1; float rolling_shutter[4];
 	float screen_center[2]; float parallax_shift[3]; int snap_to_pixel_centers; Aabb render_aabb; Mat33 to_local; float near_distance;
 	int lens_mode; float lens_params[7]; float* depthbuffer; float plane_z, aperture_size;
+	int camera_model; float sq_width, sq_height, sq_curvature; float qh_front[12], qh_back[12];   // camera_models.cuh (0 = Perspective)
 };
 
 __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
@@ -30,6 +31,10 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	const float pu = ((float)x + ox) / (float)a.res[0], pv = ((float)y + oy) / (float)a.res[1];
 	v3 dir, origin;
 	bool outside = false;
+	if (a.camera_model != 0) {       // the fork's extra camera models (1868-1908); they ignore lens, parallax shift and screen centre
+		if (a.camera_model == 2) spherical_quadrilateral_pixel_to_ray(a.sample_index, x, y, (float)a.res[0], (float)a.res[1], cam, a.sq_width, a.sq_height, a.sq_curvature, a.near_distance, a.plane_z, aperture_size, origin, dir);
+		else quadrilateral_hexahedron_pixel_to_ray(a.sample_index, x, y, (float)a.res[0], (float)a.res[1], cam, a.qh_front, a.qh_back, a.near_distance, a.plane_z, aperture_size, origin, dir);
+	} else {
 	if (a.lens_mode == 2) {          // FTheta
 		dir = f_theta_undistortion(pu - a.screen_center[0], pv - a.screen_center[1], a.lens_params, mk(1000.f, 0.f, 0.f));
 		outside = dir.x == 1000.f;   // the reference returns a ray from (1000, 0, 0): outside the aabb, the pixel is not rendered
@@ -48,6 +53,7 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 		origin = mat3_mul(cam, head_pos) + col(cam, 3);
 		apply_aperture(a.sample_index, x, y, cam, aperture_size, a.plane_z, origin, dir);   // depth of field (307-312)
 		origin = origin + dir * a.near_distance;
+	}
 	}
 
 	NgpPayload p = a.payloads[idx];
@@ -301,9 +307,16 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
                       const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
-                      float plane_z, float aperture_size) {
+                      float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host) {
 	InitRaysArgs a;
 	a.plane_z = plane_z; a.aperture_size = aperture_size;
+	a.camera_model = camera_models_host ? camera_models_host->model : 0;
+	a.sq_width = a.sq_height = a.sq_curvature = 0.f;
+	for (int i = 0; i < 12; ++i) { a.qh_front[i] = 0.f; a.qh_back[i] = 0.f; }
+	if (camera_models_host) {
+		a.sq_width = camera_models_host->sq_width; a.sq_height = camera_models_host->sq_height; a.sq_curvature = camera_models_host->sq_curvature;
+		for (int i = 0; i < 12; ++i) { a.qh_front[i] = camera_models_host->qh_front[i]; a.qh_back[i] = camera_models_host->qh_back[i]; }
+	}
 	a.sample_index = sample_index; a.payloads = payloads; a.res[0] = res_host[0]; a.res[1] = res_host[1];
 	a.focal_length[0] = focal_length_host[0]; a.focal_length[1] = focal_length_host[1];
 	a.cam0 = mat34_from_host(camera_matrix0_host); a.cam1 = mat34_from_host(camera_matrix1_host);

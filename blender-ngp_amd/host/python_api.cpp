@@ -169,7 +169,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("center", [](const QuadrilateralHexahedron& q) { return vec3_to_py(q.center()); });
 	py::class_<SphericalQuadrilateral>(m, "SphericalQuadrilateralConfig")
 		.def_static("Zero", []() { return SphericalQuadrilateral{}; })
-		.def(py::init([](float w, float h, float c) { return SphericalQuadrilateral{w, h, c}; }), py::arg("width"), py::arg("height"), py::arg("curvature"));
+		.def(py::init([](float w, float h, float c) { return SphericalQuadrilateral{w, h, c}; }), py::arg("width"), py::arg("height"), py::arg("curvature"))
+		.def_readwrite("width", &SphericalQuadrilateral::width).def_readwrite("height", &SphericalQuadrilateral::height).def_readwrite("curvature", &SphericalQuadrilateral::curvature);
 
 	py::class_<Mask3D>(m, "Mask3D")
 		.def_static("Box", [](const py::object& dims, const py::array_t<float, py::array::c_style | py::array::forcecast>& t, EMaskMode mode, float feather, float opacity) {
@@ -325,6 +326,21 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("train_nerf_dp_backward", &Testbed::train_nerf_dp_backward, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size"), py::arg("measured_before_compaction"), py::arg("measured"),
 			py::arg("get_loss_scalar") = false, py::arg("loss_sum") = 0.f)
 		.def("train_nerf_dp_end", &Testbed::train_nerf_dp_end, py::call_guard<py::gil_scoped_release>())
+		.def_property("render_camera_model", [](Testbed& t) { return (ECameraModel)t.m_render_camera_models.model; },          // python_api.cu:691-693
+			[](Testbed& t, ECameraModel m) { t.m_render_camera_models.model = (int)m; })
+		.def_property("camera_spherical_quadrilateral",
+			[](Testbed& t) { SphericalQuadrilateral q; q.width = t.m_render_camera_models.sq_width; q.height = t.m_render_camera_models.sq_height; q.curvature = t.m_render_camera_models.sq_curvature; return q; },
+			[](Testbed& t, const SphericalQuadrilateral& q) { t.m_render_camera_models.sq_width = q.width; t.m_render_camera_models.sq_height = q.height; t.m_render_camera_models.sq_curvature = q.curvature; })
+		.def_property("camera_quadrilateral_hexahedron",
+			[](Testbed& t) {
+				QuadrilateralHexahedron h; Quadrilateral3D* q[2] = {&h.front, &h.back}; const float* src[2] = {t.m_render_camera_models.qh_front, t.m_render_camera_models.qh_back};
+				for (int k = 0; k < 2; ++k) { Vec3* v[4] = {&q[k]->tl, &q[k]->tr, &q[k]->bl, &q[k]->br}; for (int i = 0; i < 4; ++i) { v[i]->x = src[k][3 * i]; v[i]->y = src[k][3 * i + 1]; v[i]->z = src[k][3 * i + 2]; } }
+				return h;
+			},
+			[](Testbed& t, const QuadrilateralHexahedron& h) {
+				const Quadrilateral3D* q[2] = {&h.front, &h.back}; float* dst[2] = {t.m_render_camera_models.qh_front, t.m_render_camera_models.qh_back};
+				for (int k = 0; k < 2; ++k) { const Vec3 v[4] = {q[k]->tl, q[k]->tr, q[k]->bl, q[k]->br}; for (int i = 0; i < 4; ++i) { dst[k][3 * i] = v[i].x; dst[k][3 * i + 1] = v[i].y; dst[k][3 * i + 2] = v[i].z; } }
+			})
 		.def_readwrite("slice_plane_z", &Testbed::m_slice_plane_z)          // python_api.cu:662-666
 		.def_readwrite("dof", &Testbed::m_aperture_size)
 		.def_readwrite("aperture_size", &Testbed::m_aperture_size)

@@ -925,7 +925,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	const uint32_t sample_index = rb.spp;
 	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, zero4, screen_center, zero3, m_snap_to_pixel_centers,
 	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
-	                        m_slice_plane_z + m_scale /* plane_z (2355); the Slice render mode, which negates it, is not built */, m_aperture_size), "init_rays");
+	                        m_slice_plane_z + m_scale /* plane_z (2355); the Slice render mode, which negates it, is not built */, m_aperture_size,
+	                        m_render_camera_models.model ? &m_render_camera_models : nullptr), "init_rays");
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_rgba[0].data(), 0, (size_t)n_pixels * 16, (hipStream_t)m_stream));
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;

@@ -55,6 +55,14 @@ typedef struct {                                                     /* nerf_loa
 	const float* depth;       /* device or NULL */
 	const NgpRay* rays;       /* device or NULL */
 } NgpImageMeta;
+typedef struct {                                                     /* render_request.cuh:55-103 RenderCameraProperties */
+	float transform[12];      /* 3x4 column-major camera-to-world */
+	int32_t model;            /* camera_models.cuh:27-31: 0 Perspective, 1 QuadrilateralHexahedron, 2 SphericalQuadrilateral */
+	float focal_length;
+	float sq_width, sq_height, sq_curvature;          /* SphericalQuadrilateral */
+	float qh_front[12], qh_back[12];                  /* QuadrilateralHexahedron: tl, tr, bl, br of each face */
+	float near_distance, aperture_size, focus_z;
+} NgpRenderCamera;
 typedef struct {                                                     /* testbed.h:603-616 ErrorMap CDFs as the kernels take them (testbed_nerf.cu:3243-3245) */
 	const float* cdf_x_cond_y; /* device [n_images][res[1]][res[0]] or NULL (sample_focal_plane_proportional_to_error off) */
 	const float* cdf_y;        /* device [n_images][res[1]]         or NULL (same switch) */
@@ -208,7 +216,8 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
                       const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host,
-                      float* depthbuffer, float plane_z /* focus distance; < 0: slice plane at -plane_z */, float aperture_size /* 0: pinhole */);   /* :1809 */
+                      float* depthbuffer, float plane_z /* focus distance; < 0: slice plane at -plane_z */, float aperture_size /* 0: pinhole */,
+                      const NgpRenderCamera* camera_models_host /* NULL or model 0: Perspective; else only model / sq_* / qh_* are read (:1868-1908) */);   /* :1809 */
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
                         uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant); /* :612 */
 int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,
@@ -297,14 +306,6 @@ typedef struct {                                                     /* nerf_pro
 	float opacity;
 } NgpNerfProps;
 typedef struct { int32_t max_res[2], scaled_res[2], skip[2]; uint32_t max_pixels, scaled_pixels; } NgpDownsampleInfo;   /* common.h:337-355 MakeFromMip */
-typedef struct {                                                     /* render_request.cuh:55-103 RenderCameraProperties */
-	float transform[12];      /* 3x4 column-major camera-to-world */
-	int32_t model;            /* camera_models.cuh:27-31: 0 Perspective, 1 QuadrilateralHexahedron, 2 SphericalQuadrilateral */
-	float focal_length;
-	float sq_width, sq_height, sq_curvature;          /* SphericalQuadrilateral */
-	float qh_front[12], qh_back[12];                  /* QuadrilateralHexahedron: tl, tr, bl, br of each face */
-	float near_distance, aperture_size, focus_z;
-} NgpRenderCamera;
 
 int ngp_hip_multi_init_global_rays(void* stream, uint32_t sample_index, NgpGlobalRay* rays, float* depthbuffer, const NgpDownsampleInfo* ds_host,
                                    const NgpRenderCamera* camera_host);                                                        /* nerf_renderer.cu:17-94 */

@@ -102,7 +102,9 @@ void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uin
 void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout);
 
 /* orc_render.c */
-void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size);
+void orc_extra_camera_model_pixel_to_ray(int model, uint32_t spp, uint32_t x, uint32_t y, float rx, float ry, const float* c, float sq_width, float sq_height, float sq_curvature,
+                                         const float* qh_front, const float* qh_back, float near_distance, float focus_z, float aperture_size, orc_vec3* origin, orc_vec3* dir);
+void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size, const orc_render_camera* camera_models);
 void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index, orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant);
 void orc_compact_rays(uint32_t n_elements, const float* src_rgba, const float* src_depth, const orc_payload* src_payloads, float* dst_rgba, float* dst_depth, orc_payload* dst_payloads, float* dst_final_rgba, float* dst_final_depth, orc_payload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);
 void orc_generate_next_inputs(uint32_t n_elements, const orc_aabb* render_aabb, const orc_aabb* train_aabb, orc_payload* payloads, orc_coord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant);

@@ -180,6 +180,52 @@ void orc_downsample_info_from_mip(const int32_t resolution[2], uint32_t mip, orc
 	}
 }
 
+/* camera_models.cuh: the two extra camera models (model 2 SphericalQuadrilateral, 1 QuadrilateralHexahedron); c = 3x4 column-major camera matrix */
+void orc_extra_camera_model_pixel_to_ray(int model, uint32_t spp, uint32_t x, uint32_t y, float rx, float ry, const float* c, float sq_width, float sq_height, float sq_curvature,
+                                         const float* qh_front, const float* qh_back, float near_distance, float focus_z, float aperture_size, orc_vec3* origin, orc_vec3* dir) {
+	if (model == 2) {     /* spherical_quadrilateral_pixel_to_ray, :162-203 */
+			const float PI = 3.14159265358979323846f;
+			float max_linear_len = sqrtf(sq_width * sq_width + sq_height * sq_height);
+			float ux = 2.0f * (((float)x + 0.5f) / rx - 0.5f), uy = 2.0f * (((float)y + 0.5f) / ry - 0.5f);
+			float qx = sq_width * ux, qy = sq_height * uy;
+			float a = atan2f(qy, qx), r = sqrtf(qx * qx + qy * qy);
+			float wx = 0.0f, wz = 0.0f;
+			float arc_t = r / (2.0f * max_linear_len);
+			if (!(arc_t == 0.0f || max_linear_len == 0.0f)) {
+				if (sq_curvature == 0.0f) { wx = max_linear_len * arc_t; wz = 0.0f; }
+				else {
+					float tpc = 2.0f * PI * sq_curvature;
+					float s_tpc = max_linear_len / tpc;
+					wx = s_tpc * sinf(tpc * arc_t); wz = s_tpc * (1.0f - cosf(tpc * arc_t));
+				}
+			}
+			*origin = orc_v3(wx * cosf(a), wx * sinf(a), wz);
+			*dir = orc_v3(0.0f, 0.0f, 1.0f);
+			if (sq_curvature != 0.0f) {
+				orc_vec3 sc = orc_v3(0.0f, 0.0f, max_linear_len / (2.0f * PI * sq_curvature));
+				float k = sq_curvature > 0.0f ? 1.0f : -1.0f;
+				*dir = orc_scale(orc_normalized(orc_sub(sc, *origin)), k);
+			}
+			*origin = orc_add(orc_mat3_mul(c, *origin), orc_col(c, 3));
+			*dir = orc_mat3_mul(c, *dir);
+			apply_aperture(spp, x, y, c, aperture_size, focus_z, origin, dir);
+			*origin = orc_add(*origin, orc_scale(*dir, near_distance));
+	} else {                          /* quadrilateral_hexahedron_pixel_to_ray, :80-118 */
+			float u = ((float)x + 0.5f) / rx, v = ((float)y + 0.5f) / ry;
+			const float *f = qh_front, *b = qh_back;
+			orc_vec3 f_ab = lerp3(f + 0, f + 3, u), f_dc = lerp3(f + 6, f + 9, u);
+			orc_vec3 front_p = orc_add(f_ab, orc_scale(orc_sub(f_dc, f_ab), v));
+			orc_vec3 b_ab = lerp3(b + 0, b + 3, u), b_dc = lerp3(b + 6, b + 9, u);
+			orc_vec3 back_p = orc_add(b_ab, orc_scale(orc_sub(b_dc, b_ab), v));
+			*dir = orc_sub(front_p, back_p);
+			*dir = orc_v3(dir->x / dir->z, dir->y / dir->z, dir->z / dir->z);
+			*origin = orc_add(orc_mat3_mul(c, back_p), orc_col(c, 3));
+			*dir = orc_mat3_mul(c, *dir);
+			apply_aperture(spp, x, y, c, aperture_size, focus_z, origin, dir);
+			*origin = orc_add(*origin, orc_scale(*dir, near_distance));
+		}
+}
+
 void orc_multi_init_global_rays(uint32_t sample_index, orc_global_ray* rays, float* depthbuffer, const orc_downsample_info* ds, const orc_render_camera* cam) { /* nerf_renderer.cu:17-94 */
 	for (int32_t ty = 0; ty < ds->scaled_res[1]; ++ty) for (int32_t tx = 0; tx < ds->scaled_res[0]; ++tx) {
 		uint32_t x = (uint32_t)tx, y = (uint32_t)ty;
@@ -198,46 +244,9 @@ void orc_multi_init_global_rays(uint32_t sample_index, orc_global_ray* rays, flo
 			origin = orc_add(orc_mat3_mul(c, orc_v3(0.f, 0.f, 0.f)), orc_col(c, 3));
 			apply_aperture(sample_index, x, y, c, cam->aperture_size, cam->focus_z, &origin, &dir);
 			origin = orc_add(origin, orc_scale(dir, cam->near_distance));
-		} else if (cam->model == 2) {     /* spherical_quadrilateral_pixel_to_ray, :162-203 */
-			const float PI = 3.14159265358979323846f;
-			float max_linear_len = sqrtf(cam->sq_width * cam->sq_width + cam->sq_height * cam->sq_height);
-			float ux = 2.0f * (((float)x + 0.5f) / rx - 0.5f), uy = 2.0f * (((float)y + 0.5f) / ry - 0.5f);
-			float qx = cam->sq_width * ux, qy = cam->sq_height * uy;
-			float a = atan2f(qy, qx), r = sqrtf(qx * qx + qy * qy);
-			float wx = 0.0f, wz = 0.0f;
-			float arc_t = r / (2.0f * max_linear_len);
-			if (!(arc_t == 0.0f || max_linear_len == 0.0f)) {
-				if (cam->sq_curvature == 0.0f) { wx = max_linear_len * arc_t; wz = 0.0f; }
-				else {
-					float tpc = 2.0f * PI * cam->sq_curvature;
-					float s_tpc = max_linear_len / tpc;
-					wx = s_tpc * sinf(tpc * arc_t); wz = s_tpc * (1.0f - cosf(tpc * arc_t));
-				}
-			}
-			origin = orc_v3(wx * cosf(a), wx * sinf(a), wz);
-			dir = orc_v3(0.0f, 0.0f, 1.0f);
-			if (cam->sq_curvature != 0.0f) {
-				orc_vec3 sc = orc_v3(0.0f, 0.0f, max_linear_len / (2.0f * PI * cam->sq_curvature));
-				float k = cam->sq_curvature > 0.0f ? 1.0f : -1.0f;
-				dir = orc_scale(orc_normalized(orc_sub(sc, origin)), k);
-			}
-			origin = orc_add(orc_mat3_mul(c, origin), orc_col(c, 3));
-			dir = orc_mat3_mul(c, dir);
-			apply_aperture(sample_index, x, y, c, cam->aperture_size, cam->focus_z, &origin, &dir);
-			origin = orc_add(origin, orc_scale(dir, cam->near_distance));
-		} else {                          /* quadrilateral_hexahedron_pixel_to_ray, :80-118 */
-			float u = ((float)x + 0.5f) / rx, v = ((float)y + 0.5f) / ry;
-			const float *f = cam->qh_front, *b = cam->qh_back;
-			orc_vec3 f_ab = lerp3(f + 0, f + 3, u), f_dc = lerp3(f + 6, f + 9, u);
-			orc_vec3 front_p = orc_add(f_ab, orc_scale(orc_sub(f_dc, f_ab), v));
-			orc_vec3 b_ab = lerp3(b + 0, b + 3, u), b_dc = lerp3(b + 6, b + 9, u);
-			orc_vec3 back_p = orc_add(b_ab, orc_scale(orc_sub(b_dc, b_ab), v));
-			dir = orc_sub(front_p, back_p);
-			dir = orc_v3(dir.x / dir.z, dir.y / dir.z, dir.z / dir.z);
-			origin = orc_add(orc_mat3_mul(c, back_p), orc_col(c, 3));
-			dir = orc_mat3_mul(c, dir);
-			apply_aperture(sample_index, x, y, c, cam->aperture_size, cam->focus_z, &origin, &dir);
-			origin = orc_add(origin, orc_scale(dir, cam->near_distance));
+		} else {
+			orc_extra_camera_model_pixel_to_ray(cam->model, sample_index, x, y, rx, ry, c, cam->sq_width, cam->sq_height, cam->sq_curvature, cam->qh_front, cam->qh_back,
+			                                    cam->near_distance, cam->focus_z, cam->aperture_size, &origin, &dir);
 		}
 		depthbuffer[idx] = 1e10f;
 		orc_global_ray* ray = &rays[idx];

@@ -62,7 +62,8 @@ static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[
 void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2],
                    const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2],
                    const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local /* 3x3 */,
-                   float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size) {
+                   float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size,
+                   const orc_render_camera* camera_models /* NULL or model 0: Perspective; only model / sq_* / qh_* are read (1868-1908) */) {
 	if (plane_z < 0) aperture_size = 0.0f;   /* :1849-1851 */
 	for (int y = 0; y < res[1]; ++y) for (int x = 0; x < res[0]; ++x) {
 		uint32_t idx = (uint32_t)x + (uint32_t)res[0] * (uint32_t)y;
@@ -71,7 +72,13 @@ void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t r
 		float ray_time = rolling_shutter[0] + rolling_shutter[1] * u + rolling_shutter[2] * v + rolling_shutter[3] * orc_ld_random_val(sample_index, idx * 72239731u, 0);
 		float cam[12];
 		for (int k = 0; k < 12; ++k) cam[k] = camera_matrix0[k] * ray_time + camera_matrix1[k] * (1.f - ray_time);
-		orc_ray ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params, plane_z, aperture_size);
+		orc_ray ray;
+		if (camera_models && camera_models->model != 0) {
+			orc_extra_camera_model_pixel_to_ray(camera_models->model, sample_index, (uint32_t)x, (uint32_t)y, (float)res[0], (float)res[1], cam, camera_models->sq_width, camera_models->sq_height,
+			                                    camera_models->sq_curvature, camera_models->qh_front, camera_models->qh_back, near_distance, plane_z, aperture_size, &ray.o, &ray.d);
+		} else {
+			ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params, plane_z, aperture_size);
+		}
 
 		orc_payload* p = &payloads[idx];
 		p->max_weight = 0.0f;
@@ -334,7 +341,7 @@ uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, u
 	uint16_t* net_out = (uint16_t*)calloc((size_t)n_pixels * 8 * 4, 2);
 
 	orc_init_rays(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
-	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f);
+	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f, NULL);
 	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant);
 
 	uint32_t n_alive = n_pixels, n_hit = 0, i = 1, dbi = 0;

@@ -6,6 +6,7 @@ exp/pow and are compared with rtol 2e-3 (v_exp_f32 / v_log_f32 based device func
 import numpy as np
 import pytest
 
+import capi
 import helpers as H
 from capi import check
 
@@ -21,7 +22,7 @@ def _camera():
     return cam, focal, res, sc
 
 
-def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plane_z=1.0, aperture=0.0, exact=True):
+def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plane_z=1.0, aperture=0.0, exact=True, cam_models=None):
     cam, focal, res, sc = _camera()
     aabb = H.unit_aabb(2 ** (n_cascades - 1))
     grid = H.blob_density_grid(n_cascades)
@@ -32,10 +33,10 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plan
     pay = np.zeros(n, H.PAYLOAD)
     depth = np.zeros(n, np.float32)
     oracle.orc_init_rays(spp, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(plane_z), H.f32(aperture))
+                         snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(plane_z), H.f32(aperture), cam_models.ctypes.data if cam_models is not None else None)
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(plane_z), H.f32(aperture)))
+                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(plane_z), H.f32(aperture), cam_models.ctypes.data if cam_models is not None else None))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
     if not exact:   # depth of field: the lens-disk sample goes through cosf / sinf (device intrinsics vs libm)
         same = g["alive"] == pay["alive"]
@@ -88,6 +89,30 @@ def test_init_rays_depth_of_field(ngp, oracle, cuda):
     tz0 = 1.7 / (d0 @ fwd)
     tz = ((o0 + d0 * tz0[:, None] - o) @ fwd) / (d @ fwd)
     np.testing.assert_allclose(o + d * tz[:, None], o0 + d0 * tz0[:, None], atol=2e-5)
+
+
+def _camera_models(model, W_, H_):
+    c = np.zeros(1, dtype=capi.RENDER_CAMERA)
+    c["model"] = model
+    c["sq_width"], c["sq_height"], c["sq_curvature"] = 0.6, 0.45, 0.35
+    # a frustum-like hexahedron in camera space: small back face at z = 0, larger front face at z = 1 (tl, tr, bl, br)
+    c["qh_back"][0] = np.array([[-0.1, -0.08, 0.0], [0.1, -0.08, 0.0], [-0.1, 0.08, 0.0], [0.1, 0.08, 0.0]], np.float32).reshape(-1)
+    c["qh_front"][0] = np.array([[-0.7, -0.5, 1.0], [0.7, -0.5, 1.0], [-0.7, 0.5, 1.0], [0.7, 0.5, 1.0]], np.float32).reshape(-1)
+    return c
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_init_rays_extra_camera_models(ngp, oracle, cuda, model):
+    """ECameraModel::QuadrilateralHexahedron (1) / SphericalQuadrilateral (2) in the stock tracer (testbed_nerf.cu:1868-1908, camera_models.cuh):
+    the same device functions the Blender renderer uses, here against the oracle; sinf / cosf / atan2f differ from libm in the last bits"""
+    S = _init_and_advance(ngp, oracle, cuda, 1, 0, exact=False, cam_models=_camera_models(model, W, Hh))
+    assert S["al"].sum() > 100
+    P0 = _init_and_advance(ngp, oracle, cuda, 1, 0)["pay"]
+    both = S["al"] & (P0["alive"] == 1)
+    assert both.sum() > 20 and np.abs(S["pay"]["dir"][both] - P0["dir"][both]).max() > 1e-2       # not the pinhole rays
+    if model == 2:   # rays start on the curved sensor surface, not at the camera centre
+        cam = S["cam"].reshape(4, 3)
+        assert np.linalg.norm(S["pay"]["origin"][S["al"]] - cam[3], axis=1).max() > 0.1
 
 
 def test_init_rays_slice_plane(ngp, oracle, cuda):
@@ -213,7 +238,7 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     fb, db = H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda)
     cnt, hcnt = H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)
     check(ngp.ngp_hip_init_rays(None, 0, pay[0].data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0)))
+                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0), None))
     check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0)))
     n_alive, i, dbi = n, 1, 0
     while i < 10000:
@@ -260,10 +285,10 @@ def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
         lp[5], lp[6] = W, Hh
     pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
     oracle.orc_init_rays(2, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data, H.f32(1.0), H.f32(0.0))
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None)
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, 2, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0)))
+                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0), None))
     g = H.to_host(d_pay, H.PAYLOAD)
     same = g["alive"] == pay["alive"]
     assert same.mean() > 0.995                      # a ray grazing the box may flip with a 1-ulp different direction
@@ -276,7 +301,7 @@ def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
     # the lens actually bends the rays: directions differ from the pinhole ones
     pin = np.zeros(n, H.PAYLOAD)
     oracle.orc_init_rays(2, pin.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0))
+                         0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None)
     both = al & (pin["alive"] == 1)
     assert both.sum() > 50 and np.abs(pin["dir"][both] - pay["dir"][both]).max() > 1e-3
 
@@ -307,3 +332,26 @@ def test_pyngp_depth_of_field_and_autofocus(cuda):
     t.aperture_size = 0.0
     again = t.render(48, 48, 4, True)
     np.testing.assert_allclose(again, sharp, atol=1e-6)
+
+
+def test_pyngp_stock_renderer_camera_models(cuda):
+    """python_api.cu:691-693: render_camera_model, camera_spherical_quadrilateral, camera_quadrilateral_hexahedron"""
+    import pyngp
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=48, device=cuda)
+    t = scene.build_testbed(ds)
+    scene.train(t, 60)
+    t.shall_train = False
+    t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    pin = t.render(40, 30, 1, True)
+    assert t.render_camera_model == pyngp.CameraModel.Perspective
+    sq = pyngp.SphericalQuadrilateralConfig.Zero()
+    sq.width, sq.height, sq.curvature = 0.8, 0.6, 0.2
+    t.camera_spherical_quadrilateral = sq
+    got = t.camera_spherical_quadrilateral
+    assert (got.width, got.height, got.curvature) == (np.float32(0.8), np.float32(0.6), np.float32(0.2))
+    t.render_camera_model = pyngp.CameraModel.SphericalQuadrilateral
+    img = t.render(40, 30, 1, True)
+    assert np.isfinite(img).all() and np.abs(img - pin).mean() > 1e-3
+    t.render_camera_model = pyngp.CameraModel.Perspective
+    np.testing.assert_allclose(t.render(40, 30, 1, True), pin, atol=1e-6)
