@@ -90,6 +90,13 @@ struct Pcg32 {
 	}
 };
 
+// default_rng_t{seed}: pcg32(initstate = seed, initseq = 1) [tcnn pcg32.h constructor]
+__device__ __forceinline__ Pcg32 pcg32_seeded(uint64_t seed) {
+	Pcg32 r; r.state = 0u; r.inc = 3u;
+	r.next_uint(); r.state += seed; r.next_uint();
+	return r;
+}
+
 // ---------------------------------------------------------------- LK-scrambled Sobol (random_val.cuh:88-288, dims 0/1 only)
 __device__ __forceinline__ uint32_t sobol01(uint32_t index, uint32_t dim) {
 	// dim 0: direction[bit] = 0x80000000 >> bit  => bit reversal.

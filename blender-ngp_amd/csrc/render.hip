@@ -186,11 +186,12 @@ typedef uint16_t us4 __attribute__((ext_vector_type(4)));
 
 __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aabb aabb, Mat34 camera_matrix, float4* __restrict__ rgba, float* __restrict__ depth,
                                  NgpPayload* __restrict__ payloads, const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride,
-                                 uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance) {
+                                 uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	NgpPayload& payload = payloads[i];
 	if (!payload.alive) return;
+	const v3 ray_origin = ld3(payload.origin);
 	float4 local_rgba = rgba[i];
 	float local_depth = depth[i];
 	const v3 cam_fwd = col(camera_matrix.m, 2), cam_pos = col(camera_matrix.m, 3);
@@ -206,9 +207,30 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 		const float dt = unwarp_dt(in.dt);
 		const float alpha = 1.f - __expf(-network_to_density(h2f(lo[3]), density_activation) * dt);
 		const float weight = alpha * T;
-		local_rgba.x += network_to_rgb(h2f(lo[0]), rgb_activation) * weight;
-		local_rgba.y += network_to_rgb(h2f(lo[1]), rgb_activation) * weight;
-		local_rgba.z += network_to_rgb(h2f(lo[2]), rgb_activation) * weight;
+		float cr = network_to_rgb(h2f(lo[0]), rgb_activation), cg = network_to_rgb(h2f(lo[1]), rgb_activation), cb = network_to_rgb(h2f(lo[2]), rgb_activation);
+		if (render_mode != 1) {   // visualisation modes that only need the sample itself (938-968); Cost / Slice composite like Shade
+			if (render_mode == 3) {           // Positions
+				if (show_accel >= 0) {
+					const int mp = mip_from_pos(pos);
+					const uint32_t mip = (uint32_t)(show_accel > mp ? show_accel : mp);
+					const uint32_t res = NGP_NERF_GRIDSIZE >> mip;
+					const int ix = (int)(pos.x * (float)res), iy = (int)(pos.y * (float)res), iz = (int)(pos.z * (float)res);
+					Pcg32 rng = pcg32_seeded((uint64_t)(int64_t)(ix + iy * 232323 + iz * 727272));
+					cr = 1.f - (float)mip * (1.f / (float)(NGP_NERF_CASCADES - 1));
+					cg = rng.next_float();
+					cb = rng.next_float();
+				} else {
+					cr = (pos.x - 0.5f) / 2.0f + 0.5f; cg = (pos.y - 0.5f) / 2.0f + 0.5f; cb = (pos.z - 0.5f) / 2.0f + 0.5f;
+				}
+			} else if (render_mode == 4) {    // Depth
+				cr = cg = cb = dot(cam_fwd, pos - ray_origin) * depth_scale;
+			} else if (render_mode == 0) {    // AO
+				cr = cg = cb = alpha;
+			}
+		}
+		local_rgba.x += cr * weight;
+		local_rgba.y += cg * weight;
+		local_rgba.z += cb * weight;
 		local_rgba.w += weight;
 		if (weight > max_weight) { max_weight = weight; local_depth = dot(cam_fwd, pos - cam_pos); }
 		if (local_rgba.w > (1.0f - min_transmittance)) {
@@ -224,16 +246,17 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 }
 
 __global__ void shade_kernel(uint32_t n_elements, const float4* __restrict__ rgba, const float* __restrict__ depth, const NgpPayload* __restrict__ payloads,
-                             bool train_in_linear_colors, float4* __restrict__ frame_buffer, float* __restrict__ depth_buffer) {
+                             bool train_in_linear_colors, float4* __restrict__ frame_buffer, float* __restrict__ depth_buffer, int render_mode) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	float4 tmp = rgba[i];
-	if (!train_in_linear_colors) { tmp.x = srgb_to_linear(tmp.x); tmp.y = srgb_to_linear(tmp.y); tmp.z = srgb_to_linear(tmp.z); }
+	if (render_mode == 6) { const float c = (float)payloads[i].n_steps / 128; tmp = make_float4(c, c, c, 1.0f); }   // Cost
+	if (!train_in_linear_colors && (render_mode == 1 || render_mode == 7)) { tmp.x = srgb_to_linear(tmp.x); tmp.y = srgb_to_linear(tmp.y); tmp.z = srgb_to_linear(tmp.z); }
 	const uint32_t idx = payloads[i].idx;
 	const float4 fb = frame_buffer[idx];
 	const float k = 1.0f - tmp.w;
 	frame_buffer[idx] = make_float4(tmp.x + fb.x * k, tmp.y + fb.y * k, tmp.z + fb.z * k, tmp.w + fb.w * k);
-	if (tmp.w > 0.2f) depth_buffer[idx] = depth[i];
+	if (render_mode != 7 && tmp.w > 0.2f) depth_buffer[idx] = depth[i];
 }
 
 __global__ void accumulate_kernel(uint32_t n, const float4* __restrict__ frame_buffer, float4* __restrict__ accumulate_buffer, float sample_count, int color_space) {
@@ -364,16 +387,30 @@ int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAab
 int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
                       NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
                       int density_activation, float min_transmittance) {
+	return ngp_hip_composite_mode(stream, n_elements, current_step, aabb_host, camera_matrix_host, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation,
+	                              density_activation, min_transmittance, 1, 1.0f, -1);
+}
+
+int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
+                           NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                           int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
+	if (render_mode != 0 && render_mode != 1 && render_mode != 3 && render_mode != 4 && render_mode != 6 && render_mode != 7) {
+		set_last_error("ngp_hip_composite_mode: render mode not built (Normals / Distortion / EncodingVis need input gradients or the distortion map)", hipErrorInvalidValue); return -1;
+	}
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
-	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance);
+	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel);
 	NGP_LAUNCH_CHECK("composite_kernel");
 	return 0;
 }
 
 int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer) {
+	return ngp_hip_shade_mode(stream, n_elements, rgba, depth, payloads, train_in_linear_colors, frame_buffer, depth_buffer, 1);
+}
+int ngp_hip_shade_mode(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
+                       int render_mode) {
 	if (!n_elements) return 0;
-	hipLaunchKernelGGL(shade_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, (const float4*)rgba, depth, payloads, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer);
+	hipLaunchKernelGGL(shade_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, (const float4*)rgba, depth, payloads, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer, render_mode);
 	NGP_LAUNCH_CHECK("shade_kernel");
 	return 0;
 }

@@ -419,8 +419,10 @@ PYBIND11_MODULE(pyngp, m) {
 			[](Testbed& t, const BoundingBox& b) { t.m_render_aabb = b.pod(); })
 		.def_property_readonly("raw_aabb", [](Testbed& t) { return BoundingBox(Vec3{t.m_raw_aabb.min[0], t.m_raw_aabb.min[1], t.m_raw_aabb.min[2]}, Vec3{t.m_raw_aabb.max[0], t.m_raw_aabb.max[1], t.m_raw_aabb.max[2]}); })
 		.def_property("up_dir", [](Testbed& t) { return vec3_to_py(t.m_up_dir); }, [](Testbed& t, const py::object& v) { t.m_up_dir = vec3_from_py(v); })
-		.def_property("render_mode", [](Testbed&) { return ERenderMode::Shade; }, [](Testbed&, ERenderMode m) {
-				if (m != ERenderMode::Shade) throw std::runtime_error{"only RenderMode.Shade is implemented on this build (the visualisation modes are GUI features)"}; })
+		.def_property("render_mode", [](Testbed& t) { return t.m_render_mode; }, [](Testbed& t, ERenderMode m) {   // python_api.cu:660
+				if (m != ERenderMode::AO && m != ERenderMode::Shade && m != ERenderMode::Positions && m != ERenderMode::Depth && m != ERenderMode::Cost)
+					throw std::runtime_error{"RenderMode: AO, Shade, Positions, Depth and Cost are built (Normals / Distortion / Slice / EncodingVis need input gradients, the distortion map or the slice evaluator)"};
+				t.m_render_mode = m; })
 		.def("set_camera_to_training_view", [](Testbed& t, int i) {   // testbed_nerf.cu: camera <- training view i (already in NGP convention)
 				if (i < 0 || (size_t)i >= t.m_nerf.training.dataset.n_images) throw std::runtime_error{"Invalid training view"};
 				memcpy(t.m_camera.m, t.m_nerf.training.transforms[i].start, sizeof(t.m_camera.m));   // testbed.cu:273-281 (rolling shutter time 0)

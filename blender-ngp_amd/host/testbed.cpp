@@ -1002,16 +1002,17 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
 			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
-			check(ngp_hip_composite(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
-			                        (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance), "composite");
+			check(ngp_hip_composite_mode(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
+			                             (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, (int)m_render_mode,
+			                             1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel), "composite");
 			pt.i += n_steps;
 		}
 	}
 	uint32_t n_hit = 0;
 	HIP_CHECK_THROW(hipMemcpyAsync(&n_hit, hit_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
 	sync();
-	check(ngp_hip_shade(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
-	                    rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>()), "shade");
+	check(ngp_hip_shade_mode(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
+	                         rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(), (int)m_render_mode), "shade");
 }
 
 // ---- Blender multi-NeRF requests -------------------------------------------------------------------------------------------

@@ -310,6 +310,7 @@ public:
 	float m_exposure = 0.f;
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
+	ERenderMode m_render_mode = ERenderMode::Shade;    // AO, Shade, Positions, Depth and Cost are built (ngp_hip_composite_mode)
 	NgpRenderCamera m_render_camera_models{};          // stock renderer: model (0 Perspective) + the SphericalQuadrilateral / QuadrilateralHexahedron shapes (python_api.cu:691-693)
 	float m_aperture_size = 0.0f;                      // depth of field: radius of the lens disk (testbed.h m_aperture_size; python `dof` / `aperture_size`)
 	float m_slice_plane_z = 0.0f;                      // focus distance is m_slice_plane_z + m_scale (testbed_nerf.cu:2355)

@@ -231,6 +231,14 @@ int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, 
                       uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance);    /* :767 */
 int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads,
                   int train_in_linear_colors, float* frame_buffer, float* depth_buffer);                                       /* :1748 */
+/* The same two kernels with ERenderMode (common.h:80-91): AO 0, Shade 1, Positions 3 (show_accel >= 0: the occupancy-cell colouring), Depth 4
+ * (depth_scale = 1 / dataset scale, :2415), Cost 6 (n_steps / 128, in shade), Slice 7 (shade only).  Normals 2, Distortion 5 and EncodingVis need
+ * network input gradients / the distortion map and are rejected. */
+int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
+                           NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                           int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel);
+int ngp_hip_shade_mode(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer,
+                       float* depth_buffer, int render_mode);
 int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space); /* render_buffer.cu:235 */
 int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
                     int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */

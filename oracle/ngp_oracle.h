@@ -110,6 +110,11 @@ void orc_compact_rays(uint32_t n_elements, const float* src_rgba, const float* s
 void orc_generate_next_inputs(uint32_t n_elements, const orc_aabb* render_aabb, const orc_aabb* train_aabb, orc_payload* payloads, orc_coord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant);
 void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix, float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance);
 void orc_shade(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer);
+void orc_composite_mode(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix, float* rgba, float* depth, orc_payload* payloads,
+                        const orc_coord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation,
+                        float min_transmittance, int render_mode, float depth_scale, int show_accel);
+void orc_shade_mode(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
+                    int render_mode);
 void orc_accumulate(const int32_t res[2], const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space_srgb);
 void orc_tonemap(const int32_t res[2], float exposure, const float background_color_in[4], const float* accumulate_buffer, int color_space_srgb, int output_color_space_srgb, int tonemap_curve, int clamp_output_color, float* surface);
 uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, uint32_t sample_index, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float screen_center[2], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb, float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation, float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer);

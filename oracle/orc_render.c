@@ -205,6 +205,16 @@ void orc_generate_next_inputs(uint32_t n_elements, const orc_aabb* render_aabb, 
 void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix /* 3x4 */,
                    float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output,
                    uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance) {
+	orc_composite_mode(n_elements, current_step, aabb, camera_matrix, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation,
+	                   min_transmittance, 1 /* Shade */, 1.0f, -1);
+}
+
+/* the visualisation modes that only need the sample itself (testbed_nerf.cu:938-968): ERenderMode AO 0, Shade 1, Positions 3 (with the
+ * show_accel colouring), Depth 4; Cost 6 and Slice 7 composite like Shade */
+void orc_composite_mode(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix /* 3x4 */,
+                        float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output,
+                        uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance,
+                        int render_mode, float depth_scale, int show_accel) {
 	orc_vec3 cam_fwd = orc_col(camera_matrix, 2);
 	orc_vec3 cam_pos = orc_col(camera_matrix, 3);
 	for (uint32_t i = 0; i < n_elements; ++i) {
@@ -224,6 +234,24 @@ void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* a
 			float weight = alpha * T;
 			float rgb[3];
 			for (int c = 0; c < 3; ++c) rgb[c] = orc_network_to_rgb(orc_h2f(lo[c]), rgb_activation);
+			if (render_mode == 3) {            /* Positions */
+				if (show_accel >= 0) {
+					int mp = orc_mip_from_pos(pos, 7);
+					uint32_t mip = (uint32_t)(show_accel > mp ? show_accel : mp);
+					uint32_t res = 128u >> mip;
+					int ix = (int)(pos.x * (float)res), iy = (int)(pos.y * (float)res), iz = (int)(pos.z * (float)res);
+					orc_pcg32 rng = orc_pcg32_make((uint64_t)(int64_t)(ix + iy * 232323 + iz * 727272));   /* default_rng_t(int) */
+					rgb[0] = 1.f - (float)mip * (1.f / 7.f);
+					rgb[1] = orc_pcg32_next_float(&rng);
+					rgb[2] = orc_pcg32_next_float(&rng);
+				} else {
+					rgb[0] = (pos.x - 0.5f) / 2.0f + 0.5f; rgb[1] = (pos.y - 0.5f) / 2.0f + 0.5f; rgb[2] = (pos.z - 0.5f) / 2.0f + 0.5f;
+				}
+			} else if (render_mode == 4) {     /* Depth */
+				rgb[0] = rgb[1] = rgb[2] = orc_dot(cam_fwd, orc_sub(pos, p->origin)) * depth_scale;
+			} else if (render_mode == 0) {     /* AO */
+				rgb[0] = rgb[1] = rgb[2] = alpha;
+			}
 			for (int c = 0; c < 3; ++c) local_rgba[c] += rgb[c] * weight;
 			local_rgba[3] += weight;
 			if (weight > p->max_weight) {
@@ -248,12 +276,18 @@ void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* a
 /* testbed_nerf.cu:1748-1781 Shade mode */
 void orc_shade(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors,
                float* frame_buffer, float* depth_buffer) {
+	orc_shade_mode(n_elements, rgba, depth, payloads, train_in_linear_colors, frame_buffer, depth_buffer, 1 /* Shade */);
+}
+/* shade_kernel_nerf with render_mode (1748-1781): Cost shows n_steps / 128; only Shade / Slice colours are sRGB-decoded */
+void orc_shade_mode(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors,
+                    float* frame_buffer, float* depth_buffer, int render_mode) {
 	for (uint32_t i = 0; i < n_elements; ++i) {
 		float tmp[4]; memcpy(tmp, rgba + 4 * i, 16);
-		if (!train_in_linear_colors) for (int c = 0; c < 3; ++c) tmp[c] = orc_srgb_to_linear(tmp[c]);
+		if (render_mode == 6) { float col = (float)payloads[i].n_steps / 128; tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f; }
+		if (!train_in_linear_colors && (render_mode == 1 || render_mode == 7)) for (int c = 0; c < 3; ++c) tmp[c] = orc_srgb_to_linear(tmp[c]);
 		float* fb = frame_buffer + 4 * (size_t)payloads[i].idx;
 		for (int c = 0; c < 4; ++c) fb[c] = tmp[c] + fb[c] * (1.0f - tmp[3]);
-		if (tmp[3] > 0.2f) depth_buffer[payloads[i].idx] = depth[i];
+		if (render_mode != 7 && tmp[3] > 0.2f) depth_buffer[payloads[i].idx] = depth[i];
 	}
 }
 

@@ -159,6 +159,7 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
         assert g_in[j * n_alive:(j + 1) * n_alive][m].tobytes() == o_in[j * n_alive:(j + 1) * n_alive][m].tobytes()
 
     # ---- composite with random network outputs
+    pay_before = o_pay[:n_alive].copy()             # state after next-inputs, before composite
     rs = np.random.RandomState(0)
     out = np.zeros((n_alive * n_steps, 4), np.float16)
     out[:, :3] = rs.randn(n_alive * n_steps, 3).astype(np.float16)
@@ -176,6 +177,21 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
     np.testing.assert_allclose(H.to_host(d_rgba2, np.float32).reshape(n_alive, 4)[same], o_rgba2[same], rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(H.to_host(d_dep2, np.float32)[same], o_dep2[same], rtol=2e-3, atol=1e-5)
     assert (o_pay["alive"][:n_alive] == 0).any() and (o_pay["alive"][:n_alive] == 1).any()
+    # ---- the visualisation modes that need nothing but the sample (testbed_nerf.cu:938-968): AO 0, Positions 3 (+ show_accel), Depth 4
+    for mode, accel in ((0, -1), (3, -1), (3, 0), (3, 2), (4, -1)):
+        o_p, o_c, o_d = pay_before.copy(), np.zeros((n_alive, 4), np.float32), np.zeros(n_alive, np.float32)
+        oracle.orc_composite_mode(n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, o_c.ctypes.data, o_d.ctypes.data, o_p.ctypes.data, o_in.ctypes.data,
+                                  out.ctypes.data, 4, n_steps, 2, 3, H.f32(0.01), mode, H.f32(3.0), accel)
+        d_p, d_c, d_d = H.to_dev(pay_before, cuda), H.dev_zeros(n_alive * 16, cuda), H.dev_zeros(n_alive * 4, cuda)
+        check(ngp.ngp_hip_composite_mode(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
+                                         d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), mode, H.f32(3.0), accel))
+        ok = H.to_host(d_p, H.PAYLOAD)["alive"] == o_p["alive"]
+        assert ok.mean() > 0.99
+        np.testing.assert_allclose(H.to_host(d_c, np.float32).reshape(n_alive, 4)[ok], o_c[ok], rtol=2e-3, atol=1e-5)
+        assert np.abs(o_c[:, :3] - o_rgba2[:, :3]).max() > 1e-2          # not the Shade colours
+    assert ngp.ngp_hip_composite_mode(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
+                                      d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 2, H.f32(1.0), -1) != 0                   # Normals: not built
+    assert b"render mode" in ngp.ngp_hip_last_error()
 
 
 def test_shade_accumulate_tonemap(ngp, oracle, cuda):
@@ -193,6 +209,14 @@ def test_shade_accumulate_tonemap(ngp, oracle, cuda):
         d_rgba, d_depth, d_pay = H.to_dev(rgba, cuda), H.to_dev(depth, cuda), H.to_dev(pay, cuda)
         check(ngp.ngp_hip_shade(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr()))
         np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-4, atol=1e-6)
+        np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
+    pay["n_steps"] = rs.randint(0, 300, n_hit)
+    for mode in (0, 4, 6):                          # AO / Depth: no sRGB decode; Cost: n_steps / 128, opaque
+        fb, db = rs.rand(npx, 4).astype(np.float32), rs.rand(npx).astype(np.float32)
+        d_fb, d_db, d_pay = H.to_dev(fb, cuda), H.to_dev(db, cuda), H.to_dev(pay, cuda)
+        oracle.orc_shade_mode(n_hit, rgba.ctypes.data, depth.ctypes.data, pay.ctypes.data, 0, fb.ctypes.data, db.ctypes.data, mode)
+        check(ngp.ngp_hip_shade_mode(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), mode))
+        np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-6, atol=1e-7)
         np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
     for cs in (0, 1):
         acc = rs.rand(npx, 4).astype(np.float32)
@@ -355,3 +379,34 @@ def test_pyngp_stock_renderer_camera_models(cuda):
     assert np.isfinite(img).all() and np.abs(img - pin).mean() > 1e-3
     t.render_camera_model = pyngp.CameraModel.Perspective
     np.testing.assert_allclose(t.render(40, 30, 1, True), pin, atol=1e-6)
+
+
+def test_pyngp_render_modes(cuda):
+    """python_api.cu:660 `render_mode`: AO, Positions, Depth and Cost through Testbed.render"""
+    import pyngp
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=48, device=cuda)
+    t = scene.build_testbed(ds)
+    scene.train(t, 80)
+    t.shall_train = False
+    t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    t.background_color = [0.0, 0.0, 0.0, 0.0]
+    shade = t.render(40, 30, 1, True)
+    t.render_mode = pyngp.RenderMode.Depth
+    depth = t.render(40, 30, 1, True)
+    hit = depth[..., 3] > 0.9                                                                                   # opaque pixels
+    assert hit.sum() > 30 and np.isfinite(depth).all()
+    d = depth[hit]
+    assert (d[:, 0] > 0).all() and np.allclose(d[:, 0], d[:, 1]) and np.allclose(d[:, 0], d[:, 2])              # grey = distance along the view axis / dataset scale
+    t.render_mode = pyngp.RenderMode.Positions
+    pos = t.render(40, 30, 1, True)
+    assert (pos[hit][:, :3] > 0.2).all() and (pos[hit][:, :3] < 0.8).all()                                       # (p - 0.5) / 2 + 0.5 of points inside the unit cube
+    t.render_mode = pyngp.RenderMode.Cost
+    cost = t.render(40, 30, 1, True)
+    assert (cost[hit][:, 3] == 1.0).all() and cost[hit][:, 0].max() > 0
+    t.render_mode = pyngp.RenderMode.AO
+    assert np.isfinite(t.render(40, 30, 1, True)).all()
+    with pytest.raises(RuntimeError):
+        t.render_mode = pyngp.RenderMode.Normals
+    t.render_mode = pyngp.RenderMode.Shade
+    np.testing.assert_allclose(t.render(40, 30, 1, True), shade, atol=1e-6)
