@@ -316,6 +316,19 @@ __global__ void fill_rollover_f32_kernel(uint32_t n_elements, uint32_t stride, c
 	inout[i] = inout[i % n_input];
 }
 
+// the three roll-overs of a training step (3314-3322 + the carried encoding rows) in one launch: element i of each array, same arithmetic
+__global__ void fill_rollover_training_kernel(uint32_t n_elements, const uint32_t* __restrict__ n_input_elements_ptr, uint16_t* __restrict__ dloss, uint32_t dl_stride,
+                                              float* __restrict__ coords, uint32_t coord_stride, float* __restrict__ encoded, uint32_t enc_stride) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	const uint32_t n_in = *n_input_elements_ptr;
+	if (n_in >= n_elements || n_in == 0) return;
+	{ const uint32_t n_total = n_elements * dl_stride, n_input = n_in * dl_stride;
+	  if (i >= n_input && i < n_total) dloss[i] = f2h(h2f(dloss[i % n_input]) * (float)n_input / (float)n_total); }
+	{ const uint32_t n_total = n_elements * coord_stride, n_input = n_in * coord_stride;
+	  if (i >= n_input && i < n_total) coords[i] = coords[i % n_input]; }
+	if (encoded) { const uint32_t n_total = n_elements * enc_stride, n_input = n_in * enc_stride;
+	  if (i >= n_input && i < n_total) encoded[i] = encoded[i % n_input]; }
+}
 
 // ---- plumbing configs P1 / P2: tcnn losses driven by Trainer::training_step, sample generation of Testbed::train_image ----------------
 // [tcnn] losses/{l2,relative_l2,l1,mape}.h: per element i of the (padded) prediction matrix, n_total = n * dims,
@@ -536,6 +549,17 @@ int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(fill_rollover_f32_kernel, dim3(div_up(n_elements * stride, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, stride, n_input_elements, inout);
 	NGP_LAUNCH_CHECK("fill_rollover_f32_kernel");
+	return 0;
+}
+
+int ngp_hip_fill_rollover_training(void* stream, uint32_t n_elements, const uint32_t* n_input_elements, uint16_t* dloss, uint32_t dl_stride, float* coords, uint32_t coord_stride_floats,
+                                   float* encoded, uint32_t encoded_stride_floats) {
+	if (!n_elements) return 0;
+	uint32_t widest = dl_stride > coord_stride_floats ? dl_stride : coord_stride_floats;
+	if (encoded && encoded_stride_floats > widest) widest = encoded_stride_floats;
+	hipLaunchKernelGGL(fill_rollover_training_kernel, dim3(div_up(n_elements * widest, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, n_input_elements, dloss, dl_stride, coords,
+	                   coord_stride_floats, encoded, encoded_stride_floats);
+	NGP_LAUNCH_CHECK("fill_rollover_training_kernel");
 	return 0;
 }
 

@@ -509,7 +509,7 @@ __host__ __device__ __forceinline__ bool gb_uses_fx(uint32_t level_size, uint32_
 	return !dense && (level_size & (level_size - 1)) == 0 && level_size >= GB_FX_SLICE && level_size / GB_FX_SLICE <= GB_FX_MAX_SLICES && resolution < GB_FX_SLICE;
 }
 // scratch of the binned path: per level and slice {total, cursor, start} u32, then the item lists (one u32 per (sample, pair))
-struct GbFxCounters { uint32_t totals[16][GB_FX_MAX_SLICES], cursors[16][GB_FX_MAX_SLICES], starts[16][GB_FX_MAX_SLICES]; };
+struct GbFxCounters { uint32_t totals[16][GB_FX_MAX_SLICES], cursors[16][GB_FX_MAX_SLICES]; };
 constexpr uint32_t GB_FX_COUNTER_BYTES = 65536;
 
 template <int D>
@@ -560,6 +560,32 @@ constexpr uint32_t GB_PARTIAL_LEVEL_BYTES = GB_ITEMS * GB_SLICE * 4u;   // priva
 static_assert(GB_D_ITEMS * GB_FX_SLICE * 16u <= GB_PARTIAL_LEVEL_BYTES, "partials");
 constexpr uint32_t GB_ITEMS_PER_SAMPLE = 8;    // list stride per level: n * 8 items (hashed: 4 (y, z) pairs, dense: at most 8 records)
 
+// where the list of `bin` starts inside its level: the exclusive prefix sum of the level's totals.  Every scatter workgroup (256 threads =
+// 256 bins) scans them itself and every owner sums its own prefix — cheaper than a separate scan launch between count and scatter.
+__device__ __forceinline__ uint32_t gb_block_exclusive_scan_256(uint32_t v, uint32_t* __restrict__ s_wave_totals /* [4] */) {
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	uint32_t incl = v;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += o; }
+	if (lane == 63u) s_wave_totals[w] = incl;
+	__syncthreads();
+	uint32_t before = 0;
+	for (uint32_t k = 0; k < w; ++k) before += s_wave_totals[k];
+	return before + incl - v;
+}
+__device__ __forceinline__ uint32_t gb_owner_start(const GbFxCounters* __restrict__ ctr, uint32_t level, uint32_t bin, uint32_t* __restrict__ s_start) {
+	if (threadIdx.x < 64u) {
+		uint32_t part = 0;
+#pragma unroll
+		for (uint32_t q = 0; q < GB_FX_MAX_SLICES / 64u; ++q) { const uint32_t k = threadIdx.x + 64u * q; if (k < bin) part += ctr->totals[level][k]; }
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+		if (threadIdx.x == 0) *s_start = part;
+	}
+	__syncthreads();
+	return *s_start;
+}
+
 // passes 1 and 3 of the counting sort.  grid (ceil(n / GB_FX_CHUNK), 16 levels), block 256.  SCATTER = false: per-bin totals;
 // SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
 // hashed level: item = sample << 3 | (y, z) pair, bin = slice.
@@ -600,7 +626,12 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 		if (threadIdx.x < GB_FX_MAX_SLICES && hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
 		return;
 	}
-	if (threadIdx.x < GB_FX_MAX_SLICES) base[threadIdx.x] = hist[threadIdx.x] ? ctr->starts[level][threadIdx.x] + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	{
+		static_assert(GB_FX_MAX_SLICES == 256, "one thread per bin");
+		const uint32_t start = gb_block_exclusive_scan_256(ctr->totals[level][threadIdx.x], base /* scratch: 4 words, overwritten below */);
+		__syncthreads();
+		base[threadIdx.x] = hist[threadIdx.x] ? start + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	}
 	__syncthreads();
 	uint32_t* __restrict__ out = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE;
 #pragma unroll
@@ -691,7 +722,12 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 		return;
 	}
 	// reserve the ranges (base[] then serves as the running cursor of each bin), walk again with the sums
-	if (threadIdx.x < GB_FX_MAX_SLICES) base[threadIdx.x] = hist[threadIdx.x] ? ctr->starts[level][threadIdx.x] + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	{
+		static_assert(GB_FX_MAX_SLICES == 256, "one thread per bin");
+		const uint32_t start = gb_block_exclusive_scan_256(ctr->totals[level][threadIdx.x], base /* scratch: 4 words, overwritten below */);
+		__syncthreads();
+		base[threadIdx.x] = hist[threadIdx.x] ? start + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
+	}
 	__syncthreads();
 	gb_dense_walk<D, true>(s_g, s_px, s_py, s_pz, base, lv, chunk_bin0, n_live, items + (size_t)level * n * GB_ITEMS_PER_SAMPLE, sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
 }
@@ -712,24 +748,11 @@ __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __rest
 	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, items);
 }
 
-// pass 2: exclusive scan of the per-slice totals of every level (16 x 64 counters: one wave per level)
-__global__ void __launch_bounds__(64) gb_fx_scan_kernel(GbFxCounters* __restrict__ ctr) {
-	const uint32_t level = blockIdx.x, lane = threadIdx.x;
-	uint32_t carry = 0;
-	for (uint32_t b = 0; b < GB_FX_MAX_SLICES; b += 64) {
-		const uint32_t v = ctr->totals[level][b + lane];
-		uint32_t incl = v;
-		for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += o; }
-		ctr->starts[level][b + lane] = carry + incl - v;
-		carry += __shfl(incl, 63, 64);
-	}
-}
-
 // pass 4: the owner of (level, slice) adds its items into 8192 x 2 64-bit fixed-point words in LDS and writes the final fp16 gradients
 template <int D>
 __device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t sl,
                                                  const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                                 const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, h2* __restrict__ grid_grad) {
+                                                 const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, h2* __restrict__ grid_grad, uint32_t* __restrict__ s_start) {
 	if (sl >= lv.size / GB_FX_SLICE) return;
 	h2* __restrict__ dst = grid_grad + lv.offset + (size_t)sl * GB_FX_SLICE;
 	const uint32_t count = ctr->totals[level][sl];
@@ -742,7 +765,7 @@ __device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict_
 	__syncthreads();
 	const uint32_t hmask = lv.size - 1;
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	const uint32_t* __restrict__ my = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE + ctr->starts[level][sl];
+	const uint32_t* __restrict__ my = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE + gb_owner_start(ctr, level, sl, s_start);
 	constexpr uint32_t UN = 8;
 	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
 		uint32_t it[UN]; h2 gq[UN]; float px[UN], py[UN], pz[UN];
@@ -787,7 +810,7 @@ __device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict_
 // Dense (coarse) levels: the owner of (slice, sample chunk) adds its merged records (see gb_bin_dense)
 __device__ __forceinline__ void gb_dense_owner(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t bin, uint32_t n,
                                                const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums,
-                                               unsigned long long* __restrict__ partials, h2* __restrict__ grid_grad) {
+                                               unsigned long long* __restrict__ partials, h2* __restrict__ grid_grad, uint32_t* __restrict__ s_start) {
 	const GbSplit sp = gb_dense_split(lv.size);
 	if (bin >= sp.n_slices * sp.k_chunks) return;
 	const uint32_t sl = bin % sp.n_slices;
@@ -796,7 +819,7 @@ __device__ __forceinline__ void gb_dense_owner(unsigned long long* __restrict__ 
 	const uint32_t count = ctr->totals[level][bin];
 	for (uint32_t i = threadIdx.x; i < 2 * cnt; i += blockDim.x) slice64[i] = 0ull;
 	__syncthreads();
-	const size_t first = (size_t)level * n * GB_ITEMS_PER_SAMPLE + ctr->starts[level][bin];
+	const size_t first = (size_t)level * n * GB_ITEMS_PER_SAMPLE + gb_owner_start(ctr, level, bin, s_start);
 	const uint32_t* __restrict__ my_e = items + first;
 	const ulonglong2* __restrict__ my_v = sums + first;
 	constexpr uint32_t UN = 4;
@@ -831,12 +854,13 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
                                                              const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask) {
 	constexpr int NC = 1 << D;
 	__shared__ unsigned long long slice64[2 * GB_FX_SLICE];
+	__shared__ uint32_t s_start;
 	const uint32_t level = blockIdx.y, item = blockIdx.x;
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation (tools/gb_level_probe.py); all ones in production
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
-	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, coords, coord_stride, n, dx_planes, ctr, items, grid_grad); return; }
-	if (dense) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad); return; }
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, coords, coord_stride, n, dx_planes, ctr, items, grid_grad, &s_start); return; }
+	if (dense) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad, &s_start); return; }
 	h2* __restrict__ slice = (h2*)slice64;
 	h2* __restrict__ partials = (h2*)partials_raw;
 	const GbSplit sp = gb_split(lv.size);
@@ -941,8 +965,10 @@ template <int ABLATE> // dev-only ablation switch (bit0: no dL/dx store, bit1: n
 __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                             const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                             const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
-                                                            h2* __restrict__ dx_planes, half_t* __restrict__ planes) {
+                                                            h2* __restrict__ dx_planes, half_t* __restrict__ planes, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
+	// the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
 	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
@@ -1155,8 +1181,9 @@ constexpr int GP_DOUT = 0, GP_H2 = 16, GP_DH2 = 80, GP_H1 = 144, GP_DH1 = 208, G
 
 // backward: recompute the MLP from the saved encoding, dgrad chain (channels 0..3 of dL_dout), planes for the weight gradients, dL/dx planes
 __global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* __restrict__ params, uint32_t n, const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout,
-                                                                  uint32_t dl_stride, h2* __restrict__ dx_planes, half_t* __restrict__ planes) {
+                                                                  uint32_t dl_stride, h2* __restrict__ dx_planes, half_t* __restrict__ planes, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_ALL_TILES * 64];
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_kernel
 	gm_stage_weights(lds_tiles, params, GM_ALL_TILES);
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
 	const uint32_t n_tiles = n / 32;
@@ -1403,19 +1430,18 @@ static int fwd_grid(uint32_t n) {
 
 // hash-grid backward for all 16 levels: binned fixed-point path for the hashed levels, LDS owner-computes path for the dense ones
 template <int D>
-static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad) {
+static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad,
+                                bool counters_cleared = false /* by the kernel that produced dx_planes */) {
 	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
 	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
 	ulonglong2* sums = (ulonglong2*)((char*)items + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 4u);
 	const char* lm = getenv("NGP_HIP_GB_LEVELS");   // dev-only timing ablation; unset in production
 	const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xffffu;
-	NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
+	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
-	hipLaunchKernelGGL(gb_fx_scan_kernel, dim3(16), dim3(64), 0, st, ctr);
-	NGP_LAUNCH_CHECK("gb_fx_scan_kernel");
 	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(1024), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
@@ -1576,13 +1602,13 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 	const char* abl = getenv("NGP_HIP_BWD_ABLATE"); // dev-only timing ablations (tools/microbench.py); unset in production
 	const int ablate = abl ? atoi(abl) : 0;
 #define NGP_LAUNCH_BWD(A) hipLaunchKernelGGL(nerf_backward_kernel<A>, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, \
-	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes)
+	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4))
 	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
 #undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (!(ablate & 4)) {
-		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS))) return -1;
+		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
 	}
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	const uint32_t n_chunks = wgrad_chunks(n);
@@ -1670,10 +1696,11 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 	float* partials = (float*)((char*)scratch + gm_scratch_off_wgrad(n));
 	h2* dx_planes = (h2*)((char*)scratch + gm_scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + gm_scratch_off_gb(n));
-	hipLaunchKernelGGL(gridmlp_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes);
+	hipLaunchKernelGGL(gridmlp_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes,
+	                   (uint32_t*)((char*)scratch + gm_scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
 	NGP_LAUNCH_CHECK("gridmlp_backward_kernel");
-	if (n_dims == 2) { if (launch_grid_backward<2>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS))) return -1; }
-	else { if (launch_grid_backward<3>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS))) return -1; }
+	if (n_dims == 2) { if (launch_grid_backward<2>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS), true)) return -1; }
+	else { if (launch_grid_backward<3>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS), true)) return -1; }
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel<1>, dim3(n_chunks, 4), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");

@@ -724,9 +724,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                         m_gen_counters.as<uint32_t>() + 2 * (m_gen_slot ^ 1), (double*)m_dp_counters_dev), "post_words");
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
-	check(ngp_hip_fill_rollover_and_rescale_f16(m_stream, target_batch_size, OUT_STRIDE, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>()), "fill_rollover_and_rescale");
-	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 7, c.numsteps_counter_compacted.as<uint32_t>(), m_coords_compacted.as<float>()), "fill_rollover");
-	check(ngp_hip_fill_rollover_f32(m_stream, target_batch_size, 16, c.numsteps_counter_compacted.as<uint32_t>(), m_x_saved.as<float>()), "fill_rollover(encoding)");
+	check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
+	                                     m_x_saved.as<float>(), 16), "fill_rollover");
 
 	// ---- train_nerf_step, second half (3324-3332): backward on the compacted batch (gradients overwrite).  The reference's forward over
 	// the compacted batch is the encoding that arrived with the compaction above; m_separate_forward restores the second pass (same bits).

@@ -199,6 +199,10 @@ int ngp_hip_compute_loss(
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);
+/* The roll-overs of one training step in ONE launch: fill_rollover_and_rescale<half> on dloss, fill_rollover<float> on the compacted coordinates
+ * (stride 7) and, optionally, on the carried encoding rows (stride 16 floats = 32 halves; see "Forward pass").  Element-wise the same arithmetic. */
+int ngp_hip_fill_rollover_training(void* stream, uint32_t n_elements, const uint32_t* n_input_elements, uint16_t* dloss, uint32_t dl_stride, float* coords, uint32_t coord_stride_floats,
+                                   float* encoded, uint32_t encoded_stride_floats);
 /* tcnn reduce_sum(float*) as used for the loss scalar (:2887): sum of n floats into out (zeroed inside). */
 int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out);
 /* NerfCounters::update_after_training (:2870-2874) reads its counters with blocking 4-byte copies.  This gathers up to four

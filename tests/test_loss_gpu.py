@@ -264,6 +264,26 @@ def test_fill_rollover(ngp, oracle, cuda):
         np.testing.assert_array_equal(H.to_host(d_c, np.float32).reshape(B, 7), c)
 
 
+def test_fill_rollover_training_equals_the_separate_launches(ngp, cuda):
+    import torch
+    n, n_in = 1024, 700
+    rs = np.random.RandomState(3)
+    dl = rs.randn(n, 4).astype(np.float16); co = rs.rand(n, 7).astype(np.float32); en = rs.rand(n, 16).astype(np.float32)
+    cnt = H.to_dev(np.array([n_in], np.uint32), cuda)
+    a = [H.to_dev(x, cuda) for x in (dl, co, en)]
+    b = [H.to_dev(x, cuda) for x in (dl, co, en)]
+    check(ngp.ngp_hip_fill_rollover_and_rescale_f16(None, n, 4, cnt.data_ptr(), a[0].data_ptr()))
+    check(ngp.ngp_hip_fill_rollover_f32(None, n, 7, cnt.data_ptr(), a[1].data_ptr()))
+    check(ngp.ngp_hip_fill_rollover_f32(None, n, 16, cnt.data_ptr(), a[2].data_ptr()))
+    check(ngp.ngp_hip_fill_rollover_training(None, n, cnt.data_ptr(), b[0].data_ptr(), 4, b[1].data_ptr(), 7, b[2].data_ptr(), 16))
+    for x, y, dt in zip(a, b, (np.uint16, np.uint32, np.uint32)):
+        np.testing.assert_array_equal(H.to_host(x, dt), H.to_host(y, dt))
+    assert not np.array_equal(H.to_host(b[1], np.float32).reshape(n, 7)[n_in:], co[n_in:])       # it did roll over
+    c2 = H.to_dev(co, cuda)
+    check(ngp.ngp_hip_fill_rollover_training(None, n, cnt.data_ptr(), b[0].data_ptr(), 4, c2.data_ptr(), 7, None, 0))   # without encoding rows
+    np.testing.assert_array_equal(H.to_host(c2, np.uint32), H.to_host(a[1], np.uint32))
+
+
 def test_reduce_sum(ngp, cuda):
     rs = np.random.RandomState(0)
     for n in (1, 255, 4096, 262144):
