@@ -370,6 +370,26 @@ __device__ __forceinline__ bool density_grid_occupied_at(v3 pos, const uint8_t* 
 	if (brick != cache.id) { cache.id = brick; cache.bits = ((const uint64_t*)bitfield)[brick]; }
 	return (cache.bits >> (idx & 63u)) & 1ull;
 }
+// ... and with a 4 KiB summary of cascade 0 in LDS (bit b = "brick b has an occupied cell"): in empty space — most iterations of a march —
+// the answer is 0 without touching global memory, whose latency every lane of the wave would otherwise wait for.  Same bit, always.
+__device__ __forceinline__ bool density_grid_occupied_at(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip, OccBrick& cache, const uint32_t* __restrict__ s_brick_any) {
+	const uint32_t idx = cascaded_grid_idx_at(pos, mip);
+	const uint32_t brick = (idx >> 6) + (NGP_NERF_GRID_N_CELLS / 64u) * mip;
+	if (mip == 0 && !((s_brick_any[brick >> 5] >> (brick & 31u)) & 1u)) return false;
+	if (brick != cache.id) { cache.id = brick; cache.bits = ((const uint64_t*)bitfield)[brick]; }
+	return (cache.bits >> (idx & 63u)) & 1ull;
+}
+// fills s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32] from cascade 0 of the bitfield; all threads of the workgroup call it, then __syncthreads()
+__device__ __forceinline__ void load_brick_summary(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ s_brick_any) {
+	constexpr uint32_t N_BRICKS = NGP_NERF_GRID_N_CELLS / 64u;
+	const uint64_t* __restrict__ words = (const uint64_t*)bitfield;
+	for (uint32_t w = threadIdx.x; w < N_BRICKS / 32u; w += blockDim.x) {
+		uint32_t bits = 0;
+#pragma unroll 8
+		for (uint32_t k = 0; k < 32u; ++k) bits |= (words[w * 32u + k] != 0ull ? 1u : 0u) << k;
+		s_brick_any[w] = bits;
+	}
+}
 __device__ __forceinline__ int mip_from_pos(v3 pos, uint32_t max_cascade = NGP_NERF_CASCADES - 1) {
 	float maxval = fmaxf(fmaxf(fabsf(pos.x - 0.5f), fabsf(pos.y - 0.5f)), fabsf(pos.z - 0.5f));
 	int m = frexp_exponent(maxval) + 1;
