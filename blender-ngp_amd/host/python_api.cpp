@@ -234,6 +234,13 @@ PYBIND11_MODULE(pyngp, m) {
 			py::arg("json"), py::arg("config_base_path") = "")
 		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
 		.def("load_snapshot", &Testbed::load_snapshot, py::arg("path"))
+		// entry points of scripts/run.py that lie outside the hot path (SURVEY §8 out of scope): present so that a driver fails loudly, not with AttributeError
+		.def("want_repl", [](Testbed&) { return false; })                                                                  // python_api.cu:363 (GUI only)
+		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: this build has no GUI (windowless rendering only)"}; },
+			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
+		.def("load_camera_path", [](Testbed&, const std::string&) { throw std::runtime_error{"load_camera_path: camera paths are not part of this build (set the camera per frame with set_nerf_camera_matrix)"}; }, py::arg("path"))
+		.def("compute_and_save_marching_cubes_mesh", [](Testbed&, const std::string&, py::object, py::object, float) { throw std::runtime_error{"compute_and_save_marching_cubes_mesh: mesh extraction is not part of this build"}; },
+			py::arg("filename"), py::arg("resolution") = py::none(), py::arg("aabb") = py::none(), py::arg("thresh") = 2.5f)
 		.def("n_params", &Testbed::n_params)
 		.def("n_encoding_params", &Testbed::n_encoding_params)
 		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float, float, float, float) {
