@@ -49,6 +49,7 @@ struct LossArgs {
 	ErrorMapCdf cdf;
 	const uint16_t* encoded_in; uint16_t* encoded_out;   // optional: [sample][32] fp16 encoding rows carried through the compaction
 	float depth_supervision_lambda; int depth_loss_type;  // testbed.h:654, 680 (off by default)
+	float* exposure_gradient;                             // [n_images][3] or NULL (optimize_exposure off)
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	}
 
 	// ---- target colour: replay the ray generator's draws (1376-1423); wave-uniform
-	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f;
+	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f, pixel_pdf = 1.0f, exposure_scale[3] = {1.f, 1.f, 1.f};
 	uint32_t img = 0;
 	int32_t img_res[2] = {1, 1};
 	v3 ray_o = mk(0, 0, 0);
@@ -147,13 +148,12 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		const NgpImageMeta& md = a.metadata[img];
 		img_res[0] = md.res[0]; img_res[1] = md.res[1];
 		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, xy[0], xy[1], &xy_pdf);
-		sample_pdf = img_pdf * xy_pdf;
+		sample_pdf = img_pdf * xy_pdf; pixel_pdf = xy_pdf;
 		max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
 		float bg[3] = {a.background_color[0], a.background_color[1], a.background_color[2]};
 		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
 #pragma unroll
 		for (int c = 0; c < 3; ++c) bg[c] = srgb_to_linear(bg[c]);
-		float exposure_scale[3];
 #pragma unroll
 		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * a.exposure[img * 3 + c]);
 		float texsamp[4];
@@ -199,6 +199,15 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	if (compacted == 0) return;
 
 	const LG lg = loss_and_gradient(rgbtarget, rgb_ray, a.loss_type);
+	// per-image exposure gradient (1558-1572): d loss / d exposure = loss_scale * (-dL/drgb / xy_pdf [/ srgb'(target)]) * 2^exposure * ln 2
+	if (a.exposure_gradient && lane == 0) {
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			float dloss_by_dgt = -lg.grad[c] / pixel_pdf;
+			if (!a.train_in_linear_colors) dloss_by_dgt /= srgb_to_linear_derivative(rgbtarget[c]);
+			atomicAdd(&a.exposure_gradient[img * 3 + c], a.loss_scale * dloss_by_dgt * exposure_scale[c] * 0.6931471805599453f);
+		}
+	}
 	// depth supervision (1450-1452): target = |d| * depth image at the ray's pixel, loss on the expected termination depth
 	float depth_loss_gradient = 0.0f;
 	if (a.depth_supervision_lambda > 0.0f) {
@@ -515,7 +524,8 @@ int ngp_hip_compute_loss(
 	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type) {
+	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
+	float* exposure_gradient) {
 	if (!n_rays) return 0;
 	if ((encoded_in == nullptr) != (encoded_out == nullptr)) { set_last_error("ngp_hip_compute_loss: encoded_in and encoded_out go together", hipErrorInvalidValue); return -1; }
 	if ((mlp_stride & 3) || (dl_stride & 3)) { set_last_error("ngp_hip_compute_loss: strides must be multiples of 4 halves", hipErrorInvalidValue); return -1; }
@@ -529,7 +539,7 @@ int ngp_hip_compute_loss(
 	a.dloss_doutput = dloss_doutput; a.dl_stride = dl_stride; a.loss_type = loss_type; a.loss_output = loss_output;
 	a.max_level_rand_training = max_level_rand_training; a.max_level_compacted = max_level_compacted; a.rgb_activation = rgb_activation;
 	a.cdf = make_error_map_cdf(cdf_host); a.encoded_in = encoded_in; a.encoded_out = encoded_out;
-	a.depth_supervision_lambda = depth_supervision_lambda; a.depth_loss_type = depth_loss_type;
+	a.depth_supervision_lambda = depth_supervision_lambda; a.depth_loss_type = depth_loss_type; a.exposure_gradient = exposure_gradient;
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;

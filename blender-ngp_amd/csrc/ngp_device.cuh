@@ -407,6 +407,7 @@ __device__ __forceinline__ int mip_from_dt(float dt, v3 pos, uint32_t max_cascad
 
 // ---------------------------------------------------------------- colour (common_device.cuh:31-77)
 __device__ __forceinline__ float srgb_to_linear(float s) { return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float srgb_to_linear_derivative(float s) { return s <= 0.04045f ? 1.0f / 12.92f : 2.4f / 1.055f * powf((s + 0.055f) / 1.055f, 1.4f); }   // common_device.cuh:43-49
 __device__ __forceinline__ float linear_to_srgb(float l) { return l < 0.0031308f ? 12.92f * l : 1.055f * powf(l, 0.41666f) - 0.055f; }
 
 // ---------------------------------------------------------------- activations (testbed_nerf.cu:215-257)

@@ -479,6 +479,13 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("offset", [](NerfTraining& t) { return vec3_to_py(t.dataset.offset); })
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
+		.def_readwrite("optimize_exposure", &NerfTraining::optimize_exposure)                   // python_api.cu:813
+		.def_readwrite("exposure_l2_reg", &NerfTraining::exposure_l2_reg)                       // python_api.cu:827
+		.def("get_camera_exposures", [](NerfTraining& t) {                                      // [n_images][3] log2 exposures as the loss kernel sees them
+				py::array_t<float> a({(py::ssize_t)t.dataset.n_images, (py::ssize_t)3});
+				if (a.size()) t.cam_exposure_gpu.copy_to_host(a.mutable_data(), (size_t)a.size() * 4);
+				return a;
+			})
 		.def_readwrite("depth_loss_type", &NerfTraining::depth_loss_type)                       // python_api.cu:809
 		.def_readwrite("depth_supervision_lambda", &NerfTraining::depth_supervision_lambda)     // python_api.cu:828
 		.def_readwrite("sample_focal_plane_proportional_to_error", &NerfTraining::sample_focal_plane_proportional_to_error)   // python_api.cu:817

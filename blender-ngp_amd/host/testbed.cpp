@@ -693,6 +693,12 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	profile_begin(PK_INFERENCE);
 	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
 	profile_end(PK_INFERENCE, max_inference);
+	if (tr.optimize_exposure) {
+		if (m_world_size > 1) throw std::runtime_error{"optimize_exposure is not supported in data-parallel training (the exposure gradients are not exchanged)"};
+		const size_t bytes = tr.dataset.n_images * 3 * sizeof(float);
+		if (tr.cam_exposure_gradient_gpu.bytes() < bytes) { tr.cam_exposure_gradient_gpu.resize(bytes); tr.n_steps_since_cam_update = 0; }
+		if (tr.n_steps_since_cam_update == 0) tr.cam_exposure_gradient_gpu.memset(0, m_stream);   // 2916-2919
+	}
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
@@ -701,7 +707,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
-	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type), "compute_loss");
+	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type,
+	                           tr.optimize_exposure ? tr.cam_exposure_gradient_gpu.as<float>() : nullptr), "compute_loss");
 	profile_end(PK_LOSS, R);
 	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
@@ -802,6 +809,36 @@ void Testbed::train_nerf_dp_end() {
 		fprintf(stderr, "Nerf training generated 0 samples. Aborting training.\n");
 		m_train = false;
 	}
+	// camera-side trainables (3026, 3056-3135): only the per-image exposure is built
+	tr.n_steps_since_cam_update += 1;
+	if (tr.optimize_exposure && tr.n_steps_since_cam_update >= tr.n_steps_between_cam_updates) {
+		const uint32_t n_img = (uint32_t)tr.n_images_for_training;
+		const float per_camera_loss_scale = (float)n_img / LOSS_SCALE / (float)tr.n_steps_between_cam_updates;
+		std::vector<float> grad(tr.dataset.n_images * 3);
+		HIP_CHECK_THROW(hipMemcpyAsync(grad.data(), tr.cam_exposure_gradient_gpu.data(), grad.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
+		if (tr.cam_exposure.size() < tr.dataset.n_images) tr.cam_exposure.resize(tr.dataset.n_images);
+		float mean[3] = {0.f, 0.f, 0.f};
+		for (uint32_t i = 0; i < n_img; ++i) {   // AdamOptimizer<Array3f>::step (adam_optimizer.h:38-45), lr = the trainer's current learning rate
+			NerfTraining::ExposureAdam& a = tr.cam_exposure[i];
+			++a.iter;
+			const float beta1 = 0.9f, beta2 = 0.99f, eps = 1e-8f;
+			const float lr = m_learning_rate * std::sqrt(1 - std::pow(beta2, (float)a.iter)) / (1 - std::pow(beta1, (float)a.iter));
+			for (int c = 0; c < 3; ++c) {
+				const float g = grad[i * 3 + c] * per_camera_loss_scale + a.x[c] * tr.exposure_l2_reg;
+				a.m[c] = beta1 * a.m[c] + (1 - beta1) * g;
+				a.v[c] = beta2 * a.v[c] + (1 - beta2) * g * g;
+				a.x[c] -= lr * a.m[c] / (std::sqrt(a.v[c]) + eps);
+				mean[c] += a.x[c];
+			}
+		}
+		std::vector<float> exposures(tr.dataset.n_images * 3, 0.f);
+		for (uint32_t i = 0; i < n_img; ++i) for (int c = 0; c < 3; ++c) { tr.cam_exposure[i].x[c] -= mean[c] / (float)n_img; exposures[i * 3 + c] = tr.cam_exposure[i].x[c]; }   // renormalise (3123-3129)
+		tr.cam_exposure_gpu.copy_from_host(exposures.data(), exposures.size() * 4);
+		tr.n_steps_since_cam_update = 0;
+		++m_state_version;   // harmless for the march (it does not read exposures); keeps "inputs changed" bookkeeping honest
+	}
+	if (tr.n_steps_since_cam_update >= tr.n_steps_between_cam_updates) tr.n_steps_since_cam_update = 0;   // 3134 (train_camera false: the reference never resets; the window only matters when training)
 	// error map -> CDFs (2971-3023): low-overhead enough to be always on in the reference; sampling from them is a separate switch
 	tr.n_steps_since_error_map_update += 1;
 	if (tr.n_steps_since_error_map_update >= tr.n_steps_between_error_map_updates && tr.error_map_res[0] > 0 && tr.dataset.n_images > 0) {

@@ -122,7 +122,14 @@ struct NerfTraining {
 	int n_images_for_training_prev = 0;
 	std::vector<NgpXForm> transforms;
 	DeviceBuffer transforms_gpu;
-	DeviceBuffer cam_exposure_gpu;               // zeros: exposure optimisation is off by default (testbed.h:658-662)
+	DeviceBuffer cam_exposure_gpu;               // [n_images][3] log2 exposures the loss kernel applies to the targets (zeros until optimised)
+	// optimize_exposure (testbed.h:647, 658-666; testbed_nerf.cu:2916-2919, 3056-3135): per-image Adam on the exposure gradient of the loss kernel
+	struct ExposureAdam { uint32_t iter = 0; float m[3] = {0, 0, 0}, v[3] = {0, 0, 0}, x[3] = {0, 0, 0}; };
+	std::vector<ExposureAdam> cam_exposure;
+	DeviceBuffer cam_exposure_gradient_gpu;
+	bool optimize_exposure = false;
+	float exposure_l2_reg = 0.0f;
+	uint32_t n_steps_between_cam_updates = 16, n_steps_since_cam_update = 0;
 	NerfCounters counters_rgb;
 	Pcg32 density_grid_rng;
 	float near_distance = 0.2f;                  // testbed.h:676

@@ -195,7 +195,9 @@ int ngp_hip_compute_loss(
 	const uint16_t* encoded_in, uint16_t* encoded_out /* both NULL, or: row i of encoded_in ([n_samples][32] fp16, the x_saved that
 	ngp_hip_nerf_forward wrote for coords_in) is copied next to coords_out — see "forward pass" below */,
 	float depth_supervision_lambda /* 0: off (testbed.h:680) */, int depth_loss_type /* ELossType for the depth term, reference default L1 (testbed.h:654);
-	target = |ray.d| * metadata[img].depth at the ray's pixel, rays of images without depth are unaffected (:1450-1452, 1536-1541) */);
+	target = |ray.d| * metadata[img].depth at the ray's pixel, rays of images without depth are unaffected (:1450-1452, 1536-1541) */,
+	float* exposure_gradient /* NULL, or [n_images][3] floats that receive (atomicAdd; the caller clears them) the gradient of the loss with
+	respect to the per-image exposures (:1558-1572, optimize_exposure) */);
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);

@@ -97,7 +97,7 @@ void orc_compute_loss(
 	int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation, int snap_to_pixel_centers,
 	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */,
 	const uint16_t* encoded_in, uint16_t* encoded_out /* optional [sample][32] fp16 rows carried through the compaction */,
-	float depth_supervision_lambda, int depth_loss_type);
+	float depth_supervision_lambda, int depth_loss_type, float* exposure_gradient /* NULL or [n_images][3], accumulated */);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);
 void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout);
 

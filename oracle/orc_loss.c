@@ -62,7 +62,8 @@ void orc_compute_loss(
 	orc_coord* coords_out_all, uint16_t* dloss_doutput_all /* [max_samples_compacted][mlp_stride] */, int loss_type,
 	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
-	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type) {
+	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
+	float* exposure_gradient) {
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		uint32_t numsteps = numsteps_in[i * 2 + 0];
 		uint32_t base = numsteps_in[i * 2 + 1];
@@ -144,6 +145,13 @@ void orc_compute_loss(
 		uint16_t* dloss_doutput = dloss_doutput_all + (size_t)compacted_base * mlp_stride;
 
 		orc_lg lg = orc_loss_and_gradient(rgbtarget, rgb_ray, loss_type);
+		if (exposure_gradient) {   /* 1558-1572 */
+			for (int c = 0; c < 3; ++c) {
+				float dloss_by_dgt = -lg.gradient[c] / xy_pdf;
+				if (!train_in_linear_colors) dloss_by_dgt /= orc_srgb_to_linear_derivative(rgbtarget[c]);
+				exposure_gradient[img * 3 + c] += loss_scale * dloss_by_dgt * exposure_scale[c] * 0.6931471805599453f;
+			}
+		}
 		/* depth supervision (1450-1452) */
 		float depth_loss_gradient = 0.0f;
 		if (depth_supervision_lambda > 0.0f) {

@@ -62,7 +62,7 @@ def _rank_gradient(orc, S, n_rays_local, ray_offset, n_rays_global):
     exposure = np.zeros((S["n_img"], 3), np.float32)
     orc.orc_compute_loss(n_rays_global, aabb.ctypes.data, st, inc, B, n_alive, H.f32(128.0), 4, bg.ctypes.data, 0, 1, 0, S["n_img"], S["md"].ctypes.data, out.ctypes.data,
                          cnt.ctypes.data, r["idx"].ctypes.data, r["rays"].ctypes.data, r["ns"].ctypes.data, r["co"].ctypes.data, co_c.ctypes.data, dl.ctypes.data, 4,
-                         loss.ctypes.data, 0, None, 2, 3, 0, em.ctypes.data, em_res.ctypes.data, H.f32(S["mean"]), exposure.ctypes.data, H.f32(0.2), None, None, None, H.f32(0.0), 2)
+                         loss.ctypes.data, 0, None, 2, 3, 0, em.ctypes.data, em_res.ctypes.data, H.f32(S["mean"]), exposure.ctypes.data, H.f32(0.2), None, None, None, H.f32(0.0), 2, None)
     n_c = int(cnt[0])
     grads = np.zeros(H.n_params(S["desc"]), np.float64)
     if n_c:

@@ -43,18 +43,18 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     bg = np.array([0.2, 0.4, 0.7], np.float32)
     em_res = np.array([16, 12], np.int32)
     n_img = len(I["xf"])
-    exposure = np.zeros((n_img, 3), np.float32)
+    exposure = I.get("exposure", np.zeros((n_img, 3), np.float32))
     # ---- oracle
     o = dict(cnt=np.zeros(1, np.uint32), ns=I["r"]["ns"].copy(), co=np.zeros(B, H.COORD), dl=np.zeros((B, 4), np.float16), loss=np.zeros(n_rays, np.float32),
-             em=np.zeros(n_img * 16 * 12, np.float32), enc=np.zeros((B, 32), np.uint16))
+             em=np.zeros(n_img * 16 * 12, np.float32), enc=np.zeros((B, 32), np.uint16), expg=np.zeros((n_img, 3), np.float32))
     oracle.orc_compute_loss(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
                             I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
                             o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None,
-                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2))
+                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), o["expg"].ctypes.data if I.get("exposure_grad") else None)
     # ---- device
     d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
-             em=H.dev_zeros(n_img * 16 * 12 * 4, cuda), enc=H.dev_zeros(B * 64, cuda))
+             em=H.dev_zeros(n_img * 16 * 12 * 4, cuda), enc=H.dev_zeros(B * 64, cuda), expg=H.dev_zeros(n_img * 12, cuda))
     d_enc_in = H.to_dev(I["enc"], cuda) if "enc" in I else None
     d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
     d_md, d_mlp, d_idx, d_rays, d_co = (H.to_dev(a, cuda) for a in (I["md_dev"], I["mlp"], I["r"]["idx"], I["r"]["rays"], I["r"]["co"]))
@@ -68,9 +68,9 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
                                    d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None,
-                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2)))
+                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), d["expg"].data_ptr() if I.get("exposure_grad") else None))
     g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
-             loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"])
+             loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"], expg=H.to_host(d["expg"], np.float32).reshape(n_img, 3))
     return o, g
 
 
@@ -160,7 +160,25 @@ def test_compaction_carries_the_saved_encoding(ngp, oracle, cuda):
     # the two pointers go together
     assert ngp.ngp_hip_compute_loss(None, 1, I["aabb"].ctypes.data, 0, 1, 256, out.data_ptr(), H.f32(128.0), 4, np.zeros(3, np.float32).ctypes.data, 0, 0, 0, 1, out.data_ptr(),
                                     out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), 4, 0, None, 0, None,
-                                    2, 3, 0, None, None, out.data_ptr(), out.data_ptr(), H.f32(0.2), None, xs.data_ptr(), None, H.f32(0.0), 2) != 0
+                                    2, 3, 0, None, None, out.data_ptr(), out.data_ptr(), H.f32(0.2), None, xs.data_ptr(), None, H.f32(0.0), 2, None) != 0
+
+
+@pytest.mark.parametrize("linear,color_space", [(0, 0), (1, 1)])
+def test_exposure_gradient(ngp, oracle, cuda, linear, color_space):
+    """optimize_exposure (testbed_nerf.cu:1558-1572): per-image sums of loss_scale * (-dL/drgb [/ srgb'(target)]) * 2^exposure * ln 2"""
+    I = _inputs(oracle, cuda)
+    n_img = len(I["xf"])
+    I["exposure"] = (np.random.RandomState(2).randn(n_img, 3) * 0.3).astype(np.float32)
+    I["exposure_grad"] = True
+    B = I["n_samples"] + 128
+    o, g = _run(ngp, oracle, cuda, I, 0, B, random_bg=1, color_space=color_space, linear=linear)
+    assert np.abs(o["expg"]).min() > 0
+    # sums over ~700 rays per image in different orders (atomics), a few borderline rays may differ in their compaction
+    np.testing.assert_allclose(g["expg"], o["expg"], rtol=2e-2, atol=2e-2 * np.abs(o["expg"]).max())
+    # the exposures themselves reach the targets: the loss differs from the unexposed run
+    I0 = dict(I); I0["exposure"] = np.zeros((n_img, 3), np.float32)
+    o0 = _run(ngp, oracle, cuda, I0, 0, B, random_bg=1, color_space=color_space, linear=linear)[0]
+    assert not np.allclose(o0["loss"], o["loss"], rtol=1e-3)
 
 
 @pytest.mark.parametrize("depth_loss", [1, 0])
