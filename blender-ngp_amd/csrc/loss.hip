@@ -499,9 +499,62 @@ __global__ void construct_cdf_1d_kernel(uint32_t n_images, uint32_t height, floa
 }
 }  // namespace ngp
 
+// ---- load-time image sharpening (nerf_loader.cu:102-123, 803-825) and the Byte -> half conversion that precedes it (common_device.cuh:562-590)
+namespace ngp {
+__global__ void from_rgba32_half_kernel(uint64_t num_pixels, const uint8_t* __restrict__ pixels, half_t* __restrict__ out, uint32_t mask_color) {
+	const uint64_t i = threadIdx.x + (uint64_t)blockIdx.x * blockDim.x;
+	if (i >= num_pixels) return;
+	const uint32_t v = ((const uint32_t*)pixels)[i];
+	const float alpha = (float)(v >> 24) * (1.0f / 255.0f);
+	half_t o[4];
+	o[0] = (half_t)(srgb_to_linear((float)(v & 0xffu) * (1.0f / 255.0f)) * alpha);
+	o[1] = (half_t)(srgb_to_linear((float)((v >> 8) & 0xffu) * (1.0f / 255.0f)) * alpha);
+	o[2] = (half_t)(srgb_to_linear((float)((v >> 16) & 0xffu) * (1.0f / 255.0f)) * alpha);
+	o[3] = (half_t)alpha;
+	if (mask_color != 0 && mask_color == v) { o[0] = o[1] = o[2] = o[3] = (half_t)-1.0f; }
+#pragma unroll
+	for (int j = 0; j < 4; ++j) out[i * 4 + j] = o[j];
+}
+template <typename T>
+__global__ void sharpen_kernel(uint64_t num_pixels, uint32_t w, const T* __restrict__ pix, T* __restrict__ destpix, float center_w, float inv_totalw) {
+	const uint64_t i = threadIdx.x + (uint64_t)blockIdx.x * blockDim.x;
+	if (i >= num_pixels) return;
+	float rgba[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) rgba[j] = (float)pix[i * 4 + j] * center_w;
+	int64_t i2 = (int64_t)i - 1; if (i2 < 0) i2 = 0; i2 *= 4;
+	for (int j = 0; j < 4; ++j) rgba[j] -= (float)pix[i2++];
+	i2 = (int64_t)i - w; if (i2 < 0) i2 = 0; i2 *= 4;
+	for (int j = 0; j < 4; ++j) rgba[j] -= (float)pix[i2++];
+	i2 = (int64_t)i + 1; if (i2 >= (int64_t)num_pixels) i2 -= (int64_t)num_pixels; i2 *= 4;
+	for (int j = 0; j < 4; ++j) rgba[j] -= (float)pix[i2++];
+	i2 = (int64_t)i + w; if (i2 >= (int64_t)num_pixels) i2 -= (int64_t)num_pixels; i2 *= 4;
+	for (int j = 0; j < 4; ++j) rgba[j] -= (float)pix[i2++];
+	for (int j = 0; j < 4; ++j) destpix[i * 4 + j] = (T)fmaxf(0.f, rgba[j] * inv_totalw);
+}
+}  // namespace ngp
+
 using namespace ngp;
 
 extern "C" {
+
+int ngp_hip_image_from_rgba32_f16(void* stream, uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color) {
+	if (!n_pixels) return 0;
+	hipLaunchKernelGGL(from_rgba32_half_kernel, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_pixels, rgba8, (half_t*)out_half4, mask_color);
+	NGP_LAUNCH_CHECK("from_rgba32_half_kernel");
+	return 0;
+}
+int ngp_hip_image_sharpen(void* stream, uint64_t n_pixels, uint32_t width, const void* pix, void* dest, int image_data_type, float sharpen_amount) {
+	if (!n_pixels) return 0;
+	if (!(sharpen_amount > 0.f) || (image_data_type != 2 && image_data_type != 3) || pix == dest) { set_last_error("ngp_hip_image_sharpen: amount > 0, half4 (2) or float4 (3) pixels, out of place", hipErrorInvalidValue); return -1; }
+	const float center_w = 4.f + 1.f / sharpen_amount;   // 5 (strong) ... infinite (none)
+	const float inv_totalw = 1.f / (center_w - 4.f);
+	const dim3 grid((uint32_t)((n_pixels + 255) / 256));
+	if (image_data_type == 2) hipLaunchKernelGGL(sharpen_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, n_pixels, width, (const half_t*)pix, (half_t*)dest, center_w, inv_totalw);
+	else hipLaunchKernelGGL(sharpen_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, n_pixels, width, (const float*)pix, (float*)dest, center_w, inv_totalw);
+	NGP_LAUNCH_CHECK("sharpen_kernel");
+	return 0;
+}
 
 int ngp_hip_construct_cdf_2d(void* stream, uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y) {
 	if (!n_images || !height || !width) return 0;

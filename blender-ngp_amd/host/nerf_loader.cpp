@@ -151,7 +151,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 		if (json.contains("scale")) result.scale = (float)json["scale"].number();
 		if (json.contains("importance_sampling")) result.wants_importance_sampling = json["importance_sampling"].boolean();
 		if (json.contains("n_extra_learnable_dims") && json["n_extra_learnable_dims"].number() != 0) throw std::runtime_error{"n_extra_learnable_dims > 0 is outside the NeRF hot path of this build (SURVEY.md §8 f4)"};
-		if (sharpen_amount > 0.f) throw std::runtime_error{"image sharpening at load time is not part of this build (SURVEY.md §8 f2 subset)"};
+		result.sharpen_amount = sharpen_amount;
 
 		LensState lens;
 		float principal_point[2] = {0.5f, 0.5f}, rolling_shutter[4] = {0, 0, 0, 0};

@@ -16,6 +16,7 @@ struct LoadedNerfData {
 	std::vector<NgpXForm> xforms;                   // already in the NGP convention (nerf_matrix_to_ngp)
 	std::vector<NgpImageMeta> metadata;             // .pixels unset
 	std::vector<std::vector<uint8_t>> pixels;       // RGBA8 per image (EImageDataType::Byte)
+	float sharpen_amount = 0.f;                     // `sharpen` key or the caller's default: applied on the device after upload (nerf_loader.cu:803-825)
 	float scale = 1.0f;                             // NERF_SCALE (nerf_loader.h:28)
 	Vec3 offset{0.f, 0.f, 0.f};
 	int aabb_scale = 1;

@@ -550,6 +550,14 @@ PYBIND11_MODULE(pyngp, m) {
 				d["image_data_type"] = m.image_data_type;
 				return d;
 			}, py::arg("frame_idx"))
+		.def("get_image_pixels", [](NerfTraining& t, int i) -> py::object {   // device copy of a training image as stored: uint8 / float16 / float32 (H, W, 4)
+				if (i < 0 || (size_t)i >= t.dataset.n_images) throw std::runtime_error{"Invalid frame index"};
+				const NgpImageMeta& m = t.dataset.metadata[i];
+				const size_t px = (size_t)m.res[0] * m.res[1];
+				if (m.image_data_type == 1) { py::array_t<uint8_t> a({m.res[1], m.res[0], 4}); t.dataset.pixelmemory[i].copy_to_host(a.mutable_data(), px * 4); return a; }
+				if (m.image_data_type == 2) { py::array_t<uint16_t> a({m.res[1], m.res[0], 4}); t.dataset.pixelmemory[i].copy_to_host(a.mutable_data(), px * 8); return a.attr("view")("float16"); }
+				py::array_t<float> a({m.res[1], m.res[0], 4}); t.dataset.pixelmemory[i].copy_to_host(a.mutable_data(), px * 16); return a;
+			}, py::arg("frame_idx"))
 		.def("get_image_rgba8", [](NerfTraining& t, int i) {      // device copy of a Byte-typed training image
 				if (i < 0 || (size_t)i >= t.dataset.n_images) throw std::runtime_error{"Invalid frame index"};
 				const NgpImageMeta& m = t.dataset.metadata[i];

@@ -103,6 +103,26 @@ void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pi
 	}
 	update_metadata(frame_idx, frame_idx + 1);
 }
+void NerfDataset::sharpen_training_image(int frame_idx, float sharpen_amount) {
+	if (!(sharpen_amount > 0.f)) return;
+	if (frame_idx < 0 || (size_t)frame_idx >= n_images) throw std::runtime_error{"NerfDataset::sharpen_training_image: invalid frame index"};
+	NgpImageMeta& m = metadata[frame_idx];
+	const uint64_t px = (uint64_t)m.res[0] * m.res[1];
+	auto chk = [](int rc, const char* what) { if (rc) throw std::runtime_error{std::string{what} + ": " + ngp_hip_last_error()}; };
+	if (m.image_data_type == 1) {   // Byte -> premultiplied linear half4 (the hot-pink mask colour of the converted bytes becomes -1)
+		DeviceBuffer half4; half4.resize(px * 8);
+		chk(ngp_hip_image_from_rgba32_f16(nullptr, px, pixelmemory[frame_idx].as<uint8_t>(), half4.as<uint16_t>(), 0x00FF00FFu), "image_from_rgba32_f16");
+		HIP_CHECK_THROW(hipStreamSynchronize(nullptr));
+		pixelmemory[frame_idx] = std::move(half4);
+		m.image_data_type = 2;
+	}
+	DeviceBuffer sharpened; sharpened.resize(px * (m.image_data_type == 2 ? 8 : 16));
+	chk(ngp_hip_image_sharpen(nullptr, px, (uint32_t)m.res[0], pixelmemory[frame_idx].data(), sharpened.data(), m.image_data_type, sharpen_amount), "image_sharpen");
+	HIP_CHECK_THROW(hipStreamSynchronize(nullptr));
+	pixelmemory[frame_idx] = std::move(sharpened);
+	m.pixels = pixelmemory[frame_idx].data();
+	update_metadata(frame_idx, frame_idx + 1);
+}
 void NerfDataset::update_metadata(int first, int last) {
 	if (last < 0 || last > (int)n_images) last = (int)n_images;
 	int n = last - first;
@@ -282,7 +302,10 @@ void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:
 	d.pixelmemory.clear(); d.pixelmemory.resize(d.n_images);
 	d.scale = data.scale; d.offset = data.offset; d.aabb_scale = data.aabb_scale; d.from_mitsuba = data.from_mitsuba; d.is_hdr = data.is_hdr;
 	d.render_aabb = data.render_aabb; d.up = data.up;
-	for (size_t i = 0; i < d.n_images; ++i) d.set_training_image((int)i, data.metadata[i].res[0], data.metadata[i].res[1], data.pixels[i].data(), 1);
+	for (size_t i = 0; i < d.n_images; ++i) {
+		d.set_training_image((int)i, data.metadata[i].res[0], data.metadata[i].res[1], data.pixels[i].data(), 1);
+		d.sharpen_training_image((int)i, data.sharpen_amount);
+	}
 	m_data_path = data_path;
 	load_nerf_post();
 	m_training_data_available = true;

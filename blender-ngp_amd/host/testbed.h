@@ -102,6 +102,7 @@ struct NerfDataset {
 	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix) const;   // nerf_loader.h:113-132
 	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix) const;    // nerf_loader.h:134-152
 	void set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type, const float* depth_host = nullptr, float depth_scale = -1.f); // nerf_loader.cu:749-
+	void sharpen_training_image(int frame_idx, float sharpen_amount);   // nerf_loader.cu:803-825: Byte -> half4, then the unsharp filter
 	void update_metadata(int first = 0, int last = -1);         // nerf_loader.cu:851-867
 };
 

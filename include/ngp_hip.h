@@ -169,6 +169,13 @@ int ngp_hip_generate_training_samples(
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
 	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */);
 
+/* ============================ load-time image sharpening (src/nerf_loader.cu:102-123, 803-825) ============================
+ * NerfDataset::set_training_image with sharpen_amount > 0: Byte images first become premultiplied linear half4 (from_rgba32<__half>,
+ * common_device.cuh:562-590; mask_color pixels -> -1), then the 5-tap unsharp filter with centre weight 4 + 1/amount runs out of place
+ * (neighbours wrap around the image like in the reference).  image_data_type: 2 half4, 3 float4. */
+int ngp_hip_image_from_rgba32_f16(void* stream, uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color);
+int ngp_hip_image_sharpen(void* stream, uint64_t n_pixels, uint32_t width, const void* pix, void* dest, int image_data_type, float sharpen_amount);
+
 /* ============================ error-map CDFs (src/testbed_nerf.cu:1982-2037, 2971-3024) ============================ */
 /* construct_cdf_2d: per image and row, running sum of (error + 1e-10) over x, normalised and blended with MIN_PDF = 0.01 of uniform;
  * cdf_y[img][y] receives the row totals.  construct_cdf_1d: the same over the row totals, cdf_img[img] receives the image total (the

@@ -98,6 +98,8 @@ void orc_compute_loss(
 	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */,
 	const uint16_t* encoded_in, uint16_t* encoded_out /* optional [sample][32] fp16 rows carried through the compaction */,
 	float depth_supervision_lambda, int depth_loss_type, float* exposure_gradient /* NULL or [n_images][3], accumulated */);
+void orc_image_from_rgba32_f16(uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color);
+void orc_image_sharpen(uint64_t n_pixels, uint32_t w, const void* pix, void* dest, int is_half, float sharpen_amount);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);
 void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, float* inout);
 

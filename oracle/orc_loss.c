@@ -249,3 +249,40 @@ void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_inpu
 	if (avail == 0 || avail >= total) return;
 	for (size_t i = avail; i < total; ++i) inout[i] = inout[i % avail];
 }
+
+/* common_device.cuh:562-590 from_rgba32<__half> (white / black -> transparent are applied to the bytes beforehand, nerf_loader.cu:59-81) */
+void orc_image_from_rgba32_f16(uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color) {
+	for (uint64_t i = 0; i < n_pixels; ++i) {
+		uint32_t v; memcpy(&v, rgba8 + i * 4, 4);
+		float alpha = (float)(v >> 24) * (1.0f / 255.0f);
+		uint16_t* o = out_half4 + i * 4;
+		o[0] = orc_f2h(orc_srgb_to_linear((float)(v & 0xffu) * (1.0f / 255.0f)) * alpha);
+		o[1] = orc_f2h(orc_srgb_to_linear((float)((v >> 8) & 0xffu) * (1.0f / 255.0f)) * alpha);
+		o[2] = orc_f2h(orc_srgb_to_linear((float)((v >> 16) & 0xffu) * (1.0f / 255.0f)) * alpha);
+		o[3] = orc_f2h(alpha);
+		if (mask_color != 0 && mask_color == v) o[0] = o[1] = o[2] = o[3] = orc_f2h(-1.0f);
+	}
+}
+/* nerf_loader.cu:102-123 sharpen<T> with center_w = 4 + 1 / amount (:817-823); half4 (is_half) or float4 pixels */
+void orc_image_sharpen(uint64_t n_pixels, uint32_t w, const void* pix, void* dest, int is_half, float sharpen_amount) {
+	const float center_w = 4.f + 1.f / sharpen_amount, inv_totalw = 1.f / (center_w - 4.f);
+	const uint16_t* ph = (const uint16_t*)pix; const float* pf = (const float*)pix;
+#define ORC_PX(k) (is_half ? orc_h2f(ph[k]) : pf[k])
+	for (uint64_t i = 0; i < n_pixels; ++i) {
+		float rgba[4];
+		for (int j = 0; j < 4; ++j) rgba[j] = ORC_PX(i * 4 + j) * center_w;
+		int64_t i2 = (int64_t)i - 1; if (i2 < 0) i2 = 0; i2 *= 4;
+		for (int j = 0; j < 4; ++j) rgba[j] -= ORC_PX(i2++);
+		i2 = (int64_t)i - w; if (i2 < 0) i2 = 0; i2 *= 4;
+		for (int j = 0; j < 4; ++j) rgba[j] -= ORC_PX(i2++);
+		i2 = (int64_t)i + 1; if (i2 >= (int64_t)n_pixels) i2 -= (int64_t)n_pixels; i2 *= 4;
+		for (int j = 0; j < 4; ++j) rgba[j] -= ORC_PX(i2++);
+		i2 = (int64_t)i + w; if (i2 >= (int64_t)n_pixels) i2 -= (int64_t)n_pixels; i2 *= 4;
+		for (int j = 0; j < 4; ++j) rgba[j] -= ORC_PX(i2++);
+		for (int j = 0; j < 4; ++j) {
+			const float v = fmaxf(0.f, rgba[j] * inv_totalw);
+			if (is_half) ((uint16_t*)dest)[i * 4 + j] = orc_f2h(v); else ((float*)dest)[i * 4 + j] = v;
+		}
+	}
+#undef ORC_PX
+}
