@@ -28,6 +28,8 @@ for p in (PKG, os.path.join(ROOT, "tests")):
 FWD_BYTES_PER_SAMPLE = 588     # 512 B gathered + 12 B position + 64 B encoded features
 BWD_BYTES_PER_SAMPLE = 1100    # 64 B dL/dy + 12 B pos + 512 B read + 512 B write (atomic RMW)
 OPT_BYTES_PER_PARAM = 36       # grads 2 + master 4+4 + m 4+4 + v 4+4 + fp16 2 + ema 4+4 ... see DESIGN.md (28 B + 8 B EMA)
+BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
+SURVEY_STEPS = 48              # untimed steps with every launch group bracketed by events (picks the dominant group, fills "kernels")
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
@@ -265,7 +267,16 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    # Bracketing a launch group with HIP events costs dispatch gaps on the step's critical chain (~5 us per bracket), so only the
+    # dominant kernel group — the one the roofline is quoted for — is timed live inside the timed region.  Which one that is, and the
+    # per-group table in "kernels", comes from SURVEY_STEPS further untimed steps with every group bracketed.
     tb.set_profiling(True)
+    tb.reset_profile()
+    for _ in range(SURVEY_STEPS):
+        one_step()
+    survey = tb.profile()
+    dom = max((n for n in survey if n in BYTES_PER_UNIT and survey[n]["launches"]), key=lambda n: survey[n]["ms"])
+    tb.set_profiling(True, [dom])
     tb.reset_profile()
     if use_dp:
         dist.barrier()
@@ -274,9 +285,11 @@ def main():
     t0 = time.perf_counter()
     samples = 0
     rays = 0
+    pre_compaction = 0
     for _ in range(a.steps):
         rays += tb.nerf.training.rays_per_batch
         samples += min(one_step(), B)
+        pre_compaction += tb.nerf.training.measured_batch_size_before_compaction
     tb.sync()
     torch.cuda.synchronize()
     if use_dp:
@@ -284,7 +297,6 @@ def main():
     dt = time.perf_counter() - t0
     prof = tb.profile()
     tb.set_profiling(False)
-    pre_compaction = prof["nerf_inference"]["units"]
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -303,15 +315,20 @@ def main():
         return
 
     # ---- roofline of the dominant kernel, from HIP-event timings taken on the launch stream during the timed region
-    bytes_per_unit = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
-    kernels = {}
-    for name, e in prof.items():
-        if e["launches"]:
-            k = {"ms_total": round(e["ms"], 3), "launches": int(e["launches"]), "avg_us": round(1000.0 * e["ms"] / e["launches"], 2), "units_per_launch": round(e["units"] / e["launches"], 1)}
-            if name in bytes_per_unit:
-                k["algorithmic_GBps"] = round(bytes_per_unit[name] * e["units"] / (e["ms"] * 1e-3) / 1e9, 1)
-            kernels[name] = k
-    dom = max((n for n in kernels if n in bytes_per_unit), key=lambda n: kernels[n]["ms_total"])
+    bytes_per_unit = BYTES_PER_UNIT
+
+    def table(p):
+        out = {}
+        for name, e in p.items():
+            if e["launches"]:
+                k = {"ms_total": round(e["ms"], 3), "launches": int(e["launches"]), "avg_us": round(1000.0 * e["ms"] / e["launches"], 2), "units_per_launch": round(e["units"] / e["launches"], 1)}
+                if name in bytes_per_unit:
+                    k["algorithmic_GBps"] = round(bytes_per_unit[name] * e["units"] / (e["ms"] * 1e-3) / 1e9, 1)
+                out[name] = k
+        return out
+
+    kernels = table(survey)            # all groups, from the untimed survey steps
+    kernels.update(table(prof))        # the dominant group, from the timed region
     achieved = kernels[dom]["algorithmic_GBps"]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -343,7 +360,7 @@ def main():
         "config": {"workload": "procedural-lego %dx%d x%d RGBA8 views (scale 0.33, offset 0.5, aabb_scale 1), configs/nerf/base.json (L=16 F=2 T=2^19, 64-wide MLPs), batch 2^18 compacted samples per GPU" % (a.res, a.res, a.n_train),
                    "global_batch": B * world, "parallelism": "dp%d" % world if use_dp else "single"},
         "rays_per_s": round(rays / dt, 1), "pre_compaction_samples_per_s": round(pre_compaction / dt, 1),
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region; other groups: %d untimed survey steps" % (dom, SURVEY_STEPS),
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:

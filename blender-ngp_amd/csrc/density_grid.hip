@@ -186,19 +186,19 @@ __global__ void gather_words_kernel(const uint32_t* a, const uint32_t* b, const 
 	}
 }
 
-__global__ void post_words_kernel(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst, uint32_t* zero2, double* sum3_dev) {
+__global__ void post_words_kernel(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst, uint32_t* zero_words, uint32_t n_zero_words, double* sum3_dev) {
 	if (threadIdx.x == 0) {
 		const uint32_t va = a ? *a : 0u, vb = b ? *b : 0u, vc = c ? *c : 0u;
 		dst[0] = va; dst[1] = vb; dst[2] = vc;
 		if (sum3_dev) { sum3_dev[0] = (double)va; sum3_dev[1] = (double)vb; sum3_dev[2] = (double)__uint_as_float(vc); }
-		if (zero2) { zero2[0] = 0u; zero2[1] = 0u; }
+		for (uint32_t k = 0; k < n_zero_words; ++k) zero_words[k] = 0u;
 		__threadfence_system();
 		__hip_atomic_store(&dst[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
-int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2, double* sum3_dev) {
-	hipLaunchKernelGGL(post_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, tag, dst4, zero2, sum3_dev);
+int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words, double* sum3_dev) {
+	hipLaunchKernelGGL(post_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c, tag, dst4, zero_words, zero_words ? n_zero_words : 0u, sum3_dev);
 	NGP_LAUNCH_CHECK("post_words_kernel");
 	return 0;
 }

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		}
 	}
 
-	// ---- compaction slots: one atomic per workgroup of 16 rays (1434)
+	// ---- compaction slots: one atomic per workgroup (1434)
 	if (lane == 0) s_counts[w] = compacted;
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -193,12 +193,13 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		s_block_base = total ? atomicAdd(a.numsteps_counter, total) : 0u;
 	}
 	__syncthreads();
-	if (!active) return;
+	// (slots that produce no loss get a zero: the reference clears the whole array before the step, :2864)
+	if (!active) { if (lane == 0 && a.loss_output && i < a.n_rays) a.loss_output[i] = 0.f; return; }
 	const uint32_t compacted_base = s_block_base + s_counts[w];
 	const uint32_t room = a.max_samples_compacted - (a.max_samples_compacted < compacted_base ? a.max_samples_compacted : compacted_base);
 	compacted = room < compacted ? room : compacted;
 	if (lane == 0) { a.numsteps_in[i * 2 + 0] = compacted; a.numsteps_in[i * 2 + 1] = compacted_base; }
-	if (compacted == 0) return;
+	if (compacted == 0) { if (lane == 0 && a.loss_output) a.loss_output[i] = 0.f; return; }
 
 	const LG lg = loss_and_gradient(rgbtarget, rgb_ray, a.loss_type);
 	// per-image exposure gradient (1558-1572): d loss / d exposure = loss_scale * (-dL/drgb / xy_pdf [/ srgb'(target)]) * 2^exposure * ln 2

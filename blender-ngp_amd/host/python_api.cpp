@@ -377,7 +377,17 @@ PYBIND11_MODULE(pyngp, m) {
 				return d;
 			})
 		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
-		.def("set_profiling", [](Testbed& t, bool on) { t.m_profile_enabled = on; })
+		.def("set_profiling", [](Testbed& t, bool on, const std::vector<std::string>& only) {
+				// only: names as in profile(); empty = all kinds.  Every bracketed launch group costs two event records on the stream.
+				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep"};
+				uint32_t mask = only.empty() ? ~0u : 0u;
+				for (const auto& n : only) {
+					bool found = false;
+					for (int k = 0; k < Testbed::PK_COUNT; ++k) if (n == names[k]) { mask |= 1u << k; found = true; }
+					if (!found) throw std::invalid_argument{"set_profiling: unknown kernel group '" + n + "'"};
+				}
+				t.m_profile_enabled = on; t.m_profile_mask = mask;
+			}, py::arg("on"), py::arg("only") = std::vector<std::string>{})
 		.def("reset_profile", &Testbed::reset_profile)
 		.def("profile", [](Testbed& t) {
 				t.sync();

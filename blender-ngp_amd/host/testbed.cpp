@@ -13,6 +13,11 @@
 #include <cstdio>
 #include <fstream>
 
+// Events of the training step order work between streams of ONE device (march on stream B -> network pass on stream A, grid gradients
+// -> the all-reduce stream) or are waited on by a host that reads host-coherent pinned words a kernel fenced itself (post_words).
+// A device-scope release is enough for both and saves the system-scope cache write-back the default record does (step -1 %).
+static constexpr unsigned STEP_EVENT_FLAGS = hipEventDisableTiming | hipEventReleaseToDevice;
+
 namespace ngp {
 
 static constexpr uint32_t GRID_CELLS = NGP_NERF_GRID_N_CELLS;
@@ -236,13 +241,13 @@ void* Testbed::prof_event() {
 	return e;
 }
 void Testbed::profile_begin(int k, void* stream) {
-	if (!m_profile_enabled) return;
+	if (!m_profile_enabled || !((m_profile_mask >> k) & 1u)) return;
 	ProfPending p{k, prof_event(), nullptr, 0};
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)(stream ? stream : m_stream)));
 	m_prof_pending.push_back(p);
 }
 void Testbed::profile_end(int k, uint64_t units, void* stream) {
-	if (!m_profile_enabled) return;
+	if (!m_profile_enabled || !((m_profile_mask >> k) & 1u)) return;
 	for (auto it = m_prof_pending.rbegin(); it != m_prof_pending.rend(); ++it) {
 		if (it->k == k && !it->e1) {
 			it->e1 = prof_event();
@@ -615,8 +620,8 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	NerfTraining& tr = m_nerf.training;
 	const size_t r_cap = std::max<size_t>(R, 1u << 18);  // rays_per_batch is capped at 2^18 (2893): size once, no reallocation under a running step
 	m_ray_indices.enlarge(r_cap * 4); m_rays.enlarge(r_cap * sizeof(NgpRay)); m_numsteps.enlarge(r_cap * 8);
-	m_gen_counters.enlarge(16);
-	uint32_t* counters = m_gen_counters.as<uint32_t>() + 2 * slot;  // [0] ray counter, [1] numsteps counter
+	m_gen_counters.enlarge(32);
+	uint32_t* counters = m_gen_counters.as<uint32_t>() + 4 * slot;  // [0] ray counter, [1] numsteps counter, [2] compacted numsteps counter (the step's)
 	if (m_next_slot_zeroed == slot) m_next_slot_zeroed = -1;   // cleared by the previous step's post_words launch
 	else HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
 	const int32_t dist_res[2] = {32, 32};
@@ -650,7 +655,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	p.cdf_mode = m_nerf.training.cdf_mode();
 	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the counters event has fired by now
 	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng);
-	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_prefetch_event = e; }
+	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
 	m_prefetch = p;
 }
@@ -670,9 +675,9 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(target_batch_size, next_max_inference(target_batch_size))));
 
 	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)
-	c.numsteps_counter_compacted.enlarge(4); c.loss.enlarge(std::max<size_t>(R, 1u << 18) * 4);
-	c.numsteps_counter_compacted.memset(0, m_stream);
-	HIP_CHECK_THROW(hipMemsetAsync(c.loss.data(), 0, (size_t)R * 4, (hipStream_t)m_stream));
+	// (the compacted-samples counter lives next to the march's counters and is cleared below; the loss kernel writes every one of the R loss
+	// slots, zeros for the unused ones, so neither needs a memset on the step's critical chain)
+	c.loss.enlarge(std::max<size_t>((size_t)R * m_world_size, 1u << 18) * 4);   // [n_rays_global]: the kernel's slot range
 	// error map (re)allocation (2933-2939)
 	if (tr.n_steps_since_error_map_update == 0 && !tr.dataset.metadata.empty()) {
 		const uint32_t n_samples_per_image = (tr.n_steps_between_error_map_updates * R) / (uint32_t)tr.dataset.n_images;
@@ -706,7 +711,10 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		drop_prefetch();
 		launch_generate(m_stream, m_gen_slot, R, max_inference, m_rng);
 	}
-	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 2 * m_gen_slot;
+	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 4 * m_gen_slot;
+	uint32_t* compacted_counter = gen_counters + 2;
+	if (m_compact_slot_zeroed == m_gen_slot) m_compact_slot_zeroed = -1;   // cleared by the previous step's post_words launch
+	else HIP_CHECK_THROW(hipMemsetAsync(compacted_counter, 0, 4, (hipStream_t)m_stream));
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	const uint32_t n_rays_global = R * m_world_size;
 	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256).  The pass also stores every sample's encoding
@@ -726,7 +734,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	NgpErrorMapCdf cdf_storage;
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
 	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
-	                           m_mlp_out.as<uint16_t>(), c.numsteps_counter_compacted.as<uint32_t>(), m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
+	                           m_mlp_out.as<uint16_t>(), compacted_counter, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
@@ -744,17 +752,17 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	if (!m_host_words) {
 		HIP_CHECK_THROW(hipHostMalloc(&m_host_words, 16, hipHostMallocMapped | hipHostMallocCoherent));
-		hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_counters_event = e;
+		hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_counters_event = e;
 	}
-	// the same launch clears the other slot's march counters: its last reader (the previous step's loss kernel) is long done, and the
+	// the same launch clears the other slot's march counters and compacted-samples counter: its last reader (the previous step's loss kernel) is long done, and the
 	// march that will bump them is launched after the host has seen this step's counters
 	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
-	m_next_slot_zeroed = m_gen_slot ^ 1;
-	check(ngp_hip_post_words(m_stream, gen_counters + 1, c.numsteps_counter_compacted.as<uint32_t>(), (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
-	                         m_gen_counters.as<uint32_t>() + 2 * (m_gen_slot ^ 1), (double*)m_dp_counters_dev), "post_words");
+	m_next_slot_zeroed = m_compact_slot_zeroed = m_gen_slot ^ 1;
+	check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
+	                         m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1), 3, (double*)m_dp_counters_dev), "post_words");
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
-	check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, c.numsteps_counter_compacted.as<uint32_t>(), m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
+	check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
 	                                     m_x_saved.as<float>(), 16), "fill_rollover");
 
 	// ---- train_nerf_step, second half (3324-3332): backward on the compacted batch (gradients overwrite).  The reference's forward over
@@ -765,7 +773,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		profile_end(PK_FORWARD, target_batch_size);
 	}
 	profile_begin(PK_BACKWARD);
-	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_grid_grad_event = e; }
+	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
 	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_grid_grad_event), "nerf_backward");
 	profile_end(PK_BACKWARD, target_batch_size);

@@ -107,7 +107,7 @@ struct NerfDataset {
 };
 
 struct NerfCounters {  // testbed.h:369-381
-	DeviceBuffer numsteps_counter, numsteps_counter_compacted, loss;
+	DeviceBuffer numsteps_counter, loss;   // (numsteps_counter_compacted: Testbed::m_gen_counters, word 2 of the step's slot)
 	uint32_t rays_per_batch = 1 << 12;
 	uint32_t n_rays_total = 0;
 	uint32_t measured_batch_size = 0;
@@ -345,6 +345,7 @@ public:
 	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
 	bool m_profile_enabled = false;
+	uint32_t m_profile_mask = ~0u;   // bit k: bracket the launches of ProfKernel k with events (each bracket costs a few us of dispatch gap)
 	ProfAccum m_prof[PK_COUNT];
 	void reset_profile();
 	void profile_begin(int k, void* stream = nullptr);
@@ -380,13 +381,14 @@ private:
 	void* m_host_words = nullptr;                      // 4 pinned, device-mapped words: {numsteps, numsteps_compacted, loss sum, -}
 	float m_local_loss_sum = 0.f;
 	int m_gen_slot = 0;
+	int m_compact_slot_zeroed = -1;                    // ... and whose compacted-samples counter
 	int m_next_slot_zeroed = -1;                       // slot whose march counters the last post_words launch cleared
 	uint32_t m_post_tag = 0;
 	void* m_dp_counters_dev = nullptr;
 	void* m_grid_grad_event = nullptr;
 	uint64_t m_state_version = 0;
 	bool m_train_continues = true;
-	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter}
+	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter, compacted numsteps counter, pad}
 	uint32_t next_max_inference(uint32_t target_batch_size) const;
 	void launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng);
 	void maybe_prefetch_next(uint32_t target_batch_size);

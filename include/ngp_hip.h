@@ -189,7 +189,9 @@ int ngp_hip_construct_cdf_1d(void* stream, uint32_t n_images, uint32_t height, f
  * recomputes the MLPs from the saved encoding, so all it needs from "forward" is x_saved — a pure function of the sample position.  A
  * host may therefore run ngp_hip_nerf_forward instead of ngp_hip_nerf_inference on the uncompacted samples and let ngp_hip_compute_loss
  * carry each kept sample's 64-byte encoding row along with its coordinates (encoded_in / encoded_out), then roll it over like the
- * coordinates (ngp_hip_fill_rollover_f32 with stride 16): same bits as the second pass would produce, one gather pass less. */
+ * coordinates (ngp_hip_fill_rollover_f32 with stride 16): same bits as the second pass would produce, one gather pass less.
+ * loss_output ([n_rays] floats, optional): every slot is written — the ray's loss / n_rays, or 0 for slots that hold no ray or whose ray
+ * got no room in the compacted batch (the reference leaves those at the zero its per-step memset put there, :2864). */
 int ngp_hip_compute_loss(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
 	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
@@ -219,9 +221,9 @@ int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out
  * host can pick the step's counters up from an event instead of draining the stream. */
 int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* dst4);
 /* Same for a host that POLLS host-mapped memory instead of waiting on an event: dst4[0..2] = *a, *b, *c (NULL -> 0), then — after a
- * system-scope fence — dst4[3] = tag, so a reader that sees the tag sees the three words.  zero2 (optional) gets two words cleared in
- * the same launch (the next march's counters, which would otherwise cost a memset on the counter -> march chain). */
-int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero2,
+ * system-scope fence — dst4[3] = tag, so a reader that sees the tag sees the three words.  zero_words (optional) gets n_zero_words (a few) words
+ * cleared in the same launch (the next step's march and compaction counters, which would otherwise cost memsets on the step's critical chain). */
+int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words,
                        double* sum3_dev /* optional DEVICE copy {(double)*a, (double)*b, (double)(float)*c}: the operand of a data-parallel host's counter all-reduce */);
 
 /* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */

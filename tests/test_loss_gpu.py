@@ -323,13 +323,13 @@ def test_counter_posting_kernels(ngp, cuda):
     torch.cuda.synchronize()
     assert dst.cpu().tolist() == [123456, 7890, 0, int(np.float32(0.375).view(np.int32))]
     dst.fill_(-1)
-    z = torch.tensor([5, 6, 7], dtype=torch.int32, device=cuda)
+    z = torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=cuda)
     s3 = torch.zeros(3, dtype=torch.float64, device=cuda)
-    check(ngp.ngp_hip_post_words(None, a.data_ptr(), b.data_ptr(), c.data_ptr(), 42, dst.data_ptr(), z.data_ptr(), s3.data_ptr()))
+    check(ngp.ngp_hip_post_words(None, a.data_ptr(), b.data_ptr(), c.data_ptr(), 42, dst.data_ptr(), z.data_ptr(), 3, s3.data_ptr()))
     torch.cuda.synchronize()
     assert dst.cpu().tolist() == [123456, 7890, int(np.float32(0.375).view(np.int32)), 42]
-    assert z.cpu().tolist() == [0, 0, 7]
+    assert z.cpu().tolist() == [0, 0, 0, 8]
     assert s3.cpu().tolist() == [123456.0, 7890.0, 0.375]
-    check(ngp.ngp_hip_post_words(None, None, None, None, 43, dst.data_ptr(), None, None))
+    check(ngp.ngp_hip_post_words(None, None, None, None, 43, dst.data_ptr(), None, 0, None))
     torch.cuda.synchronize()
     assert dst.cpu().tolist() == [0, 0, 0, 43]
