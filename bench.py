@@ -214,6 +214,9 @@ def cpu_baseline(n=65536, k=2):
 
 
 def main():
+    if os.environ.get("BENCH_HANG_DUMP"):   # dev: dump every thread's stack and exit if the run is still going after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_HANG_DUMP"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -243,7 +246,7 @@ def main():
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world > 1:
+        if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: its env:// rendezvous
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 1000), rank=0, world_size=1, device_id=dev)

@@ -760,7 +760,10 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_next_slot_zeroed = m_compact_slot_zeroed = m_gen_slot ^ 1;
 	check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
 	                         m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1), 3, (double*)m_dp_counters_dev), "post_words");
-	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
+	// an event record costs a few microseconds of dispatch gap on the stream: the two step events are only recorded at their precise
+	// points once somebody has asked to wait on them (stream_wait_*, data-parallel hosts); the polling host below does not need one
+	m_counters_event_recorded = m_want_counters_event;
+	if (m_want_counters_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
 	check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
 	                                     m_x_saved.as<float>(), 16), "fill_rollover");
@@ -775,7 +778,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
 	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_grid_grad_event), "nerf_backward");
+	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
+	m_grid_grad_event_recorded = m_want_grid_grad_event;
 	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
 
@@ -787,7 +791,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		uint32_t spins = 0;
 		while (__atomic_load_n((const uint32_t*)&w[3], __ATOMIC_ACQUIRE) != m_post_tag) {
 			if ((++spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-				HIP_CHECK_THROW(hipEventSynchronize((hipEvent_t)m_counters_event));   // also surfaces a failed kernel instead of spinning forever
+				HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));   // also surfaces a failed kernel instead of spinning forever
 				break;
 			}
 		}
@@ -799,10 +803,14 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 
 void Testbed::stream_wait_counters(void* other_stream) {
 	if (!m_counters_event) throw std::runtime_error{"stream_wait_counters: no step has been begun"};
+	m_want_counters_event = true;   // from the next step on, recorded right behind the counters
+	if (!m_counters_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream)); m_counters_event_recorded = true; }   // this step: everything queued so far
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_counters_event, 0));
 }
 void Testbed::stream_wait_grid_gradients(void* other_stream) {
 	if (!m_grid_grad_event) throw std::runtime_error{"stream_wait_grid_gradients: no step has been begun"};
+	m_want_grid_grad_event = true;
+	if (!m_grid_grad_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream)); m_grid_grad_event_recorded = true; }
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_grid_grad_event, 0));
 }
 

@@ -378,6 +378,7 @@ private:
 	PrefetchedSamples m_prefetch;
 	void* m_prefetch_event = nullptr;
 	void* m_counters_event = nullptr;
+	bool m_want_counters_event = false, m_counters_event_recorded = false, m_want_grid_grad_event = false, m_grid_grad_event_recorded = false;
 	void* m_host_words = nullptr;                      // 4 pinned, device-mapped words: {numsteps, numsteps_compacted, loss sum, -}
 	float m_local_loss_sum = 0.f;
 	int m_gen_slot = 0;
