@@ -254,6 +254,7 @@ def main():
     B = 1 << 18
     ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
     tb = scene.build_testbed(ds)
+    tb.async_training_steps = True   # frame() without the reference's per-step stream drain (pyngp property; the timed region is still bracketed by syncs)
     tb.set_distributed(rank, world)
     dp = None
     if use_dp:

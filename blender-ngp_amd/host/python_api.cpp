@@ -389,6 +389,7 @@ PYBIND11_MODULE(pyngp, m) {
 				t.m_profile_enabled = on; t.m_profile_mask = mask;
 			}, py::arg("on"), py::arg("only") = std::vector<std::string>{})
 		.def("reset_profile", &Testbed::reset_profile)
+		.def_readwrite("async_training_steps", &Testbed::m_async_training_steps, "frame() does not drain the stream after the training step (the reference does, testbed.cu:2570): the next step's launches queue behind this one's optimizer instead of after an idle gap.  Everything the API reads afterwards is ordered by the same stream; call sync() before touching device buffers from another stream.")
 		.def("profile", [](Testbed& t) {
 				t.sync();
 				t.profile_collect();

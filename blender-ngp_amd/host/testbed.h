@@ -15,6 +15,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "mini_json.h"
@@ -344,13 +345,15 @@ public:
 	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
 	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
+	bool m_async_training_steps = false;              // frame() returns with the step's tail (backward, optimizer) still running on the stream
+	std::chrono::steady_clock::time_point m_last_step_return{};
 	bool m_profile_enabled = false;
 	uint32_t m_profile_mask = ~0u;   // bit k: bracket the launches of ProfKernel k with events (each bracket costs a few us of dispatch gap)
 	ProfAccum m_prof[PK_COUNT];
 	void reset_profile();
 	void profile_begin(int k, void* stream = nullptr);
 	void profile_end(int k, uint64_t units, void* stream = nullptr);
-	void profile_collect();                            // after a stream sync: fold pending event pairs into m_prof
+	void profile_collect(bool only_finished = false);                            // after a stream sync: fold pending event pairs into m_prof
 
 	// network + optimizer state
 	NgpNetDesc m_desc{};
