@@ -93,6 +93,53 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	const NgpCoord* __restrict__ ci = a.coords_in + base;
 	const uint16_t* __restrict__ no = a.network_output + (size_t)base * a.mlp_stride;
 
+	// ---- target colour: replay the ray generator's draws (1376-1423); wave-uniform.  Placed before pass 1 (the reference computes it after): its
+	// dependent loads (ray index -> image metadata -> pixel) are then in flight while pass 1 runs; only the background term needs pass 1's result.
+	float bg[3] = {0.f, 0.f, 0.f};
+	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f, pixel_pdf = 1.0f, exposure_scale[3] = {1.f, 1.f, 1.f};
+	uint32_t img = 0;
+	int32_t img_res[2] = {1, 1};
+	v3 ray_o = mk(0, 0, 0);
+	if (active) {
+		ray_o = ld3(a.rays_in[i].o);
+		const uint32_t ray_idx = a.ray_indices_in[i];
+		Pcg32 rng = a.rng;
+		rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
+		float img_pdf = 1.0f, xy_pdf = 1.0f;
+		img = image_idx(ray_idx, a.n_rays, a.n_training_images, a.cdf.cdf_img, &img_pdf);
+		const NgpImageMeta& md = a.metadata[img];
+		img_res[0] = md.res[0]; img_res[1] = md.res[1];
+		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, xy[0], xy[1], &xy_pdf);
+		sample_pdf = img_pdf * xy_pdf; pixel_pdf = xy_pdf;
+		max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
+		bg[0] = a.background_color[0]; bg[1] = a.background_color[1]; bg[2] = a.background_color[2];
+		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
+#pragma unroll
+		for (int c = 0; c < 3; ++c) bg[c] = srgb_to_linear(bg[c]);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * a.exposure[img * 3 + c]);
+		float texsamp[4];
+		read_rgba(xy[0], xy[1], md.res, md.pixels, md.image_data_type, texsamp);
+		if (a.train_in_linear_colors || a.color_space == NGP_COLOR_LINEAR) {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) rgbtarget[c] = exposure_scale[c] * texsamp[c] + (1.0f - texsamp[3]) * bg[c];
+			if (!a.train_in_linear_colors) {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) { rgbtarget[c] = linear_to_srgb(rgbtarget[c]); bg[c] = linear_to_srgb(bg[c]); }
+			}
+		} else {
+#pragma unroll
+			for (int c = 0; c < 3; ++c) bg[c] = linear_to_srgb(bg[c]);
+			if (texsamp[3] > 0) {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) rgbtarget[c] = linear_to_srgb(exposure_scale[c] * texsamp[c] / texsamp[3]) * texsamp[3] + (1.0f - texsamp[3]) * bg[c];
+			} else {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) rgbtarget[c] = bg[c];
+			}
+		}
+	}
+
 	// ---- pass 1: transmittance, ray colour, number of samples before T < EPSILON (1341-1374)
 	{
 		float T_carry = 1.f;
@@ -135,53 +182,9 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		T_final = T_carry;
 	}
 
-	// ---- target colour: replay the ray generator's draws (1376-1423); wave-uniform
-	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f, pixel_pdf = 1.0f, exposure_scale[3] = {1.f, 1.f, 1.f};
-	uint32_t img = 0;
-	int32_t img_res[2] = {1, 1};
-	v3 ray_o = mk(0, 0, 0);
-	if (active) {
-		ray_o = ld3(a.rays_in[i].o);
-		const uint32_t ray_idx = a.ray_indices_in[i];
-		Pcg32 rng = a.rng;
-		rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
-		float img_pdf = 1.0f, xy_pdf = 1.0f;
-		img = image_idx(ray_idx, a.n_rays, a.n_training_images, a.cdf.cdf_img, &img_pdf);
-		const NgpImageMeta& md = a.metadata[img];
-		img_res[0] = md.res[0]; img_res[1] = md.res[1];
-		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, xy[0], xy[1], &xy_pdf);
-		sample_pdf = img_pdf * xy_pdf; pixel_pdf = xy_pdf;
-		max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
-		float bg[3] = {a.background_color[0], a.background_color[1], a.background_color[2]};
-		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
+	if (active && compacted == numsteps) {
 #pragma unroll
-		for (int c = 0; c < 3; ++c) bg[c] = srgb_to_linear(bg[c]);
-#pragma unroll
-		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * a.exposure[img * 3 + c]);
-		float texsamp[4];
-		read_rgba(xy[0], xy[1], md.res, md.pixels, md.image_data_type, texsamp);
-		if (a.train_in_linear_colors || a.color_space == NGP_COLOR_LINEAR) {
-#pragma unroll
-			for (int c = 0; c < 3; ++c) rgbtarget[c] = exposure_scale[c] * texsamp[c] + (1.0f - texsamp[3]) * bg[c];
-			if (!a.train_in_linear_colors) {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) { rgbtarget[c] = linear_to_srgb(rgbtarget[c]); bg[c] = linear_to_srgb(bg[c]); }
-			}
-		} else {
-#pragma unroll
-			for (int c = 0; c < 3; ++c) bg[c] = linear_to_srgb(bg[c]);
-			if (texsamp[3] > 0) {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) rgbtarget[c] = linear_to_srgb(exposure_scale[c] * texsamp[c] / texsamp[3]) * texsamp[3] + (1.0f - texsamp[3]) * bg[c];
-			} else {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) rgbtarget[c] = bg[c];
-			}
-		}
-		if (compacted == numsteps) {
-#pragma unroll
-			for (int c = 0; c < 3; ++c) rgb_ray[c] += T_final * bg[c];
-		}
+		for (int c = 0; c < 3; ++c) rgb_ray[c] += T_final * bg[c];
 	}
 
 	// ---- compaction slots: one atomic per workgroup (1434)
