@@ -16,7 +16,7 @@ STAGES = [("nerf_forward_kernelILi0ELb0E", "nerf_inference"), ("nerf_forward_ker
           ("encode_planes_kernel", "density_grid_prep"),
           ("nerf_backward_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("gb_fx_bin_kernel", "nerf_backward"), ("gb_fx_scan_kernel", "nerf_backward"),
-          ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema_kernel", "optimizer_step"),
+          ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema", "optimizer_step"),
           ("generate_training_samples_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
           ("compute_loss_kernel", "compute_loss")]
 
