@@ -21,6 +21,7 @@ struct TrainSampleArgs {
 	uint32_t n_training_images; const NgpImageMeta* metadata; const NgpXForm* xforms; const uint8_t* density_grid;
 	int max_level_rand_training; float* max_level_ptr; int snap_to_pixel_centers; int train_envmap; float cone_angle_constant;
 	const float* distortion_data; int32_t distortion_res[2]; uint32_t ray_offset; uint32_t n_rays_global; ErrorMapCdf cdf;
+	const uint32_t* brick_summary;   // optional precomputed s_brick_any
 	int dev_variant; // dev-only timing variants (NGP_HIP_GEN_VARIANT): 0 product path, 2 no sample writes, 3 no march
 };
 
@@ -34,7 +35,8 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 	__shared__ float s_run_t[MAX_RUNS][256];
 	__shared__ uint16_t s_run_n[MAX_RUNS][256];
 	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
-	load_brick_summary(a.density_grid, s_brick_any);
+	if (a.brick_summary) { for (uint32_t q = threadIdx.x; q < NGP_NERF_GRID_N_CELLS / 64 / 32; q += blockDim.x) s_brick_any[q] = a.brick_summary[q]; }
+	else load_brick_summary(a.density_grid, s_brick_any);
 	__syncthreads();
 	uint32_t n_runs = 0;
 
@@ -262,15 +264,33 @@ __global__ void __launch_bounds__(256) expand_training_samples_kernel(const Trai
 
 using namespace ngp;
 
+namespace ngp {
+__global__ void brick_summary_kernel(const uint8_t* __restrict__ bitfield, uint32_t* __restrict__ out) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= NGP_NERF_GRID_N_CELLS / 64u / 32u) return;
+	const uint64_t* __restrict__ words = (const uint64_t*)bitfield;
+	uint32_t bits = 0;
+	for (uint32_t k = 0; k < 32u; ++k) bits |= (words[w * 32u + k] != 0ull ? 1u : 0u) << k;   // as load_brick_summary
+	out[w] = bits;
+}
+}
+
+extern "C" int ngp_hip_bitfield_brick_summary(void* stream, const uint8_t* bitfield, uint32_t* summary_out) {
+	hipLaunchKernelGGL(ngp::brick_summary_kernel, dim3(NGP_NERF_GRID_N_CELLS / 64u / 32u / 64u), dim3(64), 0, (hipStream_t)stream, bitfield, summary_out);
+	NGP_LAUNCH_CHECK("brick_summary_kernel");
+	return 0;
+}
+
 extern "C" int ngp_hip_generate_training_samples(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
-	const NgpErrorMapCdf* cdf_host) {
+	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary) {
 	if (!n_rays) return 0;
 	TrainSampleArgs a;
+	a.brick_summary = brick_summary;
 	a.cdf = make_error_map_cdf(cdf_host);
 	a.n_rays = n_rays; a.aabb = aabb_from_host(aabb_host); a.max_samples = max_samples; a.rng.state = rng_state; a.rng.inc = rng_inc;
 	a.ray_counter = ray_counter; a.numsteps_counter = numsteps_counter; a.ray_indices_out = ray_indices_out; a.rays_out = rays_out_unnormalized;

@@ -596,6 +596,9 @@ void Testbed::update_density_grid_mean_and_bitfield() {  // testbed_nerf.cu:2844
 	check(ngp_hip_density_grid_mean(m_stream, m_nerf.density_grid.as<float>(), GRID_CELLS, m_nerf.density_grid_mean.as<float>()), "density_grid_mean");
 	check(ngp_hip_grid_to_bitfield_and_pool(m_stream, m_nerf.density_grid.as<float>(), m_nerf.max_cascade + 1, m_nerf.density_grid_mean.as<float>(),
 	                                        m_nerf.density_grid_bitfield.as<uint8_t>()), "grid_to_bitfield_and_pool");
+	m_nerf.bitfield_brick_summary.enlarge(GRID_CELLS / 64 / 32 * 4);
+	check(ngp_hip_bitfield_brick_summary(m_stream, m_nerf.density_grid_bitfield.as<uint8_t>(), m_nerf.bitfield_brick_summary.as<uint32_t>()), "bitfield_brick_summary");
+	m_nerf.brick_summary_valid = true;
 }
 
 void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
@@ -643,7 +646,8 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
-	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage)), "generate_training_samples");
+	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
+	                                        m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr), "generate_training_samples");
 	profile_end(PK_GEN_SAMPLES, R, stream);
 }
 

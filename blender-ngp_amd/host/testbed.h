@@ -169,6 +169,7 @@ struct NerfTraining {
 struct Nerf {
 	NerfTraining training;
 	DeviceBuffer density_grid;            // fp32 [(max_cascade+1) * 128^3], Morton order
+	DeviceBuffer bitfield_brick_summary; bool brick_summary_valid = false;   // ngp_hip_bitfield_brick_summary of the current bitfield (the march's empty-space shortcut)
 	DeviceBuffer density_grid_bitfield;   // 8 cascades * 128^3 / 8 bytes
 	DeviceBuffer density_grid_mean;       // 1 float
 	uint32_t max_cascade = 0;

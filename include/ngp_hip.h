@@ -157,6 +157,10 @@ int ngp_hip_ema_grid_samples(void* stream, uint32_t n_elements, float decay, flo
 int ngp_hip_density_grid_mean(void* stream, const float* grid, uint32_t n_elements, float* mean_out);
 /* grid_to_bitfield (:563) + 7x bitfield_max_pool (:589), as update_density_grid_mean_and_bitfield (:2854-2858) issues them. */
 int ngp_hip_grid_to_bitfield_and_pool(void* stream, const float* grid, uint32_t n_cascades_used, const float* mean_density, uint8_t* bitfield);
+/* Not in the reference: one bit per 4x4x4 brick of cascade 0 (Morton order: 64 consecutive cells) that is set when any of its cells is
+ * occupied — 1024 words.  The training march answers most of its empty-space lookups from this summary; it builds it itself from the
+ * bitfield when none is passed, which costs every workgroup a pass over the 256 KB of cascade 0. */
+int ngp_hip_bitfield_brick_summary(void* stream, const uint8_t* bitfield, uint32_t* summary_out_1024_words);
 
 /* ============================ training rays (src/testbed_nerf.cu:1085-1260) ============================ */
 /* generate_training_samples_nerf.  ray_offset / n_rays_global are the data-parallel extension: thread i marches global ray
@@ -167,7 +171,8 @@ int ngp_hip_generate_training_samples(
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
-	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */);
+	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */,
+	const uint32_t* brick_summary /* NULL, or what ngp_hip_bitfield_brick_summary wrote for density_grid (same samples either way) */);
 
 /* ============================ load-time image sharpening (src/nerf_loader.cu:102-123, 803-825) ============================
  * NerfDataset::set_training_image with sharpen_amount > 0: Byte images first become premultiplied linear half4 (from_rgba32<__half>,

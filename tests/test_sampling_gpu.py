@@ -99,7 +99,7 @@ def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):
 
 
 def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_mode=0, lens_params=None, snap=0, max_samples=None,
-                       ray_offset=0, n_rays_global=0, distortion=False, cdf_mode=0):
+                       ray_offset=0, n_rays_global=0, distortion=False, cdf_mode=0, brick_summary=False):
     imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, lens_mode=lens_mode, lens_params=lens_params, radius=1.3 * 2 ** (n_cascades - 1))
     grid = H.blob_density_grid(n_cascades)
     bf, _ = H.oracle_bitfield(oracle, grid, n_cascades)
@@ -123,12 +123,18 @@ def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_m
              ns=H.dev_zeros(n_rays * 8, cuda), co=H.dev_zeros(max_samples * 28, cuda))
     d_md, d_xf, d_bf = H.to_dev(md_dev, cuda), H.to_dev(xf, cuda), H.to_dev(bf, cuda)
     d_dist = H.to_dev(dist, cuda) if distortion else None
+    if brick_summary:   # the optional precomputed empty-brick summary of cascade 0; checked against a numpy restatement
+        d_summary = H.dev_zeros(1024 * 4, cuda)
+        check(ngp.ngp_hip_bitfield_brick_summary(None, d_bf.data_ptr(), d_summary.data_ptr()))
+        words = np.frombuffer(bf.tobytes()[:128 ** 3 // 8], np.uint64)
+        want = np.packbits((words != 0).reshape(1024, 32), axis=1, bitorder="little").view(np.uint32).ravel()
+        np.testing.assert_array_equal(H.to_host(d_summary, np.uint32), want)
     if cdf_mode:
         d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
         c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if cdf_mode & 1 else 0, d_cy.data_ptr() if cdf_mode & 1 else 0, d_ci.data_ptr() if cdf_mode & 2 else 0, C["res"])
     check(ngp.ngp_hip_generate_training_samples(None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
                                                 d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
-                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None))
+                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None, d_summary.data_ptr() if brick_summary else None))
     g = dict(rc=H.to_host(d["rc"], np.uint32), nc=H.to_host(d["nc"], np.uint32), idx=H.to_host(d["idx"], np.uint32), rays=H.to_host(d["rays"], H.RAY),
              ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD))
     return r, g
@@ -158,8 +164,9 @@ def _compare_per_ray(r, g, exact_rays=True):
         assert r["co"][br:br + nr].tobytes() == g["co"][bg:bg + ng].tobytes(), ray
 
 
-def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda):
-    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True)
+@pytest.mark.parametrize("brick_summary", [False, True])
+def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda, brick_summary):
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True, brick_summary=brick_summary)
     _compare_per_ray(r, g)
 
 
