@@ -1,0 +1,80 @@
+"""GPU tests of the host-side step schedule options that are not in the reference's pyngp (INTEGRATION.md "Host-side options"):
+`async_training_steps` (frame() without the per-step stream drain of testbed.cu:2570) must train the same model, and the live
+profiling brackets can be limited to named launch groups."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "blender-ngp_amd")]
+
+pytestmark = pytest.mark.gpu
+
+
+def _train(cuda, async_steps, n_steps=48):
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    tb = scene.build_testbed(ds)
+    tb.async_training_steps = async_steps
+    rays, sizes = [], []
+    for _ in range(n_steps):
+        tb.frame()
+        rays.append(tb.nerf.training.rays_per_batch)
+        sizes.append(tb.nerf.training.measured_batch_size)
+    tb.sync()
+    return ds, tb, np.array(rays), np.array(sizes)
+
+
+def _render(tb, ds):
+    tb.background_color = [0.0, 0.0, 0.0, 1.0]
+    tb.snap_to_pixel_centers = True
+    tb.fov_axis = 0
+    tb.fov = ds["camera_angle_x"] * 180 / np.pi
+    tb.shall_train = False
+    tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    return np.asarray(tb.render(64, 64, 1, True))
+
+
+def test_async_training_steps_train_the_same_model(cuda):
+    ds, a, rays_a, sizes_a = _train(cuda, False)
+    _, b, rays_b, sizes_b = _train(cuda, True)
+    assert a.training_step == b.training_step == 48
+    # the counter feedback (rays_per_batch <- measured sizes) follows the same trajectory.  Not bit for bit even between two runs of the same
+    # mode: the compaction assigns batch slots by atomics, so the weight-gradient sums see the samples in a different order, the weights
+    # differ in the last bits after one step and with them the number of samples that survive the transmittance cut (~0.1 %)
+    assert rays_a[0] == rays_b[0] and sizes_a[0] == sizes_b[0]
+    # ... and after the first occupancy-grid update (step 16) the tiny scene's per-step counts wander by ~10 % between any two runs
+    np.testing.assert_allclose(sizes_a[:12], sizes_b[:12], rtol=0.05)
+    np.testing.assert_allclose(rays_a[:12], rays_b[:12], rtol=0.05)
+    assert abs(sizes_a[1:].mean() - sizes_b[1:].mean()) < 0.1 * sizes_a[1:].mean()
+    assert abs(rays_a[1:].mean() - rays_b[1:].mean()) < 0.1 * rays_a[1:].mean()
+    assert np.isfinite(a.loss) and np.isfinite(b.loss) and abs(a.loss - b.loss) < 0.5 * max(a.loss, b.loss)
+    ia, ib = _render(a, ds), _render(b, ds)
+    mse = float(np.mean((ia[..., :3] - ib[..., :3]) ** 2))
+    assert mse < 5e-3, mse   # two runs of the same short training: the same picture up to training noise
+
+
+def test_profiling_brackets_can_be_limited_to_named_groups(cuda):
+    import scene
+    ds = scene.make_dataset(n_train=4, n_test=1, res=32, device=cuda)
+    tb = scene.build_testbed(ds)
+    tb.set_profiling(True)
+    tb.reset_profile()
+    for _ in range(3):
+        tb.frame()
+    p = tb.profile()
+    assert p["nerf_backward"]["launches"] == 3 and p["optimizer_step"]["launches"] == 3 and p["compute_loss"]["launches"] == 3
+    assert p["nerf_backward"]["ms"] > 0 and p["nerf_backward"]["units"] == 3 * tb.training_batch_size
+    tb.set_profiling(True, ["nerf_backward"])
+    tb.reset_profile()
+    tb.async_training_steps = True   # brackets are folded in when their events have finished, or by profile()
+    for _ in range(5):
+        tb.frame()
+    p = tb.profile()
+    assert p["nerf_backward"]["launches"] == 5
+    assert all(p[k]["launches"] == 0 for k in p if k != "nerf_backward")
+    with pytest.raises(Exception):
+        tb.set_profiling(True, ["no_such_group"])
+    tb.set_profiling(False)
