@@ -21,6 +21,7 @@
 //
 // Roofline: the hash pass is HBM/L2-request bound (512 B gathered per sample, 4 B per request); the MLP is ~20 kFLOP per
 // sample, i.e. a few % of the MFMA peak by construction (SURVEY §7 "Tiny-N MFMA").
+#include <atomic>
 #include "ngp_device.cuh"
 
 #pragma clang fp contract(fast)
@@ -1641,6 +1642,9 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	return ngp_hip_nerf_backward_ev(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr);
 }
 
+static std::atomic<int> g_backward_fork{0};
+int ngp_hip_nerf_backward_set_fork(int on) { return g_backward_fork.exchange(on ? 1 : 0); }
+
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
@@ -1659,12 +1663,37 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
 #undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
+	// Optional (ngp_hip_nerf_backward_set_fork): the weight gradients (MFMA / HBM streaming) on a library-owned side stream next to the hash-grid
+	// backward (LDS atomics, index ALU).  Both only read what the dgrad kernel wrote and write disjoint parts of `grads`; the caller's stream
+	// waits for the side stream before this call's work counts as done.  Single-GPU step +1.7 %; with an RCCL all-reduce queued right behind
+	// the call (data-parallel step) it measured slower, so the data-parallel host leaves it off.  NGP_HIP_BWD_FORK=0/1 overrides (dev).
+	static const int fork_env = getenv("NGP_HIP_BWD_FORK") ? atoi(getenv("NGP_HIP_BWD_FORK")) : -1;
+	const bool fork = fork_env >= 0 ? fork_env != 0 : g_backward_fork.load() != 0;
+	static hipStream_t side = nullptr;
+	static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t wst = st;
+	if (fork) {
+		if (!side) {
+			NGP_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming | hipEventReleaseToDevice));
+			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventReleaseToDevice));
+		}
+		NGP_HIP_TRY(hipEventRecord(ev_fork, st));
+		NGP_HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+		wst = side;
+	}
+	const uint32_t n_chunks = wgrad_chunks(n);
+	if (fork) {
+		hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, wst, (const half_t*)planes, n, n / n_chunks, partials);
+		hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, wst, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
+		NGP_HIP_TRY(hipEventRecord(ev_join, wst));
+	}
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (!(ablate & 4)) {
 		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
 	}
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
-	const uint32_t n_chunks = wgrad_chunks(n);
+	if (fork) { NGP_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); return 0; }
 	hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);

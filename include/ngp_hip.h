@@ -131,6 +131,10 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes);
+/* Process-wide switch (default 0, returns the previous value): with 1, ngp_hip_nerf_backward[_ev] runs the MLP weight-gradient kernels on a
+ * stream owned by the library, concurrently with the hash-grid backward, and makes the caller's stream wait for them before it returns to
+ * stream order.  Same results; a scheduling option for single-GPU hosts (the data-parallel step measured slower with it). */
+int ngp_hip_nerf_backward_set_fork(int on);
 /* Same; additionally records `grid_gradients_event` (a hipEvent_t, may be NULL) on the stream once the hash-grid part of `grads`
  * (everything behind the first 10240 MLP parameters) is final — the MLP weight gradients follow.  A data-parallel host starts the
  * all-reduce of the 24 MB grid slice on another stream at that point instead of after the whole call. */

@@ -154,6 +154,35 @@ def test_backward_linearity(ngp, cuda):
     assert den > 0 and num / den < 2e-2, (num, den)
 
 
+def test_backward_fork_option_is_bit_identical(ngp, cuda):
+    """ngp_hip_nerf_backward_set_fork: weight-gradient kernels on the library's side stream, concurrent with the hash-grid backward — same bits,
+    also when calls follow each other without a host sync (the scratch planes of call k+1 must not overtake the side stream of call k)."""
+    n = 1 << 16
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=19, n=n, grid_amp=0.5)
+    rs = np.random.RandomState(5)
+    out, xs = H.dev_zeros(n * 4 * 2, cuda), H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch = H.dev_zeros(sb, cuda)
+    dls = [H.to_dev((rs.randn(n, 4) * 0.01).astype(np.float16), cuda) for _ in range(3)]
+    res = {}
+    try:
+        for fork in (0, 1):
+            prev = ngp.ngp_hip_nerf_backward_set_fork(fork)
+            assert prev in (0, 1)
+            gs = [H.dev_zeros(H.n_params(desc) * 2, cuda) for _ in dls]
+            for d_dl, g in zip(dls, gs):   # back to back, no sync in between
+                check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                                g.data_ptr(), scratch.data_ptr(), sb))
+            res[fork] = [H.to_host(g, np.uint16) for g in gs]
+    finally:
+        ngp.ngp_hip_nerf_backward_set_fork(0)
+    for a, b in zip(res[0], res[1]):
+        assert np.any(a[:10240] != 0) and np.any(a[10240:] != 0)
+        np.testing.assert_array_equal(a, b)
+    assert np.any(res[0][0] != res[0][1])
+
+
 def test_init_params_bit_exact(ngp, oracle, cuda):
     desc = H.make_desc(ngp, log2_hashmap_size=14)
     np_ = H.n_params(desc)
