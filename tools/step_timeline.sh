@@ -2,7 +2,7 @@
 # GPU box: timeline of a few steady-state training steps (start / end of every kernel relative to the step's network pass, per queue)
 export TMPDIR=/tmp
 rm -rf /tmp/tl
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o t -- python bench.py --steps 60 --warmup 300 --no_cpu_baseline --no_render > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o t -- python bench.py --steps 60 --warmup 300 --no_cpu_baseline --no_render $TIMELINE_ARGS > /dev/null 2>&1
 python - <<PY
 import csv,glob
 f=glob.glob("/tmp/tl/**/*kernel_trace.csv",recursive=True)[0]
