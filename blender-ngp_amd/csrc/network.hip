@@ -1478,7 +1478,10 @@ static uint32_t next_multiple_u32(uint32_t v, uint32_t m) { return (v + m - 1) /
 static int fwd_grid(uint32_t n) {
 	uint32_t tiles = div_up(n, 32);
 	uint32_t blocks = div_up(tiles, 4);
-	const uint32_t cap = 256 * 8; // 8 workgroups per CU resident at most; grid-stride the rest
+	// grid-stride beyond 4 workgroups per CU: measured over the whole training step (caps 512 ... 2048 in steps of 128-256, repeated), 1024 is
+	// ~3 % ahead of the former 2048 — fewer, longer-lived workgroups leave the concurrently running march and the side stream more room
+	static const uint32_t cap_env = getenv("NGP_HIP_FWD_CAP") ? (uint32_t)atoi(getenv("NGP_HIP_FWD_CAP")) : 0u;   // dev-only
+	const uint32_t cap = cap_env ? cap_env : 256 * 4;
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
