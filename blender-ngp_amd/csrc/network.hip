@@ -1646,7 +1646,9 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 }
 
 static std::atomic<int> g_backward_fork{0};
+static std::atomic<void*> g_backward_side_stream{nullptr};
 int ngp_hip_nerf_backward_set_fork(int on) { return g_backward_fork.exchange(on ? 1 : 0); }
+int ngp_hip_nerf_backward_set_fork_stream(void* side_stream) { g_backward_side_stream.store(side_stream); return 0; }
 
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
@@ -1668,8 +1670,9 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
 	// Optional (ngp_hip_nerf_backward_set_fork): the weight gradients (MFMA / HBM streaming) on a library-owned side stream next to the hash-grid
 	// backward (LDS atomics, index ALU).  Both only read what the dgrad kernel wrote and write disjoint parts of `grads`; the caller's stream
-	// waits for the side stream before this call's work counts as done.  Single-GPU step +1.7 %; with an RCCL all-reduce queued right behind
-	// the call (data-parallel step) it measured slower, so the data-parallel host leaves it off.  NGP_HIP_BWD_FORK=0/1 overrides (dev).
+	// waits for the side stream before this call's work counts as done.  Step +1.7 %.  The side stream should come from the host
+	// (ngp_hip_nerf_backward_set_fork_stream): one created late can share a hardware queue with the host's march stream, and the march then
+	// waits behind the weight gradients (measured: 365 -> 294 M samples/s).  NGP_HIP_BWD_FORK=0/1 overrides (dev).
 	static const int fork_env = getenv("NGP_HIP_BWD_FORK") ? atoi(getenv("NGP_HIP_BWD_FORK")) : -1;
 	const bool fork = fork_env >= 0 ? fork_env != 0 : g_backward_fork.load() != 0;
 	static hipStream_t side = nullptr;
@@ -1681,9 +1684,10 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming | hipEventReleaseToDevice));
 			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventReleaseToDevice));
 		}
+		hipStream_t use = g_backward_side_stream.load() ? (hipStream_t)g_backward_side_stream.load() : side;
 		NGP_HIP_TRY(hipEventRecord(ev_fork, st));
-		NGP_HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
-		wst = side;
+		NGP_HIP_TRY(hipStreamWaitEvent(use, ev_fork, 0));
+		wst = use;
 	}
 	const uint32_t n_chunks = wgrad_chunks(n);
 	if (fork) {

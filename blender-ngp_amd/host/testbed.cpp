@@ -207,6 +207,9 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	hipStream_t st, st_b;
 	HIP_CHECK_THROW(hipStreamCreate(&st));
 	HIP_CHECK_THROW(hipStreamCreate(&st_b));
+	{   // the backward's side stream, created right behind the two step streams: three consecutive streams land on three hardware queues
+		hipStream_t st_c; HIP_CHECK_THROW(hipStreamCreate(&st_c)); m_stream_c = st_c;
+	}
 	m_stream = st; m_stream_b = st_b;
 	m_nerf.training.owner = this;
 	m_rng = Pcg32(m_seed);
@@ -224,6 +227,7 @@ Testbed::~Testbed() {
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
+	if (m_stream_c) { ngp_hip_nerf_backward_set_fork_stream(nullptr); (void)hipStreamSynchronize((hipStream_t)m_stream_c); (void)hipStreamDestroy((hipStream_t)m_stream_c); }
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
 
@@ -612,9 +616,7 @@ void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  //
 	if (m_nerf.training.n_images_for_training == 0) return;
 	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / _dp_backward / _dp_end around the all-reduces"};
 	uint32_t counters[2];
-	m_single_gpu_step = true;    // lets the backward fork its weight-gradient kernels onto a side stream (ngp_hip_nerf_backward_set_fork)
 	train_nerf_dp_begin(target_batch_size, counters, get_loss_scalar);
-	m_single_gpu_step = false;
 	const float loss_sum = get_loss_scalar ? local_loss_sum() : 0.f;
 	train_nerf_dp_backward(target_batch_size, counters[0], counters[1], get_loss_scalar, loss_sum);
 	train_nerf_dp_end();
@@ -795,7 +797,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
-	ngp_hip_nerf_backward_set_fork(m_single_gpu_step ? 1 : 0);
+	ngp_hip_nerf_backward_set_fork_stream(m_stream_c);
+	ngp_hip_nerf_backward_set_fork(1);
 	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
 	m_grid_grad_event_recorded = m_want_grid_grad_event;

@@ -346,7 +346,7 @@ public:
 	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
 	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
-	bool m_single_gpu_step = false;                   // train_nerf() is driving the step (not a data-parallel host)
+	void* m_stream_c = nullptr;                        // side stream of the forked backward (ngp_hip_nerf_backward_set_fork_stream)
 	bool m_async_training_steps = false;              // frame() returns with the step's tail (backward, optimizer) still running on the stream
 	std::chrono::steady_clock::time_point m_last_step_return{};
 	bool m_profile_enabled = false;

@@ -133,8 +133,12 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes);
 /* Process-wide switch (default 0, returns the previous value): with 1, ngp_hip_nerf_backward[_ev] runs the MLP weight-gradient kernels on a
  * stream owned by the library, concurrently with the hash-grid backward, and makes the caller's stream wait for them before it returns to
- * stream order.  Same results; a scheduling option for single-GPU hosts (the data-parallel step measured slower with it). */
+ * stream order.  Same results; a scheduling option (see ngp_hip_nerf_backward_set_fork_stream). */
 int ngp_hip_nerf_backward_set_fork(int on);
+/* The side stream to use (NULL: one the library creates at the first forked call).  HIP multiplexes streams onto a few hardware queues in
+ * creation order; a host with further streams of its own (the Testbed's march stream) creates the side stream right next to them so that the
+ * weight-gradient kernels do not land in front of its latency-critical work on a shared queue. */
+int ngp_hip_nerf_backward_set_fork_stream(void* side_stream);
 /* Same; additionally records `grid_gradients_event` (a hipEvent_t, may be NULL) on the stream once the hash-grid part of `grads`
  * (everything behind the first 10240 MLP parameters) is final — the MLP weight gradients follow.  A data-parallel host starts the
  * all-reduce of the 24 MB grid slice on another stream at that point instead of after the whole call. */
