@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "image_io.h"
 #include "snapshot.h"
 #include "testbed.h"
 
@@ -90,8 +91,31 @@ void Testbed::gridmlp_training_step(const float* pos, uint32_t n_dims, const flo
 }
 
 // ---- P1: image ------------------------------------------------------------------------------------------------------------------------
-void Testbed::load_image(const std::string& path) {  // load_binary_image (testbed_image.cu:416-434); EXR / STBI decoders are not part of this build
-	if (path.size() < 4 || path.substr(path.size() - 4) != ".bin") throw std::runtime_error{"Image mode loads the .bin format (int32 h, int32 w, fp16 RGBA: scripts/common.py:165-171); got " + path};
+void Testbed::load_image(const std::string& path) {  // Testbed::load_image (testbed_image.cu:362-434): .exr -> float RGBA, .bin -> half RGBA, else the 8-bit decoders
+	auto ends_with = [&](const char* ext) { const size_t n = strlen(ext); if (path.size() < n) return false; std::string tail = path.substr(path.size() - n); std::transform(tail.begin(), tail.end(), tail.begin(), ::tolower); return tail == ext; };
+	if (ends_with(".exr")) {   // load_exr_image (385-397)
+		int w = 0, h = 0; std::vector<float> px;
+		read_exr_rgba_f32(path, w, h, px);
+		set_image_data(w, h, px.data());
+		m_data_path = path;
+		return;
+	}
+	if (!ends_with(".bin")) {  // load_stbi_image (399-412): load_stbi hands back linear premultiplied floats (tinyexr_wrapper.cu load_stbi: srgb_to_linear on rgb, alpha / 255)
+		int w = 0, h = 0; std::vector<uint8_t> px8;
+		read_image_rgba8(path, w, h, px8);
+		std::vector<float> px((size_t)w * h * 4);
+		for (size_t i = 0; i < (size_t)w * h; ++i) {
+			const float a = (float)px8[i * 4 + 3] * (1.0f / 255.0f);
+			for (int c = 0; c < 3; ++c) {
+				const float v = (float)px8[i * 4 + c] * (1.0f / 255.0f);
+				px[i * 4 + c] = (v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f)) * a;
+			}
+			px[i * 4 + 3] = a;
+		}
+		set_image_data(w, h, px.data());
+		m_data_path = path;
+		return;
+	}
 	FILE* f = fopen(path.c_str(), "rb");
 	if (!f) throw std::runtime_error{path + " does not exist."};
 	int32_t hw[2];

@@ -10,6 +10,7 @@
 #include "nerf_renderer.h"
 #include "nerf_loader.h"
 #include "png_reader.h"
+#include "image_io.h"
 
 namespace py = pybind11;
 using namespace ngp;
@@ -109,6 +110,20 @@ PYBIND11_MODULE(pyngp, m) {
 		read_png_rgba8(path, w, h, px);
 		py::array_t<uint8_t> a({h, w, 4});
 		memcpy(a.mutable_data(), px.data(), px.size());
+		return a;
+	});
+	m.def("decode_image", [](const std::string& path) {   // stbi_load(path, .., 4): PNG or JPEG by signature -> (H, W, 4) uint8
+		int w = 0, h = 0; std::vector<uint8_t> px;
+		read_image_rgba8(path, w, h, px);
+		py::array_t<uint8_t> a({h, w, 4});
+		memcpy(a.mutable_data(), px.data(), px.size());
+		return a;
+	});
+	m.def("decode_exr", [](const std::string& path) {   // (H, W, 4) float32, what tinyexr's LoadEXR hands the reference (tinyexr_wrapper.cu:62-112)
+		int w = 0, h = 0; std::vector<float> px;
+		read_exr_rgba_f32(path, w, h, px);
+		py::array_t<float> a({h, w, 4});
+		memcpy(a.mutable_data(), px.data(), px.size() * sizeof(float));
 		return a;
 	});
 	m.def("load_nerf_host", [](const std::string& data_path) {
@@ -374,6 +389,71 @@ PYBIND11_MODULE(pyngp, m) {
 				d["cone_angle_constant"] = t.m_nerf.cone_angle_constant;
 				d["desc"] = (uintptr_t)t.m_desc_gpu.data();
 				d["params"] = (uintptr_t)t.m_params.data();
+				return d;
+			})
+		// test hooks (tests/test_baseline_configs_gpu.py): a stage-by-stage record of one product-path training step, and the scene as the kernels see it
+		.def("debug_capture_next_step", &Testbed::debug_capture_next_step)
+		.def("debug_captured", [](Testbed& t) {
+				Testbed::StepCapture& c = t.m_capture;
+				if (!c.valid) throw std::runtime_error{"debug_captured: no step was captured (call debug_capture_next_step() before frame())"};
+				t.sync();
+				auto bytes = [](const DeviceBuffer& b, size_t n) { py::array_t<uint8_t> a((py::ssize_t)n); if (n) b.copy_to_host(a.mutable_data(), n); return a; };
+				auto u32 = [&](const DeviceBuffer& b, size_t n) { return bytes(b, n * 4).attr("view")("uint32"); };
+				auto f32 = [&](const DeviceBuffer& b, size_t n) { return bytes(b, n * 4).attr("view")("float32"); };
+				auto u16 = [&](const DeviceBuffer& b, size_t n) { return bytes(b, n * 2).attr("view")("uint16"); };
+				py::dict d;
+				d["step"] = c.step; d["R"] = c.R; d["max_inference"] = c.max_inference; d["n_rays_global"] = c.n_rays_global; d["ray_offset"] = c.ray_offset;
+				d["target_batch_size"] = c.target_batch_size; d["rng_state"] = c.rng_state; d["rng_inc"] = c.rng_inc;
+				d["params"] = u16(c.params, t.m_n_params);
+				d["ray_indices"] = u32(c.ray_indices, c.R);
+				d["rays"] = f32(c.rays, (size_t)c.R * 6);
+				d["numsteps"] = u32(c.numsteps, (size_t)c.R * 2);
+				d["coords"] = f32(c.coords, (size_t)c.max_inference * 7);
+				d["gen_counters"] = u32(c.gen_counters, 2);                         // {rays kept, samples (may exceed max_inference)}
+				d["density_grid_mean"] = f32(c.density_grid_mean, 1);
+				d["numsteps_compacted"] = u32(c.numsteps_compacted, (size_t)c.R * 2);
+				d["coords_compacted"] = f32(c.coords_compacted, (size_t)c.target_batch_size * 7);   // before the roll-over
+				d["dloss"] = u16(c.dloss, (size_t)c.target_batch_size * 4);                       // before the roll-over / rescale
+				// buffers the step leaves behind (the prefetch of the next march is suppressed for a captured step)
+				d["mlp_out"] = u16(t.debug_buffer("mlp_out"), (size_t)c.max_inference * 4);
+				d["coords_compacted_rolled"] = f32(t.debug_buffer("coords_compacted"), (size_t)c.target_batch_size * 7);
+				d["dloss_rolled"] = u16(t.debug_buffer("dloss"), (size_t)c.target_batch_size * 4);
+				d["x_saved"] = u16(t.debug_buffer("x_saved"), (size_t)c.target_batch_size * 32);
+				d["grads"] = u16(t.debug_buffer("grads"), t.m_n_params);
+				d["loss"] = f32(t.m_nerf.training.counters_rgb.loss, c.n_rays_global);
+				d["measured_batch_size"] = t.m_nerf.training.counters_rgb.measured_batch_size;
+				d["measured_batch_size_before_compaction"] = t.m_nerf.training.counters_rgb.measured_batch_size_before_compaction;
+				return d;
+			})
+		.def("debug_params", [](Testbed& t, const std::string& which) {   // fp16 bits of the "training" or "inference" (EMA) weights
+				const DeviceBuffer& b = which == "inference" ? t.m_inference_params : t.m_params;
+				t.sync();
+				py::array_t<uint16_t> a((py::ssize_t)t.m_n_params);
+				if (t.m_n_params) b.copy_to_host(a.mutable_data(), t.m_n_params * 2);
+				return a;
+			}, py::arg("which") = "training")
+		.def("debug_scene", [](Testbed& t) {
+				py::dict d;
+				const NerfTraining& tr = t.m_nerf.training;
+				const size_t n = (size_t)tr.n_images_for_training;
+				py::array_t<uint8_t> md((py::ssize_t)(n * sizeof(NgpImageMeta))), xf((py::ssize_t)(n * sizeof(NgpXForm)));
+				if (n) { memcpy(md.mutable_data(), tr.dataset.metadata.data(), n * sizeof(NgpImageMeta)); memcpy(xf.mutable_data(), tr.transforms.data(), n * sizeof(NgpXForm)); }
+				d["metadata"] = md; d["xforms"] = xf;                                // NgpImageMeta / NgpXForm records (pixel pointers are DEVICE pointers)
+				py::array_t<uint8_t> bf((py::ssize_t)t.m_nerf.density_grid_bitfield.bytes());
+				if (bf.size()) t.m_nerf.density_grid_bitfield.copy_to_host(bf.mutable_data(), (size_t)bf.size());
+				d["bitfield"] = bf;
+				py::array_t<float> grid((py::ssize_t)(t.m_nerf.density_grid.bytes() / 4));
+				if (grid.size()) t.m_nerf.density_grid.copy_to_host(grid.mutable_data(), (size_t)grid.size() * 4);
+				d["density_grid"] = grid;
+				d["aabb"] = py::make_tuple(std::vector<float>(t.m_aabb.min, t.m_aabb.min + 3), std::vector<float>(t.m_aabb.max, t.m_aabb.max + 3));
+				d["n_cascades"] = t.m_nerf.max_cascade + 1;
+				d["cone_angle_constant"] = t.m_nerf.cone_angle_constant;
+				d["near_distance"] = tr.near_distance;
+				d["error_map_res"] = std::vector<int>{tr.error_map_res[0], tr.error_map_res[1]};
+				d["rgb_activation"] = (int)t.m_nerf.rgb_activation; d["density_activation"] = (int)t.m_nerf.density_activation;
+				d["loss_type"] = (int)tr.loss_type;
+				py::array_t<uint8_t> desc((py::ssize_t)sizeof(NgpNetDesc)); memcpy(desc.mutable_data(), &t.m_desc, sizeof(NgpNetDesc));
+				d["desc"] = desc;
 				return d;
 			})
 		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)

@@ -664,6 +664,7 @@ void Testbed::drop_prefetch() {
 
 void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	if (!m_enable_prefetch || !m_train_continues) return;
+	if (m_capture.valid && m_capture.step == m_training_step) return;   // a captured step keeps its scratch buffers until the test has read them
 	const uint32_t next_step = m_training_step + 1;
 	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
 	if (next_step % n_prep_to_skip == 0) return;  // an occupancy-grid update (new bitfield) precedes that step
@@ -733,6 +734,24 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 4 * m_gen_slot;
 	uint32_t* compacted_counter = gen_counters + 2;
+	const bool capturing = m_capture.armed;
+	auto capture_copy = [&](DeviceBuffer& dst, const void* src, size_t bytes) {
+		dst.resize(bytes);
+		HIP_CHECK_THROW(hipMemcpyAsync(dst.data(), src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+	};
+	if (capturing) {   // test hook (testbed.h StepCapture): what the march handed to the network pass, and the weights the step starts from
+		StepCapture& cap = m_capture;
+		cap.armed = false; cap.valid = true;
+		cap.step = m_training_step; cap.R = R; cap.max_inference = max_inference; cap.n_rays_global = R * m_world_size; cap.ray_offset = R * m_rank;
+		cap.target_batch_size = target_batch_size; cap.rng_state = m_rng.state; cap.rng_inc = m_rng.inc;
+		capture_copy(cap.params, m_params.data(), m_n_params * 2);
+		capture_copy(cap.ray_indices, m_ray_indices.data(), (size_t)R * 4);
+		capture_copy(cap.rays, m_rays.data(), (size_t)R * sizeof(NgpRay));
+		capture_copy(cap.numsteps, m_numsteps.data(), (size_t)R * 8);
+		capture_copy(cap.coords, m_coords.data(), (size_t)max_inference * sizeof(NgpCoord));
+		capture_copy(cap.gen_counters, gen_counters, 8);
+		capture_copy(cap.density_grid_mean, m_nerf.density_grid_mean.data(), 4);
+	}
 	if (m_compact_slot_zeroed == m_gen_slot) m_compact_slot_zeroed = -1;   // cleared by the previous step's post_words launch
 	else HIP_CHECK_THROW(hipMemsetAsync(compacted_counter, 0, 4, (hipStream_t)m_stream));
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
@@ -761,6 +780,11 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type,
 	                           tr.optimize_exposure ? tr.cam_exposure_gradient_gpu.as<float>() : nullptr), "compute_loss");
 	profile_end(PK_LOSS, R);
+	if (capturing) {   // the loss kernel's products before the roll-over pads and rescales them
+		capture_copy(m_capture.numsteps_compacted, m_numsteps.data(), (size_t)R * 8);
+		capture_copy(m_capture.coords_compacted, m_coords_compacted.data(), (size_t)target_batch_size * sizeof(NgpCoord));
+		capture_copy(m_capture.dloss, m_dloss.data(), (size_t)target_batch_size * OUT_STRIDE * 2);
+	}
 	// NerfCounters::update_after_training reads the two counters (2870-2874) with blocking copies after the whole step.  They are
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
 	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
@@ -834,6 +858,16 @@ void Testbed::stream_wait_grid_gradients(void* other_stream) {
 	m_want_grid_grad_event = true;
 	if (!m_grid_grad_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream)); m_grid_grad_event_recorded = true; }
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_grid_grad_event, 0));
+}
+
+const DeviceBuffer& Testbed::debug_buffer(const std::string& name) const {
+	if (name == "mlp_out") return m_mlp_out;
+	if (name == "coords_compacted") return m_coords_compacted;
+	if (name == "dloss") return m_dloss;
+	if (name == "x_saved") return m_x_saved;
+	if (name == "grads") return m_grads;
+	if (name == "coords") return m_coords;
+	throw std::runtime_error{"debug_buffer: unknown buffer '" + name + "'"};
 }
 
 float Testbed::local_loss_sum() { return m_local_loss_sum; }  // of the step begun last, if it was begun with get_loss_scalar

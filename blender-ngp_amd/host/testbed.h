@@ -284,6 +284,17 @@ public:
 	uint64_t m_prefetch_hits = 0;
 	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
 	float local_loss_sum();
+	// ---- test hook: a stage-by-stage record of ONE training step of the product path (tests/test_baseline_configs_gpu.py replays it through the
+	// oracle at the BASELINE sizes).  Armed by debug_capture_next_step(); the step then copies, in stream order, the parameters it starts from,
+	// the march's outputs before the loss kernel rewrites them, and the loss kernel's outputs before the roll-over.
+	struct StepCapture {
+		bool armed = false, valid = false;
+		uint32_t step = 0, R = 0, max_inference = 0, n_rays_global = 0, ray_offset = 0, target_batch_size = 0;
+		uint64_t rng_state = 0, rng_inc = 0;
+		DeviceBuffer params, ray_indices, rays, numsteps, coords, gen_counters, numsteps_compacted, coords_compacted, dloss, density_grid_mean;
+	} m_capture;
+	void debug_capture_next_step() { m_capture.armed = true; m_capture.valid = false; }
+	const DeviceBuffer& debug_buffer(const std::string& name) const;   // step scratch by name: "mlp_out", "coords_compacted", "dloss", "x_saved", "grads", "coords"
 
 	// ---- rendering (python_api.cu:132-190; testbed.cu:2695-2911; testbed_nerf.cu:2047-2267, 2354-2500)
 	std::vector<float> render_to_cpu(int width, int height, int spp, bool linear);

@@ -105,16 +105,18 @@ def render_ground_truth(c2w, w, h, device):
     return rgba8.cpu().numpy()
 
 
-def make_dataset(n_train=100, n_test=20, res=800, device=None, seed=0):
+def make_dataset(n_train=100, n_test=20, res=800, device=None, seed=0, aabb_scale=1, height=None):
+    """res = image width (and height unless `height` is given: the fox-shaped config is 1920 x 1080 with aabb_scale 4, i.e. 3 cascades)."""
     import torch
     device = device or torch.device("cuda:0")
     train = camera_poses(n_train, seed)
     test = camera_poses(n_test, seed + 1)
+    h = height or res
     fl = 0.5 * res / math.tan(0.5 * CAMERA_ANGLE_X)
-    return dict(res=res, focal=fl, camera_angle_x=CAMERA_ANGLE_X, scale=0.33, offset=[0.5, 0.5, 0.5], aabb_scale=1,
+    return dict(res=res, w=res, h=h, focal=fl, camera_angle_x=CAMERA_ANGLE_X, scale=0.33, offset=[0.5, 0.5, 0.5], aabb_scale=aabb_scale,
                 train_poses=train, test_poses=test,
-                train_images=[render_ground_truth(m, res, res, device) for m in train],
-                test_images=[render_ground_truth(m, res, res, device) for m in test])
+                train_images=[render_ground_truth(m, res, h, device) for m in train],
+                test_images=[render_ground_truth(m, res, h, device) for m in test])
 
 
 def build_testbed(ds, config_path=None, seed=1337):
@@ -127,10 +129,10 @@ def build_testbed(ds, config_path=None, seed=1337):
     n = len(ds["train_images"])
     t.create_empty_nerf_dataset(n, ds["aabb_scale"], False)
     t.nerf.training.set_dataset_transform(ds["scale"], ds["offset"])
-    res = ds["res"]
+    w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
     for i in range(n):
         t.nerf.training.set_image_rgba8(i, ds["train_images"][i])
-        t.nerf.training.set_camera_intrinsics(i, ds["focal"], ds["focal"], 0.5 * res, 0.5 * res)
+        t.nerf.training.set_camera_intrinsics(i, ds["focal"], ds["focal"], 0.5 * w, 0.5 * h)
         t.nerf.training.set_camera_extrinsics(i, ds["train_poses"][i][:3, :], True)
     t.nerf.training.n_images_for_training = n
     t.reload_network_from_file(config_path or os.path.join(HERE, "configs", "nerf", "base.json"))
@@ -160,13 +162,13 @@ def eval_test_views(testbed, ds, spp=8, max_views=None):
     testbed.fov_axis = 0
     testbed.fov = ds["camera_angle_x"] * 180 / np.pi
     testbed.shall_train = False
-    res = ds["res"]
+    w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
     psnrs, ssims = [], []
     views = list(zip(ds["test_poses"], ds["test_images"]))[:max_views]
     for pose, img8 in views:
         ref = metrics.read_image_rgba8(img8)
         testbed.set_nerf_camera_matrix(pose[:3, :])
-        image = testbed.render(res, res, spp, True)
+        image = testbed.render(w, h, spp, True)
         p, s = metrics.eval_psnr_ssim(image, ref)
         psnrs.append(p)
         ssims.append(s)
@@ -218,7 +220,7 @@ def write_dataset(ds, directory):
         Image.fromarray(np.ascontiguousarray(img), "RGBA").save(os.path.join(directory, name + ".png"))
         m = np.eye(4); m[:3, :4] = np.asarray(pose)[:3, :4]
         frames.append({"file_path": "./" + name, "transform_matrix": m.tolist()})
-    meta = {"fl_x": float(np.float32(ds["focal"])), "fl_y": float(np.float32(ds["focal"])), "cx": 0.5 * ds["res"], "cy": 0.5 * ds["res"], "w": ds["res"], "h": ds["res"],
+    meta = {"fl_x": float(np.float32(ds["focal"])), "fl_y": float(np.float32(ds["focal"])), "cx": 0.5 * ds.get("w", ds["res"]), "cy": 0.5 * ds.get("h", ds["res"]), "w": ds.get("w", ds["res"]), "h": ds.get("h", ds["res"]),
             "camera_angle_x": ds["camera_angle_x"], "aabb_scale": ds["aabb_scale"], "scale": ds["scale"], "offset": list(ds["offset"]), "frames": frames}
     path = os.path.join(directory, "transforms_train.json")
     with open(path, "w") as f:
