@@ -52,21 +52,38 @@ def device_march(cap):
                 co=cap["coords"].view(H.COORD))
 
 
-def compare_march(r, g):
-    """bit-exact: ray / sample counts, and per ray the kept-ray record and every sample record (slot order is scheduling-dependent)"""
+def compare_march(r, g, max_samples=None):
+    """bit-exact: the sample counter, and per ray the kept-ray record and every sample record (slot order is scheduling-dependent).
+    When the step's demand exceeds its budget (numsteps counter > max_samples) the rays whose run would not fit are dropped AFTER the counter was
+    bumped (testbed_nerf.cu:1225-1228) — which ones depends on the order the atomics were served in, in the reference as much as here — so the kept
+    sets may then differ by a few rays; every ray kept by both must still agree bit for bit and every kept run must fit the budget."""
     n_ref, n_got = int(r["rc"][0]), int(g["rc"][0])
-    assert n_got == n_ref and int(g["nc"][0]) == int(r["nc"][0]), (n_got, n_ref, int(g["nc"][0]), int(r["nc"][0]))
+    assert int(g["nc"][0]) == int(r["nc"][0]), (int(g["nc"][0]), int(r["nc"][0]))                 # bit-exact sample count
+    overflow = max_samples is not None and int(r["nc"][0]) > max_samples
+    if not overflow:
+        assert n_got == n_ref, (n_got, n_ref)                                                      # bit-exact ray count
     ref_slot = {int(r["idx"][k]): k for k in range(n_ref)}
     got_slot = {int(g["idx"][k]): k for k in range(n_got)}
-    assert ref_slot.keys() == got_slot.keys()
+    assert len(ref_slot) == n_ref and len(got_slot) == n_got
+    if not overflow:
+        assert ref_slot.keys() == got_slot.keys()
+    else:
+        excess = (int(r["nc"][0]) - max_samples) / float(int(r["nc"][0]))      # each side drops about this fraction of its rays, not the same ones
+        assert len(ref_slot.keys() ^ got_slot.keys()) <= 4.0 * excess * n_ref + 16, (n_ref, n_got, len(ref_slot.keys() ^ got_slot.keys()), excess)
     gns = g["ns"].reshape(-1, 2)[:n_got].astype(np.int64)
     order = np.argsort(gns[:, 1], kind="stable")
     ends = gns[order, 1] + gns[order, 0]
-    assert gns[order[0], 1] == 0 and (gns[order[1:], 1] == ends[:-1]).all()      # the kept rays' runs tile [0, total)
+    assert (gns[order[1:], 1] >= ends[:-1]).all()                                                  # the kept rays' runs do not overlap ...
+    if not overflow:
+        assert gns[order[0], 1] == 0 and (gns[order[1:], 1] == ends[:-1]).all()                    # ... and tile [0, total)
+    else:
+        assert ends.max() <= max_samples
     rco, gco = r["co"].view(np.uint8).reshape(-1, 28), g["co"].view(np.uint8).reshape(-1, 28)
     rrays, grays = r["rays"].view(np.uint8).reshape(-1, 24), g["rays"].view(np.uint8).reshape(-1, 24)
     n_samples = 0
     for ray, kr in ref_slot.items():
+        if ray not in got_slot:
+            continue
         kg = got_slot[ray]
         nr, br = int(r["ns"][2 * kr]), int(r["ns"][2 * kr + 1])
         ng, bg = int(g["ns"][2 * kg]), int(g["ns"][2 * kg + 1])
@@ -74,7 +91,7 @@ def compare_march(r, g):
         assert (rrays[kr] == grays[kg]).all(), ray
         assert (rco[br:br + nr] == gco[bg:bg + ng]).all(), ray
         n_samples += nr
-    return n_ref, n_samples
+    return n_got, int(gns[:, 0].sum())
 
 
 def covered_rows(cap):

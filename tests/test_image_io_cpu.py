@@ -1,0 +1,212 @@
+"""Host-side image decoders of the loader (row f2) against independent decoders: JPEG (baseline + progressive Huffman, grey / 4:4:4 / 4:2:2 / 4:2:0,
+restart intervals, odd sizes) against PIL (libjpeg), OpenEXR scanline files (NONE / RLE / ZIPS / ZIP, HALF / FLOAT) against a writer in this file that
+follows the published layout.  The reference reads these through the vendored stb_image / tinyexr (src/nerf_loader.cu:575-581).  No GPU needed."""
+import io
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "blender-ngp_amd")]
+
+
+def _photo(w, h, seed=0):
+    """smooth content with edges and noise (what JPEG is made for, plus what breaks it)"""
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([128 + 100 * np.sin(x / 17.0) * np.cos(y / 23.0), 128 + 90 * np.cos((x + y) / 31.0), 60 + 0.5 * x * (h - y) / max(h, 1) * 255.0 / max(w, 1)], -1)
+    img[h // 3: h // 2, w // 4: w // 2] = [250, 20, 40]
+    img += rs.randn(h, w, 3) * 6.0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (67, 53), (1, 1), (17, 8)])
+@pytest.mark.parametrize("kw", [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, progressive=True), dict(subsampling=0, progressive=True, optimize=True),
+                                dict(subsampling=1, progressive=True), dict(subsampling=2, restart_marker_blocks=3), dict(subsampling=0, restart_marker_rows=1, progressive=True), dict(grey=True),
+                                dict(grey=True, progressive=True)])
+def test_jpeg_matches_libjpeg(tmp_path, w, h, kw):
+    import pyngp
+    from PIL import Image
+    kw = dict(kw)
+    grey = kw.pop("grey", False)
+    src = _photo(w, h)
+    im = Image.fromarray(src[..., 1] if grey else src, "L" if grey else "RGB")
+    p = str(tmp_path / "t.jpg")
+    im.save(p, quality=88, **kw)
+    ref = np.asarray(Image.open(p).convert("RGB")).astype(np.int32)
+    got = pyngp.decode_image(p)
+    assert got.shape == (h, w, 4) and got.dtype == np.uint8 and (got[..., 3] == 255).all()
+    d = np.abs(got[..., :3].astype(np.int32) - ref)
+    # the inverse DCT here is an exact float transform rounded once; libjpeg's integer IDCT, its chroma filter and its fixed-point colour matrix
+    # each round in between: a few code values at isolated pixels, a small fraction of one on average
+    assert d.max() <= 5 and d.mean() < 0.5, (d.max(), d.mean())
+
+
+def test_jpeg_low_quality_and_large(tmp_path):
+    import pyngp
+    from PIL import Image
+    src = _photo(640, 360, seed=3)
+    for q, prog in ((35, False), (35, True), (97, True)):
+        buf = io.BytesIO()
+        Image.fromarray(src, "RGB").save(buf, "JPEG", quality=q, progressive=prog)
+        p = str(tmp_path / ("q%d%d.jpg" % (q, prog)))
+        open(p, "wb").write(buf.getvalue())
+        ref = np.asarray(Image.open(p).convert("RGB")).astype(np.int32)
+        d = np.abs(pyngp.decode_image(p)[..., :3].astype(np.int32) - ref)
+        assert d.max() <= 6 and d.mean() < 0.5, (q, prog, d.max(), d.mean())
+
+
+def test_image_signature_dispatch_and_errors(tmp_path):
+    import pyngp
+    from PIL import Image
+    src = _photo(40, 30)
+    p = str(tmp_path / "really_a_png.jpg")        # stb_image looks at the content, not at the extension
+    Image.fromarray(src, "RGB").save(p, "PNG")
+    np.testing.assert_array_equal(pyngp.decode_image(p)[..., :3], src)
+    bad = str(tmp_path / "x.jpg")
+    open(bad, "wb").write(b"GIF89a" + bytes(64))
+    with pytest.raises(RuntimeError):
+        pyngp.decode_image(bad)
+    trunc = str(tmp_path / "t.jpg")
+    buf = io.BytesIO()
+    Image.fromarray(src, "RGB").save(buf, "JPEG")
+    open(trunc, "wb").write(buf.getvalue()[:200])
+    img = None
+    try:
+        img = pyngp.decode_image(trunc)            # a truncated scan decodes to something (like stb_image) or raises — it must not crash
+    except RuntimeError:
+        pass
+    assert img is None or img.shape == (30, 40, 4)
+    with pytest.raises(RuntimeError):
+        pyngp.decode_image(str(tmp_path / "missing.jpg"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/data/nerf/fox/images"), reason="the reference tree (fox photographs) only exists in the build container")
+def test_fox_frames_decode_like_libjpeg():
+    """BASELINE config #2's own data: data/nerf/fox/images/*.jpg (1080 x 1920 portraits)"""
+    import glob
+    import pyngp
+    from PIL import Image
+    files = sorted(glob.glob("/root/reference/data/nerf/fox/images/*.jpg"))
+    assert len(files) == 50
+    for f in files[::17]:
+        ref = np.asarray(Image.open(f).convert("RGB")).astype(np.int32)
+        got = pyngp.decode_image(f)
+        assert got.shape == (1920, 1080, 4)
+        d = np.abs(got[..., :3].astype(np.int32) - ref)
+        assert d.max() <= 4 and d.mean() < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------- OpenEXR
+def _write_exr(path, img, compression, pixel_type, channel_names="ABGR"):
+    """scanline OpenEXR writer (test-side): img (H, W, C) float32, channels stored in alphabetical order of their names"""
+    h, w, _ = img.shape
+    names = sorted(channel_names)
+    src_index = {"R": 0, "G": 1, "B": 2, "A": 3, "Y": 0}
+    head = struct.pack("<II", 20000630, 2)
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pixel_type, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    head += attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression]))
+    head += attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1))
+    head += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    head += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    dt = np.float16 if pixel_type == 1 else np.float32
+    blocks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(img[y, :, src_index[n]].astype(dt).tobytes() for y in range(y0, min(h, y0 + lines)) for n in names)
+        data = raw
+        if compression:
+            a = np.frombuffer(raw, np.uint8)
+            split = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            pred = split.copy()
+            pred[1:] = (split[1:] - split[:-1] + 128 + 256) % 256
+            pb = pred.astype(np.uint8).tobytes()
+            if compression == 1:   # RLE: literal runs only, except one repeat run when the block starts with a repeated byte
+                out = bytearray()
+                i = 0
+                while i < len(pb):
+                    j = i
+                    while j + 1 < len(pb) and pb[j + 1] == pb[i] and j - i < 126:
+                        j += 1
+                    if j - i >= 2:
+                        out += struct.pack("b", j - i) + pb[i:i + 1]
+                        i = j + 1
+                    else:
+                        k = min(len(pb), i + 100)
+                        out += struct.pack("b", -(k - i)) + pb[i:k]
+                        i = k
+                comp = bytes(out)
+            else:
+                comp = zlib.compress(pb)
+            data = comp if len(comp) < len(raw) else raw
+        blocks.append(struct.pack("<ii", y0, len(data)) + data)
+    off = len(head) + 8 * len(blocks)
+    table = b""
+    for b in blocks:
+        table += struct.pack("<Q", off)
+        off += len(b)
+    open(path, "wb").write(head + table + b"".join(blocks))
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+@pytest.mark.parametrize("pixel_type", [1, 2])
+def test_exr_scanline_round_trip(tmp_path, compression, pixel_type):
+    import pyngp
+    rs = np.random.RandomState(compression * 2 + pixel_type)
+    h, w = 37, 29
+    img = (rs.rand(h, w, 4) ** 3 * 4.0).astype(np.float32)
+    img[5:20, 3:9] = 0.25          # flat areas: runs for RLE, long matches for zlib
+    p = str(tmp_path / "t.exr")
+    _write_exr(p, img, compression, pixel_type)
+    got = pyngp.decode_exr(p)
+    want = img.astype(np.float16).astype(np.float32) if pixel_type == 1 else img
+    np.testing.assert_array_equal(got, want)
+
+
+def test_exr_rgb_without_alpha_and_luminance(tmp_path):
+    import pyngp
+    img = np.random.RandomState(1).rand(8, 5, 4).astype(np.float32)
+    p = str(tmp_path / "rgb.exr")
+    _write_exr(p, img, 3, 2, "BGR")
+    got = pyngp.decode_exr(p)
+    np.testing.assert_array_equal(got[..., :3], img[..., :3])
+    assert (got[..., 3] == 1.0).all()
+    _write_exr(p, img, 2, 1, "Y")
+    got = pyngp.decode_exr(p)
+    want = img[..., 0].astype(np.float16).astype(np.float32)
+    for c in range(3):
+        np.testing.assert_array_equal(got[..., c], want)
+
+
+def test_exr_rejects_what_it_cannot_read(tmp_path):
+    import pyngp
+    img = np.zeros((4, 4, 4), np.float32)
+    p = str(tmp_path / "piz.exr")
+    _write_exr(p, img, 0, 2)
+    raw = bytearray(open(p, "rb").read())
+    i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[i] = 4    # PIZ
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(RuntimeError, match="PIZ"):
+        pyngp.decode_exr(p)
+    open(p, "wb").write(b"not an exr file at all")
+    with pytest.raises(RuntimeError):
+        pyngp.decode_exr(p)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/data/image/albert.exr"), reason="the reference tree only exists in the build container")
+def test_albert_exr_matches_the_reference_decoder_and_the_committed_crop():
+    """data/image/albert.exr (ZIP, four FLOAT channels): RGBA mean as the reference's vendored tinyexr reports it, and the committed crop"""
+    import pyngp
+    img = pyngp.decode_exr("/root/reference/data/image/albert.exr")
+    assert img.shape == (1024, 1024, 4)
+    np.testing.assert_allclose(img.reshape(-1, 4).mean(0), [0.18612, 0.18612, 0.18612, 1.0], atol=2e-5)
+    crop = np.load(os.path.join(ROOT, "tests", "golden", "albert_crop_128.npy"))
+    np.testing.assert_array_equal(crop, img[448:576, 448:576].astype(np.float16))
