@@ -21,7 +21,6 @@
 //
 // Roofline: the hash pass is HBM/L2-request bound (512 B gathered per sample, 4 B per request); the MLP is ~20 kFLOP per
 // sample, i.e. a few % of the MFMA peak by construction (SURVEY §7 "Tiny-N MFMA").
-#include <atomic>
 #include "ngp_device.cuh"
 
 #pragma clang fp contract(fast)
@@ -1642,17 +1641,44 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
-	return ngp_hip_nerf_backward_ev(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr);
+	return ngp_hip_nerf_backward_ctx(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr);
 }
-
-static std::atomic<int> g_backward_fork{0};
-static std::atomic<void*> g_backward_side_stream{nullptr};
-int ngp_hip_nerf_backward_set_fork(int on) { return g_backward_fork.exchange(on ? 1 : 0); }
-int ngp_hip_nerf_backward_set_fork_stream(void* side_stream) { g_backward_side_stream.store(side_stream); return 0; }
 
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
+	return ngp_hip_nerf_backward_ctx(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event, nullptr);
+}
+
+// Scheduling context of the backward pass: a side stream and its fork / join events, owned by ONE caller (one per Testbed, on that Testbed's
+// device) — not process state, so two hosts on different threads or devices never share an event pair.
+struct BackwardCtx { hipStream_t side = nullptr; bool own_side = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+
+void* ngp_hip_backward_ctx_create(void* side_stream) {
+	BackwardCtx* c = new BackwardCtx();
+	c->side = (hipStream_t)side_stream;
+	hipError_t e = hipSuccess;
+	if (!c->side) { e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking); c->own_side = e == hipSuccess; }
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventReleaseToDevice);
+	if (e != hipSuccess) { set_last_error("ngp_hip_backward_ctx_create", e); ngp_hip_backward_ctx_destroy(c); return nullptr; }
+	return c;
+}
+
+void ngp_hip_backward_ctx_destroy(void* ctx) {
+	BackwardCtx* c = (BackwardCtx*)ctx;
+	if (!c) return;
+	if (c->side) { (void)hipStreamSynchronize(c->side); if (c->own_side) (void)hipStreamDestroy(c->side); }
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+	delete c;
+}
+
+void* ngp_hip_backward_ctx_dgrad_event(void* ctx) { return ctx ? (void*)((BackwardCtx*)ctx)->ev_fork : nullptr; }
+
+int ngp_hip_nerf_backward_ctx(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event, void* ctx) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
 	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
@@ -1668,39 +1694,33 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
 #undef NGP_LAUNCH_BWD
 	NGP_LAUNCH_CHECK("nerf_backward_kernel");
-	// Optional (ngp_hip_nerf_backward_set_fork): the weight gradients (MFMA / HBM streaming) on a library-owned side stream next to the hash-grid
-	// backward (LDS atomics, index ALU).  Both only read what the dgrad kernel wrote and write disjoint parts of `grads`; the caller's stream
-	// waits for the side stream before this call's work counts as done.  Step +1.7 %.  The side stream should come from the host
-	// (ngp_hip_nerf_backward_set_fork_stream): one created late can share a hardware queue with the host's march stream, and the march then
-	// waits behind the weight gradients (measured: 365 -> 294 M samples/s).  NGP_HIP_BWD_FORK=0/1 overrides (dev).
-	static const int fork_env = getenv("NGP_HIP_BWD_FORK") ? atoi(getenv("NGP_HIP_BWD_FORK")) : -1;
-	const bool fork = fork_env >= 0 ? fork_env != 0 : g_backward_fork.load() != 0;
-	static hipStream_t side = nullptr;
-	static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// With a context: the weight gradients (MFMA / HBM streaming) run on the context's side stream next to the hash-grid backward (LDS atomics,
+	// index ALU).  Both only read what the dgrad kernel wrote and write disjoint parts of `grads`; the caller's stream waits for the side stream
+	// before this call's work counts as done.  Step +1.7 %.  The side stream should be created by the host next to its own streams: one created
+	// late can share a hardware queue with the host's march stream, and the march then waits behind the weight gradients (365 -> 294 M samples/s).
+	BackwardCtx* c = (BackwardCtx*)ctx;
+	static const int fork_env = getenv("NGP_HIP_BWD_FORK") ? atoi(getenv("NGP_HIP_BWD_FORK")) : -1;   // dev: 0 keeps everything in stream order
+	const bool fork = c && fork_env != 0;
 	hipStream_t wst = st;
+	if (c) NGP_HIP_TRY(hipEventRecord(c->ev_fork, st));   // "dgrad done" (ngp_hip_backward_ctx_dgrad_event)
 	if (fork) {
-		if (!side) {
-			NGP_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming | hipEventReleaseToDevice));
-			NGP_HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | hipEventReleaseToDevice));
-		}
-		hipStream_t use = g_backward_side_stream.load() ? (hipStream_t)g_backward_side_stream.load() : side;
-		NGP_HIP_TRY(hipEventRecord(ev_fork, st));
-		NGP_HIP_TRY(hipStreamWaitEvent(use, ev_fork, 0));
-		wst = use;
+		NGP_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+		wst = c->side;
 	}
 	const uint32_t n_chunks = wgrad_chunks(n);
 	if (fork) {
 		hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, wst, (const half_t*)planes, n, n / n_chunks, partials);
+		NGP_LAUNCH_CHECK("nerf_wgrad_kernel (side stream)");
 		hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, wst, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
-		NGP_HIP_TRY(hipEventRecord(ev_join, wst));
+		NGP_LAUNCH_CHECK("wgrad_reduce_kernel (side stream)");
+		NGP_HIP_TRY(hipEventRecord(c->ev_join, wst));
 	}
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (!(ablate & 4)) {
 		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
 	}
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
-	if (fork) { NGP_HIP_TRY(hipStreamWaitEvent(st, ev_join, 0)); return 0; }
+	if (fork) { NGP_HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); return 0; }
 	hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);

@@ -348,13 +348,18 @@ __device__ __forceinline__ v3 warp_direction(v3 d) { return mk((d.x + 1.0f) * 0.
 // exponent e of frexpf(x) = m * 2^e, m in [0.5, 1) (x >= 0 and finite here); frexp(0) -> 0.  v_frexp_exp_i32_f32 is exactly that
 // (f32 denormals are kept in hipcc's default kernel mode).
 __device__ __forceinline__ int frexp_exponent(float x) { return __builtin_amdgcn_frexp_expf(x); }
-__device__ __forceinline__ uint32_t cascaded_grid_idx_at(v3 pos, uint32_t mip) {
+// cell coordinates of cascaded_grid_idx_at (testbed_nerf.cu:318-337), clamped to [0, 127]
+__device__ __forceinline__ void cascaded_grid_coords(v3 pos, uint32_t mip, int& ix, int& iy, int& iz) {
 	float mip_scale = __uint_as_float((127u - mip) << 23); // scalbnf(1, -mip)
 	pos.x -= 0.5f; pos.y -= 0.5f; pos.z -= 0.5f;
 	pos.x *= mip_scale; pos.y *= mip_scale; pos.z *= mip_scale;
 	pos.x += 0.5f; pos.y += 0.5f; pos.z += 0.5f;
-	int ix = (int)(pos.x * 128.0f), iy = (int)(pos.y * 128.0f), iz = (int)(pos.z * 128.0f);
-	return morton3D((uint32_t)clampi(ix, 0, 127), (uint32_t)clampi(iy, 0, 127), (uint32_t)clampi(iz, 0, 127));
+	ix = clampi((int)(pos.x * 128.0f), 0, 127); iy = clampi((int)(pos.y * 128.0f), 0, 127); iz = clampi((int)(pos.z * 128.0f), 0, 127);
+}
+__device__ __forceinline__ uint32_t cascaded_grid_idx_at(v3 pos, uint32_t mip) {
+	int ix, iy, iz;
+	cascaded_grid_coords(pos, mip, ix, iy, iz);
+	return morton3D((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
 }
 __device__ __forceinline__ bool density_grid_occupied_at(v3 pos, const uint8_t* __restrict__ bitfield, uint32_t mip) {
 	uint32_t idx = cascaded_grid_idx_at(pos, mip);

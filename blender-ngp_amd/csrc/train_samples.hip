@@ -260,6 +260,374 @@ __global__ void __launch_bounds__(256) expand_training_samples_kernel(const Trai
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Wave-per-ray march for the constant-step case (cone_angle == 0: aabb_scale <= 1, where calc_dt is MIN_CONE_STEPSIZE for every t).
+//
+// Every t the reference's march visits lies on ONE additive sequence t_{k+1} = fl(t_k + dt) from the jittered start: an occupied sample
+// steps by dt, and advance_to_next_voxel (testbed_nerf.cu:201-213) walks the SAME additions until t >= t_target.  The march is therefore
+// a walk over candidate INDICES: at candidate k, "occupied -> emit, go to k + 1", "empty -> go to the first k' > k with t_k' >= t_k +
+// distance_to_next_voxel(pos_k)".  Inside one binade [2^e, 2^(e+1)) every t is a multiple of u = 2^(e-23) and fl(t + dt) = t + inc * u
+// with inc = round(dt / u) (no tie) as long as the sum stays below 2^(e+1): there t_k = fma(k - k_begin, inc * u, t_begin) EXACTLY (the
+// true value is representable, so the fused multiply-add rounds nothing).  A ray is a handful of such segments (one per binade it
+// crosses, the crossing steps done by real fp32 additions); with t_k in closed form the 64 lanes of a wave evaluate 64 consecutive
+// candidates at once (position, box test, mip, occupancy bit, skip target by exact arithmetic on the segment) and the walk over them is
+// a SCALAR loop on the two ballot masks (v_readlane for the skip targets; runs of occupied candidates by count-trailing-ones).  Same
+// visited candidates, same t, same samples as the serial march, bit for bit — without its ~450-trip dependent chain per wave.
+// One workgroup = 4 waves x 4 rays; sample slots are reserved once per workgroup (one atomic per counter), then every wave writes the
+// 28-byte records of its rays from the per-window emit masks (consecutive samples by consecutive lanes).
+constexpr uint32_t WM_WAVES = 4, WM_RAYS_PER_WAVE = 4, WM_RAYS_PER_WG = WM_WAVES * WM_RAYS_PER_WAVE;
+constexpr uint32_t WM_MAX_SEGS = 20;       // binades from t ~ 2^-18 up to 4 (a start at t = 0 takes one degenerate segment, then e = -10 ... 1)
+constexpr uint32_t WM_MAX_WINDOWS = 32;    // windows that emitted samples; a ray that needs more takes the serial path
+constexpr uint32_t WM_MAX_CANDIDATES = 1u << 20;
+
+struct WmSeg { uint32_t k_begin, k_last; float t_begin, delta, inv_delta; };   // t_k = fma(k - k_begin, delta, t_begin) for k_begin <= k <= k_last
+
+// segments of the additive sequence from `startt` until it has left the box; false = more than WM_MAX_SEGS (serial path)
+__device__ __forceinline__ bool wm_build_segments(float startt, v3 ro, v3 rd, const Aabb& aabb, WmSeg* __restrict__ segs, uint32_t& n_segs) {
+	const float dt = MIN_CONE_STEPSIZE();
+	float t = startt;
+	uint32_t k = 0;
+	n_segs = 0;
+	for (;;) {
+		if (n_segs == WM_MAX_SEGS || k >= WM_MAX_CANDIDATES) return false;
+		WmSeg s; s.k_begin = k; s.k_last = k; s.t_begin = t; s.delta = 0.f; s.inv_delta = 0.f;
+		const uint32_t bits = __float_as_uint(t);
+		const int e = (int)(bits >> 23) - 127;
+		if (e >= -60 && e <= 60) {   // (t == 0, denormals, huge values: a degenerate segment, every step a real addition)
+			const float x = dt * __uint_as_float((uint32_t)(127 + 23 - e) << 23);   // dt / u, exact
+			if (x < 16777216.0f) {
+				const float q = floorf(x), frac = x - q;
+				const uint32_t inc = (uint32_t)q + (frac > 0.5f ? 1u : 0u);
+				if (frac != 0.5f && inc != 0u) {   // a tie rounds to even, i.e. alternates: no closed form in that binade
+					const uint32_t m = (bits & 0x007fffffu) | 0x00800000u;
+					const uint32_t n = (0x00ffffffu - m) / inc;   // steps that stay below 2^(e+1)
+					s.k_last = k + n;
+					s.delta = (float)inc * __uint_as_float((uint32_t)(127 - 23 + e) << 23);
+					s.inv_delta = 1.0f / s.delta;
+				}
+			}
+		}
+		segs[n_segs++] = s;
+		const float t_last = __builtin_fmaf((float)(s.k_last - s.k_begin), s.delta, t);
+		// positions move monotonically along every axis: once a candidate is outside the (convex) box, all later ones are
+		if (!aabb_contains(aabb, ro + rd * t_last)) return true;
+		const float t_next = t_last + dt;   // the crossing step
+		if (!(t_next > t_last)) return true;   // dt below half an ulp (t > 2^14) or a non-finite t: the sequence does not advance; treat the rest as outside
+		t = t_next;
+		k = s.k_last + 1;
+	}
+}
+
+// wave-uniform copy of lane `l`'s value (v_readlane_b32: the result lives in a scalar register)
+__device__ __forceinline__ float wm_lane_f(float v, uint32_t l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), (int)l)); }
+__device__ __forceinline__ uint32_t wm_lane_u(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ v3 wm_lane_v3(v3 v, uint32_t l) { return mk(wm_lane_f(v.x, l), wm_lane_f(v.y, l), wm_lane_f(v.z, l)); }
+
+// the reference's own march, one lane (rays whose bookkeeping does not fit: > WM_MAX_SEGS binades or > WM_MAX_WINDOWS sample windows)
+__device__ __forceinline__ uint32_t wm_serial_march(const TrainSampleArgs& a, v3 ro, v3 rd, v3 idir, float startt, NgpCoord* __restrict__ co, v3 warped_dir, uint32_t limit) {
+	uint32_t j = 0;
+	float t = startt;
+	v3 pos;
+	OccBrick occ;
+	while (aabb_contains(a.aabb, pos = ro + rd * t) && j < limit) {
+		const float dt = MIN_CONE_STEPSIZE();
+		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+		if (density_grid_occupied_at(pos, a.density_grid, mip, occ)) {
+			if (co) {
+				const v3 wp = aabb_relative_pos(a.aabb, pos);
+				NgpCoord c;
+				c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
+				c.dir[0] = warped_dir.x; c.dir[1] = warped_dir.y; c.dir[2] = warped_dir.z;
+				co[j] = c;
+			}
+			++j; t += dt;
+		} else {
+			t = advance_to_next_voxel<true>(t, 0.0f, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+		}
+	}
+	return j;
+}
+
+__global__ void __launch_bounds__(256) generate_training_samples_wave_kernel(const TrainSampleArgs a) {
+	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
+	__shared__ WmSeg s_segs[WM_RAYS_PER_WG][WM_MAX_SEGS];
+	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
+	__shared__ uint32_t s_win_k0[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
+	__shared__ uint32_t s_n_windows[WM_RAYS_PER_WG], s_numsteps[WM_RAYS_PER_WG], s_base[WM_RAYS_PER_WG], s_slot[WM_RAYS_PER_WG];
+	__shared__ uint8_t s_serial[WM_RAYS_PER_WG];
+	__shared__ uint32_t s_spread[128];   // expand_bits of the 7-bit cell coordinates (morton3D by three LDS reads)
+	if (threadIdx.x < 128u) s_spread[threadIdx.x] = expand_bits(threadIdx.x);
+
+	if (a.brick_summary) { for (uint32_t q = threadIdx.x; q < NGP_NERF_GRID_N_CELLS / 64 / 32; q += blockDim.x) s_brick_any[q] = a.brick_summary[q]; }
+	else load_brick_summary(a.density_grid, s_brick_any);
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	const float dt = MIN_CONE_STEPSIZE();
+
+	// persistent workgroups: the grid size is the throttle (the march shares the chip with the step's backward pass, whose 256-register kernel
+	// loses a resident wave on every SIMD that also hosts march waves)
+	const uint32_t n_groups = (a.n_rays + WM_RAYS_PER_WG - 1) / WM_RAYS_PER_WG;
+	for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+		// ---- per-ray setup on lanes 0..3 of every wave (identical to the serial kernel's)
+		const uint32_t li = group * WM_RAYS_PER_WG + w * WM_RAYS_PER_WAVE + lane;
+		const bool setup_lane = lane < WM_RAYS_PER_WAVE;
+		const bool in_range = setup_lane && li < a.n_rays;
+		const uint32_t i = li + a.ray_offset;
+		bool valid = false;   // the ray exists, its pixel is not masked and its first candidate lies inside the box
+		bool pixel_ok = false;
+		float startt = 0.f, max_level = 1.0f;
+		v3 ro = mk(0, 0, 0), rd_unnorm = mk(0, 0, 1), rd = mk(0, 0, 1), idir = mk(1, 1, 1);
+		uint32_t n_segs = 0;
+		bool serial = false;
+		if (in_range) {
+			const uint32_t img = image_idx(i, a.n_rays_global, a.n_training_images, a.cdf.cdf_img, nullptr);
+			const NgpImageMeta& md = a.metadata[img];
+			Pcg32 rng = a.rng;
+			rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
+			float u, v;
+			nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, u, v, nullptr);
+			if (!pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) {
+				pixel_ok = true;
+				max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
+				const float motionblur_time = rng.next_float();
+				float xform[12];
+				get_xform_given_rolling_shutter(a.xforms[img], md.rolling_shutter, u, v, motionblur_time, xform);
+				if (md.rays) {
+					int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
+					px = px < md.res[0] - 1 ? px : md.res[0] - 1; px = px > 0 ? px : 0;
+					py = py < md.res[1] - 1 ? py : md.res[1] - 1; py = py > 0 ? py : 0;
+					const NgpRay r = md.rays[(uint64_t)px + (uint64_t)py * (uint64_t)md.res[0]];
+					ro = ld3(r.o); rd_unnorm = ld3(r.d);
+				} else {
+					ro = col(xform, 3);
+					v3 d;
+					if (md.lens_mode == 2) d = f_theta_undistortion(u - md.principal_point[0], v - md.principal_point[1], md.lens_params, mk(0.f, 0.f, 1.f));
+					else if (md.lens_mode == 3) d = latlong_to_dir(u, v);
+					else {
+						d = mk((u - md.principal_point[0]) * (float)md.res[0] / md.focal_length[0], (v - md.principal_point[1]) * (float)md.res[1] / md.focal_length[1], 1.0f);
+						if (md.lens_mode == 1) iterative_opencv_lens_undistortion(md.lens_params, d.x, d.y);
+					}
+					if (a.distortion_data) {
+						float o0, o1;
+						read_image2(a.distortion_data, a.distortion_res[0], a.distortion_res[1], u, v, o0, o1);
+						d.x += o0; d.y += o1;
+					}
+					rd_unnorm = mat3_mul(xform, d); // NOT normalized (1189)
+				}
+				rd = normalized(rd_unnorm);
+				float tmin, tmax;
+				aabb_ray_intersect(a.aabb, ro, rd, tmin, tmax);
+				tmin = fmaxf(tmin, 0.0f);
+				startt = tmin;
+				startt += dt * rng.next_float();
+				idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+				valid = aabb_contains(a.aabb, ro + rd * startt);   // otherwise the reference's loop ends before its first iteration
+				if (valid && a.dev_variant != 3) serial = !wm_build_segments(startt, ro, rd, a.aabb, s_segs[w * WM_RAYS_PER_WAVE + lane], n_segs);
+			}
+		}
+		const v3 warped_dir = warp_direction(rd);
+
+		// ---- march: the wave takes its rays one after the other; ray parameters become scalars
+	#pragma unroll 1
+		for (uint32_t q = 0; q < WM_RAYS_PER_WAVE; ++q) {
+			const uint32_t rl = w * WM_RAYS_PER_WAVE + q;
+			const bool r_valid = wm_lane_u(valid, q) != 0 && a.dev_variant != 3;
+			const bool r_serial = wm_lane_u(serial, q) != 0;
+			uint32_t j = 0, n_windows = 0;
+			bool overflow = false;
+			if (r_valid && !r_serial) {
+				const v3 o = wm_lane_v3(ro, q), d = wm_lane_v3(rd, q), id = wm_lane_v3(idir, q);
+				const uint32_t ns = wm_lane_u(n_segs, q);
+				const WmSeg* __restrict__ segs = s_segs[rl];
+				uint32_t k0 = 0, s_first = 0, s_loaded = 0xffffffffu;
+				WmSeg A = segs[0], B = A, C = A;   // the segment of the window's first candidate and its two successors (wave-uniform values)
+				bool has_b = false, has_c = false;
+				bool done = false;
+				while (!done) {
+					if (s_first != s_loaded) {
+						s_loaded = s_first;
+						A = segs[s_first];
+						has_b = s_first + 1 < ns; has_c = s_first + 2 < ns;
+						B = segs[has_b ? s_first + 1 : s_first];
+						C = segs[has_c ? s_first + 2 : s_first];
+					}
+					// ---- 64 candidates at once.  Common case: the window lies in A and B (segments are hundreds of candidates long except next to t = 0)
+					const uint32_t k = k0 + lane;
+					const bool fast = !has_c || k0 + 63u <= (uint32_t)__builtin_amdgcn_readfirstlane((int)B.k_last);
+					WmSeg sg; uint32_t s = s_first;
+					if (fast) {
+						const bool in_b = has_b && k > A.k_last;
+						sg.k_begin = in_b ? B.k_begin : A.k_begin; sg.k_last = in_b ? B.k_last : A.k_last;
+						sg.t_begin = in_b ? B.t_begin : A.t_begin; sg.delta = in_b ? B.delta : A.delta; sg.inv_delta = in_b ? B.inv_delta : A.inv_delta;
+						s = s_first + (in_b ? 1u : 0u);
+					} else {
+						while (s + 1 < ns && k > segs[s].k_last) ++s;
+						sg = segs[s];
+					}
+					const float t = __builtin_fmaf((float)(k - sg.k_begin), sg.delta, sg.t_begin);
+					const v3 pos = o + d * t;
+					const bool inside = k <= sg.k_last && aabb_contains(a.aabb, pos);
+					const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+					int ix, iy, iz;
+					cascaded_grid_coords(pos, mip, ix, iy, iz);
+					const uint32_t idx = s_spread[ix] | (s_spread[iy] << 1) | (s_spread[iz] << 2);   // morton3D
+					const uint32_t brick = (idx >> 6) + (NGP_NERF_GRID_N_CELLS / 64u) * mip;
+					bool occ = false;
+					if (inside && !(mip == 0 && !((s_brick_any[brick >> 5] >> (brick & 31u)) & 1u))) occ = (((const uint64_t*)a.density_grid)[brick] >> (idx & 63u)) & 1ull;
+					uint32_t nxt = k + 1;
+					if (inside && !occ) {
+						// advance_to_next_voxel: the first k' > k with t_k' >= t_target, by exact arithmetic on the segments
+						const float t_target = t + distance_to_next_voxel(pos, d, id, NGP_NERF_GRIDSIZE >> mip);
+						uint32_t ss = s, kcur = k;
+						WmSeg g = sg;
+						float tcur = t;
+						for (;;) {
+							const float t_last = __builtin_fmaf((float)(g.k_last - g.k_begin), g.delta, g.t_begin);
+							if (t_target <= t_last) {
+								// same binade: t_target - tcur is exact; the estimate is within one of the answer, settled on the exact values
+								uint32_t n = 0;
+								const float diff = t_target - tcur;
+								if (diff > 0.0f) {
+									n = (uint32_t)ceilf(diff * g.inv_delta);
+									if (n > 0u && __builtin_fmaf((float)(n - 1u), g.delta, tcur) >= t_target) --n;
+									else if (__builtin_fmaf((float)n, g.delta, tcur) < t_target) ++n;
+								}
+								if (kcur == k && n == 0u) n = 1u;   // do { t += dt } while (t < t_target): at least one step
+								nxt = kcur + n;
+								break;
+							}
+							if (ss + 1 >= ns) { nxt = g.k_last + 1u; break; }   // beyond every segment: outside the box
+							++ss;
+							if (fast && ss == s_first + 1u) g = B; else if (fast && ss == s_first + 2u) g = C; else g = segs[ss];
+							kcur = g.k_begin; tcur = g.t_begin;
+							if (tcur >= t_target) { nxt = kcur; break; }
+						}
+					}
+					// ---- the walk over this window by pointer doubling: reach = candidates on the path from this lane, jmp = where the path stands after
+					// 2^i hops (64 = it left the window or the ray ended).  Lane 0's reach after <= 6 rounds is the visited set.
+					uint32_t jmp = 64u;
+					if (inside) { jmp = nxt - k0; jmp = jmp < 64u ? jmp : 64u; }
+					uint32_t r_lo = lane < 32u ? (1u << lane) : 0u, r_hi = lane >= 32u ? (1u << (lane - 32u)) : 0u;
+	#pragma unroll 1
+					for (int it = 0; it < 6; ++it) {
+						if (wm_lane_u(jmp, 0) >= 64u) break;   // only lane 0's path matters
+						const bool live = jmp < 64u;
+						const int src = (int)((live ? jmp : lane) << 2);
+						const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_lo), pb = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_hi);
+						const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)jmp);
+						if (live) { r_lo |= pa; r_hi |= pb; jmp = pj; }
+					}
+					const uint64_t visited = (uint64_t)wm_lane_u(r_lo, 0) | ((uint64_t)wm_lane_u(r_hi, 0) << 32);
+					const uint32_t last = 63u - (uint32_t)__builtin_clzll(visited);   // lane 0 is always visited
+					const uint64_t in_m = __ballot(inside), occ_m = __ballot(occ);
+					uint64_t emit = visited & occ_m;
+					if (!((in_m >> last) & 1ull)) done = true;   // the walk reached a candidate outside the box (1204)
+					const uint32_t n_emit = (uint32_t)__popcll(emit);
+					if (j + n_emit >= NGP_NERF_STEPS) {   // j < NERF_STEPS (1204): the ray ends with its 1024th sample
+						uint32_t room = NGP_NERF_STEPS - j;
+						while ((uint32_t)__popcll(emit) > room) emit &= ~(1ull << (63u - (uint32_t)__builtin_clzll(emit)));
+						done = true;
+					}
+					j += (uint32_t)__popcll(emit);
+					if (emit) {
+						if (n_windows < WM_MAX_WINDOWS) { if (lane == 0) { s_win_mask[rl][n_windows] = emit; s_win_k0[rl][n_windows] = k0; } }
+						else overflow = true;
+						++n_windows;
+					}
+					k0 = wm_lane_u(nxt, last);   // an occupied last candidate: k + 1
+					if (k0 >= WM_MAX_CANDIDATES) done = true;
+					while (s_first + 1 < ns && k0 > segs[s_first].k_last) ++s_first;
+					s_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_first);
+				}
+			}
+			bool ray_serial = r_serial || overflow;
+			if (r_valid && ray_serial) {
+				// count with the reference's own loop (one lane); the write pass repeats it
+				uint32_t cnt = 0;
+				if (lane == q) cnt = wm_serial_march(a, ro, rd, idir, startt, nullptr, warped_dir, NGP_NERF_STEPS);
+				j = wm_lane_u(cnt, q);
+			}
+			const bool r_pixel_ok = wm_lane_u(pixel_ok, q) != 0;
+			if (lane == 0) { s_numsteps[rl] = j; s_n_windows[rl] = n_windows; s_serial[rl] = (ray_serial ? 1 : 0) | (r_pixel_ok ? 2 : 0); }
+		}
+		__syncthreads();
+
+		// ---- slot reservation, once per workgroup (the reference: two atomics per ray, 1225 / 1232)
+		if (w == 0) {
+			const bool has = lane < WM_RAYS_PER_WG;
+			uint32_t numsteps = has ? s_numsteps[lane] : 0u;
+			// a ray past n_rays or on a masked pixel returns before both atomics in the reference (1115-1135); one without samples unless an envmap trains (1221)
+			bool keep = has && (s_serial[lane < WM_RAYS_PER_WG ? lane : 0] & 2) && !(numsteps == 0 && !a.train_envmap);
+			if (!keep) numsteps = 0;
+			const uint32_t incl = wave_inclusive_scan(numsteps);
+			const uint32_t total = __shfl(incl, 63, 64);
+			uint32_t wg_base = 0;
+			if (lane == 63 && total) wg_base = atomicAdd(a.numsteps_counter, total);
+			wg_base = __shfl(wg_base, 63, 64);
+			const uint32_t base = wg_base + incl - numsteps;
+			if (keep && base + numsteps > a.max_samples) keep = false;   // dropped AFTER the counter was bumped (1225-1228)
+			const unsigned long long kept_mask = __ballot(keep);
+			const uint32_t n_kept = (uint32_t)__popcll(kept_mask);
+			uint32_t ray_base = 0;
+			if (lane == 0 && n_kept) ray_base = atomicAdd(a.ray_counter, n_kept);
+			ray_base = __shfl(ray_base, 0, 64);
+			if (has) { s_base[lane] = base; s_slot[lane] = keep ? ray_base + (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull)) : 0xffffffffu; }
+		}
+		__syncthreads();
+
+		// ---- write pass
+	#pragma unroll 1
+		for (uint32_t q = 0; q < WM_RAYS_PER_WAVE; ++q) {
+			const uint32_t rl = w * WM_RAYS_PER_WAVE + q;
+			const uint32_t slot = s_slot[rl];
+			if (slot == 0xffffffffu) continue;
+			const uint32_t numsteps = s_numsteps[rl], base = s_base[rl];
+			if (lane == q) {
+				a.ray_indices_out[slot] = i;
+				NgpRay ray_out; ray_out.o[0] = ro.x; ray_out.o[1] = ro.y; ray_out.o[2] = ro.z; ray_out.d[0] = rd_unnorm.x; ray_out.d[1] = rd_unnorm.y; ray_out.d[2] = rd_unnorm.z;
+				a.rays_out[slot] = ray_out;
+				a.numsteps_out[slot * 2 + 0] = numsteps;
+				a.numsteps_out[slot * 2 + 1] = base;
+			}
+			if (numsteps == 0 || a.dev_variant == 2) continue;
+			NgpCoord* __restrict__ co = a.coords_out + base;
+			const float ml = wm_lane_f(max_level, q);
+			if (s_serial[rl] & 1) {
+				if (lane == q) wm_serial_march(a, ro, rd, idir, startt, co, warped_dir, numsteps);
+				if (a.max_level_rand_training) for (uint32_t jj = lane; jj < numsteps; jj += 64u) a.max_level_ptr[base + jj] = ml;
+				continue;
+			}
+			const v3 o = wm_lane_v3(ro, q);
+			const v3 d = wm_lane_v3(rd, q);
+			const v3 wd = wm_lane_v3(warped_dir, q);
+			const uint32_t ns = wm_lane_u(n_segs, q);
+			const WmSeg* __restrict__ segs = s_segs[rl];
+			const uint32_t n_windows = s_n_windows[rl];
+			uint32_t j0 = 0;
+			for (uint32_t wi = 0; wi < n_windows; ++wi) {
+				const uint64_t mask = s_win_mask[rl][wi];
+				const uint32_t k = s_win_k0[rl][wi] + lane;
+				if ((mask >> lane) & 1ull) {
+					uint32_t s = 0;
+					while (s + 1 < ns && k > segs[s].k_last) ++s;
+					const WmSeg sg = segs[s];
+					const float t = __builtin_fmaf((float)(k - sg.k_begin), sg.delta, sg.t_begin);
+					const v3 wp = aabb_relative_pos(a.aabb, o + d * t);
+					const uint32_t jj = j0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+					NgpCoord c;
+					c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
+					c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+					co[jj] = c;
+					if (a.max_level_rand_training) a.max_level_ptr[base + jj] = ml;
+				}
+				j0 += (uint32_t)__popcll(mask);
+			}
+		}
+	}
+}
+
 } // namespace ngp
 
 using namespace ngp;
@@ -281,13 +649,13 @@ extern "C" int ngp_hip_bitfield_brick_summary(void* stream, const uint8_t* bitfi
 	return 0;
 }
 
-extern "C" int ngp_hip_generate_training_samples(
+static int generate_training_samples_impl(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
-	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary) {
+	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode) {
 	if (!n_rays) return 0;
 	TrainSampleArgs a;
 	a.brick_summary = brick_summary;
@@ -303,6 +671,16 @@ extern "C" int ngp_hip_generate_training_samples(
 	a.ray_offset = ray_offset; a.n_rays_global = n_rays_global ? n_rays_global : n_rays;
 	const char* var = getenv("NGP_HIP_GEN_VARIANT");
 	a.dev_variant = var ? atoi(var) : 0;
+	// cone_angle == 0 and not NGP_MARCH_LANE_PER_RAY: wave-per-ray march on the closed-form step sequence
+	static const int mode_env = getenv("NGP_HIP_GEN_MODE") ? atoi(getenv("NGP_HIP_GEN_MODE")) : 0;   // dev / A-B: overrides the caller's choice
+	if (mode_env) march_mode = (uint32_t)mode_env;
+	if (cone_angle_constant == 0.0f && march_mode != NGP_MARCH_LANE_PER_RAY) {
+		// all workgroups resident at once (4 per CU): the kernel has the chip to itself in this mode
+		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = 4096u;
+		hipLaunchKernelGGL(generate_training_samples_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
+		NGP_LAUNCH_CHECK("generate_training_samples_wave_kernel");
+		return 0;
+	}
 	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_training_samples_kernel<true>, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL(generate_training_samples_kernel<false>, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("generate_training_samples_kernel");
@@ -311,4 +689,29 @@ extern "C" int ngp_hip_generate_training_samples(
 		NGP_LAUNCH_CHECK("expand_training_samples_kernel");
 	}
 	return 0;
+}
+
+extern "C" int ngp_hip_generate_training_samples(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
+	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
+	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
+	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary) {
+	return generate_training_samples_impl(stream, n_rays, aabb_host, max_samples, rng_state, rng_inc, ray_counter, numsteps_counter, ray_indices_out, rays_out_unnormalized, numsteps_out,
+	                                      coords_out, n_training_images, metadata, xforms, density_grid, max_level_rand_training, max_level_ptr, snap_to_pixel_centers, train_envmap,
+	                                      cone_angle_constant, distortion_data, distortion_resolution_host, ray_offset, n_rays_global, cdf_host, brick_summary, NGP_MARCH_AUTO);
+}
+
+extern "C" int ngp_hip_generate_training_samples_mode(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
+	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
+	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
+	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode) {
+	if (march_mode > NGP_MARCH_WAVE_PER_RAY) { set_last_error("ngp_hip_generate_training_samples_mode: unknown march_mode", hipErrorInvalidValue); return -1; }
+	return generate_training_samples_impl(stream, n_rays, aabb_host, max_samples, rng_state, rng_inc, ray_counter, numsteps_counter, ray_indices_out, rays_out_unnormalized, numsteps_out,
+	                                      coords_out, n_training_images, metadata, xforms, density_grid, max_level_rand_training, max_level_ptr, snap_to_pixel_centers, train_envmap,
+	                                      cone_angle_constant, distortion_data, distortion_resolution_host, ray_offset, n_rays_global, cdf_host, brick_summary, march_mode);
 }

@@ -209,6 +209,8 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	HIP_CHECK_THROW(hipStreamCreate(&st_b));
 	{   // the backward's side stream, created right behind the two step streams: three consecutive streams land on three hardware queues
 		hipStream_t st_c; HIP_CHECK_THROW(hipStreamCreate(&st_c)); m_stream_c = st_c;
+		m_bwd_ctx = ngp_hip_backward_ctx_create(m_stream_c);
+		if (!m_bwd_ctx) throw std::runtime_error{std::string{"ngp_hip_backward_ctx_create failed: "} + ngp_hip_last_error()};
 	}
 	m_stream = st; m_stream_b = st_b;
 	m_nerf.training.owner = this;
@@ -227,7 +229,8 @@ Testbed::~Testbed() {
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
-	if (m_stream_c) { ngp_hip_nerf_backward_set_fork_stream(nullptr); (void)hipStreamSynchronize((hipStream_t)m_stream_c); (void)hipStreamDestroy((hipStream_t)m_stream_c); }
+	if (m_bwd_ctx) ngp_hip_backward_ctx_destroy(m_bwd_ctx);   // drains the side stream
+	if (m_stream_c) (void)hipStreamDestroy((hipStream_t)m_stream_c);
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
 
@@ -635,7 +638,7 @@ uint32_t Testbed::next_max_inference(uint32_t target_batch_size) const {  // tes
 	return next_multiple(std::min(c.measured_batch_size_before_compaction, max_samples), BATCH_SIZE_GRANULARITY);
 }
 
-void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng) {
+void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng, bool next_to_backward) {
 	NerfTraining& tr = m_nerf.training;
 	const size_t r_cap = std::max<size_t>(R, 1u << 18);  // rays_per_batch is capped at 2^18 (2893): size once, no reallocation under a running step
 	m_ray_indices.enlarge(r_cap * 4); m_rays.enlarge(r_cap * sizeof(NgpRay)); m_numsteps.enlarge(r_cap * 8);
@@ -647,11 +650,15 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
 	NgpErrorMapCdf cdf_storage;
 	profile_begin(PK_GEN_SAMPLES, stream);
-	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
+	// run ahead on stream B the march shares the chip with the backward pass: the lane-per-ray kernels are latency-bound and cost it ~20 us; the
+	// wave-per-ray kernel is 3x faster on its own but takes twice the issue slots (measured: no gain beside the backward).  In stream order
+	// (first steps, the step after every occupancy update, a discarded prefetch) nothing runs beside it: wave-per-ray
+	check(ngp_hip_generate_training_samples_mode(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
 	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
-	                                        m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr), "generate_training_samples");
+	                                        m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr,
+	                                        next_to_backward ? NGP_MARCH_LANE_PER_RAY : NGP_MARCH_WAVE_PER_RAY), "generate_training_samples");
 	profile_end(PK_GEN_SAMPLES, R, stream);
 }
 
@@ -674,8 +681,18 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	p.valid = true; p.step = next_step; p.R = c.rays_per_batch; p.max_inference = next_max_inference(target_batch_size); p.rng_state = rng.state;
 	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
 	p.cdf_mode = m_nerf.training.cdf_mode();
-	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the counters event has fired by now
-	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng);
+	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the host has seen the counters the kernel behind
+	// it posted — unless the step was begun without waiting for them (a data-parallel host that reduces them in stream order), in which case
+	// stream B waits for the counters event itself
+	if (!m_counters_host_seen) {
+		if (!m_counters_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream)); m_counters_event_recorded = true; }
+		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_counters_event, 0));
+	}
+	// the wave-per-ray march is a full-width VALU kernel: next to the step's dgrad kernel (256 registers, two waves per SIMD) it takes a
+	// resident wave away from every SIMD it lands on (dgrad 94 -> 143 us).  Held back until that kernel is through it overlaps the hash-grid
+	// backward and the optimizer instead
+	if (m_march_after_dgrad && m_dgrad_event_recorded) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)ngp_hip_backward_ctx_dgrad_event(m_bwd_ctx), 0));
+	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng, true);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
 	m_prefetch = p;
@@ -730,7 +747,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		++m_prefetch_hits;
 	} else {
 		drop_prefetch();
-		launch_generate(m_stream, m_gen_slot, R, max_inference, m_rng);
+		launch_generate(m_stream, m_gen_slot, R, max_inference, m_rng, false);
 	}
 	uint32_t* gen_counters = m_gen_counters.as<uint32_t>() + 4 * m_gen_slot;
 	uint32_t* compacted_counter = gen_counters + 2;
@@ -821,14 +838,14 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
-	ngp_hip_nerf_backward_set_fork_stream(m_stream_c);
-	ngp_hip_nerf_backward_set_fork(1);
-	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
+	check(ngp_hip_nerf_backward_ctx(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+	                                OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_want_grid_grad_event ? m_grid_grad_event : nullptr, m_bwd_ctx), "nerf_backward");
+	m_dgrad_event_recorded = true;
 	m_grid_grad_event_recorded = m_want_grid_grad_event;
 	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
 
+	m_counters_host_seen = wait_for_counters;
 	if (!wait_for_counters) { counters_out[0] = counters_out[1] = 0; return; }   // the caller reduces m_dp_counters_dev in stream order instead
 	// poll the host-mapped words (a couple of microseconds after the kernel's store; an event wake-up costs 10-20); the event is the fallback
 	const volatile uint32_t* w = (const volatile uint32_t*)m_host_words;

@@ -357,7 +357,10 @@ public:
 	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
 	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
-	void* m_stream_c = nullptr;                        // side stream of the forked backward (ngp_hip_nerf_backward_set_fork_stream)
+	void* m_stream_c = nullptr;                        // side stream of the forked backward
+	void* m_bwd_ctx = nullptr;                         // ngp_hip_backward_ctx_create(m_stream_c): this Testbed's fork / join / dgrad-done events
+	bool m_march_after_dgrad = false;                  // the run-ahead march starts once the step's dgrad kernel is through (see maybe_prefetch_next)
+	bool m_dgrad_event_recorded = false, m_counters_host_seen = true;
 	bool m_async_training_steps = false;              // frame() returns with the step's tail (backward, optimizer) still running on the stream
 	std::chrono::steady_clock::time_point m_last_step_return{};
 	bool m_profile_enabled = false;
@@ -407,7 +410,7 @@ private:
 	bool m_train_continues = true;
 	DeviceBuffer m_gen_counters;                       // 2 slots x {ray counter, numsteps counter, compacted numsteps counter, pad}
 	uint32_t next_max_inference(uint32_t target_batch_size) const;
-	void launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng);
+	void launch_generate(void* stream, int slot, uint32_t R, uint32_t max_inference, const Pcg32& rng, bool next_to_backward);
 	void maybe_prefetch_next(uint32_t target_batch_size);
 	void drop_prefetch();
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)

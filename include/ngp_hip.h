@@ -131,20 +131,28 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes);
-/* Process-wide switch (default 0, returns the previous value): with 1, ngp_hip_nerf_backward[_ev] runs the MLP weight-gradient kernels on a
- * stream owned by the library, concurrently with the hash-grid backward, and makes the caller's stream wait for them before it returns to
- * stream order.  Same results; a scheduling option (see ngp_hip_nerf_backward_set_fork_stream). */
-int ngp_hip_nerf_backward_set_fork(int on);
-/* The side stream to use (NULL: one the library creates at the first forked call).  HIP multiplexes streams onto a few hardware queues in
- * creation order; a host with further streams of its own (the Testbed's march stream) creates the side stream right next to them so that the
- * weight-gradient kernels do not land in front of its latency-critical work on a shared queue. */
-int ngp_hip_nerf_backward_set_fork_stream(void* side_stream);
 /* Same; additionally records `grid_gradients_event` (a hipEvent_t, may be NULL) on the stream once the hash-grid part of `grads`
  * (everything behind the first 10240 MLP parameters) is final — the MLP weight gradients follow.  A data-parallel host starts the
  * all-reduce of the 24 MB grid slice on another stream at that point instead of after the whole call. */
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event);
+/* Scheduling context of the backward pass, owned by one caller (one per host object and device; nothing here is process state).
+ * create(side_stream): `side_stream` is a hipStream_t of the caller, or NULL for one the context creates on the current device.  HIP
+ * multiplexes streams onto a few hardware queues in creation order: a host with further streams of its own (the Testbed's march stream)
+ * creates the side stream right next to them, so that the weight-gradient kernels do not land in front of its latency-critical work on a
+ * shared queue.  Returns an opaque handle, NULL on failure (ngp_hip_last_error).  destroy() drains the side stream first. */
+void* ngp_hip_backward_ctx_create(void* side_stream);
+void ngp_hip_backward_ctx_destroy(void* ctx);
+/* hipEvent_t of the context that every ngp_hip_nerf_backward_ctx call records on its stream right behind the dgrad kernel (the 256-register
+ * kernel of the pass): a host that runs other work next to the backward can hold that work back until this kernel is through. */
+void* ngp_hip_backward_ctx_dgrad_event(void* ctx);
+/* ngp_hip_nerf_backward_ev with a context (may be NULL = ngp_hip_nerf_backward_ev): the MLP weight-gradient kernels run on the context's side
+ * stream, concurrently with the hash-grid backward, and the caller's stream waits for them before the call's work counts as done.  Same
+ * results bit for bit; a scheduling option. */
+int ngp_hip_nerf_backward_ctx(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event, void* ctx);
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */
@@ -181,6 +189,20 @@ int ngp_hip_generate_training_samples(
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
 	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */,
 	const uint32_t* brick_summary /* NULL, or what ngp_hip_bitfield_brick_summary wrote for density_grid (same samples either way) */);
+/* The same call with the marching kernel chosen by the caller (same rays, same samples, bit for bit; slot order aside):
+ *   NGP_MARCH_AUTO          what ngp_hip_generate_training_samples does: wave-per-ray whenever cone_angle_constant == 0
+ *   NGP_MARCH_LANE_PER_RAY  one lane per ray + a wave-per-ray expansion kernel: a latency-bound serial chain (~330 us at 2^14 rays) that costs
+ *                           few issue slots — the one to run NEXT TO other kernels (the Testbed's run-ahead march beside the backward pass)
+ *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once on the closed-form step sequence (cone_angle_constant == 0 only, otherwise
+ *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order */
+enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2 };
+int ngp_hip_generate_training_samples_mode(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
+	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
+	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
+	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
+	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode);
 
 /* ============================ load-time image sharpening (src/nerf_loader.cu:102-123, 803-825) ============================
  * NerfDataset::set_training_image with sharpen_amount > 0: Byte images first become premultiplied linear half4 (from_rgba32<__half>,

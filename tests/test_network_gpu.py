@@ -155,7 +155,7 @@ def test_backward_linearity(ngp, cuda):
 
 
 def test_backward_fork_option_is_bit_identical(ngp, cuda):
-    """ngp_hip_nerf_backward_set_fork: weight-gradient kernels on the library's side stream, concurrent with the hash-grid backward — same bits,
+    """ngp_hip_nerf_backward_ctx: weight-gradient kernels on the context's side stream, concurrent with the hash-grid backward — same bits,
     also when calls follow each other without a host sync (the scratch planes of call k+1 must not overtake the side stream of call k)."""
     n = 1 << 16
     desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=19, n=n, grid_amp=0.5)
@@ -166,17 +166,17 @@ def test_backward_fork_option_is_bit_identical(ngp, cuda):
     scratch = H.dev_zeros(sb, cuda)
     dls = [H.to_dev((rs.randn(n, 4) * 0.01).astype(np.float16), cuda) for _ in range(3)]
     res = {}
+    ctx = ngp.ngp_hip_backward_ctx_create(None)   # its own side stream
+    assert ctx and ngp.ngp_hip_backward_ctx_dgrad_event(ctx)
     try:
         for fork in (0, 1):
-            prev = ngp.ngp_hip_nerf_backward_set_fork(fork)
-            assert prev in (0, 1)
             gs = [H.dev_zeros(H.n_params(desc) * 2, cuda) for _ in dls]
             for d_dl, g in zip(dls, gs):   # back to back, no sync in between
-                check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
-                                                g.data_ptr(), scratch.data_ptr(), sb))
+                check(ngp.ngp_hip_nerf_backward_ctx(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                                    g.data_ptr(), scratch.data_ptr(), sb, None, ctx if fork else None))
             res[fork] = [H.to_host(g, np.uint16) for g in gs]
     finally:
-        ngp.ngp_hip_nerf_backward_set_fork(0)
+        ngp.ngp_hip_backward_ctx_destroy(ctx)
     for a, b in zip(res[0], res[1]):
         assert np.any(a[:10240] != 0) and np.any(a[10240:] != 0)
         np.testing.assert_array_equal(a, b)

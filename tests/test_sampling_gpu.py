@@ -99,9 +99,11 @@ def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):
 
 
 def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_mode=0, lens_params=None, snap=0, max_samples=None,
-                       ray_offset=0, n_rays_global=0, distortion=False, cdf_mode=0, brick_summary=False):
-    imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, lens_mode=lens_mode, lens_params=lens_params, radius=1.3 * 2 ** (n_cascades - 1))
+                       ray_offset=0, n_rays_global=0, distortion=False, cdf_mode=0, brick_summary=False, march_mode=None, radius=None, grid_fill=None):
+    imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, lens_mode=lens_mode, lens_params=lens_params, radius=radius or 1.3 * 2 ** (n_cascades - 1))
     grid = H.blob_density_grid(n_cascades)
+    if grid_fill is not None:   # "full": every cell occupied; "sparse": isolated cells (many short runs per ray)
+        grid = np.full_like(grid, 1.0) if grid_fill == "full" else np.where(np.random.RandomState(11).rand(*grid.shape) < 0.12, 1.0, 0.0).astype(grid.dtype)
     bf, _ = H.oracle_bitfield(oracle, grid, n_cascades)
     aabb = H.unit_aabb(2 ** (n_cascades - 1))
     st, inc = H.pcg32_state(1337)
@@ -132,9 +134,13 @@ def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_m
     if cdf_mode:
         d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
         c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if cdf_mode & 1 else 0, d_cy.data_ptr() if cdf_mode & 1 else 0, d_ci.data_ptr() if cdf_mode & 2 else 0, C["res"])
-    check(ngp.ngp_hip_generate_training_samples(None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
-                                                d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
-                                                0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None, d_summary.data_ptr() if brick_summary else None))
+    args = (None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
+            d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
+            0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None, d_summary.data_ptr() if brick_summary else None)
+    if march_mode is None:
+        check(ngp.ngp_hip_generate_training_samples(*args))
+    else:   # 1: lane-per-ray kernels (what the Testbed runs ahead beside the backward pass), 2: wave-per-ray (in stream order)
+        check(ngp.ngp_hip_generate_training_samples_mode(*args, march_mode))
     g = dict(rc=H.to_host(d["rc"], np.uint32), nc=H.to_host(d["nc"], np.uint32), idx=H.to_host(d["idx"], np.uint32), rays=H.to_host(d["rays"], H.RAY),
              ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD))
     return r, g
@@ -164,9 +170,10 @@ def _compare_per_ray(r, g, exact_rays=True):
         assert r["co"][br:br + nr].tobytes() == g["co"][bg:bg + ng].tobytes(), ray
 
 
+@pytest.mark.parametrize("march_mode", [1, 2])
 @pytest.mark.parametrize("brick_summary", [False, True])
-def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda, brick_summary):
-    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True, brick_summary=brick_summary)
+def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda, brick_summary, march_mode):
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True, brick_summary=brick_summary, march_mode=march_mode)
     _compare_per_ray(r, g)
 
 
@@ -208,7 +215,7 @@ def test_training_samples_opencv_lens(ngp, oracle, cuda):
 
 def test_training_samples_sharded_equals_whole(ngp, oracle, cuda):
     """data-parallel extension: two half-batches with ray offsets reproduce the per-ray results of the full batch."""
-    rf, gf = _run_train_samples(ngp, oracle, cuda, n_rays=2048, n_cascades=1, cone_angle=0.0)
+    rf, gf = _run_train_samples(ngp, oracle, cuda, n_rays=2048, n_cascades=1, cone_angle=0.0, march_mode=1)   # the whole batch by the lane-per-ray kernels, the shards by the default
     whole = {int(gf["idx"][k]): (int(gf["ns"][2 * k]), gf["co"][int(gf["ns"][2 * k + 1]):int(gf["ns"][2 * k + 1]) + int(gf["ns"][2 * k])].tobytes()) for k in range(int(gf["rc"][0]))}
     seen = {}
     for off in (0, 1024):
@@ -220,9 +227,31 @@ def test_training_samples_sharded_equals_whole(ngp, oracle, cuda):
     assert seen == whole
 
 
-def test_training_samples_overflow_drops_rays(ngp, oracle, cuda):
+@pytest.mark.parametrize("march_mode", [1, 2])
+@pytest.mark.parametrize("case", ["inside", "full", "sparse", "big"])
+def test_training_samples_march_corner_cases(ngp, oracle, cuda, march_mode, case):
+    """The constant-step march where the wave-per-ray kernel leaves its common path: cameras INSIDE the box (t starts at 0: a dozen binades, windows
+    that span several step segments), a fully occupied grid (unbroken runs across ten windows) and a grid of isolated cells (more
+    sample windows per ray than the kernel keeps: its serial path).  Both kernels against the oracle, bit for bit."""
+    kw = dict(radius=0.3) if case == "inside" else dict(grid_fill="full" if case == "big" else case)
+    if case == "full":
+        kw["radius"] = 0.45
+    # "big": a constant step forced onto a box of twice the size (2 cascades): up to 2048 candidates per ray, i.e. more sample windows than the
+    # wave-per-ray kernel keeps (its serial path) and rays that end with their 1024th sample (NERF_STEPS, testbed_nerf.cu:1204)
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=1024 if case == "big" else 2048, n_cascades=2 if case == "big" else 1, cone_angle=0.0, march_mode=march_mode,
+                              max_samples=2048 * 1100, **kw)
+    _compare_per_ray(r, g)
+    ns = r["ns"][0:2 * int(r["rc"][0]):2]
+    if case == "big":
+        assert ns.max() == 1024
+    if case == "full":
+        assert ns.max() > 640   # unbroken runs of ten windows (the 1024-sample cap needs the full diagonal of the unit cube: 1024.0 steps)
+
+
+@pytest.mark.parametrize("march_mode", [1, 2])
+def test_training_samples_overflow_drops_rays(ngp, oracle, cuda, march_mode):
     """max_samples smaller than the demand: counts stay consistent (kept rays' runs fit, counter exceeds the budget)."""
-    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, max_samples=20000)
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, max_samples=20000, march_mode=march_mode)
     assert int(g["nc"][0]) == int(r["nc"][0]) > 20000  # the counter is bumped before the check (testbed_nerf.cu:1225-1228)
     n = int(g["rc"][0])
     assert 0 < n < 4096
