@@ -1062,6 +1062,212 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc*
 }
 
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Fused backward: the same dgrad chain PLUS the weight-gradient contraction in one kernel, so that the [480][n] activation / delta planes
+// (0.25 GB written and read back per step) never exist.  The contraction dW[o][i] = sum_s dY[o][s] * H[i][s] runs over SAMPLES, i.e. the MFMA
+// operands must hold 8 consecutive samples of one feature per lane, while the chain keeps 8 features of one sample per lane: a transpose.
+// It goes through LDS, one layer at a time: the 4 waves of the workgroup write the two operand matrices of the layer for their 4 x 32 samples
+// as [feature][128 samples] fp16 rows (2-byte scattered writes, 272-byte row pitch), and read them back as 16-byte K-blocks that ARE the A / B
+// operands (conflict-free: pitch = 4 banks mod 64).  The 12 output tiles of the five weight matrices are split over the 4 waves, three each
+// (48 accumulator registers per wave, kept across the grid-stride loop); one fp32 partial per workgroup at the end, summed by
+// wgrad_reduce_kernel.
+constexpr int FB_PITCH = 128 * 2 + 16;       // bytes per staged row: 128 samples fp16 + 16 B
+constexpr int FB_STAGE_ROWS = 128;
+constexpr int FB_STAGE_BYTES = FB_STAGE_ROWS * FB_PITCH;   // 34 816 B
+
+__device__ __forceinline__ void fb_put(char* __restrict__ stage, int row0, int map, int kb, int g, int col, const h8& v) {
+#pragma unroll
+	for (int e = 0; e < 8; ++e) *(half_t*)(stage + (row0 + slot_feature(map, kb, g, e)) * FB_PITCH + col * 2) = v[e];
+}
+__device__ __forceinline__ h8 fb_get(const char* __restrict__ stage, int row, int kbs, int g) { return *(const h8*)(stage + row * FB_PITCH + (kbs * 16 + 8 * g) * 2); }
+
+// job with a 16-row dY (padded to one 32-row M tile) and a 64-row H: N tile nt, all 8 K-blocks
+__device__ __forceinline__ void fb_job_m1n2(const char* __restrict__ stage, int dy_row0, int h_row0, int nt, int lane, f32x16& acc) {
+	const int r32 = lane & 31, g = lane >> 5;
+	const h8 zero = {};
+#pragma unroll
+	for (int kbs = 0; kbs < 8; ++kbs) {
+		h8 a = fb_get(stage, dy_row0 + (r32 & 15), kbs, g);
+		if (r32 >= 16) a = zero;
+		const h8 b = fb_get(stage, h_row0 + nt * 32 + r32, kbs, g);
+		acc = NGP_MFMA(a, b, acc);
+	}
+}
+// job with a 64-row dY and a 32-row H: M tile mt, all 8 K-blocks
+__device__ __forceinline__ void fb_job_m2n1(const char* __restrict__ stage, int dy_row0, int h_row0, int mt, int lane, f32x16& acc) {
+	const int r32 = lane & 31, g = lane >> 5;
+#pragma unroll
+	for (int kbs = 0; kbs < 8; ++kbs) {
+		const h8 a = fb_get(stage, dy_row0 + mt * 32 + r32, kbs, g);
+		const h8 b = fb_get(stage, h_row0 + r32, kbs, g);
+		acc = NGP_MFMA(a, b, acc);
+	}
+}
+// the 64 x 64 job: wave w takes tile (w >> 1, w & 1)
+__device__ __forceinline__ void fb_job_m2n2(const char* __restrict__ stage, int dy_row0, int h_row0, int w, int lane, f32x16& acc) {
+	const int r32 = lane & 31, g = lane >> 5, mt = w >> 1, nt = w & 1;
+#pragma unroll
+	for (int kbs = 0; kbs < 8; ++kbs) {
+		const h8 a = fb_get(stage, dy_row0 + mt * 32 + r32, kbs, g);
+		const h8 b = fb_get(stage, h_row0 + nt * 32 + r32, kbs, g);
+		acc = NGP_MFMA(a, b, acc);
+	}
+}
+
+// epilogue: the 4 waves' accumulator tiles of one kind -> LDS -> this workgroup's partial dW.
+// kind 0: W4, wave t holds tile (t >> 1, t & 1).  kind 1: waves 0, 1 hold the two N tiles of W5, waves 2, 3 those of W2 (16 x 64 each).
+// kind 2: waves 0, 1 hold the two M tiles of W3, waves 2, 3 those of W1 (64 x 32 each).
+__device__ __forceinline__ void fb_flush(float* __restrict__ red /* [4][16][64] */, const f32x16& acc, int w, int lane, int kind, float* __restrict__ dst /* this workgroup's [10240] */) {
+#pragma unroll
+	for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
+	__syncthreads();
+	// D[row = o in tile][col = i in tile]: lane = (col, g), register r -> row (r & 3) + 8 (r >> 2) + 4 g
+	for (int idx = threadIdx.x; idx < 4 * 16 * 64; idx += 256) {
+		const int t = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
+		const float v = red[idx];
+		const int row_in_tile = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col_in_tile = l & 31;
+		int o, i, n_out, n_in, off;
+		if (kind == 0)      { o = (t >> 1) * 32 + row_in_tile; i = (t & 1) * 32 + col_in_tile; n_out = 64; n_in = 64; off = (int)W4_OFF; }
+		else if (kind == 1) { o = row_in_tile; i = (t & 1) * 32 + col_in_tile; n_out = 16; n_in = 64; off = t < 2 ? (int)W5_OFF : (int)W2_OFF; }
+		else                { o = (t & 1) * 32 + row_in_tile; i = col_in_tile; n_out = 64; n_in = 32; off = t < 2 ? (int)W3_OFF : (int)W1_OFF; }
+		if (o < n_out && i < n_in) dst[off + o * n_in + i] = v;
+	}
+	__syncthreads();
+}
+
+__global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
+                                                                  const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                                  const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
+                                                                  h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
+	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_kernel
+	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
+
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
+	const uint32_t n_quads = n / 128;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
+	const f32x16 zero = {};
+	// 12 output tiles over 4 waves, each over all 128 samples of an iteration: W4 one tile per wave; waves 0 / 1 additionally the two tiles of W5
+	// and of W3, waves 2 / 3 those of W2 and of W1 (24 MFMAs per wave and iteration either way) — 48 accumulator registers per wave
+	f32x16 acc_w4 = zero, acc_a = zero /* W5 | W2 */, acc_b = zero /* W3 | W1 */;
+	const int col = w * 32 + j;
+	const bool low_pair = __builtin_amdgcn_readfirstlane(w) < 2;
+
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const uint32_t s = (quad * 4 + w) * 32 + j;
+		const float* c = coords + (size_t)s * coord_stride;
+		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
+		const h8 x0 = xs[0], x1 = xs[1];
+		const h8 sh = sh4_half(g, c[4], c[5], c[6]);
+		FwdActs a;
+		f32x16 dd, oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off)); // keep the LDS weight reads inside the loop
+		const h8* lt = lds_tiles + lt_off;
+		mlp_forward<false, true>(lt, lane, x0, x1, sh, dd, oo, &a);
+
+		const half_t* dl = dL_dout + (size_t)s * dl_stride;
+		h8 dout = {};
+		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; }
+		const half_t dsigma = dl[3];
+
+		// ---- W5: dY = dout (16 rows), H = h3
+		fb_put(stage, 0, MAP_CH, 0, g, col, dout);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 16, MAP_HID, kb, g, col, a.h3[kb]);
+		__syncthreads();
+		if (low_pair) fb_job_m1n2(stage, 0, 16, w, lane, acc_a);
+		// d_h3 = relu'(h3) * (W5^T dout)
+		f32x16 t0 = NGP_MFMA(lt[(T_W5T + 0) * 64 + lane], dout, zero);
+		f32x16 t1 = NGP_MFMA(lt[(T_W5T + 1) * 64 + lane], dout, zero);
+		h8 dh[4];
+		dh[0] = mask_delta(t0, 0, a.h3[0]); dh[1] = mask_delta(t0, 1, a.h3[1]);
+		dh[2] = mask_delta(t1, 0, a.h3[2]); dh[3] = mask_delta(t1, 1, a.h3[3]);
+		__syncthreads();
+
+		// ---- W4: dY = d_h3, H = h2
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) { fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]); fb_put(stage, 64, MAP_HID, kb, g, col, a.h2[kb]); }
+		__syncthreads();
+		fb_job_m2n2(stage, 0, 64, w, lane, acc_w4);
+		// d_h2 = relu'(h2) * (W4^T d_h3)
+		t0 = zero; t1 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) {
+			t0 = NGP_MFMA(lt[(T_W4T + kb) * 64 + lane], dh[kb], t0);
+			t1 = NGP_MFMA(lt[(T_W4T + 4 + kb) * 64 + lane], dh[kb], t1);
+		}
+		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
+		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
+		__syncthreads();
+
+		// ---- W3: dY = d_h2, H = rgb-net input [density out | SH]
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]);
+		fb_put(stage, 64, MAP_RGBIN, 0, g, col, a.rin[0]);
+		fb_put(stage, 64, MAP_RGBIN, 1, g, col, a.rin[1]);
+		__syncthreads();
+		if (low_pair) fb_job_m2n1(stage, 0, 64, w, lane, acc_b);
+		// d_in = W3^T d_h2 (rows 0..15 = density-net output gradient)
+		t0 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W3T + kb) * 64 + lane], dh[kb], t0);
+		h8 dden;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
+		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
+		__syncthreads();
+
+		// ---- W2: dY = d_dens (16 rows), H = h1
+		fb_put(stage, 0, MAP_RGBIN, 0, g, col, dden);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 16, MAP_HID, kb, g, col, a.h1[kb]);
+		__syncthreads();
+		if (!low_pair) fb_job_m1n2(stage, 0, 16, w - 2, lane, acc_a);
+		// d_h1 = relu'(h1) * (W2^T d_dens)
+		t0 = NGP_MFMA(lt[(T_W2T + 0) * 64 + lane], dden, zero);
+		t1 = NGP_MFMA(lt[(T_W2T + 1) * 64 + lane], dden, zero);
+		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
+		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
+		__syncthreads();
+
+		// ---- W1: dY = d_h1, H = x (the saved encoding)
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]);
+		{   // the encoding again (64 B per sample, an L2 hit): keeping x0 / x1 live through the chain costs 8 registers of a kernel that is at its limit
+			const h8* xr = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
+			uint32_t zero_off = 0;
+			asm volatile("" : "+v"(zero_off));
+			xr = (const h8*)((const char*)xr + zero_off);
+			fb_put(stage, 64, MAP_ENC, 0, g, col, xr[0]);
+			fb_put(stage, 64, MAP_ENC, 1, g, col, xr[1]);
+		}
+		__syncthreads();
+		if (!low_pair) fb_job_m2n1(stage, 0, 64, w - 2, lane, acc_b);
+		// d_x = W1^T d_h1
+		t0 = zero;
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W1T + kb) * 64 + lane], dh[kb], t0);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {   // row -> level mapping as in nerf_backward_kernel
+			const int lvl = 4 * q + 2 * g;
+			h2 u, v;
+			u[0] = (half_t)t0[4 * q + 0]; u[1] = (half_t)t0[4 * q + 1];
+			v[0] = (half_t)t0[4 * q + 2]; v[1] = (half_t)t0[4 * q + 3];
+			dx_planes[(size_t)lvl * n + s] = u;
+			dx_planes[(size_t)(lvl + 1) * n + s] = v;
+		}
+		__syncthreads();
+	}
+	// ---- this workgroup's partial weight gradients
+	float* __restrict__ dst = partials + (size_t)blockIdx.x * NGP_MLP_N_PARAMS;
+	float* red = (float*)stage;   // 4 x 16 x 64 floats = 16 KiB
+	fb_flush(red, acc_w4, w, lane, 0, dst);
+	fb_flush(red, acc_a, w, lane, 1, dst);
+	fb_flush(red, acc_b, w, lane, 2, dst);
+}
+
 // ================================================================================================================
 // Plumbing configs P1 / P2: ONE grid encoding (2-D or 3-D, 16 levels x 2 features) -> ONE FullyFusedMLP 32 -> 64 -> 64 -> 16
 // (tcnn NetworkWithInputEncoding as built by Testbed::reset_network for Image / Sdf mode, src/testbed.cu:2397-2445; configs/image/base.json,
@@ -1687,6 +1893,23 @@ int ngp_hip_nerf_backward_ctx(void* stream, const NgpNetDesc* desc_dev, const Ng
 	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
 	(void)desc_host;
+	static const int fused_env = getenv("NGP_HIP_BWD_FUSED") ? atoi(getenv("NGP_HIP_BWD_FUSED")) : 1;   // dev / A-B: 0 = the two-kernel path through the planes
+	if (fused_env) {
+		// dgrad + weight gradients in one kernel (no planes); its per-workgroup partials go where the planes would be
+		BackwardCtx* c = (BackwardCtx*)ctx;
+		const uint32_t n_quads = n / 128;
+		const uint32_t grid = n_quads < 512u ? n_quads : 512u;   // 2 resident workgroups per CU
+		float* fparts = (float*)scratch;
+		hipLaunchKernelGGL(nerf_backward_fused_kernel, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
+		                   dx_planes, fparts, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
+		NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
+		if (c) NGP_HIP_TRY(hipEventRecord(c->ev_fork, st));
+		hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)fparts, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
+		NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
+		if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
+		return 0;
+	}
 	const char* abl = getenv("NGP_HIP_BWD_ABLATE"); // dev-only timing ablations (tools/microbench.py); unset in production
 	const int ablate = abl ? atoi(abl) : 0;
 #define NGP_LAUNCH_BWD(A) hipLaunchKernelGGL(nerf_backward_kernel<A>, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, \

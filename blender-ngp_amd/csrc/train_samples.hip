@@ -676,7 +676,11 @@ static int generate_training_samples_impl(
 	if (mode_env) march_mode = (uint32_t)mode_env;
 	if (cone_angle_constant == 0.0f && march_mode != NGP_MARCH_LANE_PER_RAY) {
 		// all workgroups resident at once (4 per CU): the kernel has the chip to itself in this mode
-		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = 4096u;
+		// NGP_MARCH_WAVE_PER_RAY: all workgroups resident at once (the kernel has the chip to itself).  NGP_MARCH_WAVE_PER_RAY_SHARED: two persistent
+		// workgroups per CU — beside the step's backward pass every further march wave costs that pass more than it gains the march
+		// (sweep 192 ... 4096 workgroups: step 0.75 / 0.61 at 512 / 0.64 ms)
+		static const uint32_t wg_cap_env = getenv("NGP_HIP_GEN_WGS") ? (uint32_t)atoi(getenv("NGP_HIP_GEN_WGS")) : 0u;   // dev: sweep
+		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 512u : 4096u);
 		hipLaunchKernelGGL(generate_training_samples_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
 		NGP_LAUNCH_CHECK("generate_training_samples_wave_kernel");
 		return 0;
@@ -710,7 +714,7 @@ extern "C" int ngp_hip_generate_training_samples_mode(
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
 	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode) {
-	if (march_mode > NGP_MARCH_WAVE_PER_RAY) { set_last_error("ngp_hip_generate_training_samples_mode: unknown march_mode", hipErrorInvalidValue); return -1; }
+	if (march_mode > NGP_MARCH_WAVE_PER_RAY_SHARED) { set_last_error("ngp_hip_generate_training_samples_mode: unknown march_mode", hipErrorInvalidValue); return -1; }
 	return generate_training_samples_impl(stream, n_rays, aabb_host, max_samples, rng_state, rng_inc, ray_counter, numsteps_counter, ray_indices_out, rays_out_unnormalized, numsteps_out,
 	                                      coords_out, n_training_images, metadata, xforms, density_grid, max_level_rand_training, max_level_ptr, snap_to_pixel_centers, train_envmap,
 	                                      cone_angle_constant, distortion_data, distortion_resolution_host, ray_offset, n_rays_global, cdf_host, brick_summary, march_mode);

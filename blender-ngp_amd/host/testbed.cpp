@@ -650,15 +650,15 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
 	NgpErrorMapCdf cdf_storage;
 	profile_begin(PK_GEN_SAMPLES, stream);
-	// run ahead on stream B the march shares the chip with the backward pass: the lane-per-ray kernels are latency-bound and cost it ~20 us; the
-	// wave-per-ray kernel is 3x faster on its own but takes twice the issue slots (measured: no gain beside the backward).  In stream order
-	// (first steps, the step after every occupancy update, a discarded prefetch) nothing runs beside it: wave-per-ray
+	// run ahead on stream B the march shares the chip with the backward pass: the wave-per-ray kernel on two workgroups per CU (more of it costs the
+	// backward pass more than it gains the march).  In stream order (first steps, the step after every occupancy update, a discarded prefetch)
+	// nothing runs beside it: all workgroups at once.  With cone stepping the library runs its lane-per-ray kernels whatever the mode
 	check(ngp_hip_generate_training_samples_mode(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
 	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
 	                                        m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr,
-	                                        next_to_backward ? NGP_MARCH_LANE_PER_RAY : NGP_MARCH_WAVE_PER_RAY), "generate_training_samples");
+	                                        next_to_backward ? NGP_MARCH_WAVE_PER_RAY_SHARED : NGP_MARCH_WAVE_PER_RAY), "generate_training_samples");
 	profile_end(PK_GEN_SAMPLES, R, stream);
 }
 

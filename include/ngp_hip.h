@@ -192,10 +192,11 @@ int ngp_hip_generate_training_samples(
 /* The same call with the marching kernel chosen by the caller (same rays, same samples, bit for bit; slot order aside):
  *   NGP_MARCH_AUTO          what ngp_hip_generate_training_samples does: wave-per-ray whenever cone_angle_constant == 0
  *   NGP_MARCH_LANE_PER_RAY  one lane per ray + a wave-per-ray expansion kernel: a latency-bound serial chain (~330 us at 2^14 rays) that costs
- *                           few issue slots — the one to run NEXT TO other kernels (the Testbed's run-ahead march beside the backward pass)
+ *                           few issue slots; the only kernels for cone stepping (cone_angle_constant != 0)
  *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once on the closed-form step sequence (cone_angle_constant == 0 only, otherwise
- *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order */
-enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2 };
+ *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order
+ *   NGP_MARCH_WAVE_PER_RAY_SHARED  the same kernel on two persistent workgroups per CU (~220 us): the one to run NEXT TO the backward pass */
+enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2, NGP_MARCH_WAVE_PER_RAY_SHARED = 3 };
 int ngp_hip_generate_training_samples_mode(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,

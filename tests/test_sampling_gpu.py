@@ -170,7 +170,7 @@ def _compare_per_ray(r, g, exact_rays=True):
         assert r["co"][br:br + nr].tobytes() == g["co"][bg:bg + ng].tobytes(), ray
 
 
-@pytest.mark.parametrize("march_mode", [1, 2])
+@pytest.mark.parametrize("march_mode", [1, 2, 3])
 @pytest.mark.parametrize("brick_summary", [False, True])
 def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda, brick_summary, march_mode):
     r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=1, cone_angle=0.0, distortion=True, brick_summary=brick_summary, march_mode=march_mode)
