@@ -292,8 +292,6 @@ def main():
     B = 1 << 18
     ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
     tb = scene.build_testbed(ds)
-    if os.environ.get("BENCH_MARCH_EARLY"):   # dev: the run-ahead march right behind the counters instead of behind the dgrad kernel
-        tb.march_after_dgrad = False
     if os.environ.get("BENCH_NO_PREFETCH"):   # dev: the march in stream order, i.e. uncontended (its in-situ stand-alone time)
         tb.prefetch_samples = False
     tb.async_training_steps = True   # frame() without the reference's per-step stream drain (pyngp property; the timed region is still bracketed by syncs)

@@ -441,19 +441,7 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Activation / delta planes written by the backward kernel for the weight-gradient kernel: plane[row][sample] fp16.
-constexpr int P_DOUT = 0;    // 16 rows (channel)
-constexpr int P_H3 = 16;     // 64
-constexpr int P_DH3 = 80;    // 64
-constexpr int P_H2 = 144;    // 64
-constexpr int P_DH2 = 208;   // 64
-constexpr int P_RIN = 272;   // 32
-constexpr int P_DDENS = 304; // 16
-constexpr int P_H1 = 320;    // 64
-constexpr int P_DH1 = 384;   // 64
-constexpr int P_X = 448;     // 32
-constexpr int N_PLANE_ROWS = 480;
-
+// Activation / delta planes [row][sample] fp16 between a backward kernel and nerf_wgrad_kernel (the GridMLP path; the NeRF backward contracts in-kernel)
 __device__ __forceinline__ void store_plane(half_t* __restrict__ planes, uint32_t n, int row0, int map, int kb, int g, uint32_t s, const h8& v) {
 #pragma unroll
 	for (int e = 0; e < 8; ++e) *(half_t*)((char*)planes + (size_t)((((uint32_t)(row0 + slot_feature(map, kb, g, e))) * n + s) * 2u)) = v[e];
@@ -960,112 +948,9 @@ __global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __r
 
 #pragma clang fp contract(fast)
 
-// Backward kernel: recompute forward from the saved encoding, dgrad chain, dL/dx planes + activation planes.  n % 32 == 0.
-template <int ABLATE> // dev-only ablation switch (bit0: no dL/dx store, bit1: no plane stores); the product path launches <0>
-__global__ void __launch_bounds__(256, 2) nerf_backward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
-                                                            const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                            const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
-                                                            h2* __restrict__ dx_planes, half_t* __restrict__ planes, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
-	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
-	// the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;
-	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
-
-	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-	const uint32_t n_tiles = n / 32;
-	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-	const f32x16 zero = {};
-
-	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-		const uint32_t s = tile * 32 + j;
-		const float* c = coords + (size_t)s * coord_stride;
-		const float px = c[0], py = c[1], pz = c[2];
-		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
-		const h8 x0 = xs[0], x1 = xs[1];
-		const h8 sh = sh4_half(g, c[4], c[5], c[6]);
-		FwdActs a;
-		f32x16 dd, oo;
-		uint32_t lt_off = 0;
-		asm volatile("" : "+s"(lt_off)); // keep the LDS weight reads inside the loop
-		const h8* lt = lds_tiles + lt_off;
-		mlp_forward<false, true>(lt, lane, x0, x1, sh, dd, oo, &a);
-
-		// dL/dout -> B operand (MAP_CH): channels 0..2 live on g == 0, e = 0..2
-		const half_t* dl = dL_dout + (size_t)s * dl_stride;
-		h8 dout = {};
-		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; }
-		const half_t dsigma = dl[3];
-
-		// rgb net, output layer:   d_h3 = relu'(h3) * (W5^T dout)
-		f32x16 t0 = NGP_MFMA(lt[(T_W5T + 0) * 64 + lane], dout, zero);
-		f32x16 t1 = NGP_MFMA(lt[(T_W5T + 1) * 64 + lane], dout, zero);
-		h8 dh[4];
-		dh[0] = mask_delta(t0, 0, a.h3[0]); dh[1] = mask_delta(t0, 1, a.h3[1]);
-		dh[2] = mask_delta(t1, 0, a.h3[2]); dh[3] = mask_delta(t1, 1, a.h3[3]);
-		if (!(ABLATE & 2)) store_plane(planes, n, P_DOUT, MAP_CH, 0, g, s, dout);
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H3, MAP_HID, kb, g, s, a.h3[kb]); store_plane(planes, n, P_DH3, MAP_HID, kb, g, s, dh[kb]); } }
-
-		// hidden layer: d_h2 = relu'(h2) * (W4^T d_h3)
-		t0 = zero; t1 = zero;
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) {
-			t0 = NGP_MFMA(lt[(T_W4T + kb) * 64 + lane], dh[kb], t0);
-			t1 = NGP_MFMA(lt[(T_W4T + 4 + kb) * 64 + lane], dh[kb], t1);
-		}
-		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
-		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, P_DH2, MAP_HID, kb, g, s, dh[kb]); } }
-		if (!(ABLATE & 2)) store_plane(planes, n, P_RIN, MAP_RGBIN, 0, g, s, a.rin[0]);
-		if (!(ABLATE & 2)) store_plane(planes, n, P_RIN, MAP_RGBIN, 1, g, s, a.rin[1]);
-
-		// input layer of the rgb net: d_in = W3^T d_h2 (rows 0..15 = density-net output gradient)
-		t0 = zero;
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W3T + kb) * 64 + lane], dh[kb], t0);
-		h8 dden;
-#pragma unroll
-		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
-		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
-		if (!(ABLATE & 2)) store_plane(planes, n, P_DDENS, MAP_RGBIN, 0, g, s, dden);
-
-		// density net: d_h1 = relu'(h1) * (W2^T d_dens);  d_x = W1^T d_h1
-		t0 = NGP_MFMA(lt[(T_W2T + 0) * 64 + lane], dden, zero);
-		t1 = NGP_MFMA(lt[(T_W2T + 1) * 64 + lane], dden, zero);
-		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
-		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { if (!(ABLATE & 2)) { store_plane(planes, n, P_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, P_DH1, MAP_HID, kb, g, s, dh[kb]); } }
-		if (!(ABLATE & 2)) store_plane(planes, n, P_X, MAP_ENC, 0, g, s, x0);
-		if (!(ABLATE & 2)) store_plane(planes, n, P_X, MAP_ENC, 1, g, s, x1);
-
-		t0 = zero;
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W1T + kb) * 64 + lane], dh[kb], t0);
-
-		// t0 row = x feature (r&3)+8(r>>2)+4g  =>  this lane owns levels 4q+2g (regs 4q,4q+1) and 4q+2g+1 (regs 4q+2,4q+3), q = 0..3.
-		// dL/dx goes out in fp16 as per-level planes [level][sample] (coalesced 128 B per half-wave) for grid_backward_kernel.
-		if (!(ABLATE & 1)) {
-#pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const int lvl = 4 * q + 2 * g;
-				h2 a, b;
-				a[0] = (half_t)t0[4 * q + 0]; a[1] = (half_t)t0[4 * q + 1];
-				b[0] = (half_t)t0[4 * q + 2]; b[1] = (half_t)t0[4 * q + 3];
-				dx_planes[(size_t)lvl * n + s] = a;
-				dx_planes[(size_t)(lvl + 1) * n + s] = b;
-			}
-		}
-	}
-}
-
-
-
 // ----------------------------------------------------------------------------------------------------------------
-// Fused backward: the same dgrad chain PLUS the weight-gradient contraction in one kernel, so that the [480][n] activation / delta planes
-// (0.25 GB written and read back per step) never exist.  The contraction dW[o][i] = sum_s dY[o][s] * H[i][s] runs over SAMPLES, i.e. the MFMA
+// Backward: recompute the MLPs from the saved encoding, dgrad chain (dL/dx planes for the hash-grid backward) PLUS the weight-gradient
+// contraction in the same kernel, so that no [480][n] activation / delta planes (0.25 GB written and read back per step) exist.  The contraction dW[o][i] = sum_s dY[o][s] * H[i][s] runs over SAMPLES, i.e. the MFMA
 // operands must hold 8 consecutive samples of one feature per lane, while the chain keeps 8 features of one sample per lane: a transpose.
 // It goes through LDS, one layer at a time: the 4 waves of the workgroup write the two operand matrices of the layer for their 4 x 32 samples
 // as [feature][128 samples] fp16 rows (2-byte scattered writes, 272-byte row pitch), and read them back as 16-byte K-blocks that ARE the A / B
@@ -1142,7 +1027,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
                                                                   h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_kernel
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
 	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
@@ -1249,8 +1134,10 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 		t0 = zero;
 #pragma unroll
 		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W1T + kb) * 64 + lane], dh[kb], t0);
+		// t0 row = x feature (r&3)+8(r>>2)+4g  =>  this lane owns levels 4q+2g (regs 4q,4q+1) and 4q+2g+1 (regs 4q+2,4q+3), q = 0..3.
+		// dL/dx goes out in fp16 as per-level planes [level][sample] (coalesced 128 B per half-wave) for grid_backward_kernel.
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {   // row -> level mapping as in nerf_backward_kernel
+		for (int q = 0; q < 4; ++q) {
 			const int lvl = 4 * q + 2 * g;
 			h2 u, v;
 			u[0] = (half_t)t0[4 * q + 0]; u[1] = (half_t)t0[4 * q + 1];
@@ -1449,33 +1336,25 @@ __global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* 
 // ----------------------------------------------------------------------------------------------------------------
 // Weight gradients: dW[o][i] = sum_s dY[o][s] * H[i][s].  Contraction over samples: both operands are read straight from
 // the [row][sample] planes (64 B per lane per 64-sample step, a full 128-B line per row), K-slot <-> sample mapping is
-// identical for A and B so it never has to be made explicit.  6 balanced jobs (2 output tiles, 3 operand row groups each):
-//   0: W4 rows 0..31   1: W4 rows 32..63   2: W5   3: W2   4: W3 (both row tiles)   5: W1 (both row tiles)
+// identical for A and B so it never has to be made explicit.  Jobs of 2 output tiles and 3 operand row groups each.
 struct WgradJob { int dy_row, dy_rows, h_row, h_rows, w_off, n_in, two_mt; int mt0; };
 template <int NET>
 __device__ __forceinline__ WgradJob wgrad_job(int job) {
-	if (NET == 1) {   // GridMLP: 0/1: hidden layer rows 0..31 / 32..63, 2: output layer, 3: input layer (both row tiles)
-		switch (job) {
-			case 0: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 0};
-			case 1: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 1};
-			case 2: return {GP_DOUT, 16, GP_H2, 64, (int)GM_L2_OFF, 64, 0, 0};
-			default: return {GP_DH1, 64, GP_X, 32, (int)GM_L0_OFF, 32, 1, 0};
-		}
-	}
+	// GridMLP: 0/1: hidden layer rows 0..31 / 32..63, 2: output layer, 3: input layer (both row tiles)
 	switch (job) {
-		case 0: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 0};
-		case 1: return {P_DH3, 64, P_H2, 64, (int)W4_OFF, 64, 0, 1};
-		case 2: return {P_DOUT, 16, P_H3, 64, (int)W5_OFF, 64, 0, 0};
-		case 3: return {P_DDENS, 16, P_H1, 64, (int)W2_OFF, 64, 0, 0};
-		case 4: return {P_DH2, 64, P_RIN, 32, (int)W3_OFF, 32, 1, 0};
-		default: return {P_DH1, 64, P_X, 32, (int)W1_OFF, 32, 1, 0};
+		case 0: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 0};
+		case 1: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 1};
+		case 2: return {GP_DOUT, 16, GP_H2, 64, (int)GM_L2_OFF, 64, 0, 0};
+		default: break;
 	}
+	return {GP_DH1, 64, GP_X, 32, (int)GM_L0_OFF, 32, 1, 0};
 }
 
 // grid (n_chunks, 6); block 256 = 4 waves; wave w handles samples [chunk*chunk_len + w*chunk_len/4, ...) in steps of 64.
 template <int NET>
 __global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restrict__ planes, uint32_t n, uint32_t chunk_len, float* __restrict__ partials /* [n_chunks][n_mlp_params] */) {
-	constexpr uint32_t N_MLP = NET == 1 ? NGP_GRIDMLP_N_PARAMS : NGP_MLP_N_PARAMS;
+	constexpr uint32_t N_MLP = NGP_GRIDMLP_N_PARAMS;
+	static_assert(NET == 1, "the planes path serves the GridMLP network; the NeRF backward contracts in-kernel");
 	__shared__ float red[4][2][16][64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, g = lane >> 5;
 	const WgradJob jb = wgrad_job<NET>(blockIdx.y);
@@ -1836,9 +1715,9 @@ static uint32_t wgrad_chunks(uint32_t n) {
 	return n / chunk_len;
 }
 
-// scratch layout: [activation planes 480 x n fp16][wgrad partials chunks x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 4 MiB][binned path: counters, item lists, run sums]
-static uint64_t scratch_off_wgrad(uint32_t n) { return (uint64_t)N_PLANE_ROWS * n * 2u; }
-static uint64_t scratch_off_dx(uint32_t n) { return scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_MLP_N_PARAMS * 4u; }
+// scratch layout: [weight-gradient partials 512 x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 4 MiB][binned path: counters, item lists, run sums]
+constexpr uint32_t FB_MAX_WORKGROUPS = 512;   // two resident workgroups per CU
+static uint64_t scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS * 4u; }
 static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
 static uint64_t gb_fx_bytes(uint32_t n) { return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u); }   // counters + item lists + run sums of the binned path
 static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
@@ -1847,107 +1726,30 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
-	return ngp_hip_nerf_backward_ctx(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr);
+	return ngp_hip_nerf_backward_ev(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr);
 }
 
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
-	return ngp_hip_nerf_backward_ctx(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event, nullptr);
-}
-
-// Scheduling context of the backward pass: a side stream and its fork / join events, owned by ONE caller (one per Testbed, on that Testbed's
-// device) — not process state, so two hosts on different threads or devices never share an event pair.
-struct BackwardCtx { hipStream_t side = nullptr; bool own_side = false; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
-
-void* ngp_hip_backward_ctx_create(void* side_stream) {
-	BackwardCtx* c = new BackwardCtx();
-	c->side = (hipStream_t)side_stream;
-	hipError_t e = hipSuccess;
-	if (!c->side) { e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking); c->own_side = e == hipSuccess; }
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventReleaseToDevice);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventReleaseToDevice);
-	if (e != hipSuccess) { set_last_error("ngp_hip_backward_ctx_create", e); ngp_hip_backward_ctx_destroy(c); return nullptr; }
-	return c;
-}
-
-void ngp_hip_backward_ctx_destroy(void* ctx) {
-	BackwardCtx* c = (BackwardCtx*)ctx;
-	if (!c) return;
-	if (c->side) { (void)hipStreamSynchronize(c->side); if (c->own_side) (void)hipStreamDestroy(c->side); }
-	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-	if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-	delete c;
-}
-
-void* ngp_hip_backward_ctx_dgrad_event(void* ctx) { return ctx ? (void*)((BackwardCtx*)ctx)->ev_fork : nullptr; }
-
-int ngp_hip_nerf_backward_ctx(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event, void* ctx) {
+                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
 	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
-	half_t* planes = (half_t*)scratch;
-	float* partials = (float*)((char*)scratch + scratch_off_wgrad(n));
+	float* partials = (float*)scratch;
 	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
 	(void)desc_host;
-	static const int fused_env = getenv("NGP_HIP_BWD_FUSED") ? atoi(getenv("NGP_HIP_BWD_FUSED")) : 1;   // dev / A-B: 0 = the two-kernel path through the planes
-	if (fused_env) {
-		// dgrad + weight gradients in one kernel (no planes); its per-workgroup partials go where the planes would be
-		BackwardCtx* c = (BackwardCtx*)ctx;
-		const uint32_t n_quads = n / 128;
-		const uint32_t grid = n_quads < 512u ? n_quads : 512u;   // 2 resident workgroups per CU
-		float* fparts = (float*)scratch;
-		hipLaunchKernelGGL(nerf_backward_fused_kernel, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-		                   dx_planes, fparts, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
-		NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
-		if (c) NGP_HIP_TRY(hipEventRecord(c->ev_fork, st));
-		hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)fparts, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
-		NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
-		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
-		if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
-		return 0;
-	}
-	const char* abl = getenv("NGP_HIP_BWD_ABLATE"); // dev-only timing ablations (tools/microbench.py); unset in production
-	const int ablate = abl ? atoi(abl) : 0;
-#define NGP_LAUNCH_BWD(A) hipLaunchKernelGGL(nerf_backward_kernel<A>, dim3(fwd_grid(n)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, \
-	                   (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4))
-	if (ablate == 1) NGP_LAUNCH_BWD(1); else if (ablate == 2) NGP_LAUNCH_BWD(2); else if (ablate == 3) NGP_LAUNCH_BWD(3); else NGP_LAUNCH_BWD(0);
-#undef NGP_LAUNCH_BWD
-	NGP_LAUNCH_CHECK("nerf_backward_kernel");
-	// With a context: the weight gradients (MFMA / HBM streaming) run on the context's side stream next to the hash-grid backward (LDS atomics,
-	// index ALU).  Both only read what the dgrad kernel wrote and write disjoint parts of `grads`; the caller's stream waits for the side stream
-	// before this call's work counts as done.  Step +1.7 %.  The side stream should be created by the host next to its own streams: one created
-	// late can share a hardware queue with the host's march stream, and the march then waits behind the weight gradients (365 -> 294 M samples/s).
-	BackwardCtx* c = (BackwardCtx*)ctx;
-	static const int fork_env = getenv("NGP_HIP_BWD_FORK") ? atoi(getenv("NGP_HIP_BWD_FORK")) : -1;   // dev: 0 keeps everything in stream order
-	const bool fork = c && fork_env != 0;
-	hipStream_t wst = st;
-	if (c) NGP_HIP_TRY(hipEventRecord(c->ev_fork, st));   // "dgrad done" (ngp_hip_backward_ctx_dgrad_event)
-	if (fork) {
-		NGP_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-		wst = c->side;
-	}
-	const uint32_t n_chunks = wgrad_chunks(n);
-	if (fork) {
-		hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, wst, (const half_t*)planes, n, n / n_chunks, partials);
-		NGP_LAUNCH_CHECK("nerf_wgrad_kernel (side stream)");
-		hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, wst, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
-		NGP_LAUNCH_CHECK("wgrad_reduce_kernel (side stream)");
-		NGP_HIP_TRY(hipEventRecord(c->ev_join, wst));
-	}
-	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
-	if (!(ablate & 4)) {
-		if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
-	}
-	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
-	if (fork) { NGP_HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); return 0; }
-	hipLaunchKernelGGL(nerf_wgrad_kernel<0>, dim3(n_chunks, 6), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
-	NGP_LAUNCH_CHECK("nerf_wgrad_kernel");
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
+	const uint32_t n_quads = n / 128;
+	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
+	hipLaunchKernelGGL(nerf_backward_fused_kernel, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
+	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
+	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
+	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
+	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
+	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
 

@@ -370,7 +370,6 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property("autofocus_target", [](Testbed& t) { py::array_t<float> a(3); for (int i = 0; i < 3; ++i) a.mutable_data()[i] = t.m_autofocus_target[i]; return a; },
 			[](Testbed& t, const std::vector<float>& v) { if (v.size() != 3) throw std::runtime_error{"autofocus_target takes 3 floats"}; for (int i = 0; i < 3; ++i) t.m_autofocus_target[i] = v[i]; })
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
-		.def_readwrite("march_after_dgrad", &Testbed::m_march_after_dgrad)   // scheduling only: hold the run-ahead march back until the step's dgrad kernel is through
 		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
 		.def("training_prep_nerf", &Testbed::training_prep_nerf, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size") = 0)

@@ -207,11 +207,6 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	hipStream_t st, st_b;
 	HIP_CHECK_THROW(hipStreamCreate(&st));
 	HIP_CHECK_THROW(hipStreamCreate(&st_b));
-	{   // the backward's side stream, created right behind the two step streams: three consecutive streams land on three hardware queues
-		hipStream_t st_c; HIP_CHECK_THROW(hipStreamCreate(&st_c)); m_stream_c = st_c;
-		m_bwd_ctx = ngp_hip_backward_ctx_create(m_stream_c);
-		if (!m_bwd_ctx) throw std::runtime_error{std::string{"ngp_hip_backward_ctx_create failed: "} + ngp_hip_last_error()};
-	}
 	m_stream = st; m_stream_b = st_b;
 	m_nerf.training.owner = this;
 	m_rng = Pcg32(m_seed);
@@ -229,8 +224,6 @@ Testbed::~Testbed() {
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
-	if (m_bwd_ctx) ngp_hip_backward_ctx_destroy(m_bwd_ctx);   // drains the side stream
-	if (m_stream_c) (void)hipStreamDestroy((hipStream_t)m_stream_c);
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
 
@@ -688,10 +681,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 		if (!m_counters_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream)); m_counters_event_recorded = true; }
 		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_counters_event, 0));
 	}
-	// the wave-per-ray march is a full-width VALU kernel: next to the step's dgrad kernel (256 registers, two waves per SIMD) it takes a
-	// resident wave away from every SIMD it lands on (dgrad 94 -> 143 us).  Held back until that kernel is through it overlaps the hash-grid
-	// backward and the optimizer instead
-	if (m_march_after_dgrad && m_dgrad_event_recorded) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)ngp_hip_backward_ctx_dgrad_event(m_bwd_ctx), 0));
+	// (holding the march back until the step's MLP backward kernel is through was measured: no gain, 0.587 -> 0.593 ms)
 	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng, true);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
@@ -838,9 +828,9 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
-	check(ngp_hip_nerf_backward_ctx(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                                OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_want_grid_grad_event ? m_grid_grad_event : nullptr, m_bwd_ctx), "nerf_backward");
-	m_dgrad_event_recorded = true;
+	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
+	                               m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
 	m_grid_grad_event_recorded = m_want_grid_grad_event;
 	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)

@@ -357,10 +357,7 @@ public:
 	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
 	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
-	void* m_stream_c = nullptr;                        // side stream of the forked backward
-	void* m_bwd_ctx = nullptr;                         // ngp_hip_backward_ctx_create(m_stream_c): this Testbed's fork / join / dgrad-done events
-	bool m_march_after_dgrad = false;                  // the run-ahead march starts once the step's dgrad kernel is through (see maybe_prefetch_next)
-	bool m_dgrad_event_recorded = false, m_counters_host_seen = true;
+	bool m_counters_host_seen = true;                  // the host polled the counters of the step begun last (else the run-ahead march waits for the counters event)
 	bool m_async_training_steps = false;              // frame() returns with the step's tail (backward, optimizer) still running on the stream
 	std::chrono::steady_clock::time_point m_last_step_return{};
 	bool m_profile_enabled = false;

@@ -131,28 +131,14 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes);
-/* Same; additionally records `grid_gradients_event` (a hipEvent_t, may be NULL) on the stream once the hash-grid part of `grads`
- * (everything behind the first 10240 MLP parameters) is final — the MLP weight gradients follow.  A data-parallel host starts the
- * all-reduce of the 24 MB grid slice on another stream at that point instead of after the whole call. */
+/* Same; additionally records up to two caller-owned hipEvent_t's (either may be NULL) on the stream:
+ *   mlp_done_event        right behind the fused MLP kernel (dgrad + weight gradients; the 256-register kernel of the pass) — a host that runs
+ *                         other work next to the backward can hold that work back until this kernel is through;
+ *   grid_gradients_event  once all of `grads` is final (the MLP part is final one small kernel after mlp_done_event, the hash-grid part — everything
+ *                         behind the first 10240 parameters — last): a data-parallel host starts its all-reduce on another stream at that point. */
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event);
-/* Scheduling context of the backward pass, owned by one caller (one per host object and device; nothing here is process state).
- * create(side_stream): `side_stream` is a hipStream_t of the caller, or NULL for one the context creates on the current device.  HIP
- * multiplexes streams onto a few hardware queues in creation order: a host with further streams of its own (the Testbed's march stream)
- * creates the side stream right next to them, so that the weight-gradient kernels do not land in front of its latency-critical work on a
- * shared queue.  Returns an opaque handle, NULL on failure (ngp_hip_last_error).  destroy() drains the side stream first. */
-void* ngp_hip_backward_ctx_create(void* side_stream);
-void ngp_hip_backward_ctx_destroy(void* ctx);
-/* hipEvent_t of the context that every ngp_hip_nerf_backward_ctx call records on its stream right behind the dgrad kernel (the 256-register
- * kernel of the pass): a host that runs other work next to the backward can hold that work back until this kernel is through. */
-void* ngp_hip_backward_ctx_dgrad_event(void* ctx);
-/* ngp_hip_nerf_backward_ev with a context (may be NULL = ngp_hip_nerf_backward_ev): the MLP weight-gradient kernels run on the context's side
- * stream, concurrently with the hash-grid backward, and the caller's stream waits for them before the call's work counts as done.  Same
- * results bit for bit; a scheduling option. */
-int ngp_hip_nerf_backward_ctx(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event, void* ctx);
+                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event);
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */

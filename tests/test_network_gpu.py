@@ -154,9 +154,10 @@ def test_backward_linearity(ngp, cuda):
     assert den > 0 and num / den < 2e-2, (num, den)
 
 
-def test_backward_fork_option_is_bit_identical(ngp, cuda):
-    """ngp_hip_nerf_backward_ctx: weight-gradient kernels on the context's side stream, concurrent with the hash-grid backward — same bits,
-    also when calls follow each other without a host sync (the scratch planes of call k+1 must not overtake the side stream of call k)."""
+def test_backward_back_to_back_calls_and_events(ngp, cuda):
+    """ngp_hip_nerf_backward_ev: calls that follow each other without a host sync share one scratch (the partials / planes of call k + 1 must not
+    overtake the reduce of call k — everything is stream-ordered), with and without the two optional events: same bits."""
+    import torch
     n = 1 << 16
     desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=19, n=n, grid_amp=0.5)
     rs = np.random.RandomState(5)
@@ -166,17 +167,19 @@ def test_backward_fork_option_is_bit_identical(ngp, cuda):
     scratch = H.dev_zeros(sb, cuda)
     dls = [H.to_dev((rs.randn(n, 4) * 0.01).astype(np.float16), cuda) for _ in range(3)]
     res = {}
-    ctx = ngp.ngp_hip_backward_ctx_create(None)   # its own side stream
-    assert ctx and ngp.ngp_hip_backward_ctx_dgrad_event(ctx)
-    try:
-        for fork in (0, 1):
-            gs = [H.dev_zeros(H.n_params(desc) * 2, cuda) for _ in dls]
-            for d_dl, g in zip(dls, gs):   # back to back, no sync in between
-                check(ngp.ngp_hip_nerf_backward_ctx(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
-                                                    g.data_ptr(), scratch.data_ptr(), sb, None, ctx if fork else None))
-            res[fork] = [H.to_host(g, np.uint16) for g in gs]
-    finally:
-        ngp.ngp_hip_backward_ctx_destroy(ctx)
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    for e in evs:
+        e.record()   # materialises the hipEvent_t
+    for with_events in (0, 1):
+        gs = [H.dev_zeros(H.n_params(desc) * 2, cuda) for _ in dls]
+        for d_dl, g in zip(dls, gs):   # back to back, no sync in between
+            check(ngp.ngp_hip_nerf_backward_ev(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                               g.data_ptr(), scratch.data_ptr(), sb, evs[0].cuda_event if with_events else None, evs[1].cuda_event if with_events else None))
+        if with_events:
+            evs[1].synchronize()   # "all of grads final" of the last call
+            res[with_events] = [H.to_host(g, np.uint16) for g in gs]
+        else:
+            res[with_events] = [H.to_host(g, np.uint16) for g in gs]
     for a, b in zip(res[0], res[1]):
         assert np.any(a[:10240] != 0) and np.any(a[10240:] != 0)
         np.testing.assert_array_equal(a, b)
