@@ -69,7 +69,7 @@ def build_host(force=False, verbose=False):
     srcs = [os.path.join(HOST, s) for s in HOST_SOURCES]
     deps = srcs + [os.path.join(HOST, h) for h in os.listdir(HOST) if h.endswith(".h")] + [os.path.join(ROOT, "include", "ngp_hip.h"), lib]
     if force or _newer(deps, out):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__",
+        cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__",
                "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROCM, "include")] + srcs + ["-o", out, "-L" + LIBDIR, "-lngp_hip", "-L" + os.path.join(ROCM, "lib"),
                "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"]

@@ -352,6 +352,10 @@ void Decoder::finish(int& w, int& h, std::vector<uint8_t>& rgba) {
 					const int sx = std::min(x >> 1, cw - 1), ox = std::min(cw - 1, std::max(0, (x & 1) ? sx + 1 : sx - 1));
 					dst[x] = (uint8_t)((3 * vrow[(size_t)sx] + vrow[(size_t)ox] + 8) >> 4);
 				}
+				// stb_image's row resampler for horizontally-only subsampled chroma (stbi__resample_row_h_2, what the reference decodes 4:2:2 files
+				// with) weights the LAST pair the other way round: 3 * in[w-2] + in[w-1] at the even position.  Mirrored, so that a training pixel in
+				// that column is the one the reference sees.
+				if (vs == 1 && cw >= 2 && 2 * (cw - 1) < width) dst[2 * (cw - 1)] = (uint8_t)((3 * vrow[(size_t)cw - 2] + vrow[(size_t)cw - 1] + 8) >> 4);
 			} else {
 				for (int x = 0; x < width; ++x) dst[x] = (uint8_t)((vrow[(size_t)std::min(x, cw - 1)] + 2) >> 2);
 			}

@@ -1,17 +1,38 @@
 #include "nerf_loader.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
-#include <filesystem>
+#include <fstream>
 #include <future>
 
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include "image_io.h"
 #include "mini_json.h"
 #include "png_reader.h"
-
-namespace fs = std::filesystem;
+#include "snapshot.h"
 
 namespace ngp {
+
+// ---- the few path operations the loader needs (the reference uses wjakob's filesystem::path; plain POSIX here, C++14)
+static bool path_exists(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+static bool path_is_directory(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+static bool path_is_file(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+static std::string path_parent(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? std::string(".") : (k == 0 ? std::string("/") : p.substr(0, k)); }
+static std::string path_filename(const std::string& p) { const size_t k = p.find_last_of('/'); return k == std::string::npos ? p : p.substr(k + 1); }
+static std::string path_extension(const std::string& p) {   // without the dot, like filesystem::path::extension()
+	const std::string f = path_filename(p); const size_t k = f.find_last_of('.');
+	return (k == std::string::npos || k == 0) ? std::string() : f.substr(k + 1);
+}
+static std::string path_basename(const std::string& p) { const std::string f = path_filename(p); const size_t k = f.find_last_of('.'); return (k == std::string::npos || k == 0) ? f : f.substr(0, k); }
+static std::string path_with_extension(const std::string& p, const std::string& ext) {
+	const std::string dir = path_parent(p), base = path_basename(p);
+	return (p.find('/') == std::string::npos ? std::string() : dir + "/") + base + "." + ext;
+}
+static std::string path_join(const std::string& a, const std::string& b) { if (!b.empty() && b[0] == '/') return b; return a + "/" + b; }
 
 static const float PI_F = 3.14159265358979323846f;
 static float fov_to_focal_length(int resolution, float degrees) { return 0.5f * (float)resolution / tanf(0.5f * degrees * PI_F / 180); }  // common_device.cuh:473-475
@@ -20,11 +41,16 @@ static std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.b
 
 std::vector<std::string> resolve_nerf_json_paths(const std::string& data_path) {  // testbed_nerf.cu:2736-2753
 	std::vector<std::string> out;
-	const fs::path p(data_path);
-	if (fs::is_directory(p)) {
-		for (const auto& e : fs::directory_iterator(p)) if (e.is_regular_file() && lower(e.path().extension().string()) == ".json") out.push_back(e.path().string());
+	if (path_is_directory(data_path)) {
+		if (DIR* dir = opendir(data_path.c_str())) {
+			while (const dirent* e = readdir(dir)) {
+				const std::string f = path_join(data_path, e->d_name);
+				if (lower(path_extension(f)) == "json" && path_is_file(f)) out.push_back(f);
+			}
+			closedir(dir);
+		}
 		std::sort(out.begin(), out.end());   // directory order is unspecified; sorted keeps runs reproducible
-	} else if (lower(p.extension().string()) == ".json") {
+	} else if (lower(path_extension(data_path)) == "json") {
 		out.push_back(data_path);
 	} else {
 		throw std::runtime_error{"NeRF data path must either be a json file or a directory containing json files."};
@@ -97,7 +123,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	std::vector<std::vector<Json>> frames_of(jsons.size());
 	for (size_t i = 0; i < jsons.size(); ++i) {
 		const Json& json = jsons[i];
-		const fs::path basepath = fs::path(jsonpaths[i]).parent_path();
+		const std::string basepath = path_parent(jsonpaths[i]);
 		if (!json.contains("frames") || !json["frames"].is_array()) { fprintf(stderr, "  %s does not contain any frames. Skipping.\n", jsonpaths[i].c_str()); continue; }
 		std::vector<Json> frames(json["frames"].elements());
 		const float sharpness_discard_threshold = (float)json.value("sharpness_discard_threshold", 0.0);
@@ -116,7 +142,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 				std::string fp = f["file_path"].str();
 				std::replace(fp.begin(), fp.end(), '\\', '/');   // Windows paths on Linux
 				f["file_path"] = Json(fp);
-				if (fs::exists(basepath / fp) && (float)f["sharpness"].number() > sharpness_discard_threshold * mean_sharpness) frames.push_back(f);
+				if (path_exists(path_join(basepath, fp)) && (float)f["sharpness"].number() > sharpness_discard_threshold * mean_sharpness) frames.push_back(f);
 			}
 		}
 		for (const Json& f : frames) result.paths.push_back(f["file_path"].str());
@@ -128,19 +154,29 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	result.metadata.assign(result.n_images, NgpImageMeta{});
 	result.pixels.resize(result.n_images);
 
+	result.image_type.assign(result.n_images, 1);
+	result.depth16.resize(result.n_images);
+	result.depth_scale.assign(result.n_images, -1.f);
+	result.rays.resize(result.n_images);
+
 	// pass 2 (430-700): dataset-level keys, then the frames of each json
-	bool white_transparent = false, black_transparent = false;
+	bool white_transparent = false, black_transparent = false, fix_premult = false, enable_ray_loading = true, enable_depth_loading = true;
+	float info_depth_scale = -1.f;   // LoadedImageInfo::depth_scale (325), set by `integer_depth_scale`
 	size_t image_idx = 0;
 	std::vector<std::future<void>> futures;
+	std::atomic<bool> any_rays{false}, any_exr{false};
 	for (size_t i = 0; i < jsons.size(); ++i) {
 		const Json& json = jsons[i];
-		const fs::path basepath = fs::path(jsonpaths[i]).parent_path();
+		const std::string basepath = path_parent(jsonpaths[i]);
 		const std::string jp = jsonpaths[i];
 		size_t lastdot = jp.find_last_of('.'); if (lastdot == std::string::npos) lastdot = jp.length();
 		size_t lastunderscore = jp.find_last_of('_'); if (lastunderscore == std::string::npos) lastunderscore = lastdot; else lastunderscore++;
 		const std::string part_after_underscore = lastunderscore <= lastdot ? jp.substr(lastunderscore, lastdot - lastunderscore) : std::string();
 
+		if (json.contains("enable_ray_loading")) enable_ray_loading = json["enable_ray_loading"].boolean();
+		if (json.contains("enable_depth_loading")) enable_depth_loading = json["enable_depth_loading"].boolean();
 		if (json.contains("normal_mts_args")) result.from_mitsuba = true;
+		if (json.contains("fix_premult")) fix_premult = json["fix_premult"].boolean();
 		if (result.from_mitsuba) { result.scale = 0.66f; result.offset = Vec3{0.25f * result.scale, 0.25f * result.scale, 0.25f * result.scale}; }
 		if (json.contains("render_aabb")) {
 			for (int k = 0; k < 3; ++k) { result.render_aabb.min[k] = (float)json["render_aabb"][(size_t)0][(size_t)k].number(); result.render_aabb.max[k] = (float)json["render_aabb"][(size_t)1][(size_t)k].number(); }
@@ -155,6 +191,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 
 		LensState lens;
 		float principal_point[2] = {0.5f, 0.5f}, rolling_shutter[4] = {0, 0, 0, 0};
+		if (json.contains("integer_depth_scale")) info_depth_scale = (float)json["integer_depth_scale"].number();
 		read_lens(json, lens, principal_point, rolling_shutter);
 		if (json.contains("aabb_scale")) result.aabb_scale = (int)json["aabb_scale"].number();
 		if (json.contains("offset")) {
@@ -169,40 +206,101 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 			result.offset = Vec3{((A(1, 0) + A(0, 0)) * 0.5f) * -result.scale + 0.5f, ((A(1, 1) + A(0, 1)) * 0.5f) * -result.scale + 0.5f, ((A(1, 2) + A(0, 2)) * 0.5f) * -result.scale + 0.5f};
 		}
 		if (json.contains("up")) { result.up = Vec3{(float)json["up"][(size_t)1].number(), (float)json["up"][(size_t)2].number(), (float)json["up"][(size_t)0].number()}; }  // axes permuted like the xforms
-		if (json.contains("envmap")) throw std::runtime_error{"environment maps are outside the NeRF hot path of this build (SURVEY.md §8 f4)"};
+		if (json.contains("envmap")) throw std::runtime_error{"the `envmap` key (a trainable environment map, nerf_loader.cu:527-541) is outside the NeRF hot path of this build (SURVEY.md §8 f4)"};
 
 		const float scale = result.scale;
 		const Vec3 offset = result.offset;
+		const bool from_mitsuba = result.from_mitsuba;
 		for (size_t k = 0; k < frames_of[i].size(); ++k) {
 			const size_t i_img = k + image_idx;
 			const Json frame = frames_of[i][k];
-			futures.push_back(std::async(std::launch::async, [&result, &json, frame, basepath, i_img, k, part_after_underscore, white_transparent, black_transparent, lens, principal_point, rolling_shutter, scale, offset, from_mitsuba = result.from_mitsuba]() {
+			futures.push_back(std::async(std::launch::async, [&result, &json, &any_rays, &any_exr, frame, basepath, i_img, k, part_after_underscore, white_transparent, black_transparent, fix_premult,
+			                                                  enable_ray_loading, enable_depth_loading, info_depth_scale, lens, principal_point, rolling_shutter, scale, offset, from_mitsuba]() {
 				std::string json_provided_path = frame["file_path"].str();
 				if (json_provided_path.empty()) { char buf[256]; snprintf(buf, 256, "%s_%03d/rgba.png", part_after_underscore.c_str(), (int)k); json_provided_path = buf; }
-				fs::path path = basepath / json_provided_path;
-				if (path.extension().empty()) {
-					path.replace_extension("png");
-					if (!fs::exists(path)) path.replace_extension("exr");
-					if (!fs::exists(path)) throw std::runtime_error{"Could not find image file: " + path.string()};
+				std::string path = path_join(basepath, json_provided_path);
+				if (path_extension(path).empty()) {
+					path = path_with_extension(path, "png");
+					if (!path_exists(path)) path = path_with_extension(path, "exr");
+					if (!path_exists(path)) throw std::runtime_error{"Could not find image file: " + path};
 				}
-				if (lower(path.extension().string()) == ".exr") throw std::runtime_error{"EXR training images are not part of this build (PNG only): " + path.string()};
 				int w = 0, h = 0;
-				std::vector<uint8_t>& img = result.pixels[i_img];
-				read_png_rgba8(path.string(), w, h, img);
-				uint32_t mask_color = 0;
-				const fs::path maskpath = path.parent_path() / ("dynamic_mask_" + path.stem().string() + ".png");
-				if (fs::exists(maskpath)) {  // 604-622
-					int wa = 0, ha = 0; std::vector<uint8_t> mask;
-					read_png_rgba8(maskpath.string(), wa, ha, mask);
-					if (wa != w || ha != h) throw std::runtime_error{"Dynamic mask " + maskpath.string() + " has wrong resolution."};
-					mask_color = 0x00FF00FF;   // hot pink
-					for (size_t p = 0; p < (size_t)w * h; ++p) if (mask[p * 4] != 0) memcpy(&img[p * 4], &mask_color, 4);
-				}
-				convert_rgba32_host((size_t)w * h, img.data(), white_transparent, black_transparent, mask_color);
-
 				NgpImageMeta& m = result.metadata[i_img];
-				m.image_data_type = 1;   // EImageDataType::Byte
+				if (lower(path_extension(path)) == "exr") {
+					// load_exr_to_gpu (tinyexr_wrapper.cu:136-232): RGBA fp16, colour multiplied by alpha when `fix_premult`, missing alpha = 1
+					std::vector<float> rgba;
+					read_exr_rgba_f32(path, w, h, rgba);
+					std::vector<uint8_t>& img = result.pixels[i_img];
+					img.resize((size_t)w * h * 8);
+					uint16_t* dst = (uint16_t*)img.data();
+					for (size_t p = 0; p < (size_t)w * h; ++p) {
+						const float alpha = rgba[p * 4 + 3], fix = fix_premult ? alpha : 1.0f;
+						for (int c = 0; c < 3; ++c) dst[p * 4 + c] = float_to_half_bits(rgba[p * 4 + c] * fix);
+						dst[p * 4 + 3] = float_to_half_bits(alpha);
+					}
+					result.image_type[i_img] = 2;   // EImageDataType::Half
+					any_exr = true;
+				} else {
+					std::vector<uint8_t>& img = result.pixels[i_img];
+					read_image_rgba8(path, w, h, img);   // stbi_load(path, .., 4): PNG or JPEG by content
+					const std::string alphapath = path_join(basepath, json_provided_path + ".alpha." + path_extension(path));   // fmt "{}.alpha.{}" (585)
+					if (path_exists(alphapath)) {
+						int wa = 0, ha = 0; std::vector<uint8_t> alpha;
+						read_image_rgba8(alphapath, wa, ha, alpha);
+						if (wa != w || ha != h) throw std::runtime_error{"Alpha image " + alphapath + " has wrong resolution."};
+						for (size_t p = 0; p < (size_t)w * h; ++p) {   // red channel of the alpha image, sRGB -> linear (595-597)
+							const float sv = alpha[p * 4] * (1.f / 255.f);
+							const float lin = sv <= 0.04045f ? sv / 12.92f : std::pow((sv + 0.055f) / 1.055f, 2.4f);
+							img[p * 4 + 3] = (uint8_t)(255.0f * lin);
+						}
+					}
+					uint32_t mask_color = 0;
+					const std::string maskpath = path_join(path_parent(path), "dynamic_mask_" + path_basename(path) + ".png");
+					if (path_exists(maskpath)) {  // 600-620
+						int wa = 0, ha = 0; std::vector<uint8_t> mask;
+						read_image_rgba8(maskpath, wa, ha, mask);
+						if (wa != w || ha != h) throw std::runtime_error{"Dynamic mask " + maskpath + " has wrong resolution."};
+						mask_color = 0x00FF00FF;   // hot pink
+						for (size_t p = 0; p < (size_t)w * h; ++p) if (mask[p * 4] != 0) memcpy(&img[p * 4], &mask_color, 4);
+					}
+					convert_rgba32_host((size_t)w * h, img.data(), white_transparent, black_transparent, mask_color);
+					result.image_type[i_img] = 1;   // EImageDataType::Byte
+				}
+				m.image_data_type = result.image_type[i_img];
 				m.res[0] = w; m.res[1] = h;
+
+				// depth (630-645): a 16-bit image whose values are scaled by integer_depth_scale * scale at upload (727)
+				if (enable_depth_loading && info_depth_scale > 0.f && frame.contains("depth_path")) {
+					const std::string depthpath = path_join(basepath, frame["depth_path"].str());
+					if (path_exists(depthpath)) {
+						int wa = 0, ha = 0;
+						read_png_gray16(depthpath, wa, ha, result.depth16[i_img]);
+						if (wa != w || ha != h) throw std::runtime_error{"Depth image " + depthpath + " has wrong resolution."};
+					}
+				}
+				result.depth_scale[i_img] = info_depth_scale;
+
+				// per-pixel rays (647-668): rays_<image name>.dat next to the image, w * h records of 6 floats, converted to the NGP frame
+				const std::string rayspath = path_join(path_parent(path), "rays_" + path_basename(path) + ".dat");
+				if (enable_ray_loading && path_exists(rayspath)) {
+					std::vector<NgpRay>& rays = result.rays[i_img];
+					rays.resize((size_t)w * h);
+					std::ifstream f(rayspath, std::ios::binary);
+					f.read((char*)rays.data(), (std::streamsize)(rays.size() * sizeof(NgpRay)));
+					if ((size_t)f.gcount() != rays.size() * sizeof(NgpRay)) throw std::runtime_error{"Rays file " + rayspath + " is too short."};
+					for (NgpRay& r : rays) {   // nerf_ray_to_ngp (nerf_loader.h:165-180): origin scaled + offset, both cycled (x, y, z) <- (y, z, x)
+						const float o[3] = {r.o[0] * scale + offset.x, r.o[1] * scale + offset.y, r.o[2] * scale + offset.z};
+						const float d[3] = {r.d[0], r.d[1], r.d[2]};
+						r.o[0] = o[1]; r.o[1] = o[2]; r.o[2] = o[0];
+						r.d[0] = d[1]; r.d[1] = d[2]; r.d[2] = d[0];
+					}
+					any_rays = true;
+				}
+				if (frame.contains("driver_parameters")) {
+					static std::atomic<bool> warned{false};
+					if (!warned.exchange(true)) fprintf(stderr, "transforms.json: `driver_parameters` (per-image light directions, an extra network input) are ignored by this build\n");
+				}
+
 				bool got_fl = read_focal_length(json, m.focal_length, m.res);
 				got_fl |= read_focal_length(frame, m.focal_length, m.res);
 				if (!got_fl) throw std::runtime_error{"Couldn't read fov."};
@@ -224,6 +322,8 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 		image_idx += frames_of[i].size();
 	}
 	for (auto& f : futures) f.get();
+	result.has_rays = any_rays;
+	result.is_hdr = any_exr;
 	return result;
 }
 

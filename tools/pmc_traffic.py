@@ -3,21 +3,22 @@
 profiles/pmc_traffic.json: HBM bytes per C-ABI call of each step stage, per the gfx950 recipe in MI355X_MICROARCH.md §HBM
 (unit = KiB; FETCH_SIZE doubled because this rocprofv3 tallies 128-B read requests at 64 B).
 
-usage: pmc_traffic.py <dir with *counter_collection.csv of the FETCH pass> <dir of the WRITE pass> <out.json>
+usage: pmc_traffic.py <dir with *counter_collection.csv of the FETCH pass> <dir of the WRITE pass> <out.json> [tag]
 """
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 # kernel-name substring -> stage (one stage = one ngp_hip_* entry point as bench.py times it)
 STAGES = [("nerf_forward_kernelILi0ELb0E", "nerf_inference"), ("nerf_forward_kernelILi2ELb0E", "nerf_forward"), ("nerf_forward_kernelILi1E", "density_grid_prep"),
           ("encode_planes_kernel", "density_grid_prep"),
-          ("nerf_backward_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
+          ("nerf_backward_fused_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("gb_fx_bin_kernel", "nerf_backward"), ("gb_fx_scan_kernel", "nerf_backward"),
           ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema", "optimizer_step"),
-          ("generate_training_samples_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
+          ("generate_training_samples_kernel", "generate_training_samples"), ("generate_training_samples_wave_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
           ("compute_loss_kernel", "compute_loss")]
 
 
@@ -51,6 +52,8 @@ def main():
         out[stage] = out.get(stage, 0.0) + (2.0 * f_kib + w_kib) * 1024.0
         launches[stage] = launches.get(stage, 0) + 1
     res = {s: round(v) for s, v in out.items()}
+    ks = re.search(r'KERNEL_SET = "([^"]+)"', open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read())
+    res["_meta"] = {"tag": sys.argv[4] if len(sys.argv) > 4 else os.path.basename(sys.argv[3]).replace("_pmc_traffic.json", ""), "kernel_set": ks.group(1) if ks else None}
     res["_method"] = "per call: sum over the stage's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 B, dispatch averages; separate --pmc passes"
     res["_kernels"] = detail
     json.dump(res, open(sys.argv[3], "w"), indent=1)
