@@ -1472,7 +1472,7 @@ __global__ void gridmlp_init_params_kernel(uint32_t n_params, uint64_t seed_stat
 
 // Ema o ExponentialDecay o Adam (tcnn optimizers as configured by configs/nerf/base.json:5-22); one streaming pass.
 __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, float lr, float beta1, float beta2, float epsilon, float l2_reg,
-                                float loss_scale, float ema_decay, float ema_debias_old, float ema_debias_new,
+                                float loss_scale, float ema_decay, float ema_debias_old, float ema_debias_new, uint32_t optimize_mask,
                                 const half_t* __restrict__ grads, float* __restrict__ master, half_t* __restrict__ params,
                                 float* __restrict__ m1, float* __restrict__ m2, float* __restrict__ ema, half_t* __restrict__ inference) {
 #pragma clang fp contract(off)
@@ -1480,7 +1480,8 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 	if (i >= n_params) return;
 	float g = (float)grads[i] / loss_scale;
 	half_t p16 = params[i];
-	const bool skip = (i >= n_matrix_params) && g == 0.0f;
+	// optimize_mask: bit 0 = matrix (MLP) parameters, bit 1 = the others (encoding) — tcnn Adam's optimize_matrix_params / optimize_non_matrix_params
+	const bool skip = i >= n_matrix_params ? (g == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u);
 	if (!skip) {
 		float w = master[i];
 		if (i < n_matrix_params) g += l2_reg * w;
@@ -1509,7 +1510,7 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 // four parameters has work (hash-grid entries without gradient: most of them), and then rewritten with unchanged bits for the others.
 struct alignas(8) half4_t { half_t v[4]; };
 __global__ void __launch_bounds__(256) adam_ema_vec4_kernel(uint32_t n_groups, uint32_t n_matrix_params, float lr, float beta1, float beta2, float epsilon, float l2_reg,
-                                     float loss_scale, float ema_decay, float ema_debias_old, float ema_debias_new,
+                                     float loss_scale, float ema_decay, float ema_debias_old, float ema_debias_new, uint32_t optimize_mask,
                                      const half4_t* __restrict__ grads, float4* __restrict__ master, half4_t* __restrict__ params,
                                      float4* __restrict__ m1, float4* __restrict__ m2, float4* __restrict__ ema, half4_t* __restrict__ inference) {
 #pragma clang fp contract(off)
@@ -1522,7 +1523,7 @@ __global__ void __launch_bounds__(256) adam_ema_vec4_kernel(uint32_t n_groups, u
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		g[k] = (float)g4.v[k] / loss_scale;
-		skip[k] = (t * 4u + k >= n_matrix_params) && g[k] == 0.0f;
+		skip[k] = t * 4u + k >= n_matrix_params ? (g[k] == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u);
 		any |= !skip[k];
 	}
 	if (any) {
@@ -1846,6 +1847,13 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
                            float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
                            float* first_moments, float* second_moments, float* ema, uint16_t* inference_params) {
+	return ngp_hip_optimizer_step_masked(stream, n_params, n_matrix_params, step, learning_rate, beta1, beta2, epsilon, l2_reg, loss_scale, ema_decay, grads, master, params,
+	                                     first_moments, second_moments, ema, inference_params, 3u);
+}
+
+int ngp_hip_optimizer_step_masked(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
+                                  float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
+                                  float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask) {
 	const float lr = learning_rate * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
 	const float ema_debias_old = 1.0f - powf(ema_decay, (float)(step - 1));
 	const float ema_debias_new = 1.0f / (1.0f - powf(ema_decay, (float)step));
@@ -1853,14 +1861,14 @@ int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_pa
 	const uint32_t n_vec = (align_or & 15u) ? 0u : (n_params & ~3u);   // 16-byte aligned arrays: groups of four, then a scalar tail
 	if (n_vec) {
 		hipLaunchKernelGGL(adam_ema_vec4_kernel, dim3(div_up(n_vec / 4, 256)), dim3(256), 0, (hipStream_t)stream, n_vec / 4, n_matrix_params, lr, beta1, beta2, epsilon, l2_reg,
-		                   loss_scale, ema_decay, ema_debias_old, ema_debias_new, (const half4_t*)grads, (float4*)master, (half4_t*)params, (float4*)first_moments, (float4*)second_moments,
+		                   loss_scale, ema_decay, ema_debias_old, ema_debias_new, optimize_mask, (const half4_t*)grads, (float4*)master, (half4_t*)params, (float4*)first_moments, (float4*)second_moments,
 		                   (float4*)ema, (half4_t*)inference_params);
 		NGP_LAUNCH_CHECK("adam_ema_vec4_kernel");
 	}
 	if (n_vec < n_params) {
 		const uint32_t r = n_params - n_vec, nm = n_matrix_params > n_vec ? n_matrix_params - n_vec : 0u;
 		hipLaunchKernelGGL(adam_ema_kernel, dim3(div_up(r, 256)), dim3(256), 0, (hipStream_t)stream, r, nm, lr, beta1, beta2, epsilon, l2_reg,
-		                   loss_scale, ema_decay, ema_debias_old, ema_debias_new, (const half_t*)grads + n_vec, master + n_vec, (half_t*)params + n_vec, first_moments + n_vec,
+		                   loss_scale, ema_decay, ema_debias_old, ema_debias_new, optimize_mask, (const half_t*)grads + n_vec, master + n_vec, (half_t*)params + n_vec, first_moments + n_vec,
 		                   second_moments + n_vec, ema + n_vec, (half_t*)inference_params + n_vec);
 		NGP_LAUNCH_CHECK("adam_ema_kernel");
 	}

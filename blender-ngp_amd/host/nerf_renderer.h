@@ -3,6 +3,8 @@
 // camera_models.cuh, common.h:300-355), one NeuralRadianceField per snapshot path (neural_radiance_field.cuh) and the render loop
 // (src/nerf_renderer.cu:565-791) over the ngp_hip_multi_* kernels.
 #pragma once
+#include <algorithm>
+#include <cmath>
 
 #include <memory>
 #include <string>
@@ -31,6 +33,36 @@ struct BoundingBox {  // bounding_box.cuh:43-268 (the members the request schema
 	void inflate(float amount);
 	Vec3 relative_pos(const Vec3& p) const;
 	NgpAabb pod() const { return NgpAabb{{min.x, min.y, min.z}, {max.x, max.y, max.z}}; }
+	bool is_empty() const { return max.x < min.x || max.y < min.y || max.z < min.z; }
+	BoundingBox intersection(const BoundingBox& o) const {   // bounding_box.cuh:94-103
+		return BoundingBox(Vec3{std::max(min.x, o.min.x), std::max(min.y, o.min.y), std::max(min.z, o.min.z)}, Vec3{std::min(max.x, o.max.x), std::min(max.y, o.max.y), std::min(max.z, o.max.z)});
+	}
+	bool intersects(const BoundingBox& o) const { return !intersection(o).is_empty(); }
+	float distance_sq(const Vec3& p) const {                  // bounding_box.cuh:246-248
+		const float d[3] = {std::max(std::max(min.x - p.x, p.x - max.x), 0.f), std::max(std::max(min.y - p.y, p.y - max.y), 0.f), std::max(std::max(min.z - p.z, p.z - max.z), 0.f)};
+		return d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+	}
+	float signed_distance(const Vec3& p) const {              // bounding_box.cuh:250-253 (as written there: |p - min| - diag)
+		const float q[3] = {std::fabs(p.x - min.x) - (max.x - min.x), std::fabs(p.y - min.y) - (max.y - min.y), std::fabs(p.z - min.z) - (max.z - min.z)};
+		const float m0 = std::max(q[0], 0.f), m1 = std::max(q[1], 0.f), m2 = std::max(q[2], 0.f);
+		return std::sqrt(m0 * m0 + m1 * m1 + m2 * m2) + std::min(std::max(q[0], std::max(q[1], q[2])), 0.0f);
+	}
+	void ray_intersect(const Vec3& pos, const Vec3& dir, float t[2]) const {   // bounding_box.cuh:163-210 (the slab test; miss = both FLT_MAX)
+		const float FMAX = 3.402823466e+38f;
+		float tmin = (min.x - pos.x) / dir.x, tmax = (max.x - pos.x) / dir.x;
+		if (tmin > tmax) std::swap(tmin, tmax);
+		float tymin = (min.y - pos.y) / dir.y, tymax = (max.y - pos.y) / dir.y;
+		if (tymin > tymax) std::swap(tymin, tymax);
+		if (tmin > tymax || tymin > tmax) { t[0] = t[1] = FMAX; return; }
+		if (tymin > tmin) tmin = tymin;
+		if (tymax < tmax) tmax = tymax;
+		float tzmin = (min.z - pos.z) / dir.z, tzmax = (max.z - pos.z) / dir.z;
+		if (tzmin > tzmax) std::swap(tzmin, tzmax);
+		if (tmin > tzmax || tzmin > tmax) { t[0] = t[1] = FMAX; return; }
+		if (tzmin > tmin) tmin = tzmin;
+		if (tzmax < tmax) tmax = tzmax;
+		t[0] = tmin; t[1] = tmax;
+	}
 };
 
 enum class EMaskMode : int { Add, Subtract };

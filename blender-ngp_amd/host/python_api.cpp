@@ -77,14 +77,28 @@ static Mat4 mat4_from_py(const py::array_t<float, py::array::c_style | py::array
 	return m;
 }
 
+// python-side value types of python_api.cu:733-802 over this build's PODs
+enum class EGroundTruthRenderMode : int { Shade, Depth };
+enum class ERandomMode : int { Random, Halton, Sobol, Stratified };
+struct PyLens {
+	ELensMode mode = ELensMode::Perspective; float params[7] = {0, 0, 0, 0, 0, 0, 0};
+	static PyLens from(const NgpImageMeta& m) { PyLens l; l.mode = (ELensMode)m.lens_mode; memcpy(l.params, m.lens_params, sizeof(l.params)); return l; }
+	void to(NgpImageMeta& m) const { m.lens_mode = (int)mode; memcpy(m.lens_params, params, sizeof(params)); }
+};
+struct PyImageMetadata { NgpImageMeta m; Vec3 light_dir; };
+struct PyNerfDataset { NerfDataset* d; };
+
 PYBIND11_MODULE(pyngp, m) {
 	m.doc() = "MI355X-native Instant-NGP NeRF engine behind the blender-ngp `pyngp` API";
 
 	py::enum_<ETestbedMode>(m, "TestbedMode").value("Nerf", ETestbedMode::Nerf).value("Sdf", ETestbedMode::Sdf).value("Image", ETestbedMode::Image).value("Volume", ETestbedMode::Volume).export_values();
 	py::enum_<ERenderMode>(m, "RenderMode").value("AO", ERenderMode::AO).value("Shade", ERenderMode::Shade).value("Normals", ERenderMode::Normals).value("Positions", ERenderMode::Positions)
 		.value("Depth", ERenderMode::Depth).value("Distortion", ERenderMode::Distortion).value("Cost", ERenderMode::Cost).value("Slice", ERenderMode::Slice).export_values();
+	py::enum_<EGroundTruthRenderMode>(m, "GroundTruthRenderMode").value("Shade", EGroundTruthRenderMode::Shade).value("Depth", EGroundTruthRenderMode::Depth).export_values();
+	py::enum_<ERandomMode>(m, "RandomMode").value("Random", ERandomMode::Random).value("Halton", ERandomMode::Halton).value("Sobol", ERandomMode::Sobol).value("Stratified", ERandomMode::Stratified).export_values();
+	py::enum_<ELensMode>(m, "LensMode").value("Perspective", ELensMode::Perspective).value("OpenCV", ELensMode::OpenCV).value("FTheta", ELensMode::FTheta).value("LatLong", ELensMode::LatLong).export_values();
 	py::enum_<ELossType>(m, "LossType").value("L2", ELossType::L2).value("L1", ELossType::L1).value("Mape", ELossType::Mape).value("Smape", ELossType::Smape)
-		.value("Huber", ELossType::Huber).value("LogL1", ELossType::LogL1).value("RelativeL2", ELossType::RelativeL2).export_values();
+		.value("Huber", ELossType::Huber).value("SmoothL1", ELossType::Huber) /* legacy name (python_api.cu:347-349) */.value("LogL1", ELossType::LogL1).value("RelativeL2", ELossType::RelativeL2).export_values();
 	py::enum_<ENerfActivation>(m, "NerfActivation").value("None", ENerfActivation::None).value("ReLU", ENerfActivation::ReLU).value("Logistic", ENerfActivation::Logistic)
 		.value("Exponential", ENerfActivation::Exponential).export_values();
 	py::enum_<EColorSpace>(m, "ColorSpace").value("Linear", EColorSpace::Linear).value("SRGB", EColorSpace::SRGB).export_values();
@@ -188,6 +202,13 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("diag", [](const BoundingBox& b) { return vec3_to_py(b.diag()); })
 		.def("enlarge", [](BoundingBox& b, const py::object& p) { if (py::isinstance<BoundingBox>(p)) b.enlarge(p.cast<BoundingBox>()); else b.enlarge(vec3_from_py(p)); })
 		.def("inflate", &BoundingBox::inflate)
+		.def("distance", [](const BoundingBox& b, const py::object& p) { return std::sqrt(b.distance_sq(vec3_from_py(p))); })
+		.def("distance_sq", [](const BoundingBox& b, const py::object& p) { return b.distance_sq(vec3_from_py(p)); })
+		.def("signed_distance", [](const BoundingBox& b, const py::object& p) { return b.signed_distance(vec3_from_py(p)); })
+		.def("intersection", &BoundingBox::intersection)
+		.def("intersects", &BoundingBox::intersects)
+		.def("ray_intersect", [](const BoundingBox& b, const py::object& pos, const py::object& dir) { float t[2]; b.ray_intersect(vec3_from_py(pos), vec3_from_py(dir), t); py::array_t<float> a(2); a.mutable_data()[0] = t[0]; a.mutable_data()[1] = t[1]; return a; })
+		.def("get_vertices", [](const BoundingBox& b) { py::list l; for (int i = 0; i < 8; ++i) l.append(vec3_to_py(Vec3{(i & 4) ? b.max.x : b.min.x, (i & 2) ? b.max.y : b.min.y, (i & 1) ? b.max.z : b.min.z})); return l; })
 		.def("relative_pos", [](const BoundingBox& b, const py::object& p) { return vec3_to_py(b.relative_pos(vec3_from_py(p))); })
 		.def_property("min", [](const BoundingBox& b) { return vec3_to_py(b.min); }, [](BoundingBox& b, const py::object& v) { b.min = vec3_from_py(v); })
 		.def_property("max", [](const BoundingBox& b) { return vec3_to_py(b.max); }, [](BoundingBox& b, const py::object& v) { b.max = vec3_from_py(v); });
@@ -255,9 +276,49 @@ PYBIND11_MODULE(pyngp, m) {
 				return RenderRequest{output, camera, modifiers, nerfs, aabb};
 			}), py::arg("output"), py::arg("camera"), py::arg("modifiers"), py::arg("nerfs"), py::arg("aabb"));
 
-	py::class_<Testbed> testbed(m, "Testbed");
+	// python_api.cu:733-742, 771-802: value views.  Like the reference's (std::vector members cross pybind11 by COPY), what Python gets are copies.
+	py::class_<PyLens>(m, "Lens")
+		.def(py::init<>())
+		.def_readwrite("mode", &PyLens::mode)
+		.def_property_readonly("params", [](py::object& obj) { PyLens& o = obj.cast<PyLens&>(); return py::array(py::dtype::of<float>(), {7}, {sizeof(float)}, o.params, obj); });
+	py::class_<PyImageMetadata>(m, "TrainingImageMetadata")
+		.def_property("focal_length", [](PyImageMetadata& t) { py::array_t<float> a(2); a.mutable_data()[0] = t.m.focal_length[0]; a.mutable_data()[1] = t.m.focal_length[1]; return a; },
+			[](PyImageMetadata& t, const std::vector<float>& v) { t.m.focal_length[0] = v.at(0); t.m.focal_length[1] = v.at(1); })
+		.def_property("principal_point", [](PyImageMetadata& t) { py::array_t<float> a(2); a.mutable_data()[0] = t.m.principal_point[0]; a.mutable_data()[1] = t.m.principal_point[1]; return a; },
+			[](PyImageMetadata& t, const std::vector<float>& v) { t.m.principal_point[0] = v.at(0); t.m.principal_point[1] = v.at(1); })
+		.def_property("rolling_shutter", [](PyImageMetadata& t) { py::array_t<float> a(4); memcpy(a.mutable_data(), t.m.rolling_shutter, 16); return a; },
+			[](PyImageMetadata& t, const std::vector<float>& v) { for (int k = 0; k < 4; ++k) t.m.rolling_shutter[k] = v.at(k); })
+		.def_property("light_dir", [](PyImageMetadata& t) { return vec3_to_py(t.light_dir); }, [](PyImageMetadata& t, const py::object& v) { t.light_dir = vec3_from_py(v); })
+		.def_property("lens", [](PyImageMetadata& t) { return PyLens::from(t.m); }, [](PyImageMetadata& t, const PyLens& l) { l.to(t.m); })
+		.def_property("camera_distortion", [](PyImageMetadata& t) { return PyLens::from(t.m); }, [](PyImageMetadata& t, const PyLens& l) { l.to(t.m); })   // legacy name
+		.def_property_readonly("resolution", [](PyImageMetadata& t) { return std::vector<int>{t.m.res[0], t.m.res[1]}; });
+	py::class_<PyNerfDataset>(m, "NerfDataset")
+		.def_property_readonly("metadata", [](PyNerfDataset& d) { std::vector<PyImageMetadata> v; for (const NgpImageMeta& m : d.d->metadata) v.push_back(PyImageMetadata{m, Vec3{}}); return v; })
+		.def_property_readonly("transforms", [](PyNerfDataset& d) { py::list l; for (const NgpXForm& x : d.d->xforms) { Mat34 a, b; memcpy(a.m, x.start, 48); memcpy(b.m, x.end, 48); l.append(py::make_tuple(mat34_to_py(a), mat34_to_py(b))); } return l; })
+		.def_property_readonly("paths", [](PyNerfDataset& d) { return d.d->paths; })
+		.def_property_readonly("render_aabb", [](PyNerfDataset& d) { const NgpAabb& a = d.d->render_aabb; return BoundingBox(Vec3{a.min[0], a.min[1], a.min[2]}, Vec3{a.max[0], a.max[1], a.max[2]}); })
+		.def_property_readonly("render_aabb_to_local", [](PyNerfDataset&) { py::array_t<float> a({3, 3}); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.mutable_at(r, c) = r == c ? 1.f : 0.f; return a; })   // the loader of this build reads no `render_aabb_to_local`-style key (nerf_loader.cu sets identity too)
+		.def_property_readonly("up", [](PyNerfDataset& d) { return vec3_to_py(d.d->up); })
+		.def_property_readonly("offset", [](PyNerfDataset& d) { return vec3_to_py(d.d->offset); })
+		.def_property_readonly("n_images", [](PyNerfDataset& d) { return d.d->n_images; })
+		.def_property_readonly("envmap_resolution", [](PyNerfDataset&) { return std::vector<int>{0, 0}; })   // environment maps are not loaded by this build
+		.def_property_readonly("scale", [](PyNerfDataset& d) { return d.d->scale; })
+		.def_property_readonly("aabb_scale", [](PyNerfDataset& d) { return d.d->aabb_scale; })
+		.def_property_readonly("from_mitsuba", [](PyNerfDataset& d) { return d.d->from_mitsuba; })
+		.def_property_readonly("is_hdr", [](PyNerfDataset& d) { return d.d->is_hdr; });
+
+	// a Testbed that is collected while an async render is in flight waits for the worker, and the worker needs the GIL for its callback
+	struct TestbedDeleter { void operator()(Testbed* t) const { { py::gil_scoped_release rel; t->bl_wait_for_renders(); } delete t; } };
+	py::class_<Testbed, std::unique_ptr<Testbed, TestbedDeleter>> testbed(m, "Testbed");
 	testbed
 		.def(py::init<ETestbedMode>(), py::arg("mode") = ETestbedMode::Nerf)
+		.def(py::init([](ETestbedMode mode, const std::string& data_path, const py::object& network_config) {   // python_api.cu:541-543 (testbed.cu:3108-3122)
+				std::unique_ptr<Testbed, TestbedDeleter> t(new Testbed(mode));
+				t->load_training_data(data_path);
+				if (py::isinstance<py::str>(network_config)) t->reload_network_from_file(network_config.cast<std::string>());
+				else t->reload_network_from_json(json_from_py(network_config));
+				return t;
+			}), py::arg("mode"), py::arg("data_path"), py::arg("network_config"))
 		.def("load_training_data", &Testbed::load_training_data, py::call_guard<py::gil_scoped_release>(), py::arg("path"))
 		.def("create_empty_nerf_dataset", &Testbed::create_empty_nerf_dataset, py::arg("n_images"), py::arg("aabb_scale") = 1, py::arg("is_hdr") = false)
 		.def("frame", &Testbed::frame, py::call_guard<py::gil_scoped_release>())
@@ -269,6 +330,29 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("save_snapshot", &Testbed::save_snapshot, py::arg("path"), py::arg("include_optimizer_state") = false)
 		.def("load_snapshot", &Testbed::load_snapshot, py::arg("path"))
 		// entry points of scripts/run.py that lie outside the hot path (SURVEY §8 out of scope): present so that a driver fails loudly, not with AttributeError
+		.def("render_with_rolling_shutter", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& m0, const py::array_t<float, py::array::c_style | py::array::forcecast>& m1,
+		                                       const std::vector<float>& rolling_shutter, int width, int height, int spp, bool linear) {   // python_api.cu:262-275, 584-593
+				if (rolling_shutter.size() != 4) throw std::runtime_error{"rolling_shutter takes 4 floats [A, B, C, D]"};
+				std::vector<float> px;
+				{ py::gil_scoped_release rel; px = t.render_with_rolling_shutter_to_cpu(mat34_from_py(m0), mat34_from_py(m1), rolling_shutter.data(), width, height, spp, linear); }
+				py::array_t<float> result({height, width, 4});
+				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				return result;
+			}, "Renders an image at the requested resolution. Does not require a window. Supports rolling shutter, with per ray time being computed as A+B*u+C*v+D*t for [A,B,C,D]",
+			py::arg("transform_matrix_start"), py::arg("transform_matrix_end"), py::arg("rolling_shutter") = std::vector<float>{0.f, 0.f, 0.f, 0.f}, py::arg("width") = 1920, py::arg("height") = 1080,
+			py::arg("spp") = 1, py::arg("linear") = true)
+		.def("destroy_window", [](Testbed&) {})                                                                          // python_api.cu:594 (there never is one)
+		.def("calculate_iou", [](Testbed&, uint64_t, float, bool, bool) -> float { throw std::runtime_error{"calculate_iou: the SDF ground-truth metric (mesh BVH, testbed_sdf.cu) is not part of this build"}; },
+			py::arg("n_samples") = 128 * 1024 * 1024, py::arg("scale_existing_results_factor") = 0.0f, py::arg("blocking") = true, py::arg("force_use_octree") = true)
+		.def("compute_and_save_png_slices", [](Testbed&, const std::string&, py::object, py::object, float, float, bool) { throw std::runtime_error{"compute_and_save_png_slices: density-slice export is not part of this build"}; },
+			py::arg("filename"), py::arg("resolution") = py::none(), py::arg("aabb") = py::none(), py::arg("thresh") = 3.4e38f, py::arg("density_range") = 4.f, py::arg("flip_y_and_z_axes") = false)
+		.def("compute_marching_cubes_mesh", [](Testbed&, py::object, py::object, float) -> py::dict { throw std::runtime_error{"compute_marching_cubes_mesh: mesh extraction is not part of this build"}; },
+			py::arg("resolution") = py::none(), py::arg("aabb") = py::none(), py::arg("thresh") = 3.4e38f)
+		.def("first_training_view", &Testbed::first_training_view).def("last_training_view", &Testbed::last_training_view)
+		.def("previous_training_view", &Testbed::previous_training_view).def("next_training_view", &Testbed::next_training_view)
+		.def("crop_box", [](Testbed& t, bool nerf_space) { return mat34_to_py(t.crop_box(nerf_space)); }, py::arg("nerf_space") = true)             // python_api.cu:729-731
+		.def("set_crop_box", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& m, bool nerf_space) { t.set_crop_box(mat34_from_py(m), nerf_space); }, py::arg("matrix"), py::arg("nerf_space") = true)
+		.def("crop_box_corners", [](Testbed& t, bool nerf_space) { py::list l; for (const Vec3& v : t.crop_box_corners(nerf_space)) l.append(vec3_to_py(v)); return l; }, py::arg("nerf_space") = true)
 		.def("want_repl", [](Testbed&) { return false; })                                                                  // python_api.cu:363 (GUI only)
 		.def("init_window", [](Testbed&, int, int, bool, bool) { throw std::runtime_error{"init_window: this build has no GUI (windowless rendering only)"}; },
 			py::arg("width"), py::arg("height"), py::arg("hidden") = false, py::arg("second_window") = false)
@@ -322,40 +406,44 @@ PYBIND11_MODULE(pyngp, m) {
 				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
 				return result;
 			}, "Requests a nerf render frame.", py::arg("render_request"))
-		.def("request_nerf_render_async", [](Testbed& t, const RenderRequest& req, const py::function& callback) {  // python_api.cu:192-231, 577
+		.def("request_nerf_render_async", [](Testbed& t, const RenderRequest& req, const py::function& render_callback) {  // python_api.cu:192-231, 577-580
 				if (!t.bl_try_begin_render()) return;   // a render is already in flight: the request is dropped (:218-220)
-				if (t.m_render_thread.joinable()) { py::gil_scoped_release rel; t.m_render_thread.join(); }
-				auto cb = std::make_shared<py::function>(callback);
-				t.m_render_thread = std::thread([&t, req, cb]() mutable {
-					std::vector<float> px;
-					std::string error;
-					try {
-						RenderBuffer& rb = t.m_bl_render_surface;
-						rb.resize(req.output.resolution[0], req.output.resolution[1]);
-						rb.reset_accumulation();
-						t.bl_render_frame(rb, req);
-						px.resize((size_t)req.output.resolution[0] * req.output.resolution[1] * 4);
-						rb.surface.copy_to_host(px.data(), px.size() * 4);
-					} catch (const std::exception& e) { error = e.what(); }
-					t.bl_end_render();   // before the callback, so that it may queue the next request
-					py::gil_scoped_acquire acquire;
-					try {
-						if (error.empty()) {
-							py::array_t<float> result({req.output.resolution[1], req.output.resolution[0], 4});
-							memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
-							(*cb)(result);
-						} else {
-							fprintf(stderr, "request_nerf_render_async failed: %s\n", error.c_str());
-						}
-					} catch (py::error_already_set& e) { fprintf(stderr, "render callback raised: %s\n", e.what()); }
-					cb.reset();   // drop the Python reference while the GIL is held
-				});
-			}, "Requests a nerf render frame.", py::arg("render_request"), py::arg("callback"))
-		.def("wait_for_render", [](Testbed& t) { py::gil_scoped_release rel; if (t.m_render_thread.joinable()) t.m_render_thread.join(); })
+				struct EndRender { Testbed& t; bool armed = true; ~EndRender() { if (armed) t.bl_end_render(); } void now() { if (armed) { armed = false; t.bl_end_render(); } } };
+				auto cb = std::make_shared<py::function>(render_callback);
+				try {
+					if (t.m_autofocus) t.autofocus();   // :222-224
+					t.bl_start_async([&t, req, cb]() mutable {
+						EndRender end{t};   // whatever happens below, the busy flag is cleared
+						std::vector<float> px;
+						std::string error;
+						try {
+							RenderBuffer& rb = t.m_bl_render_surface;
+							rb.resize(req.output.resolution[0], req.output.resolution[1]);
+							rb.reset_accumulation();
+							t.bl_render_frame(rb, req);
+							px.resize((size_t)req.output.resolution[0] * req.output.resolution[1] * 4);
+							rb.surface.copy_to_host(px.data(), px.size() * 4);
+						} catch (const std::exception& e) { error = e.what(); } catch (...) { error = "unknown error"; }
+						end.now();   // before the callback, so that it may queue the next request (from this very thread: nothing joins it)
+						py::gil_scoped_acquire acquire;
+						try {
+							if (error.empty()) {
+								py::array_t<float> result({req.output.resolution[1], req.output.resolution[0], 4});
+								memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+								(*cb)(result);
+							} else {
+								fprintf(stderr, "request_nerf_render_async failed: %s\n", error.c_str());
+							}
+						} catch (py::error_already_set& e) { fprintf(stderr, "render callback raised: %s\n", e.what()); }
+						cb.reset();   // drop the Python reference while the GIL is held
+					});
+				} catch (...) { t.bl_end_render(); throw; }
+			}, "Requests a nerf render frame.", py::arg("render_request"), py::arg("render_callback"))
+		.def("wait_for_render", [](Testbed& t) { py::gil_scoped_release rel; t.bl_wait_for_renders(); })
 		.def_readonly("bl_render_samples", &Testbed::m_bl_render_samples)
 		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& cam) { t.set_nerf_camera_matrix(mat34_from_py(cam)); })
 		.def("reset_camera", &Testbed::reset_camera)
-		.def("reset_accumulation", [](Testbed& t) { t.m_windowless_render_surface.reset_accumulation(); })
+		.def("reset_accumulation", [](Testbed& t, bool, bool) { t.m_windowless_render_surface.reset_accumulation(); }, py::arg("due_to_camera_movement") = false, py::arg("immediate_redraw") = true)
 		// data-parallel extension
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
 		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss, bool wait) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss, wait); } return py::make_tuple(c[0], c[1]); },
@@ -502,13 +590,35 @@ PYBIND11_MODULE(pyngp, m) {
 				return d;
 			})
 		.def_readwrite("shall_train", &Testbed::m_train)
+		.def_readwrite("shall_train_encoding", &Testbed::m_train_encoding)      // python_api.cu:656-657
+		.def_readwrite("shall_train_network", &Testbed::m_train_network)
+		.def_readwrite("render_groundtruth", &Testbed::m_render_ground_truth)   // GUI overlays and window state below: stored, read back, consumed by nothing headless
+		.def_property("groundtruth_render_mode", [](Testbed& t) { return (EGroundTruthRenderMode)t.m_ground_truth_render_mode; }, [](Testbed& t, EGroundTruthRenderMode v) { t.m_ground_truth_render_mode = (int)v; })
+		.def_readwrite("dynamic_res_target_fps", &Testbed::m_dynamic_res_target_fps)
+		.def_readwrite("fixed_res_factor", &Testbed::m_fixed_res_factor)
+		.def_readwrite("floor_enable", &Testbed::m_floor_enable)
+		.def_readwrite("display_gui", &Testbed::m_imgui_enabled)
+		.def_readwrite("visualize_unit_cube", &Testbed::m_visualize_unit_cube)
+		.def_readwrite("visualized_dimension", &Testbed::m_visualized_dimension)
+		.def_readwrite("visualized_layer", &Testbed::m_visualized_layer)
+		.def_readwrite("dlss_sharpening", &Testbed::m_dlss_sharpening)
+		.def_property("dlss", [](Testbed& t) { return t.m_dlss; }, [](Testbed& t, bool v) { if (v) throw std::runtime_error{"DLSS requires a Window to be initialized via `init_window`."}; t.m_dlss = false; })   // python_api.cu:713-727
+		.def_readonly("bounding_radius", &Testbed::m_bounding_radius)
+		.def_property("render_aabb_to_local", [](Testbed& t) { py::array_t<float> a({3, 3}); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.mutable_at(r, c) = t.m_render_aabb_to_local[3 * c + r]; return a; },
+			[](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& a) { if (a.ndim() != 2 || a.shape(0) != 3 || a.shape(1) != 3) throw std::runtime_error{"expected a 3x3 matrix"}; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) t.m_render_aabb_to_local[3 * c + r] = a.at(r, c); })
+		.def_property("fov_xy", [](Testbed& t) { float f[2]; t.fov_xy(f); py::array_t<float> a(2); a.mutable_data()[0] = f[0]; a.mutable_data()[1] = f[1]; return a; },
+			[](Testbed& t, const std::vector<float>& v) { if (v.size() != 2) throw std::runtime_error{"fov_xy takes 2 floats"}; t.set_fov_xy(v.data()); })
+		.def_property("sun_dir", [](Testbed& t) { return vec3_to_py(t.m_sun_dir); }, [](Testbed& t, const py::object& v) { t.m_sun_dir = vec3_from_py(v); })
+		.def_property("look_at", [](Testbed& t) { return vec3_to_py(t.look_at()); }, [](Testbed& t, const py::object& v) { t.set_look_at(vec3_from_py(v)); })
+		.def_property("view_dir", [](Testbed& t) { return vec3_to_py(t.view_dir()); }, [](Testbed& t, const py::object& v) { t.set_view_dir(vec3_from_py(v)); })
+		.def_property("parallax_shift", [](Testbed& t) { return std::vector<float>(t.m_parallax_shift, t.m_parallax_shift + 3); }, [](Testbed& t, const std::vector<float>& v) { for (int k = 0; k < 3; ++k) t.m_parallax_shift[k] = v.at(k); })
 		.def_readwrite("exposure", &Testbed::m_exposure)
 		.def_readwrite("snap_to_pixel_centers", &Testbed::m_snap_to_pixel_centers)
 		.def_readwrite("fov_axis", &Testbed::m_fov_axis)
 		.def_property("fov", &Testbed::fov, &Testbed::set_fov)
 		.def_readwrite("color_space", &Testbed::m_color_space)
 		.def_readwrite("zoom", &Testbed::m_zoom)
-		.def_readwrite("scale", &Testbed::m_scale)
+		.def_property("scale", &Testbed::scale, &Testbed::set_scale)            // python_api.cu:669 (moves the camera along its view ray, testbed.cu:231-235)
 		.def_readwrite("seed", &Testbed::m_seed)
 		.def_readwrite("training_batch_size", &Testbed::m_training_batch_size)
 		.def_readwrite("max_level_rand_training", &Testbed::m_max_level_rand_training)
@@ -540,18 +650,22 @@ PYBIND11_MODULE(pyngp, m) {
 				if (m != ERenderMode::AO && m != ERenderMode::Shade && m != ERenderMode::Positions && m != ERenderMode::Depth && m != ERenderMode::Cost)
 					throw std::runtime_error{"RenderMode: AO, Shade, Positions, Depth and Cost are built (Normals / Distortion / Slice / EncodingVis need input gradients, the distortion map or the slice evaluator)"};
 				t.m_render_mode = m; })
-		.def("set_camera_to_training_view", [](Testbed& t, int i) {   // testbed_nerf.cu: camera <- training view i (already in NGP convention)
-				if (i < 0 || (size_t)i >= t.m_nerf.training.dataset.n_images) throw std::runtime_error{"Invalid training view"};
-				memcpy(t.m_camera.m, t.m_nerf.training.transforms[i].start, sizeof(t.m_camera.m));   // testbed.cu:273-281 (rolling shutter time 0)
-				const NgpImageMeta& m = t.m_nerf.training.dataset.metadata[i];
-				t.m_relative_focal_length[0] = m.focal_length[0] / (float)m.res[t.m_fov_axis]; t.m_relative_focal_length[1] = m.focal_length[1] / (float)m.res[t.m_fov_axis];
-				t.m_nerf.render_with_lens_distortion = true;
-				t.m_nerf.render_lens_proxy = m;
-				const NgpImageMeta& m0 = t.m_nerf.training.dataset.metadata[0];
-				t.m_screen_center[0] = 1.f - m0.principal_point[0]; t.m_screen_center[1] = 1.f - m0.principal_point[1];
-			}, py::arg("trainview"))
+		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view, py::arg("trainview"))
 		.def("clear_training_data", [](Testbed& t) { t.m_training_data_available = false; t.m_nerf.training.n_images_for_training = 0; })
-		.def_readonly("nerf", &Testbed::m_nerf);
+		.def_readonly("nerf", &Testbed::m_nerf)
+		.def_readonly("image", &Testbed::m_image)                                // python_api.cu:707, 875-886
+		.def_readonly("sdf", &Testbed::m_sdf);
+
+	py::class_<Testbed::ImageState> image(testbed, "Image");
+	image
+		.def_property_readonly("training", [](Testbed::ImageState& i) -> Testbed::ImageState& { return i; }, py::return_value_policy::reference_internal)   // .training.snap_to_pixel_centers / .linear_colors live on the same record
+		.def_readwrite("snap_to_pixel_centers", &Testbed::ImageState::snap_to_pixel_centers)
+		.def_readwrite("linear_colors", &Testbed::ImageState::linear_colors)
+		.def_property("random_mode", [](Testbed::ImageState& i) { return i.stratified ? ERandomMode::Stratified : ERandomMode::Random; },
+			[](Testbed::ImageState& i, ERandomMode m) { if (m != ERandomMode::Stratified && m != ERandomMode::Random) throw std::runtime_error{"Image.random_mode: Random and Stratified are built (Halton / Sobol are not)"}; i.stratified = m == ERandomMode::Stratified; })
+		.def_property("pos", [](Testbed::ImageState& i) { return std::vector<float>{i.pos[0], i.pos[1]}; }, [](Testbed::ImageState& i, const std::vector<float>& v) { i.pos[0] = v.at(0); i.pos[1] = v.at(1); });
+	py::class_<Testbed::SdfState>(testbed, "Sdf")
+		.def_readwrite("mesh_scale", &Testbed::SdfState::mesh_scale);
 
 	py::class_<Nerf> nerf(testbed, "Nerf");
 	nerf
@@ -567,6 +681,11 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("render_n_streams", &Nerf::render_n_streams)
 		.def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
 		.def_readwrite("show_accel", &Nerf::show_accel)
+		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)
+		.def_readwrite("glow_y_cutoff", &Nerf::glow_y_cutoff)
+		.def_readwrite("glow_mode", &Nerf::glow_mode)
+		.def_property("render_lens", [](Nerf& n) { return PyLens::from(n.render_lens_proxy); }, [](Nerf& n, const PyLens& l) { l.to(n.render_lens_proxy); })          // python_api.cu:750-751
+		.def_property("render_distortion", [](Nerf& n) { return PyLens::from(n.render_lens_proxy); }, [](Nerf& n, const PyLens& l) { l.to(n.render_lens_proxy); })   // legacy name
 		.def_readonly("max_cascade", &Nerf::max_cascade)
 		.def("density_grid_bitfield", [](Nerf& n) {
 				py::array_t<uint8_t> a((py::ssize_t)n.density_grid_bitfield.bytes());
@@ -590,6 +709,17 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
 		.def_readwrite("optimize_exposure", &NerfTraining::optimize_exposure)                   // python_api.cu:813
+		.def_readwrite("optimize_extrinsics", &NerfTraining::optimize_extrinsics)               // python_api.cu:811-815: switches of trainables this build lacks; train() refuses while one is set
+		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)
+		.def_readwrite("optimize_distortion", &NerfTraining::optimize_distortion)
+		.def_readwrite("optimize_focal_length", &NerfTraining::optimize_focal_length)
+		.def_readwrite("n_steps_between_cam_updates", &NerfTraining::n_steps_between_cam_updates)
+		.def_readwrite("include_sharpness_in_error", &NerfTraining::include_sharpness_in_error)
+		.def_readwrite("extrinsic_l2_reg", &NerfTraining::extrinsic_l2_reg)
+		.def_readwrite("extrinsic_learning_rate", &NerfTraining::extrinsic_learning_rate)
+		.def_readwrite("intrinsic_l2_reg", &NerfTraining::intrinsic_l2_reg)
+		.def_property_readonly("dataset", py::cpp_function([](NerfTraining& t) { return PyNerfDataset{&t.dataset}; }, py::keep_alive<0, 1>()))   // python_api.cu:830
+		.def_property_readonly("transforms", [](NerfTraining& t) { py::list l; for (const NgpXForm& x : t.transforms) { Mat34 a, b; memcpy(a.m, x.start, 48); memcpy(b.m, x.end, 48); l.append(py::make_tuple(mat34_to_py(a), mat34_to_py(b))); } return l; })
 		.def_readwrite("exposure_l2_reg", &NerfTraining::exposure_l2_reg)                       // python_api.cu:827
 		.def("get_camera_exposures", [](NerfTraining& t) {                                      // [n_images][3] log2 exposures as the loss kernel sees them
 				py::array_t<float> a({(py::ssize_t)t.dataset.n_images, (py::ssize_t)3});

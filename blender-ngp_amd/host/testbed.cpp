@@ -61,9 +61,10 @@ void DeviceBuffer::copy_to_host(void* dst, size_t bytes, size_t src_offset) cons
 size_t DeviceBuffer::total_allocated() { return g_total_allocated; }
 
 // ------------------------------------------------------------------------------------------------ dataset
-Mat34 NerfDataset::nerf_matrix_to_ngp(const Mat34& in) const {
+Mat34 NerfDataset::nerf_matrix_to_ngp(const Mat34& in, bool scale_columns) const {
 	Mat34 r = in;
-	for (int k = 0; k < 3; ++k) { r.m[3 + k] *= -1.f; r.m[6 + k] *= -1.f; }
+	const float s0 = scale_columns ? scale : 1.f, s12 = scale_columns ? -scale : -1.f;
+	for (int k = 0; k < 3; ++k) { r.m[k] *= s0; r.m[3 + k] *= s12; r.m[6 + k] *= s12; }
 	r.m[9] = r.m[9] * scale + offset.x; r.m[10] = r.m[10] * scale + offset.y; r.m[11] = r.m[11] * scale + offset.z;
 	if (from_mitsuba) {
 		for (int k = 0; k < 3; ++k) { r.m[k] *= -1.f; r.m[6 + k] *= -1.f; }
@@ -73,14 +74,15 @@ Mat34 NerfDataset::nerf_matrix_to_ngp(const Mat34& in) const {
 	}
 	return r;
 }
-Mat34 NerfDataset::ngp_matrix_to_nerf(const Mat34& in) const {
+Mat34 NerfDataset::ngp_matrix_to_nerf(const Mat34& in, bool scale_columns) const {
 	Mat34 r = in;
 	if (from_mitsuba) {
 		for (int k = 0; k < 3; ++k) { r.m[k] *= -1.f; r.m[6 + k] *= -1.f; }
 	} else {
 		for (int c = 0; c < 4; ++c) { float t = r.m[3 * c + 2]; r.m[3 * c + 2] = r.m[3 * c + 1]; r.m[3 * c + 1] = r.m[3 * c]; r.m[3 * c] = t; }
 	}
-	for (int k = 0; k < 3; ++k) { r.m[3 + k] *= -1.f; r.m[6 + k] *= -1.f; }
+	const float s0 = scale_columns ? 1.f / scale : 1.f, s12 = scale_columns ? -1.f / scale : -1.f;
+	for (int k = 0; k < 3; ++k) { r.m[k] *= s0; r.m[3 + k] *= s12; r.m[6 + k] *= s12; }
 	r.m[9] = (r.m[9] - offset.x) / scale; r.m[10] = (r.m[10] - offset.y) / scale; r.m[11] = (r.m[11] - offset.z) / scale;
 	return r;
 }
@@ -215,10 +217,10 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	bl_wait_for_renders();   // before any stream goes away (a Python owner releases the GIL around this wait: python_api.cpp TestbedDeleter)
 	for (void* st : m_render_streams) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
 	if (m_render_host_words) (void)hipHostFree(m_render_host_words);
 	if (m_render_event) (void)hipEventDestroy((hipEvent_t)m_render_event);
-	if (m_render_thread.joinable()) m_render_thread.join();
 	(void)hipDeviceSynchronize();
 	if (m_host_words) (void)hipHostFree(m_host_words);
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
@@ -293,6 +295,121 @@ float Testbed::fov() const { return 2.f * 180.f / 3.14159265358979323846f * atan
 void Testbed::set_fov(float val) {
 	const float f = 0.5f * 1.0f / tanf(0.5f * val * 3.14159265358979323846f / 180.f);
 	m_relative_focal_length[0] = m_relative_focal_length[1] = f;
+}
+void Testbed::fov_xy(float out[2]) const { for (int k = 0; k < 2; ++k) out[k] = 2.f * 180.f / 3.14159265358979323846f * atanf(1.0f / (m_relative_focal_length[k] * 2.f)); }
+void Testbed::set_fov_xy(const float val[2]) { for (int k = 0; k < 2; ++k) m_relative_focal_length[k] = 0.5f * 1.0f / tanf(0.5f * val[k] * 3.14159265358979323846f / 180.f); }
+
+static inline Vec3 v3_add(Vec3 a, Vec3 b) { return Vec3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline Vec3 v3_sub(Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline Vec3 v3_mul(Vec3 a, float s) { return Vec3{a.x * s, a.y * s, a.z * s}; }
+static inline float v3_dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline Vec3 v3_cross(Vec3 a, Vec3 b) { return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline Vec3 v3_normalized(Vec3 a) { const float n = std::sqrt(v3_dot(a, a)); return n > 0.f ? v3_mul(a, 1.f / n) : a; }
+
+// position lerp + rotation slerp between two column-major 3x4 poses (Eigen: Quaternionf(R0).slerp(t, Quaternionf(R1)).normalized().toRotationMatrix())
+static void mat_to_quat(const float* m, float q[4]) {   // q = (w, x, y, z); R(r, c) = m[3 c + r]
+	auto R = [&](int r, int c) { return m[3 * c + r]; };
+	const float tr = R(0, 0) + R(1, 1) + R(2, 2);
+	if (tr > 0.f) {
+		float t = std::sqrt(tr + 1.0f); q[0] = 0.5f * t; t = 0.5f / t;
+		q[1] = (R(2, 1) - R(1, 2)) * t; q[2] = (R(0, 2) - R(2, 0)) * t; q[3] = (R(1, 0) - R(0, 1)) * t;
+	} else {
+		int i = 0; if (R(1, 1) > R(0, 0)) i = 1; if (R(2, 2) > R(i, i)) i = 2;
+		const int j = (i + 1) % 3, k = (j + 1) % 3;
+		float t = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.0f);
+		q[1 + i] = 0.5f * t; t = 0.5f / t;
+		q[0] = (R(k, j) - R(j, k)) * t; q[1 + j] = (R(j, i) + R(i, j)) * t; q[1 + k] = (R(k, i) + R(i, k)) * t;
+	}
+}
+static Mat34 pose_lerp(const float* p0, const float* p1, float t) {
+	Mat34 rv;
+	if (t == 0.f || memcmp(p0, p1, sizeof(float) * 12) == 0) { memcpy(rv.m, p0, sizeof(rv.m)); return rv; }
+	float a[4], b[4], q[4];
+	mat_to_quat(p0, a); mat_to_quat(p1, b);
+	const float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3], ad = std::fabs(d);
+	float s0, s1;
+	if (ad >= 1.0f - 1.1920929e-07f) { s0 = 1.0f - t; s1 = t; }
+	else { const float th = std::acos(ad), st = std::sin(th); s0 = std::sin((1.0f - t) * th) / st; s1 = std::sin(t * th) / st; }
+	if (d < 0.f) s1 = -s1;
+	for (int k = 0; k < 4; ++k) q[k] = s0 * a[k] + s1 * b[k];
+	const float n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+	for (int k = 0; k < 4; ++k) q[k] /= n;
+	const float w = q[0], x = q[1], y = q[2], z = q[3];
+	const float Rm[9] = {1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w),      // column 0
+	                     2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w),      // column 1
+	                     2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y)};     // column 2
+	memcpy(rv.m, Rm, sizeof(Rm));
+	for (int k = 0; k < 3; ++k) rv.m[9 + k] = p0[9 + k] + (p1[9 + k] - p0[9 + k]) * t;
+	return rv;
+}
+
+Vec3 Testbed::look_at() const { return v3_add(view_pos(), v3_mul(view_dir(), m_scale)); }                       // testbed.cu:223-225
+void Testbed::set_look_at(const Vec3& pos) { const Vec3 d = v3_sub(pos, look_at()); m_camera.m[9] += d.x; m_camera.m[10] += d.y; m_camera.m[11] += d.z; }
+void Testbed::set_scale(float scale) {                                                                          // testbed.cu:231-235
+	const Vec3 prev = look_at();
+	const Vec3 p = v3_add(v3_mul(v3_sub(view_pos(), prev), scale / m_scale), prev);
+	m_camera.m[9] = p.x; m_camera.m[10] = p.y; m_camera.m[11] = p.z;
+	m_scale = scale;
+}
+void Testbed::set_view_dir(const Vec3& dir) {                                                                    // testbed.cu:237-243
+	const Vec3 old = look_at();
+	const Vec3 c0 = v3_normalized(v3_cross(dir, m_up_dir)), c1 = v3_normalized(v3_cross(dir, c0)), c2 = v3_normalized(dir);
+	const Vec3 cols[3] = {c0, c1, c2};
+	for (int c = 0; c < 3; ++c) { m_camera.m[3 * c] = cols[c].x; m_camera.m[3 * c + 1] = cols[c].y; m_camera.m[3 * c + 2] = cols[c].z; }
+	set_look_at(old);
+}
+void Testbed::set_camera_to_training_view(int trainview) {                                                       // testbed.cu:273-281
+	NerfTraining& tr = m_nerf.training;
+	if (trainview < 0 || (size_t)trainview >= tr.dataset.n_images) throw std::runtime_error{"Invalid training view"};
+	const Vec3 old_look_at = look_at();
+	const NgpImageMeta& m = tr.dataset.metadata[trainview];
+	// get_xform_given_rolling_shutter(xform, rolling_shutter, uv = (0.5, 0.5), motionblur_time = 0) (common_device.cuh:224-234)
+	const float t = m.rolling_shutter[0] + m.rolling_shutter[1] * 0.5f + m.rolling_shutter[2] * 0.5f;
+	m_camera = pose_lerp(tr.transforms[trainview].start, tr.transforms[trainview].end, t);
+	m_relative_focal_length[0] = m.focal_length[0] / (float)m.res[m_fov_axis]; m_relative_focal_length[1] = m.focal_length[1] / (float)m.res[m_fov_axis];
+	m_scale = std::max(v3_dot(v3_sub(old_look_at, view_pos()), view_dir()), 0.1f);
+	m_nerf.render_with_lens_distortion = true;
+	m_nerf.render_lens_proxy = m;
+	const NgpImageMeta& m0 = tr.dataset.metadata[0];
+	m_screen_center[0] = 1.f - m0.principal_point[0]; m_screen_center[1] = 1.f - m0.principal_point[1];
+}
+void Testbed::first_training_view() { m_nerf.training.view = 0; set_camera_to_training_view(0); m_windowless_render_surface.reset_accumulation(); }
+void Testbed::last_training_view() { m_nerf.training.view = (int)m_nerf.training.dataset.n_images - 1; set_camera_to_training_view(m_nerf.training.view); m_windowless_render_surface.reset_accumulation(); }
+void Testbed::previous_training_view() { if (m_nerf.training.view != 0) m_nerf.training.view -= 1; set_camera_to_training_view(m_nerf.training.view); m_windowless_render_surface.reset_accumulation(); }
+void Testbed::next_training_view() { if (m_nerf.training.view != (int)m_nerf.training.dataset.n_images - 1) m_nerf.training.view += 1; set_camera_to_training_view(m_nerf.training.view); m_windowless_render_surface.reset_accumulation(); }
+
+// m_render_aabb_to_local is a column-major 3x3 (element (r, c) at [3 c + r]), like the Eigen matrix it replaces
+Mat34 Testbed::crop_box(bool nerf_space) const {                                                                  // testbed.cu:395-410
+	const float* L = m_render_aabb_to_local;
+	const float c[3] = {0.5f * (m_render_aabb.min[0] + m_render_aabb.max[0]), 0.5f * (m_render_aabb.min[1] + m_render_aabb.max[1]), 0.5f * (m_render_aabb.min[2] + m_render_aabb.max[2])};
+	const float rad[3] = {0.5f * (m_render_aabb.max[0] - m_render_aabb.min[0]), 0.5f * (m_render_aabb.max[1] - m_render_aabb.min[1]), 0.5f * (m_render_aabb.max[2] - m_render_aabb.min[2])};
+	Mat34 rv;
+	for (int k = 0; k < 3; ++k) {
+		rv.m[9 + k] = L[3 * k + 0] * c[0] + L[3 * k + 1] * c[1] + L[3 * k + 2] * c[2];   // cen = L^T * center
+		for (int ax = 0; ax < 3; ++ax) rv.m[3 * ax + k] = L[3 * k + ax] * rad[ax];         // column ax = row ax of L, times the radius
+	}
+	if (nerf_space) rv = m_nerf.training.dataset.ngp_matrix_to_nerf(rv, true);
+	return rv;
+}
+void Testbed::set_crop_box(Mat34 m, bool nerf_space) {                                                            // testbed.cu:412-424
+	if (nerf_space) m = m_nerf.training.dataset.nerf_matrix_to_ngp(m, true);
+	float rad[3];
+	for (int ax = 0; ax < 3; ++ax) rad[ax] = std::sqrt(m.m[3 * ax] * m.m[3 * ax] + m.m[3 * ax + 1] * m.m[3 * ax + 1] + m.m[3 * ax + 2] * m.m[3 * ax + 2]);
+	float* L = m_render_aabb_to_local;
+	for (int ax = 0; ax < 3; ++ax) for (int k = 0; k < 3; ++k) L[3 * k + ax] = m.m[3 * ax + k] / rad[ax];   // row ax of L = column ax of m / radius
+	for (int r = 0; r < 3; ++r) {
+		const float cen = L[r] * m.m[9] + L[3 + r] * m.m[10] + L[6 + r] * m.m[11];
+		m_render_aabb.min[r] = cen - rad[r]; m_render_aabb.max[r] = cen + rad[r];
+	}
+}
+std::vector<Vec3> Testbed::crop_box_corners(bool nerf_space) const {                                             // testbed.cu:426-445
+	const Mat34 m = crop_box(nerf_space);
+	std::vector<Vec3> rv(8);
+	for (int i = 0; i < 8; ++i) {
+		const float v[3] = {(i & 1) ? 1.f : -1.f, (i & 2) ? 1.f : -1.f, (i & 4) ? 1.f : -1.f};
+		rv[i] = Vec3{m.m[0] * v[0] + m.m[3] * v[1] + m.m[6] * v[2] + m.m[9], m.m[1] * v[0] + m.m[4] * v[1] + m.m[7] * v[2] + m.m[10], m.m[2] * v[0] + m.m[5] * v[1] + m.m[8] * v[2] + m.m[11]};
+	}
+	return rv;
 }
 
 void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:196-218 (Nerf mode) -> Testbed::load_nerf (testbed_nerf.cu:2735-2759)
@@ -622,6 +739,12 @@ void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
+	{
+		const NerfTraining& tr = m_nerf.training;
+		if (tr.optimize_extrinsics || tr.optimize_focal_length || tr.optimize_distortion || tr.optimize_extra_dims)
+			throw std::runtime_error{"nerf.training.optimize_extrinsics / optimize_focal_length / optimize_distortion / optimize_extra_dims: these camera-side trainables "
+			                         "(testbed_nerf.cu:1600-1746, 3056-3135) are not part of this build (optimize_exposure is)"};
+	}
 	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / _dp_backward / _dp_end around the all-reduces"};
 	uint32_t counters[2];
 	train_nerf_dp_begin(target_batch_size, counters, get_loss_scalar);
@@ -903,9 +1026,9 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
 	++m_optimizer_step;
 	profile_begin(PK_OPTIMIZER);
-	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
-	                             m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
-	                             m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>()), "optimizer_step");
+	check(ngp_hip_optimizer_step_masked(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	                                    m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
+	                                    m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>(), (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u)), "optimizer_step");
 	profile_end(PK_OPTIMIZER, m_n_params);
 	// tcnn ExponentialDecay::step: after the nested step, lr *= decay_base whenever the step count hits start + k * interval
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
@@ -1016,7 +1139,27 @@ std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool l
 	m_render_samples_evaluated = 0;
 	if (m_autofocus) autofocus();   // python_api.cu:174-176
 	auto start = std::chrono::steady_clock::now();
-	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, rb, !linear);
+	const float no_rolling_shutter[4] = {0.f, 0.f, 0.f, 0.f};   // python_api.cu:177 (Vector4f::Zero())
+	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, no_rolling_shutter, rb, !linear);
+	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
+	std::vector<float> out((size_t)width * height * 4);
+	rb.surface.copy_to_host(out.data(), out.size() * 4);
+	return out;
+}
+
+std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height,
+                                                               int spp, bool linear) {  // python_api.cu:262-275
+	if (m_n_params == 0) throw std::runtime_error{"render_with_rolling_shutter(): no network"};
+	RenderBuffer& rb = m_windowless_render_surface;
+	rb.resize(width, height);
+	rb.reset_accumulation();
+	m_render_samples_evaluated = 0;
+	const Mat34 c0 = m_nerf.training.dataset.nerf_matrix_to_ngp(camera_transform_start), c1 = m_nerf.training.dataset.nerf_matrix_to_ngp(camera_transform_end);
+	auto start = std::chrono::steady_clock::now();
+	for (int i = 0; i < spp; ++i) {
+		if (m_autofocus) autofocus();
+		render_frame(c0, c1, rolling_shutter, rb, !linear);
+	}
 	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	std::vector<float> out((size_t)width * height * 4);
 	rb.surface.copy_to_host(out.data(), out.size() * 4);
@@ -1033,7 +1176,7 @@ void Testbed::autofocus() {  // testbed.cu:2933-2941: focus on m_autofocus_targe
 	}
 }
 
-void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb) {  // testbed.cu:2695-2911
+void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], RenderBuffer& rb, bool to_srgb) {  // testbed.cu:2695-2911
 	rb.frame_buffer.memset(0, m_stream);
 	rb.depth_buffer.memset(0, m_stream);
 	if (m_testbed_mode == ETestbedMode::Image) {
@@ -1050,7 +1193,8 @@ void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& r
 	if (m_testbed_mode == ETestbedMode::Sdf) throw std::runtime_error{"rendering an SDF (sphere tracing, testbed_sdf.cu) is outside the scope of this build; P2 covers the training step"};
 	const float focal_length[2] = {m_relative_focal_length[0] * (float)rb.res[m_fov_axis] * m_zoom, m_relative_focal_length[1] * (float)rb.res[m_fov_axis] * m_zoom};
 	const float screen_center[2] = {(0.5f - m_screen_center[0]) * m_zoom + 0.5f, (0.5f - m_screen_center[1]) * m_zoom + 0.5f};
-	render_nerf(rb, focal_length, cam0, cam1, screen_center);
+	if (m_nerf.glow_mode != 0) throw std::runtime_error{"nerf.glow_mode: the glow shading (testbed_nerf.cu:843-871) is not part of this build"};
+	render_nerf(rb, focal_length, cam0, cam1, rolling_shutter, screen_center);
 	// CudaRenderBuffer::accumulate / tonemap (render_buffer.cu:609-664)
 	if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);
 	rb.color_space = m_color_space;
@@ -1061,7 +1205,7 @@ void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& r
 	sync();
 }
 
-void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float screen_center[2]) {  // testbed_nerf.cu:2354-2500, 2047-2267
+void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], const float screen_center[2]) {  // testbed_nerf.cu:2354-2500, 2047-2267
 	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)rb.res[1];
 	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY);
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
@@ -1073,7 +1217,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	const int lens_mode = m_nerf.render_with_lens_distortion ? m_nerf.render_lens_proxy.lens_mode : 0;   // testbed_nerf.cu:2381
 	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
 	const uint32_t sample_index = rb.spp;
-	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, zero4, screen_center, zero3, m_snap_to_pixel_centers,
+	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, zero3, m_snap_to_pixel_centers,
 	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
 	                        m_slice_plane_z + m_scale /* plane_z (2355); the Slice render mode, which negates it, is not built */, m_aperture_size,
 	                        m_render_camera_models.model ? &m_render_camera_models : nullptr), "init_rays");
@@ -1181,6 +1325,24 @@ void Testbed::bl_render_frame(RenderBuffer& rb, const RenderRequest& request) { 
 	sync();
 }
 
+void Testbed::bl_start_async(std::function<void()> job) {
+	{ std::lock_guard<std::mutex> lock(m_render_mutex); ++m_render_workers; }
+	try {
+		std::thread([this, job]() {
+			try { job(); } catch (...) {}
+			{ std::lock_guard<std::mutex> lock(m_render_mutex); --m_render_workers; }
+			m_render_cv.notify_all();
+		}).detach();
+	} catch (...) {
+		{ std::lock_guard<std::mutex> lock(m_render_mutex); --m_render_workers; }
+		throw;
+	}
+}
+void Testbed::bl_wait_for_renders() {
+	std::unique_lock<std::mutex> lock(m_render_mutex);
+	m_render_cv.wait(lock, [this]() { return m_render_workers == 0; });
+}
+
 bool Testbed::bl_try_begin_render() { bool expected = false; return m_currently_rendering.compare_exchange_strong(expected, true); }
 void Testbed::bl_end_render() { m_currently_rendering.store(false); }
 
@@ -1189,6 +1351,7 @@ std::vector<float> Testbed::bl_request_nerf_render_sync(const RenderRequest& req
 	std::vector<float> out((size_t)w * h * 4, 0.f);
 	if (!bl_try_begin_render()) return out;   // the reference returns the untouched array while another render is in flight (:235-237)
 	try {
+		if (m_autofocus) autofocus();   // python_api.cu:240
 		RenderBuffer& rb = m_bl_render_surface;
 		rb.resize(w, h);
 		rb.reset_accumulation();

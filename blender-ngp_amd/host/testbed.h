@@ -9,6 +9,9 @@
 #pragma once
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -101,8 +104,8 @@ struct NerfDataset {
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
 
-	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix) const;   // nerf_loader.h:113-132
-	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix) const;    // nerf_loader.h:134-152
+	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix, bool scale_columns = false) const;   // nerf_loader.h:113-132
+	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix, bool scale_columns = false) const;    // nerf_loader.h:134-152
 	void set_training_image(int frame_idx, int w, int h, const void* pixels_host, int image_data_type, const float* depth_host = nullptr, float depth_scale = -1.f); // nerf_loader.cu:749-
 	void sharpen_training_image(int frame_idx, float sharpen_amount);   // nerf_loader.cu:803-825: Byte -> half4, then the unsharp filter
 	void update_metadata(int first = 0, int last = -1);         // nerf_loader.cu:851-867
@@ -132,6 +135,12 @@ struct NerfTraining {
 	DeviceBuffer cam_exposure_gradient_gpu;
 	bool optimize_exposure = false;
 	float exposure_l2_reg = 0.0f;
+	// camera-side trainables of testbed.h:651-662 that this build does not train: the switches exist so that a script setting them fails loudly
+	// in train() instead of silently training something else (python_api.cu:804-812)
+	bool optimize_extrinsics = false, optimize_extra_dims = false, optimize_distortion = false, optimize_focal_length = false;
+	bool include_sharpness_in_error = false;                       // testbed.h:670 (the sharpness map is not computed by this loader)
+	float extrinsic_l2_reg = 1e-4f, extrinsic_learning_rate = 1e-3f, intrinsic_l2_reg = 1e-4f;   // testbed.h:673-678
+	int view = 0;                                                  // current training view of the GUI navigation (testbed.h:636)
 	uint32_t n_steps_between_cam_updates = 16, n_steps_since_cam_update = 0;
 	NerfCounters counters_rgb;
 	Pcg32 density_grid_rng;
@@ -184,6 +193,8 @@ struct Nerf {
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
+	bool visualize_cameras = false;          // GUI-side (stored)
+	float glow_y_cutoff = 0.f; int glow_mode = 0;   // testbed.h:730-731; the glow shading of composite_kernel_nerf is not built (glow_mode != 0 throws in render)
 	NgpImageMeta render_lens_proxy{};        // only lens_mode / lens_params are used (render_lens)
 };
 
@@ -278,7 +289,11 @@ public:
 	void bl_end_render();
 	uint64_t m_bl_render_samples = 0;
 	RenderBuffer m_bl_render_surface;
-	std::thread m_render_thread;                       // request_nerf_render_async worker (joined before the next request / on destruction)
+	// request_nerf_render_async workers: detached like the reference's (python_api.cu:228-229), but counted, so that the Testbed can wait for them
+	// (a worker may itself queue the next request from its callback — nobody ever joins a thread, least of all itself)
+	void bl_start_async(std::function<void()> job);
+	void bl_wait_for_renders();
+	std::mutex m_render_mutex; std::condition_variable m_render_cv; int m_render_workers = 0;
 	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
@@ -299,12 +314,29 @@ public:
 
 	// ---- rendering (python_api.cu:132-190; testbed.cu:2695-2911; testbed_nerf.cu:2047-2267, 2354-2500)
 	std::vector<float> render_to_cpu(int width, int height, int spp, bool linear);
-	void render_frame(const Mat34& cam0, const Mat34& cam1, RenderBuffer& rb, bool to_srgb);
-	void render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float screen_center[2]);
+	void render_frame(const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], RenderBuffer& rb, bool to_srgb);
+	void render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], const float screen_center[2]);
 	void set_nerf_camera_matrix(const Mat34& cam) { m_camera = m_nerf.training.dataset.nerf_matrix_to_ngp(cam); } // testbed.cu:219-221
 	void reset_camera();
 	float fov() const;
 	void set_fov(float val);
+	void fov_xy(float out[2]) const;                                   // testbed.cu:2161-2167
+	void set_fov_xy(const float val[2]);
+	// camera helpers of testbed.cu:223-243 (column-major 3x4: columns 0..2 = right / up(down) / view direction, column 3 = position)
+	Vec3 view_pos() const { return Vec3{m_camera.m[9], m_camera.m[10], m_camera.m[11]}; }
+	Vec3 view_dir() const { return Vec3{m_camera.m[6], m_camera.m[7], m_camera.m[8]}; }
+	Vec3 look_at() const;
+	void set_look_at(const Vec3& pos);
+	void set_view_dir(const Vec3& dir);
+	float scale() const { return m_scale; }
+	void set_scale(float scale);
+	void set_camera_to_training_view(int trainview);                   // testbed.cu:273-281
+	void first_training_view(); void last_training_view(); void previous_training_view(); void next_training_view();   // testbed.cu:245-271
+	Mat34 crop_box(bool nerf_space) const;                             // testbed.cu:395-445
+	void set_crop_box(Mat34 m, bool nerf_space);
+	std::vector<Vec3> crop_box_corners(bool nerf_space) const;
+	// python_api.cu:262-275: spp frames between two camera poses, per-ray time A + B u + C v + D t from `rolling_shutter`
+	std::vector<float> render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height, int spp, bool linear);
 
 	// ---- snapshots (testbed.cu:3006-3106) — next-row f1, see DESIGN.md
 	void save_snapshot(const std::string& path, bool include_optimizer_state);
@@ -318,6 +350,7 @@ public:
 	ETestbedMode m_testbed_mode;
 	Nerf m_nerf;
 	bool m_train = false;
+	bool m_train_encoding = true, m_train_network = true;   // testbed.h:914-915: Adam's optimize_non_matrix_params / optimize_matrix_params (testbed.cu:2556-2563)
 	bool m_training_data_available = false;
 	uint32_t m_training_step = 0;
 	uint32_t m_training_batch_size = 1 << 18;          // testbed.h:909
@@ -341,6 +374,11 @@ public:
 	void autofocus();                                  // testbed.cu:2933-2941
 	Mat34 m_camera;
 	bool m_camera_smoothing = false, m_loop_animation = false, m_dynamic_res = false;   // GUI-side state kept for script compatibility
+	float m_dynamic_res_target_fps = 20.0f; int m_fixed_res_factor = 8;                 // testbed.h:521-522
+	bool m_imgui_enabled = true, m_visualize_unit_cube = false, m_floor_enable = false, m_dlss = false; float m_dlss_sharpening = 0.0f;
+	bool m_render_ground_truth = false; int m_ground_truth_render_mode = 0;             // testbed.h:880-881 (GUI overlay of the training images)
+	int m_visualized_dimension = -1; uint32_t m_visualized_layer = 0;                   // EncodingVis / neuron visualisation (not built)
+	Vec3 m_sun_dir{0.57735027f, 0.57735027f, 0.57735027f}; float m_parallax_shift[3] = {0.f, 0.f, 0.f};
 	Vec3 m_up_dir{0.f, 1.f, 0.f};
 	float m_relative_focal_length[2] = {1.f, 1.f};
 	uint32_t m_fov_axis = 1;

@@ -145,6 +145,12 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
                            float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
                            float* first_moments, float* second_moments, float* ema, uint16_t* inference_params);
+/* The same step with tcnn Adam's `optimize_matrix_params` (bit 0 of optimize_mask: the MLP weights) and `optimize_non_matrix_params` (bit 1: the
+ * encoding) switches — what Testbed::train sets from `shall_train_network` / `shall_train_encoding` every step (src/testbed.cu:2556-2563).  A
+ * parameter class that is switched off keeps its weights and moments; the Ema copy is updated for every parameter either way. */
+int ngp_hip_optimizer_step_masked(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
+                                  float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
+                                  float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask);
 
 /* ============================ occupancy grid (src/testbed_nerf.cu:369-610, 2761-2859) ============================ */
 int ngp_hip_mark_untrained_density_grid(void* stream, uint32_t n_elements, float* grid_out, uint32_t n_training_images,

@@ -151,6 +151,37 @@ def test_request_nerf_render_async_and_errors(cuda, two_snapshots, tmp_path):
     assert done.wait(60.0)
     tb.wait_for_render()
     np.testing.assert_array_equal(got[0], sync_img)
+    # the add-on's progressive preview: the callback queues the NEXT request itself (it runs on the worker thread), by keyword like
+    # python_api.cu:577-580; three frames chain without a join of the worker on itself, and the busy flag is free afterwards
+    chain, chain_done = [], threading.Event()
+
+    def chained(arr):
+        chain.append(np.array(arr))
+        if len(chain) < 3:
+            tb.request_nerf_render_async(render_request=req, render_callback=chained)
+        else:
+            chain_done.set()
+
+    tb.request_nerf_render_async(render_request=req, render_callback=chained)
+    assert chain_done.wait(120.0) and len(chain) == 3
+    tb.wait_for_render()
+    for c in chain:
+        np.testing.assert_array_equal(c, sync_img)
+    # a failing async request (missing snapshot) reports on stderr, never calls back, and leaves the renderer usable
+    bad_async = _request(pyngp, [str(tmp_path / "nope_async.msgpack")], [_trs()], [1.0], [[]], [], (1.7, -1.3, 1.0), 42.0)
+    never = []
+    tb.request_nerf_render_async(bad_async, lambda a: never.append(1))
+    tb.wait_for_render()
+    assert not never
+    np.testing.assert_array_equal(tb.request_nerf_render_sync(req), sync_img)
+    # a Testbed collected while its worker is still rendering waits for it (the GIL is released around the wait; the worker needs it for the callback)
+    tb2 = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    late, late_done = [], threading.Event()
+    tb2.request_nerf_render_async(req, lambda a: (late.append(1), late_done.set()))
+    del tb2
+    import gc
+    gc.collect()
+    assert late_done.wait(60.0) and late == [1]
     # an empty request renders the background only
     empty = _request(pyngp, [], [], [], [], [], (1.7, -1.3, 1.0), 42.0)
     img = tb.request_nerf_render_sync(empty)
