@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--no_render", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--force_dp", action="store_true", help="run the data-parallel step path (RCCL all-reduce) even with one rank")
+    ap.add_argument("--dp_impl", choices=["product", "torch"], default="product", help="product: Testbed.init_data_parallel — the step's two exchanges inside the C++ Testbed (shared-memory "
+                    "counters, its own RCCL communicator), frame() as on one GPU; torch: the same exchanges driven from this script through torch.distributed (dp_step). product falls back to torch if it cannot initialise")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: 2^18 compacted samples per GPU and step (N x the global batch); strong: 2^18 per step over all GPUs (the reference's convergence per step)")
     ap.add_argument("--min_train_step", type=int, default=1000, help="BASELINE.md M1 quotes the metric on steps [1000, 2000): the timed region never starts before this training step, whatever --warmup says")
     ap.add_argument("--psnr_gate", type=float, default=35.0, help="BASELINE config #3 'train to 35 PSNR then render': keep pre-training (untimed) until the held-out PSNR reaches this")
     a = ap.parse_args()
@@ -297,13 +300,33 @@ def main():
     tb.async_training_steps = True   # frame() without the reference's per-step stream drain (pyngp property; the timed region is still bracketed by syncs)
     tb.set_distributed(rank, world)
     dp = None
-    if use_dp:
+    dp_impl = None
+    if use_dp and a.dp_impl == "product" and (world > 1 or a.force_dp):
+        try:
+            tb.init_data_parallel(rank, world, "bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid() if world == 1 else 0), a.scaling == "strong")
+            ok = 1.0
+        except Exception as e:   # e.g. no RCCL to bind, a rendezvous that times out
+            print("rank %d: product data-parallel path failed to initialise (%s); using the torch.distributed driver" % (rank, e), file=sys.stderr, flush=True)
+            ok = 0.0
+        t = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)   # all ranks or none
+        if float(t.item()) == 1.0:
+            dp_impl = "product"
+        else:
+            tb.shutdown_data_parallel()
+            tb.set_distributed(rank, world)
+    if use_dp and dp_impl is None:
+        if a.scaling == "strong":
+            raise SystemExit("--scaling strong needs the product data-parallel path")
+        dp_impl = "torch"
         grads = torch.as_tensor(CudaArray(tb.gradients_ptr(), tb.n_params(), "<f2"), device=dev)
         assert grads.data_ptr() == tb.gradients_ptr()
         dp = make_dp_state(torch, dist, tb, grads, dev)
+    if a.scaling == "strong":
+        tb.training_batch_size = B   # per step over all ranks; the Testbed back-propagates B / world per rank
 
     def one_step():
-        if not use_dp:
+        if dp is None:
             tb.frame()
             return tb.nerf.training.measured_batch_size
         dp_step(tb, torch, dist, B, dp)
@@ -376,8 +399,9 @@ def main():
     if rank != 0:
         if use_dp:
             dist.barrier()
-            if dp.shm is not None:
+            if dp is not None and dp.shm is not None:
                 dp.shm.close()
+            tb.shutdown_data_parallel()
             dist.destroy_process_group()
         return
 
@@ -449,9 +473,9 @@ def main():
     line = {
         "metric": "train samples/s (compacted samples back-propagated per second), nerf-synthetic/lego stand-in",
         "value": round(samples / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "procedural-lego %dx%d x%d RGBA8 views (scale 0.33, offset 0.5, aabb_scale 1), configs/nerf/base.json (L=16 F=2 T=2^19, 64-wide MLPs), batch 2^18 compacted samples per GPU" % (a.res, a.res, a.n_train),
-                   "global_batch": B * world, "parallelism": "dp%d" % world if use_dp else "single"},
+                   "global_batch": B if a.scaling == "strong" else B * world, "parallelism": "dp%d" % world if use_dp else "single", "dp_impl": dp_impl},
         "rays_per_s": round(rays / dt, 1), "pre_compaction_samples_per_s": round(pre_compaction / dt, 1),
         "pretrain_steps": pretrain_steps, "timed_from_training_step": int(timed_from), "psnr_at_bench": None if psnr_at_bench is None else round(psnr_at_bench, 2),
         "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region; other groups: %d untimed survey steps" % (dom, SURVEY_STEPS),
@@ -462,8 +486,9 @@ def main():
     print(json.dumps(line), flush=True)
     if use_dp:
         dist.barrier()
-        if dp.shm is not None:
+        if dp is not None and dp.shm is not None:
             dp.shm.close()
+        tb.shutdown_data_parallel()
         dist.destroy_process_group()
 
 

@@ -19,8 +19,8 @@ OBJDIR = os.path.join(HERE, "build")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-KERNEL_SOURCES = ["density_grid.hip", "train_samples.hip", "network.hip", "loss.hip", "render.hip", "multi_render.hip"]
-HOST_SOURCES = ["testbed.cpp", "python_api.cpp", "mini_json.cpp", "snapshot.cpp", "nerf_renderer.cpp", "nerf_loader.cpp", "png_reader.cpp", "exr_reader.cpp", "jpeg_reader.cpp", "image_io.cpp", "plumbing.cpp"]
+KERNEL_SOURCES = ["density_grid.hip", "train_samples.hip", "network.hip", "loss.hip", "render.hip", "multi_render.hip", "comm.hip"]
+HOST_SOURCES = ["testbed.cpp", "python_api.cpp", "mini_json.cpp", "snapshot.cpp", "nerf_renderer.cpp", "nerf_loader.cpp", "png_reader.cpp", "exr_reader.cpp", "jpeg_reader.cpp", "image_io.cpp", "plumbing.cpp", "dp.cpp"]
 
 # -ffp-contract=off: the index / count paths must round exactly like the CPU oracle; network.hip re-enables contraction locally.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
@@ -57,7 +57,7 @@ def build_kernels(force=False, verbose=False):
                 print(out)
     lib = os.path.join(LIBDIR, "libngp_hip.so")
     if force or jobs or not os.path.exists(lib):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib, "-ldl"])
     return lib
 
 
@@ -72,7 +72,7 @@ def build_host(force=False, verbose=False):
         cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__",
                "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROCM, "include")] + srcs + ["-o", out, "-L" + LIBDIR, "-lngp_hip", "-L" + os.path.join(ROCM, "lib"),
-               "-lamdhip64", "-lz", "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"]
+               "-lamdhip64", "-lz", "-lrt", "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"]
         o = _run(cmd)
         if verbose and o.strip():
             print(o)

@@ -101,7 +101,7 @@ def load_ngp_hip():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _ngp = CLib(os.path.join(HERE, "lib", "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), "ngp_hip_")
+        _ngp = CLib(os.path.join(HERE, "lib", "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), ("ngp_hip_", "ngp_rccl_"))
     return _ngp
 
 

@@ -1,0 +1,129 @@
+// comm.hip — the collectives of the data-parallel training step behind the C ABI: one RCCL communicator per rank (one process per
+// GPU, xGMI inside the node), stream-ordered all-reduces on the caller's HIP stream.  The reference has no multi-GPU path at all ("Can this
+// codebase use multiple GPUs…? No.", README.md:239-241); these entry points are what its Trainer would call between backward and optimizer_step
+// (src/testbed_nerf.cu:3331 / 2950) and around NerfCounters::update_after_training (2870-2894).
+//
+// RCCL is bound at run time (dlopen): libngp_hip.so itself needs libamdhip64 only, and a process that already carries an RCCL — PyTorch bundles
+// its own next to its own HIP runtime — must keep using THAT copy (one HIP runtime per process), so a loaded librccl is looked up
+// first and /opt/rocm/lib is the fallback.
+#include <dlfcn.h>
+#include <link.h>
+#include <string.h>
+#include <string>
+
+#include "ngp_device.cuh"
+
+namespace {
+
+typedef struct { char internal[128]; } RcclUniqueId;   // ncclUniqueId (rccl.h:43)
+typedef void* RcclComm;
+enum { RCCL_SUM = 0, RCCL_FLOAT16 = 6, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8 };   // ncclRedOp_t / ncclDataType_t values (rccl.h)
+
+struct RcclApi {
+	void* handle = nullptr;
+	int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+	int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+	int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*CommDestroy)(RcclComm) = nullptr;
+	const char* (*GetErrorString)(int) = nullptr;
+	std::string where;
+};
+
+struct Loaded { std::string rccl, hip_dir; };
+int find_loaded(struct dl_phdr_info* info, size_t, void* out) {
+	Loaded* l = (Loaded*)out;
+	if (!info->dlpi_name) return 0;
+	if (strstr(info->dlpi_name, "librccl")) l->rccl = info->dlpi_name;
+	if (const char* p = strstr(info->dlpi_name, "libamdhip64")) l->hip_dir = std::string(info->dlpi_name, (size_t)(p - info->dlpi_name));
+	return 0;
+}
+
+RcclApi* rccl() {
+	static RcclApi api;
+	static bool tried = false;
+	if (tried) return api.handle ? &api : nullptr;
+	tried = true;
+	// 1. an RCCL this process already carries; 2. the one that sits NEXT TO the HIP runtime in use (PyTorch ships librccl.so beside its own
+	// libamdhip64 and loads it lazily: binding /opt/rocm's copy instead would pull a second HIP runtime into the process); 3. the system's
+	Loaded l;
+	dl_iterate_phdr(find_loaded, &l);
+	const std::string beside = l.hip_dir.empty() ? std::string() : l.hip_dir + "librccl.so", beside1 = l.hip_dir.empty() ? std::string() : l.hip_dir + "librccl.so.1";
+	const char* candidates[] = {l.rccl.empty() ? nullptr : l.rccl.c_str(), beside.empty() ? nullptr : beside.c_str(), beside1.empty() ? nullptr : beside1.c_str(),
+	                            "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	for (const char* c : candidates) {
+		if (!c) continue;
+		api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+		if (api.handle) { api.where = c; break; }
+	}
+	if (!api.handle) return nullptr;
+	api.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(api.handle, "ncclGetUniqueId");
+	api.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(api.handle, "ncclCommInitRank");
+	api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+	api.CommDestroy = (int (*)(RcclComm))dlsym(api.handle, "ncclCommDestroy");
+	api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
+	if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
+	return &api;
+}
+
+int fail(const char* what, int rc) {
+	RcclApi* a = rccl();
+	std::string msg = std::string(what) + ": " + (a && a->GetErrorString ? a->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+	ngp::set_last_error(msg.c_str(), hipErrorUnknown);
+	return -1;
+}
+
+struct Comm { RcclComm comm = nullptr; int rank = 0, world = 1; };
+
+}  // namespace
+
+extern "C" {
+
+int ngp_rccl_available(void) { return rccl() ? 1 : 0; }
+
+int ngp_rccl_get_unique_id(uint8_t* out128) {
+	RcclApi* a = rccl();
+	if (!a) { ngp::set_last_error("ngp_rccl_get_unique_id: librccl could not be loaded", hipErrorNotSupported); return -1; }
+	RcclUniqueId id;
+	const int rc = a->GetUniqueId(&id);
+	if (rc) return fail("ncclGetUniqueId", rc);
+	memcpy(out128, id.internal, 128);
+	return 0;
+}
+
+void* ngp_rccl_init(int rank, int world_size, const uint8_t* unique_id128) {
+	RcclApi* a = rccl();
+	if (!a) { ngp::set_last_error("ngp_rccl_init: librccl could not be loaded", hipErrorNotSupported); return nullptr; }
+	if (world_size < 1 || rank < 0 || rank >= world_size || !unique_id128) { ngp::set_last_error("ngp_rccl_init: bad rank / world_size / id", hipErrorInvalidValue); return nullptr; }
+	RcclUniqueId id;
+	memcpy(id.internal, unique_id128, 128);
+	Comm* c = new Comm();
+	c->rank = rank; c->world = world_size;
+	const int rc = a->CommInitRank(&c->comm, world_size, id, rank);   // collective: every rank of the job calls it with the same id, its own device current
+	if (rc) { fail("ncclCommInitRank", rc); delete c; return nullptr; }
+	return c;
+}
+
+static int all_reduce(void* comm, void* stream, void* buf, uint64_t count, int dtype, const char* who) {
+	RcclApi* a = rccl();
+	Comm* c = (Comm*)comm;
+	if (!a || !c) { ngp::set_last_error(who, hipErrorInvalidValue); return -1; }
+	if (count == 0) return 0;
+	const int rc = a->AllReduce(buf, buf, (size_t)count, dtype, RCCL_SUM, c->comm, (hipStream_t)stream);   // in place, ordered on the caller's stream
+	return rc ? fail(who, rc) : 0;
+}
+
+int ngp_rccl_allreduce_grads(void* comm, void* stream, uint16_t* grads_f16, uint64_t n_params) { return all_reduce(comm, stream, grads_f16, n_params, RCCL_FLOAT16, "ngp_rccl_allreduce_grads"); }
+int ngp_rccl_allreduce_f32(void* comm, void* stream, float* values, uint64_t count) { return all_reduce(comm, stream, values, count, RCCL_FLOAT32, "ngp_rccl_allreduce_f32"); }
+int ngp_rccl_allreduce_counters(void* comm, void* stream, double* values, uint64_t count) { return all_reduce(comm, stream, values, count, RCCL_FLOAT64, "ngp_rccl_allreduce_counters"); }
+
+int ngp_rccl_finalize(void* comm) {
+	Comm* c = (Comm*)comm;
+	if (!c) return 0;
+	RcclApi* a = rccl();
+	int rc = 0;
+	if (a && c->comm) rc = a->CommDestroy(c->comm);
+	delete c;
+	return rc ? fail("ncclCommDestroy", rc) : 0;
+}
+
+}  // extern "C"

@@ -11,6 +11,7 @@
 #include "nerf_loader.h"
 #include "png_reader.h"
 #include "image_io.h"
+#include "dp.h"
 
 namespace py = pybind11;
 using namespace ngp;
@@ -185,6 +186,14 @@ PYBIND11_MODULE(pyngp, m) {
 		out["depth_scale"] = d.depth_scale; out["has_rays"] = d.has_rays; out["is_hdr"] = d.is_hdr;
 		return out;
 	});
+	// data-parallel plumbing that needs no GPU (tests): the shared-memory counter exchange of the ranks of one node, and the RCCL binding probe
+	py::class_<ShmCounterExchange>(m, "ShmCounterExchange")
+		.def(py::init<uint32_t, uint32_t, const std::string&, double>(), py::call_guard<py::gil_scoped_release>(), py::arg("rank"), py::arg("world_size"), py::arg("key"), py::arg("timeout_s") = 60.0)
+		.def("all_sum", [](ShmCounterExchange& x, uint64_t step, double a, double b, double c) { const double in[3] = {a, b, c}; double out[3]; { py::gil_scoped_release rel; x.all_sum(step, in, out); } return py::make_tuple(out[0], out[1], out[2]); })
+		.def("publish_blob", [](ShmCounterExchange& x, const py::bytes& b) { const std::string s = b; if (s.size() != 128) throw std::runtime_error{"128 bytes"}; x.publish_blob((const uint8_t*)s.data()); })
+		.def("fetch_blob", [](ShmCounterExchange& x) { uint8_t b[128]; { py::gil_scoped_release rel; x.fetch_blob(b); } return py::bytes((const char*)b, 128); })
+		.def("barrier", &ShmCounterExchange::barrier, py::call_guard<py::gil_scoped_release>());
+	m.def("rccl_available", []() { return ngp_rccl_available() != 0; });
 	m.def("free_temporary_memory", []() {});  // python_api.cu:309 (arenas are RAII buffers here)
 	m.def("device_memory_allocated", []() { return DeviceBuffer::total_allocated(); });
 
@@ -446,6 +455,13 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("reset_accumulation", [](Testbed& t, bool, bool) { t.m_windowless_render_surface.reset_accumulation(); }, py::arg("due_to_camera_movement") = false, py::arg("immediate_redraw") = true)
 		// data-parallel extension
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
+		.def("init_data_parallel", &Testbed::init_data_parallel, py::call_guard<py::gil_scoped_release>(), py::arg("rank"), py::arg("world_size"), py::arg("key") = std::string("0"), py::arg("strong_scaling") = false,
+			"One process per GPU of one node: after this call frame() / train() run the data-parallel step (shared-memory counter exchange, RCCL gradient all-reduce over xGMI). "
+			"`key` names the rendezvous and must be the same on every rank of the job (e.g. MASTER_PORT). strong_scaling: train(B) back-propagates B / world_size samples per rank.")
+		.def("shutdown_data_parallel", &Testbed::shutdown_data_parallel, py::call_guard<py::gil_scoped_release>())
+		.def_readonly("world_size", &Testbed::m_world_size)
+		.def_readonly("rank", &Testbed::m_rank)
+		.def_readonly("strong_scaling", &Testbed::m_dp_strong_scaling)
 		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss, bool wait) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss, wait); } return py::make_tuple(c[0], c[1]); },
 			py::arg("batch_size"), py::arg("get_loss_scalar") = false, py::arg("wait_for_counters") = true)
 		.def("set_dp_counter_buffer", [](Testbed& t, uintptr_t p) { t.set_dp_counter_buffer((void*)p); })                 // 3 doubles on the device

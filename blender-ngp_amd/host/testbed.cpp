@@ -2,6 +2,7 @@
 #include "testbed.h"
 #include "snapshot.h"
 #include "nerf_loader.h"
+#include "dp.h"
 #include "nerf_renderer.h"
 
 #include <hip/hip_runtime_api.h>
@@ -217,6 +218,7 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 }
 
 Testbed::~Testbed() {
+	try { shutdown_data_parallel(); } catch (...) {}
 	bl_wait_for_renders();   // before any stream goes away (a Python owner releases the GIL around this wait: python_api.cpp TestbedDeleter)
 	for (void* st : m_render_streams) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
 	if (m_render_host_words) (void)hipHostFree(m_render_host_words);
@@ -737,8 +739,47 @@ void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
 	m_rank = rank; m_world_size = world_size;
 }
 
+void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::string& key, bool strong_scaling) {
+	shutdown_data_parallel();
+	set_distributed(rank, world_size);
+	m_dp_strong_scaling = strong_scaling;
+	m_dp_exchange_step = 0;
+	// (a world of one rank sets up the same machinery — a 1-rank segment and communicator — so that the whole step path can be run on one GPU)
+	if (!ngp_rccl_available()) throw std::runtime_error{"init_data_parallel: no RCCL library could be loaded (librccl.so.1)"};
+	m_dp_shm.reset(new ShmCounterExchange(rank, world_size, key));
+	uint8_t id[128];
+	if (rank == 0) { check(ngp_rccl_get_unique_id(id), "ngp_rccl_get_unique_id"); m_dp_shm->publish_blob(id); }
+	else m_dp_shm->fetch_blob(id);
+	m_dp_comm = ngp_rccl_init((int)rank, (int)world_size, id);
+	if (!m_dp_comm) { m_dp_shm.reset(); set_distributed(0, 1); throw std::runtime_error{std::string{"ngp_rccl_init failed: "} + ngp_hip_last_error()}; }
+	m_dp_shm->barrier();
+}
+void Testbed::shutdown_data_parallel() {
+	if (m_dp_comm) { if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream); ngp_rccl_finalize(m_dp_comm); m_dp_comm = nullptr; }
+	m_dp_shm.reset();
+}
+
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
+	if (m_dp_comm) {
+		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
+		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
+		// optimizer and occupancy-grid updates run replicated on identical parameters and rng, i.e. bit-identically — no collective for them
+		uint32_t B = target_batch_size;
+		if (m_dp_strong_scaling) {
+			if (target_batch_size % (256 * m_world_size)) throw std::runtime_error{"strong scaling: the batch size must be a multiple of 256 x world_size"};
+			B = target_batch_size / m_world_size;
+		}
+		uint32_t counters[2];
+		train_nerf_dp_begin(B, counters, get_loss_scalar);
+		const double mine[3] = {(double)counters[0], (double)counters[1], get_loss_scalar ? (double)local_loss_sum() : 0.0};
+		double sum[3];
+		m_dp_shm->all_sum(m_dp_exchange_step++, mine, sum);
+		train_nerf_dp_backward(B, (uint32_t)sum[0], (uint32_t)sum[1], get_loss_scalar, (float)sum[2]);
+		check(ngp_rccl_allreduce_grads(m_dp_comm, m_stream, m_grads.as<uint16_t>(), m_n_params), "ngp_rccl_allreduce_grads");
+		train_nerf_dp_end();
+		return;
+	}
 	{
 		const NerfTraining& tr = m_nerf.training;
 		if (tr.optimize_extrinsics || tr.optimize_focal_length || tr.optimize_distortion || tr.optimize_extra_dims)
@@ -906,7 +947,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
 	profile_end(PK_INFERENCE, max_inference);
 	if (tr.optimize_exposure) {
-		if (m_world_size > 1) throw std::runtime_error{"optimize_exposure is not supported in data-parallel training (the exposure gradients are not exchanged)"};
+		if (m_world_size > 1 && !m_dp_comm) throw std::runtime_error{"optimize_exposure at world_size > 1 needs init_data_parallel (the exposure gradients are summed over the ranks)"};
 		const size_t bytes = tr.dataset.n_images * 3 * sizeof(float);
 		if (tr.cam_exposure_gradient_gpu.bytes() < bytes) { tr.cam_exposure_gradient_gpu.resize(bytes); tr.n_steps_since_cam_update = 0; }
 		if (tr.n_steps_since_cam_update == 0) tr.cam_exposure_gradient_gpu.memset(0, m_stream);   // 2916-2919
@@ -1052,6 +1093,7 @@ void Testbed::train_nerf_dp_end() {
 		const uint32_t n_img = (uint32_t)tr.n_images_for_training;
 		const float per_camera_loss_scale = (float)n_img / LOSS_SCALE / (float)tr.n_steps_between_cam_updates;
 		std::vector<float> grad(tr.dataset.n_images * 3);
+		if (m_dp_comm) check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, tr.cam_exposure_gradient_gpu.as<float>(), tr.dataset.n_images * 3), "ngp_rccl_allreduce_f32 (exposure gradients)");
 		HIP_CHECK_THROW(hipMemcpyAsync(grad.data(), tr.cam_exposure_gradient_gpu.data(), grad.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
 		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
 		if (tr.cam_exposure.size() < tr.dataset.n_images) tr.cam_exposure.resize(tr.dataset.n_images);
@@ -1082,6 +1124,8 @@ void Testbed::train_nerf_dp_end() {
 		const uint32_t n_img = (uint32_t)tr.dataset.n_images, W = (uint32_t)tr.error_map_res[0], H = (uint32_t)tr.error_map_res[1];
 		tr.cdf_res[0] = tr.error_map_res[0]; tr.cdf_res[1] = tr.error_map_res[1];
 		tr.cdf_x_cond_y.resize((size_t)W * H * n_img * 4); tr.cdf_y.resize((size_t)H * n_img * 4); tr.cdf_img.resize((size_t)n_img * 4);
+		// data parallel: every rank deposited the error of its own rays; the CDFs are built from the sum, identical on every rank
+		if (m_dp_comm) check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, tr.error_map_data.as<float>(), (uint64_t)W * H * n_img), "ngp_rccl_allreduce_f32 (error map)");
 		check(ngp_hip_construct_cdf_2d(m_stream, n_img, H, W, tr.error_map_data.as<float>(), tr.cdf_x_cond_y.as<float>(), tr.cdf_y.as<float>()), "construct_cdf_2d");
 		check(ngp_hip_construct_cdf_1d(m_stream, n_img, H, tr.cdf_y.as<float>(), tr.cdf_img.as<float>()), "construct_cdf_1d");
 		// image CDF on the CPU ("single-threaded anyway", 2999-3015)

@@ -213,6 +213,7 @@ struct TrainStats { float training_prep_ms = 0, training_ms = 0, render_ms = 0; 
 
 class NerfRenderer;
 struct RenderRequest;
+class ShmCounterExchange;
 
 class Testbed {
 public:
@@ -243,6 +244,13 @@ public:
 	// data-parallel split of train_nerf: begin = everything up to and including backward (gradients ready in
 	// gradients()), end = optimizer step + counter feedback given the GLOBAL (all-rank summed) counters.
 	void set_distributed(uint32_t rank, uint32_t world_size);
+	// The whole data-parallel step inside train(): ranks of ONE node, shared-memory counter exchange + an RCCL communicator of this Testbed's own
+	// (ngp_rccl_*).  `key` names the rendezvous (same on every rank of the job, e.g. MASTER_PORT); strong_scaling: train(B) back-propagates B / world
+	// samples per rank (the reference's convergence per step); otherwise B per rank (world x the global batch).  After this frame() / train() work
+	// at world_size > 1 like at 1.
+	void init_data_parallel(uint32_t rank, uint32_t world_size, const std::string& key, bool strong_scaling);
+	void shutdown_data_parallel();
+	bool m_dp_strong_scaling = false;
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
 	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)
 	//      -> [all-reduce gradients] -> end (optimizer, bookkeeping)
@@ -423,6 +431,9 @@ public:
 
 	// distributed
 	uint32_t m_rank = 0, m_world_size = 1;
+	void* m_dp_comm = nullptr;                         // ngp_rccl_init handle (init_data_parallel)
+	std::unique_ptr<class ShmCounterExchange> m_dp_shm;
+	uint64_t m_dp_exchange_step = 0;
 
 private:
 	std::unique_ptr<NerfRenderer> m_renderer;

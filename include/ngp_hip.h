@@ -388,6 +388,18 @@ int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uin
 int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                         const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
 
+/* ---- data-parallel collectives: one RCCL communicator per rank (one process per GPU; xGMI inside the node).  The reference is
+ * single-GPU (README.md:239-241); these are the calls its training step would make between backward and optimizer_step (src/testbed_nerf.cu:3331,
+ * 2950) and around NerfCounters::update_after_training (2870-2894).  RCCL is bound at run time: a copy the process already carries (PyTorch
+ * bundles one with its own HIP runtime) is used, else /opt/rocm/lib/librccl.so.1.  All-reduces are sums, in place, ordered on `stream`. */
+int ngp_rccl_available(void);                                  /* 1 if an RCCL library could be bound */
+int ngp_rccl_get_unique_id(uint8_t* out128);                   /* ncclGetUniqueId: rank 0 makes one, every rank passes the same 128 bytes to init */
+void* ngp_rccl_init(int rank, int world_size, const uint8_t* unique_id128);   /* ncclCommInitRank (collective; the rank's device is current); NULL on failure */
+int ngp_rccl_allreduce_grads(void* comm, void* stream, uint16_t* grads_f16, uint64_t n_params);   /* fp16 sum of the loss-scaled gradient vector */
+int ngp_rccl_allreduce_f32(void* comm, void* stream, float* values, uint64_t count);              /* error maps, exposure gradients */
+int ngp_rccl_allreduce_counters(void* comm, void* stream, double* values, uint64_t count);        /* {samples, compacted samples, loss sum} of a step */
+int ngp_rccl_finalize(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,3 +199,45 @@ def test_shared_memory_counter_exchange():
     """bench.ShmCounters: the single-node counter all-reduce of the data-parallel step (two ranks, 300 back-to-back steps)"""
     import torch.multiprocessing as mp
     mp.spawn(_shm_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _cpp_shm_worker(rank, world, key, q):
+    sys.path.insert(0, os.path.join(ROOT, "blender-ngp_amd"))
+    import torch  # noqa: F401
+    import pyngp
+    x = pyngp.ShmCounterExchange(rank, world, key, 30.0)
+    if rank == 0:
+        x.publish_blob(bytes(range(128)))
+    blob = x.fetch_blob()
+    x.barrier()
+    out = []
+    for step in range(200):
+        out.append(x.all_sum(step, float(rank + 1) * (step + 1), float(step), 0.25 * (rank + 1)))
+    x.barrier()
+    q.put((rank, blob == bytes(range(128)), out[0], out[-1]))
+
+
+def test_cpp_shared_memory_counter_exchange_and_rccl_binding():
+    """the product's own exchange (host/dp.cpp, what Testbed.init_data_parallel uses): three ranks, 200 steps, blob hand-over (the RCCL unique id),
+    barrier; and the RCCL library binds (dlopen) on this machine"""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "blender-ngp_amd"))
+    import torch  # noqa: F401
+    import pyngp
+    assert pyngp.rccl_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "test_%d" % os.getpid()
+    world = 3
+    ps = [ctx.Process(target=_cpp_shm_worker, args=(r, world, key, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, blob_ok, first, last in res:
+        assert blob_ok
+        assert first == (6.0, 0.0, 1.5)                  # (1 + 2 + 3) * 1, 3 * 0, 0.25 * 6
+        assert last == (6.0 * 200, 3 * 199.0, 1.5)
+    assert not os.path.exists("/dev/shm/ngp_dp_" + key)   # rank 0 unlinked the name
