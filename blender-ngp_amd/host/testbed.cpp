@@ -1529,14 +1529,24 @@ void Testbed::load_snapshot(const std::string& path) {
 	m_inference_params.copy_from_host(p16.data(), m_n_params * 2);
 	m_master.copy_from_host(p32.data(), m_n_params * 4);
 	if (snapshot.contains("optimizer")) {
+		// tiny-cuda-nn's Trainer::serialize is not in the reference tree: the key names below are this build's own layout (host/snapshot.h).  A block
+		// written by the CUDA build that names its buffers differently restores nothing — say so instead of resuming silently on zero moments.
 		const Json* o = &snapshot["optimizer"];
+		uint32_t restored = 0, blocks = 0;
+		auto take = [&](const Json& j, const char* key, DeviceBuffer& dst) {
+			if (!j.contains(key)) return false;
+			if (j.at(key).bin().size() != m_n_params * 4) { fprintf(stderr, "load_snapshot: optimizer.%s has %zu bytes, expected %zu: ignored\n", key, j.at(key).bin().size(), m_n_params * 4); return false; }
+			dst.copy_from_host(j.at(key).bin().data(), m_n_params * 4);
+			++restored;
+			return true;
+		};
 		while (true) {
 			const std::string otype = o->value("otype", "");
+			++blocks;
 			if (otype == "Ema") {
-				if (o->contains("ema_binary") && o->at("ema_binary").bin().size() == m_n_params * 4) m_ema.copy_from_host(o->at("ema_binary").bin().data(), m_n_params * 4);
-				if (o->contains("params_full_precision_binary") && o->at("params_full_precision_binary").bin().size() == m_n_params * 4) {
+				take(*o, "ema_binary", m_ema);
+				if (take(*o, "params_full_precision_binary", m_master)) {
 					const std::vector<uint8_t>& mb = o->at("params_full_precision_binary").bin();
-					m_master.copy_from_host(mb.data(), m_n_params * 4);
 					std::vector<uint16_t> train16(m_n_params);
 					const float* mf = (const float*)mb.data();
 					for (size_t i = 0; i < m_n_params; ++i) train16[i] = float_to_half_bits(mf[i]);
@@ -1546,12 +1556,15 @@ void Testbed::load_snapshot(const std::string& path) {
 				m_learning_rate = (float)o->value("learning_rate", (double)m_learning_rate);
 			} else if (otype == "Adam") {
 				m_optimizer_step = (uint32_t)o->value("current_step", 0);
-				if (o->contains("first_moments_binary") && o->at("first_moments_binary").bin().size() == m_n_params * 4) m_first_moments.copy_from_host(o->at("first_moments_binary").bin().data(), m_n_params * 4);
-				if (o->contains("second_moments_binary") && o->at("second_moments_binary").bin().size() == m_n_params * 4) m_second_moments.copy_from_host(o->at("second_moments_binary").bin().data(), m_n_params * 4);
+				take(*o, "first_moments_binary", m_first_moments);
+				take(*o, "second_moments_binary", m_second_moments);
+			} else {
+				fprintf(stderr, "load_snapshot: optimizer block of type '%s' is not understood: skipped\n", otype.c_str());
 			}
 			if (!o->contains("nested")) break;
 			o = &o->at("nested");
 		}
+		if (restored == 0) fprintf(stderr, "load_snapshot: the snapshot carries an optimizer state (%u nested blocks) but none of its buffers could be restored: training resumes with fresh Adam moments\n", blocks);
 	}
 	sync();
 }

@@ -11,73 +11,81 @@ Pinned by tests/golden/common_py_metrics.npz, captured from the reference module
 import numpy as np
 from scipy.ndimage import convolve1d
 
+# IEC 61966-2-1 transfer function, knees on the encoded / linear side
+_KNEE_ENCODED, _KNEE_LINEAR = 0.04045, 0.0031308
+_REC709_LUMA = (0.2126, 0.7152, 0.0722)
+_GAUSS5 = np.array([0.120078, 0.233881, 0.292082, 0.233881, 0.120078])   # the 5-tap blur of the SSIM windows
+_SSIM_C1, _SSIM_C2 = 0.01 ** 2, 0.03 ** 2
+
 
 def mse2psnr(x):
     return -10.0 * np.log(x) / np.log(10.0)
 
 
 def srgb_to_linear(img):
-    limit = 0.04045
-    return np.where(img > limit, np.power((img + 0.055) / 1.055, 2.4), img / 12.92)
+    above = img > _KNEE_ENCODED
+    return np.where(above, np.power((img + 0.055) / 1.055, 2.4), img / 12.92)
 
 
 def linear_to_srgb(img):
-    limit = 0.0031308
-    return np.where(img > limit, 1.055 * (img ** (1.0 / 2.4)) - 0.055, 12.92 * img)
+    above = img > _KNEE_LINEAR
+    return np.where(above, 1.055 * (img ** (1.0 / 2.4)) - 0.055, 12.92 * img)
 
 
-def luminance(a):
-    return 0.2126 * a[:, :, 0] + 0.7152 * a[:, :, 1] + 0.0722 * a[:, :, 2]
+def luminance(rgb):
+    r, g, b = (w * rgb[:, :, c] for c, w in enumerate(_REC709_LUMA))
+    return r + g + b
+
+
+def _window(x):
+    """separable 5-tap Gaussian, rows then columns"""
+    return convolve1d(convolve1d(x, _GAUSS5, axis=0), _GAUSS5, axis=1)
 
 
 def SSIM(a, b):
-    k = np.array([0.120078, 0.233881, 0.292082, 0.233881, 0.120078])
+    """per-pixel structural similarity of the luminance of two RGB images: (2 mu_a mu_b + c1)(2 cov + c2) / ((mu_a^2 + mu_b^2 + c1)(var_a + var_b + c2))"""
+    ya, yb = luminance(a), luminance(b)
+    mu_a, mu_b = _window(ya), _window(yb)
+    var_a = _window(ya * ya) - mu_a ** 2
+    var_b = _window(yb * yb) - mu_b ** 2
+    cov = _window(ya * yb) - mu_a * mu_b
+    mean_term = (2.0 * mu_a * mu_b + _SSIM_C1) / (mu_a * mu_a + mu_b * mu_b + _SSIM_C1)
+    structure_term = (2.0 * cov + _SSIM_C2) / (var_a + var_b + _SSIM_C2)
+    return mean_term * structure_term
 
-    def blur(x):
-        return convolve1d(convolve1d(x, k, axis=0), k, axis=1)
 
-    a = luminance(a)
-    b = luminance(b)
-    mA, mB = blur(a), blur(b)
-    sA = blur(a * a) - mA ** 2
-    sB = blur(b * b) - mB ** 2
-    sAB = blur(a * b) - mA * mB
-    c1, c2 = 0.01 ** 2, 0.03 ** 2
-    p1 = (2.0 * mA * mB + c1) / (mA * mA + mB * mB + c1)
-    p2 = (2.0 * sAB + c2) / (sA + sB + c2)
-    return p1 * p2
+def _clip01(x):
+    return np.clip(x, 0.0, 1.0)
+
+
+# per-pixel error maps by name (image first, reference second)
+_ERROR_MAPS = {
+    "MAE": lambda i, r: np.abs(i - r),
+    "MAPE": lambda i, r: np.abs(i - r) / (1e-2 + r),
+    "SMAPE": lambda i, r: np.abs(i - r) / (1e-2 + (r + i) / 2.0),
+    "MSE": lambda i, r: (i - r) ** 2,
+    "MScE": lambda i, r: (_clip01(i) - _clip01(r)) ** 2,
+    "MRSE": lambda i, r: (i - r) ** 2 / (1e-2 + r ** 2),
+    "MRScE": lambda i, r: (np.clip(i, 0, 100) - np.clip(r, 0, 100)) ** 2 / (1e-2 + np.clip(r, 0, 100) ** 2),
+    "SSIM": lambda i, r: SSIM(_clip01(i), _clip01(r)),
+}
 
 
 def compute_error_img(metric, img, ref):
-    img = np.array(img, copy=True)
-    img[np.logical_not(np.isfinite(img))] = 0
-    img = np.maximum(img, 0.0)
-    if metric == "MAE":
-        return np.abs(img - ref)
-    if metric == "MAPE":
-        return np.abs(img - ref) / (1e-2 + ref)
-    if metric == "SMAPE":
-        return np.abs(img - ref) / (1e-2 + (ref + img) / 2.0)
-    if metric == "MSE":
-        return (img - ref) ** 2
-    if metric == "MScE":
-        return (np.clip(img, 0.0, 1.0) - np.clip(ref, 0.0, 1.0)) ** 2
-    if metric == "MRSE":
-        return (img - ref) ** 2 / (1e-2 + ref ** 2)
-    if metric == "MRScE":
-        i, r = np.clip(img, 0, 100), np.clip(ref, 0, 100)
-        return (i - r) ** 2 / (1e-2 + r ** 2)
-    if metric == "SSIM":
-        return SSIM(np.clip(img, 0.0, 1.0), np.clip(ref, 0.0, 1.0))
-    raise ValueError("Unknown metric: %s." % metric)
+    if metric not in _ERROR_MAPS:
+        raise ValueError("Unknown metric: %s." % metric)
+    sane = np.array(img, copy=True)
+    sane[~np.isfinite(sane)] = 0          # non-finite pixels count as black ...
+    sane = np.maximum(sane, 0.0)          # ... and negative ones too
+    return _ERROR_MAPS[metric](sane, ref)
 
 
 def compute_error(metric, img, ref):
-    metric_map = compute_error_img(metric, img, ref)
-    metric_map[np.logical_not(np.isfinite(metric_map))] = 0
-    if metric_map.ndim == 3:
-        metric_map = np.mean(metric_map, axis=2)
-    return np.mean(metric_map)
+    per_pixel = compute_error_img(metric, img, ref)
+    per_pixel[~np.isfinite(per_pixel)] = 0
+    if per_pixel.ndim == 3:
+        per_pixel = np.mean(per_pixel, axis=2)
+    return np.mean(per_pixel)
 
 
 def read_image_rgba8(rgba8):
