@@ -73,8 +73,9 @@ def test_adam_ema_against_update_rules(oracle):
     inf16 = np.zeros(n, np.uint16)
     oracle.orc_adam_ema_step(n, int(n_matrix), int(step), H.f32(lr), H.f32(b1), H.f32(b2), H.f32(eps), H.f32(l2), H.f32(scale), H.f32(decay), g16.ctypes.data, master.ctypes.data,
                              p16.ctypes.data, m1.ctypes.data, m2.ctypes.data, ema.ctypes.data, inf16.ctypes.data)
-    np.testing.assert_allclose(m1, G["adam_new_m1"], rtol=2e-6, atol=1e-12)
-    np.testing.assert_allclose(m2, G["adam_new_m2"], rtol=2e-6, atol=1e-14)
+    # fp32 on the oracle's side: errors are relative to the OPERANDS (moments ~1e-3 / 1e-4, gradients up to ~0.1 / loss scale), not to a result that cancels
+    np.testing.assert_allclose(m1, G["adam_new_m1"], rtol=2e-6, atol=3e-9)
+    np.testing.assert_allclose(m2, G["adam_new_m2"], rtol=2e-6, atol=1e-11)
     np.testing.assert_allclose(master, G["adam_new_master"], rtol=3e-6, atol=1e-9)
     np.testing.assert_allclose(ema, G["adam_new_ema"], rtol=5e-6, atol=1e-8)
     np.testing.assert_array_equal(p16.view(np.float16), master.astype(np.float16))          # fp16 copy = rounded master weight (skipped entries unchanged on both)
