@@ -67,6 +67,7 @@ void orc_nerf_forward_one(const orc_net* net, const uint16_t* params, const floa
 void orc_nerf_inference(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, uint16_t* out, uint32_t out_stride);
 void orc_nerf_density(const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0);
 void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, uint16_t* out_rgbsigma, double* grads_out, uint16_t* dL_dx_out);
+void orc_nerf_input_gradient(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, float* dL_dinput /* [n][6] */);
 void orc_nerf_init_params(const orc_net* net, uint64_t seed, float* params_fp32);
 void orc_f32_to_f16(const float* in, uint16_t* out, uint32_t n);
 void orc_f16_to_f32(const uint16_t* in, float* out, uint32_t n);

@@ -255,6 +255,92 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
 	}
 }
 
+/* dL/d(network input) — NerfNetwork::backward_impl with a dL_dinput matrix (nerf_network.h:187-266), requested by the training step when camera
+ * parameters train (prepare_input_gradients, testbed_nerf.cu:3324-3346).  [tcnn] GridEncoding: the forward pass keeps dy/dx of the trilinear
+ * interpolation per level, feature and dimension in fp32 — weight = scale * prod over the OTHER dimensions of (1 - w | w), times (value at the
+ * +1 corner - value at the 0 corner) — and backward_input sums dL/dy * dy/dx over levels and features in fp32.  [tcnn] SphericalHarmonics: the
+ * analytic derivative of the 16 polynomials in (2 d - 1), times 2.  dL/dy are the fp16 values the MLP backward produced (d_x, d_in[16..31]).
+ * Output: [n][6] fp32 = d/d(pos x, y, z), d/d(dir x, y, z) in the WARPED input coordinates the network sees. */
+static void orc_sh4_grad(const float dir[3], const float g[16], float out[3]) {
+	const float x = dir[0] * 2.0f - 1.0f, y = dir[1] * 2.0f - 1.0f, z = dir[2] * 2.0f - 1.0f;
+	const float x2 = x * x, y2 = y * y, z2 = z * z;
+	const float A = 0.48860251190291987f, B = 1.0925484305920792f, C = 0.94617469575755997f, E = 0.54627421529603959f, F = 0.59004358992664352f,
+	            G = 2.8906114426405538f, Hh = 0.45704579946446572f, K = 0.3731763325901154f, M = 1.4453057213202769f;
+	float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+	dy += g[1] * -A;
+	dz += g[2] * A;
+	dx += g[3] * -A;
+	dx += g[4] * (B * y);            dy += g[4] * (B * x);
+	dy += g[5] * (-B * z);           dz += g[5] * (-B * y);
+	dz += g[6] * (2.0f * C * z);
+	dx += g[7] * (-B * z);           dz += g[7] * (-B * x);
+	dx += g[8] * (2.0f * E * x);     dy += g[8] * (-2.0f * E * y);
+	dx += g[9] * (-6.0f * F * x * y); dy += g[9] * (F * (-3.0f * x2 + 3.0f * y2));
+	dx += g[10] * (G * y * z);       dy += g[10] * (G * x * z);        dz += g[10] * (G * x * y);
+	dy += g[11] * (Hh * (1.0f - 5.0f * z2)); dz += g[11] * (-10.0f * Hh * y * z);
+	dz += g[12] * (K * (15.0f * z2 - 3.0f));
+	dx += g[13] * (Hh * (1.0f - 5.0f * z2)); dz += g[13] * (-10.0f * Hh * x * z);
+	dx += g[14] * (2.0f * M * x * z); dy += g[14] * (-2.0f * M * y * z); dz += g[14] * (M * (x2 - y2));
+	dx += g[15] * (F * (-3.0f * x2 + 3.0f * y2)); dy += g[15] * (6.0f * F * x * y);
+	out[0] = 2.0f * dx; out[1] = 2.0f * dy; out[2] = 2.0f * dz;
+}
+
+void orc_nerf_input_gradient(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout,
+                             float* dL_dinput /* [n][6] */) {
+	const uint16_t* grid = params + GRID_OFF;
+	#pragma omp parallel for schedule(static)
+	for (uint32_t i = 0; i < n; ++i) {
+		const float* coord = coords + (size_t)i * coord_stride_floats;
+		orc_act a;
+		orc_nerf_forward_one(net, params, coord, &a);
+		uint16_t d_out[16]; memset(d_out, 0, sizeof(d_out));
+		for (int c = 0; c < 3; ++c) d_out[c] = dL_dout[(size_t)i * 4 + c];
+		uint16_t d_h3[64], d_h2[64], d_in[32], d_h1[64], d_x[32];
+		orc_dense_bwd_input(params + W5_OFF, 16, 64, d_out, a.h3, d_h3);
+		orc_dense_bwd_input(params + W4_OFF, 64, 64, d_h3, a.h2, d_h2);
+		orc_dense_bwd_input(params + W3_OFF, 64, 32, d_h2, NULL, d_in);
+		d_in[0] = orc_f2h(orc_h2f(d_in[0]) + orc_h2f(dL_dout[(size_t)i * 4 + 3]));
+		orc_dense_bwd_input(params + W2_OFF, 16, 64, d_in, a.h1, d_h1);
+		orc_dense_bwd_input(params + W1_OFF, 64, 32, d_h1, NULL, d_x);
+		float gp[3] = {0.0f, 0.0f, 0.0f};
+		for (uint32_t l = 0; l < net->n_levels; ++l) {
+			const orc_grid_level* lv = &net->levels[l];
+			float w[3]; uint32_t pg[3];
+			for (int d = 0; d < 3; ++d) {
+				float p = fmaf(lv->scale, coord[d], 0.5f);
+				float fl = floorf(p);
+				pg[d] = (uint32_t)(int)fl;
+				w[d] = p - fl;
+			}
+			const float g0 = orc_h2f(d_x[2 * l]), g1 = orc_h2f(d_x[2 * l + 1]);
+			for (int gd = 0; gd < 3; ++gd) {
+				float dy0 = 0.0f, dy1 = 0.0f;   /* dy/dx[gd] of the level's two features */
+				for (uint32_t idx = 0; idx < 4; ++idx) {
+					float weight = lv->scale; uint32_t c[3];
+					for (int nd = 0; nd < 2; ++nd) {
+						const int dim = nd >= gd ? nd + 1 : nd;
+						if ((idx & (1u << nd)) == 0) { weight *= 1.0f - w[dim]; c[dim] = pg[dim]; }
+						else { weight *= w[dim]; c[dim] = pg[dim] + 1; }
+					}
+					c[gd] = pg[gd];
+					const size_t lo = 2u * ((size_t)lv->offset + orc_grid_index(lv, c[0], c[1], c[2]));
+					c[gd] = pg[gd] + 1;
+					const size_t hi = 2u * ((size_t)lv->offset + orc_grid_index(lv, c[0], c[1], c[2]));
+					dy0 += weight * (orc_h2f(grid[hi]) - orc_h2f(grid[lo]));
+					dy1 += weight * (orc_h2f(grid[hi + 1]) - orc_h2f(grid[lo + 1]));
+				}
+				gp[gd] += g0 * dy0;
+				gp[gd] += g1 * dy1;
+			}
+		}
+		float gsh[16], gd3[3];
+		for (int k = 0; k < 16; ++k) gsh[k] = orc_h2f(d_in[16 + k]);
+		orc_sh4_grad(coord + 4, gsh, gd3);
+		float* o = dL_dinput + (size_t)i * 6;
+		o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2]; o[3] = gd3[0]; o[4] = gd3[1]; o[5] = gd3[2];
+	}
+}
+
 /* nerf_network.h:396-441 initialize_params order: density MLP, rgb MLP, pos grid (dir enc has none).
  * [tcnn] Xavier-uniform for matrices (scale sqrt(6/(fan_in+fan_out))), U(-1e-4,1e-4) for the grid, drawn from the
  * Trainer's pcg32(seed) (testbed.cu:2445).  tcnn's generator kernel interleaves streams across threads in a way

@@ -38,7 +38,7 @@ def encode(levels, table, pos):
         p = pos * float(np.float32(scale)) + 0.5
         g = torch.floor(p)
         w = p - g
-        gi = g.to(torch.int64).numpy()
+        gi = g.detach().to(torch.int64).numpy()
         acc = 0
         for c in range(8):
             bit = [(c >> d) & 1 for d in range(3)]
@@ -75,7 +75,7 @@ def real_sh4(dirs):
 def network(params, levels, coords, sh_fn):
     """(r, g, b, sigma) raw network outputs; params: dict of float64 tensors"""
     pos, dirs = coords[:, 0:3], coords[:, 4:7]
-    x = encode(levels, params["grid"], pos)
+    x = encode(levels, params["grid"], pos)   # (floor() has zero gradient: the weights carry d/dpos)
     h1 = torch.relu(x @ params["W1"].T)
     dens = h1 @ params["W2"].T                                  # 16 outputs, [0] = density
     sh = sh_fn(dirs)
@@ -110,12 +110,25 @@ def main():
         return out
 
     P = tensors()
-    c64 = torch.tensor(coords.astype(np.float64))
+    c64 = torch.tensor(coords.astype(np.float64), requires_grad=True)
     sh_np = real_sh4(coords[:, 4:7].astype(np.float64) * 2.0 - 1.0)
     out = network(P, levels, c64, lambda dirs: torch.tensor(sh_np))
     loss = (out * torch.tensor(dl.astype(np.float64))).sum()
     loss.backward()
     grads = np.concatenate([P[name].grad.numpy().ravel() for name, _, _ in sizes] + [P["grid"].grad.numpy().ravel()])
+    dpos = c64.grad.numpy()[:, 0:3].copy()      # d loss / d position (trilinear interpolation is piecewise linear in the position)
+    # d loss / d direction: the SH basis came from scipy (no autograd); central differences of the whole model in float64 instead
+    ddir = np.zeros((n, 3))
+    h = 1e-6
+    for k in range(3):
+        res = []
+        for sgn in (+1, -1):
+            cc = coords.astype(np.float64).copy(); cc[:, 4 + k] += sgn * h
+            with torch.no_grad():
+                Pn = {key: v.detach() for key, v in P.items()}
+                o = network(Pn, levels, torch.tensor(cc), lambda dirs: torch.tensor(real_sh4(cc[:, 4:7] * 2.0 - 1.0)))
+            res.append((o * torch.tensor(dl.astype(np.float64))).sum(dim=1).numpy())
+        ddir[:, k] = (res[0] - res[1]) / (2 * h)
 
     # Adam (Kingma & Ba) with L2 on the matrix weights, zero-gradient skip for encoding entries, bias-corrected EMA of the fp16 weights
     m_n = 4000
@@ -139,7 +152,7 @@ def main():
     new_ema = (A["ema"].astype(np.float64) * decay * (1 - decay ** (step - 1)) + w16 * (1 - decay)) / (1 - decay ** step)
 
     out_path = os.path.join(ROOT, "tests", "golden", "network_f64.npz")
-    np.savez_compressed(out_path, desc=desc.view(np.uint8), coords=coords, params16=p16.view(np.uint16), dL_dout=dl.view(np.uint16), out=out.detach().numpy(), grads=grads, sh=sh_np,
+    np.savez_compressed(out_path, dL_dpos=dpos, dL_ddir=ddir, desc=desc.view(np.uint8), coords=coords, params16=p16.view(np.uint16), dL_dout=dl.view(np.uint16), out=out.detach().numpy(), grads=grads, sh=sh_np,
                         adam_grads16=g16.view(np.uint16), adam_master=A["master"], adam_m1=A["m1"], adam_m2=A["m2"], adam_ema=A["ema"], adam_params16=p16_prev.view(np.uint16),
                         adam_hyper=np.array([step, lr, b1, b2, eps, l2, scale, decay, n_matrix], np.float64),
                         adam_new_master=nw, adam_new_m1=n1, adam_new_m2=n2, adam_new_ema=new_ema)

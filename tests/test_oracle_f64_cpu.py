@@ -80,3 +80,22 @@ def test_adam_ema_against_update_rules(oracle):
     np.testing.assert_allclose(ema, G["adam_new_ema"], rtol=5e-6, atol=1e-8)
     np.testing.assert_array_equal(p16.view(np.float16), master.astype(np.float16))          # fp16 copy = rounded master weight (skipped entries unchanged on both)
     np.testing.assert_array_equal(inf16.view(np.float16), ema.astype(np.float16))
+
+
+def test_input_gradient_against_autograd(oracle):
+    """dL/d(position) through the hash encoding and dL/d(direction) through the SH basis (what camera optimisation consumes: nerf_network.h:187-266
+    with a dL_dinput matrix) against the float64 model: autograd for the position, central differences of the whole model for the direction"""
+    desc, coords, p16, dl = _desc(), np.ascontiguousarray(G["coords"]), np.ascontiguousarray(G["params16"]), np.ascontiguousarray(G["dL_dout"])
+    n = len(coords)
+    got = np.zeros((n, 6), np.float32)
+    oracle.orc_nerf_input_gradient(desc.ctypes.data, p16.ctypes.data, coords.ctypes.data, 7, n, dl.ctypes.data, got.ctypes.data)
+    # The float64 model evaluates the SH basis on the NORMALISED direction, tcnn's polynomials are defined off the sphere as well: the two agree on
+    # the unit sphere and so do their TANGENTIAL derivatives; the radial component of the polynomial gradient has no counterpart (and no consumer:
+    # the camera gradient takes ray.d x gradient, testbed_nerf.cu:1700-1706).
+    r = coords[:, 4:7].astype(np.float64) * 2.0 - 1.0
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    tangential = lambda v: v - (v * r).sum(1, keepdims=True) * r
+    for name, a, b, tol in (("pos", got[:, 0:3].astype(np.float64), G["dL_dpos"], 5e-2), ("dir", tangential(got[:, 3:6].astype(np.float64)), tangential(G["dL_ddir"]), 5e-2)):
+        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert np.linalg.norm(b) > 0 and rel < tol, (name, rel)       # fp16 deltas + ReLU decisions flipped by fp16 rounding, as for the weight gradients
+        assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.998, name
