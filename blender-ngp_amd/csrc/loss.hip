@@ -542,6 +542,58 @@ __global__ void sharpen_kernel(uint64_t num_pixels, uint32_t w, const T* __restr
 
 using namespace ngp;
 
+// ---------------------------------------------------------------- camera gradient (1600-1712, extrinsics part)
+// The reference walks a ray's compacted samples in ONE THREAD.  Here 16 lanes share a ray (the compacted batch averages ~10-20 samples a ray):
+// lane l sums samples l, l+16, ... and the 16 partial sums are folded with xor-shuffles, so the per-ray sums are associated differently
+// from the sequential loop (the atomic accumulation over rays is unordered in the reference as well).
+constexpr int CAMGRAD_LANES = 16;
+__global__ void __launch_bounds__(256) compute_cam_gradient_kernel(
+	uint32_t n_rays, Aabb aabb, Pcg32 rng_in, const uint32_t* __restrict__ rays_counter, int snap_to_pixel_centers, float* __restrict__ cam_pos_gradient,
+	float* __restrict__ cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* __restrict__ metadata, const uint32_t* __restrict__ ray_indices_in,
+	const NgpRay* __restrict__ rays_in, const uint32_t* __restrict__ numsteps_in, const NgpCoord* __restrict__ coords, const float* __restrict__ coords_gradient, ErrorMapCdf cdf) {
+	const uint32_t sub = threadIdx.x % CAMGRAD_LANES;
+	const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / CAMGRAD_LANES;
+	const bool active = i < *rays_counter;
+	const uint32_t numsteps = active ? numsteps_in[i * 2 + 0] : 0;          // 0: "the ray doesn't matter" (1633-1636)
+	const uint32_t base = active ? numsteps_in[i * 2 + 1] : 0;
+	const v3 ray_o = active ? ld3(rays_in[i].o) : mk(0.f, 0.f, 0.f);
+	const v3 inv_diag = mk(1.0f / (aabb.mx.x - aabb.mn.x), 1.0f / (aabb.mx.y - aabb.mn.y), 1.0f / (aabb.mx.z - aabb.mn.z));   // warp_position_derivative (288-290)
+	v3 go = mk(0.f, 0.f, 0.f), gd = mk(0.f, 0.f, 0.f);
+	for (uint32_t j = sub; j < numsteps; j += CAMGRAD_LANES) {
+		const NgpCoord& c = coords[base + j];
+		const float* g = coords_gradient + (size_t)(base + j) * 6;
+		const v3 pg = mk(g[0] * inv_diag.x, g[1] * inv_diag.y, g[2] * inv_diag.z);
+		go = go + pg;
+		const v3 pos = unwarp_position(mk(c.pos[0], c.pos[1], c.pos[2]), aabb);
+		const float t = norm(pos - ray_o);
+		gd = gd + (pg * t + mk(g[3] * 0.5f, g[4] * 0.5f, g[5] * 0.5f));    // warp_direction_derivative = 0.5 (300-302)
+	}
+#pragma unroll
+	for (int off = CAMGRAD_LANES / 2; off > 0; off >>= 1) {
+		go.x += __shfl_xor(go.x, off, 64); go.y += __shfl_xor(go.y, off, 64); go.z += __shfl_xor(go.z, off, 64);
+		gd.x += __shfl_xor(gd.x, off, 64); gd.y += __shfl_xor(gd.y, off, 64); gd.z += __shfl_xor(gd.z, off, 64);
+	}
+	if (sub != 0 || numsteps == 0) return;
+	const uint32_t ray_idx = ray_indices_in[i];
+	const uint32_t img = image_idx(ray_idx, n_rays, n_training_images, cdf.cdf_img, nullptr);
+	Pcg32 rng = rng_in;
+	rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
+	float u, v, xy_pdf = 1.0f;
+	nerf_random_image_pos_training(rng, metadata[img].res, snap_to_pixel_centers, cdf, img, u, v, &xy_pdf);
+	if (cam_pos_gradient) {
+		atomicAdd(&cam_pos_gradient[img * 3 + 0], go.x / xy_pdf);
+		atomicAdd(&cam_pos_gradient[img * 3 + 1], go.y / xy_pdf);
+		atomicAdd(&cam_pos_gradient[img * 3 + 2], go.z / xy_pdf);
+	}
+	if (cam_rot_gradient) {
+		// rotation is averaged in log space: angle-axis = ray.d x ray_gradient.d (1692-1707)
+		const v3 d = normalized(ld3(rays_in[i].d));
+		atomicAdd(&cam_rot_gradient[img * 3 + 0], (d.y * gd.z - d.z * gd.y) / xy_pdf);
+		atomicAdd(&cam_rot_gradient[img * 3 + 1], (d.z * gd.x - d.x * gd.z) / xy_pdf);
+		atomicAdd(&cam_rot_gradient[img * 3 + 2], (d.x * gd.y - d.y * gd.x) / xy_pdf);
+	}
+}
+
 extern "C" {
 
 int ngp_hip_image_from_rgba32_f16(void* stream, uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color) {
@@ -605,6 +657,19 @@ int ngp_hip_compute_loss(
 	// n_rays upper-bounds *rays_counter (the number of ray slots the generator filled); one wave per slot
 	hipLaunchKernelGGL(compute_loss_kernel, dim3(div_up(n_rays, LOSS_RAYS_PER_BLOCK)), dim3(LOSS_RAYS_PER_BLOCK * 64), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("compute_loss_kernel");
+	return 0;
+}
+
+int ngp_hip_compute_cam_gradient(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
+	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host) {
+	if (!n_rays || (!cam_pos_gradient && !cam_rot_gradient)) return 0;
+	Pcg32 rng; rng.state = rng_state; rng.inc = rng_inc;
+	hipLaunchKernelGGL(compute_cam_gradient_kernel, dim3(div_up(n_rays * CAMGRAD_LANES, 256u)), dim3(256), 0, (hipStream_t)stream, n_rays, aabb_from_host(aabb_host), rng,
+	                   rays_counter, snap_to_pixel_centers, cam_pos_gradient, cam_rot_gradient, n_training_images, metadata, ray_indices_in, rays_in_unnormalized, numsteps_in,
+	                   coords_compacted, coords_gradient, make_error_map_cdf(cdf_host));
+	NGP_LAUNCH_CHECK("compute_cam_gradient_kernel");
 	return 0;
 }
 

@@ -1021,10 +1021,43 @@ __device__ __forceinline__ void fb_flush(float* __restrict__ red /* [4][16][64] 
 	__syncthreads();
 }
 
+// SH degree 4 backward to the direction for the 8 coefficients lane group g holds after the W3^T product (rows 16 + {0-3, 8-11} for g = 0,
+// 16 + {4-7, 12-15} for g = 1): sum_k g_k * d(SH_k)/d(x, y, z) over those 8, with x = 2 d - 1 ([tcnn] SphericalHarmonics backward to the input)
+__device__ __forceinline__ v3 sh4_grad_half(int g, float dx_, float dy_, float dz_, const float* __restrict__ gk /* 8 */) {
+	const float x = dx_ * 2.0f - 1.0f, y = dy_ * 2.0f - 1.0f, z = dz_ * 2.0f - 1.0f;
+	const float x2 = x * x, y2 = y * y, z2 = z * z;
+	const float A = 0.48860251190291987f, B = 1.0925484305920792f, C = 0.94617469575755997f, E = 0.54627421529603959f, F = 0.59004358992664352f,
+	            G = 2.8906114426405538f, Hh = 0.45704579946446572f, K = 0.3731763325901154f, M = 1.4453057213202769f;
+	float ax = 0.0f, ay = 0.0f, az = 0.0f;
+	if (g == 0) {   // coefficients 0, 1, 2, 3, 8, 9, 10, 11
+		ay += gk[1] * -A;
+		az += gk[2] * A;
+		ax += gk[3] * -A;
+		ax += gk[4] * (2.0f * E * x);      ay += gk[4] * (-2.0f * E * y);
+		ax += gk[5] * (-6.0f * F * x * y); ay += gk[5] * (F * (-3.0f * x2 + 3.0f * y2));
+		ax += gk[6] * (G * y * z);         ay += gk[6] * (G * x * z);          az += gk[6] * (G * x * y);
+		ay += gk[7] * (Hh * (1.0f - 5.0f * z2)); az += gk[7] * (-10.0f * Hh * y * z);
+	} else {        // coefficients 4, 5, 6, 7, 12, 13, 14, 15
+		ax += gk[0] * (B * y);             ay += gk[0] * (B * x);
+		ay += gk[1] * (-B * z);            az += gk[1] * (-B * y);
+		az += gk[2] * (2.0f * C * z);
+		ax += gk[3] * (-B * z);            az += gk[3] * (-B * x);
+		az += gk[4] * (K * (15.0f * z2 - 3.0f));
+		ax += gk[5] * (Hh * (1.0f - 5.0f * z2)); az += gk[5] * (-10.0f * Hh * x * z);
+		ax += gk[6] * (2.0f * M * x * z);  ay += gk[6] * (-2.0f * M * y * z);  az += gk[6] * (M * (x2 - y2));
+		ax += gk[7] * (F * (-3.0f * x2 + 3.0f * y2)); ay += gk[7] * (6.0f * F * x * y);
+	}
+	return mk(ax, ay, az);
+}
+
+// DIR_GRAD: additionally dL/d(direction) of every sample into dL_dinput[s][3..5] (fp32) — the input gradient a training step asks for when
+// camera parameters train (NerfNetwork::backward_impl with dL_dinput, nerf_network.h:187-266; testbed_nerf.cu:3324-3346)
+template <bool DIR_GRAD>
 __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                                   const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                                   const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
-                                                                  h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
+                                                                  h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words,
+                                                                  float* __restrict__ dL_dinput /* [n][6] or NULL */) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
@@ -1102,6 +1135,15 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 #pragma unroll
 		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
 		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
+		if (DIR_GRAD) {
+			// rows 16..31 of d_in are dL/d(SH coefficients), fp16 like the rgb network's dL_dinput matrix
+			float gk[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) gk[e] = (float)(half_t)t0[8 + e];
+			v3 dd3 = sh4_grad_half(g, c[4], c[5], c[6], gk);
+			dd3.x += __shfl_xor(dd3.x, 32, 64); dd3.y += __shfl_xor(dd3.y, 32, 64); dd3.z += __shfl_xor(dd3.z, 32, 64);
+			if (g == 0) { float* o = dL_dinput + (size_t)s * 6; o[3] = 2.0f * dd3.x; o[4] = 2.0f * dd3.y; o[5] = 2.0f * dd3.z; }
+		}
 		__syncthreads();
 
 		// ---- W2: dY = d_dens (16 rows), H = h1
@@ -1154,6 +1196,54 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 	fb_flush(red, acc_a, w, lane, 1, dst);
 	fb_flush(red, acc_b, w, lane, 2, dst);
 }
+
+// dL/d(position) through the hash encoding ([tcnn] GridEncoding: dy/dx of the trilinear interpolation — scale * prod over the other two
+// dimensions of (1 - w | w), times (value at the +1 corner - value at the 0 corner) — summed with dL/dy over levels and features in fp32, in
+// the order levels, dimension, corner pair, feature; oracle: orc_nerf_input_gradient).  One thread per sample; dL/dy = the dL/dx planes the
+// backward kernel left.  Only run when camera parameters train.
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) nerf_input_pos_gradient_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
+                                                                      uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes, float* __restrict__ dL_dinput) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const float* c = coords + (size_t)s * coord_stride;
+	const f3_t pv = load_pos3(c);
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	float gp[3] = {0.0f, 0.0f, 0.0f};
+	for (int l = 0; l < 16; ++l) {
+		const NgpGridLevel lv = desc->levels[l];
+		const LevelPos p = level_pos(lv, pv.x, pv.y, pv.z);
+		const uint32_t pg[3] = {p.gx, p.gy, p.gz};
+		const float w[3] = {p.fx, p.fy, p.fz};
+		h2 v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = grid[lv.offset + grid_index(lv, pg[0] + (k & 1), pg[1] + ((k >> 1) & 1), pg[2] + ((k >> 2) & 1))];
+		const h2 gq = dx_planes[(size_t)l * n + s];
+		const float g0 = (float)gq[0], g1 = (float)gq[1];
+#pragma unroll
+		for (int gd = 0; gd < 3; ++gd) {
+			float dy0 = 0.0f, dy1 = 0.0f;
+#pragma unroll
+			for (int idx = 0; idx < 4; ++idx) {
+				float weight = lv.scale;
+				int corner = 0;
+#pragma unroll
+				for (int nd = 0; nd < 2; ++nd) {
+					const int dim = nd >= gd ? nd + 1 : nd;
+					if ((idx >> nd) & 1) { weight *= w[dim]; corner |= 1 << dim; } else weight *= 1.0f - w[dim];
+				}
+				const h2 lo = v[corner], hi = v[corner | (1 << gd)];
+				dy0 += weight * ((float)hi[0] - (float)lo[0]);
+				dy1 += weight * ((float)hi[1] - (float)lo[1]);
+			}
+			gp[gd] += g0 * dy0;
+			gp[gd] += g1 * dy1;
+		}
+	}
+	float* o = dL_dinput + (size_t)s * 6;
+	o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
+}
+#pragma clang fp contract(fast)
 
 // ================================================================================================================
 // Plumbing configs P1 / P2: ONE grid encoding (2-D or 3-D, 16 levels x 2 features) -> ONE FullyFusedMLP 32 -> 64 -> 64 -> 16
@@ -1730,9 +1820,26 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 	return ngp_hip_nerf_backward_ev(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr);
 }
 
+static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput);
+
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event) {
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, nullptr);
+}
+
+int ngp_hip_nerf_backward_input(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, float* dL_dinput) {
+	if (!dL_dinput) { set_last_error("ngp_hip_nerf_backward_input: dL_dinput is NULL", hipErrorInvalidValue); return -1; }
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr, dL_dinput);
+}
+
+static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
 	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
@@ -1742,9 +1849,15 @@ int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const Ngp
 	(void)desc_host;
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
-	hipLaunchKernelGGL(nerf_backward_fused_kernel, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
+	if (dL_dinput) hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
+	                                  dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), dL_dinput);
+	else hipLaunchKernelGGL(nerf_backward_fused_kernel<false>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
+	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
+	if (dL_dinput) {
+		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const h2*)dx_planes, dL_dinput);
+		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
+	}
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");

@@ -139,6 +139,14 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                              uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event);
+/* The same backward pass PLUS the gradient with respect to the network INPUT — NerfNetwork::backward_impl with a dL_dinput matrix
+ * (nerf_network.h:187-266), which the training step requests when camera parameters train (prepare_input_gradients, src/testbed_nerf.cu:3324-3346).
+ * dL_dinput: fp32 [n][6] = d/d(pos x, y, z) through the hash encoding (tcnn GridEncoding backward to the input: fp32 sum over levels and
+ * features of dL/dy * dy/dx of the trilinear interpolation) and d/d(dir x, y, z) through the SH basis, both in the warped [0, 1] coordinates of
+ * NgpCoord; dt carries no gradient. */
+int ngp_hip_nerf_backward_input(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, float* dL_dinput);
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */
@@ -235,6 +243,16 @@ int ngp_hip_compute_loss(
 	target = |ray.d| * metadata[img].depth at the ray's pixel, rays of images without depth are unaffected (:1450-1452, 1536-1541) */,
 	float* exposure_gradient /* NULL, or [n_images][3] floats that receive (atomicAdd; the caller clears them) the gradient of the loss with
 	respect to the per-image exposures (:1558-1572, optimize_exposure) */);
+/* compute_cam_gradient_train_nerf (:1600-1712, call site :3350-3378), the extrinsics outputs: per kept ray, the network's input gradient of its COMPACTED samples
+ * (coords_gradient: [sample][6] fp32 as ngp_hip_nerf_backward_input writes it; numsteps_in holds the compacted (count, base) pairs ngp_hip_compute_loss left) is
+ * folded into a ray-origin and a ray-direction gradient and added (atomicAdd; the caller clears them every n_steps_between_cam_updates, :2916-2918) to
+ * cam_pos_gradient[img] and, as the angle-axis ray.d x grad_d, to cam_rot_gradient[img] ([n_images][3] floats each; either may be NULL), both divided by the pixel
+ * pdf of the ray's draw.  rng / cdf_host must be what ngp_hip_compute_loss got.  The lens-distortion branch (:1671-1683) is out of scope; the reference kernel
+ * takes a cam_focal_length_gradient pointer and never writes it. */
+int ngp_hip_compute_cam_gradient(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
+	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host);
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);

@@ -99,6 +99,11 @@ void orc_compute_loss(
 	float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance, const orc_error_map_cdf* cdf /* NULL: uniform */,
 	const uint16_t* encoded_in, uint16_t* encoded_out /* optional [sample][32] fp16 rows carried through the compaction */,
 	float depth_supervision_lambda, int depth_loss_type, float* exposure_gradient /* NULL or [n_images][3], accumulated */);
+void orc_compute_cam_gradient(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t n_rays_alive, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const orc_image_meta* metadata, const uint32_t* ray_indices_in,
+	const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in, const orc_coord* coords_all, const float* coords_gradient_all /* [sample][6] */,
+	const orc_error_map_cdf* cdf);
 void orc_image_from_rgba32_f16(uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color);
 void orc_image_sharpen(uint64_t n_pixels, uint32_t w, const void* pix, void* dest, int is_half, float sharpen_amount);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);

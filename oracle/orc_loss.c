@@ -239,6 +239,52 @@ void orc_compute_loss(
  *   fill_rollover:             inout[i] = inout[i % n_input]
  *   fill_rollover_and_rescale: inout[i] = (T)((float)inout[i % n_input] * n_input / n_total)
  * i.e. only the wrapped-around copies are rescaled; the kept originals are left untouched. */
+/* compute_cam_gradient_train_nerf (src/testbed_nerf.cu:1600-1712), the extrinsics part (cam_pos_gradient / cam_rot_gradient).
+ * numsteps_in holds the COMPACTED (numsteps, base) pairs compute_loss left (:1472-1473); coords / coords_gradient are the compacted batch and the
+ * network's input gradient ([sample][6]: d/dpos xyz, d/ddir xyz in warped coordinates, what tcnn's backward writes with dL_dinput).
+ * The distortion branch (:1671-1683) is out of scope; cam_focal_length_gradient is a parameter the reference kernel never writes. */
+void orc_compute_cam_gradient(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t n_rays_alive, int snap_to_pixel_centers,
+	float* cam_pos_gradient /* [n_images][3] or NULL, accumulated */, float* cam_rot_gradient /* likewise */, uint32_t n_training_images,
+	const orc_image_meta* metadata, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in,
+	const orc_coord* coords_all, const float* coords_gradient_all /* [sample][6] */, const orc_error_map_cdf* cdf) {
+	const orc_vec3 diag = orc_sub(aabb->max, aabb->min);
+	for (uint32_t i = 0; i < n_rays_alive; ++i) {
+		const uint32_t numsteps = numsteps_in[i * 2 + 0];
+		if (numsteps == 0) continue;                                         /* :1633-1636 */
+		const uint32_t base = numsteps_in[i * 2 + 1];
+		const orc_coord* coords = coords_all + base;
+		const float* cg = coords_gradient_all + (size_t)base * 6;
+		const uint32_t ray_idx = ray_indices_in[i];
+		const uint32_t img = orc_image_idx(ray_idx, n_rays, n_training_images, cdf ? cdf->cdf_img : NULL, NULL);
+		const orc_vec3 ray_o = rays_in_unnormalized[i].o;
+		const orc_vec3 ray_d = orc_normalized(rays_in_unnormalized[i].d);
+		orc_vec3 go = orc_v3(0, 0, 0), gd = orc_v3(0, 0, 0);
+		for (uint32_t j = 0; j < numsteps; ++j) {
+			const orc_vec3 warped = orc_v3(coords[j].pos[0], coords[j].pos[1], coords[j].pos[2]);
+			/* warp_position_derivative = 1 / aabb.diag() (:288-290) */
+			const orc_vec3 pg = orc_v3(cg[j * 6 + 0] * (1.0f / diag.x), cg[j * 6 + 1] * (1.0f / diag.y), cg[j * 6 + 2] * (1.0f / diag.z));
+			go = orc_add(go, pg);
+			const orc_vec3 pos = orc_unwarp_position(warped, aabb);
+			const float t = orc_norm(orc_sub(pos, ray_o));
+			/* warp_direction_derivative = 0.5 (:300-302) */
+			const orc_vec3 dg = orc_v3(cg[j * 6 + 3] * 0.5f, cg[j * 6 + 4] * 0.5f, cg[j * 6 + 5] * 0.5f);
+			gd = orc_add(gd, orc_add(orc_scale(pg, t), dg));
+		}
+		orc_pcg32 rng = {rng_state, rng_inc};
+		orc_pcg32_advance(&rng, (int64_t)((uint64_t)(uint32_t)(ray_idx * ORC_N_MAX_RANDOM_SAMPLES_PER_RAY)));
+		float xy_pdf = 1.0f, xy[2];
+		orc_nerf_random_image_pos_training(&rng, metadata[img].res, snap_to_pixel_centers, cdf, img, xy, &xy_pdf);
+		if (cam_pos_gradient) {
+			cam_pos_gradient[img * 3 + 0] += go.x / xy_pdf; cam_pos_gradient[img * 3 + 1] += go.y / xy_pdf; cam_pos_gradient[img * 3 + 2] += go.z / xy_pdf;
+		}
+		if (cam_rot_gradient) {
+			const orc_vec3 aa = orc_v3(ray_d.y * gd.z - ray_d.z * gd.y, ray_d.z * gd.x - ray_d.x * gd.z, ray_d.x * gd.y - ray_d.y * gd.x);                           /* :1697-1701 */
+			cam_rot_gradient[img * 3 + 0] += aa.x / xy_pdf; cam_rot_gradient[img * 3 + 1] += aa.y / xy_pdf; cam_rot_gradient[img * 3 + 2] += aa.z / xy_pdf;
+		}
+	}
+}
+
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout) {
 	size_t total = (size_t)n_elements * stride, avail = (size_t)n_input_elements * stride;
 	if (avail == 0 || avail >= total) return;

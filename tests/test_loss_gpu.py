@@ -333,3 +333,42 @@ def test_counter_posting_kernels(ngp, cuda):
     check(ngp.ngp_hip_post_words(None, None, None, None, 43, dst.data_ptr(), None, 0, None))
     torch.cuda.synchronize()
     assert dst.cpu().tolist() == [0, 0, 0, 43]
+
+
+@pytest.mark.parametrize("cdf_mode", [0, 3])
+def test_cam_gradient_matches_oracle(ngp, oracle, cuda, cdf_mode):
+    """compute_cam_gradient_train_nerf (extrinsics outputs): both sides get the ORACLE's compacted batch and one random input gradient, so the
+    comparison does not depend on the compaction's threshold decisions.  Per-ray sums are associated differently (16 lanes + shuffles vs a sequential
+    loop) and the accumulation over rays is atomic: rtol 2e-4 of the per-image gradient's magnitude."""
+    I = _inputs(oracle, cuda, n_rays=2048, seed=5, cdf_mode=cdf_mode)
+    B = 1 << 13                                                               # smaller than what the rays keep: the tail gets no room (numsteps 0)
+    o, _ = _run(ngp, oracle, cuda, I, 4, B)
+    n_rays, n_alive, n_img = I["n_rays"], I["n_alive"], len(I["xf"])
+    assert int(o["cnt"][0]) > B and (o["ns"][0::2][:n_alive] == 0).any() and (o["ns"][0::2][:n_alive] > 16).any()           # some rays were dropped: the "ray doesn't matter" branch runs
+    rs = np.random.RandomState(9)
+    cg = (rs.randn(B, 6) * 0.1).astype(np.float32)
+    ref_pos, ref_rot = np.zeros((n_img, 3), np.float32), np.zeros((n_img, 3), np.float32)
+    oracle.orc_compute_cam_gradient(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], n_alive, 0, ref_pos.ctypes.data, ref_rot.ctypes.data, n_img, I["md_host"].ctypes.data,
+                                    I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data, o["co"].ctypes.data, cg.ctypes.data,
+                                    I["c_host"].ctypes.data if cdf_mode else None)
+    d_pos, d_rot = H.dev_zeros(n_img * 12, cuda), H.dev_zeros(n_img * 12, cuda)
+    d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
+    d_md, d_idx, d_rays, d_ns, d_co, d_cg = (H.to_dev(a, cuda) for a in (I["md_dev"], I["r"]["idx"], I["r"]["rays"], o["ns"], o["co"], cg))
+    c_dev = None
+    if cdf_mode:
+        C = I["C"]
+        d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
+        c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if cdf_mode & 1 else 0, d_cy.data_ptr() if cdf_mode & 1 else 0, d_ci.data_ptr() if cdf_mode & 2 else 0, C["res"])
+    for rep in range(2):                                                       # accumulates: the second call doubles the sums
+        check(ngp.ngp_hip_compute_cam_gradient(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, d_pos.data_ptr(), d_rot.data_ptr(), n_img,
+                                               d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(),
+                                               c_dev.ctypes.data if c_dev is not None else None))
+        got_pos, got_rot = H.to_host(d_pos, np.float32).reshape(n_img, 3), H.to_host(d_rot, np.float32).reshape(n_img, 3)
+        for got, ref in ((got_pos, ref_pos), (got_rot, ref_rot)):
+            assert np.abs(ref).max() > 0
+            np.testing.assert_allclose(got, ref * (rep + 1), rtol=0, atol=2e-4 * np.abs(ref).max() * (rep + 1))
+    # either output may be left out
+    d_pos2 = H.dev_zeros(n_img * 12, cuda)
+    check(ngp.ngp_hip_compute_cam_gradient(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, d_pos2.data_ptr(), None, n_img, d_md.data_ptr(), d_idx.data_ptr(),
+                                           d_rays.data_ptr(), d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), c_dev.ctypes.data if c_dev is not None else None))
+    np.testing.assert_allclose(H.to_host(d_pos2, np.float32).reshape(n_img, 3), ref_pos, rtol=0, atol=2e-4 * np.abs(ref_pos).max())

@@ -130,6 +130,50 @@ def test_backward_matches_oracle(ngp, oracle, cuda):
     np.testing.assert_allclose(gg, rg, rtol=5e-2, atol=5e-3 * np.abs(rg).max())
 
 
+def test_backward_input_gradient_matches_oracle(ngp, oracle, cuda):
+    """ngp_hip_nerf_backward_input: the same parameter gradients as ngp_hip_nerf_backward plus dL/d(pos, dir) per sample (what tcnn's backward writes when the
+    caller passes dL_dinput, testbed_nerf.cu:3329-3330).  The position gradient runs through 16 levels of fp16 feature gradients, the direction gradient
+    through the SH polynomials' derivatives: norm-relative 2e-2 like the grid gradients, plus a per-element bound."""
+    n = 2048
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=n, grid_amp=0.5)
+    rs = np.random.RandomState(12)
+    dl = (rs.randn(n, 4) * 0.05).astype(np.float16)
+    d_dl = H.to_dev(dl, cuda)
+    out = H.dev_zeros(n * 4 * 2, cuda)
+    xs = H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    np_ = H.n_params(desc)
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch = H.dev_zeros(sb, cuda)
+    g_plain, g_input = H.dev_zeros(np_ * 2, cuda), H.dev_zeros(np_ * 2, cuda)
+    d_in = H.to_dev(np.full((n, 6), 7.0, np.float32), cuda)                   # poison: every element is overwritten
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                    g_plain.data_ptr(), scratch.data_ptr(), sb))
+    check(ngp.ngp_hip_nerf_backward_input(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                          g_input.data_ptr(), scratch.data_ptr(), sb, d_in.data_ptr()))
+    a, b = H.to_host(g_plain, np.float16).astype(np.float64), H.to_host(g_input, np.float16).astype(np.float64)
+    np.testing.assert_array_equal(a[:10240], b[:10240])                       # MLP part: same arithmetic, fixed reduction order
+    assert np.linalg.norm(a[10240:] - b[10240:]) <= 2e-3 * np.linalg.norm(a[10240:])   # grid part: fp16 atomics, order varies between launches
+    got = H.to_host(d_in, np.float32).reshape(n, 6).astype(np.float64)
+    ref = np.zeros((n, 6), np.float32)
+    oracle.orc_nerf_input_gradient(desc.ctypes.data, params.ctypes.data, coords.ctypes.data, 7, n, dl.ctypes.data, ref.ctypes.data)
+    ref = ref.astype(np.float64)
+    assert np.isfinite(got).all()
+    for name, sl in (("pos", slice(0, 3)), ("dir", slice(3, 6))):
+        g, r = got[:, sl], ref[:, sl]
+        assert np.linalg.norm(r) > 0
+        rel = np.linalg.norm(g - r) / np.linalg.norm(r)
+        assert rel < 2e-2, (name, rel)
+        np.testing.assert_allclose(g, r, rtol=5e-2, atol=2e-2 * np.abs(r).max(), err_msg=name)
+    # a prefix of the batch gives the prefix of the result (n is a multiple of 256, like ngp_hip_nerf_backward)
+    for m_ in (256, 768):
+        d_in2 = H.dev_zeros(m_ * 24, cuda)
+        check(ngp.ngp_hip_nerf_backward_input(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, m_, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                              g_input.data_ptr(), scratch.data_ptr(), sb, d_in2.data_ptr()))
+        g2 = H.to_host(d_in2, np.float32).reshape(m_, 6)
+        np.testing.assert_allclose(g2, got[:m_], rtol=1e-3, atol=1e-3 * np.abs(got).max())
+
+
 def test_backward_linearity(ngp, cuda):
     """size-independent property at the full batch size B = 2^18 and the real T = 2^19 table: grads(2*dL) ~= 2*grads(dL)."""
     n = 1 << 18

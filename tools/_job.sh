@@ -1,1 +1,4 @@
-for a in 0 1 2 3; do echo "== fwd ablate $a"; NGP_HIP_FWD_ABLATE=$a NGP_BWD_MODES=0 timeout 120 python tools/microbench.py --iters 20 2>&1 | grep "nerf_forward"; done
+#!/bin/bash
+cd /root/repo
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_network_gpu.py tests/test_loss_gpu.py -x -q -m gpu -k "cam_gradient" 2>&1 | tail -30
