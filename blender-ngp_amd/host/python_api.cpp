@@ -134,6 +134,36 @@ PYBIND11_MODULE(pyngp, m) {
 		memcpy(a.mutable_data(), px.data(), px.size());
 		return a;
 	});
+	// test hooks for cam_adam.h (the reference's adam_optimizer.h is header-only host code without a Python face): run a sequence of steps, return every iterate
+	m.def("_vec3_adam_steps", [](const py::array_t<float, py::array::c_style | py::array::forcecast>& grads, const py::array_t<float, py::array::c_style | py::array::forcecast>& lrs) {
+		auto g = grads.request();
+		if (g.ndim != 2 || g.shape[1] != 3 || lrs.size() != g.shape[0]) throw std::runtime_error{"grads must be (n, 3), lrs (n,)"};
+		Vec3Adam a;
+		py::array_t<float> out({g.shape[0], (py::ssize_t)3});
+		for (py::ssize_t i = 0; i < g.shape[0]; ++i) { a.h.learning_rate = lrs.data()[i]; a.step((const float*)g.ptr + i * 3); for (int c = 0; c < 3; ++c) out.mutable_at(i, c) = a.variable[c]; }
+		return out;
+	});
+	m.def("_rotation_adam_steps", [](const py::array_t<float, py::array::c_style | py::array::forcecast>& grads, const py::array_t<float, py::array::c_style | py::array::forcecast>& lrs) {
+		auto g = grads.request();
+		if (g.ndim != 2 || g.shape[1] != 3 || lrs.size() != g.shape[0]) throw std::runtime_error{"grads must be (n, 3), lrs (n,)"};
+		RotationAdam a;
+		py::array_t<float> out({g.shape[0], (py::ssize_t)3});
+		for (py::ssize_t i = 0; i < g.shape[0]; ++i) { a.h.learning_rate = lrs.data()[i]; a.step((const float*)g.ptr + i * 3); for (int c = 0; c < 3; ++c) out.mutable_at(i, c) = a.variable[c]; }
+		return out;
+	});
+	m.def("_angle_axis_round_trip", [](const py::array_t<float, py::array::c_style | py::array::forcecast>& angle_axis) {   // -> (3x3 matrix, angle-axis recovered from it)
+		if (angle_axis.size() != 3) throw std::runtime_error{"angle_axis must have 3 elements"};
+		const float* v = angle_axis.data();
+		const float angle = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+		const float axis[3] = {angle > 0 ? v[0] / angle : 0.f, angle > 0 ? v[1] / angle : 0.f, angle > 0 ? v[2] / angle : 1.f};
+		float mcm[9], a2, ax2[3];
+		angle_axis_to_matrix(angle, axis, mcm);
+		matrix_to_angle_axis(mcm, a2, ax2);
+		py::array_t<float> mat({3, 3}), back(3);
+		for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mat.mutable_at(r, c) = mcm[3 * c + r];
+		for (int c = 0; c < 3; ++c) back.mutable_at(c) = ax2[c] * a2;
+		return py::make_tuple(mat, back);
+	});
 	m.def("decode_png_gray16", [](const std::string& path) {   // stbi_load_16(path, .., 1) for PNG files: the loader's depth images -> (H, W) uint16
 		int w = 0, h = 0; std::vector<uint16_t> px;
 		read_png_gray16(path, w, h, px);
@@ -543,6 +573,7 @@ PYBIND11_MODULE(pyngp, m) {
 				d["dloss_rolled"] = u16(t.debug_buffer("dloss"), (size_t)c.target_batch_size * 4);
 				d["x_saved"] = u16(t.debug_buffer("x_saved"), (size_t)c.target_batch_size * 32);
 				d["grads"] = u16(t.debug_buffer("grads"), t.m_n_params);
+				if (t.m_nerf.training.optimize_extrinsics) d["coords_gradient"] = f32(t.debug_buffer("coords_gradient"), (size_t)c.target_batch_size * 6);   // dL/d(pos, dir) of the rolled-over batch
 				d["loss"] = f32(t.m_nerf.training.counters_rgb.loss, c.n_rays_global);
 				d["measured_batch_size"] = t.m_nerf.training.counters_rgb.measured_batch_size;
 				d["measured_batch_size_before_compaction"] = t.m_nerf.training.counters_rgb.measured_batch_size_before_compaction;
@@ -725,10 +756,27 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("snap_to_pixel_centers", &NerfTraining::snap_to_pixel_centers)
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
 		.def_readwrite("optimize_exposure", &NerfTraining::optimize_exposure)                   // python_api.cu:813
-		.def_readwrite("optimize_extrinsics", &NerfTraining::optimize_extrinsics)               // python_api.cu:811-815: switches of trainables this build lacks; train() refuses while one is set
-		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)
+		.def_readwrite("optimize_extrinsics", &NerfTraining::optimize_extrinsics)               // python_api.cu:811
+		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)               // python_api.cu:812, 814: switches of trainables this build lacks; train() refuses while one is set
 		.def_readwrite("optimize_distortion", &NerfTraining::optimize_distortion)
-		.def_readwrite("optimize_focal_length", &NerfTraining::optimize_focal_length)
+		.def_readwrite("optimize_focal_length", &NerfTraining::optimize_focal_length)           // python_api.cu:815: accepted; trains nothing, like the reference (testbed.h note)
+		.def("reset_camera_extrinsics", [](NerfTraining& t) { t.reset_camera_extrinsics(); })   // testbed_nerf.cu:2543-2555 (not bound by the reference's pyngp; GUI button there)
+		.def("_cam_offsets", [](NerfTraining& t) {   // test hook: (positions [n][3], angle-axis rotations [n][3], optimizer steps [n]) of optimize_extrinsics
+				const size_t n = t.cam_pos_offset.size();
+				py::array_t<float> pos({(py::ssize_t)n, (py::ssize_t)3}), rot({(py::ssize_t)n, (py::ssize_t)3});
+				py::array_t<uint32_t> it((py::ssize_t)n);
+				for (size_t i = 0; i < n; ++i) {
+					for (int c = 0; c < 3; ++c) { pos.mutable_at(i, c) = t.cam_pos_offset[i].variable[c]; rot.mutable_at(i, c) = i < t.cam_rot_offset.size() ? t.cam_rot_offset[i].variable[c] : 0.f; }
+					it.mutable_at(i) = t.cam_pos_offset[i].iter;
+				}
+				return py::make_tuple(pos, rot, it);
+			})
+		.def("_cam_gradients", [](NerfTraining& t) {   // test hook: the per-image gradients the last camera update consumed (summed over its window and over the ranks)
+				const size_t n = t.cam_pos_gradient.size() / 3;
+				py::array_t<float> pos({(py::ssize_t)n, (py::ssize_t)3}), rot({(py::ssize_t)n, (py::ssize_t)3});
+				if (n) { memcpy(pos.mutable_data(), t.cam_pos_gradient.data(), n * 12); memcpy(rot.mutable_data(), t.cam_rot_gradient.data(), n * 12); }
+				return py::make_tuple(pos, rot);
+			})
 		.def_readwrite("n_steps_between_cam_updates", &NerfTraining::n_steps_between_cam_updates)
 		.def_readwrite("include_sharpness_in_error", &NerfTraining::include_sharpness_in_error)
 		.def_readwrite("extrinsic_l2_reg", &NerfTraining::extrinsic_l2_reg)

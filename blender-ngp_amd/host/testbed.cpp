@@ -158,6 +158,9 @@ void NerfTraining::set_camera_extrinsics(int frame_idx, const Mat34& camera_to_w
 	memcpy(dataset.xforms[frame_idx].end, m.m, sizeof(m.m));
 	memset(dataset.metadata[frame_idx].rolling_shutter, 0, sizeof(float) * 4);
 	dataset.update_metadata(frame_idx, frame_idx + 1);
+	if ((size_t)frame_idx < cam_rot_offset.size()) cam_rot_offset[frame_idx].reset_state();   // 2533-2535
+	if ((size_t)frame_idx < cam_pos_offset.size()) cam_pos_offset[frame_idx].reset_state();
+	if ((size_t)frame_idx < cam_exposure.size()) cam_exposure[frame_idx] = ExposureAdam{};
 	update_transforms(frame_idx, frame_idx + 1);
 }
 Mat34 NerfTraining::get_camera_extrinsics(int frame_idx) const {
@@ -180,12 +183,34 @@ void NerfTraining::set_camera_intrinsics(int frame_idx, float fx, float fy, floa
 	m.focal_length[0] = fx; m.focal_length[1] = fy;
 	dataset.update_metadata(frame_idx, frame_idx + 1);
 }
+void NerfTraining::reset_camera_extrinsics() {
+	for (auto& o : cam_rot_offset) o.reset_state();
+	for (auto& o : cam_pos_offset) o.reset_state();
+	for (auto& o : cam_exposure) o = ExposureAdam{};
+}
 void NerfTraining::update_transforms(int first, int last) {
 	if (last < 0 || last > (int)dataset.n_images) last = (int)dataset.n_images;
 	int n = last - first;
 	if (n <= 0) return;
 	if (transforms.size() < (size_t)last) transforms.resize(last);
-	for (int i = first; i < last; ++i) transforms[i] = dataset.xforms[i];
+	for (int i = first; i < last; ++i) {
+		NgpXForm xform = dataset.xforms[i];
+		if ((size_t)i < cam_rot_offset.size()) {   // 2614-2622: the angle-axis offset rotates both shutter matrices
+			const float* rot = cam_rot_offset[i].variable;
+			const float angle = std::sqrt(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+			if (angle > 0) {
+				const float axis[3] = {rot[0] / angle, rot[1] / angle, rot[2] / angle};
+				float r[9];
+				angle_axis_to_matrix(angle, axis, r);
+				mat3_mul(r, xform.start, xform.start);   // the rotation block is the first 9 floats of the column-major 3x4
+				mat3_mul(r, xform.end, xform.end);
+			}
+		}
+		if ((size_t)i < cam_pos_offset.size()) {   // 2624-2627
+			for (int c = 0; c < 3; ++c) { xform.start[9 + c] += cam_pos_offset[i].variable[c]; xform.end[9 + c] += cam_pos_offset[i].variable[c]; }
+		}
+		transforms[i] = xform;
+	}
 	transforms_gpu.enlarge(dataset.n_images * sizeof(NgpXForm));
 	transforms_gpu.copy_from_host(transforms.data() + first, (size_t)n * sizeof(NgpXForm), (size_t)first * sizeof(NgpXForm));
 }
@@ -479,6 +504,8 @@ void Testbed::load_nerf_post() {
 	tr.cam_exposure_gpu.resize(zeros.size() * 4);
 	tr.cam_exposure_gpu.copy_from_host(zeros.data(), zeros.size() * 4);
 	if (tr.dataset.has_rays) tr.near_distance = 0.0f;
+	tr.cam_pos_offset.assign(tr.dataset.n_images, Vec3Adam{});      // 2654-2655 (learning rates are set per update, 3076-3077)
+	tr.cam_rot_offset.assign(tr.dataset.n_images, RotationAdam{});
 	tr.update_transforms();
 	if (!tr.dataset.metadata.empty()) {
 		m_nerf.render_lens_proxy = tr.dataset.metadata[0];
@@ -566,10 +593,12 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	NerfTraining& tr = m_nerf.training;
 	tr.counters_rgb.rays_per_batch = 1 << 12;
 	tr.counters_rgb.measured_batch_size_before_compaction = 0;
+	tr.n_steps_since_cam_update = 0;
 	tr.n_steps_since_error_map_update = 0;
 	tr.n_rays_since_error_map_update = 0;
 	tr.n_steps_between_error_map_updates = 128;
 	tr.density_grid_rng = Pcg32(m_rng.next_uint());
+	tr.reset_camera_extrinsics();   // testbed.cu:2267: the optimizer states only — the transforms keep the old offsets until the next update_transforms, like there
 
 	Json config = m_network_config;
 	const Json empty = Json::object();
@@ -761,6 +790,9 @@ void Testbed::shutdown_data_parallel() {
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
+	if (m_nerf.training.optimize_distortion || m_nerf.training.optimize_extra_dims)
+		throw std::runtime_error{"nerf.training.optimize_distortion / optimize_extra_dims: these camera-side trainables (testbed_nerf.cu:1671-1683, 1714-1746, 3034-3054, 3095-3101) "
+		                         "are not part of this build (optimize_extrinsics and optimize_exposure are; optimize_focal_length trains nothing in the reference either)"};
 	if (m_dp_comm) {
 		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
 		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
@@ -779,12 +811,6 @@ void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  //
 		check(ngp_rccl_allreduce_grads(m_dp_comm, m_stream, m_grads.as<uint16_t>(), m_n_params), "ngp_rccl_allreduce_grads");
 		train_nerf_dp_end();
 		return;
-	}
-	{
-		const NerfTraining& tr = m_nerf.training;
-		if (tr.optimize_extrinsics || tr.optimize_focal_length || tr.optimize_distortion || tr.optimize_extra_dims)
-			throw std::runtime_error{"nerf.training.optimize_extrinsics / optimize_focal_length / optimize_distortion / optimize_extra_dims: these camera-side trainables "
-			                         "(testbed_nerf.cu:1600-1746, 3056-3135) are not part of this build (optimize_exposure is)"};
 	}
 	if (m_world_size != 1) throw std::runtime_error{"train(): world_size > 1 — drive the step with train_nerf_dp_begin / _dp_backward / _dp_end around the all-reduces"};
 	uint32_t counters[2];
@@ -844,6 +870,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	const uint32_t next_step = m_training_step + 1;
 	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
 	if (next_step % n_prep_to_skip == 0) return;  // an occupancy-grid update (new bitfield) precedes that step
+	if (m_nerf.training.optimize_extrinsics && m_nerf.training.n_steps_since_cam_update + 1 >= m_nerf.training.n_steps_between_cam_updates) return;  // new camera transforms precede it (3060-3093)
 	NerfCounters& c = m_nerf.training.counters_rgb;
 	Pcg32 rng = m_rng;   // m_rng was already advanced for the next step (3380)
 	PrefetchedSamples p;
@@ -952,6 +979,13 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		if (tr.cam_exposure_gradient_gpu.bytes() < bytes) { tr.cam_exposure_gradient_gpu.resize(bytes); tr.n_steps_since_cam_update = 0; }
 		if (tr.n_steps_since_cam_update == 0) tr.cam_exposure_gradient_gpu.memset(0, m_stream);   // 2916-2919
 	}
+	if (tr.optimize_extrinsics) {
+		if (m_world_size > 1 && !m_dp_comm) throw std::runtime_error{"optimize_extrinsics at world_size > 1 needs init_data_parallel (the camera gradients are summed over the ranks)"};
+		const size_t bytes = tr.dataset.n_images * 3 * sizeof(float);
+		if (tr.cam_pos_gradient_gpu.bytes() < bytes) { tr.cam_pos_gradient_gpu.resize(bytes); tr.cam_rot_gradient_gpu.resize(bytes); tr.n_steps_since_cam_update = 0; }
+		if (tr.n_steps_since_cam_update == 0 || !tr.cam_gradient_window_open) { tr.cam_pos_gradient_gpu.memset(0, m_stream); tr.cam_rot_gradient_gpu.memset(0, m_stream); }   // 2916-2918
+	}
+	tr.cam_gradient_window_open = tr.optimize_extrinsics;
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
@@ -972,6 +1006,14 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
 	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
 	// march can be launched (stream B) while they run.
+	if (tr.optimize_extrinsics) {
+		// the camera-gradient kernel runs behind the backward pass and reads this step's rays; the next step's march (stream B, launched once the host has
+		// seen the counters posted below) overwrites them — so they are set aside here, in stream order before the post (R x 36 bytes)
+		m_cam_rays.enlarge((size_t)R * (sizeof(NgpRay) + 8)); m_cam_ray_indices.enlarge((size_t)R * 4);
+		HIP_CHECK_THROW(hipMemcpyAsync(m_cam_rays.data(), m_rays.data(), (size_t)R * sizeof(NgpRay), hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipMemcpyAsync((char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay), m_numsteps.data(), (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipMemcpyAsync(m_cam_ray_indices.data(), m_ray_indices.data(), (size_t)R * 4, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+	}
 	const float* loss_sum_dev = nullptr;
 	if (get_loss_scalar) {
 		check(ngp_hip_reduce_sum_f32(m_stream, c.loss.as<float>(), R, m_loss_scalar_gpu.as<float>()), "reduce_sum");
@@ -1004,11 +1046,25 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
-	check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-	                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
-	                               m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
+	if (tr.optimize_extrinsics) {
+		// prepare_input_gradients (3327-3330): the backward pass also writes dL/d(pos, dir) of every compacted sample; compute_cam_gradient_train_nerf (3350-3378)
+		// folds them into per-image position / rotation gradients.  The ray counter of this step's slot is stable until the step after next.
+		m_coords_gradient.enlarge((size_t)target_batch_size * 6 * sizeof(float));
+		check(ngp_hip_nerf_backward_input(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		                                  OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_coords_gradient.as<float>()), "nerf_backward_input");
+		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
+		profile_end(PK_BACKWARD, target_batch_size);
+		check(ngp_hip_compute_cam_gradient(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers, tr.cam_pos_gradient_gpu.as<float>(),
+		                                   tr.cam_rot_gradient_gpu.as<float>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(), m_cam_ray_indices.as<uint32_t>(),
+		                                   m_cam_rays.as<NgpRay>(), (const uint32_t*)((const char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay)), m_coords_compacted.as<NgpCoord>(),
+		                                   m_coords_gradient.as<float>(), tr.error_map_cdf(cdf_storage)), "compute_cam_gradient");
+	} else {
+		check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
+		                               m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
+		profile_end(PK_BACKWARD, target_batch_size);
+	}
 	m_grid_grad_event_recorded = m_want_grid_grad_event;
-	profile_end(PK_BACKWARD, target_batch_size);
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
 
 	m_counters_host_seen = wait_for_counters;
@@ -1050,6 +1106,7 @@ const DeviceBuffer& Testbed::debug_buffer(const std::string& name) const {
 	if (name == "x_saved") return m_x_saved;
 	if (name == "grads") return m_grads;
 	if (name == "coords") return m_coords;
+	if (name == "coords_gradient") return m_coords_gradient;
 	throw std::runtime_error{"debug_buffer: unknown buffer '" + name + "'"};
 }
 
@@ -1089,7 +1146,8 @@ void Testbed::train_nerf_dp_end() {
 	}
 	// camera-side trainables (3026, 3056-3135): only the per-image exposure is built
 	tr.n_steps_since_cam_update += 1;
-	if (tr.optimize_exposure && tr.n_steps_since_cam_update >= tr.n_steps_between_cam_updates) {
+	const bool cam_update_due = tr.n_steps_since_cam_update >= tr.n_steps_between_cam_updates;
+	if (tr.optimize_exposure && cam_update_due) {
 		const uint32_t n_img = (uint32_t)tr.n_images_for_training;
 		const float per_camera_loss_scale = (float)n_img / LOSS_SCALE / (float)tr.n_steps_between_cam_updates;
 		std::vector<float> grad(tr.dataset.n_images * 3);
@@ -1114,10 +1172,40 @@ void Testbed::train_nerf_dp_end() {
 		std::vector<float> exposures(tr.dataset.n_images * 3, 0.f);
 		for (uint32_t i = 0; i < n_img; ++i) for (int c = 0; c < 3; ++c) { tr.cam_exposure[i].x[c] -= mean[c] / (float)n_img; exposures[i * 3 + c] = tr.cam_exposure[i].x[c]; }   // renormalise (3123-3129)
 		tr.cam_exposure_gpu.copy_from_host(exposures.data(), exposures.size() * 4);
-		tr.n_steps_since_cam_update = 0;
 		++m_state_version;   // harmless for the march (it does not read exposures); keeps "inputs changed" bookkeeping honest
 	}
-	if (tr.n_steps_since_cam_update >= tr.n_steps_between_cam_updates) tr.n_steps_since_cam_update = 0;   // 3134 (train_camera false: the reference never resets; the window only matters when training)
+	if (tr.optimize_extrinsics && cam_update_due) {   // 3063-3093
+		const uint32_t n_img = (uint32_t)tr.n_images_for_training, n_all = (uint32_t)tr.dataset.n_images;
+		const float per_camera_loss_scale = (float)n_img / LOSS_SCALE / (float)tr.n_steps_between_cam_updates;
+		if (m_dp_comm) {
+			check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, tr.cam_pos_gradient_gpu.as<float>(), n_all * 3), "ngp_rccl_allreduce_f32 (camera position gradients)");
+			check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, tr.cam_rot_gradient_gpu.as<float>(), n_all * 3), "ngp_rccl_allreduce_f32 (camera rotation gradients)");
+		}
+		tr.cam_pos_gradient.resize(n_all * 3); tr.cam_rot_gradient.resize(n_all * 3);
+		HIP_CHECK_THROW(hipMemcpyAsync(tr.cam_pos_gradient.data(), tr.cam_pos_gradient_gpu.data(), n_all * 12, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipMemcpyAsync(tr.cam_rot_gradient.data(), tr.cam_rot_gradient_gpu.data(), n_all * 12, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
+		if (tr.cam_pos_offset.size() < n_all) tr.cam_pos_offset.resize(n_all);
+		if (tr.cam_rot_offset.size() < n_all) tr.cam_rot_offset.resize(n_all);
+		for (uint32_t i = 0; i < n_img; ++i) {
+			float pos_gradient[3], rot_gradient[3];
+			for (int c = 0; c < 3; ++c) {
+				pos_gradient[c] = tr.cam_pos_gradient[i * 3 + c] * per_camera_loss_scale;
+				rot_gradient[c] = tr.cam_rot_gradient[i * 3 + c] * per_camera_loss_scale;
+				pos_gradient[c] += tr.cam_pos_offset[i].variable[c] * tr.extrinsic_l2_reg;
+				rot_gradient[c] += tr.cam_rot_offset[i].variable[c] * tr.extrinsic_l2_reg;
+			}
+			// decays by a third every 128 camera updates, floored at a thousandth of the trainer's current learning rate (3076-3077)
+			tr.cam_pos_offset[i].h.learning_rate = std::max(tr.extrinsic_learning_rate * std::pow(0.33f, (float)(tr.cam_pos_offset[i].iter / 128)), m_learning_rate / 1000.0f);
+			tr.cam_rot_offset[i].h.learning_rate = std::max(tr.extrinsic_learning_rate * std::pow(0.33f, (float)(tr.cam_rot_offset[i].iter / 128)), m_learning_rate / 1000.0f);
+			tr.cam_pos_offset[i].step(pos_gradient);
+			tr.cam_rot_offset[i].step(rot_gradient);
+		}
+		drop_prefetch();            // no march is in flight (maybe_prefetch_next skipped this step); a stale one would be discarded through the version below
+		tr.update_transforms();
+		++m_state_version;
+	}
+	if (cam_update_due) tr.n_steps_since_cam_update = 0;   // 3134 (train_camera false: the reference never resets; the window only matters when training)
 	// error map -> CDFs (2971-3023): low-overhead enough to be always on in the reference; sampling from them is a separate switch
 	tr.n_steps_since_error_map_update += 1;
 	if (tr.n_steps_since_error_map_update >= tr.n_steps_between_error_map_updates && tr.error_map_res[0] > 0 && tr.dataset.n_images > 0) {

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <vector>
 
+#include "cam_adam.h"
 #include "mini_json.h"
 #include "ngp_hip.h"
 
@@ -135,9 +136,22 @@ struct NerfTraining {
 	DeviceBuffer cam_exposure_gradient_gpu;
 	bool optimize_exposure = false;
 	float exposure_l2_reg = 0.0f;
-	// camera-side trainables of testbed.h:651-662 that this build does not train: the switches exist so that a script setting them fails loudly
+	// optimize_extrinsics (testbed.h:633-644, 651; testbed_nerf.cu:1600-1712, 2598-2633, 3056-3093): per-image position / angle-axis rotation offsets on top of
+	// dataset.xforms, trained with the ray gradients the backward pass hands to ngp_hip_compute_cam_gradient, applied by update_transforms
+	bool optimize_extrinsics = false;
+	std::vector<Vec3Adam> cam_pos_offset;
+	std::vector<RotationAdam> cam_rot_offset;
+	DeviceBuffer cam_pos_gradient_gpu, cam_rot_gradient_gpu;       // [n_images][3] fp32 each, accumulated over n_steps_between_cam_updates steps
+	bool cam_gradient_window_open = false;                         // the buffers hold this window's sums (cleared when the switch comes on mid-window)
+	std::vector<float> cam_pos_gradient, cam_rot_gradient;         // host copies of the last update (python_api.cu does not expose them; tests do)
+	void reset_camera_extrinsics();                                // testbed_nerf.cu:2543-2555 (optimizer states only; the transforms follow at the next update_transforms)
+	// optimize_focal_length (testbed.h:652; testbed_nerf.cu:3095-3103): compute_cam_gradient_train_nerf receives cam_focal_length_gradient and never writes it, so
+	// the reference's Adam step sees a zero gradient on a zero variable and the offset stays exactly 0 — and nothing reads the offset.  The switch is accepted and
+	// trains nothing, like there.
+	bool optimize_focal_length = false;
+	// camera-side trainables of testbed.h:653-662 that this build does not train: the switches exist so that a script setting them fails loudly
 	// in train() instead of silently training something else (python_api.cu:804-812)
-	bool optimize_extrinsics = false, optimize_extra_dims = false, optimize_distortion = false, optimize_focal_length = false;
+	bool optimize_extra_dims = false, optimize_distortion = false;
 	bool include_sharpness_in_error = false;                       // testbed.h:670 (the sharpness map is not computed by this loader)
 	float extrinsic_l2_reg = 1e-4f, extrinsic_learning_rate = 1e-3f, intrinsic_l2_reg = 1e-4f;   // testbed.h:673-678
 	int view = 0;                                                  // current training view of the GUI navigation (testbed.h:636)
@@ -173,7 +187,7 @@ struct NerfTraining {
 	void set_camera_extrinsics(int frame_idx, const Mat34& camera_to_world, bool convert_to_ngp = true); // testbed_nerf.cu:2539-2541
 	Mat34 get_camera_extrinsics(int frame_idx) const;
 	void set_camera_intrinsics(int frame_idx, float fx, float fy, float cx, float cy, float k1, float k2, float p1, float p2); // testbed_nerf.cu:2502-2516
-	void update_transforms(int first = 0, int last = -1);                                // testbed_nerf.cu:2598-2633 (no extrinsic offsets)
+	void update_transforms(int first = 0, int last = -1);                                // testbed_nerf.cu:2598-2633 (dataset.xforms + the extrinsic offsets)
 };
 
 struct Nerf {
@@ -462,6 +476,7 @@ private:
 	void drop_prefetch();
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
 	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
+	DeviceBuffer m_cam_rays, m_cam_ray_indices, m_coords_gradient;   // optimize_extrinsics: the step's rays kept past the next march, and the network's input gradient [sample][6]
 	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;

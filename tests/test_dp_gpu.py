@@ -50,8 +50,11 @@ def test_testbed_data_parallel_step_with_one_rank(cuda, strong):
     assert b.world_size == 1 and b.rank == 0 and b.strong_scaling == strong
     b.nerf.training.optimize_exposure = True          # its gradients go through ngp_rccl_allreduce_f32 in the data-parallel step
     b.nerf.training.n_steps_between_error_map_updates = 16   # ... and so does the error map at every CDF rebuild
+    b.nerf.training.optimize_extrinsics = True        # ... and the per-image camera gradients at every camera update
     scene.train(a, 80)
     scene.train(b, 80)
+    pos, rot, it = b.nerf.training._cam_offsets()
+    assert (it == 5).all() and np.isfinite(pos).all() and np.abs(pos).max() > 0 and np.abs(rot).max() > 0
     assert a.training_step == b.training_step == 80
     assert b.nerf.training.is_cdf_valid
     assert np.isfinite(b.loss) and 0.4 < a.loss / b.loss < 2.5
