@@ -685,9 +685,13 @@ __device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, 
 template <int D, bool SCATTER>
 __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, uint32_t* __restrict__ stage, const NgpGridLevel& lv, uint32_t level,
                                              const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                             GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums) {
+                                             GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist) {
 	constexpr int PER = GB_FX_CHUNK / 256;
 	const GbSplit sp = gb_dense_split(lv.size);
+	// the count pass leaves this workgroup's per-bin record counts behind (256 words): the scatter pass picks them up instead of walking twice
+	uint32_t* __restrict__ my_hist = wg_hist + ((size_t)level * gridDim.x + blockIdx.x) * GB_FX_MAX_SLICES;
+	uint32_t saved = 0;
+	if (SCATTER && threadIdx.x < GB_FX_MAX_SLICES) saved = my_hist[threadIdx.x];
 	const uint32_t chunk_bin0 = (uint32_t)(((uint64_t)blockIdx.x * sp.k_chunks) / gridDim.x) * sp.n_slices;
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
 	uint32_t* s_g = stage;
@@ -702,11 +706,15 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 		s_g[ip] = __builtin_bit_cast(uint32_t, dxl[sc]);
 		if (D == 3) { const f3_t v = load_pos3(c); s_px[ip] = v.x; s_py[ip] = v.y; s_pz[ip] = v.z; } else { s_px[ip] = c[0]; s_py[ip] = c[1]; }
 	}
-	__syncthreads();
-	gb_dense_walk<D, false>(s_g, s_px, s_py, s_pz, hist, lv, chunk_bin0, n_live, nullptr, nullptr);
+	if (SCATTER && threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = saved;
 	__syncthreads();
 	if (!SCATTER) {
-		if (threadIdx.x < GB_FX_MAX_SLICES && hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
+		gb_dense_walk<D, false>(s_g, s_px, s_py, s_pz, hist, lv, chunk_bin0, n_live, nullptr, nullptr);
+		__syncthreads();
+		if (threadIdx.x < GB_FX_MAX_SLICES) {
+			my_hist[threadIdx.x] = hist[threadIdx.x];
+			if (hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
+		}
 		return;
 	}
 	// reserve the ranges (base[] then serves as the running cursor of each bin), walk again with the sums
@@ -722,7 +730,7 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 
 template <int D, bool SCATTER>
 __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums) {
+                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist) {
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
 	const uint32_t level = blockIdx.y;
 	const NgpGridLevel lv = desc->levels[level];
@@ -732,7 +740,7 @@ __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __rest
 	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[4 * GB_STAGE];
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
-	if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums);
+	if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums, wg_hist);
 	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, items);
 }
 
@@ -1672,9 +1680,10 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xffffu;
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
-	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
+	uint32_t* wg_hist = (uint32_t*)((char*)sums + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 16u);
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
-	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums);
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(1024), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
 	NGP_LAUNCH_CHECK("grid_backward_kernel");
@@ -1810,7 +1819,9 @@ static uint32_t wgrad_chunks(uint32_t n) {
 constexpr uint32_t FB_MAX_WORKGROUPS = 512;   // two resident workgroups per CU
 static uint64_t scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS * 4u; }
 static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
-static uint64_t gb_fx_bytes(uint32_t n) { return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u); }   // counters + item lists + run sums of the binned path
+static uint64_t gb_fx_bytes(uint32_t n) {   // counters + item lists + run sums of the binned path + the dense levels' per-workgroup bin counts
+	return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u) + (uint64_t)16 * ((n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u;
+}
 static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx(n) + gb_fx_bytes(n); }
 

@@ -13,7 +13,13 @@ from scipy.spatial.transform import Rotation
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "blender-ngp_amd")]
 
-pyngp = pytest.importorskip("pyngp")
+
+
+@pytest.fixture(scope="module")
+def pyngp():
+    import torch  # noqa: F401  (one HIP runtime per process: torch's first, see capi.load_ngp_hip)
+    return pytest.importorskip("pyngp")
+
 
 B1, B2, EPS = np.float64(np.float32(0.9)), np.float64(np.float32(0.99)), np.float64(np.float32(1e-8))
 
@@ -35,7 +41,7 @@ def _adam_f64(grads, lrs, rotation):
 
 
 @pytest.mark.parametrize("rotation", [False, True])
-def test_adam_iterates(rotation):
+def test_adam_iterates(pyngp, rotation):
     rs = np.random.RandomState(3)
     n = 400
     grads = (rs.randn(n, 3) * np.array([1.0, 0.1, 10.0]) + np.array([0.5, -0.02, 0.0])).astype(np.float32)
@@ -47,7 +53,7 @@ def test_adam_iterates(rotation):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
 
 
-def test_adam_zero_gradient_from_zero_state_stays_zero():
+def test_adam_zero_gradient_from_zero_state_stays_zero(pyngp):
     """optimize_focal_length in the reference: zero gradient on a zero variable -> 0 / (0 + eps) = 0, the variable never moves (testbed_nerf.cu:3095-3101)."""
     z = np.zeros((20, 3), np.float32)
     lrs = np.full(20, 1e-3, np.float32)
@@ -56,7 +62,7 @@ def test_adam_zero_gradient_from_zero_state_stays_zero():
 
 
 @pytest.mark.parametrize("aa", [(0.3, -0.2, 0.1), (0.0, 0.0, 1e-4), (2.0, 2.0, 0.5), (0.0, 3.1, 0.0), (0, 0, 0)])
-def test_angle_axis_matrix_round_trip(aa):
+def test_angle_axis_matrix_round_trip(pyngp, aa):
     aa = np.array(aa, np.float32)
     mat, back = pyngp._angle_axis_round_trip(aa)
     np.testing.assert_allclose(mat, Rotation.from_rotvec(aa.astype(np.float64)).as_matrix(), atol=3e-7)

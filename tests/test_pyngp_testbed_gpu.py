@@ -141,7 +141,7 @@ def test_shall_train_encoding_and_network(trained):
     assert (q[:n_mlp] != p[:n_mlp]).sum() > 1000
     t.shall_train_encoding = True
     # trainables this build lacks refuse loudly instead of training something else
-    for name in ("optimize_extrinsics", "optimize_focal_length", "optimize_distortion", "optimize_extra_dims"):
+    for name in ("optimize_distortion", "optimize_extra_dims"):               # (optimize_extrinsics / optimize_focal_length: tests/test_extrinsics_gpu.py)
         setattr(t.nerf.training, name, True)
         with pytest.raises(RuntimeError, match="not part of this build"):
             t.frame()

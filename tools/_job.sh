@@ -1,4 +1,6 @@
 #!/bin/bash
 cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_dp_gpu.py tests/test_extrinsics_gpu.py tests/test_error_map_gpu.py tests/test_step_schedule_gpu.py -x -q -m gpu 2>&1 | tail -20
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/full_gpu.log 2>&1
+tail -5 gpurun_out/full_gpu.log
+grep -n "RuntimeError" gpurun_out/full_gpu.log | head
