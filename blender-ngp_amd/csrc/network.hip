@@ -730,9 +730,10 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 
 template <int D, bool SCATTER>
 __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist) {
+                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask) {
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
 	const uint32_t level = blockIdx.y;
+	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
 	const bool fx = gb_uses_fx(lv.size, lv.resolution, dense);
@@ -1681,9 +1682,9 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	uint32_t* wg_hist = (uint32_t*)((char*)sums + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 16u);
-	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist);
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
-	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist);
+	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(1024), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
 	NGP_LAUNCH_CHECK("grid_backward_kernel");
