@@ -137,6 +137,9 @@ RENDER_CAMERA = np.dtype([("transform", "<f4", 12), ("model", "<i4"), ("focal_le
                           ("qh_front", "<f4", 12), ("qh_back", "<f4", 12), ("near_distance", "<f4"), ("aperture_size", "<f4"), ("focus_z", "<f4")])
 assert GLOBAL_RAY.itemsize == 52 and PROXY_RAY.itemsize == 40 and MASK3D.itemsize == 168 and NERF_PROPS.itemsize == 224
 assert DOWNSAMPLE_INFO.itemsize == 32 and RENDER_CAMERA.itemsize == 176
+LOSS_EXTRAS = np.dtype([("envmap_data", "<u8"), ("envmap_gradient", "<u8"), ("envmap_res", "<i4", 2), ("envmap_loss_type", "<i4")], align=True)   # NgpLossExtras
+RENDER_EXTRAS = np.dtype([("render_masks", "<u8"), ("n_render_masks", "<u4"), ("glow_mode", "<i4"), ("glow_y_cutoff", "<f4"), ("envmap", "<u8"), ("envmap_res", "<i4", 2),
+                          ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8")], align=True)   # NgpRenderExtras
 
 assert AABB.itemsize == 24 and RAY.itemsize == 24 and XFORM.itemsize == 96 and COORD.itemsize == 28 and PAYLOAD.itemsize == 40
 assert NET_DESC.itemsize == 8 + 16 * 16

@@ -50,6 +50,7 @@ struct LossArgs {
 	const uint16_t* encoded_in; uint16_t* encoded_out;   // optional: [sample][32] fp16 encoding rows carried through the compaction
 	float depth_supervision_lambda; int depth_loss_type;  // testbed.h:654, 680 (off by default)
 	float* exposure_gradient;                             // [n_images][3] or NULL (optimize_exposure off)
+	const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int envmap_loss_type;   // 1289-1292: fp32 [h][w][4] (TrainableBuffer<4,2,float>) or NULL
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	float rgbtarget[3] = {0, 0, 0}, xy[2] = {0, 0}, max_level = 1.0f, sample_pdf = 1.0f, pixel_pdf = 1.0f, exposure_scale[3] = {1.f, 1.f, 1.f};
 	uint32_t img = 0;
 	int32_t img_res[2] = {1, 1};
-	v3 ray_o = mk(0, 0, 0);
+	v3 ray_o = mk(0, 0, 0), env_dir = mk(0, 0, 1);
 	if (active) {
 		ray_o = ld3(a.rays_in[i].o);
 		const uint32_t ray_idx = a.ray_indices_in[i];
@@ -116,6 +117,13 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
 #pragma unroll
 		for (int c = 0; c < 3; ++c) bg[c] = srgb_to_linear(bg[c]);
+		if (a.envmap_data) {   // composit the background behind the envmap (1394-1401)
+			env_dir = normalized(ld3(a.rays_in[i].d));
+			float e[4];
+			read_envmap(a.envmap_data, a.envmap_res[0], a.envmap_res[1], env_dir, e);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) bg[c] = e[c] + bg[c] * (1.0f - e[3]);
+		}
 #pragma unroll
 		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * a.exposure[img * 3 + c]);
 		float texsamp[4];
@@ -212,6 +220,21 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			float dloss_by_dgt = -lg.grad[c] / pixel_pdf;
 			if (!a.train_in_linear_colors) dloss_by_dgt /= srgb_to_linear_derivative(rgbtarget[c]);
 			atomicAdd(&a.exposure_gradient[img * 3 + c], a.loss_scale * dloss_by_dgt * exposure_scale[c] * 0.6931471805599453f);
+		}
+	}
+	// environment-map gradient (1573-1596): only rays whose every sample was kept see the background; the value and the bilinear weight pass through
+	// network_precision_t (fp16) like the reference's vector_t<half, 4> / `T weight`, the accumulation is fp32 (TrainableBuffer<4, 2, float>)
+	if (a.envmap_gradient && compacted == numsteps && lane == 0) {
+		LG lge = lg;
+		if (a.envmap_loss_type != a.loss_type) lge = loss_and_gradient(rgbtarget, rgb_ray, a.envmap_loss_type);
+		const EnvmapTap tap = envmap_taps(a.envmap_res[0], a.envmap_res[1], env_dir);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			float d = T_final * lge.grad[c];
+			if (!a.train_in_linear_colors) d /= srgb_to_linear_derivative(bg[c]);
+			const half_t v16 = (half_t)(a.loss_scale * d);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) atomicAdd(&a.envmap_gradient[tap.idx[k] + c], (float)(half_t)(v16 * (half_t)tap.w[k]));
 		}
 	}
 	// depth supervision (1450-1452): target = |d| * depth image at the ray's pixel, loss on the expected termination depth
@@ -538,6 +561,31 @@ __global__ void sharpen_kernel(uint64_t num_pixels, uint32_t w, const T* __restr
 	for (int j = 0; j < 4; ++j) rgba[j] -= (float)pix[i2++];
 	for (int j = 0; j < 4; ++j) destpix[i * 4 + j] = (T)fmaxf(0.f, rgba[j] * inv_totalw);
 }
+// safe_divide (2039-2045): the distortion gradient image over its weight image
+__global__ void safe_divide_kernel(uint32_t n, float* __restrict__ inout, const float* __restrict__ divisor) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n) return;
+	const float d = divisor[i];
+	inout[i] = d > 0.0f ? (inout[i] / d) : 0.0f;
+}
+// [tcnn] Adam (+ Ema) on a TrainableBuffer<N, 2, float>: every parameter is a non-matrix parameter (layer_sizes() is empty), so an entry whose
+// gradient is exactly zero is skipped and l2_reg never applies; weights, gradients and the Ema copy are all fp32.
+__global__ void __launch_bounds__(256) adam_ema_f32_kernel(uint32_t n, float lr, float beta1, float beta2, float epsilon, float loss_scale, float ema_decay, float ema_debias_old,
+                                                           float ema_debias_new, const float* __restrict__ grads, float* __restrict__ params, float* __restrict__ m1,
+                                                           float* __restrict__ m2, float* __restrict__ ema) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float g = grads[i] / loss_scale;
+	float w = params[i];
+	if (g != 0.0f) {
+		const float fm = beta1 * m1[i] + (1.0f - beta1) * g;
+		const float sm = beta2 * m2[i] + (1.0f - beta2) * (g * g);
+		m1[i] = fm; m2[i] = sm;
+		w = w - (lr / (sqrtf(sm) + epsilon)) * fm;
+		params[i] = w;
+	}
+	if (ema) ema[i] = (ema[i] * ema_decay * ema_debias_old + w * (1.0f - ema_decay)) * ema_debias_new;
+}
 }  // namespace ngp
 
 using namespace ngp;
@@ -550,7 +598,8 @@ constexpr int CAMGRAD_LANES = 16;
 __global__ void __launch_bounds__(256) compute_cam_gradient_kernel(
 	uint32_t n_rays, Aabb aabb, Pcg32 rng_in, const uint32_t* __restrict__ rays_counter, int snap_to_pixel_centers, float* __restrict__ cam_pos_gradient,
 	float* __restrict__ cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* __restrict__ metadata, const uint32_t* __restrict__ ray_indices_in,
-	const NgpRay* __restrict__ rays_in, const uint32_t* __restrict__ numsteps_in, const NgpCoord* __restrict__ coords, const float* __restrict__ coords_gradient, ErrorMapCdf cdf) {
+	const NgpRay* __restrict__ rays_in, const uint32_t* __restrict__ numsteps_in, const NgpCoord* __restrict__ coords, const float* __restrict__ coords_gradient, ErrorMapCdf cdf,
+	const NgpXForm* __restrict__ xforms, float* __restrict__ distortion_gradient, float* __restrict__ distortion_gradient_weight, int dist_rx, int dist_ry) {
 	const uint32_t sub = threadIdx.x % CAMGRAD_LANES;
 	const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / CAMGRAD_LANES;
 	const bool active = i < *rays_counter;
@@ -580,6 +629,15 @@ __global__ void __launch_bounds__(256) compute_cam_gradient_kernel(
 	rng.advance((uint64_t)(uint32_t)(ray_idx * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
 	float u, v, xy_pdf = 1.0f;
 	nerf_random_image_pos_training(rng, metadata[img].res, snap_to_pixel_centers, cdf, img, u, v, &xy_pdf);
+	if (distortion_gradient) {   // 1673-1685: the ray-direction gradient, projected onto the plane normal to the ray, rotated into the camera frame, splatted at the pixel
+		const v3 d = normalized(ld3(rays_in[i].d));
+		const float gdd = dot(gd, d);
+		const v3 og = gd - d * gdd;
+		float inv[9];
+		mat3_inverse(xforms[img].start, inv);
+		const v3 ipg = mat3_mul(inv, og);
+		deposit_image_gradient2(ipg.x / xy_pdf, ipg.y / xy_pdf, distortion_gradient, distortion_gradient_weight, dist_rx, dist_ry, u, v);
+	}
 	if (cam_pos_gradient) {
 		atomicAdd(&cam_pos_gradient[img * 3 + 0], go.x / xy_pdf);
 		atomicAdd(&cam_pos_gradient[img * 3 + 1], go.y / xy_pdf);
@@ -637,6 +695,23 @@ int ngp_hip_compute_loss(
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
 	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
 	float* exposure_gradient) {
+	return ngp_hip_compute_loss_ex(stream, n_rays, aabb_host, rng_state, rng_inc, max_samples_compacted, rays_counter, loss_scale, mlp_stride, background_color_host, color_space,
+	                               train_with_random_bg_color, train_in_linear_colors, n_training_images, metadata, network_output, numsteps_counter, ray_indices_in, rays_in_unnormalized,
+	                               numsteps_in, coords_in, coords_out, dloss_doutput, dl_stride, loss_type, loss_output, max_level_rand_training, max_level_compacted, rgb_activation,
+	                               density_activation, snap_to_pixel_centers, error_map, error_map_res_host, mean_density, exposure, near_distance, cdf_host, encoded_in, encoded_out,
+	                               depth_supervision_lambda, depth_loss_type, exposure_gradient, nullptr);
+}
+
+int ngp_hip_compute_loss_ex(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
+	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
+	int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const NgpImageMeta* metadata,
+	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const NgpRay* rays_in_unnormalized,
+	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
+	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
+	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
+	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
+	float* exposure_gradient, const NgpLossExtras* extras_host) {
 	if (!n_rays) return 0;
 	if ((encoded_in == nullptr) != (encoded_out == nullptr)) { set_last_error("ngp_hip_compute_loss: encoded_in and encoded_out go together", hipErrorInvalidValue); return -1; }
 	if ((mlp_stride & 3) || (dl_stride & 3)) { set_last_error("ngp_hip_compute_loss: strides must be multiples of 4 halves", hipErrorInvalidValue); return -1; }
@@ -654,6 +729,11 @@ int ngp_hip_compute_loss(
 	a.density_activation = density_activation; a.snap_to_pixel_centers = snap_to_pixel_centers; a.error_map = error_map;
 	a.error_map_res[0] = error_map_res_host ? error_map_res_host[0] : 0; a.error_map_res[1] = error_map_res_host ? error_map_res_host[1] : 0;
 	a.mean_density = mean_density; a.exposure = exposure; a.near_distance = near_distance;
+	a.envmap_data = nullptr; a.envmap_gradient = nullptr; a.envmap_res[0] = a.envmap_res[1] = 0; a.envmap_loss_type = loss_type;
+	if (extras_host && extras_host->envmap_data && extras_host->envmap_res[0] > 0 && extras_host->envmap_res[1] > 0) {
+		a.envmap_data = extras_host->envmap_data; a.envmap_gradient = extras_host->envmap_gradient;
+		a.envmap_res[0] = extras_host->envmap_res[0]; a.envmap_res[1] = extras_host->envmap_res[1]; a.envmap_loss_type = extras_host->envmap_loss_type;
+	}
 	// n_rays upper-bounds *rays_counter (the number of ray slots the generator filled); one wave per slot
 	hipLaunchKernelGGL(compute_loss_kernel, dim3(div_up(n_rays, LOSS_RAYS_PER_BLOCK)), dim3(LOSS_RAYS_PER_BLOCK * 64), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("compute_loss_kernel");
@@ -664,12 +744,45 @@ int ngp_hip_compute_cam_gradient(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
 	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host) {
-	if (!n_rays || (!cam_pos_gradient && !cam_rot_gradient)) return 0;
+	return ngp_hip_compute_cam_gradient_ex(stream, n_rays, aabb_host, rng_state, rng_inc, rays_counter, snap_to_pixel_centers, cam_pos_gradient, cam_rot_gradient, n_training_images, metadata,
+	                                       ray_indices_in, rays_in_unnormalized, numsteps_in, coords_compacted, coords_gradient, cdf_host, nullptr, nullptr, nullptr, nullptr);
+}
+
+int ngp_hip_compute_cam_gradient_ex(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
+	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host,
+	const NgpXForm* xforms, float* distortion_gradient, float* distortion_gradient_weight, const int32_t* distortion_resolution_host) {
+	if (!n_rays || (!cam_pos_gradient && !cam_rot_gradient && !distortion_gradient)) return 0;
+	if (distortion_gradient && (!xforms || !distortion_gradient_weight || !distortion_resolution_host || distortion_resolution_host[0] <= 0 || distortion_resolution_host[1] <= 0)) {
+		set_last_error("ngp_hip_compute_cam_gradient_ex: the distortion gradient needs the training transforms, a weight buffer and a resolution", hipErrorInvalidValue); return -1;
+	}
 	Pcg32 rng; rng.state = rng_state; rng.inc = rng_inc;
 	hipLaunchKernelGGL(compute_cam_gradient_kernel, dim3(div_up(n_rays * CAMGRAD_LANES, 256u)), dim3(256), 0, (hipStream_t)stream, n_rays, aabb_from_host(aabb_host), rng,
 	                   rays_counter, snap_to_pixel_centers, cam_pos_gradient, cam_rot_gradient, n_training_images, metadata, ray_indices_in, rays_in_unnormalized, numsteps_in,
-	                   coords_compacted, coords_gradient, make_error_map_cdf(cdf_host));
+	                   coords_compacted, coords_gradient, make_error_map_cdf(cdf_host), xforms, distortion_gradient, distortion_gradient_weight,
+	                   distortion_gradient ? distortion_resolution_host[0] : 0, distortion_gradient ? distortion_resolution_host[1] : 0);
 	NGP_LAUNCH_CHECK("compute_cam_gradient_kernel");
+	return 0;
+}
+
+int ngp_hip_safe_divide(void* stream, uint32_t n_elements, float* inout, const float* divisor) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(safe_divide_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, inout, divisor);
+	NGP_LAUNCH_CHECK("safe_divide_kernel");
+	return 0;
+}
+
+int ngp_hip_optimizer_step_f32(void* stream, uint32_t n_params, uint32_t step, float learning_rate, float beta1, float beta2, float epsilon, float loss_scale, float ema_decay,
+                               const float* grads, float* params, float* first_moments, float* second_moments, float* ema) {
+	if (!n_params) return 0;
+	if (step == 0) { set_last_error("ngp_hip_optimizer_step_f32: step is the 1-based count of optimizer steps", hipErrorInvalidValue); return -1; }
+	const float lr = learning_rate * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+	const float ema_debias_old = 1.0f - powf(ema_decay, (float)(step - 1));
+	const float ema_debias_new = 1.0f / (1.0f - powf(ema_decay, (float)step));
+	hipLaunchKernelGGL(adam_ema_f32_kernel, dim3(div_up(n_params, 256)), dim3(256), 0, (hipStream_t)stream, n_params, lr, beta1, beta2, epsilon, loss_scale, ema_decay, ema_debias_old, ema_debias_new,
+	                   grads, params, first_moments, second_moments, ema);
+	NGP_LAUNCH_CHECK("adam_ema_f32_kernel");
 	return 0;
 }
 

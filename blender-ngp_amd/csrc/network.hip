@@ -1254,6 +1254,75 @@ __global__ void __launch_bounds__(256) nerf_input_pos_gradient_kernel(const NgpN
 }
 #pragma clang fp contract(fast)
 
+// ---- visualisation passes of the renderer (not on the training path): [tcnn] Network::visualize_activation and the in-place write-back of
+// DifferentiableObject::input_gradient.  One thread per sample, scalar fp32 accumulation over the row-major fp16 weights (their index is
+// wave-uniform: scalar loads), activations rounded to fp16 between layers like the MFMA kernels store them.
+__device__ __forceinline__ float vis_dot(const half_t* __restrict__ w, const half_t* __restrict__ x, int n) {
+	float acc = 0.0f;
+	for (int i = 0; i < n; ++i) acc += (float)w[i] * (float)x[i];
+	return acc;
+}
+__global__ void __launch_bounds__(256) nerf_visualize_activation_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, uint32_t layer, uint32_t dim,
+                                                                        const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, float* __restrict__ out, uint32_t out_stride) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const float* c = coords + (size_t)s * coord_stride;
+	const f3_t pv = load_pos3(c);
+	const float d0 = c[4], d1 = c[5], d2 = c[6];
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	half_t x[32];
+	for (int l = 0; l < 16; ++l) encode_level<false>(desc->levels[l], grid, pv.x, pv.y, pv.z, x[2 * l], x[2 * l + 1]);
+	float v;
+	if (layer == 0) {
+		v = (float)x[dim & 31];
+	} else if (layer == 1) {
+		v = fmaxf((float)(half_t)vis_dot(params + W1_OFF + (dim & 63) * 32, x, 32), 0.0f);
+	} else {
+		half_t rin[32];
+		if (layer == 2 && dim >= 16) {
+			const h8 a = sh4_half(0, d0, d1, d2), b = sh4_half(1, d0, d1, d2);
+			v = (float)((dim & 31) < 24 ? a[dim & 7] : b[dim & 7]);
+		} else {
+			half_t h[64];
+			for (int o = 0; o < 64; ++o) h[o] = (half_t)fmaxf(vis_dot(params + W1_OFF + o * 32, x, 32), 0.0f);
+			if (layer == 2) {
+				v = (float)(half_t)vis_dot(params + W2_OFF + (dim & 15) * 64, h, 64);
+			} else {
+				for (int o = 0; o < 16; ++o) rin[o] = (half_t)vis_dot(params + W2_OFF + o * 64, h, 64);
+				const h8 a = sh4_half(0, d0, d1, d2), b = sh4_half(1, d0, d1, d2);
+				for (int o = 0; o < 8; ++o) { rin[16 + o] = a[o]; rin[24 + o] = b[o]; }
+				if (layer == 3) {
+					v = fmaxf((float)(half_t)vis_dot(params + W3_OFF + (dim & 63) * 32, rin, 32), 0.0f);
+				} else {
+					for (int o = 0; o < 64; ++o) h[o] = (half_t)fmaxf(vis_dot(params + W3_OFF + o * 32, rin, 32), 0.0f);
+					v = fmaxf((float)(half_t)vis_dot(params + W4_OFF + (dim & 63) * 64, h, 64), 0.0f);
+				}
+			}
+		}
+	}
+	// [tcnn] extract_dimension_pos_neg_kernel: row 0 = negative part, row 1 = positive part, row 2 = 0, further rows = 1
+	float* o = out + (size_t)s * out_stride;
+	if (out_stride == 1) { o[0] = v; return; }
+	for (uint32_t k = 0; k < out_stride; ++k) o[k] = k == 0 ? fmaxf(-v, 0.0f) : k == 1 ? fmaxf(v, 0.0f) : k == 2 ? 0.0f : 1.0f;
+}
+
+__global__ void __launch_bounds__(256) one_hot_dl_kernel(uint32_t n, uint32_t dim, float scale, half_t* __restrict__ dL_dout /* [n][4] */) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	for (uint32_t k = 0; k < 4; ++k) dL_dout[(size_t)s * 4 + k] = (half_t)(k == dim ? scale : 0.0f);
+}
+// d_output_d_input aliases the input: position and direction rows <- gradient / scale, every other row (dt) <- old value / scale
+__global__ void __launch_bounds__(256) input_gradient_writeback_kernel(uint32_t n, float inv_scale, const float* __restrict__ dL_dinput /* [n][6] */, float* __restrict__ coords, uint32_t coord_stride) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	float* c = coords + (size_t)s * coord_stride;
+	const float* g = dL_dinput + (size_t)s * 6;
+	c[0] = g[0] * inv_scale; c[1] = g[1] * inv_scale; c[2] = g[2] * inv_scale;
+	c[3] = c[3] * inv_scale;
+	c[4] = g[3] * inv_scale; c[5] = g[4] * inv_scale; c[6] = g[5] * inv_scale;
+	for (uint32_t k = 7; k < coord_stride; ++k) c[k] = c[k] * inv_scale;
+}
+
 // ================================================================================================================
 // Plumbing configs P1 / P2: ONE grid encoding (2-D or 3-D, 16 levels x 2 features) -> ONE FullyFusedMLP 32 -> 64 -> 64 -> 16
 // (tcnn NetworkWithInputEncoding as built by Testbed::reset_network for Image / Sdf mode, src/testbed.cu:2397-2445; configs/image/base.json,
@@ -1876,6 +1945,55 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
+	return 0;
+}
+
+// ---- renderer visualisation passes: input gradient (Normals), activation visualisation (EncodingVis / Slice)
+static uint64_t ig_off_dl(uint32_t n) { return ngp_hip_nerf_backward_scratch_bytes(n); }
+static uint64_t ig_off_x(uint32_t n) { return ig_off_dl(n) + (uint64_t)n * 4 * 2; }
+static uint64_t ig_off_out(uint32_t n) { return ig_off_x(n) + (uint64_t)n * 32 * 2; }
+static uint64_t ig_off_din(uint32_t n) { return ig_off_out(n) + (uint64_t)n * 4 * 2; }
+uint64_t ngp_hip_nerf_input_gradient_scratch_bytes(uint32_t n) { return ig_off_din(n) + (uint64_t)n * 6 * 4; }
+
+int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, uint32_t dim, float* coords_inout,
+                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_input_gradient: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (dim >= 4) { set_last_error("ngp_hip_nerf_input_gradient: dim must be 0..3 (the padded outputs 4..15 carry nothing)", hipErrorInvalidValue); return -1; }
+	if (coord_stride_floats < 7) { set_last_error("ngp_hip_nerf_input_gradient: coords are NgpCoord records (>= 7 floats)", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_input_gradient_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_input_gradient: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	const float backprop_scale = 128.0f;   // [tcnn] input_gradient's default: keeps the fp16 backward out of the denormals
+	half_t* dl = (half_t*)((char*)scratch + ig_off_dl(n));
+	uint16_t* x_saved = (uint16_t*)((char*)scratch + ig_off_x(n));
+	uint16_t* out = (uint16_t*)((char*)scratch + ig_off_out(n));
+	float* din = (float*)((char*)scratch + ig_off_din(n));
+	hipLaunchKernelGGL(one_hot_dl_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, dim, backprop_scale, dl);
+	NGP_LAUNCH_CHECK("one_hot_dl_kernel");
+	if (ngp_hip_nerf_forward(stream, desc_dev, params, coords_inout, coord_stride_floats, n, out, 4, x_saved)) return -1;
+	// the fused backward kernel with the direction gradient, then dL/dpos through the hash encoding; no parameter gradients (EGradientMode::Ignore):
+	// the per-workgroup weight-gradient partials land in scratch and are dropped, the hash-grid backward does not run
+	float* partials = (float*)scratch;
+	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
+	const uint32_t n_quads = n / 128;
+	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
+	(void)desc_host;
+	hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u,
+	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din);
+	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel (input gradient)");
+	hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din);
+	NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
+	hipLaunchKernelGGL(input_gradient_writeback_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, 1.0f / backprop_scale, (const float*)din, coords_inout, coord_stride_floats);
+	NGP_LAUNCH_CHECK("input_gradient_writeback_kernel");
+	return 0;
+}
+
+int ngp_hip_nerf_visualize_activation(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords,
+                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats) {
+	static const uint32_t widths[5] = {32, 64, 32, 64, 64};   // NerfNetwork::width(layer) (nerf_network.h:474-484)
+	if (layer >= 5 || dimension >= widths[layer]) { set_last_error("ngp_hip_nerf_visualize_activation: layer 0..4, dimension below the layer's width (32, 64, 32, 64, 64)", hipErrorInvalidValue); return -1; }
+	if (!n) return 0;
+	hipLaunchKernelGGL(nerf_visualize_activation_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, layer, dimension, coords, coord_stride_floats, n, out, out_stride_floats);
+	NGP_LAUNCH_CHECK("nerf_visualize_activation_kernel");
 	return 0;
 }
 

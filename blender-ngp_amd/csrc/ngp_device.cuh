@@ -632,4 +632,78 @@ __device__ __forceinline__ v3 latlong_to_dir(float u, float v) {
 	return mk(sp * ct, st, cp * ct);
 }
 
+// ---------------------------------------------------------------- trainable 2-D buffers: distortion map, environment map
+// inverse of the 3x3 block of a column-major 3x4 (Eigen's Matrix3f::inverse(): cofactors over the determinant)
+__device__ __forceinline__ void mat3_inverse(const float* m, float* inv /* 9, column-major */) {
+	const float a = m[0], b = m[3], c = m[6], d = m[1], e = m[4], f = m[7], g = m[2], h = m[5], k = m[8];
+	const float A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g;
+	const float invdet = 1.0f / (a * A + b * B + c * C);
+	inv[0] = A * invdet; inv[3] = -(b * k - c * h) * invdet; inv[6] = (b * f - c * e) * invdet;
+	inv[1] = B * invdet; inv[4] = (a * k - c * g) * invdet;  inv[7] = -(a * f - c * d) * invdet;
+	inv[2] = C * invdet; inv[5] = -(a * h - b * g) * invdet; inv[8] = (a * e - b * d) * invdet;
+}
+// deposit_image_gradient<2> (common_device.cuh:112-143): value * weight into the gradient image, weight into the weight image
+__device__ __forceinline__ void deposit_image_gradient2(float v0, float v1, float* __restrict__ gradient, float* __restrict__ gradient_weight, int rx, int ry, float px, float py) {
+	const float fx = px * (float)(rx - 1), fy = py * (float)(ry - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		int x = tx + (k & 1), y = ty + (k >> 1);
+		x = x < rx - 1 ? x : rx - 1; x = x > 0 ? x : 0;
+		y = y < ry - 1 ? y : ry - 1; y = y > 0 ? y : 0;
+		const float w = ((k & 1) ? wx : 1 - wx) * ((k >> 1) ? wy : 1 - wy);
+		const size_t o = ((size_t)x + (size_t)y * rx) * 2;
+		atomicAdd(&gradient[o], v0 * w); atomicAdd(&gradient_weight[o], w);
+		atomicAdd(&gradient[o + 1], v1 * w); atomicAdd(&gradient_weight[o + 1], w);
+	}
+}
+// envmap.cuh:29-63 / 65-103: lat-long lookup of a [h][w][4] fp32 map by direction (x wraps, y clamps); dir_to_spherical_unorm: random_val.cuh:64-69
+struct EnvmapTap { int idx[4]; float w[4]; };
+__device__ __forceinline__ EnvmapTap envmap_taps(int rx, int ry, v3 dir) {
+	const float PI = 3.14159265358979323846f;
+	const float dx = dir.z, dy = -dir.x, dz = dir.y;
+	const float cos_theta = fminf(fmaxf(dz, -1.0f), 1.0f);
+	const float theta = acosf(cos_theta);
+	const float phi = atan2f(dy, dx);
+	const float cx = theta / PI, cy = phi / (2.0f * PI) + 0.5f;
+	const float fx = cy * (float)(rx - 1), fy = cx * (float)(ry - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	EnvmapTap t;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		int x = tx + (k & 1), y = ty + (k >> 1);
+		if (x < 0) x += rx; else if (x >= rx) x -= rx;
+		y = y < ry - 1 ? y : ry - 1; y = y > 0 ? y : 0;
+		t.idx[k] = (x + y * rx) * 4;
+		t.w[k] = ((k & 1) ? wx : 1 - wx) * ((k >> 1) ? wy : 1 - wy);
+	}
+	return t;
+}
+__device__ __forceinline__ void read_envmap(const float* __restrict__ data, int rx, int ry, v3 dir, float out[4]) {
+	const EnvmapTap t = envmap_taps(rx, ry, dir);
+#pragma unroll
+	for (int c = 0; c < 4; ++c) out[c] = ((t.w[0] * data[t.idx[0] + c] + t.w[1] * data[t.idx[1] + c]) + t.w[2] * data[t.idx[2] + c]) + t.w[3] * data[t.idx[3] + c];
+}
+// hsv_to_rgb / to_rgb (common_device.cuh:594-619): the Distortion render mode's colouring of a 2-D offset
+__device__ __forceinline__ v3 hsv_to_rgb(float h, float s, float v) {
+	if (s == 0.0f) return mk(v, v, v);
+	h = fmodf(h, 1.0f) * 6.0f;
+	const int i = (int)h;
+	const float f = h - (float)i;
+	const float p = v * (1.0f - s), q = v * (1.0f - s * f), t = v * (1.0f - s * (1.0f - f));
+	switch (i) {
+		case 0: return mk(v, t, p);
+		case 1: return mk(q, v, p);
+		case 2: return mk(p, v, t);
+		case 3: return mk(p, q, v);
+		case 4: return mk(t, p, v);
+		default: return mk(v, p, q);
+	}
+}
+__device__ __forceinline__ v3 offset_to_rgb(float dx, float dy) {
+	return hsv_to_rgb(atan2f(dy, dx) / (2.0f * 3.14159265358979323846f) + 0.5f, 1.0f, sqrtf(dx * dx + dy * dy));
+}
+
 } // namespace ngp

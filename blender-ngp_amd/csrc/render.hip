@@ -4,36 +4,62 @@
 // 1809-1978 (init_rays_with_payload_kernel_nerf; Perspective / OpenCV / FTheta / LatLong lenses, rolling shutter, depth of field, slice plane) and src/render_buffer.cu:235-272, 274-348, 540-567.
 // Compaction uses wave64 ballots: one atomic per wave per counter instead of one per ray.
 #include "ngp_device.cuh"
+#include "ngp_masks.cuh"
 
 namespace ngp {
+
+// What the reference's kernels take beyond the round-1 argument lists (NgpRenderExtras): crop masks, glow, envmap background, distortion map, quilting.
+struct RenderExtras {
+	const NgpMask3D* render_masks; uint32_t n_render_masks; int glow_mode; float glow_y_cutoff;
+	const float* envmap; int envmap_res[2]; const float* distortion; int distortion_res[2]; int quilting_dims[2]; int render_mode; float4* frame_buffer;
+};
 
 struct InitRaysArgs {
 	uint32_t sample_index; NgpPayload* payloads; int32_t res[2]; float focal_length[2]; Mat34 cam0, cam1; float rolling_shutter[4];
 	float screen_center[2]; float parallax_shift[3]; int snap_to_pixel_centers; Aabb render_aabb; Mat33 to_local; float near_distance;
 	int lens_mode; float lens_params[7]; float* depthbuffer; float plane_z, aperture_size;
 	int camera_model; float sq_width, sq_height, sq_curvature; float qh_front[12], qh_back[12];   // camera_models.cuh (0 = Perspective)
+	RenderExtras ex;
 };
 
 __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
-	const uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
+	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
 	if (x >= (uint32_t)a.res[0] || y >= (uint32_t)a.res[1]) return;
 	const uint32_t idx = x + (uint32_t)a.res[0] * y;
+	float parallax_shift[3] = {a.parallax_shift[0], a.parallax_shift[1], a.parallax_shift[2]};
+	const int qx = a.ex.quilting_dims[0], qy = a.ex.quilting_dims[1];
+	if (qx != 1 || qy != 1) {   // apply_quilting (common_device.cuh:541-560): the pixel inside its panel, the panel's parallax
+		const float resx = (float)a.res[0] / (float)qx, resy = (float)a.res[1] / (float)qy;
+		const int panelx = (int)floorf((float)x / resx), panely = (int)floorf((float)y / resy);
+		x = (uint32_t)((float)x - (float)panelx * resx);
+		y = (uint32_t)((float)y - (float)panely * resy);
+		const int pidx = panelx + qx * panely;
+		if (qx == 2 && qy == 1) {
+			parallax_shift[0] = pidx ? (-0.5f * parallax_shift[0]) : (0.5f * parallax_shift[0]);
+		} else {
+			const float max_parallax_angle = 17.5f;
+			const float parallax_angle = max_parallax_angle * 3.14159265358979323846f / 180.f * (((float)pidx + 0.5f) * 2.f / (float)(qy * qx) - 1.f);
+			parallax_shift[0] = atanf(parallax_angle) / parallax_shift[2];
+		}
+	}
 	const float u = ((float)x + 0.5f) * (1.f / (float)a.res[0]), v = ((float)y + 0.5f) * (1.f / (float)a.res[1]);
 	const float ray_time = a.rolling_shutter[0] + a.rolling_shutter[1] * u + a.rolling_shutter[2] * v + a.rolling_shutter[3] * ld_random_val(a.sample_index, idx * 72239731u);
 	float cam[12];
 #pragma unroll
 	for (int k = 0; k < 12; ++k) cam[k] = a.cam0.m[k] * ray_time + a.cam1.m[k] * (1.f - ray_time);
+	const int rx = a.res[0] / qx, ry = a.res[1] / qy;   // resolution.cwiseQuotient(quilting_dims) (1863)
+	const float frx = (float)rx, fry = (float)ry;
 
-	// pixel_to_ray (common_device.cuh:260-317), no distortion grid
+	// pixel_to_ray (common_device.cuh:260-317)
 	const float aperture_size = a.plane_z < 0 ? 0.0f : a.aperture_size;   // 1849-1851
 	float ox, oy;
 	ld_random_pixel_offset(a.snap_to_pixel_centers ? 0 : a.sample_index, ox, oy);
-	const float pu = ((float)x + ox) / (float)a.res[0], pv = ((float)y + oy) / (float)a.res[1];
+	const float pu = ((float)x + ox) / frx, pv = ((float)y + oy) / fry;
 	v3 dir, origin;
 	bool outside = false;
 	if (a.camera_model != 0) {       // the fork's extra camera models (1868-1908); they ignore lens, parallax shift and screen centre
-		if (a.camera_model == 2) spherical_quadrilateral_pixel_to_ray(a.sample_index, x, y, (float)a.res[0], (float)a.res[1], cam, a.sq_width, a.sq_height, a.sq_curvature, a.near_distance, a.plane_z, aperture_size, origin, dir);
-		else quadrilateral_hexahedron_pixel_to_ray(a.sample_index, x, y, (float)a.res[0], (float)a.res[1], cam, a.qh_front, a.qh_back, a.near_distance, a.plane_z, aperture_size, origin, dir);
+		if (a.camera_model == 2) spherical_quadrilateral_pixel_to_ray(a.sample_index, x, y, frx, fry, cam, a.sq_width, a.sq_height, a.sq_curvature, a.near_distance, a.plane_z, aperture_size, origin, dir);
+		else quadrilateral_hexahedron_pixel_to_ray(a.sample_index, x, y, frx, fry, cam, a.qh_front, a.qh_back, a.near_distance, a.plane_z, aperture_size, origin, dir);
 	} else {
 	if (a.lens_mode == 2) {          // FTheta
 		dir = f_theta_undistortion(pu - a.screen_center[0], pv - a.screen_center[1], a.lens_params, mk(1000.f, 0.f, 0.f));
@@ -41,14 +67,19 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	} else if (a.lens_mode == 3) {   // LatLong
 		dir = latlong_to_dir(pu, pv);
 	} else {
-		dir = mk((pu - a.screen_center[0]) * (float)a.res[0] / a.focal_length[0], (pv - a.screen_center[1]) * (float)a.res[1] / a.focal_length[1], 1.0f);
+		dir = mk((pu - a.screen_center[0]) * frx / a.focal_length[0], (pv - a.screen_center[1]) * fry / a.focal_length[1], 1.0f);
 		if (a.lens_mode == 1) iterative_opencv_lens_undistortion(a.lens_params, dir.x, dir.y);
 	}
 	if (outside) {
 		origin = mk(1000.f, 0.f, 0.f); dir = mk(0.f, 0.f, 1.f);
 	} else {
-		const v3 head_pos = mk(a.parallax_shift[0], a.parallax_shift[1], 0.f);
-		dir = dir - head_pos * a.parallax_shift[2];
+		if (a.ex.distortion) {   // common_device.cuh:297-299
+			float d0, d1;
+			read_image2(a.ex.distortion, a.ex.distortion_res[0], a.ex.distortion_res[1], pu, pv, d0, d1);
+			dir.x += d0; dir.y += d1;
+		}
+		const v3 head_pos = mk(parallax_shift[0], parallax_shift[1], 0.f);
+		dir = dir - head_pos * parallax_shift[2];
 		dir = mat3_mul(cam, dir);
 		origin = mat3_mul(cam, head_pos) + col(cam, 3);
 		apply_aperture(a.sample_index, x, y, cam, aperture_size, a.plane_z, origin, dir);   // depth of field (307-312)
@@ -70,16 +101,41 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	}
 	a.depthbuffer[idx] = 1e10f;
 	dir = normalized(dir);
+	if (a.ex.envmap) {   // 1931-1933
+		float e[4];
+		read_envmap(a.ex.envmap, a.ex.envmap_res[0], a.ex.envmap_res[1], dir, e);
+		a.ex.frame_buffer[idx] = make_float4(e[0], e[1], e[2], e[3]);
+	}
 	float tmin, tmax;
 	aabb_ray_intersect(a.render_aabb, mat3_mul(a.to_local.m, origin), mat3_mul(a.to_local.m, dir), tmin, tmax);
 	const float t = fmaxf(tmin, 0.0f) + 1e-6f;
 	p.origin[0] = origin.x; p.origin[1] = origin.y; p.origin[2] = origin.z;
 	if (!aabb_contains(a.render_aabb, mat3_mul(a.to_local.m, origin + dir * t))) {
 		p.alive = 0;
-	} else {
-		p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
-		p.t = t; p.idx = idx; p.n_steps = 0; p.alive = 1;
+		a.payloads[idx] = p;
+		return;
 	}
+	bool ray_intersects_any_mask = a.ex.n_render_masks == 0;   // 1943-1956
+	for (uint32_t k = 0; k < a.ex.n_render_masks && !ray_intersects_any_mask; ++k) ray_intersects_any_mask = mask_intersects_ray(a.ex.render_masks[k], origin, dir);
+	if (!ray_intersects_any_mask) {
+		p.alive = 0;
+		a.payloads[idx] = p;
+		return;
+	}
+	if (a.ex.render_mode == 5) {   // Distortion (1959-1970): paint the map's offset at the pixel centre, the ray is done
+		float d0 = 0.0f, d1 = 0.0f;
+		if (a.ex.distortion) read_image2(a.ex.distortion, a.ex.distortion_res[0], a.ex.distortion_res[1], ((float)x + 0.5f) / (float)a.res[0], ((float)y + 0.5f) / (float)a.res[1], d0, d1);
+		const v3 c = offset_to_rgb(d0 * 50.0f, d1 * 50.0f);
+		a.ex.frame_buffer[idx] = make_float4(c.x, c.y, c.z, 1.0f);
+		a.depthbuffer[idx] = 1.0f;
+		const v3 far = origin + dir * 10000.0f;
+		p.origin[0] = far.x; p.origin[1] = far.y; p.origin[2] = far.z;
+		p.alive = 0;
+		a.payloads[idx] = p;
+		return;
+	}
+	p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
+	p.t = t; p.idx = idx; p.n_steps = 0; p.alive = 1;
 	a.payloads[idx] = p;
 }
 
@@ -184,9 +240,58 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
 
+// Glow / grid-line visualisation of composite_kernel_nerf (src/testbed_nerf.cu:843-939; the "#if 0" variant there is dead code)
+__device__ __forceinline__ float glow_lines(v3 pos) {
+	float line = 0.0f;
+#pragma unroll
+	for (int o = 0; o < 4; ++o) {
+		const float f = (float)(2 << o);   // 2, 4, 8, 16
+		line += fmaxf(0.f, cosf(pos.y * f * 3.141592653589793f * 16.f) - 0.975f);
+		line += fmaxf(0.f, cosf(pos.x * f * 3.141592653589793f * 16.f) - 0.975f);
+		line += fmaxf(0.f, cosf(pos.z * f * 3.141592653589793f * 16.f) - 0.975f);
+	}
+	return line;
+}
+__device__ __forceinline__ void glow_shading(int glow_mode, float glow_y_cutoff, v3 pos, v3 cam_pos, float& r, float& g, float& b, float& weight) {
+	float glow = 0.f;
+	const bool green_grid = glow_mode & 1, green_cutline = glow_mode & 2, mask_to_alpha = glow_mode & 4, radial_mode = glow_mode & 8, grid_mode = glow_mode & 16;
+	float dist;
+	if (radial_mode) {
+		dist = norm(pos - cam_pos);
+		dist = fminf(dist, (4.5f - pos.y) * 0.333f);
+	} else {
+		dist = pos.y;
+	}
+	if (grid_mode) {
+		glow = 1.f / fmaxf(1.f, dist);
+	} else {
+		float y = glow_y_cutoff - dist;
+		float mask = 0.f;
+		if (y > 0.f) {
+			y *= 80.f;
+			mask = fminf(1.f, y);
+			if (green_cutline) glow += fmaxf(0.f, 1.f - fabsf(1.f - y)) * 4.f;
+			if (y > 1.f) y = 1.f - (y - 1.f) * 0.05f;
+			if (green_grid) glow += fmaxf(0.f, y / fmaxf(1.f, dist));
+		}
+		if (mask_to_alpha) weight *= mask;
+	}
+	if (glow > 0.f) {
+		const float line = glow_lines(pos);
+		if (grid_mode) {
+			glow = glow * line * 15.f;
+			g = glow; b = glow * 0.5f; r = glow * 0.25f;
+		} else {
+			glow = glow * glow * 0.25f + glow * line * 15.f;
+			g += glow; b += glow * 0.5f; r += glow * 0.25f;
+		}
+	}
+}
+
 __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aabb aabb, Mat34 camera_matrix, float4* __restrict__ rgba, float* __restrict__ depth,
                                  NgpPayload* __restrict__ payloads, const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride,
-                                 uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
+                                 uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel,
+                                 const RenderExtras ex) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	NgpPayload& payload = payloads[i];
@@ -205,11 +310,24 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 		const v3 pos = unwarp_position(mk(in.pos[0], in.pos[1], in.pos[2]), aabb);
 		const float T = 1.f - local_rgba.w;
 		const float dt = unwarp_dt(in.dt);
-		const float alpha = 1.f - __expf(-network_to_density(h2f(lo[3]), density_activation) * dt);
-		const float weight = alpha * T;
+		float alpha = 1.f - __expf(-network_to_density(h2f(lo[3]), density_activation) * dt);
+		if (show_accel >= 0) alpha = 1.f;   // 827-829
+		float weight = alpha * T;
 		float cr = network_to_rgb(h2f(lo[0]), rgb_activation), cg = network_to_rgb(h2f(lo[1]), rgb_activation), cb = network_to_rgb(h2f(lo[2]), rgb_activation);
-		if (render_mode != 1) {   // visualisation modes that only need the sample itself (938-968); Cost / Slice composite like Shade
-			if (render_mode == 3) {           // Positions
+		if (ex.n_render_masks) {   // crop masks (833-840)
+			float mask_weight = 1.f;
+			for (uint32_t k = 0; k < ex.n_render_masks; ++k) mask_weight = clampf(mask_weight + mask_sample(ex.render_masks[k], pos), 0.0f, 1.0f);
+			weight *= mask_weight;
+		}
+		if (ex.glow_mode) glow_shading(ex.glow_mode, ex.glow_y_cutoff, pos, cam_pos, cr, cg, cb, weight);   // 843-939
+		if (render_mode != 1) {   // visualisation modes (941-968); Cost / Slice composite like Shade
+			if (render_mode == 2) {           // Normals: in.pos holds d(density output)/d(pos) (ngp_hip_nerf_input_gradient)
+				const float k = -network_to_density_derivative(h2f(lo[3]), density_activation);
+				const v3 nrm = normalized(mk(k * in.pos[0], k * in.pos[1], k * in.pos[2]));
+				cr = nrm.x; cg = nrm.y; cb = nrm.z;
+			} else if (render_mode == 8) {    // EncodingVis: in.pos holds the visualised activation (ngp_hip_nerf_visualize_activation)
+				cr = in.pos[0]; cg = in.pos[1]; cb = in.pos[2];
+			} else if (render_mode == 3) {    // Positions
 				if (show_accel >= 0) {
 					const int mp = mip_from_pos(pos);
 					const uint32_t mip = (uint32_t)(show_accel > mp ? show_accel : mp);
@@ -250,13 +368,38 @@ __global__ void shade_kernel(uint32_t n_elements, const float4* __restrict__ rgb
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	float4 tmp = rgba[i];
-	if (render_mode == 6) { const float c = (float)payloads[i].n_steps / 128; tmp = make_float4(c, c, c, 1.0f); }   // Cost
+	if (render_mode == 2) {   // Normals (1764-1767): accumulated normal -> unit length -> [0, 1], premultiplied
+		const v3 n = normalized(mk(tmp.x, tmp.y, tmp.z));
+		tmp.x = (0.5f * n.x + 0.5f) * tmp.w; tmp.y = (0.5f * n.y + 0.5f) * tmp.w; tmp.z = (0.5f * n.z + 0.5f) * tmp.w;
+	} else if (render_mode == 6) { const float c = (float)payloads[i].n_steps / 128; tmp = make_float4(c, c, c, 1.0f); }   // Cost
 	if (!train_in_linear_colors && (render_mode == 1 || render_mode == 7)) { tmp.x = srgb_to_linear(tmp.x); tmp.y = srgb_to_linear(tmp.y); tmp.z = srgb_to_linear(tmp.z); }
 	const uint32_t idx = payloads[i].idx;
 	const float4 fb = frame_buffer[idx];
 	const float k = 1.0f - tmp.w;
 	frame_buffer[idx] = make_float4(tmp.x + fb.x * k, tmp.y + fb.y * k, tmp.z + fb.z * k, tmp.w + fb.w * k);
 	if (render_mode != 7 && tmp.w > 0.2f) depth_buffer[idx] = depth[i];
+}
+
+// Slice mode (2445-2476): the network evaluated where every ray meets the slice plane
+__global__ void generate_inputs_at_current_position_kernel(uint32_t n_elements, Aabb aabb, const NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const v3 dir = ld3(payloads[i].dir), origin = ld3(payloads[i].origin);
+	const v3 wp = aabb_relative_pos(aabb, origin + dir * payloads[i].t), wd = warp_direction(dir);
+	NgpCoord c;
+	c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(MIN_CONE_STEPSIZE()); c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+	network_input[i] = c;
+}
+__global__ void compute_nerf_rgba_kernel(uint32_t n_elements, const uint16_t* __restrict__ network_output, uint32_t out_stride, float4* __restrict__ rgba, int rgb_activation,
+                                         int density_activation, float depth, bool density_as_alpha) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (i >= n_elements) return;
+	const us4 lo = *(const us4*)(network_output + (size_t)i * out_stride);
+	const float density = network_to_density(h2f(lo[3]), density_activation);
+	float alpha = 1.f, w;
+	if (density_as_alpha) w = density;
+	else w = alpha = clampf(1.f - __expf(-density * depth), 0.0f, 1.0f);
+	rgba[i] = make_float4(network_to_rgb(h2f(lo[0]), rgb_activation) * alpha, network_to_rgb(h2f(lo[1]), rgb_activation) * alpha, network_to_rgb(h2f(lo[2]), rgb_activation) * alpha, w);
 }
 
 __global__ void accumulate_kernel(uint32_t n, const float4* __restrict__ frame_buffer, float4* __restrict__ accumulate_buffer, float sample_count, int color_space) {
@@ -331,7 +474,31 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
                       const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
                       float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host) {
+	return ngp_hip_init_rays_ex(stream, sample_index, payloads, res_host, focal_length_host, camera_matrix0_host, camera_matrix1_host, rolling_shutter_host, screen_center_host, parallax_shift_host,
+	                            snap_to_pixel_centers, render_aabb_host, render_aabb_to_local_host, near_distance, lens_mode, lens_params_host, depthbuffer, plane_z, aperture_size, camera_models_host, nullptr);
+}
+
+static int extras_from_host(const NgpRenderExtras* e, RenderExtras& x, const char* who) {
+	x.render_masks = nullptr; x.n_render_masks = 0; x.glow_mode = 0; x.glow_y_cutoff = 0.f; x.envmap = nullptr; x.envmap_res[0] = x.envmap_res[1] = 0;
+	x.distortion = nullptr; x.distortion_res[0] = x.distortion_res[1] = 0; x.quilting_dims[0] = x.quilting_dims[1] = 1; x.render_mode = 1; x.frame_buffer = nullptr;
+	if (!e) return 0;
+	x.render_masks = e->n_render_masks ? e->render_masks : nullptr; x.n_render_masks = e->render_masks ? e->n_render_masks : 0;
+	x.glow_mode = e->glow_mode; x.glow_y_cutoff = e->glow_y_cutoff;
+	if (e->envmap && e->envmap_res[0] > 0 && e->envmap_res[1] > 0) { x.envmap = e->envmap; x.envmap_res[0] = e->envmap_res[0]; x.envmap_res[1] = e->envmap_res[1]; }
+	if (e->distortion && e->distortion_res[0] > 0 && e->distortion_res[1] > 0) { x.distortion = e->distortion; x.distortion_res[0] = e->distortion_res[0]; x.distortion_res[1] = e->distortion_res[1]; }
+	if (e->quilting_dims[0] > 0 && e->quilting_dims[1] > 0) { x.quilting_dims[0] = e->quilting_dims[0]; x.quilting_dims[1] = e->quilting_dims[1]; }
+	x.render_mode = e->render_mode; x.frame_buffer = (float4*)e->frame_buffer;
+	if ((x.envmap || x.render_mode == 5) && !x.frame_buffer) { set_last_error(who, hipErrorInvalidValue); return -1; }
+	return 0;
+}
+
+int ngp_hip_init_rays_ex(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
+                         const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
+                         const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
+                         const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
+                         float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host, const NgpRenderExtras* extras_host) {
 	InitRaysArgs a;
+	if (extras_from_host(extras_host, a.ex, "ngp_hip_init_rays_ex: an envmap or the Distortion mode needs extras->frame_buffer")) return -1;
 	a.plane_z = plane_z; a.aperture_size = aperture_size;
 	a.camera_model = camera_models_host ? camera_models_host->model : 0;
 	a.sq_width = a.sq_height = a.sq_curvature = 0.f;
@@ -394,12 +561,21 @@ int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, 
 int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
                            NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
                            int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
-	if (render_mode != 0 && render_mode != 1 && render_mode != 3 && render_mode != 4 && render_mode != 6 && render_mode != 7) {
-		set_last_error("ngp_hip_composite_mode: render mode not built (Normals / Distortion / EncodingVis need input gradients or the distortion map)", hipErrorInvalidValue); return -1;
-	}
+	if (render_mode == 2 || render_mode == 8) { set_last_error("ngp_hip_composite_mode: Normals / EncodingVis go through ngp_hip_composite_ex", hipErrorInvalidValue); return -1; }
+	return ngp_hip_composite_ex(stream, n_elements, current_step, aabb_host, camera_matrix_host, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation,
+	                            density_activation, min_transmittance, render_mode, depth_scale, show_accel, nullptr);
+}
+
+int ngp_hip_composite_ex(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
+                         NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                         int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host) {
+	if (render_mode < 0 || render_mode > 8) { set_last_error("ngp_hip_composite_ex: render mode out of range (ERenderMode 0..7, EncodingVis 8)", hipErrorInvalidValue); return -1; }
+	RenderExtras ex;
+	extras_from_host(nullptr, ex, "");
+	if (extras_host) { RenderExtras t; extras_from_host(extras_host, t, ""); ex.render_masks = t.render_masks; ex.n_render_masks = t.n_render_masks; ex.glow_mode = t.glow_mode; ex.glow_y_cutoff = t.glow_y_cutoff; }
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
-	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel);
+	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel, ex);
 	NGP_LAUNCH_CHECK("composite_kernel");
 	return 0;
 }
@@ -412,6 +588,21 @@ int ngp_hip_shade_mode(void* stream, uint32_t n_elements, const float* rgba, con
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(shade_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, (const float4*)rgba, depth, payloads, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer, render_mode);
 	NGP_LAUNCH_CHECK("shade_kernel");
+	return 0;
+}
+
+int ngp_hip_generate_inputs_at_current_position(void* stream, uint32_t n_elements, const NgpAabb* aabb_host, const NgpPayload* payloads, NgpCoord* network_input) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(generate_inputs_at_current_position_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(aabb_host), payloads, network_input);
+	NGP_LAUNCH_CHECK("generate_inputs_at_current_position_kernel");
+	return 0;
+}
+int ngp_hip_compute_nerf_rgba(void* stream, uint32_t n_elements, const uint16_t* network_output, uint32_t out_stride, float* rgba, int rgb_activation, int density_activation,
+                              float depth, int density_as_alpha) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(compute_nerf_rgba_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, network_output, out_stride, (float4*)rgba, rgb_activation, density_activation,
+	                   depth, density_as_alpha != 0);
+	NGP_LAUNCH_CHECK("compute_nerf_rgba_kernel");
 	return 0;
 }
 

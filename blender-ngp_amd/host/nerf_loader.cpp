@@ -32,6 +32,8 @@ static std::string path_with_extension(const std::string& p, const std::string& 
 	const std::string dir = path_parent(p), base = path_basename(p);
 	return (p.find('/') == std::string::npos ? std::string() : dir + "/") + base + "." + ext;
 }
+static std::string lower_extension(const std::string& p) { std::string e = path_extension(p); for (char& c : e) c = (char)std::tolower((unsigned char)c); return e; }
+static float srgb_to_linear_host(float srgb) { return srgb <= 0.04045f ? srgb / 12.92f : std::pow((srgb + 0.055f) / 1.055f, 2.4f); }   // common_device.cuh:31-37
 static std::string path_join(const std::string& a, const std::string& b) { if (!b.empty() && b[0] == '/') return b; return a + "/" + b; }
 
 static const float PI_F = 3.14159265358979323846f;
@@ -206,7 +208,27 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 			result.offset = Vec3{((A(1, 0) + A(0, 0)) * 0.5f) * -result.scale + 0.5f, ((A(1, 1) + A(0, 1)) * 0.5f) * -result.scale + 0.5f, ((A(1, 2) + A(0, 2)) * 0.5f) * -result.scale + 0.5f};
 		}
 		if (json.contains("up")) { result.up = Vec3{(float)json["up"][(size_t)1].number(), (float)json["up"][(size_t)2].number(), (float)json["up"][(size_t)0].number()}; }  // axes permuted like the xforms
-		if (json.contains("envmap")) throw std::runtime_error{"the `envmap` key (a trainable environment map, nerf_loader.cu:527-541) is outside the NeRF hot path of this build (SURVEY.md §8 f4)"};
+		if (json.contains("envmap") && result.envmap_resolution[0] == 0 && result.envmap_resolution[1] == 0) {   // nerf_loader.cu:533-546: the first json that names one wins
+			const std::string envmap_path = path_join(basepath, json["envmap"].str());
+			if (!path_exists(envmap_path)) throw std::runtime_error{"Environment map " + envmap_path + " does not exist."};
+			int w = 0, h = 0;
+			if (lower_extension(envmap_path) == "exr") {            // load_exr (common_device.cu:39-47): the file's floats as they are
+				read_exr_rgba_f32(envmap_path, w, h, result.envmap_data);
+				result.is_hdr = true;
+			} else {                                                // load_stbi (common_device.cu:49-80): 8-bit -> from_rgba32<float> (sRGB decode, premultiplied)
+				if (lower_extension(envmap_path) == "hdr") throw std::runtime_error{"Radiance .hdr environment maps (stbi_loadf) are not decoded by this build; use .exr"};
+				std::vector<uint8_t> px;
+				read_image_rgba8(envmap_path, w, h, px);
+				if (w == 0 || h == 0) throw std::runtime_error{"Image has zero pixels."};
+				result.envmap_data.resize((size_t)w * h * 4);
+				for (size_t i = 0; i < (size_t)w * h; ++i) {
+					const float alpha = px[i * 4 + 3] * (1.0f / 255.0f);
+					for (int c = 0; c < 3; ++c) result.envmap_data[i * 4 + c] = srgb_to_linear_host(px[i * 4 + c] * (1.0f / 255.0f)) * alpha;
+					result.envmap_data[i * 4 + 3] = alpha;
+				}
+			}
+			result.envmap_resolution[0] = w; result.envmap_resolution[1] = h;
+		}
 
 		const float scale = result.scale;
 		const Vec3 offset = result.offset;

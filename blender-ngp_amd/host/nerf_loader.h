@@ -28,6 +28,8 @@ struct LoadedNerfData {
 	bool from_mitsuba = false, is_hdr = false, wants_importance_sampling = true;
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
+	std::vector<float> envmap_data;                 // `envmap` key (nerf_loader.cu:533-546): linear premultiplied RGBA fp32, [h][w][4]
+	int envmap_resolution[2] = {0, 0};
 };
 
 // a .json file, or a directory (every *.json in it), like Testbed::load_nerf

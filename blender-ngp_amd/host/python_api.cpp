@@ -214,6 +214,9 @@ PYBIND11_MODULE(pyngp, m) {
 		}
 		out["xforms"] = xf; out["metadata"] = meta; out["pixels"] = px; out["depth16"] = depth; out["rays"] = rays;
 		out["depth_scale"] = d.depth_scale; out["has_rays"] = d.has_rays; out["is_hdr"] = d.is_hdr;
+		out["envmap_resolution"] = std::vector<int>{d.envmap_resolution[0], d.envmap_resolution[1]};
+		if (d.envmap_data.empty()) out["envmap"] = py::none();
+		else { py::array_t<float> e({(size_t)d.envmap_resolution[1], (size_t)d.envmap_resolution[0], (size_t)4}); memcpy(e.mutable_data(), d.envmap_data.data(), d.envmap_data.size() * 4); out["envmap"] = e; }
 		return out;
 	});
 	// data-parallel plumbing that needs no GPU (tests): the shared-memory counter exchange of the ranks of one node, and the RCCL binding probe
@@ -340,7 +343,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("up", [](PyNerfDataset& d) { return vec3_to_py(d.d->up); })
 		.def_property_readonly("offset", [](PyNerfDataset& d) { return vec3_to_py(d.d->offset); })
 		.def_property_readonly("n_images", [](PyNerfDataset& d) { return d.d->n_images; })
-		.def_property_readonly("envmap_resolution", [](PyNerfDataset&) { return std::vector<int>{0, 0}; })   // environment maps are not loaded by this build
+		.def_property_readonly("envmap_resolution", [](PyNerfDataset& d) { return std::vector<int>{d.d->envmap_resolution[0], d.d->envmap_resolution[1]}; })   // python_api.cu:797
 		.def_property_readonly("scale", [](PyNerfDataset& d) { return d.d->scale; })
 		.def_property_readonly("aabb_scale", [](PyNerfDataset& d) { return d.d->aabb_scale; })
 		.def_property_readonly("from_mitsuba", [](PyNerfDataset& d) { return d.d->from_mitsuba; })
@@ -693,10 +696,11 @@ PYBIND11_MODULE(pyngp, m) {
 			[](Testbed& t, const BoundingBox& b) { t.m_render_aabb = b.pod(); })
 		.def_property_readonly("raw_aabb", [](Testbed& t) { return BoundingBox(Vec3{t.m_raw_aabb.min[0], t.m_raw_aabb.min[1], t.m_raw_aabb.min[2]}, Vec3{t.m_raw_aabb.max[0], t.m_raw_aabb.max[1], t.m_raw_aabb.max[2]}); })
 		.def_property("up_dir", [](Testbed& t) { return vec3_to_py(t.m_up_dir); }, [](Testbed& t, const py::object& v) { t.m_up_dir = vec3_from_py(v); })
-		.def_property("render_mode", [](Testbed& t) { return t.m_render_mode; }, [](Testbed& t, ERenderMode m) {   // python_api.cu:660
-				if (m != ERenderMode::AO && m != ERenderMode::Shade && m != ERenderMode::Positions && m != ERenderMode::Depth && m != ERenderMode::Cost)
-					throw std::runtime_error{"RenderMode: AO, Shade, Positions, Depth and Cost are built (Normals / Distortion / Slice / EncodingVis need input gradients, the distortion map or the slice evaluator)"};
-				t.m_render_mode = m; })
+		.def_readwrite("render_mode", &Testbed::m_render_mode)   // python_api.cu:660: every ERenderMode of the stock tracer is built
+		.def_property("render_masks", [](Testbed& t) { std::vector<Mask3D> v; for (const NgpMask3D& p : t.m_render_masks) { Mask3D m; m.pod = p; v.push_back(m); } return v; },   // python_api.cu:694
+			[](Testbed& t, const std::vector<Mask3D>& v) { t.m_render_masks.clear(); for (const Mask3D& m : v) t.m_render_masks.push_back(m.pod); })
+		.def_property("quilting_dims", [](Testbed& t) { return std::vector<int>{t.m_quilting_dims[0], t.m_quilting_dims[1]}; },   // testbed.h:549 (GUI-only in the reference)
+			[](Testbed& t, const std::vector<int>& v) { if (v.size() != 2 || v[0] < 1 || v[1] < 1) throw std::runtime_error{"quilting_dims: two positive integers"}; t.m_quilting_dims[0] = v[0]; t.m_quilting_dims[1] = v[1]; })
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view, py::arg("trainview"))
 		.def("clear_training_data", [](Testbed& t) { t.m_training_data_available = false; t.m_nerf.training.n_images_for_training = 0; })
 		.def_readonly("nerf", &Testbed::m_nerf)
@@ -759,6 +763,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("optimize_extrinsics", &NerfTraining::optimize_extrinsics)               // python_api.cu:811
 		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)               // python_api.cu:812, 814: switches of trainables this build lacks; train() refuses while one is set
 		.def_readwrite("optimize_distortion", &NerfTraining::optimize_distortion)
+		.def_readwrite("train_envmap", &NerfTraining::train_envmap)   // testbed.h:656 (the reference flips it from its GUI)
 		.def_readwrite("optimize_focal_length", &NerfTraining::optimize_focal_length)           // python_api.cu:815: accepted; trains nothing, like the reference (testbed.h note)
 		.def("reset_camera_extrinsics", [](NerfTraining& t) { t.reset_camera_extrinsics(); })   // testbed_nerf.cu:2543-2555 (not bound by the reference's pyngp; GUI button there)
 		.def("_cam_offsets", [](NerfTraining& t) {   // test hook: (positions [n][3], angle-axis rotations [n][3], optimizer steps [n]) of optimize_extrinsics

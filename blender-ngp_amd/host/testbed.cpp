@@ -453,6 +453,7 @@ void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:
 	d.pixelmemory.clear(); d.pixelmemory.resize(d.n_images);
 	d.scale = data.scale; d.offset = data.offset; d.aabb_scale = data.aabb_scale; d.from_mitsuba = data.from_mitsuba; d.is_hdr = data.is_hdr;
 	d.render_aabb = data.render_aabb; d.up = data.up;
+	d.envmap_data = data.envmap_data; d.envmap_resolution[0] = data.envmap_resolution[0]; d.envmap_resolution[1] = data.envmap_resolution[1];
 	d.has_rays = data.has_rays;
 	d.raymemory.clear(); d.raymemory.resize(d.n_images);
 	for (size_t i = 0; i < d.n_images; ++i) {
@@ -583,6 +584,47 @@ void Testbed::parse_optimizer_config(const Json& opt_in) {
 	m_learning_rate = m_base_learning_rate;
 }
 
+// ---- TrainableBuffer: trainable_buffer.cuh + Trainer<float, float, float> + create_optimizer<float>(json) ----
+void TrainableBuffer::reset(int w, int h, uint32_t dims, const Json& optimizer_config, void* stream) {
+	resolution[0] = w; resolution[1] = h; n_dims = dims; step = 0;
+	use_ema = false; has_decay = false; ema_decay = 0.99f; decay_start = 0; decay_interval = 1; decay_end = 0; decay_base = 1.0f;
+	base_learning_rate = 1e-3f; beta1 = 0.9f; beta2 = 0.999f; epsilon = 1e-8f;
+	const Json* o = optimizer_config.is_object() ? &optimizer_config : nullptr;
+	while (o) {   // [Ema o] [ExponentialDecay o] Adam, as Testbed::parse_optimizer_config reads the network's
+		std::string lower = o->value("otype", "Adam"); std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+		if (lower == "ema") { use_ema = true; ema_decay = (float)o->value("decay", 0.99); }
+		else if (lower == "exponentialdecay") {
+			has_decay = true; decay_start = (uint32_t)o->value("decay_start", 0); decay_interval = (uint32_t)o->value("decay_interval", 1);
+			decay_end = (uint32_t)o->value("decay_end", 0); decay_base = (float)o->value("decay_base", 1.0);
+		} else if (lower == "adam") {
+			base_learning_rate = (float)o->value("learning_rate", 1e-3); beta1 = (float)o->value("beta1", 0.9); beta2 = (float)o->value("beta2", 0.999); epsilon = (float)o->value("epsilon", 1e-8);
+			break;
+		} else throw std::runtime_error{"optimizer otype '" + lower + "' of a trainable buffer: Ema / ExponentialDecay / Adam are built"};
+		o = o->contains("nested") ? &o->at("nested") : nullptr;
+	}
+	learning_rate = base_learning_rate;
+	const size_t bytes = n_params() * sizeof(float);
+	DeviceBuffer* all[6] = {&params, &ema, &gradients, &gradient_weights, &first_moments, &second_moments};
+	for (DeviceBuffer* b : all) { b->resize(bytes); if (bytes) b->memset(0, stream); }
+}
+void TrainableBuffer::set_params(const float* host, size_t n) {
+	if (n != n_params()) throw std::runtime_error{"TrainableBuffer::set_params: size mismatch"};
+	params.copy_from_host(host, n * sizeof(float));
+}
+void TrainableBuffer::clear_gradients(void* stream, bool weights_too) {
+	if (!n_params()) return;
+	gradients.memset(0, stream);
+	if (weights_too) gradient_weights.memset(0, stream);
+}
+void TrainableBuffer::optimizer_step(void* stream, float loss_scale) {
+	if (!n_params()) return;
+	++step;
+	const int rc = ngp_hip_optimizer_step_f32(stream, (uint32_t)n_params(), step, learning_rate, beta1, beta2, epsilon, loss_scale, use_ema ? ema_decay : 0.0f, gradients.as<float>(),
+	                                           params.as<float>(), first_moments.as<float>(), second_moments.as<float>(), use_ema ? ema.as<float>() : nullptr);
+	if (rc != 0) throw std::runtime_error{std::string("ngp_hip_optimizer_step_f32: ") + ngp_hip_last_error()};
+	if (has_decay && step >= decay_start && (decay_end == 0 || step < decay_end) && decay_interval && step % decay_interval == 0) learning_rate *= decay_base;   // as Testbed::optimizer_step
+}
+
 void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	if (m_testbed_mode != ETestbedMode::Nerf) { reset_network_gridmlp(); return; }
 	drop_prefetch();
@@ -640,8 +682,27 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream);
 	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>()), "ngp_hip_nerf_init_params");
 
-	m_distortion_map.resize(32 * 32 * 2 * 4);
-	m_distortion_map.memset(0, m_stream);
+	{   // distortion map model (testbed.cu:2386-2396) and envmap model (2447-2462): their own optimizers, else the network's
+		int dres[2] = {32, 32};
+		const Json* dopt = config.contains("optimizer") ? &config["optimizer"] : nullptr;
+		if (config.contains("distortion_map")) {
+			const Json& dm = config["distortion_map"];
+			if (dm.contains("optimizer")) dopt = &dm["optimizer"];
+			if (dm.contains("resolution")) { dres[0] = (int)dm["resolution"][(size_t)0].number(); dres[1] = (int)dm["resolution"][(size_t)1].number(); }
+		}
+		m_distortion.reset(dres[0], dres[1], 2, dopt ? *dopt : Json{}, m_stream);
+		const Json* eopt = config.contains("optimizer") ? &config["optimizer"] : nullptr;
+		std::string eloss = config.contains("loss") ? config["loss"].value("otype", "L2") : std::string("L2");
+		if (config.contains("envmap")) {
+			const Json& em = config["envmap"];
+			if (em.contains("optimizer")) eopt = &em["optimizer"];
+			if (em.contains("loss")) eloss = em["loss"].value("otype", "L2");
+		}
+		const NerfDataset& ds = m_nerf.training.dataset;
+		m_envmap.reset(ds.envmap_resolution[0], ds.envmap_resolution[1], 4, eopt ? *eopt : Json{}, m_stream);
+		m_envmap.loss_type = string_to_loss_type(eloss);
+		if (!ds.envmap_data.empty()) m_envmap.set_params(ds.envmap_data.data(), ds.envmap_data.size());
+	}
 	m_loss_scalar_gpu.resize(4);
 
 	m_training_step = 0;
@@ -790,9 +851,9 @@ void Testbed::shutdown_data_parallel() {
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
-	if (m_nerf.training.optimize_distortion || m_nerf.training.optimize_extra_dims)
-		throw std::runtime_error{"nerf.training.optimize_distortion / optimize_extra_dims: these camera-side trainables (testbed_nerf.cu:1671-1683, 1714-1746, 3034-3054, 3095-3101) "
-		                         "are not part of this build (optimize_extrinsics and optimize_exposure are; optimize_focal_length trains nothing in the reference either)"};
+	if (m_nerf.training.optimize_extra_dims)
+		throw std::runtime_error{"nerf.training.optimize_extra_dims: per-image latent codes (testbed_nerf.cu:1710-1746, 3029-3054) widen the network input and are not part of this build "
+		                         "(optimize_extrinsics, optimize_exposure, optimize_distortion and the environment map are; optimize_focal_length trains nothing in the reference either)"};
 	if (m_dp_comm) {
 		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
 		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
@@ -841,7 +902,7 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	uint32_t* counters = m_gen_counters.as<uint32_t>() + 4 * slot;  // [0] ray counter, [1] numsteps counter, [2] compacted numsteps counter (the step's)
 	if (m_next_slot_zeroed == slot) m_next_slot_zeroed = -1;   // cleared by the previous step's post_words launch
 	else HIP_CHECK_THROW(hipMemsetAsync(counters, 0, 8, (hipStream_t)stream));
-	const int32_t dist_res[2] = {32, 32};
+	const int32_t dist_res[2] = {m_distortion.resolution[0], m_distortion.resolution[1]};
 	const uint32_t n_rays_global = R * m_world_size, ray_offset = R * m_rank;
 	NgpErrorMapCdf cdf_storage;
 	profile_begin(PK_GEN_SAMPLES, stream);
@@ -850,8 +911,8 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	// nothing runs beside it: all workgroups at once.  With cone stepping the library runs its lane-per-ray kernels whatever the mode
 	check(ngp_hip_generate_training_samples_mode(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
-	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, 0,
-	                                        m_nerf.cone_angle_constant, m_distortion_map.as<float>(), dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
+	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, tr.train_envmap,
+	                                        m_nerf.cone_angle_constant, m_distortion.params.as<float>() /* map->params(), 3241 */, dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
 	                                        m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr,
 	                                        next_to_backward ? NGP_MARCH_WAVE_PER_RAY_SHARED : NGP_MARCH_WAVE_PER_RAY), "generate_training_samples");
 	profile_end(PK_GEN_SAMPLES, R, stream);
@@ -870,7 +931,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	const uint32_t next_step = m_training_step + 1;
 	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
 	if (next_step % n_prep_to_skip == 0) return;  // an occupancy-grid update (new bitfield) precedes that step
-	if (m_nerf.training.optimize_extrinsics && m_nerf.training.n_steps_since_cam_update + 1 >= m_nerf.training.n_steps_between_cam_updates) return;  // new camera transforms precede it (3060-3093)
+	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && m_nerf.training.n_steps_since_cam_update + 1 >= m_nerf.training.n_steps_between_cam_updates) return;  // new camera transforms / a new distortion map precede it (3060-3093)
 	NerfCounters& c = m_nerf.training.counters_rgb;
 	Pcg32 rng = m_rng;   // m_rng was already advanced for the next step (3380)
 	PrefetchedSamples p;
@@ -986,16 +1047,31 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		if (tr.n_steps_since_cam_update == 0 || !tr.cam_gradient_window_open) { tr.cam_pos_gradient_gpu.memset(0, m_stream); tr.cam_rot_gradient_gpu.memset(0, m_stream); }   // 2916-2918
 	}
 	tr.cam_gradient_window_open = tr.optimize_extrinsics;
+	if (tr.optimize_distortion) {
+		if (m_world_size > 1 && !m_dp_comm) throw std::runtime_error{"optimize_distortion at world_size > 1 needs init_data_parallel (the map's gradients are summed over the ranks)"};
+		if (tr.n_steps_since_cam_update == 0 || !tr.distortion_gradient_window_open) m_distortion.clear_gradients(m_stream, true);   // 2919-2920
+	}
+	tr.distortion_gradient_window_open = tr.optimize_distortion;
+	const bool train_envmap = tr.train_envmap && m_envmap.n_params() > 0;
+	if (train_envmap) {
+		if (m_world_size > 1 && !m_dp_comm) throw std::runtime_error{"train_envmap at world_size > 1 needs init_data_parallel (the map's gradients are summed over the ranks)"};
+		m_envmap.clear_gradients(m_stream, false);   // 2941-2944: every step
+	}
+	NgpLossExtras loss_extras{};
+	if (m_envmap.n_params() > 0) {   // 3219-3222: the training copy of the map, its gradient buffer only while it trains
+		loss_extras.envmap_data = m_envmap.params.as<float>(); loss_extras.envmap_gradient = train_envmap ? m_envmap.gradients.as<float>() : nullptr;
+		loss_extras.envmap_res[0] = m_envmap.resolution[0]; loss_extras.envmap_res[1] = m_envmap.resolution[1]; loss_extras.envmap_loss_type = (int)m_envmap.loss_type;
+	}
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
-	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
+	check(ngp_hip_compute_loss_ex(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
 	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                           m_mlp_out.as<uint16_t>(), compacted_counter, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
 	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type,
-	                           tr.optimize_exposure ? tr.cam_exposure_gradient_gpu.as<float>() : nullptr), "compute_loss");
+	                           tr.optimize_exposure ? tr.cam_exposure_gradient_gpu.as<float>() : nullptr, &loss_extras), "compute_loss");
 	profile_end(PK_LOSS, R);
 	if (capturing) {   // the loss kernel's products before the roll-over pads and rescales them
 		capture_copy(m_capture.numsteps_compacted, m_numsteps.data(), (size_t)R * 8);
@@ -1006,7 +1082,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// final once the loss kernel ran, so a one-wave kernel gathers them (and the loss sum when asked for) into pinned host memory
 	// here and the host picks them up from an event: forward / backward are queued behind it without a gap, and the next step's
 	// march can be launched (stream B) while they run.
-	if (tr.optimize_extrinsics) {
+	if (tr.optimize_extrinsics || tr.optimize_distortion) {
 		// the camera-gradient kernel runs behind the backward pass and reads this step's rays; the next step's march (stream B, launched once the host has
 		// seen the counters posted below) overwrites them — so they are set aside here, in stream order before the post (R x 36 bytes)
 		m_cam_rays.enlarge((size_t)R * (sizeof(NgpRay) + 8)); m_cam_ray_indices.enlarge((size_t)R * 4);
@@ -1046,7 +1122,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	}
 	profile_begin(PK_BACKWARD);
 	if (!m_grid_grad_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_grad_event = e; }
-	if (tr.optimize_extrinsics) {
+	if (tr.optimize_extrinsics || tr.optimize_distortion) {
 		// prepare_input_gradients (3327-3330): the backward pass also writes dL/d(pos, dir) of every compacted sample; compute_cam_gradient_train_nerf (3350-3378)
 		// folds them into per-image position / rotation gradients.  The ray counter of this step's slot is stable until the step after next.
 		m_coords_gradient.enlarge((size_t)target_batch_size * 6 * sizeof(float));
@@ -1054,10 +1130,13 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		                                  OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_coords_gradient.as<float>()), "nerf_backward_input");
 		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
 		profile_end(PK_BACKWARD, target_batch_size);
-		check(ngp_hip_compute_cam_gradient(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers, tr.cam_pos_gradient_gpu.as<float>(),
-		                                   tr.cam_rot_gradient_gpu.as<float>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(), m_cam_ray_indices.as<uint32_t>(),
-		                                   m_cam_rays.as<NgpRay>(), (const uint32_t*)((const char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay)), m_coords_compacted.as<NgpCoord>(),
-		                                   m_coords_gradient.as<float>(), tr.error_map_cdf(cdf_storage)), "compute_cam_gradient");
+		check(ngp_hip_compute_cam_gradient_ex(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
+		                                      tr.optimize_extrinsics ? tr.cam_pos_gradient_gpu.as<float>() : nullptr, tr.optimize_extrinsics ? tr.cam_rot_gradient_gpu.as<float>() : nullptr,
+		                                      (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(), m_cam_ray_indices.as<uint32_t>(),
+		                                      m_cam_rays.as<NgpRay>(), (const uint32_t*)((const char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay)), m_coords_compacted.as<NgpCoord>(),
+		                                      m_coords_gradient.as<float>(), tr.error_map_cdf(cdf_storage), tr.transforms_gpu.as<NgpXForm>(),
+		                                      tr.optimize_distortion ? m_distortion.gradients.as<float>() : nullptr, tr.optimize_distortion ? m_distortion.gradient_weights.as<float>() : nullptr,
+		                                      m_distortion.resolution), "compute_cam_gradient");
 	} else {
 		check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 		                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
@@ -1138,6 +1217,10 @@ void Testbed::train_nerf_dp_end() {
 	NerfTraining& tr = m_nerf.training;
 	optimizer_step();
 	++m_training_step;
+	if (tr.train_envmap && m_envmap.n_params() > 0) {   // 2954-2956
+		if (m_dp_comm) check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, m_envmap.gradients.as<float>(), m_envmap.n_params()), "ngp_rccl_allreduce_f32 (envmap gradients)");
+		m_envmap.optimizer_step(m_stream, LOSS_SCALE);
+	}
 	const bool zero_records = tr.counters_rgb.measured_batch_size == 0;
 	if (zero_records) {
 		m_loss_scalar = 0.f;
@@ -1204,6 +1287,16 @@ void Testbed::train_nerf_dp_end() {
 		drop_prefetch();            // no march is in flight (maybe_prefetch_next skipped this step); a stale one would be discarded through the version below
 		tr.update_transforms();
 		++m_state_version;
+	}
+	if (tr.optimize_distortion && cam_update_due) {   // 3085-3092
+		if (m_dp_comm) {
+			check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, m_distortion.gradients.as<float>(), m_distortion.n_params()), "ngp_rccl_allreduce_f32 (distortion gradients)");
+			check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, m_distortion.gradient_weights.as<float>(), m_distortion.n_params()), "ngp_rccl_allreduce_f32 (distortion gradient weights)");
+		}
+		check(ngp_hip_safe_divide(m_stream, (uint32_t)m_distortion.n_params(), m_distortion.gradients.as<float>(), m_distortion.gradient_weights.as<float>()), "safe_divide");
+		m_distortion.optimizer_step(m_stream, LOSS_SCALE * (float)tr.n_steps_between_cam_updates);
+		drop_prefetch();
+		++m_state_version;   // the ray generator reads the map
 	}
 	if (cam_update_due) tr.n_steps_since_cam_update = 0;   // 3134 (train_camera false: the reference never resets; the window only matters when training)
 	// error map -> CDFs (2971-3023): low-overhead enough to be always on in the reference; sampling from them is a separate switch
@@ -1325,7 +1418,6 @@ void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, const float rol
 	if (m_testbed_mode == ETestbedMode::Sdf) throw std::runtime_error{"rendering an SDF (sphere tracing, testbed_sdf.cu) is outside the scope of this build; P2 covers the training step"};
 	const float focal_length[2] = {m_relative_focal_length[0] * (float)rb.res[m_fov_axis] * m_zoom, m_relative_focal_length[1] * (float)rb.res[m_fov_axis] * m_zoom};
 	const float screen_center[2] = {(0.5f - m_screen_center[0]) * m_zoom + 0.5f, (0.5f - m_screen_center[1]) * m_zoom + 0.5f};
-	if (m_nerf.glow_mode != 0) throw std::runtime_error{"nerf.glow_mode: the glow shading (testbed_nerf.cu:843-871) is not part of this build"};
 	render_nerf(rb, focal_length, cam0, cam1, rolling_shutter, screen_center);
 	// CudaRenderBuffer::accumulate / tonemap (render_buffer.cu:609-664)
 	if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);
@@ -1337,9 +1429,21 @@ void Testbed::render_frame(const Mat34& cam0, const Mat34& cam1, const float rol
 	sync();
 }
 
+void Testbed::prepare_nerf_masks() {  // testbed_nerf.cu:2339-2352
+	m_n_render_masks = (uint32_t)m_render_masks.size();
+	if (m_render_masks.empty()) return;
+	const NgpMask3D first_mask = m_render_masks[0];
+	if (first_mask.shape != (int)EMaskShape::All) {   // an `All` mask of the opposite mode goes in front (and stays there, like the reference's member vector)
+		m_render_masks.insert(m_render_masks.begin(), Mask3D::All(first_mask.mode == (int)EMaskMode::Add ? EMaskMode::Subtract : EMaskMode::Add).pod);
+		m_n_render_masks = (uint32_t)m_render_masks.size();
+	}
+	m_render_masks_gpu.resize(m_render_masks.size() * sizeof(NgpMask3D));
+	m_render_masks_gpu.copy_from_host(m_render_masks.data(), m_render_masks.size() * sizeof(NgpMask3D));
+}
+
 void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], const float screen_center[2]) {  // testbed_nerf.cu:2354-2500, 2047-2267
 	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)rb.res[1];
-	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY);
+	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY) + 256;   // + 256: the input-gradient pass of the Normals mode works on multiples of 256
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
 	m_tr_hit_payload.enlarge(n_el * sizeof(NgpPayload)); m_tr_hit_rgba.enlarge(n_el * 16); m_tr_hit_depth.enlarge(n_el * 4);
 	m_tr_net_in.enlarge(n_el * 8 * sizeof(NgpCoord)); m_tr_net_out.enlarge(n_el * 8 * OUT_STRIDE * 2);
@@ -1347,12 +1451,41 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	uint32_t* hit_counter = m_tr_counters.as<uint32_t>() + 1;
 
 	const int lens_mode = m_nerf.render_with_lens_distortion ? m_nerf.render_lens_proxy.lens_mode : 0;   // testbed_nerf.cu:2381
-	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
 	const uint32_t sample_index = rb.spp;
-	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, zero3, m_snap_to_pixel_centers,
-	                        &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
-	                        m_slice_plane_z + m_scale /* plane_z (2355); the Slice render mode, which negates it, is not built */, m_aperture_size,
-	                        m_render_camera_models.model ? &m_render_camera_models : nullptr), "init_rays");
+	float plane_z = m_slice_plane_z + m_scale;   // 2355-2358
+	if (m_render_mode == ERenderMode::Slice) plane_z = -plane_z;
+	const int render_mode = m_visualized_dimension > -1 ? 8 /* EncodingVis */ : (int)m_render_mode;   // 2360
+	prepare_nerf_masks();
+	NgpRenderExtras ex{};
+	ex.render_masks = m_n_render_masks ? m_render_masks_gpu.as<NgpMask3D>() : nullptr; ex.n_render_masks = m_n_render_masks;
+	ex.glow_mode = m_nerf.glow_mode; ex.glow_y_cutoff = m_nerf.glow_y_cutoff;
+	if (m_envmap.resolution[0] > 0 && m_envmap.resolution[1] > 0) { ex.envmap = m_envmap.params_inference(); ex.envmap_res[0] = m_envmap.resolution[0]; ex.envmap_res[1] = m_envmap.resolution[1]; }   // 2399-2400
+	if (m_nerf.render_with_lens_distortion && m_distortion.resolution[0] > 0) {   // render_grid_distortion (2370, 2401-2402)
+		ex.distortion = m_distortion.params_inference(); ex.distortion_res[0] = m_distortion.resolution[0]; ex.distortion_res[1] = m_distortion.resolution[1];
+	}
+	ex.quilting_dims[0] = m_quilting_dims[0]; ex.quilting_dims[1] = m_quilting_dims[1];
+	ex.render_mode = render_mode; ex.frame_buffer = rb.frame_buffer.as<float>();
+	float parallax_shift[3] = {m_parallax_shift[0], m_parallax_shift[1], m_parallax_shift[2]};
+	if ((m_quilting_dims[0] != 1 || m_quilting_dims[1] != 1) && !(m_quilting_dims[0] == 2 && m_quilting_dims[1] == 1)) parallax_shift[2] = 1.0f / m_scale;   // testbed.cu:2703-2706 (lenticular display)
+	check(ngp_hip_init_rays_ex(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, parallax_shift, m_snap_to_pixel_centers,
+	                           &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
+	                           plane_z, m_aperture_size, m_render_camera_models.model ? &m_render_camera_models : nullptr, &ex), "init_rays");
+	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	if (m_render_mode == ERenderMode::Slice) {   // 2445-2476: the network where every ray meets the slice plane; all rays of the frame are shaded
+		const uint32_t n_hit = n_pixels, n_elements = (uint32_t)next_multiple(n_hit, BATCH_SIZE_GRANULARITY);
+		m_tr_vis_rgba.enlarge((size_t)n_elements * 16);
+		check(ngp_hip_generate_inputs_at_current_position(m_stream, n_hit, &m_aabb, m_tr_payload[0].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>()), "generate_inputs_at_current_position");
+		if (m_visualized_dimension == -1) {
+			check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>() /* m_network->inference: the training weights (2459) */, m_tr_net_in.as<float>(), 7, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference (slice)");
+			check(ngp_hip_compute_nerf_rgba(m_stream, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_tr_vis_rgba.as<float>(), (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, 0.01f, 0), "compute_nerf_rgba");
+		} else {
+			check(ngp_hip_nerf_visualize_activation(m_stream, desc, m_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, m_tr_net_in.as<float>(), 7, n_hit, m_tr_vis_rgba.as<float>(), 4), "visualize_activation (slice)");
+		}
+		m_render_samples_evaluated += n_elements;
+		check(ngp_hip_shade_mode(m_stream, n_hit, m_tr_vis_rgba.as<float>(), nullptr, m_tr_payload[0].as<NgpPayload>(), m_nerf.training.linear_colors, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(),
+		                         (int)m_render_mode), "shade (slice)");
+		return;
+	}
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_rgba[0].data(), 0, (size_t)n_pixels * 16, (hipStream_t)m_stream));
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;
@@ -1384,7 +1517,6 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	}
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_render_event, (hipStream_t)m_stream));
 	for (uint32_t p = 0; p < K; ++p) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_render_streams[p], (hipEvent_t)m_render_event, 0));
-	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	uint32_t* alive_counters = m_tr_counters.as<uint32_t>() + 2;
 	volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
 	static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: pass structure on stderr
@@ -1428,9 +1560,16 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
 			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
-			check(ngp_hip_composite_mode(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
-			                             (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, (int)m_render_mode,
-			                             1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel), "composite");
+			if (render_mode == (int)ERenderMode::Normals) {   // 2225-2226: network.input_gradient(stream, 3, positions, positions) — on the inference weights like the pass above
+				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);
+				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
+				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes()), "nerf_input_gradient (normals)");
+			} else if (render_mode == 8) {                    // 2227-2228: network.visualize_activation(stream, layer, dim, positions, positions)
+				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
+			}
+			check(ngp_hip_composite_ex(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
+			                           (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,
+			                           1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel, &ex), "composite");
 			pt.i += n_steps;
 		}
 	}

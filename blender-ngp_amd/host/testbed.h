@@ -104,6 +104,8 @@ struct NerfDataset {
 	bool has_rays = false;
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
+	std::vector<float> envmap_data;              // `envmap` key of transforms.json (nerf_loader.h envmap_data; host copy, uploaded by reset_network like testbed.cu:2459-2461)
+	int envmap_resolution[2] = {0, 0};
 
 	Mat34 nerf_matrix_to_ngp(const Mat34& nerf_matrix, bool scale_columns = false) const;   // nerf_loader.h:113-132
 	Mat34 ngp_matrix_to_nerf(const Mat34& ngp_matrix, bool scale_columns = false) const;    // nerf_loader.h:134-152
@@ -118,6 +120,24 @@ struct NerfCounters {  // testbed.h:369-381
 	uint32_t n_rays_total = 0;
 	uint32_t measured_batch_size = 0;
 	uint32_t measured_batch_size_before_compaction = 0;
+};
+
+// trainable_buffer.cuh together with the tcnn Trainer / optimizer the reference pairs it with: an all-fp32 [h][w][n_dims] image trained by
+// [Ema o] ExponentialDecay o Adam.  The environment map (N = 4; testbed.cu:2447-2462, testbed.h:936-944) and the lens-distortion map (N = 2;
+// testbed.cu:2386-2396, testbed.h:946-952) are the two on the NeRF path.
+struct TrainableBuffer {
+	int resolution[2] = {0, 0}; uint32_t n_dims = 0;
+	DeviceBuffer params, ema, gradients, gradient_weights, first_moments, second_moments;
+	bool use_ema = false, has_decay = false;
+	float ema_decay = 0.99f, decay_base = 1.f, base_learning_rate = 1e-3f, learning_rate = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-8f;
+	uint32_t decay_start = 0, decay_interval = 1, decay_end = 0, step = 0;
+	ELossType loss_type = ELossType::L2;
+	size_t n_params() const { return (size_t)resolution[0] * (size_t)resolution[1] * n_dims; }
+	float* params_inference() const { return (use_ema && step > 0) ? ema.as<float>() : params.as<float>(); }   // Ema's custom weights once it has stepped
+	void reset(int w, int h, uint32_t dims, const Json& optimizer_config, void* stream);    // zero-initialised (trainable_buffer.cuh:64-69)
+	void set_params(const float* host, size_t n);                                            // Trainer::set_params_full_precision
+	void clear_gradients(void* stream, bool weights_too);
+	void optimizer_step(void* stream, float loss_scale);                                     // Trainer::optimizer_step(stream, loss_scale)
 };
 
 class Testbed;
@@ -152,6 +172,8 @@ struct NerfTraining {
 	// camera-side trainables of testbed.h:653-662 that this build does not train: the switches exist so that a script setting them fails loudly
 	// in train() instead of silently training something else (python_api.cu:804-812)
 	bool optimize_extra_dims = false, optimize_distortion = false;
+	bool distortion_gradient_window_open = false;                  // the distortion gradients of the current n_steps_between_cam_updates window are being accumulated
+	bool train_envmap = false;                                     // testbed.h:656 (the reference sets it from its GUI only; exposed on pyngp here)
 	bool include_sharpness_in_error = false;                       // testbed.h:670 (the sharpness map is not computed by this loader)
 	float extrinsic_l2_reg = 1e-4f, extrinsic_learning_rate = 1e-3f, intrinsic_l2_reg = 1e-4f;   // testbed.h:673-678
 	int view = 0;                                                  // current training view of the GUI navigation (testbed.h:636)
@@ -208,7 +230,7 @@ struct Nerf {
 	float sharpen = 0.f;
 	int show_accel = -1;
 	bool visualize_cameras = false;          // GUI-side (stored)
-	float glow_y_cutoff = 0.f; int glow_mode = 0;   // testbed.h:730-731; the glow shading of composite_kernel_nerf is not built (glow_mode != 0 throws in render)
+	float glow_y_cutoff = 0.f; int glow_mode = 0;   // testbed.h:730-731; the glow shading of composite_kernel_nerf (testbed_nerf.cu:843-939)
 	NgpImageMeta render_lens_proxy{};        // only lens_mode / lens_params are used (render_lens)
 };
 
@@ -387,7 +409,11 @@ public:
 	float m_exposure = 0.f;
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
-	ERenderMode m_render_mode = ERenderMode::Shade;    // AO, Shade, Positions, Depth and Cost are built (ngp_hip_composite_mode)
+	ERenderMode m_render_mode = ERenderMode::Shade;    // every ERenderMode of the stock tracer (ngp_hip_composite_ex / ngp_hip_init_rays_ex / the Slice kernels)
+	std::vector<NgpMask3D> m_render_masks;             // python_api.cu:694: crop masks of the STOCK renderer (testbed_nerf.cu:2339-2352, 833-840, 1943-1956)
+	uint32_t m_n_render_masks = 0;
+	void prepare_nerf_masks();                         // testbed_nerf.cu:2339-2352
+	int m_quilting_dims[2] = {1, 1};                   // testbed.h:549 (set by the reference's VR / HoloPlay GUI paths only)
 	NgpRenderCamera m_render_camera_models{};          // stock renderer: model (0 Perspective) + the SphericalQuadrilateral / QuadrilateralHexahedron shapes (python_api.cu:691-693)
 	float m_aperture_size = 0.0f;                      // depth of field: radius of the lens disk (testbed.h m_aperture_size; python `dof` / `aperture_size`)
 	float m_slice_plane_z = 0.0f;                      // focus distance is m_slice_plane_z + m_scale (testbed_nerf.cu:2355)
@@ -399,7 +425,7 @@ public:
 	float m_dynamic_res_target_fps = 20.0f; int m_fixed_res_factor = 8;                 // testbed.h:521-522
 	bool m_imgui_enabled = true, m_visualize_unit_cube = false, m_floor_enable = false, m_dlss = false; float m_dlss_sharpening = 0.0f;
 	bool m_render_ground_truth = false; int m_ground_truth_render_mode = 0;             // testbed.h:880-881 (GUI overlay of the training images)
-	int m_visualized_dimension = -1; uint32_t m_visualized_layer = 0;                   // EncodingVis / neuron visualisation (not built)
+	int m_visualized_dimension = -1; uint32_t m_visualized_layer = 0;                   // > -1: EncodingVis / neuron visualisation (testbed_nerf.cu:2360)
 	Vec3 m_sun_dir{0.57735027f, 0.57735027f, 0.57735027f}; float m_parallax_shift[3] = {0.f, 0.f, 0.f};
 	Vec3 m_up_dir{0.f, 1.f, 0.f};
 	float m_relative_focal_length[2] = {1.f, 1.f};
@@ -480,13 +506,15 @@ private:
 	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
-	DeviceBuffer m_distortion_map;  // 32x32x2 zeros: passed unconditionally to the ray generator
+	TrainableBuffer m_envmap;       // testbed.h:936-944: resolution of the dataset's `envmap` image ((0, 0): none)
+	TrainableBuffer m_distortion;   // testbed.h:946-952: 32 x 32 x 2 zeros unless trained; passed unconditionally to the ray generator
 	DeviceBuffer m_loss_scalar_gpu;
 	// tracer scratch (NerfTracer::enlarge 2270-2295)
 	std::vector<void*> m_render_streams;
 	void* m_render_event = nullptr;
 	void* m_render_host_words = nullptr;
 	std::vector<DeviceBuffer> m_tr_enc_ws;
+	DeviceBuffer m_render_masks_gpu, m_tr_vis_scratch, m_tr_vis_rgba;
 	DeviceBuffer m_tr_payload[2], m_tr_rgba[2], m_tr_depth[2], m_tr_hit_payload, m_tr_hit_rgba, m_tr_hit_depth, m_tr_net_in, m_tr_net_out, m_tr_counters;
 	struct ProfPending { int k; void* e0; void* e1; uint64_t units; };
 	std::vector<ProfPending> m_prof_pending;

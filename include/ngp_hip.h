@@ -253,6 +253,36 @@ int ngp_hip_compute_cam_gradient(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
 	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host);
+/* The loss kernel with the environment map (compute_loss_kernel_train_nerf's envmap_data / envmap_gradient / envmap_resolution / envmap_loss_type,
+ * :1289-1292): the map (fp32 rgba [h][w][4], TrainableBuffer<4,2,float>::params) is composited in front of the background colour of every ray
+ * (:1394-1401); with envmap_gradient (train_envmap; the caller clears it every step, :2941-2944) rays whose every sample was kept deposit
+ * loss_scale * T * dL/drgb [/ srgb'(background)] bilinearly (:1573-1596, envmap.cuh:65-103; alpha gets no gradient).  extras_host NULL = ngp_hip_compute_loss. */
+typedef struct { const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type; } NgpLossExtras;
+int ngp_hip_compute_loss_ex(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
+	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
+	int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const NgpImageMeta* metadata,
+	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const NgpRay* rays_in_unnormalized,
+	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
+	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
+	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
+	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
+	float* exposure_gradient, const NgpLossExtras* extras_host);
+/* compute_cam_gradient_train_nerf with its lens-distortion branch (:1671-1685): the ray-direction gradient minus its component along the ray, rotated by
+ * the inverse of the image's camera rotation (xforms[img].start), is splatted (x, y; divided by the pixel pdf) into distortion_gradient at the ray's pixel and
+ * the bilinear weights into distortion_gradient_weight (both fp32 [h][w][2], atomicAdd; the caller clears them every n_steps_between_cam_updates, :2919-2920). */
+int ngp_hip_compute_cam_gradient_ex(
+	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
+	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host,
+	const NgpXForm* xforms, float* distortion_gradient, float* distortion_gradient_weight, const int32_t* distortion_resolution_host);
+/* safe_divide (:2039-2045, call site :3086-3090): inout[i] = divisor[i] > 0 ? inout[i] / divisor[i] : 0 */
+int ngp_hip_safe_divide(void* stream, uint32_t n_elements, float* inout, const float* divisor);
+/* Trainer<float, float, float>::optimizer_step(stream, loss_scale) of the envmap / distortion-map TrainableBuffers (:2955, :3091) with [Ema o] ExponentialDecay o Adam
+ * (configs/nerf/base.json:59-101): all-fp32 Adam in which every parameter is a non-matrix parameter (zero gradient: skipped; no l2_reg), `learning_rate` = base rate
+ * after ExponentialDecay (the host applies it), `step` 1-based, ema NULL or the fp32 Ema copy (ema_decay its decay).  In place. */
+int ngp_hip_optimizer_step_f32(void* stream, uint32_t n_params, uint32_t step, float learning_rate, float beta1, float beta2, float epsilon, float loss_scale, float ema_decay,
+                               const float* grads, float* params, float* first_moments, float* second_moments, float* ema);
 /* tcnn fill_rollover_and_rescale<half> / fill_rollover<float> (call sites :3314-3322) */
 int ngp_hip_fill_rollover_and_rescale_f16(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, uint16_t* inout);
 int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride, const uint32_t* n_input_elements, float* inout);
@@ -405,6 +435,53 @@ int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uin
                                  float min_transmittance, const NgpNerfProps* props);
 int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                         const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
+
+/* ============================ stock renderer, the rest of row f3: masks, glow, quilting, envmap background, distortion map, Normals /
+ * EncodingVis / Distortion / Slice render modes ============================
+ * NgpRenderExtras carries what init_rays_with_payload_kernel_nerf (src/testbed_nerf.cu:1809-1978) and composite_kernel_nerf (:767-989) take
+ * beyond the arguments of ngp_hip_init_rays / ngp_hip_composite_mode.  Host struct; the pointers inside are device pointers (or NULL). */
+typedef struct {
+	const NgpMask3D* render_masks; uint32_t n_render_masks;   /* Testbed::prepare_nerf_masks (:2339-2352): rays that hit no mask die in init_rays (:1943-1956);
+	                                                             per sample, weight *= clamp(1 + sum of mask.sample(pos), 0, 1) (:833-840) */
+	int32_t glow_mode; float glow_y_cutoff;                   /* :843-939 */
+	const float* envmap; int32_t envmap_res[2];               /* fp32 rgba [h][w][4] (TrainableBuffer<4,2,float>::params_inference); init_rays writes
+	                                                             read_envmap(dir) into frame_buffer (:1931-1933; envmap.cuh:29-63) */
+	const float* distortion; int32_t distortion_res[2];       /* fp32 [h][w][2] (TrainableBuffer<2,2,float>): added to the ray direction before the camera
+	                                                             rotation (common_device.cuh:297-299); Distortion render mode paints it (:1959-1970) */
+	int32_t quilting_dims[2];                                 /* {1,1}: off; apply_quilting (common_device.cuh:541-560, :1853-1863) */
+	int32_t render_mode;                                      /* ERenderMode of the frame (init_rays only needs to know Distortion = 5) */
+	float* frame_buffer;                                      /* [h][w][4] fp32, written by init_rays for the envmap background and the Distortion mode */
+} NgpRenderExtras;
+int ngp_hip_init_rays_ex(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
+                         const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host, const float* screen_center_host,
+                         const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
+                         float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer, float plane_z, float aperture_size,
+                         const NgpRenderCamera* camera_models_host, const NgpRenderExtras* extras_host);
+/* render_mode additionally: Normals 2 (network_input.pos holds d(density output)/d(pos), written there by ngp_hip_nerf_input_gradient: the colour
+ * is normalize(-density'(out[3]) * that), :941-946), EncodingVis 8 (network_input.pos holds what ngp_hip_nerf_visualize_activation wrote, :961-962). */
+int ngp_hip_composite_ex(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
+                         NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
+                         int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host);
+/* [tcnn] DifferentiableObject::input_gradient(stream, dim, input, d_output_d_input = input) as the tracer calls it for the Normals mode
+ * (src/testbed_nerf.cu:2225-2226; also :3432 for the marching-cubes normals): dL/doutput = backprop_scale (128) at output `dim` and 0 elsewhere,
+ * forward + backward of NerfNetwork (nerf_network.h:143-266) without parameter gradients, then every element of the input matrix times
+ * 1 / backprop_scale — the position and direction rows then hold d out[dim] / d input, the dt row its old value / 128 (no gradient is written
+ * to it).  coords: [n] NgpCoord, overwritten in place.  n must be a multiple of 256.  scratch: ngp_hip_nerf_input_gradient_scratch_bytes(n). */
+uint64_t ngp_hip_nerf_input_gradient_scratch_bytes(uint32_t n);
+int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, uint32_t dim, float* coords_inout,
+                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes);
+/* [tcnn] Network::visualize_activation(stream, layer, dimension, input, output): forward pass, then extract_dimension_pos_neg_kernel on
+ * forward_activations(layer) — NerfNetwork's layer map (nerf_network.h:474-501): 0 = hash encoding (32), 1 = density hidden layer (64),
+ * 2 = colour network input [density output 16 | SH 16], 3.. = colour hidden layers (64).  Output row 0 = max(-v, 0), row 1 = max(v, 0),
+ * row 2 = 0, every further row = 1; out_stride_floats = 7 writes over the NgpCoord it read (the tracer's EncodingVis, src/testbed_nerf.cu:2227-2228),
+ * 4 gives the rgba of the Slice mode (:2462). */
+int ngp_hip_nerf_visualize_activation(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords,
+                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats);
+/* Slice mode (src/testbed_nerf.cu:2445-2476): network inputs at payload.origin + dir * t (generate_nerf_network_inputs_at_current_position, :676-682),
+ * fp16 network outputs -> fp32 rgba with alpha = clamp(1 - exp(-density * depth), 0, 1) and colours premultiplied (compute_nerf_rgba, :684-703). */
+int ngp_hip_generate_inputs_at_current_position(void* stream, uint32_t n_elements, const NgpAabb* aabb_host, const NgpPayload* payloads, NgpCoord* network_input);
+int ngp_hip_compute_nerf_rgba(void* stream, uint32_t n_elements, const uint16_t* network_output, uint32_t out_stride, float* rgba, int rgb_activation, int density_activation,
+                              float depth, int density_as_alpha);
 
 /* ---- data-parallel collectives: one RCCL communicator per rank (one process per GPU; xGMI inside the node).  The reference is
  * single-GPU (README.md:239-241); these are the calls its training step would make between backward and optimizer_step (src/testbed_nerf.cu:3331,

@@ -68,6 +68,7 @@ void orc_nerf_inference(const orc_net* net, const uint16_t* params, const float*
 void orc_nerf_density(const orc_net* net, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0);
 void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, uint16_t* out_rgbsigma, double* grads_out, uint16_t* dL_dx_out);
 void orc_nerf_input_gradient(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, float* dL_dinput /* [n][6] */);
+void orc_nerf_visualize_activation(const orc_net* net, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords, uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats);
 void orc_nerf_init_params(const orc_net* net, uint64_t seed, float* params_fp32);
 void orc_f32_to_f16(const float* in, uint16_t* out, uint32_t n);
 void orc_f16_to_f32(const uint16_t* in, float* out, uint32_t n);
@@ -104,6 +105,21 @@ void orc_compute_cam_gradient(
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const orc_image_meta* metadata, const uint32_t* ray_indices_in,
 	const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in, const orc_coord* coords_all, const float* coords_gradient_all /* [sample][6] */,
 	const orc_error_map_cdf* cdf);
+typedef struct { const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type; } orc_loss_extras;   /* NgpLossExtras */
+void orc_compute_loss_ex(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted, uint32_t n_rays_alive, float loss_scale, uint32_t mlp_stride,
+	const float background_color_in[3], int color_space_srgb, int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const orc_image_meta* metadata,
+	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, uint32_t* numsteps_in, const orc_coord* coords_in_all,
+	orc_coord* coords_out_all, uint16_t* dloss_doutput_all, int loss_type, float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation,
+	int density_activation, int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure, float near_distance,
+	const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type, float* exposure_gradient, const orc_loss_extras* ex);
+void orc_compute_cam_gradient_ex(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t n_rays_alive, int snap_to_pixel_centers, float* cam_pos_gradient, float* cam_rot_gradient,
+	uint32_t n_training_images, const orc_image_meta* metadata, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in, const orc_coord* coords_all,
+	const float* coords_gradient_all, const orc_error_map_cdf* cdf, const orc_xform* xforms, float* distortion_gradient, float* distortion_gradient_weight, const int32_t* distortion_resolution);
+void orc_safe_divide(uint32_t n, float* inout, const float* divisor);
+void orc_optimizer_step_f32(uint32_t n, uint32_t step, float base_lr_after_decay, float beta1, float beta2, float epsilon, float loss_scale, float ema_decay, const float* grads, float* params,
+                            float* m1, float* m2, float* ema);
 void orc_image_from_rgba32_f16(uint64_t n_pixels, const uint8_t* rgba8, uint16_t* out_half4, uint32_t mask_color);
 void orc_image_sharpen(uint64_t n_pixels, uint32_t w, const void* pix, void* dest, int is_half, float sharpen_amount);
 void orc_fill_rollover_and_rescale_f16(uint32_t n_elements, uint32_t stride, uint32_t n_input_elements, uint16_t* inout);
@@ -123,6 +139,18 @@ void orc_composite_mode(uint32_t n_elements, uint32_t current_step, const orc_aa
                         float min_transmittance, int render_mode, float depth_scale, int show_accel);
 void orc_shade_mode(uint32_t n_elements, const float* rgba, const float* depth, const orc_payload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                     int render_mode);
+typedef struct {   /* NgpRenderExtras of include/ngp_hip.h */
+	const orc_mask3d* render_masks; uint32_t n_render_masks; int32_t glow_mode; float glow_y_cutoff; const float* envmap; int32_t envmap_res[2];
+	const float* distortion; int32_t distortion_res[2]; int32_t quilting_dims[2]; int32_t render_mode; float* frame_buffer;
+} orc_render_extras;
+void orc_read_image2(const float* data, const int32_t res[2], const float pos[2], float out[2]);
+void orc_read_envmap(const float* data, const int32_t res[2], const float dir[3], float out[4]);
+void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size, const orc_render_camera* camera_models, const orc_render_extras* ex);
+void orc_composite_ex(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix, float* rgba, float* depth, orc_payload* payloads,
+                      const orc_coord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation,
+                      float min_transmittance, int render_mode, float depth_scale, int show_accel, const orc_render_extras* ex);
+void orc_generate_inputs_at_current_position(uint32_t n_elements, const orc_aabb* aabb, const orc_payload* payloads, orc_coord* network_input);
+void orc_compute_nerf_rgba(uint32_t n_elements, const uint16_t* network_output, uint32_t out_stride, float* rgba, int rgb_activation, int density_activation, float depth, int density_as_alpha);
 void orc_accumulate(const int32_t res[2], const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space_srgb);
 void orc_tonemap(const int32_t res[2], float exposure, const float background_color_in[4], const float* accumulate_buffer, int color_space_srgb, int output_color_space_srgb, int tonemap_curve, int clamp_output_color, float* surface);
 uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, uint32_t sample_index, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float screen_center[2], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb, float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation, float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer);

@@ -64,6 +64,26 @@ void orc_compute_loss(
 	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure /* [n_images][3] */,
 	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
 	float* exposure_gradient) {
+	orc_compute_loss_ex(n_rays, aabb, rng_state, rng_inc, max_samples_compacted, n_rays_alive, loss_scale, mlp_stride, background_color_in, color_space_srgb, train_with_random_bg_color,
+	                    train_in_linear_colors, n_training_images, metadata, network_output, numsteps_counter, ray_indices_in, rays_in_unnormalized, numsteps_in, coords_in_all, coords_out_all,
+	                    dloss_doutput_all, loss_type, loss_output, max_level_rand_training, max_level_compacted_ptr_all, rgb_activation, density_activation, snap_to_pixel_centers, error_map,
+	                    error_map_res, mean_density, exposure, near_distance, cdf, encoded_in, encoded_out, depth_supervision_lambda, depth_loss_type, exposure_gradient, NULL);
+}
+
+/* the same kernel with its environment-map arguments (:1289-1292): the map in front of the background colour (:1394-1401), its gradient (:1573-1596) */
+void orc_compute_loss_ex(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc,
+	uint32_t max_samples_compacted, uint32_t n_rays_alive, float loss_scale, uint32_t mlp_stride,
+	const float background_color_in[3], int color_space_srgb, int train_with_random_bg_color, int train_in_linear_colors,
+	uint32_t n_training_images, const orc_image_meta* metadata, const uint16_t* network_output, uint32_t* numsteps_counter,
+	const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, uint32_t* numsteps_in, const orc_coord* coords_in_all,
+	orc_coord* coords_out_all, uint16_t* dloss_doutput_all, int loss_type,
+	float* loss_output, int max_level_rand_training, float* max_level_compacted_ptr_all, int rgb_activation, int density_activation,
+	int snap_to_pixel_centers, float* error_map, const int32_t error_map_res[2], float mean_density, const float* exposure,
+	float near_distance, const orc_error_map_cdf* cdf, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
+	float* exposure_gradient, const orc_loss_extras* ex) {
+	const float* envmap_data = ex && ex->envmap_data && ex->envmap_res[0] > 0 && ex->envmap_res[1] > 0 ? ex->envmap_data : NULL;
+	float* envmap_gradient = envmap_data ? ex->envmap_gradient : NULL;
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		uint32_t numsteps = numsteps_in[i * 2 + 0];
 		uint32_t base = numsteps_in[i * 2 + 1];
@@ -108,6 +128,14 @@ void orc_compute_loss(
 			for (int c = 0; c < 3; ++c) background_color[c] = orc_pcg32_next_float(&rng);
 		}
 		for (int c = 0; c < 3; ++c) background_color[c] = orc_srgb_to_linear(background_color[c]);
+		float env_dir[3] = {0.f, 0.f, 1.f};
+		if (envmap_data) {   /* :1394-1401 */
+			const orc_vec3 d = orc_normalized(rays_in_unnormalized[i].d);
+			env_dir[0] = d.x; env_dir[1] = d.y; env_dir[2] = d.z;
+			float e[4];
+			orc_read_envmap(envmap_data, ex->envmap_res, env_dir, e);
+			for (int c = 0; c < 3; ++c) background_color[c] = e[c] + background_color[c] * (1.0f - e[3]);
+		}
 
 		float exposure_scale[3];
 		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * exposure[img * 3 + c]);
@@ -230,6 +258,28 @@ void orc_compute_loss(
 				(lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) +
 				(lof[3] > -10.0f && depth < near_distance ? 1e-4f : 0.0f));
 		}
+		if (compacted_numsteps == numsteps && envmap_gradient) {   /* :1573-1596; deposit_envmap_gradient, envmap.cuh:65-103 (value and weight pass through fp16) */
+			orc_lg lge = lg;
+			if (ex->envmap_loss_type != loss_type) lge = orc_loss_and_gradient(rgbtarget, rgb_ray, ex->envmap_loss_type);
+			const float PI = 3.14159265358979323846f;
+			const float dx = env_dir[2], dy = -env_dir[0], dz = env_dir[1];
+			const float theta = acosf(fminf(fmaxf(dz, -1.0f), 1.0f)), phi = atan2f(dy, dx);
+			const float fx = (phi / (2.0f * PI) + 0.5f) * (float)(ex->envmap_res[0] - 1), fy = (theta / PI) * (float)(ex->envmap_res[1] - 1);
+			const int tx = (int)fx, ty = (int)fy;
+			const float wx = fx - (float)tx, wy = fy - (float)ty;
+			for (int c = 0; c < 3; ++c) {
+				float d = T * lge.gradient[c];
+				if (!train_in_linear_colors) d /= orc_srgb_to_linear_derivative(background_color[c]);
+				const float v16 = orc_h2f(orc_f2h(loss_scale * d));
+				for (int k = 0; k < 4; ++k) {
+					int x = tx + (k & 1), y = ty + (k >> 1);
+					if (x < 0) x += ex->envmap_res[0]; else if (x >= ex->envmap_res[0]) x -= ex->envmap_res[0];
+					y = y < ex->envmap_res[1] - 1 ? y : ex->envmap_res[1] - 1; y = y > 0 ? y : 0;
+					const float w16 = orc_h2f(orc_f2h(((k & 1) ? wx : 1 - wx) * ((k >> 1) ? wy : 1 - wy)));
+					envmap_gradient[((size_t)x + (size_t)y * ex->envmap_res[0]) * 4 + c] += orc_h2f(orc_f2h(v16 * w16));
+				}
+			}
+		}
 	}
 }
 
@@ -248,6 +298,34 @@ void orc_compute_cam_gradient(
 	float* cam_pos_gradient /* [n_images][3] or NULL, accumulated */, float* cam_rot_gradient /* likewise */, uint32_t n_training_images,
 	const orc_image_meta* metadata, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in,
 	const orc_coord* coords_all, const float* coords_gradient_all /* [sample][6] */, const orc_error_map_cdf* cdf) {
+	orc_compute_cam_gradient_ex(n_rays, aabb, rng_state, rng_inc, n_rays_alive, snap_to_pixel_centers, cam_pos_gradient, cam_rot_gradient, n_training_images, metadata, ray_indices_in,
+	                            rays_in_unnormalized, numsteps_in, coords_all, coords_gradient_all, cdf, NULL, NULL, NULL, NULL);
+}
+
+/* deposit_image_gradient<2> (common_device.cuh:112-143) */
+static void orc_deposit_image_gradient2(const float value[2], float* gradient, float* gradient_weight, const int32_t res[2], const float pos[2]) {
+	const float fx = pos[0] * (float)(res[0] - 1), fy = pos[1] * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	for (int k = 0; k < 4; ++k) {
+		int x = tx + (k & 1), y = ty + (k >> 1);
+		x = x < res[0] - 1 ? x : res[0] - 1; x = x > 0 ? x : 0;
+		y = y < res[1] - 1 ? y : res[1] - 1; y = y > 0 ? y : 0;
+		const float w = ((k & 1) ? wx : 1 - wx) * ((k >> 1) ? wy : 1 - wy);
+		for (int c = 0; c < 2; ++c) {
+			gradient[((size_t)x + (size_t)y * res[0]) * 2 + c] += value[c] * w;
+			gradient_weight[((size_t)x + (size_t)y * res[0]) * 2 + c] += w;
+		}
+	}
+}
+
+/* the same kernel with its lens-distortion branch (:1671-1685) */
+void orc_compute_cam_gradient_ex(
+	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t n_rays_alive, int snap_to_pixel_centers,
+	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images,
+	const orc_image_meta* metadata, const uint32_t* ray_indices_in, const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in,
+	const orc_coord* coords_all, const float* coords_gradient_all, const orc_error_map_cdf* cdf,
+	const orc_xform* xforms, float* distortion_gradient /* [h][w][2] or NULL, accumulated */, float* distortion_gradient_weight, const int32_t* distortion_resolution) {
 	const orc_vec3 diag = orc_sub(aabb->max, aabb->min);
 	for (uint32_t i = 0; i < n_rays_alive; ++i) {
 		const uint32_t numsteps = numsteps_in[i * 2 + 0];
@@ -275,6 +353,15 @@ void orc_compute_cam_gradient(
 		orc_pcg32_advance(&rng, (int64_t)((uint64_t)(uint32_t)(ray_idx * ORC_N_MAX_RANDOM_SAMPLES_PER_RAY)));
 		float xy_pdf = 1.0f, xy[2];
 		orc_nerf_random_image_pos_training(&rng, metadata[img].res, snap_to_pixel_centers, cdf, img, xy, &xy_pdf);
+		if (distortion_gradient) {   /* :1673-1685 */
+			const orc_vec3 og = orc_sub(gd, orc_scale(ray_d, orc_dot(gd, ray_d)));
+			const float* m = xforms[img].start;
+			const double a = m[0], b = m[3], c = m[6], d = m[1], e = m[4], f = m[7], g = m[2], h = m[5], k = m[8];   /* inverse of the rotation block by cofactors */
+			const double A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g, det = a * A + b * B + c * C;
+			const double inv[9] = {A / det, B / det, C / det, -(b * k - c * h) / det, (a * k - c * g) / det, -(a * h - b * g) / det, (b * f - c * e) / det, -(a * f - c * d) / det, (a * e - b * d) / det};
+			const float ipg[2] = {(float)(inv[0] * og.x + inv[3] * og.y + inv[6] * og.z) / xy_pdf, (float)(inv[1] * og.x + inv[4] * og.y + inv[7] * og.z) / xy_pdf};
+			orc_deposit_image_gradient2(ipg, distortion_gradient, distortion_gradient_weight, distortion_resolution, xy);
+		}
 		if (cam_pos_gradient) {
 			cam_pos_gradient[img * 3 + 0] += go.x / xy_pdf; cam_pos_gradient[img * 3 + 1] += go.y / xy_pdf; cam_pos_gradient[img * 3 + 2] += go.z / xy_pdf;
 		}
@@ -282,6 +369,28 @@ void orc_compute_cam_gradient(
 			const orc_vec3 aa = orc_v3(ray_d.y * gd.z - ray_d.z * gd.y, ray_d.z * gd.x - ray_d.x * gd.z, ray_d.x * gd.y - ray_d.y * gd.x);                           /* :1697-1701 */
 			cam_rot_gradient[img * 3 + 0] += aa.x / xy_pdf; cam_rot_gradient[img * 3 + 1] += aa.y / xy_pdf; cam_rot_gradient[img * 3 + 2] += aa.z / xy_pdf;
 		}
+	}
+}
+
+/* safe_divide (:2039-2045) */
+void orc_safe_divide(uint32_t n, float* inout, const float* divisor) { for (uint32_t i = 0; i < n; ++i) inout[i] = divisor[i] > 0.0f ? (inout[i] / divisor[i]) : 0.0f; }
+
+/* [tcnn] Adam (+ Ema) on a TrainableBuffer<N, 2, float> (envmap.cuh / trainable_buffer.cuh users; Trainer::optimizer_step at :2955, :3091): every
+ * parameter is a non-matrix parameter (zero gradient: skipped, no l2_reg); fp32 throughout.  `step` 1-based, ema NULL without the Ema wrapper. */
+void orc_optimizer_step_f32(uint32_t n, uint32_t step, float base_lr_after_decay, float beta1, float beta2, float epsilon, float loss_scale, float ema_decay,
+                            const float* grads, float* params, float* m1, float* m2, float* ema) {
+	const float lr = base_lr_after_decay * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+	const float ema_debias_old = 1.0f - powf(ema_decay, (float)(step - 1)), ema_debias_new = 1.0f / (1.0f - powf(ema_decay, (float)step));
+	for (uint32_t i = 0; i < n; ++i) {
+		const float g = grads[i] / loss_scale;
+		float w = params[i];
+		if (g != 0.0f) {
+			const float fm = m1[i] = beta1 * m1[i] + (1.0f - beta1) * g;
+			const float sm = m2[i] = beta2 * m2[i] + (1.0f - beta2) * (g * g);
+			w = w - (lr / (sqrtf(sm) + epsilon)) * fm;
+			params[i] = w;
+		}
+		if (ema) ema[i] = (ema[i] * ema_decay * ema_debias_old + w * (1.0f - ema_decay)) * ema_debias_new;
 	}
 }
 

@@ -154,6 +154,23 @@ void orc_nerf_forward_one(const orc_net* net, const uint16_t* params, const floa
 	a->out[3] = a->in_rgb[0];                                  /* extract_density: nerf_network.h:32-43, 130-136 */
 }
 
+/* [tcnn] Network::visualize_activation: forward pass, then extract_dimension_pos_neg_kernel on forward_activations(layer) with NerfNetwork's layer
+ * map (nerf_network.h:474-501): 0 = encoding, 1 = density hidden layer, 2 = colour network input, 3.. = colour hidden layers.  Output row 0 =
+ * max(-v, 0), row 1 = max(v, 0), row 2 = 0, further rows = 1; a single output row gets v itself.  `out` may alias `coords`. */
+void orc_nerf_visualize_activation(const orc_net* net, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords, uint32_t coord_stride_floats,
+                                   uint32_t n, float* out, uint32_t out_stride_floats) {
+	#pragma omp parallel for schedule(static) if (n >= 512)
+	for (uint32_t i = 0; i < n; ++i) {
+		orc_act a;
+		orc_nerf_forward_one(net, params, coords + (size_t)i * coord_stride_floats, &a);
+		const uint16_t* src = layer == 0 ? a.x : layer == 1 ? a.h1 : layer == 2 ? a.in_rgb : layer == 3 ? a.h2 : a.h3;
+		const float v = orc_h2f(src[dimension]);
+		float* o = out + (size_t)i * out_stride_floats;
+		if (out_stride_floats == 1) { o[0] = v; continue; }
+		for (uint32_t k = 0; k < out_stride_floats; ++k) o[k] = k == 0 ? fmaxf(-v, 0.0f) : k == 1 ? fmaxf(v, 0.0f) : k == 2 ? 0.0f : 1.0f;
+	}
+}
+
 /* nerf_network.h:103-137: N samples -> rgbsigma fp16, `out_stride` halves per sample (>= 4), channels 0..3 written.
  * With out_stride >= 16 all 16 padded rgb-net outputs are written like the reference's AoS matrix. */
 void orc_nerf_inference(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,

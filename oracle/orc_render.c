@@ -21,7 +21,7 @@ static void orc_square2disk_shirley(float a, float b, float* ox, float* oy) {
 /* common_device.cuh:260-317 pixel_to_ray (no distortion grid) */
 static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[2], const float focal_length[2], const float* cam /* 3x4 */,
                                 const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, float near_distance,
-                                int lens_mode, const float* lens_params, float focus_z, float aperture_size) {
+                                int lens_mode, const float* lens_params, float focus_z, float aperture_size, const float* distortion_grid, const int32_t* distortion_res) {
 	float offset[2];
 	orc_ld_random_pixel_offset(snap_to_pixel_centers ? 0 : spp, offset);
 	float u = ((float)px + offset[0]) / (float)res[0];
@@ -38,6 +38,11 @@ static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[
 			(v - screen_center[1]) * (float)res[1] / focal_length[1],
 			1.0f);
 		if (lens_mode == 1) orc_iterative_opencv_lens_undistortion(lens_params, &dir.x, &dir.y);
+	}
+	if (distortion_grid) {   /* :297-299 */
+		float uv[2] = {u, v}, off[2];
+		orc_read_image2(distortion_grid, distortion_res, uv, off);
+		dir.x += off[0]; dir.y += off[1];
 	}
 	orc_vec3 head_pos = orc_v3(parallax_shift[0], parallax_shift[1], 0.f);
 	dir = orc_sub(dir, orc_scale(head_pos, parallax_shift[2]));
@@ -57,27 +62,99 @@ static orc_ray orc_pixel_to_ray(uint32_t spp, int px, int py, const int32_t res[
 	return r;
 }
 
-/* testbed_nerf.cu:1809-1978 init_rays_with_payload_kernel_nerf, Perspective camera model, no masks / envmap / quilting,
- * render_aabb_to_local = identity-or-given 3x3 (column-major). */
+/* envmap.cuh:29-63 read_envmap (fp32 map), random_val.cuh:64-69 dir_to_spherical_unorm */
+void orc_read_envmap(const float* data, const int32_t res[2], const float dir_in[3], float out[4]) {
+	const float PI = 3.14159265358979323846f;
+	const float dx = dir_in[2], dy = -dir_in[0], dz = dir_in[1];
+	const float cos_theta = fminf(fmaxf(dz, -1.0f), 1.0f);
+	const float theta = acosf(cos_theta);
+	const float phi = atan2f(dy, dx);
+	const float cyl[2] = {theta / PI, phi / (2.0f * PI) + 0.5f};
+	const float fx = cyl[1] * (float)(res[0] - 1), fy = cyl[0] * (float)(res[1] - 1);
+	const int tx = (int)fx, ty = (int)fy;
+	const float wx = fx - (float)tx, wy = fy - (float)ty;
+	for (int c = 0; c < 4; ++c) out[c] = 0.0f;
+	for (int k = 0; k < 4; ++k) {
+		int x = tx + (k & 1), y = ty + (k >> 1);
+		if (x < 0) x += res[0]; else if (x >= res[0]) x -= res[0];
+		y = y < res[1] - 1 ? y : res[1] - 1; y = y > 0 ? y : 0;
+		const float w = ((k & 1) ? wx : 1 - wx) * ((k >> 1) ? wy : 1 - wy);
+		const float* t = data + ((size_t)x + (size_t)y * res[0]) * 4;
+		for (int c = 0; c < 4; ++c) out[c] = k == 0 ? w * t[c] : out[c] + w * t[c];
+	}
+}
+/* common_device.cuh:594-619 */
+static void orc_hsv_to_rgb(float h, float s, float v, float out[3]) {
+	if (s == 0.0f) { out[0] = out[1] = out[2] = v; return; }
+	h = fmodf(h, 1.0f) * 6.0f;
+	int i = (int)h;
+	float f = h - (float)i;
+	float p = v * (1.0f - s), q = v * (1.0f - s * f), t = v * (1.0f - s * (1.0f - f));
+	switch (i) {
+		case 0: out[0] = v; out[1] = t; out[2] = p; break;
+		case 1: out[0] = q; out[1] = v; out[2] = p; break;
+		case 2: out[0] = p; out[1] = v; out[2] = t; break;
+		case 3: out[0] = p; out[1] = q; out[2] = v; break;
+		case 4: out[0] = t; out[1] = p; out[2] = v; break;
+		default: out[0] = v; out[1] = p; out[2] = q; break;
+	}
+}
+/* common_device.cuh:541-560 */
+static void orc_apply_quilting(uint32_t* x, uint32_t* y, const int32_t res[2], float parallax_shift[3], const int32_t qd[2]) {
+	float resx = (float)res[0] / (float)qd[0], resy = (float)res[1] / (float)qd[1];
+	int panelx = (int)floorf((float)*x / resx), panely = (int)floorf((float)*y / resy);
+	*x = (uint32_t)((float)*x - (float)panelx * resx);
+	*y = (uint32_t)((float)*y - (float)panely * resy);
+	int idx = panelx + qd[0] * panely;
+	if (qd[0] == 2 && qd[1] == 1) {
+		parallax_shift[0] = idx ? (-0.5f * parallax_shift[0]) : (0.5f * parallax_shift[0]);
+	} else {
+		const float max_parallax_angle = 17.5f;
+		float parallax_angle = max_parallax_angle * 3.14159265358979323846f / 180.f * (((float)idx + 0.5f) * 2.f / (float)(qd[1] * qd[0]) - 1.f);
+		parallax_shift[0] = atanf(parallax_angle) / parallax_shift[2];
+	}
+}
+
 void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2],
                    const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2],
                    const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local /* 3x3 */,
                    float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size,
-                   const orc_render_camera* camera_models /* NULL or model 0: Perspective; only model / sq_* / qh_* are read (1868-1908) */) {
+                   const orc_render_camera* camera_models) {
+	orc_init_rays_ex(sample_index, payloads, res, focal_length, camera_matrix0, camera_matrix1, rolling_shutter, screen_center, parallax_shift, snap_to_pixel_centers, render_aabb,
+	                 render_aabb_to_local, near_distance, lens_mode, lens_params, depthbuffer, plane_z, aperture_size, camera_models, NULL);
+}
+
+/* testbed_nerf.cu:1809-1978 init_rays_with_payload_kernel_nerf: camera models, quilting, envmap background, crop masks, Distortion mode;
+ * render_aabb_to_local = identity-or-given 3x3 (column-major). */
+void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2],
+                      const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2],
+                      const float parallax_shift_in[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local /* 3x3 */,
+                      float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size,
+                      const orc_render_camera* camera_models /* NULL or model 0: Perspective; only model / sq_* / qh_* are read (1868-1908) */,
+                      const orc_render_extras* ex) {
 	if (plane_z < 0) aperture_size = 0.0f;   /* :1849-1851 */
-	for (int y = 0; y < res[1]; ++y) for (int x = 0; x < res[0]; ++x) {
-		uint32_t idx = (uint32_t)x + (uint32_t)res[0] * (uint32_t)y;
+	const int32_t one[2] = {1, 1};
+	const int32_t* qd = ex && ex->quilting_dims[0] > 0 && ex->quilting_dims[1] > 0 ? ex->quilting_dims : one;
+	const float* distortion = ex && ex->distortion && ex->distortion_res[0] > 0 ? ex->distortion : NULL;
+	const float* envmap = ex && ex->envmap && ex->envmap_res[0] > 0 ? ex->envmap : NULL;
+	for (int yy = 0; yy < res[1]; ++yy) for (int xx = 0; xx < res[0]; ++xx) {
+		uint32_t x = (uint32_t)xx, y = (uint32_t)yy;
+		uint32_t idx = x + (uint32_t)res[0] * y;
+		float parallax_shift[3] = {parallax_shift_in[0], parallax_shift_in[1], parallax_shift_in[2]};
+		if (qd[0] != 1 || qd[1] != 1) orc_apply_quilting(&x, &y, res, parallax_shift, qd);
 		float u = ((float)x + 0.5f) * (1.f / (float)res[0]);
 		float v = ((float)y + 0.5f) * (1.f / (float)res[1]);
 		float ray_time = rolling_shutter[0] + rolling_shutter[1] * u + rolling_shutter[2] * v + rolling_shutter[3] * orc_ld_random_val(sample_index, idx * 72239731u, 0);
 		float cam[12];
 		for (int k = 0; k < 12; ++k) cam[k] = camera_matrix0[k] * ray_time + camera_matrix1[k] * (1.f - ray_time);
+		const int32_t qres[2] = {res[0] / qd[0], res[1] / qd[1]};   /* :1863 */
 		orc_ray ray;
 		if (camera_models && camera_models->model != 0) {
-			orc_extra_camera_model_pixel_to_ray(camera_models->model, sample_index, (uint32_t)x, (uint32_t)y, (float)res[0], (float)res[1], cam, camera_models->sq_width, camera_models->sq_height,
+			orc_extra_camera_model_pixel_to_ray(camera_models->model, sample_index, x, y, (float)qres[0], (float)qres[1], cam, camera_models->sq_width, camera_models->sq_height,
 			                                    camera_models->sq_curvature, camera_models->qh_front, camera_models->qh_back, near_distance, plane_z, aperture_size, &ray.o, &ray.d);
 		} else {
-			ray = orc_pixel_to_ray(sample_index, x, y, res, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params, plane_z, aperture_size);
+			ray = orc_pixel_to_ray(sample_index, (int)x, (int)y, qres, focal_length, cam, screen_center, parallax_shift, snap_to_pixel_centers, near_distance, lens_mode, lens_params, plane_z, aperture_size,
+			                       distortion, ex ? ex->distortion_res : NULL);
 		}
 
 		orc_payload* p = &payloads[idx];
@@ -95,12 +172,41 @@ void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t r
 		}
 		depthbuffer[idx] = 1e10f;
 		ray.d = orc_normalized(ray.d);
+		if (envmap) {   /* :1931-1933 */
+			const float d3[3] = {ray.d.x, ray.d.y, ray.d.z};
+			orc_read_envmap(envmap, ex->envmap_res, d3, ex->frame_buffer + 4 * (size_t)idx);
+		}
 		orc_vec3 lo = orc_mat3_mul(render_aabb_to_local, ray.o), ld = orc_mat3_mul(render_aabb_to_local, ray.d);
 		float tmm[2];
 		orc_aabb_ray_intersect(render_aabb, lo, ld, tmm);
 		float t = fmaxf(tmm[0], 0.0f) + 1e-6f;
 		if (!orc_aabb_contains(render_aabb, orc_mat3_mul(render_aabb_to_local, orc_add(ray.o, orc_scale(ray.d, t))))) {
 			p->origin = ray.o;
+			p->alive = 0;
+			continue;
+		}
+		int ray_intersects_any_mask = !ex || ex->n_render_masks == 0;   /* :1943-1956 */
+		if (ex) for (uint32_t k = 0; k < ex->n_render_masks && !ray_intersects_any_mask; ++k) {
+			const float ro[3] = {ray.o.x, ray.o.y, ray.o.z}, rd[3] = {ray.d.x, ray.d.y, ray.d.z};
+			ray_intersects_any_mask = orc_mask_intersects_ray(&ex->render_masks[k], ro, rd);
+		}
+		if (!ray_intersects_any_mask) {
+			p->origin = ray.o;
+			p->alive = 0;
+			continue;
+		}
+		if (ex && ex->render_mode == 5) {   /* Distortion (:1959-1970) */
+			float off[2] = {0.0f, 0.0f};
+			if (distortion) {
+				const float uv[2] = {((float)x + 0.5f) / (float)res[0], ((float)y + 0.5f) / (float)res[1]};
+				orc_read_image2(distortion, ex->distortion_res, uv, off);
+			}
+			float* fb = ex->frame_buffer + 4 * (size_t)idx;
+			const float ox = off[0] * 50.0f, oy = off[1] * 50.0f;
+			orc_hsv_to_rgb(atan2f(oy, ox) / (2.0f * 3.14159265358979323846f) + 0.5f, 1.0f, sqrtf(ox * ox + oy * oy), fb);
+			fb[3] = 1.0f;
+			depthbuffer[idx] = 1.0f;
+			p->origin = orc_add(ray.o, orc_scale(ray.d, 10000.0f));
 			p->alive = 0;
 			continue;
 		}
@@ -215,6 +321,59 @@ void orc_composite_mode(uint32_t n_elements, uint32_t current_step, const orc_aa
                         float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output,
                         uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance,
                         int render_mode, float depth_scale, int show_accel) {
+	orc_composite_ex(n_elements, current_step, aabb, camera_matrix, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation,
+	                 min_transmittance, render_mode, depth_scale, show_accel, NULL);
+}
+
+/* glow / grid-line visualisation (testbed_nerf.cu:843-939; the "#if 0" block there is dead) */
+static void orc_glow_shading(int glow_mode, float glow_y_cutoff, orc_vec3 pos, orc_vec3 cam_pos, float rgb[3], float* weight) {
+	float glow = 0.f;
+	int green_grid = glow_mode & 1, green_cutline = glow_mode & 2, mask_to_alpha = glow_mode & 4, radial_mode = glow_mode & 8, grid_mode = glow_mode & 16;
+	float dist;
+	if (radial_mode) {
+		dist = orc_norm(orc_sub(pos, cam_pos));
+		dist = fminf(dist, (4.5f - pos.y) * 0.333f);
+	} else {
+		dist = pos.y;
+	}
+	if (grid_mode) {
+		glow = 1.f / fmaxf(1.f, dist);
+	} else {
+		float y = glow_y_cutoff - dist;
+		float mask = 0.f;
+		if (y > 0.f) {
+			y *= 80.f;
+			mask = fminf(1.f, y);
+			if (green_cutline) glow += fmaxf(0.f, 1.f - fabsf(1.f - y)) * 4.f;
+			if (y > 1.f) y = 1.f - (y - 1.f) * 0.05f;
+			if (green_grid) glow += fmaxf(0.f, y / fmaxf(1.f, dist));
+		}
+		if (mask_to_alpha) *weight *= mask;
+	}
+	if (glow > 0.f) {
+		float line = 0.0f;
+		for (int o = 0; o < 4; ++o) {
+			const float f = (float)(2 << o);
+			line += fmaxf(0.f, cosf(pos.y * f * 3.141592653589793f * 16.f) - 0.975f);
+			line += fmaxf(0.f, cosf(pos.x * f * 3.141592653589793f * 16.f) - 0.975f);
+			line += fmaxf(0.f, cosf(pos.z * f * 3.141592653589793f * 16.f) - 0.975f);
+		}
+		if (grid_mode) {
+			glow = glow * line * 15.f;
+			rgb[1] = glow; rgb[2] = glow * 0.5f; rgb[0] = glow * 0.25f;
+		} else {
+			glow = glow * glow * 0.25f + glow * line * 15.f;
+			rgb[1] += glow; rgb[2] += glow * 0.5f; rgb[0] += glow * 0.25f;
+		}
+	}
+}
+
+/* composite_kernel_nerf in full (testbed_nerf.cu:767-989): crop masks, glow, every render mode.  Normals 2: network_input.pos holds
+ * d(density output)/d(pos) (input_gradient wrote it there, :2225-2226); EncodingVis 8: it holds the visualised activation (:2227-2228). */
+void orc_composite_ex(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix /* 3x4 */,
+                      float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output,
+                      uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance,
+                      int render_mode, float depth_scale, int show_accel, const orc_render_extras* ex) {
 	orc_vec3 cam_fwd = orc_col(camera_matrix, 2);
 	orc_vec3 cam_pos = orc_col(camera_matrix, 3);
 	for (uint32_t i = 0; i < n_elements; ++i) {
@@ -231,10 +390,24 @@ void orc_composite_mode(uint32_t n_elements, uint32_t current_step, const orc_aa
 			float T = 1.f - local_rgba[3];
 			float dt = orc_unwarp_dt(in->dt);
 			float alpha = 1.f - expf(-orc_network_to_density(orc_h2f(lo[3]), density_activation) * dt);
+			if (show_accel >= 0) alpha = 1.f;   /* :827-829 */
 			float weight = alpha * T;
 			float rgb[3];
 			for (int c = 0; c < 3; ++c) rgb[c] = orc_network_to_rgb(orc_h2f(lo[c]), rgb_activation);
-			if (render_mode == 3) {            /* Positions */
+			if (ex && ex->n_render_masks) {   /* :833-840 */
+				float mask_weight = 1.f;
+				const float p3[3] = {pos.x, pos.y, pos.z};
+				for (uint32_t k = 0; k < ex->n_render_masks; ++k) mask_weight = orc_clampf(mask_weight + orc_mask_sample(&ex->render_masks[k], p3), 0.0f, 1.0f);
+				weight *= mask_weight;
+			}
+			if (ex && ex->glow_mode) orc_glow_shading(ex->glow_mode, ex->glow_y_cutoff, pos, cam_pos, rgb, &weight);
+			if (render_mode == 2) {            /* Normals (:941-946) */
+				float k = -orc_network_to_density_derivative(orc_h2f(lo[3]), density_activation);
+				orc_vec3 nrm = orc_normalized(orc_v3(k * in->pos[0], k * in->pos[1], k * in->pos[2]));
+				rgb[0] = nrm.x; rgb[1] = nrm.y; rgb[2] = nrm.z;
+			} else if (render_mode == 8) {     /* EncodingVis (:961-962) */
+				rgb[0] = in->pos[0]; rgb[1] = in->pos[1]; rgb[2] = in->pos[2];
+			} else if (render_mode == 3) {     /* Positions */
 				if (show_accel >= 0) {
 					int mp = orc_mip_from_pos(pos, 7);
 					uint32_t mip = (uint32_t)(show_accel > mp ? show_accel : mp);
@@ -283,11 +456,35 @@ void orc_shade_mode(uint32_t n_elements, const float* rgba, const float* depth, 
                     float* frame_buffer, float* depth_buffer, int render_mode) {
 	for (uint32_t i = 0; i < n_elements; ++i) {
 		float tmp[4]; memcpy(tmp, rgba + 4 * i, 16);
-		if (render_mode == 6) { float col = (float)payloads[i].n_steps / 128; tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f; }
+		if (render_mode == 2) {   /* Normals (:1764-1767) */
+			orc_vec3 n = orc_normalized(orc_v3(tmp[0], tmp[1], tmp[2]));
+			tmp[0] = (0.5f * n.x + 0.5f) * tmp[3]; tmp[1] = (0.5f * n.y + 0.5f) * tmp[3]; tmp[2] = (0.5f * n.z + 0.5f) * tmp[3];
+		} else if (render_mode == 6) { float col = (float)payloads[i].n_steps / 128; tmp[0] = tmp[1] = tmp[2] = col; tmp[3] = 1.0f; }
 		if (!train_in_linear_colors && (render_mode == 1 || render_mode == 7)) for (int c = 0; c < 3; ++c) tmp[c] = orc_srgb_to_linear(tmp[c]);
 		float* fb = frame_buffer + 4 * (size_t)payloads[i].idx;
 		for (int c = 0; c < 4; ++c) fb[c] = tmp[c] + fb[c] * (1.0f - tmp[3]);
 		if (render_mode != 7 && tmp[3] > 0.2f) depth_buffer[payloads[i].idx] = depth[i];
+	}
+}
+
+/* Slice mode (testbed_nerf.cu:2445-2476): generate_nerf_network_inputs_at_current_position (:676-682), compute_nerf_rgba (:684-703) */
+void orc_generate_inputs_at_current_position(uint32_t n_elements, const orc_aabb* aabb, const orc_payload* payloads, orc_coord* network_input) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		orc_vec3 dir = payloads[i].dir;
+		orc_vec3 wp = orc_aabb_relative_pos(aabb, orc_add(payloads[i].origin, orc_scale(dir, payloads[i].t))), wd = orc_warp_direction(dir);
+		orc_coord* c = &network_input[i];
+		c->pos[0] = wp.x; c->pos[1] = wp.y; c->pos[2] = wp.z; c->dt = orc_warp_dt(ORC_MIN_CONE_STEPSIZE); c->dir[0] = wd.x; c->dir[1] = wd.y; c->dir[2] = wd.z;
+	}
+}
+void orc_compute_nerf_rgba(uint32_t n_elements, const uint16_t* network_output, uint32_t out_stride, float* rgba, int rgb_activation, int density_activation, float depth, int density_as_alpha) {
+	for (uint32_t i = 0; i < n_elements; ++i) {
+		const uint16_t* lo = network_output + (size_t)i * out_stride;
+		float density = orc_network_to_density(orc_h2f(lo[3]), density_activation);
+		float alpha = 1.f, w;
+		if (density_as_alpha) w = density;
+		else w = alpha = orc_clampf(1.f - expf(-density * depth), 0.0f, 1.0f);
+		for (int c = 0; c < 3; ++c) rgba[4 * (size_t)i + c] = orc_network_to_rgb(orc_h2f(lo[c]), rgb_activation) * alpha;
+		rgba[4 * (size_t)i + 3] = w;
 	}
 }
 

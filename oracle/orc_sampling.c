@@ -205,7 +205,7 @@ void orc_update_bitfield(const float* grid, uint32_t n_cascades_used, float mean
 /* ------------------------------------------------------------------ */
 
 /* common_device.cuh:80-111 read_image<2,float> */
-static void orc_read_image2(const float* data, const int32_t res[2], const float pos[2], float out[2]) {
+void orc_read_image2(const float* data, const int32_t res[2], const float pos[2], float out[2]) {
 	float pfx = pos[0] * (float)(res[0] - 1), pfy = pos[1] * (float)(res[1] - 1);
 	int tx = (int)pfx, ty = (int)pfy;
 	float wx = pfx - (float)tx, wy = pfy - (float)ty;

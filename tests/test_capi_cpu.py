@@ -30,14 +30,14 @@ def test_no_torch_or_oracle_in_the_abi(ngp):
 
 
 def test_pod_layouts_match_the_header():
-    src = '#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(NgpAabb), sizeof(NgpRay), sizeof(NgpXForm), sizeof(NgpCoord), sizeof(NgpPayload), sizeof(NgpImageMeta), sizeof(NgpNetDesc), sizeof(NgpErrorMapCdf), sizeof(NgpGlobalRay), sizeof(NgpProxyRay), sizeof(NgpMask3D), sizeof(NgpNerfProps), sizeof(NgpDownsampleInfo), sizeof(NgpRenderCamera));}' % os.path.join(ROOT, "include", "ngp_hip.h")
+    src = '#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(NgpAabb), sizeof(NgpRay), sizeof(NgpXForm), sizeof(NgpCoord), sizeof(NgpPayload), sizeof(NgpImageMeta), sizeof(NgpNetDesc), sizeof(NgpErrorMapCdf), sizeof(NgpGlobalRay), sizeof(NgpProxyRay), sizeof(NgpMask3D), sizeof(NgpNerfProps), sizeof(NgpDownsampleInfo), sizeof(NgpRenderCamera), sizeof(NgpRenderExtras), sizeof(NgpLossExtras));}' % os.path.join(ROOT, "include", "ngp_hip.h")
     exe = "/tmp/ngp_sizes_%d" % os.getpid()
     subprocess.run(["gcc", "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
     sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     os.remove(exe)
     assert sizes == [capi.AABB.itemsize, capi.RAY.itemsize, capi.XFORM.itemsize, capi.COORD.itemsize, capi.PAYLOAD.itemsize, capi.IMAGE_META.itemsize, capi.NET_DESC.itemsize,
                      capi.ERROR_MAP_CDF.itemsize, capi.GLOBAL_RAY.itemsize, capi.PROXY_RAY.itemsize, capi.MASK3D.itemsize, capi.NERF_PROPS.itemsize, capi.DOWNSAMPLE_INFO.itemsize,
-                     capi.RENDER_CAMERA.itemsize]
+                     capi.RENDER_CAMERA.itemsize, capi.RENDER_EXTRAS.itemsize, capi.LOSS_EXTRAS.itemsize]
 
 
 def test_host_only_entry_points(ngp):

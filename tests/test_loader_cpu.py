@@ -256,10 +256,25 @@ def test_loader_jpeg_exr_alpha_depth_and_ray_files(pyngp, tmp_path):
     open(p, "w").write(json.dumps(base))
     out = pyngp.load_nerf_host(p)
     assert out["depth16"][0] is None and out["rays"][0] is None and not out["has_rays"]
+    # `envmap` key (nerf_loader.cu:533-546): an 8-bit file goes through from_rgba32<float> (sRGB decode, premultiplied by alpha), an .exr is taken as it is
+    assert out["envmap"] is None and out["envmap_resolution"] == [0, 0]
     base["envmap"] = "env.png"
     open(p, "w").write(json.dumps(base))
-    with pytest.raises(RuntimeError, match="envmap"):
+    with pytest.raises(RuntimeError, match="Environment map .* does not exist"):
         pyngp.load_nerf_host(p)
+    rs = np.random.RandomState(4)
+    env8 = rs.randint(0, 256, (6, 12, 4)).astype(np.uint8)
+    Image.fromarray(env8, "RGBA").save(os.path.join(d, "env.png"))
+    out = pyngp.load_nerf_host(p)
+    assert out["envmap_resolution"] == [12, 6] and out["envmap"].shape == (6, 12, 4)
+    c = env8[..., :3].astype(np.float32) * np.float32(1 / 255.0)
+    a = env8[..., 3:4].astype(np.float32) * np.float32(1 / 255.0)
+    lin = np.where(c <= 0.04045, c / np.float32(12.92), ((c + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4)).astype(np.float32)
+    np.testing.assert_allclose(out["envmap"], np.concatenate([lin * a, a], -1), rtol=2e-6, atol=1e-7)
+    base["envmap"] = "im/b.exr"
+    open(p, "w").write(json.dumps(base))
+    out = pyngp.load_nerf_host(p)
+    np.testing.assert_array_equal(out["envmap"], pyngp.decode_exr(os.path.join(d, "im", "b.exr")))
 
 
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_imageio.so")

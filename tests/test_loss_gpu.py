@@ -7,6 +7,7 @@ exact count comparison (reported, must be rare); everything else must match exac
 import numpy as np
 import pytest
 
+import capi
 import helpers as H
 from capi import check
 from test_sampling_gpu import _cameras
@@ -47,11 +48,18 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     # ---- oracle
     o = dict(cnt=np.zeros(1, np.uint32), ns=I["r"]["ns"].copy(), co=np.zeros(B, H.COORD), dl=np.zeros((B, 4), np.float16), loss=np.zeros(n_rays, np.float32),
              em=np.zeros(n_img * 16 * 12, np.float32), enc=np.zeros((B, 32), np.uint16), expg=np.zeros((n_img, 3), np.float32))
-    oracle.orc_compute_loss(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
+    env = I.get("envmap")      # dict(data fp32 [h][w][4], res (w, h), loss_type, train): the *_ex entry points (environment map in front of the background)
+    o_loss_fn, o_tail = oracle.orc_compute_loss, ()
+    if env is not None:
+        o["envg"] = np.zeros_like(env["data"])
+        ex_o = np.zeros(1, capi.LOSS_EXTRAS)
+        ex_o["envmap_data"], ex_o["envmap_gradient"], ex_o["envmap_res"][0], ex_o["envmap_loss_type"] = env["data"].ctypes.data, o["envg"].ctypes.data if env["train"] else 0, env["res"], env["loss_type"]
+        o_loss_fn, o_tail = oracle.orc_compute_loss_ex, (ex_o.ctypes.data,)
+    o_loss_fn(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
                             I["r"]["co"].ctypes.data, o["co"].ctypes.data, o["dl"].ctypes.data, loss_type, o["loss"].ctypes.data, 0, None, rgb_act, 3, 0,
                             o["em"].ctypes.data, em_res.ctypes.data, H.f32(I["mean"]), exposure.ctypes.data, H.f32(0.2), I["c_host"].ctypes.data if I.get("cdf_mode") else None,
-                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), o["expg"].ctypes.data if I.get("exposure_grad") else None)
+                            I["enc"].ctypes.data if "enc" in I else None, o["enc"].ctypes.data if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), o["expg"].ctypes.data if I.get("exposure_grad") else None, *o_tail)
     # ---- device
     d = dict(cnt=H.dev_zeros(4, cuda), ns=H.to_dev(I["r"]["ns"], cuda), co=H.dev_zeros(B * 28, cuda), dl=H.dev_zeros(B * 8, cuda), loss=H.dev_zeros(n_rays * 4, cuda),
              em=H.dev_zeros(n_img * 16 * 12 * 4, cuda), enc=H.dev_zeros(B * 64, cuda), expg=H.dev_zeros(n_img * 12, cuda))
@@ -64,13 +72,21 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
         m, C = I["cdf_mode"], I["C"]
         d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
         c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if m & 1 else 0, d_cy.data_ptr() if m & 1 else 0, d_ci.data_ptr() if m & 2 else 0, C["res"])
-    check(ngp.ngp_hip_compute_loss(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
+    d_loss_fn, d_tail = ngp.ngp_hip_compute_loss, ()
+    if env is not None:
+        d_env, d["envg"] = H.to_dev(env["data"], cuda), H.dev_zeros(env["data"].nbytes, cuda)
+        ex_d = np.zeros(1, capi.LOSS_EXTRAS)
+        ex_d["envmap_data"], ex_d["envmap_gradient"], ex_d["envmap_res"][0], ex_d["envmap_loss_type"] = d_env.data_ptr(), d["envg"].data_ptr() if env["train"] else 0, env["res"], env["loss_type"]
+        d_loss_fn, d_tail = ngp.ngp_hip_compute_loss_ex, (ex_d.ctypes.data,)
+    check(d_loss_fn(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
                                    d_mean.data_ptr(), d_exp.data_ptr(), H.f32(0.2), c_dev.ctypes.data if c_dev is not None else None,
-                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), d["expg"].data_ptr() if I.get("exposure_grad") else None))
+                                   d_enc_in.data_ptr() if "enc" in I else None, d["enc"].data_ptr() if "enc" in I else None, H.f32(I.get("depth_lambda", 0.0)), I.get("depth_loss", 2), d["expg"].data_ptr() if I.get("exposure_grad") else None, *d_tail))
     g = dict(cnt=H.to_host(d["cnt"], np.uint32), ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD), dl=H.to_host(d["dl"], np.float16).reshape(B, 4),
              loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"], expg=H.to_host(d["expg"], np.float32).reshape(n_img, 3))
+    if env is not None:
+        g["envg"] = H.to_host(d["envg"], np.float32).reshape(env["data"].shape)
     return o, g
 
 
@@ -372,3 +388,92 @@ def test_cam_gradient_matches_oracle(ngp, oracle, cuda, cdf_mode):
     check(ngp.ngp_hip_compute_cam_gradient(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, d_pos2.data_ptr(), None, n_img, d_md.data_ptr(), d_idx.data_ptr(),
                                            d_rays.data_ptr(), d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), c_dev.ctypes.data if c_dev is not None else None))
     np.testing.assert_allclose(H.to_host(d_pos2, np.float32).reshape(n_img, 3), ref_pos, rtol=0, atol=2e-4 * np.abs(ref_pos).max())
+
+
+@pytest.mark.parametrize("linear,env_loss", [(0, 6), (1, 4)])
+def test_loss_with_environment_map(ngp, oracle, cuda, linear, env_loss):
+    """compute_loss_kernel_train_nerf with envmap_data / envmap_gradient (:1289-1292, 1394-1401, 1573-1596): the map in front of the background colour changes
+    the targets' background term and the ray colours; rays whose every sample is kept deposit their background gradient (fp16 value x fp16 bilinear weight,
+    fp32 sums).  The envmap loss (RelativeL2 in base.json:77-79) may differ from the NeRF loss (Huber)."""
+    rs = np.random.RandomState(21)
+    env = dict(data=(rs.rand(8, 16, 4) * np.array([1, 1, 1, 0.8])).astype(np.float32), res=(16, 8), loss_type=env_loss, train=True)
+    I = _inputs(oracle, cuda, n_rays=4096, seed=8, sigma_gain=1.0)
+    I["mlp"][:, 3] -= np.float16(4.0)                     # thin density: most rays keep every sample and see the background
+    B = 1 << 18
+    plain_o, _ = _run(ngp, oracle, cuda, I, 4, B, linear=linear)
+    I["envmap"] = env
+    o, g = _run(ngp, oracle, cuda, I, 4, B, linear=linear)
+    n_alive = I["n_alive"]
+    assert np.abs(o["loss"] - plain_o["loss"]).max() > 1e-7  # the map matters
+    bad = _borderline_rays(I)
+    ok = np.array([i not in bad for i in range(n_alive)])
+    np.testing.assert_array_equal(g["ns"][0::2][:n_alive][ok], o["ns"][0::2][:n_alive][ok])
+    np.testing.assert_allclose(g["loss"][:n_alive][ok], o["loss"][:n_alive][ok], rtol=4e-3, atol=1e-9)
+    ref, got = o["envg"], g["envg"]
+    assert np.abs(ref[..., :3]).max() > 0 and np.abs(ref[..., 3]).max() == 0 and np.abs(got[..., 3]).max() == 0     # alpha gets no gradient (:1592-1593)
+    assert np.linalg.norm(got - ref) < 1e-2 * np.linalg.norm(ref)
+    # without train_envmap the map is still composited, and nothing is deposited
+    I["envmap"] = dict(env, train=False)
+    o2, g2 = _run(ngp, oracle, cuda, I, 4, B, linear=linear)
+    np.testing.assert_array_equal(o2["loss"], o["loss"])
+    assert np.abs(g2["envg"]).max() == 0
+
+
+def test_cam_gradient_distortion_branch(ngp, oracle, cuda):
+    """compute_cam_gradient_train_nerf's distortion outputs (:1671-1685): image-plane gradient splatted into the distortion map, weights beside it; safe_divide."""
+    I = _inputs(oracle, cuda, n_rays=2048, seed=5)
+    B = 1 << 15
+    o, _ = _run(ngp, oracle, cuda, I, 4, B)
+    n_rays, n_alive, n_img = I["n_rays"], I["n_alive"], len(I["xf"])
+    rs = np.random.RandomState(9)
+    cg = (rs.randn(B, 6) * 0.1).astype(np.float32)
+    dres = np.array([12, 10], np.int32)
+    ref_g, ref_w = np.zeros((10, 12, 2), np.float32), np.zeros((10, 12, 2), np.float32)
+    oracle.orc_compute_cam_gradient_ex(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], n_alive, 0, None, None, n_img, I["md_host"].ctypes.data, I["r"]["idx"].ctypes.data,
+                                       I["r"]["rays"].ctypes.data, o["ns"].ctypes.data, o["co"].ctypes.data, cg.ctypes.data, None, I["xf"].ctypes.data, ref_g.ctypes.data, ref_w.ctypes.data,
+                                       dres.ctypes.data)
+    d_g, d_w = H.dev_zeros(ref_g.nbytes, cuda), H.dev_zeros(ref_w.nbytes, cuda)
+    d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
+    d_md, d_idx, d_rays, d_ns, d_co, d_cg, d_xf = (H.to_dev(a, cuda) for a in (I["md_dev"], I["r"]["idx"], I["r"]["rays"], o["ns"], o["co"], cg, I["xf"]))
+    check(ngp.ngp_hip_compute_cam_gradient_ex(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
+                                              d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), None, d_xf.data_ptr(), d_g.data_ptr(), d_w.data_ptr(), dres.ctypes.data))
+    got_g, got_w = H.to_host(d_g, np.float32).reshape(ref_g.shape), H.to_host(d_w, np.float32).reshape(ref_w.shape)
+    assert ref_w.min() >= 0 and ref_w.sum() > 100 and np.abs(ref_g).max() > 0
+    np.testing.assert_allclose(got_w, ref_w, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got_g, ref_g, rtol=0, atol=3e-4 * np.abs(ref_g).max())
+    # safe_divide: gradient / weight where the weight is positive, else 0
+    ref_div = ref_g.copy().reshape(-1)
+    ref_w_flat = ref_w.reshape(-1).copy(); ref_w_flat[::7] = 0.0
+    oracle.orc_safe_divide(ref_div.size, ref_div.ctypes.data, ref_w_flat.ctypes.data)
+    d_div, d_wz = H.to_dev(ref_g.reshape(-1), cuda), H.to_dev(ref_w_flat, cuda)
+    check(ngp.ngp_hip_safe_divide(None, ref_div.size, d_div.data_ptr(), d_wz.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_div, np.float32), ref_div)
+    assert (ref_div[::7] == 0).all()
+    # the distortion outputs need the transforms and the weight buffer
+    assert ngp.ngp_hip_compute_cam_gradient_ex(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
+                                               d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), None, None, d_g.data_ptr(), d_w.data_ptr(), dres.ctypes.data) != 0
+
+
+@pytest.mark.parametrize("use_ema", [0, 1])
+def test_trainable_buffer_optimizer_step(ngp, oracle, cuda, use_ema):
+    """[tcnn] Adam (+ Ema) over an all-fp32 TrainableBuffer: zero-gradient entries are skipped, the rest follow Adam's update rule; three steps in a row."""
+    rs = np.random.RandomState(3)
+    n = 5000
+    p, m1, m2, ema = rs.randn(n).astype(np.float32) * 0.1, np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    d_p, d_m1, d_m2, d_ema = (H.to_dev(a, cuda) for a in (p, m1, m2, ema))
+    for step in (1, 2, 3):
+        g = (rs.randn(n) * 50.0).astype(np.float32)
+        g[rs.rand(n) < 0.3] = 0.0
+        before = p.copy()
+        oracle.orc_optimizer_step_f32(n, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), g.ctypes.data, p.ctypes.data, m1.ctypes.data, m2.ctypes.data,
+                                      ema.ctypes.data if use_ema else None)
+        check(ngp.ngp_hip_optimizer_step_f32(None, n, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), H.to_dev(g, cuda).data_ptr(), d_p.data_ptr(),
+                                             d_m1.data_ptr(), d_m2.data_ptr(), d_ema.data_ptr() if use_ema else None))
+        assert (p[g == 0] == before[g == 0]).all() and (p[g != 0] != before[g != 0]).all()
+        np.testing.assert_allclose(H.to_host(d_p, np.float32), p, rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(H.to_host(d_m2, np.float32), m2, rtol=2e-6, atol=1e-12)
+        if use_ema:
+            np.testing.assert_allclose(H.to_host(d_ema, np.float32), ema, rtol=4e-6, atol=1e-8)
+    if use_ema:
+        assert np.abs(ema - p).max() > 0 and np.abs(ema - p).max() < 0.2
+    assert ngp.ngp_hip_optimizer_step_f32(None, n, 0, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), d_p.data_ptr(), d_p.data_ptr(), d_m1.data_ptr(), d_m2.data_ptr(), None) != 0

@@ -267,3 +267,101 @@ def test_exact_grid_backward_is_the_rounded_rational_sum(oracle, ngp):
         ref[k] = np.float16(float(v))        # sums of < 2^12 terms of 41-bit fixed point fit a double exactly; numpy rounds to nearest even
     np.testing.assert_array_equal(got, ref.view(np.uint16))
     assert (got != 0).sum() > 10000
+
+
+# ---- the rest of the stock renderer (row f3): oracle-side properties that follow from the reference's code ----
+def _f3_extras(**kw):
+    import capi
+    e = np.zeros(1, capi.RENDER_EXTRAS)
+    e["quilting_dims"][0] = (1, 1)
+    e["render_mode"] = 1
+    for k, v in kw.items():
+        e[k][0] = v
+    return e
+
+
+def _f3_init(oracle, ex, res=(48, 32), parallax=(0.0, 0.0, 0.0)):
+    cam = H.look_at_xform([1.6, 1.3, 1.1])
+    focal, r, sc = np.array([40.0, 40.0], np.float32), np.array(res, np.int32), np.array([0.5, 0.5], np.float32)
+    aabb, ident = H.unit_aabb(1), np.eye(3, dtype=np.float32).reshape(-1)
+    n = res[0] * res[1]
+    pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
+    oracle.orc_init_rays_ex(1, pay.ctypes.data, r.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, np.zeros(4, np.float32).ctypes.data, sc.ctypes.data,
+                            np.array(parallax, np.float32).ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None,
+                            ex.ctypes.data if ex is not None else None)
+    return pay, depth
+
+
+def test_init_rays_ex_reduces_to_init_rays_and_honours_masks_and_quilting(oracle):
+    import capi
+    plain, _ = _f3_init(oracle, None)
+    same, _ = _f3_init(oracle, _f3_extras())
+    assert plain.tobytes() == same.tobytes()
+    m = np.zeros(1, capi.MASK3D)               # an Add sphere of radius 0.2 at the scene centre
+    m["mode"], m["shape"], m["opacity"] = 0, 2, 1.0
+    t = np.eye(4, dtype=np.float32); t[:3, 3] = 0.5
+    m["transform"][0] = t.T.reshape(-1); m["itransform"][0] = np.linalg.inv(t).T.reshape(-1)
+    m["config"][0][0] = 0.2
+    masked, _ = _f3_init(oracle, _f3_extras(render_masks=m.ctypes.data, n_render_masks=1))
+    assert 0 < masked["alive"].sum() < 0.5 * plain["alive"].sum()
+    # rays that survive point at the sphere: distance of the centre from the ray below radius (+ nothing for feather 0)
+    al = masked["alive"] == 1
+    oc = 0.5 - masked["origin"][al]
+    dist = np.linalg.norm(np.cross(oc, masked["dir"][al]), axis=1)
+    assert dist.max() <= 0.2 + 1e-5
+    m["mode"] = 1                               # Subtract masks never kill a ray (mask_3D.cuh: infinite additive area around them)
+    sub, _ = _f3_init(oracle, _f3_extras(render_masks=m.ctypes.data, n_render_masks=1))
+    assert sub.tobytes() == plain.tobytes()
+    # quilting (2, 1): two panels, each the half-width view, eyes +- IPD / 2 apart along the camera's x axis
+    q, _ = _f3_init(oracle, _f3_extras(quilting_dims=(2, 1)), parallax=(0.08, 0.0, 0.0))
+    o = q["origin"].reshape(32, 48, 3)
+    left, right = o[:, :24], o[:, 24:]
+    d = left[0, 0] - right[0, 0]
+    assert abs(np.linalg.norm(d) - 0.08) < 1e-6 and np.allclose(left - right, d, atol=1e-6)
+
+
+def test_envmap_lookup_and_distortion_mode(oracle):
+    rs = np.random.RandomState(0)
+    const = np.tile(np.array([0.1, 0.2, 0.3, 0.4], np.float32), (8, 16, 1))
+    out = np.zeros(4, np.float32)
+    for d in rs.randn(20, 3).astype(np.float32):
+        d /= np.linalg.norm(d)
+        oracle.orc_read_envmap(const.ctypes.data, np.array([16, 8], np.int32).ctypes.data, d.ctypes.data, out.ctypes.data)
+        np.testing.assert_allclose(out, [0.1, 0.2, 0.3, 0.4], rtol=1e-6)
+    # rows = polar angle from +y (envmap.cuh:31 feeds {z, -x, y} to dir_to_spherical_unorm): straight up reads row 0, straight down the last row
+    ramp = np.zeros((8, 16, 4), np.float32); ramp[..., 0] = np.arange(8, dtype=np.float32)[:, None]
+    oracle.orc_read_envmap(ramp.ctypes.data, np.array([16, 8], np.int32).ctypes.data, np.array([0, 1, 0], np.float32).ctypes.data, out.ctypes.data)
+    assert out[0] == 0.0
+    oracle.orc_read_envmap(ramp.ctypes.data, np.array([16, 8], np.int32).ctypes.data, np.array([0, -1, 0], np.float32).ctypes.data, out.ctypes.data)
+    assert out[0] == 7.0
+    # Distortion mode: a constant offset along +x paints hue 0.5 (atan2(0, x) / 2 pi + 0.5), value |offset| * 50; every ray is done
+    dist = np.zeros((4, 4, 2), np.float32); dist[..., 0] = 0.01
+    fb = np.zeros((48 * 32, 4), np.float32)
+    pay, depth = _f3_init(oracle, _f3_extras(distortion=dist.ctypes.data, distortion_res=(4, 4), render_mode=5, frame_buffer=fb.ctypes.data))
+    assert pay["alive"].sum() == 0
+    hit = depth == 1.0
+    assert hit.sum() > 100
+    np.testing.assert_allclose(fb[hit], np.tile([0.0, 0.5, 0.5, 1.0], (hit.sum(), 1)), atol=1e-5)   # hsv (0.5, 1, 0.5) = cyan at half value
+
+
+def test_visualize_activation_layers_are_the_forward_pass(oracle, ngp):
+    n = 64
+    desc = H.make_desc(ngp, log2_hashmap_size=15)   # host-only entry point of the C ABI: runs without a GPU
+    params = H.random_params(desc, seed=2)
+    coords = H.random_coords(n, seed=3)
+    flat = coords.view(np.float32).reshape(n, 7)
+    out4 = np.zeros((n, 4), np.uint16)
+    oracle.orc_nerf_inference(desc.ctypes.data, params.ctypes.data, flat.ctypes.data, 7, n, out4.ctypes.data, 4)
+    vis = np.zeros((n, 4), np.float32)
+    oracle.orc_nerf_visualize_activation(desc.ctypes.data, params.ctypes.data, 2, 0, flat.ctypes.data, 7, n, vis.ctypes.data, 4)
+    sigma = out4.view(np.float16)[:, 3].astype(np.float32)      # colour-network input 0 IS the density output (nerf_network.h:160, 130-136)
+    np.testing.assert_array_equal(vis[:, 1] - vis[:, 0], sigma)
+    assert (vis[:, 2] == 0).all() and (vis[:, 3] == 1).all()
+    sh = np.zeros(16, np.float32)
+    oracle.orc_sh4(flat[0, 4:7].copy().ctypes.data, sh.ctypes.data)
+    one = np.zeros((n, 1), np.float32)
+    oracle.orc_nerf_visualize_activation(desc.ctypes.data, params.ctypes.data, 2, 16 + 5, flat.ctypes.data, 7, n, one.ctypes.data, 1)
+    assert one[0, 0] == np.float16(sh[5])
+    for layer in (1, 3, 4):                                      # hidden layers are post-ReLU: no negative part
+        oracle.orc_nerf_visualize_activation(desc.ctypes.data, params.ctypes.data, layer, 7, flat.ctypes.data, 7, n, vis.ctypes.data, 4)
+        assert (vis[:, 0] == 0).all() and vis[:, 1].max() > 0

@@ -20,7 +20,6 @@ OUT_OF_SCOPE = {
         "groundtruth_mode", "brick_level", "brick_res", "generate_sdf_data_online", "surface_offset_scale"},
     "GUI / window (NGP_GUI builds only)": {"keyboard_event_callback", "is_key_pressed", "is_key_down", "is_alt_down", "is_ctrl_down", "is_shift_down", "is_super_down", "screenshot"},
     "dead binding in the reference (commented out, python_api.cu:822)": {"focal_lengths"},
-    "render_masks: a std::vector<Mask3D> the stock renderer never reads (the Blender path carries masks in RenderModifiers)": {"render_masks"},
 }
 
 
