@@ -561,7 +561,7 @@ int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, 
 int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
                            NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
                            int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
-	if (render_mode == 2 || render_mode == 8) { set_last_error("ngp_hip_composite_mode: Normals / EncodingVis go through ngp_hip_composite_ex", hipErrorInvalidValue); return -1; }
+	if (render_mode == 2 || render_mode == 8) { set_last_error("ngp_hip_composite_mode: render mode Normals / EncodingVis goes through ngp_hip_composite_ex (the tracer runs an extra network pass for them)", hipErrorInvalidValue); return -1; }
 	return ngp_hip_composite_ex(stream, n_elements, current_step, aabb_host, camera_matrix_host, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation,
 	                            density_activation, min_transmittance, render_mode, depth_scale, show_accel, nullptr);
 }

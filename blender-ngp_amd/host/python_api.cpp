@@ -699,6 +699,14 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("render_mode", &Testbed::m_render_mode)   // python_api.cu:660: every ERenderMode of the stock tracer is built
 		.def_property("render_masks", [](Testbed& t) { std::vector<Mask3D> v; for (const NgpMask3D& p : t.m_render_masks) { Mask3D m; m.pod = p; v.push_back(m); } return v; },   // python_api.cu:694
 			[](Testbed& t, const std::vector<Mask3D>& v) { t.m_render_masks.clear(); for (const Mask3D& m : v) t.m_render_masks.push_back(m.pod); })
+		// extensions (no counterpart in the reference's module): the two trainable 2-D buffers as arrays, so that scripts and tests can inspect / seed them
+		.def("get_envmap", [](Testbed& t) { t.sync(); py::array_t<float> a({(size_t)t.m_envmap.resolution[1], (size_t)t.m_envmap.resolution[0], (size_t)4});
+				if (t.m_envmap.n_params()) t.m_envmap.params.copy_to_host(a.mutable_data(), t.m_envmap.n_params() * 4); return a; })
+		.def("get_distortion_map", [](Testbed& t) { t.sync(); py::array_t<float> a({(size_t)t.m_distortion.resolution[1], (size_t)t.m_distortion.resolution[0], (size_t)2});
+				if (t.m_distortion.n_params()) t.m_distortion.params.copy_to_host(a.mutable_data(), t.m_distortion.n_params() * 4); return a; })
+		.def("set_distortion_map", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+				if ((size_t)a.size() != t.m_distortion.n_params()) throw std::runtime_error{"set_distortion_map: expected resolution[1] x resolution[0] x 2 floats"};
+				t.sync(); t.m_distortion.set_params(a.data(), (size_t)a.size()); t.invalidate_training_inputs(); }, py::arg("map"))
 		.def_property("quilting_dims", [](Testbed& t) { return std::vector<int>{t.m_quilting_dims[0], t.m_quilting_dims[1]}; },   // testbed.h:549 (GUI-only in the reference)
 			[](Testbed& t, const std::vector<int>& v) { if (v.size() != 2 || v[0] < 1 || v[1] < 1) throw std::runtime_error{"quilting_dims: two positive integers"}; t.m_quilting_dims[0] = v[0]; t.m_quilting_dims[1] = v[1]; })
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view, py::arg("trainview"))

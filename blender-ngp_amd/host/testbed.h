@@ -410,6 +410,8 @@ public:
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
 	ERenderMode m_render_mode = ERenderMode::Shade;    // every ERenderMode of the stock tracer (ngp_hip_composite_ex / ngp_hip_init_rays_ex / the Slice kernels)
+	TrainableBuffer m_envmap;       // testbed.h:936-944: resolution of the dataset's `envmap` image ((0, 0): none)
+	TrainableBuffer m_distortion;   // testbed.h:946-952: 32 x 32 x 2 zeros unless trained; passed unconditionally to the ray generator (SURVEY App. A.4)
 	std::vector<NgpMask3D> m_render_masks;             // python_api.cu:694: crop masks of the STOCK renderer (testbed_nerf.cu:2339-2352, 833-840, 1943-1956)
 	uint32_t m_n_render_masks = 0;
 	void prepare_nerf_masks();                         // testbed_nerf.cu:2339-2352
@@ -506,8 +508,6 @@ private:
 	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
-	TrainableBuffer m_envmap;       // testbed.h:936-944: resolution of the dataset's `envmap` image ((0, 0): none)
-	TrainableBuffer m_distortion;   // testbed.h:946-952: 32 x 32 x 2 zeros unless trained; passed unconditionally to the ray generator (SURVEY App. A.4)
 	DeviceBuffer m_loss_scalar_gpu;
 	// tracer scratch (NerfTracer::enlarge 2270-2295)
 	std::vector<void*> m_render_streams;

@@ -106,7 +106,7 @@ def test_focal_length_switch_trains_nothing_and_unsupported_switches_fail_loudly
     scene.train(a, 20); scene.train(b, 20)
     # (two runs of the same configuration drift apart themselves: the hash-grid gradients are summed with fp16 atomics and Adam's first steps are sign-like)
     assert abs(a.loss - b.loss) < 0.1 * a.loss and a.training_step == b.training_step == 20
-    for name in ("optimize_distortion", "optimize_extra_dims"):
+    for name in ("optimize_extra_dims",):
         c = scene.build_testbed(ds)
         setattr(c.nerf.training, name, True)
         with pytest.raises(RuntimeError, match="not part of this build"):

@@ -467,7 +467,8 @@ def test_trainable_buffer_optimizer_step(ngp, oracle, cuda, use_ema):
         before = p.copy()
         oracle.orc_optimizer_step_f32(n, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), g.ctypes.data, p.ctypes.data, m1.ctypes.data, m2.ctypes.data,
                                       ema.ctypes.data if use_ema else None)
-        check(ngp.ngp_hip_optimizer_step_f32(None, n, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), H.to_dev(g, cuda).data_ptr(), d_p.data_ptr(),
+        d_g = H.to_dev(g, cuda)
+        check(ngp.ngp_hip_optimizer_step_f32(None, n, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), d_g.data_ptr(), d_p.data_ptr(),
                                              d_m1.data_ptr(), d_m2.data_ptr(), d_ema.data_ptr() if use_ema else None))
         assert (p[g == 0] == before[g == 0]).all() and (p[g != 0] != before[g != 0]).all()
         np.testing.assert_allclose(H.to_host(d_p, np.float32), p, rtol=2e-6, atol=1e-8)

@@ -189,9 +189,13 @@ def test_composite_crop_masks_and_glow(ngp, oracle, cuda):
     d_masks = H.to_dev(masks, cuda)
     masked, _ = _composite_both(ngp, oracle, cuda, S, out, 1, _extras(render_masks=masks.ctypes.data, n_render_masks=len(masks)), _extras(render_masks=d_masks.data_ptr(), n_render_masks=len(masks)))
     assert masked[:, 3].sum() < 0.9 * plain[:, 3].sum() and masked[:, 3].sum() > 0.05 * plain[:, 3].sum()
+    ys = S["coords"]["pos"][:, 1]
+    cutoff = float(np.median(ys[ys > 0])) + 0.05            # the glow band is the 0.26 below the cut-off: put the samples into it
     for glow_mode in (1, 2, 3, 4 | 1, 8 | 1, 16, 16 | 8):
-        glowing, _ = _composite_both(ngp, oracle, cuda, S, out, 1, _extras(glow_mode=glow_mode, glow_y_cutoff=0.6), _extras(glow_mode=glow_mode, glow_y_cutoff=0.6))
-        assert np.abs(glowing - plain).max() > 1e-2
+        if glow_mode & 8 and not glow_mode & 16:            # radial: the distance from the camera (about 1.5 here), capped at (4.5 - y) / 3
+            cutoff = 1.4
+        glowing, _ = _composite_both(ngp, oracle, cuda, S, out, 1, _extras(glow_mode=glow_mode, glow_y_cutoff=cutoff), _extras(glow_mode=glow_mode, glow_y_cutoff=cutoff))
+        assert np.abs(glowing - plain).max() > 1e-2, glow_mode
     # show_accel >= 0 makes every sample opaque (:827-829)
     opaque, p = _composite_both(ngp, oracle, cuda, S, out, 3, None, None, accel=0)
     assert (p["alive"] == 0).all() and np.allclose(opaque[:, 3], 1.0)
@@ -246,16 +250,17 @@ def test_input_gradient_and_normals_mode(ngp, oracle, cuda):
     out[:, 3] += np.float16(3.0)   # random weights give little density: make the rays terminate
     nrm, p_after = _composite_both(ngp, oracle, cuda, S, out, 2, None, None, coords=grad_coords)
     shade_out = _random_outputs(n, 1)
-    assert np.abs(np.linalg.norm(nrm[:, :3], axis=1)[nrm[:, 3] > 0.5]).max() <= 1.0 + 1e-3   # a weighted mean of unit vectors
+    assert nrm[:, 3].max() > 0.05 and (np.linalg.norm(nrm[:, :3], axis=1) <= nrm[:, 3] + 1e-4).all()   # a sum of unit vectors with weights that add up to alpha
     res = np.array([W, Hh], np.int32)
     fb_o, db_o = np.zeros((W * Hh, 4), np.float32), np.zeros(W * Hh, np.float32)
     dep = np.linspace(1, 2, na).astype(np.float32)
     oracle.orc_shade_mode(na, nrm.ctypes.data, dep.ctypes.data, p_after.ctypes.data, 0, fb_o.ctypes.data, db_o.ctypes.data, 2)
     d_fb, d_db = H.dev_zeros(W * Hh * 16, cuda), H.dev_zeros(W * Hh * 4, cuda)
-    check(ngp.ngp_hip_shade_mode(None, na, H.to_dev(nrm, cuda).data_ptr(), H.to_dev(dep, cuda).data_ptr(), H.to_dev(p_after, cuda).data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), 2))
+    d_nrm, d_dep, d_pa = H.to_dev(nrm, cuda), H.to_dev(dep, cuda), H.to_dev(p_after, cuda)
+    check(ngp.ngp_hip_shade_mode(None, na, d_nrm.data_ptr(), d_dep.data_ptr(), d_pa.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), 2))
     np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(-1, 4), fb_o, rtol=1e-4, atol=1e-6)
-    hit = fb_o[:, 3] > 0.5
-    assert hit.sum() > 50 and fb_o[hit][:, :3].min() >= -1e-6 and fb_o[hit][:, :3].max() <= 1.0 + 1e-6   # (0.5 n + 0.5) alpha
+    hit = fb_o[:, 3] > 0.05
+    assert hit.sum() > 50 and fb_o[hit][:, :3].min() >= -1e-6 and (fb_o[hit][:, :3] <= fb_o[hit][:, 3:4] + 1e-6).all()   # (0.5 n + 0.5) alpha
 
 
 @pytest.mark.parametrize("layer,dim", [(0, 5), (0, 31), (1, 17), (2, 0), (2, 3), (2, 16), (2, 29), (3, 40), (4, 63)])
@@ -298,12 +303,14 @@ def test_encoding_vis_composite_and_slice_kernels(ngp, oracle, cuda):
     o_in = np.zeros(len(pay), H.COORD)
     oracle.orc_generate_inputs_at_current_position(len(pay), S["aabb"].ctypes.data, pay.ctypes.data, o_in.ctypes.data)
     d_in = H.dev_zeros(len(pay) * 28, cuda)
-    check(ngp.ngp_hip_generate_inputs_at_current_position(None, len(pay), S["aabb"].ctypes.data, H.to_dev(pay, cuda).data_ptr(), d_in.data_ptr()))
+    d_pay = H.to_dev(pay, cuda)
+    check(ngp.ngp_hip_generate_inputs_at_current_position(None, len(pay), S["aabb"].ctypes.data, d_pay.data_ptr(), d_in.data_ptr()))
     assert H.to_host(d_in, H.COORD).tobytes() == o_in.tobytes()
     assert (o_in["dt"] == 0).all()
     for density_as_alpha in (0, 1):
         o_rgba = np.zeros((n, 4), np.float32)
         oracle.orc_compute_nerf_rgba(n, out.ctypes.data, 4, o_rgba.ctypes.data, 2, 3, H.f32(0.01), density_as_alpha)
         d_rgba = H.dev_zeros(n * 16, cuda)
-        check(ngp.ngp_hip_compute_nerf_rgba(None, n, H.to_dev(out, cuda).data_ptr(), 4, d_rgba.data_ptr(), 2, 3, H.f32(0.01), density_as_alpha))
+        d_out = H.to_dev(out, cuda)
+        check(ngp.ngp_hip_compute_nerf_rgba(None, n, d_out.data_ptr(), 4, d_rgba.data_ptr(), 2, 3, H.f32(0.01), density_as_alpha))
         np.testing.assert_allclose(H.to_host(d_rgba, np.float32).reshape(n, 4), o_rgba, rtol=2e-3, atol=1e-6)

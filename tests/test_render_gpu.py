@@ -406,7 +406,5 @@ def test_pyngp_render_modes(cuda):
     assert (cost[hit][:, 3] == 1.0).all() and cost[hit][:, 0].max() > 0
     t.render_mode = pyngp.RenderMode.AO
     assert np.isfinite(t.render(40, 30, 1, True)).all()
-    with pytest.raises(RuntimeError):
-        t.render_mode = pyngp.RenderMode.Normals
     t.render_mode = pyngp.RenderMode.Shade
     np.testing.assert_allclose(t.render(40, 30, 1, True), shade, atol=1e-6)
