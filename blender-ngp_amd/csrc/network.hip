@@ -32,6 +32,12 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NGP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// The backward chain runs beside the next step's march (stream B).  Its waves raise their issue priority (s_setprio: the SIMD's instruction
+// arbiter prefers the higher level) so that the march — default priority 0 — only takes the issue slots the chain leaves idle.
+#ifndef NGP_CHAIN_PRIO
+#define NGP_CHAIN_PRIO 3
+#endif
+#define NGP_RAISE_CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(NGP_CHAIN_PRIO)
 
 // parameter offsets (nerf_network.h:361-394: density MLP, rgb MLP, grid)
 constexpr uint32_t W1_OFF = 0;                    // [64][32]
@@ -355,6 +361,67 @@ __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const Ng
 				*(h4*)(out + (size_t)s * out_stride) = o;
 			}
 		}
+	}
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Training forward pass that walks RAYS: the reference evaluates the network on every marched sample and only then lets the loss kernel drop what lies
+// behind each ray's termination (transmittance < 1e-4, src/testbed_nerf.cu:1341-1374) — on a trained scene half of the samples.  Here one wave takes a
+// ray (dynamic queue) and walks it in tiles of 32 consecutive samples — the same per-sample arithmetic as nerf_forward_kernel<2>, so evaluated samples
+// are bit-identical — accumulating the ray's transmittance from the tile's density outputs, and stops behind the first tile that ends below
+// `stop_transmittance` (half the loss kernel's threshold: a factor-two margin over the rounding differences between the two evaluations, so every
+// sample the loss kernel keeps has been evaluated).  The outputs of the samples it skips are ZEROED (finite density and colour: the loss kernel's
+// first pass may read them but can never include them, and writes nothing from them); their saved encodings stay unwritten (never read).
+__global__ void __launch_bounds__(256, 2) nerf_forward_rays_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
+                                                                   const float* __restrict__ coords, uint32_t coord_stride, const uint32_t* __restrict__ numsteps /* [ray](count, base) */,
+                                                                   const uint32_t* __restrict__ rays_counter, uint32_t max_samples, half_t* __restrict__ out, uint32_t out_stride,
+                                                                   half_t* __restrict__ x_saved, int density_activation, float stop_transmittance, uint32_t* __restrict__ queue) {
+	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_FWD_TILES * 64];
+	stage_weights(lds_tiles, params, 0, N_FWD_TILES);
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	const uint32_t n_rays = *rays_counter;
+	typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+	while (true) {
+		uint32_t ray = 0;
+		if (lane == 0) ray = atomicAdd(queue, 1u);
+		ray = __builtin_amdgcn_readfirstlane(ray);
+		if (ray >= n_rays) break;
+		uint32_t n = numsteps[2 * ray], base = numsteps[2 * ray + 1];
+		n = __builtin_amdgcn_readfirstlane(n); base = __builtin_amdgcn_readfirstlane(base);
+		if (base >= max_samples) continue;
+		if (n > max_samples - base) n = max_samples - base;
+		float T = 1.0f;
+		uint32_t t0 = 0;
+		for (; t0 < n; t0 += 32) {
+			const bool valid = t0 + (uint32_t)j < n;
+			const uint32_t s = base + t0 + (valid ? (uint32_t)j : 0u);
+			const float* c = coords + (size_t)s * coord_stride;
+			h8 x0, x1;
+			encode_half(desc, grid, g, c[0], c[1], c[2], x0, x1);
+			if (valid) {
+				h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
+				dst[0] = x0; dst[1] = x1;
+			}
+			const h8 sh = sh4_half(g, c[4], c[5], c[6]);
+			f32x16 dd, oo;
+			uint32_t lt_off = 0;
+			asm volatile("" : "+s"(lt_off));
+			mlp_forward<false, false>(lds_tiles + lt_off, lane, x0, x1, sh, dd, oo, nullptr);
+			const half_t sigma = (half_t)dd[0];
+			if (valid && g == 0) {
+				h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = sigma;
+				*(h4*)(out + (size_t)s * out_stride) = o;
+			}
+			// transmittance behind this tile: product of (1 - alpha) over its samples (lanes 0..31 hold the density outputs), as the loss kernel forms alpha
+			float keep = 1.0f;
+			if (valid && g == 0) keep = 1.0f - (1.0f - __expf(-network_to_density((float)sigma, density_activation) * unwarp_dt(c[3])));
+#pragma unroll
+			for (int off = 16; off > 0; off >>= 1) keep *= __shfl_xor(keep, off, 64);
+			T *= __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, keep)));
+			if (T < stop_transmittance) { t0 += 32; break; }
+		}
+		for (uint32_t k = t0 + (uint32_t)lane; k < n; k += 64) { const h4 z = {}; *(h4*)(out + (size_t)(base + k) * out_stride) = z; }
 	}
 }
 
@@ -731,6 +798,7 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 template <int D, bool SCATTER>
 __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask) {
+	NGP_RAISE_CHAIN_PRIORITY();
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
 	const uint32_t level = blockIdx.y;
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
@@ -849,6 +917,7 @@ template <int D>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z t
 __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                              const h2* __restrict__ dx_planes, void* __restrict__ partials_raw,
                                                              const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask) {
+	NGP_RAISE_CHAIN_PRIORITY();
 	constexpr int NC = 1 << D;
 	__shared__ unsigned long long slice64[2 * GB_FX_SLICE];
 	__shared__ uint32_t s_start;
@@ -921,6 +990,7 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 
 // sums the K chunk-copies of every entry in fp32 and writes the fp16 gradient table (each entry exactly once)
 __global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __restrict__ desc, const void* __restrict__ partials_raw, h2* __restrict__ grid_grad, uint32_t dims) {
+	NGP_RAISE_CHAIN_PRIORITY();
 	const uint32_t level = blockIdx.y;
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = (dims == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
@@ -1067,6 +1137,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
                                                                   const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
                                                                   h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words,
                                                                   float* __restrict__ dL_dinput /* [n][6] or NULL */) {
+	NGP_RAISE_CHAIN_PRIORITY();
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
@@ -1577,6 +1648,7 @@ __global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restric
 // sums the per-chunk partial weight gradients.  64 parameters x 4 chunk groups per block; every thread keeps 8 independent loads in
 // flight (the straightforward one-thread-per-parameter loop is a chain of n_chunks dependent L2 latencies: 40 us for 5 MB)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads, uint32_t n_mlp_params) {
+	NGP_RAISE_CHAIN_PRIORITY();
 	__shared__ float red[4][64];
 	const uint32_t p = threadIdx.x & 63u, q = threadIdx.x >> 6;
 	const uint32_t i = blockIdx.x * 64u + p;
@@ -1682,6 +1754,7 @@ __global__ void __launch_bounds__(256) adam_ema_vec4_kernel(uint32_t n_groups, u
                                      const half4_t* __restrict__ grads, float4* __restrict__ master, half4_t* __restrict__ params,
                                      float4* __restrict__ m1, float4* __restrict__ m2, float4* __restrict__ ema, half4_t* __restrict__ inference) {
 #pragma clang fp contract(off)
+	NGP_RAISE_CHAIN_PRIORITY();
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_groups) return;
 	const half4_t g4 = grads[t];
@@ -1825,6 +1898,21 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	hipLaunchKernelGGL((nerf_forward_kernel<2, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
+	return 0;
+}
+
+int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, const uint32_t* numsteps,
+                              const uint32_t* rays_counter, uint32_t n_rays_max, uint32_t max_samples, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, int density_activation,
+                              float stop_transmittance, uint32_t* queue_counter) {
+	if (!n_rays_max || !max_samples) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward_rays: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	if (!x_saved || !queue_counter || !numsteps || !rays_counter) { set_last_error("ngp_hip_nerf_forward_rays: x_saved, numsteps, rays_counter and queue_counter are required", hipErrorInvalidValue); return -1; }
+	// one wave per ray at a time: no more workgroups than rays / 4, at most what the chip holds (2 workgroups of 4 waves per CU at this register count)
+	static const uint32_t cap_env = getenv("NGP_HIP_FWD_RAYS_CAP") ? (uint32_t)atoi(getenv("NGP_HIP_FWD_RAYS_CAP")) : 0u;   // dev-only
+	const uint32_t cap = cap_env ? cap_env : 384 /* sweep 256 / 384 / 512 / 768: 173 / 166 / 177 / 178 us */, want = div_up(n_rays_max, 4);
+	hipLaunchKernelGGL(nerf_forward_rays_kernel, dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, numsteps,
+	                   rays_counter, max_samples, (half_t*)out, out_stride, (half_t*)x_saved, density_activation, stop_transmittance, queue_counter);
+	NGP_LAUNCH_CHECK("nerf_forward_rays_kernel");
 	return 0;
 }
 

@@ -1024,7 +1024,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		capture_copy(cap.density_grid_mean, m_nerf.density_grid_mean.data(), 4);
 	}
 	if (m_compact_slot_zeroed == m_gen_slot) m_compact_slot_zeroed = -1;   // cleared by the previous step's post_words launch
-	else HIP_CHECK_THROW(hipMemsetAsync(compacted_counter, 0, 4, (hipStream_t)m_stream));
+	else HIP_CHECK_THROW(hipMemsetAsync(compacted_counter, 0, 8, (hipStream_t)m_stream));   // word 2: the compaction counter, word 3: the ray queue of the forward pass
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	const uint32_t n_rays_global = R * m_world_size;
 	// inference over the (padded) pre-compaction samples with the TRAINING weights (3256).  The pass also stores every sample's encoding
@@ -1032,7 +1032,16 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// pass over the compacted batch (3330) — its only product that backward consumes is that encoding (ngp_hip.h "Forward pass").
 	m_x_all.enlarge((size_t)max_inference * 32 * 2);
 	profile_begin(PK_INFERENCE);
-	check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
+	// The reference evaluates every marched sample (3256) and lets the loss kernel drop what lies behind each ray's termination.  m_forward_walks_rays: the pass walks the
+	// rays instead and stops behind the 32-sample tile in which a ray's transmittance fell below half the loss kernel's threshold — the kept samples get the same
+	// bits, the others (half of the batch on a trained scene) are never gathered (ngp_hip_nerf_forward_rays).
+	static const int fwd_rays_env = getenv("NGP_HIP_FWD_RAYS") ? atoi(getenv("NGP_HIP_FWD_RAYS")) : -1;   // dev: A / B (1 on, 0 off)
+	if (fwd_rays_env >= 0 ? fwd_rays_env != 0 : m_forward_walks_rays) {
+		check(ngp_hip_nerf_forward_rays(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, m_numsteps.as<uint32_t>(), gen_counters + 0, R, max_inference, m_mlp_out.as<uint16_t>(),
+		                                OUT_STRIDE, m_x_all.as<uint16_t>(), (int)m_nerf.density_activation, getenv("NGP_HIP_FWD_STOP") ? (float)atof(getenv("NGP_HIP_FWD_STOP")) : 0.5f * 1e-4f /* half of EPSILON (testbed_nerf.cu:1345) */, gen_counters + 3), "nerf_forward_rays");
+	} else {
+		check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
+	}
 	profile_end(PK_INFERENCE, max_inference);
 	if (tr.optimize_exposure) {
 		if (m_world_size > 1 && !m_dp_comm) throw std::runtime_error{"optimize_exposure at world_size > 1 needs init_data_parallel (the exposure gradients are summed over the ranks)"};
@@ -1104,7 +1113,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
 	m_next_slot_zeroed = m_compact_slot_zeroed = m_gen_slot ^ 1;
 	check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
-	                         m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1), 3, (double*)m_dp_counters_dev), "post_words");
+	                         m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1), 4 /* ray, sample and compaction counters + the forward pass's ray queue */, (double*)m_dp_counters_dev), "post_words");
 	// an event record costs a few microseconds of dispatch gap on the stream: the two step events are only recorded at their precise
 	// points once somebody has asked to wait on them (stream_wait_*, data-parallel hosts); the polling host below does not need one
 	m_counters_event_recorded = m_want_counters_event;
@@ -1558,7 +1567,9 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			const uint32_t n_elements = next_multiple(pt.n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 			// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
-			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
+			static const bool fused_render = getenv("NGP_HIP_RENDER_FUSED") != nullptr;   // dev: the fused kernel instead of encode + MLP (re-measurement knob)
+			if (fused_render) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE), "nerf_inference (render, fused)");
+			else check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
 			if (render_mode == (int)ERenderMode::Normals) {   // 2225-2226: network.input_gradient(stream, 3, positions, positions) — on the inference weights like the pass above
 				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);

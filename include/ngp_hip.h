@@ -110,6 +110,16 @@ int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_
  * encoded features x_saved [n][32] fp16 that backward consumes (the tcnn ForwardContext). */
 int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                          uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+/* The training step's pre-compaction network pass (src/testbed_nerf.cu:3256) restricted to what the loss kernel can keep.  The reference evaluates every marched
+ * sample and lets compute_loss_kernel_train_nerf stop at the first sample whose transmittance fell below 1e-4 (:1341-1374); this entry point walks each ray
+ * (numsteps: the ray generator's (count, base) pairs, *rays_counter of them) in tiles of 32 consecutive samples, multiplies the tile's (1 - alpha) — alpha from the
+ * density output and the sample's dt exactly as the loss kernel forms it — into the ray's transmittance and stops behind the first tile that ends below
+ * stop_transmittance (pass half the loss kernel's threshold).  Evaluated samples get the same bits as ngp_hip_nerf_forward (out, x_saved); the outputs of skipped
+ * samples are zeroed (finite, and behind the termination: the loss kernel cannot include them), their x_saved rows are left unwritten.  queue_counter: one device
+ * word, zero at launch (the ray queue); samples at or beyond max_samples are ignored. */
+int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, const uint32_t* numsteps,
+                              const uint32_t* rays_counter, uint32_t n_rays_max, uint32_t max_samples, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, int density_activation,
+                              float stop_transmittance, uint32_t* queue_counter);
 /* Two-kernel variants of the three forward passes above (same results, bit for bit): an XCD-affine hash-encode kernel writes the
  * 32 features of every sample into level planes inside `workspace` (each XCD of the MI355X walks at most two 2-MiB level tables,
  * so its 4-MiB L2 holds them), then the MLP kernel reads the planes.  Faster whenever n is large enough to fill the chip

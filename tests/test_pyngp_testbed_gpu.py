@@ -141,7 +141,7 @@ def test_shall_train_encoding_and_network(trained):
     assert (q[:n_mlp] != p[:n_mlp]).sum() > 1000
     t.shall_train_encoding = True
     # trainables this build lacks refuse loudly instead of training something else
-    for name in ("optimize_distortion", "optimize_extra_dims"):               # (optimize_extrinsics / optimize_focal_length: tests/test_extrinsics_gpu.py)
+    for name in ("optimize_extra_dims",):               # (extrinsics / focal length: tests/test_extrinsics_gpu.py; distortion / envmap: tests/test_render_modes_e2e_gpu.py)
         setattr(t.nerf.training, name, True)
         with pytest.raises(RuntimeError, match="not part of this build"):
             t.frame()
@@ -152,7 +152,6 @@ def test_shall_train_encoding_and_network(trained):
         t.calculate_iou()
     with pytest.raises(RuntimeError, match="DLSS"):
         t.dlss = True
-    t.nerf.glow_mode = 1
-    with pytest.raises(RuntimeError, match="glow"):
-        t.render(16, 16, 1, True)
+    t.nerf.glow_mode = 1                                                        # built since round 2 (tests/test_render_modes_e2e_gpu.py)
+    assert np.isfinite(t.render(16, 16, 1, True)).all()
     t.nerf.glow_mode = 0

@@ -8,7 +8,7 @@ import csv,glob
 f=glob.glob("/tmp/tl/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-fw=[i for i,r in enumerate(rows) if "nerf_forward_kernel" in r["Kernel_Name"]]
+fw=[i for i,r in enumerate(rows) if "nerf_forward_kernelILi2" in r["Kernel_Name"] or "nerf_forward_rays_kernel" in r["Kernel_Name"]]
 # three consecutive steps near the end that have no occupancy update in between
 for k in range(len(fw)-8, len(fw)-5):
     a,b=fw[k],fw[k+1]
