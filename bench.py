@@ -31,7 +31,7 @@ OPT_BYTES_PER_PARAM = 36       # grads 2 + master 4+4 + m 4+4 + v 4+4 + fp16 2 +
 BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
 MARCH_BYTES_PER_SAMPLE = 28    # one NerfCoordinate written per sample (nerf.h:62-107)
 MARCH_BYTES_PER_RAY = 40       # ray index 4 + Ray 24 + numsteps 8 written, one RGBA8 pixel read (testbed_nerf.cu:1232-1258)
-KERNEL_SET = "r02c"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
+KERNEL_SET = "r02f"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
 GROUP_KERNELS = {"nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
                  "nerf_inference": "one ngp_hip_nerf_forward call: fused hash-grid encode + both MLPs (single kernel)", "optimizer_step": "adam_ema_vec4_kernel (single kernel)"}
 SURVEY_STEPS = 48              # untimed steps with every launch group bracketed by events (picks the dominant group, fills "kernels")
@@ -365,7 +365,10 @@ def main():
         one_step()
     survey = tb.profile()
     dom = max((n for n in survey if n in BYTES_PER_UNIT and survey[n]["launches"]), key=lambda n: survey[n]["ms"])
-    tb.set_profiling(True, [dom])
+    # ... and only on every 4th step of the timed region (a bracket is two event records = two ~5 us dispatch gaps on the step's critical chain): the
+    # average launch duration the roofline uses is still measured live, over the timed region, on a quarter of its launches
+    profile_every = 4 if a.steps >= 16 else 1
+    tb.set_profiling(True, [dom], profile_every)
     tb.reset_profile()
     if use_dp:
         dist.barrier()
@@ -478,7 +481,7 @@ def main():
                    "global_batch": B if a.scaling == "strong" else B * world, "parallelism": "dp%d" % world if use_dp else "single", "dp_impl": dp_impl},
         "rays_per_s": round(rays / dt, 1), "pre_compaction_samples_per_s": round(pre_compaction / dt, 1),
         "pretrain_steps": pretrain_steps, "timed_from_training_step": int(timed_from), "psnr_at_bench": None if psnr_at_bench is None else round(psnr_at_bench, 2),
-        "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region; other groups: %d untimed survey steps" % (dom, SURVEY_STEPS),
+        "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
     if world == 1 and not a.no_cpu_baseline:

@@ -382,46 +382,69 @@ __global__ void __launch_bounds__(256, 2) nerf_forward_rays_kernel(const NgpNetD
 	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
 	const uint32_t n_rays = *rays_counter;
 	typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-	while (true) {
-		uint32_t ray = 0;
-		if (lane == 0) ray = atomicAdd(queue, 1u);
-		ray = __builtin_amdgcn_readfirstlane(ray);
-		if (ray >= n_rays) break;
-		uint32_t n = numsteps[2 * ray], base = numsteps[2 * ray + 1];
-		n = __builtin_amdgcn_readfirstlane(n); base = __builtin_amdgcn_readfirstlane(base);
-		if (base >= max_samples) continue;
-		if (n > max_samples - base) n = max_samples - base;
-		float T = 1.0f;
-		uint32_t t0 = 0;
-		for (; t0 < n; t0 += 32) {
-			const bool valid = t0 + (uint32_t)j < n;
-			const uint32_t s = base + t0 + (valid ? (uint32_t)j : 0u);
-			const float* c = coords + (size_t)s * coord_stride;
-			h8 x0, x1;
-			encode_half(desc, grid, g, c[0], c[1], c[2], x0, x1);
-			if (valid) {
-				h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
-				dst[0] = x0; dst[1] = x1;
-			}
-			const h8 sh = sh4_half(g, c[4], c[5], c[6]);
-			f32x16 dd, oo;
-			uint32_t lt_off = 0;
-			asm volatile("" : "+s"(lt_off));
-			mlp_forward<false, false>(lds_tiles + lt_off, lane, x0, x1, sh, dd, oo, nullptr);
-			const half_t sigma = (half_t)dd[0];
-			if (valid && g == 0) {
-				h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = sigma;
-				*(h4*)(out + (size_t)s * out_stride) = o;
-			}
-			// transmittance behind this tile: product of (1 - alpha) over its samples (lanes 0..31 hold the density outputs), as the loss kernel forms alpha
-			float keep = 1.0f;
-			if (valid && g == 0) keep = 1.0f - (1.0f - __expf(-network_to_density((float)sigma, density_activation) * unwarp_dt(c[3])));
-#pragma unroll
-			for (int off = 16; off > 0; off >>= 1) keep *= __shfl_xor(keep, off, 64);
-			T *= __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, keep)));
-			if (T < stop_transmittance) { t0 += 32; break; }
+	// next ray of the queue with at least one sample inside the budget; false when the queue is empty (all wave-uniform)
+	auto pop = [&](uint32_t& n, uint32_t& base) -> bool {
+		while (true) {
+			uint32_t ray = 0;
+			if (lane == 0) ray = atomicAdd(queue, 1u);
+			ray = __builtin_amdgcn_readfirstlane(ray);
+			if (ray >= n_rays) return false;
+			n = __builtin_amdgcn_readfirstlane(numsteps[2 * ray]); base = __builtin_amdgcn_readfirstlane(numsteps[2 * ray + 1]);
+			if (base >= max_samples) continue;
+			if (n > max_samples - base) n = max_samples - base;
+			if (n) return true;
 		}
-		for (uint32_t k = t0 + (uint32_t)lane; k < n; k += 64) { const h4 z = {}; *(h4*)(out + (size_t)(base + k) * out_stride) = z; }
+	};
+	auto zero_rest = [&](uint32_t base, uint32_t from, uint32_t n) {
+		for (uint32_t k = from + (uint32_t)lane; k < n; k += 64) { const h4 z = {}; *(h4*)(out + (size_t)(base + k) * out_stride) = z; }
+	};
+	// A tile holds the next (up to 32) samples of the current ray and, when the ray ends inside it, the first samples of the next ray of the queue, so that
+	// only the last tile a wave ever builds can be partly empty.
+	uint32_t n0 = 0, b0 = 0, p0 = 0;   // current ray: count, base, samples done
+	float T0 = 1.0f;
+	bool have = pop(n0, b0);
+	while (have) {
+		const uint32_t a = n0 - p0 < 32u ? n0 - p0 : 32u;
+		uint32_t n1 = 0, b1 = 0, c = 0;
+		bool have1 = false;
+		if (a < 32u) { have1 = pop(n1, b1); if (have1) c = n1 < 32u - a ? n1 : 32u - a; }
+		const bool in0 = (uint32_t)j < a, in1 = !in0 && (uint32_t)j < a + c, valid = in0 || in1;
+		const uint32_t s = in0 ? b0 + p0 + (uint32_t)j : in1 ? b1 + ((uint32_t)j - a) : b0 + p0;
+		const float* cp = coords + (size_t)s * coord_stride;
+		h8 x0, x1;
+		encode_half(desc, grid, g, cp[0], cp[1], cp[2], x0, x1);
+		if (valid) {
+			h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
+			dst[0] = x0; dst[1] = x1;
+		}
+		const h8 sh = sh4_half(g, cp[4], cp[5], cp[6]);
+		f32x16 dd, oo;
+		uint32_t lt_off = 0;
+		asm volatile("" : "+s"(lt_off));
+		mlp_forward<false, false>(lds_tiles + lt_off, lane, x0, x1, sh, dd, oo, nullptr);
+		const half_t sigma = (half_t)dd[0];
+		if (valid && g == 0) {
+			h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = sigma;
+			*(h4*)(out + (size_t)s * out_stride) = o;
+		}
+		// transmittance behind the tile, per ray segment: product of (1 - alpha) over its samples (lanes 0..31 hold the density outputs), alpha as the loss kernel forms it
+		float keep = 1.0f;
+		if (valid && g == 0) keep = 1.0f - (1.0f - __expf(-network_to_density((float)sigma, density_activation) * unwarp_dt(cp[3])));
+		float k0 = in0 ? keep : 1.0f, k1 = in1 ? keep : 1.0f;
+#pragma unroll
+		for (int off = 16; off > 0; off >>= 1) { k0 *= __shfl_xor(k0, off, 64); k1 *= __shfl_xor(k1, off, 64); }
+		T0 *= __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k0)));
+		p0 += a;
+		if (a == 32u && p0 < n0 && !(T0 < stop_transmittance)) continue;   // the ray goes on alone in the next tile
+		if (p0 < n0) zero_rest(b0, p0, n0);                                 // terminated: what is left of it is skipped
+		// the next ray becomes the current one (its first c samples are done); one that is already through, or terminated, is finished on the spot
+		have = have1; n0 = n1; b0 = b1; p0 = c;
+		T0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k1)));
+		if (a == 32u) { have = pop(n0, b0); p0 = 0; T0 = 1.0f; }
+		while (have && (p0 >= n0 || T0 < stop_transmittance)) {
+			if (p0 < n0) zero_rest(b0, p0, n0);
+			have = pop(n0, b0); p0 = 0; T0 = 1.0f;
+		}
 	}
 }
 

@@ -614,7 +614,7 @@ PYBIND11_MODULE(pyngp, m) {
 				return d;
 			})
 		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
-		.def("set_profiling", [](Testbed& t, bool on, const std::vector<std::string>& only) {
+		.def("set_profiling", [](Testbed& t, bool on, const std::vector<std::string>& only, uint32_t every) {
 				// only: names as in profile(); empty = all kinds.  Every bracketed launch group costs two event records on the stream.
 				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep"};
 				uint32_t mask = only.empty() ? ~0u : 0u;
@@ -623,8 +623,8 @@ PYBIND11_MODULE(pyngp, m) {
 					for (int k = 0; k < Testbed::PK_COUNT; ++k) if (n == names[k]) { mask |= 1u << k; found = true; }
 					if (!found) throw std::invalid_argument{"set_profiling: unknown kernel group '" + n + "'"};
 				}
-				t.m_profile_enabled = on; t.m_profile_mask = mask;
-			}, py::arg("on"), py::arg("only") = std::vector<std::string>{})
+				t.m_profile_enabled = on; t.m_profile_mask = mask; t.m_profile_every = every ? every : 1u;   // every: bracket the launches of every n-th training step only
+			}, py::arg("on"), py::arg("only") = std::vector<std::string>{}, py::arg("every") = 1u)
 		.def("reset_profile", &Testbed::reset_profile)
 		.def_readwrite("async_training_steps", &Testbed::m_async_training_steps, "frame() does not drain the stream after the training step (the reference does, testbed.cu:2570): the next step's launches queue behind this one's optimizer instead of after an idle gap.  Everything the API reads afterwards is ordered by the same stream; call sync() before touching device buffers from another stream.")
 		.def("profile", [](Testbed& t) {

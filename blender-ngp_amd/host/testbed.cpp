@@ -271,6 +271,7 @@ void* Testbed::prof_event() {
 }
 void Testbed::profile_begin(int k, void* stream) {
 	if (!m_profile_enabled || !((m_profile_mask >> k) & 1u)) return;
+	if (m_profile_every > 1 && m_training_step % m_profile_every) return;   // profile_end finds no pending bracket for this launch and returns
 	ProfPending p{k, prof_event(), nullptr, 0};
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)(stream ? stream : m_stream)));
 	m_prof_pending.push_back(p);

@@ -453,6 +453,7 @@ public:
 	std::chrono::steady_clock::time_point m_last_step_return{};
 	bool m_profile_enabled = false;
 	uint32_t m_profile_mask = ~0u;   // bit k: bracket the launches of ProfKernel k with events (each bracket costs a few us of dispatch gap)
+	uint32_t m_profile_every = 1;    // bracket the launches of every n-th training step only (a sampled live measurement: 1/n of the dispatch gaps)
 	ProfAccum m_prof[PK_COUNT];
 	void reset_profile();
 	void profile_begin(int k, void* stream = nullptr);

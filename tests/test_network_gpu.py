@@ -303,7 +303,7 @@ def test_ws_rejects_small_workspace(ngp, cuda):
 
 
 def test_forward_rays_evaluates_what_the_loss_kernel_can_keep(ngp, cuda):
-    """ngp_hip_nerf_forward_rays (experimental pre-compaction pass): per ray, 32-sample tiles until the ray's transmittance falls below stop_transmittance.
+    """ngp_hip_nerf_forward_rays (experimental pre-compaction pass): per ray, tiles of 32 consecutive samples (the head of a ray may share a tile with the tail of the previous one) until the ray's transmittance falls below stop_transmittance.
     Evaluated samples carry the bits of ngp_hip_nerf_forward (outputs and saved encodings), skipped ones are zero; every sample in front of a ray's
     termination at the loss kernel's threshold (twice the stop value) is evaluated."""
     desc = H.make_desc(ngp, log2_hashmap_size=15)
@@ -342,15 +342,14 @@ def test_forward_rays_evaluates_what_the_loss_kernel_can_keep(ngp, cuda):
         T = np.cumprod(np.exp(-od[b:b + c]))                          # transmittance BEHIND each sample (float64)
         zero = (out[b:b + c] == 0).all(axis=1)
         k = int(np.argmax(zero)) if zero.any() else c                 # first skipped sample
-        assert k % 32 == 0 or k == c                                  # whole tiles
         assert zero[k:].all() and not zero[:k].any()
         np.testing.assert_array_equal(out[b:b + k], ref_out_h[b:b + k])
         np.testing.assert_array_equal(x[b:b + k], ref_x_h[b:b + k])
         assert (x[b + k:b + c] == 0x7e00).all()                       # skipped rows are not written
         if k < c:
             assert T[k - 1] < stop * 1.001                            # it only stops behind a tile that ends below the threshold ...
-            if k >= 64:
-                assert T[k - 33] >= stop * 0.999                      # ... and at the first such tile
+            if k > 32:
+                assert T[k - 33] >= stop * 0.999                      # ... and at the first such tile (a ray's first segment may share its tile with the tail of another ray)
         # everything the loss kernel could keep at 2 x stop is there: samples whose transmittance IN FRONT of them is >= 2 * stop
         in_front = np.concatenate([[1.0], T[:-1]])
         assert not zero[in_front >= 2 * stop].any()
