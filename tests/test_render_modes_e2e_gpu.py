@@ -157,13 +157,14 @@ def test_envmap_from_transforms_json_renders_and_trains(cuda, tmp_path):
     seen = env[..., :3].sum(-1) > 0.5 * want.sum()                               # texels in the middle of what the training rays looked at
     assert seen.sum() > 30 and np.abs(env[..., 3]).max() == 0                    # alpha gets no gradient
     assert np.abs(np.median(env[seen][:, :3], axis=0) - want).max() < 0.08
-    # the renderer shows the map behind the scene: a camera looking away from the object sees the backdrop colour
+    # the renderer shows the map behind the scene: from a TRAINING pose (directions the map was trained on) the pixels the scene leaves transparent carry the backdrop colour
     t.shall_train = False
     t.background_color = [0.0, 0.0, 0.0, 0.0]
-    t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
-    img = t.render(48, 48, 1, True)
-    corner = img[:4, :4].reshape(-1, 4)                                          # the object sits in the middle of the frame
-    got = np.median(corner[:, :3], axis=0)                                       # (the renderer reads the Ema copy of the map, decay 0.99: it trails the trained values)
+    t.set_nerf_camera_matrix(ds["train_poses"][0][:3, :])
+    img = t.render(64, 64, 1, True)
+    bg = img[..., 3] < 0.05                                                      # (the map's alpha stays 0: these pixels are colour without coverage)
+    assert bg.sum() > 500
+    got = np.median(img[bg][:, :3], axis=0)                                      # (the renderer reads the Ema copy of the map, decay 0.99: it trails the trained values)
     assert np.abs(got - want).max() < 0.2 and got[2] > 2 * got[1] > 4 * got[0]
     # without train_envmap the map stays what it is
     t.shall_train = True
