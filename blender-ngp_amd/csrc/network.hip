@@ -1851,7 +1851,9 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
 	hipLaunchKernelGGL((gb_fx_bin_kernel<D, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
-	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(1024), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
+	static const uint32_t owner_threads_env = getenv("NGP_HIP_GB_OWNER_THREADS") ? (uint32_t)atoi(getenv("NGP_HIP_GB_OWNER_THREADS")) : 0u;   // dev: sweep (256 / 512 / 1024)
+	const uint32_t owner_threads = owner_threads_env ? owner_threads_env : 1024u;
+	hipLaunchKernelGGL(grid_backward_kernel<D>, dim3(GB_FX_MAX_SLICES, 16), dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
 	NGP_LAUNCH_CHECK("grid_backward_kernel");
 	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const void*)gb_partials, grid_grad, (uint32_t)D);
 	NGP_LAUNCH_CHECK("grid_combine_kernel");
