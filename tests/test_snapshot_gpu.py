@@ -143,8 +143,9 @@ def test_script_facing_properties(trained):
     bb = tb.render_aabb
     assert np.allclose(bb.min, [0, 0, 0]) and np.allclose(bb.max, [1, 1, 1]) and np.allclose(tb.raw_aabb.max, [1, 1, 1])
     tb.render_mode = pyngp.RenderMode.Shade
-    with pytest.raises(RuntimeError):
-        tb.render_mode = pyngp.RenderMode.Normals
+    tb.render_mode = pyngp.RenderMode.Normals                 # every ERenderMode is built since round 2 (tests/test_render_modes_e2e_gpu.py)
+    assert tb.render_mode == pyngp.RenderMode.Normals
+    tb.render_mode = pyngp.RenderMode.Shade
     tb.set_camera_to_training_view(3)
     tb.shall_train = False
     tb.background_color = [0.0, 0.0, 0.0, 0.0]
