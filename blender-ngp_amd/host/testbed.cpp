@@ -232,6 +232,7 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
 		throw std::runtime_error{"no MI355X / ROCm device visible: the product path has no CPU fallback"};
 	}
+	HIP_CHECK_THROW(hipGetDevice(&m_device));   // the caller's current device (one process per GPU: torch.cuda.set_device(LOCAL_RANK) came first); worker threads re-select it
 	hipStream_t st, st_b;
 	HIP_CHECK_THROW(hipStreamCreate(&st));
 	HIP_CHECK_THROW(hipStreamCreate(&st_b));
@@ -1612,7 +1613,7 @@ void Testbed::bl_start_async(std::function<void()> job) {
 	{ std::lock_guard<std::mutex> lock(m_render_mutex); ++m_render_workers; }
 	try {
 		std::thread([this, job]() {
-			try { job(); } catch (...) {}
+			try { (void)hipSetDevice(m_device); job(); } catch (...) {}   // HIP's current device is per thread
 			{ std::lock_guard<std::mutex> lock(m_render_mutex); --m_render_workers; }
 			m_render_cv.notify_all();
 		}).detach();

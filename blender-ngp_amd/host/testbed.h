@@ -412,6 +412,7 @@ public:
 	bool m_snap_to_pixel_centers = false;
 	float m_render_near_distance = 0.0f;
 	ERenderMode m_render_mode = ERenderMode::Shade;    // every ERenderMode of the stock tracer (ngp_hip_composite_ex / ngp_hip_init_rays_ex / the Slice kernels)
+	int m_device = 0;               // the HIP device this Testbed's streams and buffers live on
 	TrainableBuffer m_envmap;       // testbed.h:936-944: resolution of the dataset's `envmap` image ((0, 0): none)
 	TrainableBuffer m_distortion;   // testbed.h:946-952: 32 x 32 x 2 zeros unless trained; passed unconditionally to the ray generator
 	std::vector<NgpMask3D> m_render_masks;             // python_api.cu:694: crop masks of the STOCK renderer (testbed_nerf.cu:2339-2352, 833-840, 1943-1956)
