@@ -259,6 +259,13 @@ Testbed::~Testbed() {
 
 void Testbed::check(int rc, const char* what) {
 	if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + ngp_hip_last_error());
+	static const bool trace_sync = getenv("NGP_HIP_TRACE_SYNC") != nullptr;   // dev: drain both streams behind every launch group and say which one it was (finds a kernel that never returns)
+	if (trace_sync) {
+		fprintf(stderr, "[ngp] step %u: %s ...", m_training_step, what); fflush(stderr);
+		if (m_stream_b) (void)hipStreamSynchronize((hipStream_t)m_stream_b);
+		if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream);
+		fprintf(stderr, " done\n"); fflush(stderr);
+	}
 }
 void Testbed::sync() { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
 void Testbed::invalidate_training_inputs() { drop_prefetch(); ++m_state_version; }

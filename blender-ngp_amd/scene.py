@@ -146,6 +146,8 @@ def build_testbed(ds, config_path=None, seed=1337):
 def train(testbed, n_steps, log_every=0):
     """run.py:187-210"""
     t0 = time.time()
+    if not testbed.shall_train:
+        raise RuntimeError("scene.train: testbed.shall_train is off (eval_test_views switches it off): frame() would not advance training_step")
     while testbed.frame():
         if testbed.training_step >= n_steps:
             break
