@@ -74,7 +74,7 @@ def test_camera_gradients_of_a_training_step_match_the_oracle_and_move_the_trans
     lr = max(tr.extrinsic_learning_rate, t.learning_rate / 1000.0)            # 3076: 0.33^(0 / 128) = 1
     scale = 8 / 128.0 / 1.0                                                    # per_camera_loss_scale = n_images / LOSS_SCALE / n_steps_between_cam_updates (3061)
     g = got_pos * np.float32(scale)
-    strong = np.abs(g) > 1e-6                                                    # eps = 1e-8 in the denominator: tiny gradients move less than lr
+    strong = np.abs(g) > 1e-5                                                    # eps = 1e-8 in the denominator: tiny gradients move less than lr (1e-6 was seen 2.6 % short, one run in twenty)
     np.testing.assert_allclose(pos1[strong], (-lr * np.sign(g))[strong], rtol=2e-2)
     after = np.array([tr.get_camera_extrinsics(i) for i in range(8)])
     assert np.abs(after - before).max() > 1e-4 and np.abs(after - before).max() < 0.02
