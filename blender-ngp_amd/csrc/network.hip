@@ -582,7 +582,10 @@ __host__ __device__ __forceinline__ GbSplit gb_split(uint32_t level_size) {
 //    owner exactly its ~n/16 items, and the owner writes its 8192 final fp16 gradients directly (no partial copies, no combine pass).
 constexpr uint32_t GB_FX_SLICE = GB_SLICE / 4;   // 4096 entries x 16 B = the same 64 KiB of LDS
 constexpr uint32_t GB_FX_MAX_SLICES = 256;       // tables up to 2^20 entries
-constexpr uint32_t GB_FX_CHUNK = 2048;           // samples per binning workgroup
+#ifndef NGP_GB_FX_CHUNK
+#define NGP_GB_FX_CHUNK 2048
+#endif
+constexpr uint32_t GB_FX_CHUNK = NGP_GB_FX_CHUNK;   // samples per binning workgroup
 __host__ __device__ __forceinline__ bool gb_uses_fx(uint32_t level_size, uint32_t resolution, bool dense) {
 	return !dense && (level_size & (level_size - 1)) == 0 && level_size >= GB_FX_SLICE && level_size / GB_FX_SLICE <= GB_FX_MAX_SLICES && resolution < GB_FX_SLICE;
 }
