@@ -73,7 +73,10 @@ __device__ __forceinline__ float wave_inclusive(float v, uint32_t lane) {
 
 // one wave per ray; 4 rays per workgroup: the two block barriers around the compaction scan make every wave wait for the slowest ray of
 // its workgroup, and ~1000 workgroups of 16 rays quantise badly over 512 resident slots (measured: 16 -> 4 rays, step -3.4 %)
-constexpr int LOSS_RAYS_PER_BLOCK = 4;
+#ifndef NGP_LOSS_RAYS_PER_BLOCK
+#define NGP_LOSS_RAYS_PER_BLOCK 4
+#endif
+constexpr int LOSS_RAYS_PER_BLOCK = NGP_LOSS_RAYS_PER_BLOCK;
 
 __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(const LossArgs a) {
 	__shared__ uint32_t s_counts[LOSS_RAYS_PER_BLOCK];
