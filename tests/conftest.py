@@ -20,6 +20,16 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs (a kernel that never returns, a spinning host loop) must fail, not hold the box: pytest-timeout (in the image) ends it after 5 minutes —
+    the slowest test of the suite takes under 20 s."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import helpers
