@@ -1673,23 +1673,29 @@ __global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restric
 
 // sums the per-chunk partial weight gradients.  64 parameters x 4 chunk groups per block; every thread keeps 8 independent loads in
 // flight (the straightforward one-thread-per-parameter loop is a chain of n_chunks dependent L2 latencies: 40 us for 5 MB)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads, uint32_t n_mlp_params) {
+constexpr uint32_t WR_WAVES = 16;   // waves per workgroup: each sums every 16th partial of the workgroup's 64 parameters (512 partials: 32 loads per thread, 8 in flight)
+__global__ void __launch_bounds__(64 * WR_WAVES) wgrad_reduce_kernel(const float* __restrict__ partials, uint32_t n_chunks, half_t* __restrict__ grads, uint32_t n_mlp_params) {
 	NGP_RAISE_CHAIN_PRIORITY();
-	__shared__ float red[4][64];
+	__shared__ float red[WR_WAVES][64];
 	const uint32_t p = threadIdx.x & 63u, q = threadIdx.x >> 6;
 	const uint32_t i = blockIdx.x * 64u + p;
 	float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	if (i < n_mlp_params) {
 		uint32_t c = q;
-		for (; c + 28 < n_chunks; c += 32) {
+		for (; c + 7 * WR_WAVES < n_chunks; c += 8 * WR_WAVES) {
 #pragma unroll
-			for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(c + 4 * u) * n_mlp_params + i];
+			for (int u = 0; u < 8; ++u) acc[u] += partials[(size_t)(c + WR_WAVES * u) * n_mlp_params + i];
 		}
-		for (int u = 0; c < n_chunks; c += 4, ++u) acc[u & 7] += partials[(size_t)c * n_mlp_params + i];
+		for (int u = 0; c < n_chunks; c += WR_WAVES, ++u) acc[u & 7] += partials[(size_t)c * n_mlp_params + i];
 	}
 	red[q][p] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 	__syncthreads();
-	if (q == 0 && i < n_mlp_params) grads[i] = (half_t)((red[0][p] + red[1][p]) + (red[2][p] + red[3][p]));
+	if (q == 0 && i < n_mlp_params) {
+		float sum = 0.0f;
+#pragma unroll
+		for (uint32_t k = 0; k < WR_WAVES; ++k) sum += red[k][p];
+		grads[i] = (half_t)sum;
+	}
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -2056,7 +2062,7 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
 	}
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
 	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
@@ -2198,7 +2204,7 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 	const uint32_t n_chunks = wgrad_chunks(n);
 	hipLaunchKernelGGL(nerf_wgrad_kernel<1>, dim3(n_chunks, 4), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(256), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	return 0;
 }
