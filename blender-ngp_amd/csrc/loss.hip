@@ -371,6 +371,31 @@ __global__ void fill_rollover_training_kernel(uint32_t n_elements, const uint32_
 	  if (i >= n_input && i < n_total) encoded[i] = encoded[i % n_input]; }
 }
 
+// The step's counter post and its three roll-overs in ONE launch of 256 workgroups: thread 0 first hands {*a, *b, *c, tag} to the (host-mapped) dst4 like
+// post_words_kernel (density_grid.hip) — the host is polling for it — then all threads fill the wrapped-around tails, enumerating only the positions that need a fill
+// (fill_rollover_training_kernel launches a thread per element of the widest array, 16 k workgroups that mostly have nothing to do).
+__global__ void __launch_bounds__(256) post_and_rollover_training_kernel(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words,
+                                                                         double* sum3_dev, uint32_t n_elements, const uint32_t* __restrict__ n_input_elements_ptr, uint16_t* __restrict__ dloss,
+                                                                         uint32_t dl_stride, float* __restrict__ coords, uint32_t coord_stride, float* __restrict__ encoded, uint32_t enc_stride) {
+	const uint32_t n_in = *n_input_elements_ptr;   // (read before the post clears nothing of it: the zeroed words belong to the NEXT step's slot)
+	if (blockIdx.x == 0 && threadIdx.x == 0 && dst4) {
+		const uint32_t va = a ? *a : 0u, vb = b ? *b : 0u, vc = c ? *c : 0u;
+		dst4[0] = va; dst4[1] = vb; dst4[2] = vc;
+		if (sum3_dev) { sum3_dev[0] = (double)va; sum3_dev[1] = (double)vb; sum3_dev[2] = (double)__uint_as_float(vc); }
+		for (uint32_t k = 0; k < n_zero_words; ++k) zero_words[k] = 0u;
+		__threadfence_system();
+		__hip_atomic_store(&dst4[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (n_in >= n_elements || n_in == 0) return;
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+	{ const uint32_t n_total = n_elements * dl_stride, n_input = n_in * dl_stride;
+	  for (uint32_t i = n_input + t; i < n_total; i += nt) dloss[i] = f2h(h2f(dloss[i % n_input]) * (float)n_input / (float)n_total); }
+	{ const uint32_t n_total = n_elements * coord_stride, n_input = n_in * coord_stride;
+	  for (uint32_t i = n_input + t; i < n_total; i += nt) coords[i] = coords[i % n_input]; }
+	if (encoded) { const uint32_t n_total = n_elements * enc_stride, n_input = n_in * enc_stride;
+	  for (uint32_t i = n_input + t; i < n_total; i += nt) encoded[i] = encoded[i % n_input]; }
+}
+
 // ---- plumbing configs P1 / P2: tcnn losses driven by Trainer::training_step, sample generation of Testbed::train_image ----------------
 // [tcnn] losses/{l2,relative_l2,l1,mape}.h: per element i of the (padded) prediction matrix, n_total = n * dims,
 //   value = f(d) / n_total, gradient = loss_scale * f'(d) / n_total with d = prediction - target.  Padding channels get zero gradient.
@@ -810,6 +835,16 @@ int ngp_hip_fill_rollover_training(void* stream, uint32_t n_elements, const uint
 	hipLaunchKernelGGL(fill_rollover_training_kernel, dim3(div_up(n_elements * widest, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, n_input_elements, dloss, dl_stride, coords,
 	                   coord_stride_floats, encoded, encoded_stride_floats);
 	NGP_LAUNCH_CHECK("fill_rollover_training_kernel");
+	return 0;
+}
+
+int ngp_hip_post_words_and_fill_rollover_training(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words,
+                                                  double* sum3_dev, uint32_t n_elements, const uint32_t* n_input_elements, uint16_t* dloss, uint32_t dl_stride, float* coords,
+                                                  uint32_t coord_stride_floats, float* encoded, uint32_t encoded_stride_floats) {
+	if (!n_elements || !n_input_elements) { set_last_error("ngp_hip_post_words_and_fill_rollover_training: n_elements and n_input_elements are required", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(post_and_rollover_training_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, a, b, c, tag, dst4, zero_words, zero_words ? n_zero_words : 0u, sum3_dev, n_elements,
+	                   n_input_elements, dloss, dl_stride, coords, coord_stride_floats, encoded, encoded_stride_floats);
+	NGP_LAUNCH_CHECK("post_and_rollover_training_kernel");
 	return 0;
 }
 

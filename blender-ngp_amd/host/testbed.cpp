@@ -1121,15 +1121,21 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// march that will bump them is launched after the host has seen this step's counters
 	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
 	m_next_slot_zeroed = m_compact_slot_zeroed = m_gen_slot ^ 1;
-	check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words,
-	                         m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1), 4 /* ray, sample and compaction counters + the forward pass's ray queue */, (double*)m_dp_counters_dev), "post_words");
-	// an event record costs a few microseconds of dispatch gap on the stream: the two step events are only recorded at their precise
-	// points once somebody has asked to wait on them (stream_wait_*, data-parallel hosts); the polling host below does not need one
+	uint32_t* next_slot = m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1);   // its ray, sample and compaction counters + the forward pass's ray queue
+	if (m_want_counters_event) {
+		// somebody waits on the counters event (stream_wait_counters: a data-parallel host that reduces the counters in stream order): it is recorded right behind the post,
+		// in front of the roll-overs, which are not needed for the counters
+		check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4, (double*)m_dp_counters_dev), "post_words");
+		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
+		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
+		                                     m_x_saved.as<float>(), 16), "fill_rollover");
+	} else {
+		// the polling host needs no event (a record costs a few microseconds of dispatch gap): post and roll-overs in one launch, the post first
+		check(ngp_hip_post_words_and_fill_rollover_training(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4,
+		                                                    (double*)m_dp_counters_dev, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
+		                                                    m_x_saved.as<float>(), 16), "post_words + fill_rollover");
+	}
 	m_counters_event_recorded = m_want_counters_event;
-	if (m_want_counters_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
-	// (the roll-overs are not needed for the counters: they run behind the event, off the counter -> next march -> next step chain)
-	check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
-	                                     m_x_saved.as<float>(), 16), "fill_rollover");
 
 	// ---- train_nerf_step, second half (3324-3332): backward on the compacted batch (gradients overwrite).  The reference's forward over
 	// the compacted batch is the encoding that arrived with the compaction above; m_separate_forward restores the second pass (same bits).

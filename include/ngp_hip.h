@@ -300,6 +300,11 @@ int ngp_hip_fill_rollover_f32(void* stream, uint32_t n_elements, uint32_t stride
  * (stride 7) and, optionally, on the carried encoding rows (stride 16 floats = 32 halves; see "Forward pass").  Element-wise the same arithmetic. */
 int ngp_hip_fill_rollover_training(void* stream, uint32_t n_elements, const uint32_t* n_input_elements, uint16_t* dloss, uint32_t dl_stride, float* coords, uint32_t coord_stride_floats,
                                    float* encoded, uint32_t encoded_stride_floats);
+/* ngp_hip_post_words (below) and ngp_hip_fill_rollover_training in one launch: the counters reach the polling host first, the roll-overs follow in the same kernel
+ * (one launch less on the step's chain; only the positions that need a fill are visited).  dst4 NULL: roll-overs only. */
+int ngp_hip_post_words_and_fill_rollover_training(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words,
+                                                  double* sum3_dev, uint32_t n_elements, const uint32_t* n_input_elements, uint16_t* dloss, uint32_t dl_stride, float* coords,
+                                                  uint32_t coord_stride_floats, float* encoded, uint32_t encoded_stride_floats);
 /* tcnn reduce_sum(float*) as used for the loss scalar (:2887): sum of n floats into out (zeroed inside). */
 int ngp_hip_reduce_sum_f32(void* stream, const float* in, uint32_t n, float* out);
 /* NerfCounters::update_after_training (:2870-2874) reads its counters with blocking 4-byte copies.  This gathers up to four

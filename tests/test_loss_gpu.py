@@ -316,6 +316,21 @@ def test_fill_rollover_training_equals_the_separate_launches(ngp, cuda):
     c2 = H.to_dev(co, cuda)
     check(ngp.ngp_hip_fill_rollover_training(None, n, cnt.data_ptr(), b[0].data_ptr(), 4, c2.data_ptr(), 7, None, 0))   # without encoding rows
     np.testing.assert_array_equal(H.to_host(c2, np.uint32), H.to_host(a[1], np.uint32))
+    # the step's merged launch: the counter post of ngp_hip_post_words, then the same three roll-overs
+    m = [H.to_dev(x, cuda) for x in (dl, co, en)]
+    wa, wb = torch.tensor([4242], dtype=torch.int32, device=cuda), torch.tensor([0.625], dtype=torch.float32, device=cuda)
+    dst, zero, sums = torch.full((4,), -1, dtype=torch.int32, device=cuda), torch.full((4,), 9, dtype=torch.int32, device=cuda), torch.zeros(3, dtype=torch.float64, device=cuda)
+    check(ngp.ngp_hip_post_words_and_fill_rollover_training(None, wa.data_ptr(), cnt.data_ptr(), wb.data_ptr(), 77, dst.data_ptr(), zero.data_ptr(), 4, sums.data_ptr(), n, cnt.data_ptr(),
+                                                            m[0].data_ptr(), 4, m[1].data_ptr(), 7, m[2].data_ptr(), 16))
+    for x, y, dt in zip(a, m, (np.uint16, np.uint32, np.uint32)):
+        np.testing.assert_array_equal(H.to_host(x, dt), H.to_host(y, dt))
+    d = dst.cpu().numpy()
+    assert d[0] == 4242 and d[1] == n_in and d[2:3].view(np.float32)[0] == 0.625 and d[3] == 77 and (zero.cpu().numpy() == 0).all()
+    assert sums.cpu().numpy().tolist() == [4242.0, float(n_in), 0.625]
+    for n_in2 in (0, n, n + 5):                                            # nothing to fill: untouched
+        m2, cnt2 = H.to_dev(co, cuda), H.to_dev(np.array([n_in2], np.uint32), cuda)
+        check(ngp.ngp_hip_post_words_and_fill_rollover_training(None, None, None, None, 1, None, None, 0, None, n, cnt2.data_ptr(), m[0].data_ptr(), 4, m2.data_ptr(), 7, None, 0))
+        np.testing.assert_array_equal(H.to_host(m2, np.float32).reshape(n, 7), co)
 
 
 def test_reduce_sum(ngp, cuda):
