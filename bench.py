@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — train-samples/s (+ render MP/s, PSNR) of the NeRF hot path on the procedural-lego workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one Testbed::train() call (src/testbed.cu:2527-2587): occupancy-grid prep on its schedule + ray marching +
@@ -249,6 +249,22 @@ def cpu_baseline(tb, ds, res, budget_s=12.0):
     return out
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` — one process per GPU, LOCAL_RANK -> device, rank 0 prints the
+    JSON line.  exec, not spawn: the launcher keeps this PID, so whoever started bench.py still owns (and can time out) the whole job."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    os.environ.setdefault("OMP_NUM_THREADS", "1")              # what torchrun would set (with a warning) anyway
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: exec %s" % (n_gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     if os.environ.get("BENCH_HANG_DUMP"):   # dev: dump every thread's stack and exit if the run is still going after that many seconds
         import faulthandler
@@ -270,6 +286,8 @@ def main():
     ap.add_argument("--min_train_step", type=int, default=1000, help="BASELINE.md M1 quotes the metric on steps [1000, 2000): the timed region never starts before this training step, whatever --warmup says")
     ap.add_argument("--psnr_gate", type=float, default=35.0, help="BASELINE config #3 'train to 35 PSNR then render': keep pre-training (untimed) until the held-out PSNR reaches this")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)   # does not return
 
     import torch  # first: one HIP runtime per process
     import scene
@@ -279,7 +297,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    if not torch.cuda.is_available():
+        raise SystemExit("rank %d of %d: bench.py needs a GPU (no CPU fallback in the product path)" % (rank, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d of %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, world, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -11,7 +11,10 @@ namespace ngp {
 
 class ShmCounterExchange {
 public:
-	// rank 0 creates (replacing a stale segment of the same name), the others attach once it is ready; throws std::runtime_error after `timeout_s`
+	// A rendezvous of all ranks: rank 0 creates the segment (replacing a stale one of the same name), the others attach and keep the mapping only
+	// once a LIVE rank 0 has echoed their random nonce — a leftover of a crashed job never answers, so it is never used (dp.cpp).  Returns on every
+	// rank once all have attached; throws std::runtime_error after `timeout_s` (monotonic clock).  `key` should still be unique per job (two LIVE jobs
+	// with one key collide: the second rank 0 fails on O_EXCL or replaces the first one's name)
 	ShmCounterExchange(uint32_t rank, uint32_t world, const std::string& key, double timeout_s = 60.0);
 	~ShmCounterExchange();
 	ShmCounterExchange(const ShmCounterExchange&) = delete;

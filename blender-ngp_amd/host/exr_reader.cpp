@@ -53,6 +53,7 @@ void unrle_block(const uint8_t* src, size_t n_src, std::vector<uint8_t>& dst, si
 		const int8_t c = (int8_t)src[i++];
 		if (c < 0) { const size_t n = (size_t)(-(int)c); if (i + n > n_src) throw std::runtime_error{"EXR: bad RLE run"}; dst.insert(dst.end(), src + i, src + i + n); i += n; }
 		else { if (i >= n_src) throw std::runtime_error{"EXR: bad RLE run"}; dst.insert(dst.end(), (size_t)c + 1, src[i++]); }
+		if (dst.size() > n_expected) throw std::runtime_error{"EXR: RLE block expands past the expected size"};   // a crafted block must not grow without bound
 	}
 	if (dst.size() != n_expected) throw std::runtime_error{"EXR: RLE block does not expand to the expected size"};
 }
@@ -89,8 +90,11 @@ void decode_exr_rgba_f32(const uint8_t* data, size_t n_bytes, int& w, int& h, st
 	if (compression < 0 || compression > 3) {
 		throw std::runtime_error{std::string{"EXR: compression "} + (compression >= 0 && compression < 10 ? comp_names[compression] : "?") + " is not supported by this reader (NONE, RLE, ZIPS, ZIP are)"};
 	}
-	w = dw[2] - dw[0] + 1; h = dw[3] - dw[1] + 1;
-	if (w <= 0 || h <= 0 || channels.empty()) throw std::runtime_error{"EXR: empty data window or channel list"};
+	// the window comes from the file: 64-bit arithmetic and a cap before anything is sized from it
+	const int64_t w64 = (int64_t)dw[2] - dw[0] + 1, h64 = (int64_t)dw[3] - dw[1] + 1;
+	if (w64 <= 0 || h64 <= 0 || channels.empty()) throw std::runtime_error{"EXR: empty data window or channel list"};
+	if (w64 > 65536 || h64 > 65536 || w64 * h64 > ((int64_t)1 << 28)) throw std::runtime_error{"EXR: data window larger than 2^28 pixels"};
+	w = (int)w64; h = (int)h64;
 	const int lines_per_block = compression == 3 ? 16 : 1;
 	const int n_blocks = (h + lines_per_block - 1) / lines_per_block;
 	size_t bytes_per_line = 0;
@@ -109,7 +113,7 @@ void decode_exr_rgba_f32(const uint8_t* data, size_t n_bytes, int& w, int& h, st
 	rgba.assign((size_t)w * h * 4, 1.0f);
 	std::vector<uint8_t> block, tmp;
 	for (int b = 0; b < n_blocks; ++b) {
-		if (offsets[(size_t)b] + 8 > n_bytes) throw std::runtime_error{"EXR: block offset out of range"};
+		if (n_bytes < 8 || offsets[(size_t)b] > n_bytes - 8) throw std::runtime_error{"EXR: block offset out of range"};
 		Cursor bc{data + offsets[(size_t)b], data + n_bytes};
 		const int y0 = bc.i32() - dw[1];
 		const uint32_t n_src = bc.u32();

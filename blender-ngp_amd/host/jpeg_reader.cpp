@@ -27,8 +27,20 @@ struct HuffTable {
 	int32_t maxcode[18];         // largest code of each length, left-aligned to 16 bits, +1
 	int32_t delta[17];           // symbol index = (code >> (16 - len)) + delta[len]
 	uint8_t symbols[256];
+	int n_symbols = 0;
 	void build(const uint8_t counts[16], const uint8_t* syms, int n_syms) {
+		// validate BEFORE anything is written: an over-subscribed table (e.g. three codes of length 1) would index past the 512-entry prefix
+		// tables below — every count and symbol comes from the file
+		int total = 0, next_code = 0;
+		for (int len = 1; len <= 16; ++len) {
+			total += counts[len - 1];
+			next_code += counts[len - 1];
+			if (next_code > (1 << len)) throw std::runtime_error{"JPEG: bad Huffman table (over-subscribed code lengths)"};
+			next_code <<= 1;
+		}
+		if (total != n_syms || n_syms > 256) throw std::runtime_error{"JPEG: bad Huffman table"};
 		memcpy(symbols, syms, (size_t)n_syms);
+		n_symbols = n_syms;
 		memset(fast_len, 0, sizeof(fast_len));
 		int code = 0, k = 0;
 		for (int len = 1; len <= 16; ++len) {
@@ -105,11 +117,20 @@ private:
 		for (len = 10; len <= 16; ++len) if (code16 < t.maxcode[len]) break;
 		if (len > 16) throw std::runtime_error{"JPEG: bad Huffman code"};
 		const int idx = (code16 >> (16 - len)) + t.delta[len];
-		if (idx < 0 || idx > 255) throw std::runtime_error{"JPEG: bad Huffman code"};
+		if (idx < 0 || idx >= t.n_symbols) throw std::runtime_error{"JPEG: bad Huffman code"};
 		bitbuf <<= len; bitcnt -= len;
 		return t.symbols[idx];
 	}
-	int receive_extend(int s) { if (s == 0) return 0; const int v = getbits(s); return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+	// s: the magnitude category of T.81 F.1.2.1 — at most 11 for DC differences, 10 for AC coefficients of 8-bit data (Tables F.1 / F.2);
+	// the callers check that bound, 16 is what the 32-bit reader can deliver
+	int receive_extend(int s) {
+		if (s == 0) return 0;
+		if (s < 0 || s > 16) throw std::runtime_error{"JPEG: bad magnitude category"};
+		const int v = getbits(s);
+		return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+	}
+	int dc_category(const HuffTable& t) { const int c = decode_symbol(t); if (c > 11) throw std::runtime_error{"JPEG: DC difference category above 11"}; return c; }
+	static int ac_size(int s) { if (s > 10) throw std::runtime_error{"JPEG: AC coefficient size above 10"}; return s; }
 	void reset_entropy() { bitbuf = 0; bitcnt = 0; hit_marker = false; eobrun = 0; for (auto& c : comp) c.pred = 0; }
 
 	void parse_dqt(); void parse_dht(); void parse_sof(int marker); void parse_sos();
@@ -170,7 +191,7 @@ void Decoder::parse_sof(int marker) {
 
 void Decoder::decode_block(Component& c, int16_t* blk, int ss, int se, int ah, int al) {
 	if (!progressive) {
-		const int t = decode_symbol(hdc[c.td]);
+		const int t = dc_category(hdc[c.td]);
 		c.pred += receive_extend(t);
 		blk[0] = (int16_t)c.pred;
 		for (int k = 1; k < 64;) {
@@ -178,13 +199,13 @@ void Decoder::decode_block(Component& c, int16_t* blk, int ss, int se, int ah, i
 			if (s == 0) { if (r != 15) break; k += 16; continue; }
 			k += r;
 			if (k > 63) throw std::runtime_error{"JPEG: coefficient index out of range"};
-			blk[ZIGZAG[k]] = (int16_t)receive_extend(s);
+			blk[ZIGZAG[k]] = (int16_t)receive_extend(ac_size(s));
 			++k;
 		}
 		return;
 	}
 	if (ss == 0) {   // DC scan of a progressive file
-		if (ah == 0) { const int t = decode_symbol(hdc[c.td]); c.pred += receive_extend(t); blk[0] = (int16_t)(c.pred * (1 << al)); }
+		if (ah == 0) { const int t = dc_category(hdc[c.td]); c.pred += receive_extend(t); blk[0] = (int16_t)(c.pred * (1 << al)); }
 		else if (getbit()) blk[0] |= (int16_t)(1 << al);
 		return;
 	}
@@ -199,7 +220,7 @@ void Decoder::decode_block(Component& c, int16_t* blk, int ss, int se, int ah, i
 			} else {
 				k += r;
 				if (k > se) throw std::runtime_error{"JPEG: coefficient index out of range"};
-				blk[ZIGZAG[k]] = (int16_t)(receive_extend(s) * (1 << al));
+				blk[ZIGZAG[k]] = (int16_t)(receive_extend(ac_size(s)) * (1 << al));
 				++k;
 			}
 		}
@@ -288,12 +309,12 @@ void Decoder::parse_sos() {
 
 void Decoder::finish(int& w, int& h, std::vector<uint8_t>& rgba) {
 	// dequantise + inverse DCT: out = M F M^T with M[x][u] = c(u)/2 cos((2x+1) u pi / 16), rounded once, level shift 128
-	static float M[8][8];
-	static bool init = false;
-	if (!init) {
-		for (int x = 0; x < 8; ++x) for (int u = 0; u < 8; ++u) M[x][u] = (float)((u == 0 ? std::sqrt(0.5) : 1.0) * 0.5 * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0));
-		init = true;
-	}
+	struct Basis {
+		float m[8][8];
+		Basis() { for (int x = 0; x < 8; ++x) for (int u = 0; u < 8; ++u) m[x][u] = (float)((u == 0 ? std::sqrt(0.5) : 1.0) * 0.5 * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0)); }
+	};
+	static const Basis basis;   // initialised once, thread-safe (frames are decoded by several threads)
+	const float (*M)[8] = basis.m;
 	for (int ci = 0; ci < n_comp; ++ci) {
 		Component& c = comp[ci];
 		if (!qt_present[c.tq]) throw std::runtime_error{"JPEG: missing quantisation table"};

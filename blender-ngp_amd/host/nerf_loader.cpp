@@ -345,7 +345,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	}
 	for (auto& f : futures) f.get();
 	result.has_rays = any_rays;
-	result.is_hdr = any_exr;
+	result.is_hdr = result.is_hdr || any_exr;   // an .exr envmap already set it (nerf_loader.cu:542 keeps it)
 	return result;
 }
 

@@ -376,7 +376,8 @@ PYBIND11_MODULE(pyngp, m) {
 		                                       const std::vector<float>& rolling_shutter, int width, int height, int spp, bool linear) {   // python_api.cu:262-275, 584-593
 				if (rolling_shutter.size() != 4) throw std::runtime_error{"rolling_shutter takes 4 floats [A, B, C, D]"};
 				std::vector<float> px;
-				{ py::gil_scoped_release rel; px = t.render_with_rolling_shutter_to_cpu(mat34_from_py(m0), mat34_from_py(m1), rolling_shutter.data(), width, height, spp, linear); }
+				const Mat34 start = mat34_from_py(m0), end = mat34_from_py(m1);   // buffer requests touch refcounts: before the GIL is released
+				{ py::gil_scoped_release rel; px = t.render_with_rolling_shutter_to_cpu(start, end, rolling_shutter.data(), width, height, spp, linear); }
 				py::array_t<float> result({height, width, 4});
 				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
 				return result;

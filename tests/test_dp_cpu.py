@@ -241,3 +241,53 @@ def test_cpp_shared_memory_counter_exchange_and_rccl_binding():
         assert first == (6.0, 0.0, 1.5)                  # (1 + 2 + 3) * 1, 3 * 0, 0.25 * 6
         assert last == (6.0 * 200, 3 * 199.0, 1.5)
     assert not os.path.exists("/dev/shm/ngp_dp_" + key)   # rank 0 unlinked the name
+
+
+def _late_rank0_worker(rank, world, key, q, delay):
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "blender-ngp_amd"))
+    import torch  # noqa: F401
+    import pyngp
+    time.sleep(delay)
+    x = pyngp.ShmCounterExchange(rank, world, key, 30.0)
+    if rank == 0:
+        x.publish_blob(bytes([7] * 128))
+    blob = x.fetch_blob()
+    x.barrier()
+    q.put((rank, blob == bytes([7] * 128), x.all_sum(0, 1.0, 2.0, 3.0)))
+    x.barrier()
+
+
+def test_cpp_exchange_ignores_the_leftover_segment_of_a_crashed_job():
+    """a segment a crashed job left in /dev/shm carries a valid magic, the right world size and a published (dead) communicator
+    id.  Rank 1 arrives BEFORE this job's rank 0 has replaced it; it must not keep that mapping — nobody answers its nonce there — and must end up
+    on the new segment with the new id."""
+    import multiprocessing as mp
+    import struct
+    key = "stale_%d" % os.getpid()
+    world = 2
+    n_bytes = 256 + 2 * world * 64 + world * 64
+    stale = bytearray(n_bytes)
+    struct.pack_into("<QIIQ", stale, 0, 0x6e67705f64703032, world, 0, 1)    # magic "ngp_dp02", world, pad, blob_ready = 1
+    stale[24:24 + 128] = bytes([0xEE] * 128)                                 # the dead job's unique id
+    struct.pack_into("<QQQ", stale, 256 + 2 * world * 64 + 64, 5, 5, 5)      # ... whose rank 1 had completed its handshake
+    path = "/dev/shm/ngp_dp_" + key
+    with open(path, "wb") as f:
+        f.write(stale)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_late_rank0_worker, args=(r, world, key, q, 1.5 if r == 0 else 0.0)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = [q.get(timeout=120) for _ in ps]
+        for p in ps:
+            p.join(30)
+            assert p.exitcode == 0
+        for rank, blob_ok, sums in res:
+            assert blob_ok, "rank %d read the crashed job's communicator id" % rank
+            assert sums == (2.0, 4.0, 6.0)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    assert not os.path.exists(path)

@@ -212,3 +212,118 @@ def test_albert_exr_matches_the_reference_decoder_and_the_committed_crop():
     np.testing.assert_allclose(img.reshape(-1, 4).mean(0), [0.18612, 0.18612, 0.18612, 1.0], atol=2e-5)
     crop = np.load(os.path.join(ROOT, "tests", "golden", "albert_crop_128.npy"))
     np.testing.assert_array_equal(crop, img[448:576, 448:576].astype(np.float16))
+
+
+# ---------------------------------------------------------------------------------------------------------------- hostile files
+def _replace_dht(jpeg_bytes, new_segments):
+    """drop every DHT segment of a baseline JPEG and put `new_segments` (payloads without marker / length) in front of the first SOS"""
+    out, i = bytearray(jpeg_bytes[:2]), 2
+    while i < len(jpeg_bytes):
+        assert jpeg_bytes[i] == 0xFF
+        m = jpeg_bytes[i + 1]
+        ln = struct.unpack(">H", jpeg_bytes[i + 2:i + 4])[0]
+        if m == 0xDA:
+            for seg in new_segments:
+                out += b"\xFF\xC4" + struct.pack(">H", len(seg) + 2) + seg
+            out += jpeg_bytes[i:]
+            return bytes(out)
+        if m != 0xC4:
+            out += jpeg_bytes[i:i + 2 + ln]
+        i += 2 + ln
+    raise AssertionError("no SOS")
+
+
+def _baseline_jpeg(tmp_path):
+    from PIL import Image
+    p = str(tmp_path / "ok.jpg")
+    Image.fromarray(_photo(32, 24)).save(p, quality=90, subsampling=0)
+    return open(p, "rb").read()
+
+
+@pytest.mark.parametrize("counts", [[200] + [0] * 15, [3] + [0] * 15, [1, 3] + [0] * 14, [0] * 8 + [255, 1] + [0] * 6, [2, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 7])
+def test_jpeg_oversubscribed_huffman_tables_are_rejected_before_any_write(tmp_path, counts):
+    """a DHT whose code lengths over-subscribe the code space (e.g. 200 codes of length 1) used to index past the 512-entry prefix tables of the
+    decoder object on the stack; it must raise, for DC and AC classes alike"""
+    import pyngp
+    base = _baseline_jpeg(tmp_path)
+    total = sum(counts)
+    for tc in (0, 1):
+        seg = bytes([tc << 4]) + bytes(counts) + bytes(range(total % 256)) * 0 + bytes([i % 256 for i in range(total)])
+        p = str(tmp_path / ("dht_%d.jpg" % tc))
+        open(p, "wb").write(_replace_dht(base, [seg]))
+        with pytest.raises(RuntimeError, match="Huffman"):
+            pyngp.decode_image(p)
+
+
+def test_jpeg_out_of_range_magnitude_categories_raise(tmp_path):
+    """DC categories above 11 / AC sizes above 10 would shift by 32 or more in receive_extend (undefined behaviour): one-symbol tables that
+    decode every code to such a category must raise, not shift"""
+    import pyngp
+    base = _baseline_jpeg(tmp_path)
+    one = [2] + [0] * 15                                               # the two 1-bit codes: every bit pattern decodes
+    ok_ac = bytes([0x10]) + bytes(one) + bytes([0x00, 0x00])           # AC: every code = end of block
+    bad_dc = bytes([0x00]) + bytes(one) + bytes([31, 31])              # DC: category 31
+    ok_dc = bytes([0x00]) + bytes(one) + bytes([0x00, 0x00])
+    bad_ac = bytes([0x10]) + bytes(one) + bytes([0x0F, 0x0F])          # AC: run 0, size 15
+    for name, segs in (("dc", [bad_dc, ok_ac]), ("ac", [ok_dc, bad_ac])):
+        both = []
+        for th in (0, 1):                                              # the file uses tables 0 and 1 of each class
+            both += [bytes([s[0] | th]) + s[1:] for s in segs]
+        p = str(tmp_path / ("cat_%s.jpg" % name))
+        open(p, "wb").write(_replace_dht(base, both))
+        with pytest.raises(RuntimeError, match="category|size"):
+            pyngp.decode_image(p)
+
+
+def test_jpeg_random_corruption_never_crashes(tmp_path):
+    """cheap fuzz: flip bytes of valid baseline / progressive files; every outcome is an image or a RuntimeError"""
+    import pyngp
+    from PIL import Image
+    rs = np.random.RandomState(5)
+    for kw in (dict(subsampling=2), dict(subsampling=1, progressive=True)):
+        p = str(tmp_path / "src.jpg")
+        Image.fromarray(_photo(40, 40)).save(p, quality=85, **kw)
+        src = open(p, "rb").read()
+        for it in range(150):
+            b = bytearray(src)
+            for _ in range(rs.randint(1, 6)):
+                b[rs.randint(2, len(b))] = rs.randint(0, 256)
+            q = str(tmp_path / "fuzz.jpg")
+            open(q, "wb").write(bytes(b))
+            try:
+                img = pyngp.decode_image(q)
+                assert img.ndim == 3 and img.shape[2] == 4
+            except RuntimeError:
+                pass
+
+
+def test_exr_hostile_headers_and_blocks_raise(tmp_path):
+    import pyngp
+    img = np.random.RandomState(0).rand(8, 8, 4).astype(np.float32)
+    p = str(tmp_path / "src.exr")
+    _write_exr(p, img, 1, 2)
+    raw = open(p, "rb").read()
+    key = b"dataWindow\0box2i\0" + struct.pack("<I", 16)
+    i = raw.index(key) + len(key)
+    # a data window whose extent overflows int32
+    bad = raw[:i] + struct.pack("<iiii", -2147483647, 0, 2147483647, 7) + raw[i + 16:]
+    q = str(tmp_path / "bad.exr")
+    open(q, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="data window"):
+        pyngp.decode_exr(q)
+    # a block offset near 2^64 (offset + 8 wraps around)
+    j = raw.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+    bad = raw[:j] + struct.pack("<Q", 0xFFFFFFFFFFFFFFFC) + raw[j + 8:]
+    open(q, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="offset"):
+        pyngp.decode_exr(q)
+    # an RLE block that expands far past the block's size (a flat image, so that the writer keeps the RLE form)
+    _write_exr(p, np.full((8, 8, 4), 0.25, np.float32), 1, 2)
+    raw = open(p, "rb").read()
+    off0 = struct.unpack("<Q", raw[j:j + 8])[0]
+    n0 = struct.unpack("<i", raw[off0 + 4:off0 + 8])[0]
+    bomb = (struct.pack("b", 127) + b"\x80") * (n0 // 2)
+    bad = raw[:off0 + 8] + bomb + raw[off0 + 8 + len(bomb):]
+    open(q, "wb").write(bad)
+    with pytest.raises(RuntimeError, match="RLE"):
+        pyngp.decode_exr(q)
