@@ -310,9 +310,9 @@ __device__ __forceinline__ void mlp_forward(const h8* __restrict__ lt, int lane,
 // ----------------------------------------------------------------------------------------------------------------
 // Fused forward kernel: hash encode -> density MLP -> SH -> rgb MLP.  MODE 0 inference (rgb sigma), 1 density only,
 // 2 training forward (also stores the encoded features for backward).
-// PRE = false: fully fused (gathers inside).  PRE = true: the features were produced by encode_planes_kernel into
+// PRE = 0: fully fused (gathers inside).  PRE = 1: the features were produced by encode_planes_kernel into
 // x_planes[level][n_pad] (half2 per sample); the kernel is then the MLP alone and runs at twice the occupancy.
-template <int MODE, bool PRE>
+template <int MODE, int PRE>
 __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
                                                            const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                            half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved,
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const Ng
 		const bool valid = s < n;
 		const float* c = coords + (size_t)(valid ? s : 0) * coord_stride;
 		h8 x0, x1;
-		if (PRE) {
+		if (PRE == 1) {
 			const h2* xp = x_planes + (size_t)(8 * g) * n_pad + (valid ? s : 0);
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
@@ -464,7 +464,7 @@ constexpr uint32_t ENC_QUEUE_BYTES = 8 * ENC_QUEUE_STRIDE * 4;
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
 
 __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
-                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues) {
+                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model) {
 	__shared__ uint32_t s_first[9];
 	__shared__ uint32_t s_item;
 	const uint32_t n_chunks = (n + ENC_CHUNK - 1) / ENC_CHUNK;
@@ -474,7 +474,11 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 		for (int l = 0; l < 16; ++l) {
 			const NgpGridLevel lv = desc->levels[l];
 			const uint64_t dense = (uint64_t)lv.resolution * lv.resolution * lv.resolution;
-			cost[l] = dense > lv.size ? 2u : 1u;
+			// relative cost of one (level, chunk) item = its L2 requests (the vector L1 -> L2 request path, ~0.5 per clock and CU, is what bounds a gather that hits
+			// the L2): measured per level on ray-coherent samples (one launch per level, tools/fwd_path_trace.sh): dense levels 4.2 us / 2^19 samples each, hashed
+			// levels 9 us at resolution 81 rising to 15 us from resolution ~600 on, where every sample touches its four (y, z) rows' lines alone
+			if (cost_model == 0) cost[l] = dense > lv.size ? 2u : 1u;
+			else cost[l] = dense > lv.size ? 56u + (lv.resolution < 600u ? lv.resolution * 64u / 600u : 64u) : 34u;
 			total += cost[l] * n_chunks;
 		}
 		const uint32_t target = (uint32_t)((uint64_t)total * threadIdx.x / 8u);
@@ -526,6 +530,26 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 					if (smp < n) dst[smp] = v;
 				}
 			}
+		}
+	}
+}
+
+// Encode of the levels [l0, l1) for all samples, one thread per sample, into the level planes: one LAUNCH per group of levels whose tables fit an XCD's L2
+// together.  Between two launches nothing else touches the tables, so each XCD fetches a level's 2 MiB once and serves every further touch from its L2.
+template <bool PAIR>
+__global__ void __launch_bounds__(256) encode_levels_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
+                                                                   uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t l0, uint32_t l1) {
+	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) {
+		const float* c = coords + (size_t)s * coord_stride;
+		// the positions stream through once per launch: keep them from displacing table lines in the L2
+		const float px = __builtin_nontemporal_load(c), py = __builtin_nontemporal_load(c + 1), pz = __builtin_nontemporal_load(c + 2);
+#pragma unroll 1
+		for (uint32_t l = l0; l < l1; ++l) {
+			half_t a, b;
+			encode_level<PAIR>(desc->levels[l], grid, px, py, pz, a, b);
+			h2 v; v[0] = a; v[1] = b;
+			__builtin_nontemporal_store(__builtin_bit_cast(uint32_t, v), (uint32_t*)(planes + (size_t)l * n_pad + s));
 		}
 	}
 }
@@ -1914,14 +1938,14 @@ int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint1
                            uint32_t n, uint16_t* out, uint32_t out_stride) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	hipLaunchKernelGGL((nerf_forward_kernel<0, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, (const h2*)nullptr, 0u);
+	hipLaunchKernelGGL((nerf_forward_kernel<0, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0>");
 	return 0;
 }
 
 int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0) {
 	if (n == 0) return 0;
-	hipLaunchKernelGGL((nerf_forward_kernel<1, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, (const h2*)nullptr, 0u);
+	hipLaunchKernelGGL((nerf_forward_kernel<1, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<1>");
 	return 0;
 }
@@ -1930,7 +1954,7 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
                          uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	hipLaunchKernelGGL((nerf_forward_kernel<2, false>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
+	hipLaunchKernelGGL((nerf_forward_kernel<2, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
 	return 0;
 }
@@ -1954,15 +1978,39 @@ int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const ui
 uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n) { return ENC_QUEUE_BYTES + (uint64_t)16 * next_multiple_u32(n, ENC_CHUNK) * 4u; }
 
 static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, void* workspace, uint64_t workspace_bytes,
-                         const h2** planes_out, uint32_t* n_pad_out, const char* who) {
+                         const h2** planes_out, uint32_t* n_pad_out, const char* who, const NgpNetDesc* desc_host_for_groups = nullptr) {
 	if (!workspace || workspace_bytes < ngp_hip_nerf_encode_workspace_bytes(n)) { set_last_error(who, hipErrorInvalidValue); return -1; }
 	const uint32_t n_pad = next_multiple_u32(n, ENC_CHUNK);
 	uint32_t* queues = (uint32_t*)workspace;
 	h2* planes = (h2*)((char*)workspace + ENC_QUEUE_BYTES);
+	static const int enc_mode = getenv("NGP_HIP_ENC_MODE") ? atoi(getenv("NGP_HIP_ENC_MODE")) : 0;   // dev: 1 = one launch per group of levels (NGP_HIP_ENC_GROUP_KIB of table each)
+	static NgpNetDesc cached_desc; static const NgpNetDesc* cached_for = nullptr;   // dev experiment: the level sizes decide the grouping
+	if (enc_mode == 1 && !desc_host_for_groups) {
+		if (cached_for != desc_dev) { NGP_HIP_TRY(hipMemcpy(&cached_desc, desc_dev, sizeof(NgpNetDesc), hipMemcpyDeviceToHost)); cached_for = desc_dev; }
+		desc_host_for_groups = &cached_desc;
+	}
+	if (enc_mode == 1 && desc_host_for_groups) {
+		static const uint32_t cap_kib = getenv("NGP_HIP_ENC_GROUP_KIB") ? (uint32_t)atoi(getenv("NGP_HIP_ENC_GROUP_KIB")) : 2560u;
+		static const int pair = getenv("NGP_HIP_ENC_PAIR") ? atoi(getenv("NGP_HIP_ENC_PAIR")) : 1;
+		const uint32_t blocks = div_up(n, 256u) < 2048u ? div_up(n, 256u) : 2048u;
+		uint32_t l0 = 0;
+		while (l0 < 16) {
+			uint64_t bytes = (uint64_t)desc_host_for_groups->levels[l0].size * 4u;
+			uint32_t l1 = l0 + 1;
+			while (l1 < 16 && bytes + (uint64_t)desc_host_for_groups->levels[l1].size * 4u <= (uint64_t)cap_kib * 1024u) { bytes += (uint64_t)desc_host_for_groups->levels[l1].size * 4u; ++l1; }
+			if (pair) hipLaunchKernelGGL(encode_levels_planes_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1);
+			else hipLaunchKernelGGL(encode_levels_planes_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1);
+			NGP_LAUNCH_CHECK("encode_levels_planes_kernel");
+			l0 = l1;
+		}
+		*planes_out = planes; *n_pad_out = n_pad;
+		return 0;
+	}
 	NGP_HIP_TRY(hipMemsetAsync(queues, 0, ENC_QUEUE_BYTES, (hipStream_t)stream));
 	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
 	const uint32_t blocks = items < 2048u ? items : 2048u;  // persistent: 8 workgroups per CU
-	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues);
+	static const uint32_t cost_model = getenv("NGP_HIP_ENC_COST") ? (uint32_t)atoi(getenv("NGP_HIP_ENC_COST")) : 0u;   // dev: A / B of the queue cut
+	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model);
 	NGP_LAUNCH_CHECK("encode_planes_kernel");
 	*planes_out = planes; *n_pad_out = n_pad;
 	return 0;
@@ -1974,7 +2022,7 @@ int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const ui
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_inference_ws: workspace too small")) return -1;
-	hipLaunchKernelGGL((nerf_forward_kernel<0, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, planes, n_pad);
+	hipLaunchKernelGGL((nerf_forward_kernel<0, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, planes, n_pad);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0, pre>");
 	return 0;
 }
@@ -1984,7 +2032,7 @@ int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 	if (n == 0) return 0;
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_density_ws: workspace too small")) return -1;
-	hipLaunchKernelGGL((nerf_forward_kernel<1, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, planes, n_pad);
+	hipLaunchKernelGGL((nerf_forward_kernel<1, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, planes, n_pad);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<1, pre>");
 	return 0;
 }
@@ -1995,7 +2043,7 @@ int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_forward_ws: workspace too small")) return -1;
-	hipLaunchKernelGGL((nerf_forward_kernel<2, true>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad);
+	hipLaunchKernelGGL((nerf_forward_kernel<2, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2, pre>");
 	return 0;
 }

@@ -1049,7 +1049,9 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		check(ngp_hip_nerf_forward_rays(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, m_numsteps.as<uint32_t>(), gen_counters + 0, R, max_inference, m_mlp_out.as<uint16_t>(),
 		                                OUT_STRIDE, m_x_all.as<uint16_t>(), (int)m_nerf.density_activation, getenv("NGP_HIP_FWD_STOP") ? (float)atof(getenv("NGP_HIP_FWD_STOP")) : 0.5f * 1e-4f /* half of EPSILON (testbed_nerf.cu:1345) */, gen_counters + 3), "nerf_forward_rays");
 	} else {
-		check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
+		static const bool fwd_ws = getenv("NGP_HIP_FWD_WS") != nullptr;   // dev: the two-kernel pass (encode into level planes, then the MLP kernel) instead of the fused one
+		if (fwd_ws) check(ngp_hip_nerf_forward_ws(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (ws)");
+		else check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
 	}
 	profile_end(PK_INFERENCE, max_inference);
 	if (tr.optimize_exposure) {
