@@ -32,7 +32,8 @@ BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BY
 MARCH_BYTES_PER_SAMPLE = 28    # one NerfCoordinate written per sample (nerf.h:62-107)
 MARCH_BYTES_PER_RAY = 40       # ray index 4 + Ray 24 + numsteps 8 written, one RGBA8 pixel read (testbed_nerf.cu:1232-1258)
 KERNEL_SET = "r02i"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
-GROUP_KERNELS = {"nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
+GROUP_KERNELS = {"grad_exchange": "data-parallel step: fp16 -> fp32 copy, RCCL reduce-scatter (fp32 sums), fp32 -> fp16 of this rank's shard", "param_gather": "data-parallel step: RCCL all-gather of the fp16 weights",
+                 "nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
                  "nerf_inference": "one ngp_hip_nerf_forward call: fused hash-grid encode + both MLPs (single kernel)", "optimizer_step": "adam_ema_vec4_kernel (single kernel)"}
 SURVEY_STEPS = 48              # untimed steps with every launch group bracketed by events (picks the dominant group, fills "kernels")
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
@@ -420,6 +421,32 @@ def main():
         dist.all_reduce(s)
         samples, rays, pre_compaction = (float(x) for x in s.tolist())
 
+    # ---- render MP/s + PSNR on the trained model, outside the timed region.  With the product's data-parallel communicator every render() is a collective: rank r traces
+    # the rows [r * ceil(H / N), ...) of the frame and the rows are all-gathered over RCCL (Testbed::fetch_render_surface), so ALL ranks run this leg
+    extra = {}
+    render_sharded = dp_impl == "product" and use_dp
+    if not a.no_render and (render_sharded or rank == 0):
+        psnr, ssim, per = scene.eval_test_views(tb, ds, spp=a.eval_spp, max_views=a.n_test)
+        n_frames = 3
+        if render_sharded:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(n_frames):
+            tb.set_nerf_camera_matrix(ds["test_poses"][i % len(ds["test_poses"])][:3, :])
+            tb.render(a.res, a.res, 1, True)
+        rdt = (time.perf_counter() - t1) / n_frames
+        n_render_samples = float(tb.render_samples_evaluated)
+        if render_sharded and world > 1:
+            t = torch.tensor([rdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = float(t.item())
+            t = torch.tensor([n_render_samples], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            n_render_samples = float(t.item())
+        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_network_samples_per_frame": int(n_render_samples),
+                 "render_ranks": world if render_sharded else 1, "render_rows_per_rank": (a.res + world - 1) // world if render_sharded else a.res,
+                 "psnr_db": round(psnr, 2), "ssim": round(ssim, 4), "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
+
     if rank != 0:
         if use_dp:
             dist.barrier()
@@ -481,19 +508,6 @@ def main():
         g["resident_waves"] = int(min((rays_l + 15) // 16, 512) * 4)
         g["note"] = "wave-per-ray march, %d persistent waves (two 4-wave workgroups per CU) on 1024 SIMDs; runs one step ahead on a second stream beside the backward pass" % g["resident_waves"]
 
-    # ---- render MP/s + PSNR on the trained model (rank 0), outside the timed region
-    extra = {}
-    if not a.no_render:
-        psnr, ssim, per = scene.eval_test_views(tb, ds, spp=a.eval_spp, max_views=a.n_test)
-        t1 = time.perf_counter()
-        n_frames = 3
-        for i in range(n_frames):
-            tb.set_nerf_camera_matrix(ds["test_poses"][i % len(ds["test_poses"])][:3, :])
-            tb.render(a.res, a.res, 1, True)
-        rdt = (time.perf_counter() - t1) / n_frames
-        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_network_samples_per_frame": int(tb.render_samples_evaluated),
-                 "psnr_db": round(psnr, 2), "ssim": round(ssim, 4), "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
-
     line = {
         "metric": "train samples/s (compacted samples back-propagated per second), nerf-synthetic/lego stand-in",
         "value": round(samples / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 4),
@@ -505,6 +519,14 @@ def main():
         "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
+    if use_dp:   # what the communicator itself says, and what the step's exchanges cost (HIP events on the training stream, survey steps)
+        dp_info = {"impl": dp_impl, "world_size_env": world, "rccl_comm_ranks": int(tb.dp_comm_size) if dp_impl == "product" else int(dist.get_world_size()),
+                   "sharded_optimizer": bool(tb.dp_sharded_optimizer) if dp_impl == "product" else False}
+        for k_name, label in (("grad_exchange", "grad_exchange_us_per_step"), ("param_gather", "param_gather_us_per_step")):
+            if k_name in kernels:
+                dp_info[label] = kernels[k_name]["avg_us"]
+        dp_info["exchange_us_per_step"] = round(sum(dp_info.get(k, 0.0) for k in ("grad_exchange_us_per_step", "param_gather_us_per_step")), 2)
+        line["data_parallel"] = dp_info
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(tb, ds, a.res)
     print(json.dumps(line), flush=True)

@@ -139,7 +139,8 @@ assert GLOBAL_RAY.itemsize == 52 and PROXY_RAY.itemsize == 40 and MASK3D.itemsiz
 assert DOWNSAMPLE_INFO.itemsize == 32 and RENDER_CAMERA.itemsize == 176
 LOSS_EXTRAS = np.dtype([("envmap_data", "<u8"), ("envmap_gradient", "<u8"), ("envmap_res", "<i4", 2), ("envmap_loss_type", "<i4")], align=True)   # NgpLossExtras
 RENDER_EXTRAS = np.dtype([("render_masks", "<u8"), ("n_render_masks", "<u4"), ("glow_mode", "<i4"), ("glow_y_cutoff", "<f4"), ("envmap", "<u8"), ("envmap_res", "<i4", 2),
-                          ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8")], align=True)   # NgpRenderExtras
+                          ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8"),
+                          ("row_begin", "<i4"), ("row_end", "<i4")], align=True)   # NgpRenderExtras
 
 assert AABB.itemsize == 24 and RAY.itemsize == 24 and XFORM.itemsize == 96 and COORD.itemsize == 28 and PAYLOAD.itemsize == 40
 assert NET_DESC.itemsize == 8 + 16 * 16

@@ -24,6 +24,9 @@ struct RcclApi {
 	int (*GetUniqueId)(RcclUniqueId*) = nullptr;
 	int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
 	int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+	int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*CommCount)(RcclComm, int*) = nullptr;
 	int (*CommDestroy)(RcclComm) = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
 	std::string where;
@@ -59,9 +62,12 @@ RcclApi* rccl() {
 	api.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(api.handle, "ncclGetUniqueId");
 	api.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(api.handle, "ncclCommInitRank");
 	api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclAllReduce");
+	api.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclAllGather");
+	api.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclReduceScatter");
+	api.CommCount = (int (*)(RcclComm, int*))dlsym(api.handle, "ncclCommCount");
 	api.CommDestroy = (int (*)(RcclComm))dlsym(api.handle, "ncclCommDestroy");
 	api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
-	if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
+	if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.AllGather || !api.ReduceScatter || !api.CommDestroy) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
 	return &api;
 }
 
@@ -115,6 +121,38 @@ static int all_reduce(void* comm, void* stream, void* buf, uint64_t count, int d
 int ngp_rccl_allreduce_grads(void* comm, void* stream, uint16_t* grads_f16, uint64_t n_params) { return all_reduce(comm, stream, grads_f16, n_params, RCCL_FLOAT16, "ngp_rccl_allreduce_grads"); }
 int ngp_rccl_allreduce_f32(void* comm, void* stream, float* values, uint64_t count) { return all_reduce(comm, stream, values, count, RCCL_FLOAT32, "ngp_rccl_allreduce_f32"); }
 int ngp_rccl_allreduce_counters(void* comm, void* stream, double* values, uint64_t count) { return all_reduce(comm, stream, values, count, RCCL_FLOAT64, "ngp_rccl_allreduce_counters"); }
+
+// in place: rank r's chunk sits at buf + r * count_per_rank elements before the call, every rank holds all chunks after it
+static int all_gather(void* comm, void* stream, void* buf, uint64_t count_per_rank, int dtype, size_t elem_bytes, const char* who) {
+	RcclApi* a = rccl();
+	Comm* c = (Comm*)comm;
+	if (!a || !c) { ngp::set_last_error(who, hipErrorInvalidValue); return -1; }
+	if (count_per_rank == 0) return 0;
+	const int rc = a->AllGather((const char*)buf + (size_t)c->rank * count_per_rank * elem_bytes, buf, (size_t)count_per_rank, dtype, c->comm, (hipStream_t)stream);
+	return rc ? fail(who, rc) : 0;
+}
+int ngp_rccl_allgather_f32(void* comm, void* stream, float* buf, uint64_t count_per_rank) { return all_gather(comm, stream, buf, count_per_rank, RCCL_FLOAT32, 4, "ngp_rccl_allgather_f32"); }
+int ngp_rccl_allgather_f16(void* comm, void* stream, uint16_t* buf, uint64_t count_per_rank) { return all_gather(comm, stream, buf, count_per_rank, RCCL_FLOAT16, 2, "ngp_rccl_allgather_f16"); }
+
+// sum over the ranks of `in` (world x count_per_rank elements); rank r receives elements [r * count_per_rank, (r + 1) * count_per_rank) of the sum in out
+int ngp_rccl_reduce_scatter_f32(void* comm, void* stream, const float* in, float* out, uint64_t count_per_rank) {
+	RcclApi* a = rccl();
+	Comm* c = (Comm*)comm;
+	if (!a || !c) { ngp::set_last_error("ngp_rccl_reduce_scatter_f32", hipErrorInvalidValue); return -1; }
+	if (count_per_rank == 0) return 0;
+	const int rc = a->ReduceScatter(in, out, (size_t)count_per_rank, RCCL_FLOAT32, RCCL_SUM, c->comm, (hipStream_t)stream);
+	return rc ? fail("ngp_rccl_reduce_scatter_f32", rc) : 0;
+}
+
+int ngp_rccl_comm_size(void* comm) {   // ncclCommCount: what the communicator itself says (bench.py prints it next to WORLD_SIZE)
+	RcclApi* a = rccl();
+	Comm* c = (Comm*)comm;
+	if (!a || !c) return -1;
+	int n = c->world;
+	if (a->CommCount && a->CommCount(c->comm, &n) != 0) return -1;
+	return n;
+}
+int ngp_rccl_comm_rank(void* comm) { Comm* c = (Comm*)comm; return c ? c->rank : -1; }
 
 int ngp_rccl_finalize(void* comm) {
 	Comm* c = (Comm*)comm;

@@ -1774,10 +1774,11 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 #pragma clang fp contract(off)
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_params) return;
-	float g = (float)grads[i] / loss_scale;
+	// optimize_mask bit 3 (NGP_OPT_EMA_ONLY): the Ema stage alone, no gradient is read (sharded optimizer step: the weights of other ranks' shards arrive by all-gather)
+	float g = (optimize_mask & 8u) ? 0.0f : (float)grads[i] / loss_scale;
 	half_t p16 = params[i];
 	// optimize_mask: bit 0 = matrix (MLP) parameters, bit 1 = the others (encoding) — tcnn Adam's optimize_matrix_params / optimize_non_matrix_params
-	const bool skip = i >= n_matrix_params ? (g == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u);
+	const bool skip = (optimize_mask & 8u) ? true : (i >= n_matrix_params ? (g == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u));
 	if (!skip) {
 		float w = master[i];
 		if (i < n_matrix_params) g += l2_reg * w;
@@ -1795,6 +1796,7 @@ __global__ void adam_ema_kernel(uint32_t n_params, uint32_t n_matrix_params, flo
 		p16 = (half_t)nw_rounded;
 		params[i] = p16;
 	}
+	if (optimize_mask & 4u) return;   // NGP_OPT_NO_EMA: the Adam stage alone
 	float filtered = (ema[i] * ema_decay * ema_debias_old + (float)p16 * (1.0f - ema_decay)) * ema_debias_new;
 	asm volatile("" : "+v"(filtered));
 	ema[i] = filtered;
@@ -1813,14 +1815,14 @@ __global__ void __launch_bounds__(256) adam_ema_vec4_kernel(uint32_t n_groups, u
 	NGP_RAISE_CHAIN_PRIORITY();
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_groups) return;
-	const half4_t g4 = grads[t];
+	half4_t g4 = {};
+	if (!(optimize_mask & 8u)) g4 = grads[t];
 	half4_t p4 = params[t];
-	const float4 e4 = ema[t];
 	float g[4]; bool skip[4]; bool any = false;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		g[k] = (float)g4.v[k] / loss_scale;
-		skip[k] = t * 4u + k >= n_matrix_params ? (g[k] == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u);
+		skip[k] = (optimize_mask & 8u) ? true : (t * 4u + k >= n_matrix_params ? (g[k] == 0.0f || !(optimize_mask & 2u)) : !(optimize_mask & 1u));
 		any |= !skip[k];
 	}
 	if (any) {
@@ -1843,6 +1845,8 @@ __global__ void __launch_bounds__(256) adam_ema_vec4_kernel(uint32_t n_groups, u
 		}
 		master[t] = w4; m1[t] = a4; m2[t] = b4; params[t] = p4;
 	}
+	if (optimize_mask & 4u) return;
+	const float4 e4 = ema[t];
 	float4 f4; float* f = &f4.x; const float* e = &e4.x;
 	half4_t i4;
 #pragma unroll
@@ -2254,6 +2258,31 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	return 0;
+}
+
+// fp16 <-> fp32 copies of the gradient vector around the reduce-scatter of the sharded optimizer step (the sum over the ranks is taken in fp32)
+namespace ngp {
+__global__ void __launch_bounds__(256) f16_to_f32_kernel(uint32_t n, uint32_t n_padded, const half_t* __restrict__ src, float* __restrict__ dst) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_padded) dst[i] = i < n ? (float)src[i] : 0.0f;
+}
+__global__ void __launch_bounds__(256) f32_to_f16_kernel(uint32_t n, const float* __restrict__ src, half_t* __restrict__ dst) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = (half_t)src[i];
+}
+}
+int ngp_hip_f16_to_f32(void* stream, uint32_t n, uint32_t n_padded, const uint16_t* src, float* dst) {
+	if (n_padded < n) { set_last_error("ngp_hip_f16_to_f32: n_padded < n", hipErrorInvalidValue); return -1; }
+	if (!n_padded) return 0;
+	hipLaunchKernelGGL(f16_to_f32_kernel, dim3(div_up(n_padded, 256)), dim3(256), 0, (hipStream_t)stream, n, n_padded, (const half_t*)src, dst);
+	NGP_LAUNCH_CHECK("f16_to_f32_kernel");
+	return 0;
+}
+int ngp_hip_f32_to_f16(void* stream, uint32_t n, const float* src, uint16_t* dst) {
+	if (!n) return 0;
+	hipLaunchKernelGGL(f32_to_f16_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, src, (half_t*)dst);
+	NGP_LAUNCH_CHECK("f32_to_f16_kernel");
 	return 0;
 }
 

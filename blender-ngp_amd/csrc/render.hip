@@ -12,6 +12,7 @@ namespace ngp {
 struct RenderExtras {
 	const NgpMask3D* render_masks; uint32_t n_render_masks; int glow_mode; float glow_y_cutoff;
 	const float* envmap; int envmap_res[2]; const float* distortion; int distortion_res[2]; int quilting_dims[2]; int render_mode; float4* frame_buffer;
+	int row_begin, row_end;   // the rows this launch sets up (a shard of the frame, or 0 .. res[1])
 };
 
 struct InitRaysArgs {
@@ -23,9 +24,10 @@ struct InitRaysArgs {
 };
 
 __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
-	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y;
-	if (x >= (uint32_t)a.res[0] || y >= (uint32_t)a.res[1]) return;
-	const uint32_t idx = x + (uint32_t)a.res[0] * y;
+	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y + (uint32_t)a.ex.row_begin;
+	if (x >= (uint32_t)a.res[0] || y >= (uint32_t)a.ex.row_end) return;
+	// idx: the pixel in the WHOLE frame (frame / depth buffer slot, key of every per-pixel random number); slot: its payload in this launch's ray array
+	const uint32_t idx = x + (uint32_t)a.res[0] * y, slot = idx - (uint32_t)a.res[0] * (uint32_t)a.ex.row_begin;
 	float parallax_shift[3] = {a.parallax_shift[0], a.parallax_shift[1], a.parallax_shift[2]};
 	const int qx = a.ex.quilting_dims[0], qy = a.ex.quilting_dims[1];
 	if (qx != 1 || qy != 1) {   // apply_quilting (common_device.cuh:541-560): the pixel inside its panel, the panel's parallax
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	}
 	}
 
-	NgpPayload p = a.payloads[idx];
+	NgpPayload p = a.payloads[slot];
 	p.max_weight = 0.0f;
 	if (a.plane_z < 0) {   // slice plane (1913-1923): the ray stops at depth -plane_z along the view axis
 		const float n = norm(dir);
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 		p.dir[0] = dn.x; p.dir[1] = dn.y; p.dir[2] = dn.z;
 		p.t = -a.plane_z * n; p.idx = idx; p.n_steps = 0; p.alive = 0;
 		a.depthbuffer[idx] = -a.plane_z;
-		a.payloads[idx] = p;
+		a.payloads[slot] = p;
 		return;
 	}
 	a.depthbuffer[idx] = 1e10f;
@@ -112,14 +114,14 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	p.origin[0] = origin.x; p.origin[1] = origin.y; p.origin[2] = origin.z;
 	if (!aabb_contains(a.render_aabb, mat3_mul(a.to_local.m, origin + dir * t))) {
 		p.alive = 0;
-		a.payloads[idx] = p;
+		a.payloads[slot] = p;
 		return;
 	}
 	bool ray_intersects_any_mask = a.ex.n_render_masks == 0;   // 1943-1956
 	for (uint32_t k = 0; k < a.ex.n_render_masks && !ray_intersects_any_mask; ++k) ray_intersects_any_mask = mask_intersects_ray(a.ex.render_masks[k], origin, dir);
 	if (!ray_intersects_any_mask) {
 		p.alive = 0;
-		a.payloads[idx] = p;
+		a.payloads[slot] = p;
 		return;
 	}
 	if (a.ex.render_mode == 5) {   // Distortion (1959-1970): paint the map's offset at the pixel centre, the ray is done
@@ -131,17 +133,17 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 		const v3 far = origin + dir * 10000.0f;
 		p.origin[0] = far.x; p.origin[1] = far.y; p.origin[2] = far.z;
 		p.alive = 0;
-		a.payloads[idx] = p;
+		a.payloads[slot] = p;
 		return;
 	}
 	p.dir[0] = dir.x; p.dir[1] = dir.y; p.dir[2] = dir.z;
 	p.t = t; p.idx = idx; p.n_steps = 0; p.alive = 1;
-	a.payloads[idx] = p;
+	a.payloads[slot] = p;
 }
 
 template <bool CONST_DT>   // cone_angle == 0: see calc_dt_t
 __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
-                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
+                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	if (i >= n_elements) return;
 	NgpPayload& payload = payloads[i];
@@ -151,7 +153,7 @@ __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 
 	const float cone_angle = cone_angle_constant;
 	float t = payload.t;
 	float dt = calc_dt(t, cone_angle);
-	t += ld_random_val(sample_index, i * 786433u) * dt;
+	t += ld_random_val(sample_index, (i + first_pixel) * 786433u) * dt;   // keyed by the pixel's index in the whole frame: a sharded frame jitters like the whole one
 	v3 pos;
 	OccBrick occ;
 	while (1) {
@@ -469,19 +471,12 @@ using namespace ngp;
 
 extern "C" {
 
-int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
-                      const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
-                      const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
-                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
-                      float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host) {
-	return ngp_hip_init_rays_ex(stream, sample_index, payloads, res_host, focal_length_host, camera_matrix0_host, camera_matrix1_host, rolling_shutter_host, screen_center_host, parallax_shift_host,
-	                            snap_to_pixel_centers, render_aabb_host, render_aabb_to_local_host, near_distance, lens_mode, lens_params_host, depthbuffer, plane_z, aperture_size, camera_models_host, nullptr);
-}
-
 static int extras_from_host(const NgpRenderExtras* e, RenderExtras& x, const char* who) {
 	x.render_masks = nullptr; x.n_render_masks = 0; x.glow_mode = 0; x.glow_y_cutoff = 0.f; x.envmap = nullptr; x.envmap_res[0] = x.envmap_res[1] = 0;
 	x.distortion = nullptr; x.distortion_res[0] = x.distortion_res[1] = 0; x.quilting_dims[0] = x.quilting_dims[1] = 1; x.render_mode = 1; x.frame_buffer = nullptr;
+	x.row_begin = x.row_end = 0;
 	if (!e) return 0;
+	x.row_begin = e->row_begin; x.row_end = e->row_end;
 	x.render_masks = e->n_render_masks ? e->render_masks : nullptr; x.n_render_masks = e->render_masks ? e->n_render_masks : 0;
 	x.glow_mode = e->glow_mode; x.glow_y_cutoff = e->glow_y_cutoff;
 	if (e->envmap && e->envmap_res[0] > 0 && e->envmap_res[1] > 0) { x.envmap = e->envmap; x.envmap_res[0] = e->envmap_res[0]; x.envmap_res[1] = e->envmap_res[1]; }
@@ -492,13 +487,16 @@ static int extras_from_host(const NgpRenderExtras* e, RenderExtras& x, const cha
 	return 0;
 }
 
-int ngp_hip_init_rays_ex(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
-                         const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
-                         const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
-                         const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
-                         float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host, const NgpRenderExtras* extras_host) {
+int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
+                      const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
+                      const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
+                      const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer,
+                      float plane_z, float aperture_size, const NgpRenderCamera* camera_models_host, const NgpRenderExtras* extras_host) {
 	InitRaysArgs a;
-	if (extras_from_host(extras_host, a.ex, "ngp_hip_init_rays_ex: an envmap or the Distortion mode needs extras->frame_buffer")) return -1;
+	if (extras_from_host(extras_host, a.ex, "ngp_hip_init_rays: an envmap or the Distortion mode needs extras->frame_buffer")) return -1;
+	if (a.ex.row_begin == 0 && a.ex.row_end == 0) a.ex.row_end = res_host[1];
+	if (a.ex.row_begin < 0 || a.ex.row_end > res_host[1] || a.ex.row_begin > a.ex.row_end) { set_last_error("ngp_hip_init_rays: row range outside the frame", hipErrorInvalidValue); return -1; }
+	if (a.ex.row_begin == a.ex.row_end) return 0;
 	a.plane_z = plane_z; a.aperture_size = aperture_size;
 	a.camera_model = camera_models_host ? camera_models_host->model : 0;
 	a.sq_width = a.sq_height = a.sq_curvature = 0.f;
@@ -518,17 +516,17 @@ int ngp_hip_init_rays_ex(void* stream, uint32_t sample_index, NgpPayload* payloa
 	for (int i = 0; i < 7; ++i) a.lens_params[i] = lens_params_host ? lens_params_host[i] : 0.0f;
 	a.depthbuffer = depthbuffer;
 	const dim3 threads(16, 8, 1);
-	const dim3 blocks(div_up((uint32_t)res_host[0], 16), div_up((uint32_t)res_host[1], 8), 1);
+	const dim3 blocks(div_up((uint32_t)res_host[0], 16), div_up((uint32_t)(a.ex.row_end - a.ex.row_begin), 8), 1);
 	hipLaunchKernelGGL(init_rays_kernel, blocks, threads, 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("init_rays_kernel");
 	return 0;
 }
 
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host, uint32_t sample_index,
-                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel) {
 	if (!n_elements) return 0;
-	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
-	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, first_pixel);
+	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, first_pixel);
 	NGP_LAUNCH_CHECK("advance_pos_kernel");
 	return 0;
 }
@@ -553,23 +551,8 @@ int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAab
 
 int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
                       NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                      int density_activation, float min_transmittance) {
-	return ngp_hip_composite_mode(stream, n_elements, current_step, aabb_host, camera_matrix_host, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation,
-	                              density_activation, min_transmittance, 1, 1.0f, -1);
-}
-
-int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
-                           NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                           int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel) {
-	if (render_mode == 2 || render_mode == 8) { set_last_error("ngp_hip_composite_mode: render mode Normals / EncodingVis goes through ngp_hip_composite_ex (the tracer runs an extra network pass for them)", hipErrorInvalidValue); return -1; }
-	return ngp_hip_composite_ex(stream, n_elements, current_step, aabb_host, camera_matrix_host, rgba, depth, payloads, network_input, network_output, out_stride, n_steps, rgb_activation,
-	                            density_activation, min_transmittance, render_mode, depth_scale, show_accel, nullptr);
-}
-
-int ngp_hip_composite_ex(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
-                         NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                         int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host) {
-	if (render_mode < 0 || render_mode > 8) { set_last_error("ngp_hip_composite_ex: render mode out of range (ERenderMode 0..7, EncodingVis 8)", hipErrorInvalidValue); return -1; }
+                      int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host) {
+	if (render_mode < 0 || render_mode > 8) { set_last_error("ngp_hip_composite: render mode out of range (ERenderMode 0..7, EncodingVis 8)", hipErrorInvalidValue); return -1; }
 	RenderExtras ex;
 	extras_from_host(nullptr, ex, "");
 	if (extras_host) { RenderExtras t; extras_from_host(extras_host, t, ""); ex.render_masks = t.render_masks; ex.n_render_masks = t.n_render_masks; ex.glow_mode = t.glow_mode; ex.glow_y_cutoff = t.glow_y_cutoff; }
@@ -580,11 +563,8 @@ int ngp_hip_composite_ex(void* stream, uint32_t n_elements, uint32_t current_ste
 	return 0;
 }
 
-int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer) {
-	return ngp_hip_shade_mode(stream, n_elements, rgba, depth, payloads, train_in_linear_colors, frame_buffer, depth_buffer, 1);
-}
-int ngp_hip_shade_mode(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
-                       int render_mode) {
+int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
+                  int render_mode) {
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(shade_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, (const float4*)rgba, depth, payloads, train_in_linear_colors != 0, (float4*)frame_buffer, depth_buffer, render_mode);
 	NGP_LAUNCH_CHECK("shade_kernel");

@@ -493,6 +493,11 @@ PYBIND11_MODULE(pyngp, m) {
 			"One process per GPU of one node: after this call frame() / train() run the data-parallel step (shared-memory counter exchange, RCCL gradient all-reduce over xGMI). "
 			"`key` names the rendezvous and must be the same on every rank of the job (e.g. MASTER_PORT). strong_scaling: train(B) back-propagates B / world_size samples per rank.")
 		.def("shutdown_data_parallel", &Testbed::shutdown_data_parallel, py::call_guard<py::gil_scoped_release>())
+		.def("set_render_shard", &Testbed::set_render_shard, py::arg("rank"), py::arg("world_size"),
+			"render() traces only the rows of shard `rank` of `world_size` (rows [rank * ceil(H / world), ...)); the rest of the returned frame is background. With init_data_parallel the split and the gather happen inside render().")
+		.def("render_shard_rows", [](Testbed& t, int height) { int a, b; t.render_shard_rows(height, a, b); return py::make_tuple(a, b); }, py::arg("height"))
+		.def_readwrite("dp_sharded_optimizer", &Testbed::m_dp_sharded_optimizer, "data-parallel step: reduce-scatter (fp32 sums) -> Adam on this rank's 1 / world of the parameters -> all-gather of the fp16 weights (default); False: fp16 all-reduce of the gradients, the whole optimizer step on every rank")
+		.def_property_readonly("dp_comm_size", [](Testbed& t) { return t.m_dp_comm ? ngp_rccl_comm_size(t.m_dp_comm) : 0; }, "ranks of the RCCL communicator of init_data_parallel (ncclCommCount), 0 without one")
 		.def_readonly("world_size", &Testbed::m_world_size)
 		.def_readonly("rank", &Testbed::m_rank)
 		.def_readonly("strong_scaling", &Testbed::m_dp_strong_scaling)
@@ -617,7 +622,7 @@ PYBIND11_MODULE(pyngp, m) {
 		// live per-kernel timing with HIP events on the launch stream (bench.py roofline numbers)
 		.def("set_profiling", [](Testbed& t, bool on, const std::vector<std::string>& only, uint32_t every) {
 				// only: names as in profile(); empty = all kinds.  Every bracketed launch group costs two event records on the stream.
-				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep"};
+				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep", "grad_exchange", "param_gather"};
 				uint32_t mask = only.empty() ? ~0u : 0u;
 				for (const auto& n : only) {
 					bool found = false;
@@ -631,7 +636,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("profile", [](Testbed& t) {
 				t.sync();
 				t.profile_collect();
-				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep"};
+				static const char* names[Testbed::PK_COUNT] = {"generate_training_samples", "nerf_inference", "compute_loss", "nerf_forward", "nerf_backward", "optimizer_step", "density_grid_prep", "grad_exchange", "param_gather"};
 				py::dict d;
 				for (int k = 0; k < Testbed::PK_COUNT; ++k) {
 					py::dict e;

@@ -686,9 +686,10 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	if (config.contains("optimizer")) parse_optimizer_config(config["optimizer"]);
 	m_optimizer_step = 0;
 
-	m_params.resize(m_n_params * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize(m_n_params * 2);
-	m_master.resize(m_n_params * 4); m_first_moments.resize(m_n_params * 4); m_second_moments.resize(m_n_params * 4); m_ema.resize(m_n_params * 4);
-	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream);
+	// (+ DP_PARAM_SLACK elements behind the weights and the gradients: the sharded optimizer step all-gathers world equal shards in place, the last one padded)
+	m_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize((m_n_params + DP_PARAM_SLACK) * 2);
+	m_master.resize((m_n_params + DP_PARAM_SLACK) * 4); m_first_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_second_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_ema.resize(m_n_params * 4);
+	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream); m_params.memset(0, m_stream); m_master.memset(0, m_stream);
 	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>()), "ngp_hip_nerf_init_params");
 
 	{   // distortion map model (testbed.cu:2386-2396) and envmap model (2447-2462): their own optimizers, else the network's
@@ -853,7 +854,18 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 	if (!m_dp_comm) { m_dp_shm.reset(); set_distributed(0, 1); throw std::runtime_error{std::string{"ngp_rccl_init failed: "} + ngp_hip_last_error()}; }
 	m_dp_shm->barrier();
 }
+// The sharded optimizer step leaves the fp32 state (master weights, Adam moments) of other ranks' shards stale.  Whoever needs the whole state — a snapshot with
+// optimizer state, training on after shutdown_data_parallel — gathers it first.  Collective: every rank of the communicator calls it.
+void Testbed::dp_gather_optimizer_state() {
+	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) return;
+	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
+	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_master.as<float>(), shard), "ngp_rccl_allgather_f32 (master weights)");
+	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_first_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (first moments)");
+	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_second_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (second moments)");
+	sync();
+}
 void Testbed::shutdown_data_parallel() {
+	if (m_dp_comm && m_stream) { try { dp_gather_optimizer_state(); } catch (...) {} }
 	if (m_dp_comm) { if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream); ngp_rccl_finalize(m_dp_comm); m_dp_comm = nullptr; }
 	m_dp_shm.reset();
 }
@@ -878,7 +890,11 @@ void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  //
 		double sum[3];
 		m_dp_shm->all_sum(m_dp_exchange_step++, mine, sum);
 		train_nerf_dp_backward(B, (uint32_t)sum[0], (uint32_t)sum[1], get_loss_scalar, (float)sum[2]);
-		check(ngp_rccl_allreduce_grads(m_dp_comm, m_stream, m_grads.as<uint16_t>(), m_n_params), "ngp_rccl_allreduce_grads");
+		if (!m_dp_sharded_optimizer) {   // the round-1 / round-2 exchange: fp16 all-reduce of the whole gradient vector, the optimizer step replicated on every rank
+			profile_begin(PK_GRAD_EXCHANGE);
+			check(ngp_rccl_allreduce_grads(m_dp_comm, m_stream, m_grads.as<uint16_t>(), m_n_params), "ngp_rccl_allreduce_grads");
+			profile_end(PK_GRAD_EXCHANGE, m_n_params);
+		}
 		train_nerf_dp_end();
 		return;
 	}
@@ -1226,7 +1242,45 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 	// as a torch ExternalStream; a caller without stream ordering calls sync() before and after its collective instead
 }
 
+// The data-parallel optimizer step: reduce-scatter -> Adam on this rank's shard -> all-gather (SURVEY.md §5 "Distributed communication backend").
+//   * the ranks' fp16 gradient vectors are summed in FP32 (each is the exact sum of its rank's terms rounded once, §5.2; summing them in fp16 would round world - 1 more
+//     times) and every rank receives 1 / world of the sum — half the wire volume of the all-reduce for this half of the exchange;
+//   * Adam (28 B / parameter of fp32 state) runs on that shard only: 1 / world of the 62 us sweep;
+//   * the new fp16 weights are all-gathered in place (2 B / parameter); the Ema stage reads fp16 weights only, so every rank runs it over all parameters from the gathered
+//     weights (12 B / parameter, no wire).  The fp32 state (master weights, moments) stays sharded: rank r owns elements [r * shard, (r + 1) * shard).
+// Element for element the arithmetic of the replicated step: tests/test_dp_cpu.py (gloo, oracle) and tests/test_dp_gpu.py (shards on one GPU) compare bit for bit.
+void Testbed::optimizer_step_sharded() {
+	++m_optimizer_step;
+	const uint32_t world = m_world_size, rank = m_rank;
+	const uint32_t shard = next_multiple(((uint32_t)m_n_params + world - 1) / world, 8u);
+	if ((uint64_t)shard * world > m_n_params + DP_PARAM_SLACK) throw std::runtime_error{"optimizer_step_sharded: world size too large for the parameter buffers' slack"};
+	m_dp_grads_f32.enlarge((size_t)shard * world * 4); m_dp_shard_f32.enlarge((size_t)shard * 4);
+	const uint32_t off = shard * rank;
+	const uint32_t mine = off < m_n_params ? std::min<uint32_t>(shard, (uint32_t)m_n_params - off) : 0u;
+	const uint32_t mask = (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u);
+	const float ema_decay = m_use_ema ? m_ema_decay : 0.0f;
+	profile_begin(PK_GRAD_EXCHANGE);
+	check(ngp_hip_f16_to_f32(m_stream, (uint32_t)m_n_params, shard * world, m_grads.as<uint16_t>(), m_dp_grads_f32.as<float>()), "f16_to_f32 (gradients)");
+	check(ngp_rccl_reduce_scatter_f32(m_dp_comm, m_stream, m_dp_grads_f32.as<float>(), m_dp_shard_f32.as<float>(), shard), "ngp_rccl_reduce_scatter_f32 (gradients)");
+	check(ngp_hip_f32_to_f16(m_stream, shard, m_dp_shard_f32.as<float>(), m_grads.as<uint16_t>() + off), "f32_to_f16 (gradient shard)");
+	profile_end(PK_GRAD_EXCHANGE, m_n_params);
+	profile_begin(PK_OPTIMIZER);
+	if (mine) check(ngp_hip_optimizer_step_masked(m_stream, mine, m_n_matrix_params > off ? m_n_matrix_params - off : 0u, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	                                              ema_decay, m_grads.as<uint16_t>() + off, m_master.as<float>() + off, m_params.as<uint16_t>() + off, m_first_moments.as<float>() + off,
+	                                              m_second_moments.as<float>() + off, nullptr, nullptr, mask | NGP_OPT_NO_EMA), "optimizer_step (Adam, this rank's shard)");
+	profile_end(PK_OPTIMIZER, mine);
+	profile_begin(PK_PARAM_GATHER);
+	check(ngp_rccl_allgather_f16(m_dp_comm, m_stream, m_params.as<uint16_t>(), shard), "ngp_rccl_allgather_f16 (weights)");
+	profile_end(PK_PARAM_GATHER, m_n_params);
+	check(ngp_hip_optimizer_step_masked(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
+	                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema, all parameters)");
+	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
+		m_learning_rate *= m_decay_base;
+	}
+}
+
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
+	if (m_dp_comm && m_dp_sharded_optimizer) { optimizer_step_sharded(); return; }
 	++m_optimizer_step;
 	profile_begin(PK_OPTIMIZER);
 	check(ngp_hip_optimizer_step_masked(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
@@ -1392,9 +1446,9 @@ std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool l
 	auto start = std::chrono::steady_clock::now();
 	const float no_rolling_shutter[4] = {0.f, 0.f, 0.f, 0.f};   // python_api.cu:177 (Vector4f::Zero())
 	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, no_rolling_shutter, rb, !linear);
-	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	std::vector<float> out((size_t)width * height * 4);
-	rb.surface.copy_to_host(out.data(), out.size() * 4);
+	fetch_render_surface(rb, out);
+	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	return out;
 }
 
@@ -1411,10 +1465,41 @@ std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& came
 		if (m_autofocus) autofocus();
 		render_frame(c0, c1, rolling_shutter, rb, !linear);
 	}
-	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	std::vector<float> out((size_t)width * height * 4);
-	rb.surface.copy_to_host(out.data(), out.size() * 4);
+	fetch_render_surface(rb, out);
+	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
 	return out;
+}
+
+// ---- a frame rendered by several ranks -------------------------------------------------------------------------------------
+// Rows [r * ceil(H / P), (r + 1) * ceil(H / P)) go to rank r (the last rank's range is cut at H; equal chunks keep the gather one collective).  With a
+// data-parallel communicator (init_data_parallel) every render() is sharded over its ranks and every rank returns the whole frame; set_render_shard is the
+// same split without a communicator: the caller renders (rank, world) and owns the gather (tests; a host with its own transport).
+void Testbed::set_render_shard(uint32_t rank, uint32_t world) {
+	if (world == 0 || rank >= world) throw std::runtime_error{"set_render_shard: bad rank / world"};
+	m_render_shard_rank = rank; m_render_shard_world = world;
+}
+void Testbed::render_shard_rows(int height, int& row_begin, int& row_end) const {
+	const bool dp = m_dp_comm && m_world_size > 1;
+	const uint32_t world = dp ? m_world_size : m_render_shard_world, rank = dp ? m_rank : m_render_shard_rank;
+	const int rows_per = (height + (int)world - 1) / (int)world;
+	row_begin = std::min(height, (int)rank * rows_per);
+	row_end = std::min(height, row_begin + rows_per);
+}
+void Testbed::fetch_render_surface(RenderBuffer& rb, std::vector<float>& out) {
+	const int W = rb.res[0], H = rb.res[1];
+	if (!(m_dp_comm && m_world_size > 1)) { rb.surface.copy_to_host(out.data(), out.size() * 4); return; }
+	// all-gather of the ranks' row ranges (RCCL over xGMI, in place in a buffer of world equal chunks), then one copy to the host
+	int row_begin, row_end;
+	render_shard_rows(H, row_begin, row_end);
+	const int rows_per = (H + (int)m_world_size - 1) / (int)m_world_size;
+	const size_t chunk_floats = (size_t)rows_per * W * 4;
+	m_render_gather.enlarge(chunk_floats * m_world_size * 4);
+	float* gather = m_render_gather.as<float>();
+	if (row_end > row_begin) HIP_CHECK_THROW(hipMemcpyAsync(gather + chunk_floats * m_rank, rb.surface.as<float>() + (size_t)row_begin * W * 4, (size_t)(row_end - row_begin) * W * 16, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, gather, chunk_floats), "ngp_rccl_allgather_f32 (frame rows)");
+	HIP_CHECK_THROW(hipMemcpyAsync(out.data(), gather, out.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+	sync();
 }
 
 void Testbed::autofocus() {  // testbed.cu:2933-2941: focus on m_autofocus_target
@@ -1468,7 +1553,13 @@ void Testbed::prepare_nerf_masks() {  // testbed_nerf.cu:2339-2352
 }
 
 void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], const float screen_center[2]) {  // testbed_nerf.cu:2354-2500, 2047-2267
-	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)rb.res[1];
+	// A frame rendered by several ranks (SURVEY.md §8e "Render: image tiles/rows per rank + gather"): this rank traces the rows [row_begin, row_end) only.  Rays are
+	// independent and every per-pixel random number is keyed by the pixel's index in the whole frame, so the rows are the rows of the frame rendered at once;
+	// render_to_cpu gathers them.  n_pixels below = the pixels THIS rank traces.
+	int row_begin = 0, row_end = rb.res[1];
+	render_shard_rows(rb.res[1], row_begin, row_end);
+	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)(row_end - row_begin), first_pixel = (uint32_t)rb.res[0] * (uint32_t)row_begin;
+	if (n_pixels == 0) return;
 	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY) + 256;   // + 256: the input-gradient pass of the Normals mode works on multiples of 256
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
 	m_tr_hit_payload.enlarge(n_el * sizeof(NgpPayload)); m_tr_hit_rgba.enlarge(n_el * 16); m_tr_hit_depth.enlarge(n_el * 4);
@@ -1491,9 +1582,10 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	}
 	ex.quilting_dims[0] = m_quilting_dims[0]; ex.quilting_dims[1] = m_quilting_dims[1];
 	ex.render_mode = render_mode; ex.frame_buffer = rb.frame_buffer.as<float>();
+	ex.row_begin = row_begin; ex.row_end = row_end;
 	float parallax_shift[3] = {m_parallax_shift[0], m_parallax_shift[1], m_parallax_shift[2]};
 	if ((m_quilting_dims[0] != 1 || m_quilting_dims[1] != 1) && !(m_quilting_dims[0] == 2 && m_quilting_dims[1] == 1)) parallax_shift[2] = 1.0f / m_scale;   // testbed.cu:2703-2706 (lenticular display)
-	check(ngp_hip_init_rays_ex(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, parallax_shift, m_snap_to_pixel_centers,
+	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, parallax_shift, m_snap_to_pixel_centers,
 	                           &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
 	                           plane_z, m_aperture_size, m_render_camera_models.model ? &m_render_camera_models : nullptr, &ex), "init_rays");
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
@@ -1508,7 +1600,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			check(ngp_hip_nerf_visualize_activation(m_stream, desc, m_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, m_tr_net_in.as<float>(), 7, n_hit, m_tr_vis_rgba.as<float>(), 4), "visualize_activation (slice)");
 		}
 		m_render_samples_evaluated += n_elements;
-		check(ngp_hip_shade_mode(m_stream, n_hit, m_tr_vis_rgba.as<float>(), nullptr, m_tr_payload[0].as<NgpPayload>(), m_nerf.training.linear_colors, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(),
+		check(ngp_hip_shade(m_stream, n_hit, m_tr_vis_rgba.as<float>(), nullptr, m_tr_payload[0].as<NgpPayload>(), m_nerf.training.linear_colors, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(),
 		                         (int)m_render_mode), "shade (slice)");
 		return;
 	}
@@ -1516,7 +1608,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;
 	check(ngp_hip_advance_pos(m_stream, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
-	                          min_mip, m_nerf.cone_angle_constant), "advance_pos");
+	                          min_mip, m_nerf.cone_angle_constant, first_pixel), "advance_pos");
 
 	HIP_CHECK_THROW(hipMemsetAsync(hit_counter, 0, 4, (hipStream_t)m_stream));
 
@@ -1595,7 +1687,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			} else if (render_mode == 8) {                    // 2227-2228: network.visualize_activation(stream, layer, dim, positions, positions)
 				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
 			}
-			check(ngp_hip_composite_ex(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
+			check(ngp_hip_composite(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
 			                           (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,
 			                           1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel, &ex), "composite");
 			pt.i += n_steps;
@@ -1604,7 +1696,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	uint32_t n_hit = 0;
 	HIP_CHECK_THROW(hipMemcpyAsync(&n_hit, hit_counter, 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
 	sync();
-	check(ngp_hip_shade_mode(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
+	check(ngp_hip_shade(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
 	                         rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(), (int)m_render_mode), "shade");
 }
 
@@ -1672,6 +1764,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	if (m_n_params == 0) throw std::runtime_error{"save_snapshot: no network"};
 	drop_prefetch();
 	sync();
+	if (include_optimizer_state) dp_gather_optimizer_state();   // data-parallel with the sharded optimizer: a collective — every rank calls save_snapshot (it may write to its own path)
 	Json snapshot = Json::object();
 	// Trainer::serialize [tcnn]: the inference (EMA) weights in the network precision
 	snapshot["n_params"] = Json((unsigned long long)m_n_params);

@@ -285,6 +285,19 @@ public:
 	// samples per rank (the reference's convergence per step); otherwise B per rank (world x the global batch).  After this frame() / train() work
 	// at world_size > 1 like at 1.
 	void init_data_parallel(uint32_t rank, uint32_t world_size, const std::string& key, bool strong_scaling);
+	// a frame rendered in row shards (testbed.cpp "a frame rendered by several ranks"): with a data-parallel communicator render() is sharded over its ranks
+	// automatically; set_render_shard makes this Testbed trace the rows of (rank, world) only, the rest of the surface stays background
+	void set_render_shard(uint32_t rank, uint32_t world);
+	void render_shard_rows(int height, int& row_begin, int& row_end) const;
+	void fetch_render_surface(RenderBuffer& rb, std::vector<float>& out);
+	uint32_t m_render_shard_rank = 0, m_render_shard_world = 1;
+	DeviceBuffer m_render_gather;
+	// the data-parallel optimizer step (testbed.cpp optimizer_step_sharded): reduce-scatter -> Adam on the rank's shard -> all-gather; false: fp16 all-reduce + replicated step
+	bool m_dp_sharded_optimizer = true;
+	static constexpr size_t DP_PARAM_SLACK = 1024;   // elements behind the weights / gradients: world x shard (shard a multiple of 8) may exceed n_params by < 8 x world
+	DeviceBuffer m_dp_grads_f32, m_dp_shard_f32;
+	void optimizer_step_sharded();
+	void dp_gather_optimizer_state();   // collective: the whole fp32 optimizer state on every rank (before a snapshot with optimizer state / leaving data-parallel mode)
 	void shutdown_data_parallel();
 	bool m_dp_strong_scaling = false;
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
@@ -447,7 +460,7 @@ public:
 	uint64_t m_render_samples_evaluated = 0;          // network samples of the last render_to_cpu (for MP/s + roofline accounting)
 
 	// ---- live kernel timing (HIP events on m_stream, the stream the kernels are launched on): bench.py's roofline numbers
-	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_COUNT };
+	enum ProfKernel { PK_GEN_SAMPLES = 0, PK_INFERENCE, PK_LOSS, PK_FORWARD, PK_BACKWARD, PK_OPTIMIZER, PK_GRID_PREP, PK_GRAD_EXCHANGE, PK_PARAM_GATHER, PK_COUNT };
 	struct ProfAccum { double ms = 0; uint64_t launches = 0; uint64_t units = 0; };
 	bool m_counters_host_seen = true;                  // the host polled the counters of the step begun last (else the run-ahead march waits for the counters event)
 	bool m_async_training_steps = false;              // frame() returns with the step's tail (backward, optimizer) still running on the stream

@@ -169,6 +169,14 @@ int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_pa
 int ngp_hip_optimizer_step_masked(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
                                   float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
                                   float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask);
+/* Two more bits of optimize_mask split the step into its stages, for the SHARDED optimizer step of the data-parallel path: a rank runs the Adam stage
+ * on its 1 / world of the parameters (pointers advanced to the shard, n_matrix_params counted from there), the fp16 weights are all-gathered, and the Ema stage — which
+ * reads the fp16 weights only — runs over all parameters on every rank.  Element-wise the same arithmetic as the unsplit step, bit for bit. */
+#define NGP_OPT_NO_EMA 4u     /* Adam stage alone: ema / inference_params are not touched (may be NULL) */
+#define NGP_OPT_EMA_ONLY 8u   /* Ema stage alone: grads / master / moments are not touched (may be NULL) */
+/* fp16 <-> fp32 copies around the fp32 reduce-scatter of that step: dst[i] = src[i] for i < n, 0 for n <= i < n_padded */
+int ngp_hip_f16_to_f32(void* stream, uint32_t n, uint32_t n_padded, const uint16_t* src, float* dst);
+int ngp_hip_f32_to_f16(void* stream, uint32_t n, const float* src, uint16_t* dst);
 
 /* ============================ occupancy grid (src/testbed_nerf.cu:369-610, 2761-2859) ============================ */
 int ngp_hip_mark_untrained_density_grid(void* stream, uint32_t n_elements, float* grid_out, uint32_t n_training_images,
@@ -317,34 +325,60 @@ int ngp_hip_gather_words(void* stream, const uint32_t* a, const uint32_t* b, con
 int ngp_hip_post_words(void* stream, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t tag, uint32_t* dst4, uint32_t* zero_words, uint32_t n_zero_words,
                        double* sum3_dev /* optional DEVICE copy {(double)*a, (double)*b, (double)(float)*c}: the operand of a data-parallel host's counter all-reduce */);
 
-/* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============ */
+/* ============================ renderer (src/testbed_nerf.cu:612-989, 1748-1978; src/render_buffer.cu:235-348, 540-567) ============
+ * NgpRenderExtras carries what init_rays_with_payload_kernel_nerf (:1809-1978) and composite_kernel_nerf (:767-989) take beyond their
+ * camera / ray arguments, and the row range of a frame that is rendered in shards (SURVEY.md §8e "Render: image tiles/rows per rank + gather").
+ * Host struct; the pointers inside are device pointers (or NULL).  A NULL NgpRenderExtras* means all defaults (whole frame, nothing extra). */
+typedef struct {                                                     /* mask_3D.cuh:129-255 Mask3D (shared with the Blender renderer below) */
+	int32_t mode;             /* EMaskMode: 0 Add, 1 Subtract */
+	int32_t shape;            /* EMaskShape: 0 Box, 1 Cylinder, 2 Sphere, 3 All */
+	float transform[16], itransform[16];
+	float config[6];          /* box: dims xyz; cylinder: radius, height; sphere: radius */
+	float feather, opacity;
+} NgpMask3D;
+typedef struct {
+	const NgpMask3D* render_masks; uint32_t n_render_masks;   /* Testbed::prepare_nerf_masks (:2339-2352): rays that hit no mask die in init_rays (:1943-1956);
+	                                                             per sample, weight *= clamp(1 + sum of mask.sample(pos), 0, 1) (:833-840) */
+	int32_t glow_mode; float glow_y_cutoff;                   /* :843-939 */
+	const float* envmap; int32_t envmap_res[2];               /* fp32 rgba [h][w][4] (TrainableBuffer<4,2,float>::params_inference); init_rays writes
+	                                                             read_envmap(dir) into frame_buffer (:1931-1933; envmap.cuh:29-63) */
+	const float* distortion; int32_t distortion_res[2];       /* fp32 [h][w][2] (TrainableBuffer<2,2,float>): added to the ray direction before the camera
+	                                                             rotation (common_device.cuh:297-299); Distortion render mode paints it (:1959-1970) */
+	int32_t quilting_dims[2];                                 /* {1,1} (or {0,0}): off; apply_quilting (common_device.cuh:541-560, :1853-1863) */
+	int32_t render_mode;                                      /* ERenderMode of the frame (init_rays only needs to know Distortion = 5) */
+	float* frame_buffer;                                      /* [h][w][4] fp32, written by init_rays for the envmap background and the Distortion mode */
+	int32_t row_begin, row_end;                               /* {0,0}: the whole frame.  Else init_rays sets up the pixels of rows [row_begin, row_end) only:
+	                                                             payloads[i] is pixel row_begin * width + i, payload.idx stays the pixel's index in the WHOLE frame (what
+	                                                             shade writes to and every per-pixel random number is keyed by), so a frame cut into row ranges — one per
+	                                                             rank — has the pixels of the frame rendered at once, bit for bit */
+} NgpRenderExtras;
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
                       const float* render_aabb_to_local_host, float near_distance, int lens_mode, const float* lens_params_host,
                       float* depthbuffer, float plane_z /* focus distance; < 0: slice plane at -plane_z */, float aperture_size /* 0: pinhole */,
-                      const NgpRenderCamera* camera_models_host /* NULL or model 0: Perspective; else only model / sq_* / qh_* are read (:1868-1908) */);   /* :1809 */
+                      const NgpRenderCamera* camera_models_host /* NULL or model 0: Perspective; else only model / sq_* / qh_* are read (:1868-1908) */,
+                      const NgpRenderExtras* extras_host);                                                                       /* :1809 */
+/* first_pixel: index in the whole frame of the pixel payloads[0] belongs to (row_begin * width of a sharded frame, else 0): the start jitter is keyed by it */
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
-                        uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant); /* :612 */
+                        uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel); /* :612 */
 int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,
                          float* dst_rgba, float* dst_depth, NgpPayload* dst_payloads, float* dst_final_rgba, float* dst_final_depth,
                          NgpPayload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);                          /* :1784 */
 int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host,
                                  NgpPayload* payloads, NgpCoord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip,
                                  float cone_angle_constant);                                                                   /* :705 */
+/* render_mode = ERenderMode (common.h:80-91): AO 0, Shade 1, Normals 2 (network_input.pos holds d(density output)/d(pos), written there by
+ * ngp_hip_nerf_input_gradient: the colour is normalize(-density'(out[3]) * that), :941-946), Positions 3 (show_accel >= 0: the occupancy-cell colouring),
+ * Depth 4 (depth_scale = 1 / dataset scale, :2415), Distortion 5 (painted by init_rays), Cost 6 (n_steps / 128, in shade), Slice 7 (shade only),
+ * EncodingVis 8 (network_input.pos holds what ngp_hip_nerf_visualize_activation wrote, :961-962).  The plain Shade frame is
+ * (render_mode 1, depth_scale 1, show_accel -1, extras NULL). */
 int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host,
                       float* rgba, float* depth, NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output,
-                      uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance);    /* :767 */
+                      uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance,
+                      int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host);                  /* :767 */
 int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads,
-                  int train_in_linear_colors, float* frame_buffer, float* depth_buffer);                                       /* :1748 */
-/* The same two kernels with ERenderMode (common.h:80-91): AO 0, Shade 1, Positions 3 (show_accel >= 0: the occupancy-cell colouring), Depth 4
- * (depth_scale = 1 / dataset scale, :2415), Cost 6 (n_steps / 128, in shade), Slice 7 (shade only).  Normals 2, Distortion 5 and EncodingVis need
- * network input gradients / the distortion map and are rejected. */
-int ngp_hip_composite_mode(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
-                           NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                           int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel);
-int ngp_hip_shade_mode(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads, int train_in_linear_colors, float* frame_buffer,
-                       float* depth_buffer, int render_mode);
+                  int train_in_linear_colors, float* frame_buffer, float* depth_buffer, int render_mode);                      /* :1748 */
 int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space); /* render_buffer.cu:235 */
 int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const float* background_color_host, const float* accumulate_buffer,
                     int color_space, int output_color_space, int tonemap_curve, int clamp_output_color, float* surface);       /* render_buffer.cu:540 */
@@ -401,13 +435,6 @@ typedef struct {                                                     /* render_d
 typedef struct {                                                     /* render_data_workspace.cuh:22-31 NerfProxyRay */
 	float origin[3]; float dir[3]; float t; uint32_t idx; uint16_t n_steps; uint8_t alive; uint8_t active; float mask_alpha;
 } NgpProxyRay;                                                       /* 40 B */
-typedef struct {                                                     /* mask_3D.cuh:129-255 Mask3D */
-	int32_t mode;             /* EMaskMode: 0 Add, 1 Subtract */
-	int32_t shape;            /* EMaskShape: 0 Box, 1 Cylinder, 2 Sphere, 3 All */
-	float transform[16], itransform[16];
-	float config[6];          /* box: dims xyz; cylinder: radius, height; sphere: radius */
-	float feather, opacity;
-} NgpMask3D;
 typedef struct {                                                     /* nerf_props.cuh:14-48 NerfProps */
 	float transform[16], itransform[16];
 	const uint8_t* density_grid_bitfield;   /* device, 8 cascades, max-pooled (may be NULL) */
@@ -451,32 +478,7 @@ int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uin
 int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                         const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
 
-/* ============================ stock renderer, the rest of row f3: masks, glow, quilting, envmap background, distortion map, Normals /
- * EncodingVis / Distortion / Slice render modes ============================
- * NgpRenderExtras carries what init_rays_with_payload_kernel_nerf (src/testbed_nerf.cu:1809-1978) and composite_kernel_nerf (:767-989) take
- * beyond the arguments of ngp_hip_init_rays / ngp_hip_composite_mode.  Host struct; the pointers inside are device pointers (or NULL). */
-typedef struct {
-	const NgpMask3D* render_masks; uint32_t n_render_masks;   /* Testbed::prepare_nerf_masks (:2339-2352): rays that hit no mask die in init_rays (:1943-1956);
-	                                                             per sample, weight *= clamp(1 + sum of mask.sample(pos), 0, 1) (:833-840) */
-	int32_t glow_mode; float glow_y_cutoff;                   /* :843-939 */
-	const float* envmap; int32_t envmap_res[2];               /* fp32 rgba [h][w][4] (TrainableBuffer<4,2,float>::params_inference); init_rays writes
-	                                                             read_envmap(dir) into frame_buffer (:1931-1933; envmap.cuh:29-63) */
-	const float* distortion; int32_t distortion_res[2];       /* fp32 [h][w][2] (TrainableBuffer<2,2,float>): added to the ray direction before the camera
-	                                                             rotation (common_device.cuh:297-299); Distortion render mode paints it (:1959-1970) */
-	int32_t quilting_dims[2];                                 /* {1,1}: off; apply_quilting (common_device.cuh:541-560, :1853-1863) */
-	int32_t render_mode;                                      /* ERenderMode of the frame (init_rays only needs to know Distortion = 5) */
-	float* frame_buffer;                                      /* [h][w][4] fp32, written by init_rays for the envmap background and the Distortion mode */
-} NgpRenderExtras;
-int ngp_hip_init_rays_ex(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
-                         const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host, const float* screen_center_host,
-                         const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
-                         float near_distance, int lens_mode, const float* lens_params_host, float* depthbuffer, float plane_z, float aperture_size,
-                         const NgpRenderCamera* camera_models_host, const NgpRenderExtras* extras_host);
-/* render_mode additionally: Normals 2 (network_input.pos holds d(density output)/d(pos), written there by ngp_hip_nerf_input_gradient: the colour
- * is normalize(-density'(out[3]) * that), :941-946), EncodingVis 8 (network_input.pos holds what ngp_hip_nerf_visualize_activation wrote, :961-962). */
-int ngp_hip_composite_ex(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
-                         NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                         int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host);
+/* ============================ stock renderer, the rest of row f3: Normals / EncodingVis / Slice passes ============================ */
 /* [tcnn] DifferentiableObject::input_gradient(stream, dim, input, d_output_d_input = input) as the tracer calls it for the Normals mode
  * (src/testbed_nerf.cu:2225-2226; also :3432 for the marching-cubes normals): dL/doutput = backprop_scale (128) at output `dim` and 0 elsewhere,
  * forward + backward of NerfNetwork (nerf_network.h:143-266) without parameter gradients, then every element of the input matrix times
@@ -508,6 +510,15 @@ void* ngp_rccl_init(int rank, int world_size, const uint8_t* unique_id128);   /*
 int ngp_rccl_allreduce_grads(void* comm, void* stream, uint16_t* grads_f16, uint64_t n_params);   /* fp16 sum of the loss-scaled gradient vector */
 int ngp_rccl_allreduce_f32(void* comm, void* stream, float* values, uint64_t count);              /* error maps, exposure gradients */
 int ngp_rccl_allreduce_counters(void* comm, void* stream, double* values, uint64_t count);        /* {samples, compacted samples, loss sum} of a step */
+/* in place: rank r's chunk sits at buf + r * count_per_rank elements before the call, every rank holds all world chunks after it
+ * (frame rows of a sharded render; the parameter shards behind the sharded optimizer step) */
+int ngp_rccl_allgather_f32(void* comm, void* stream, float* buf, uint64_t count_per_rank);
+int ngp_rccl_allgather_f16(void* comm, void* stream, uint16_t* buf, uint64_t count_per_rank);
+/* sum over the ranks of in[world * count_per_rank]; rank r receives elements [r * count_per_rank, (r + 1) * count_per_rank) of the sum (fp32: the
+ * gradient shards of the sharded optimizer step are summed in fp32, not in the fp16 they are stored in) */
+int ngp_rccl_reduce_scatter_f32(void* comm, void* stream, const float* in, float* out, uint64_t count_per_rank);
+int ngp_rccl_comm_size(void* comm);                              /* ncclCommCount; -1 on error */
+int ngp_rccl_comm_rank(void* comm);
 int ngp_rccl_finalize(void* comm);
 
 #ifdef __cplusplus

@@ -137,9 +137,13 @@ void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_
 	const int32_t* qd = ex && ex->quilting_dims[0] > 0 && ex->quilting_dims[1] > 0 ? ex->quilting_dims : one;
 	const float* distortion = ex && ex->distortion && ex->distortion_res[0] > 0 ? ex->distortion : NULL;
 	const float* envmap = ex && ex->envmap && ex->envmap_res[0] > 0 ? ex->envmap : NULL;
-	for (int yy = 0; yy < res[1]; ++yy) for (int xx = 0; xx < res[0]; ++xx) {
+	/* a frame rendered in row shards (include/ngp_hip.h NgpRenderExtras.row_begin / row_end): only the rows of the range are set up; payload slot = pixel - first pixel of
+	 * the range, payload.idx and every random-number key = the pixel's index in the whole frame */
+	const int row_begin = ex && (ex->row_begin || ex->row_end) ? ex->row_begin : 0, row_end = ex && (ex->row_begin || ex->row_end) ? ex->row_end : res[1];
+	for (int yy = row_begin; yy < row_end; ++yy) for (int xx = 0; xx < res[0]; ++xx) {
 		uint32_t x = (uint32_t)xx, y = (uint32_t)yy;
 		uint32_t idx = x + (uint32_t)res[0] * y;
+		const uint32_t slot = idx - (uint32_t)res[0] * (uint32_t)row_begin;
 		float parallax_shift[3] = {parallax_shift_in[0], parallax_shift_in[1], parallax_shift_in[2]};
 		if (qd[0] != 1 || qd[1] != 1) orc_apply_quilting(&x, &y, res, parallax_shift, qd);
 		float u = ((float)x + 0.5f) * (1.f / (float)res[0]);
@@ -157,7 +161,7 @@ void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_
 			                       distortion, ex ? ex->distortion_res : NULL);
 		}
 
-		orc_payload* p = &payloads[idx];
+		orc_payload* p = &payloads[slot];
 		p->max_weight = 0.0f;
 		if (plane_z < 0) {   /* slice plane (:1913-1923): the ray stops at depth -plane_z along the view axis */
 			float n = orc_norm(ray.d);
@@ -221,7 +225,7 @@ void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_
 
 /* testbed_nerf.cu:612-664 */
 void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index,
-                     orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
+                     orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel /* of a row shard, else 0 */) {
 	for (uint32_t i = 0; i < n_elements; ++i) {
 		orc_payload* p = &payloads[i];
 		if (!p->alive) continue;
@@ -230,7 +234,7 @@ void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const flo
 		float cone_angle = cone_angle_constant;
 		float t = p->t;
 		float dt = orc_calc_dt(t, cone_angle);
-		t += orc_ld_random_val(sample_index, i * 786433u, 0) * dt;
+		t += orc_ld_random_val(sample_index, (i + first_pixel) * 786433u, 0) * dt;
 		orc_vec3 pos;
 		while (1) {
 			pos = orc_add(origin, orc_scale(dir, t));
@@ -557,7 +561,24 @@ uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, u
                          int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb,
                          float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation,
                          float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer) {
-	const uint32_t n_pixels = (uint32_t)res[0] * (uint32_t)res[1];
+	return orc_render_nerf_rows(net, inference_params, sample_index, res, focal_length, camera_matrix0, camera_matrix1, screen_center, snap_to_pixel_centers, render_aabb, render_aabb_to_local,
+	                            train_aabb, near_distance, density_grid, cone_angle_constant, rgb_activation, density_activation, min_transmittance, train_in_linear_colors, frame_buffer, depth_buffer,
+	                            0, res[1]);
+}
+
+/* The same frame, rows [row_begin, row_end) only (SURVEY.md §8e "Render: image tiles/rows per rank + gather"): frame_buffer / depth_buffer are the WHOLE frame's, the
+ * pixels of the other rows are not touched.  Rays do not interact and every random number is keyed by the pixel's index in the whole frame, so the rows written
+ * are, bit for bit, those of the frame rendered at once — whatever the partition (the n_steps-per-pass schedule differs, the per-ray sample sequence does not). */
+uint64_t orc_render_nerf_rows(const orc_net* net, const uint16_t* inference_params, uint32_t sample_index, const int32_t res[2],
+                              const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float screen_center[2],
+                              int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, const orc_aabb* train_aabb,
+                              float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation,
+                              float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer, int row_begin, int row_end) {
+	if (row_end <= row_begin) return 0;
+	const uint32_t n_pixels = (uint32_t)res[0] * (uint32_t)(row_end - row_begin), first_pixel = (uint32_t)res[0] * (uint32_t)row_begin;
+	orc_render_extras rows_ex;
+	memset(&rows_ex, 0, sizeof(rows_ex));
+	rows_ex.quilting_dims[0] = rows_ex.quilting_dims[1] = 1; rows_ex.render_mode = 1; rows_ex.row_begin = row_begin; rows_ex.row_end = row_end;
 	const float zero4[4] = {0, 0, 0, 0}, zero3[3] = {0, 0, 0};
 	orc_payload* payload[2]; float* rgba[2]; float* depth[2];
 	for (int b = 0; b < 2; ++b) {
@@ -571,9 +592,9 @@ uint64_t orc_render_nerf(const orc_net* net, const uint16_t* inference_params, u
 	orc_coord* net_in = (orc_coord*)calloc((size_t)n_pixels * 8, sizeof(orc_coord));
 	uint16_t* net_out = (uint16_t*)calloc((size_t)n_pixels * 8 * 4, 2);
 
-	orc_init_rays(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
-	              snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f, NULL);
-	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant);
+	orc_init_rays_ex(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
+	                 snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f, NULL, &rows_ex);
+	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant, first_pixel);
 
 	uint32_t n_alive = n_pixels, n_hit = 0, i = 1, dbi = 0;
 	uint64_t n_samples = 0;

@@ -291,3 +291,74 @@ def test_cpp_exchange_ignores_the_leftover_segment_of_a_crashed_job():
         if os.path.exists(path):
             os.unlink(path)
     assert not os.path.exists(path)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the sharded optimizer step
+def _sharded_optimizer_worker(rank, world, port, q):
+    """reduce-scatter (fp32 sums) -> Adam on the rank's shard -> all-gather of the fp16 weights -> Ema over everything, with the oracle as each rank's compute, against the
+    replicated step (all-reduce, whole Adam / Ema on every rank).  What Testbed::optimizer_step_sharded does on the GPUs with ngp_rccl_* and the NGP_OPT_* stages."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    orc = H.load_oracle()
+    n, nm = 10240 + 30011, 10240
+    shard = ((n + world - 1) // world + 7) // 8 * 8
+    rs0 = np.random.RandomState(5)                       # the replicated state: identical on every rank
+    master = (rs0.randn(n) * 0.1).astype(np.float32)
+    p16, m1, m2 = master.astype(np.float16), (rs0.randn(n) * 1e-3).astype(np.float32), (rs0.rand(n) * 1e-5).astype(np.float32)
+    ema, inf = master.copy(), master.astype(np.float16)
+    hp = (H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95))
+    rs = np.random.RandomState(100 + rank)               # this rank's gradients
+    grads = (rs.randn(n) * 0.3).astype(np.float16)
+    grads[rs.rand(n) < 0.5] = 0
+    # ---- the wire: fp32 sums (reduce-scatter == a slice of the all-reduce)
+    g32 = torch.zeros(shard * world, dtype=torch.float32)
+    g32[:n] = torch.from_numpy(grads.astype(np.float32))
+    dist.all_reduce(g32)
+    gsum16 = g32.numpy()[:n].astype(np.float16)
+    # ---- replicated reference: the whole step on every rank
+    ref = [a.copy() for a in (master, p16, m1, m2, ema, inf)]
+    orc.orc_adam_ema_step(n, nm, 9, *hp, gsum16.ctypes.data, *[a.ctypes.data for a in ref])
+    # ---- sharded: Adam on my shard only (the Ema outputs of this call are discarded) ...
+    off = shard * rank
+    mine = max(0, min(shard, n - off))
+    my = [np.ascontiguousarray(a[off:off + mine]) for a in (master, p16, m1, m2)]
+    junk_ema, junk_inf = np.zeros(mine, np.float32), np.zeros(mine, np.float16)
+    if mine:
+        gs = np.ascontiguousarray(gsum16[off:off + mine])
+        orc.orc_adam_ema_step(mine, max(nm - off, 0), 9, *hp, gs.ctypes.data, my[0].ctypes.data, my[1].ctypes.data, my[2].ctypes.data, my[3].ctypes.data, junk_ema.ctypes.data, junk_inf.ctypes.data)
+    # ... all-gather of the fp16 weights (equal shards, the last one padded) ...
+    chunk = torch.zeros(shard * 2, dtype=torch.uint8)                 # (gloo moves bytes; RCCL moves ncclFloat16 — an all-gather does no arithmetic)
+    chunk[:mine * 2] = torch.from_numpy(my[1].view(np.uint8))
+    parts = [torch.zeros_like(chunk) for _ in range(world)]
+    dist.all_gather(parts, chunk)
+    new_p16 = torch.cat(parts).numpy()[:n * 2].view(np.float16).copy()
+    # ... Ema over all parameters from the gathered weights: the oracle's step with nothing to optimise (no matrix parameters, zero gradients) is its Ema stage
+    zeros = np.zeros(n, np.float16)
+    m_, a_, b_ = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    new_ema, new_inf = ema.copy(), inf.copy()
+    orc.orc_adam_ema_step(n, 0, 9, *hp, zeros.ctypes.data, m_.ctypes.data, new_p16.ctypes.data, a_.ctypes.data, b_.ctypes.data, new_ema.ctypes.data, new_inf.ctypes.data)
+    ok = dict(params=np.array_equal(new_p16.view(np.uint16), ref[1].view(np.uint16)), ema=np.array_equal(new_ema, ref[4]), inference=np.array_equal(new_inf.view(np.uint16), ref[5].view(np.uint16)),
+              master=np.array_equal(my[0], ref[0][off:off + mine]), m1=np.array_equal(my[2], ref[2][off:off + mine]), m2=np.array_equal(my[3], ref[3][off:off + mine]))
+    q.put((rank, ok, int((ref[1] != p16).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_equals_replicated_bit_for_bit(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_sharded_optimizer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, n_changed in res:
+        assert all(ok.values()), (rank, ok)
+        assert n_changed > 10000            # the step did move the weights

@@ -63,3 +63,131 @@ def test_testbed_data_parallel_step_with_one_rank(cuda, strong):
     b.shutdown_data_parallel()
     scene.train(b, 90)                                 # back on the single-GPU step
     assert b.training_step == 90
+
+
+# ---------------------------------------------------------------------------------------------------------------- a frame rendered in row shards
+@pytest.fixture(scope="module")
+def trained(cuda):
+    import scene
+    ds = scene.make_dataset(n_train=12, n_test=1, res=96, device=cuda)
+    tb = scene.build_testbed(ds)
+    scene.train(tb, 150)
+    tb.shall_train = False
+    tb.background_color = [0.0, 0.0, 0.0, 0.0]
+    tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    tb.fov_axis = 0
+    tb.fov = ds["camera_angle_x"] * 180 / np.pi
+    return ds, tb
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("snap,spp", [(True, 1), (False, 3)])
+def test_render_row_shards_are_the_rows_of_the_whole_frame(trained, world, snap, spp):
+    """VERDICT r02 row e-r: rank r traces the rows [r * ceil(H / P), (r + 1) * ceil(H / P)) of the frame — ray set-up, start jitter and sub-pixel offsets keyed by
+    the pixel's index in the whole frame — so the shards' rows are bit for bit the rows of the frame rendered at once (also over several spp, with jitter)."""
+    ds, tb = trained
+    W, Hh = 80, 50                                       # 50 rows: uneven over 3 and 8 shards
+    tb.snap_to_pixel_centers = snap
+    tb.set_render_shard(0, 1)
+    whole = tb.render(W, Hh, spp, True)
+    assert (whole[..., 3] > 0.5).any() and (whole[..., 3] == 0).any()
+    frame = np.zeros_like(whole)
+    n_samples = 0
+    for r in range(world):
+        tb.set_render_shard(r, world)
+        a, b = tb.render_shard_rows(Hh)
+        per = (Hh + world - 1) // world
+        assert (a, b) == (min(Hh, r * per), min(Hh, r * per + per))
+        img = tb.render(W, Hh, spp, True)
+        assert not img[:a].any() and not img[b:].any()   # transparent background: rows of other shards stay empty
+        frame[a:b] = img[a:b]
+        n_samples += tb.render_samples_evaluated
+    tb.set_render_shard(0, 1)
+    np.testing.assert_array_equal(frame, whole)
+
+
+def test_render_through_a_one_rank_communicator_gathers_the_frame(trained):
+    """init_data_parallel makes render() shard over the communicator's ranks and all-gather the rows (ngp_rccl_allgather_f32); with one rank the whole path runs
+    — split, in-place gather buffer, RCCL call, copy-out — and must return the frame of the plain path"""
+    ds, tb = trained
+    tb.set_render_shard(0, 1)
+    tb.snap_to_pixel_centers = True
+    whole = tb.render(64, 40, 1, True)
+    tb.init_data_parallel(0, 1, "render_%d" % os.getpid(), False)
+    try:
+        assert tb.dp_comm_size == 1
+        got = tb.render(64, 40, 1, True)
+    finally:
+        tb.shutdown_data_parallel()
+    np.testing.assert_array_equal(got, whole)
+
+
+def test_rccl_allgather_and_reduce_scatter_on_one_rank(ngp, cuda):
+    import torch
+    uid = np.zeros(128, np.uint8)
+    check(ngp.ngp_rccl_get_unique_id(uid.ctypes.data))
+    comm = ngp.ngp_rccl_init(0, 1, uid.ctypes.data)
+    assert comm and ngp.ngp_rccl_comm_size(comm) == 1 and ngp.ngp_rccl_comm_rank(comm) == 0
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        f = torch.linspace(-2, 2, 3000, device=cuda, dtype=torch.float32)
+        h = (torch.arange(2048, device=cuda, dtype=torch.float16) * 0.5)
+        want_f, want_h = f.clone(), h.clone()
+        check(ngp.ngp_rccl_allgather_f32(comm, st, f.data_ptr(), f.numel()))
+        check(ngp.ngp_rccl_allgather_f16(comm, st, h.data_ptr(), h.numel()))
+        out = torch.zeros_like(f)
+        check(ngp.ngp_rccl_reduce_scatter_f32(comm, st, f.data_ptr(), out.data_ptr(), f.numel()))
+        torch.cuda.synchronize()
+        assert torch.equal(f, want_f) and torch.equal(h, want_h) and torch.equal(out, want_f)
+    finally:
+        check(ngp.ngp_rccl_finalize(comm))
+
+
+# ---------------------------------------------------------------------------------------------------------------- the sharded optimizer step
+@pytest.mark.parametrize("n,nm,world", [(10240 + 40000, 10240, 3), (10240 + 5000, 10240, 8), (3000, 5000, 2), (1 << 16, 0, 4)])
+def test_sharded_optimizer_stages_equal_the_whole_step_bit_for_bit(ngp, cuda, n, nm, world):
+    """Testbed::optimizer_step_sharded's arithmetic on one GPU: the Adam stage (NGP_OPT_NO_EMA) on each of `world` shards (pointers advanced to the shard, matrix-parameter
+    count from there, shard length a multiple of 8, the last one cut at n), then the Ema stage (NGP_OPT_EMA_ONLY) over everything == ngp_hip_optimizer_step over everything."""
+    import torch
+    rs = np.random.RandomState(n % 97)
+    grads = (rs.randn(n) * 0.3).astype(np.float16)
+    grads[rs.rand(n) < 0.5] = 0                                   # untouched hash entries are skipped
+    master = (rs.randn(n) * 0.1).astype(np.float32)
+    p16, m1, m2 = master.astype(np.float16), (rs.randn(n) * 1e-3).astype(np.float32), (rs.rand(n) * 1e-5).astype(np.float32)
+    ema, inf = master.copy(), master.astype(np.float16)
+    args = (H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95))
+    step = 11
+    whole = [H.to_dev(a, cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
+    check(ngp.ngp_hip_optimizer_step(None, n, min(nm, n), step, *args, *[t.data_ptr() for t in whole]))
+    parts = [H.to_dev(a, cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
+    size = [2, 4, 2, 4, 4, 4, 2]
+    shard = ((n + world - 1) // world + 7) // 8 * 8
+    for r in range(world):
+        off = shard * r
+        mine = min(shard, n - off) if off < n else 0
+        if mine:
+            p = [t.data_ptr() + off * sz for t, sz in zip(parts, size)]
+            check(ngp.ngp_hip_optimizer_step_masked(None, mine, max(min(nm, n) - off, 0), step, *args, p[0], p[1], p[2], p[3], p[4], None, None, 3 | 4))
+    check(ngp.ngp_hip_optimizer_step_masked(None, n, min(nm, n), step, *args, None, None, parts[2].data_ptr(), None, None, parts[5].data_ptr(), parts[6].data_ptr(), 8))
+    torch.cuda.synchronize()
+    for name, a, b in zip(("grads", "master", "params", "m1", "m2", "ema", "inference"), whole, parts):
+        assert torch.equal(a, b), name
+    # the fp32 round trip of the gradient vector around the reduce-scatter is the identity on one rank, and pads with zeros
+    g32 = torch.full((shard * world,), 7.0, device=cuda, dtype=torch.float32)
+    check(ngp.ngp_hip_f16_to_f32(None, n, shard * world, parts[0].data_ptr(), g32.data_ptr()))
+    back = torch.zeros(n, device=cuda, dtype=torch.float16)
+    check(ngp.ngp_hip_f32_to_f16(None, n, g32.data_ptr(), back.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(H.to_host(back, np.uint16), grads.view(np.uint16)) and float(g32[n:].abs().sum()) == 0.0
+
+
+def test_data_parallel_step_replicated_optimizer_still_runs(cuda):
+    """dp_sharded_optimizer = False: the fp16 all-reduce + replicated optimizer step of rounds 1 / 2 stays selectable"""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    b = scene.build_testbed(ds)
+    b.dp_sharded_optimizer = False
+    b.init_data_parallel(0, 1, "t_rep_%d" % os.getpid(), False)
+    scene.train(b, 40)
+    assert b.training_step == 40 and np.isfinite(b.loss)
+    b.shutdown_data_parallel()

@@ -67,7 +67,7 @@ def _init(ngp, oracle, cuda, ex_host, ex_dev, spp=1, parallax=(0.0, 0.0, 0.0)):
     oracle.orc_init_rays_ex(spp, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, par.ctypes.data,
                             0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None, ex_host.ctypes.data)
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
-    check(ngp.ngp_hip_init_rays_ex(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, par.ctypes.data,
+    check(ngp.ngp_hip_init_rays(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, par.ctypes.data,
                                    0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0), None, ex_dev.ctypes.data))
     return pay, depth, H.to_host(d_pay, H.PAYLOAD).copy(), H.to_host(d_depth, np.float32).copy()
 
@@ -130,7 +130,7 @@ def test_init_rays_envmap_background_and_distortion(ngp, oracle, cuda):
     np.testing.assert_allclose(H.to_host(d_fb2, np.float32).reshape(n, 4)[hit], fb2[hit], rtol=0, atol=2e-4)
     assert (fb2[hit][:, 3] == 1.0).all() and fb2[hit][:, :3].max() > 0.3
     # an envmap / the Distortion mode without a frame buffer is refused
-    assert ngp.ngp_hip_init_rays_ex(None, 0, 0, np.array([4, 4], np.int32).ctypes.data, np.ones(2, np.float32).ctypes.data, np.eye(3, 4, dtype=np.float32).ctypes.data,
+    assert ngp.ngp_hip_init_rays(None, 0, 0, np.array([4, 4], np.int32).ctypes.data, np.ones(2, np.float32).ctypes.data, np.eye(3, 4, dtype=np.float32).ctypes.data,
                                     np.eye(3, 4, dtype=np.float32).ctypes.data, None, np.ones(2, np.float32).ctypes.data, None, 0, H.unit_aabb(1).ctypes.data, None, H.f32(0.0), 0, None, 0,
                                     H.f32(1.0), H.f32(0.0), None, _extras(render_mode=5).ctypes.data) != 0
 
@@ -147,7 +147,7 @@ def _march_inputs(oracle, n_steps=4):
     pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
     oracle.orc_init_rays(0, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
                          1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None)
-    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, 0, pay.ctypes.data, bf.ctypes.data, 0, H.f32(0.0))
+    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, 0, pay.ctypes.data, bf.ctypes.data, 0, H.f32(0.0), 0)
     alive = pay[pay["alive"] == 1].copy()
     na = len(alive)
     coords = np.zeros(na * n_steps, H.COORD)
@@ -163,7 +163,7 @@ def _composite_both(ngp, oracle, cuda, S, out, mode, ex_host, ex_dev, coords=Non
                             H.f32(0.01), mode, H.f32(3.0), accel, ex_host.ctypes.data if ex_host is not None else None)
     d_p, d_c, d_d = H.to_dev(S["pay"], cuda), H.dev_zeros(na * 16, cuda), H.dev_zeros(na * 4, cuda)
     d_in, d_out = H.to_dev(coords, cuda), H.to_dev(out, cuda)
-    check(ngp.ngp_hip_composite_ex(None, na, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 4, n_steps, 2, 3,
+    check(ngp.ngp_hip_composite(None, na, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(), d_out.data_ptr(), 4, n_steps, 2, 3,
                                    H.f32(0.01), mode, H.f32(3.0), accel, ex_dev.ctypes.data if ex_dev is not None else None))
     ok = H.to_host(d_p, H.PAYLOAD)["alive"] == o_p["alive"]
     assert ok.mean() > 0.99
@@ -257,7 +257,7 @@ def test_input_gradient_and_normals_mode(ngp, oracle, cuda):
     oracle.orc_shade_mode(na, nrm.ctypes.data, dep.ctypes.data, p_after.ctypes.data, 0, fb_o.ctypes.data, db_o.ctypes.data, 2)
     d_fb, d_db = H.dev_zeros(W * Hh * 16, cuda), H.dev_zeros(W * Hh * 4, cuda)
     d_nrm, d_dep, d_pa = H.to_dev(nrm, cuda), H.to_dev(dep, cuda), H.to_dev(p_after, cuda)
-    check(ngp.ngp_hip_shade_mode(None, na, d_nrm.data_ptr(), d_dep.data_ptr(), d_pa.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), 2))
+    check(ngp.ngp_hip_shade(None, na, d_nrm.data_ptr(), d_dep.data_ptr(), d_pa.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), 2))
     np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(-1, 4), fb_o, rtol=1e-4, atol=1e-6)
     hit = fb_o[:, 3] > 0.05
     assert hit.sum() > 50 and fb_o[hit][:, :3].min() >= -1e-6 and (fb_o[hit][:, :3] <= fb_o[hit][:, 3:4] + 1e-6).all()   # (0.5 n + 0.5) alpha

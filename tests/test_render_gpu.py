@@ -36,7 +36,7 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plan
                          snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(plane_z), H.f32(aperture), cam_models.ctypes.data if cam_models is not None else None)
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, spp, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(plane_z), H.f32(aperture), cam_models.ctypes.data if cam_models is not None else None))
+                                zero3.ctypes.data, snap, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, d_depth.data_ptr(), H.f32(plane_z), H.f32(aperture), cam_models.ctypes.data if cam_models is not None else None, None))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
     if not exact:   # depth of field: the lens-disk sample goes through cosf / sinf (device intrinsics vs libm)
         same = g["alive"] == pay["alive"]
@@ -57,9 +57,9 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plan
         np.testing.assert_array_equal(g["dir"], pay["dir"])
         return dict(pay=pay, g=g, depth=depth)
 
-    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone))
+    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone), 0)
     d_bf = H.to_dev(bf, cuda)
-    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone)))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone), 0))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
     np.testing.assert_array_equal(g["alive"], pay["alive"])
     al = pay["alive"] == 1
@@ -170,7 +170,7 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
     d_rgba2, d_dep2 = H.dev_zeros(n_alive * 16, cuda), H.dev_zeros(n_alive * 4, cuda)
     d_out = H.to_dev(out, cuda)
     check(ngp.ngp_hip_composite(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_rgba2.data_ptr(), d_dep2.data_ptr(), d_pay2.data_ptr(), d_in.data_ptr(),
-                                d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
+                                d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 1, H.f32(1.0), -1, None))
     g_pay3 = H.to_host(d_pay2, H.PAYLOAD)
     same = g_pay3["alive"] == o_pay["alive"][:n_alive]
     assert same.mean() > 0.99  # termination is a float threshold; allow a hair of disagreement
@@ -183,14 +183,14 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
         oracle.orc_composite_mode(n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, o_c.ctypes.data, o_d.ctypes.data, o_p.ctypes.data, o_in.ctypes.data,
                                   out.ctypes.data, 4, n_steps, 2, 3, H.f32(0.01), mode, H.f32(3.0), accel)
         d_p, d_c, d_d = H.to_dev(pay_before, cuda), H.dev_zeros(n_alive * 16, cuda), H.dev_zeros(n_alive * 4, cuda)
-        check(ngp.ngp_hip_composite_mode(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
-                                         d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), mode, H.f32(3.0), accel))
+        check(ngp.ngp_hip_composite(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
+                                    d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), mode, H.f32(3.0), accel, None))
         ok = H.to_host(d_p, H.PAYLOAD)["alive"] == o_p["alive"]
         assert ok.mean() > 0.99
         np.testing.assert_allclose(H.to_host(d_c, np.float32).reshape(n_alive, 4)[ok], o_c[ok], rtol=2e-3, atol=1e-5)
         assert np.abs(o_c[:, :3] - o_rgba2[:, :3]).max() > 1e-2          # not the Shade colours
-    assert ngp.ngp_hip_composite_mode(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
-                                      d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 2, H.f32(1.0), -1) != 0                   # Normals: not built
+    assert ngp.ngp_hip_composite(None, n_alive, 1, S["aabb"].ctypes.data, S["cam"].ctypes.data, d_c.data_ptr(), d_d.data_ptr(), d_p.data_ptr(), d_in.data_ptr(),
+                                 d_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 9, H.f32(1.0), -1, None) != 0                   # no such ERenderMode
     assert b"render mode" in ngp.ngp_hip_last_error()
 
 
@@ -207,7 +207,7 @@ def test_shade_accumulate_tonemap(ngp, oracle, cuda):
         d_fb, d_db = H.to_dev(fb, cuda), H.to_dev(db, cuda)
         oracle.orc_shade(n_hit, rgba.ctypes.data, depth.ctypes.data, pay.ctypes.data, linear, fb.ctypes.data, db.ctypes.data)
         d_rgba, d_depth, d_pay = H.to_dev(rgba, cuda), H.to_dev(depth, cuda), H.to_dev(pay, cuda)
-        check(ngp.ngp_hip_shade(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr()))
+        check(ngp.ngp_hip_shade(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), linear, d_fb.data_ptr(), d_db.data_ptr(), 1))
         np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-4, atol=1e-6)
         np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
     pay["n_steps"] = rs.randint(0, 300, n_hit)
@@ -215,7 +215,7 @@ def test_shade_accumulate_tonemap(ngp, oracle, cuda):
         fb, db = rs.rand(npx, 4).astype(np.float32), rs.rand(npx).astype(np.float32)
         d_fb, d_db, d_pay = H.to_dev(fb, cuda), H.to_dev(db, cuda), H.to_dev(pay, cuda)
         oracle.orc_shade_mode(n_hit, rgba.ctypes.data, depth.ctypes.data, pay.ctypes.data, 0, fb.ctypes.data, db.ctypes.data, mode)
-        check(ngp.ngp_hip_shade_mode(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), mode))
+        check(ngp.ngp_hip_shade(None, n_hit, d_rgba.data_ptr(), d_depth.data_ptr(), d_pay.data_ptr(), 0, d_fb.data_ptr(), d_db.data_ptr(), mode))
         np.testing.assert_allclose(H.to_host(d_fb, np.float32).reshape(npx, 4), fb, rtol=2e-6, atol=1e-7)
         np.testing.assert_array_equal(H.to_host(d_db, np.float32), db)
     for cs in (0, 1):
@@ -262,8 +262,8 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     fb, db = H.dev_zeros(n * 16, cuda), H.dev_zeros(n * 4, cuda)
     cnt, hcnt = H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)
     check(ngp.ngp_hip_init_rays(None, 0, pay[0].data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
-                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0), None))
-    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0)))
+                                1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0), None, None))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0), 0))
     n_alive, i, dbi = n, 1, 0
     while i < 10000:
         cur, tmp = (dbi + 1) % 2, dbi % 2
@@ -278,10 +278,10 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
         check(ngp.ngp_hip_generate_next_inputs(None, n_alive, aabb.ctypes.data, aabb.ctypes.data, pay[cur].data_ptr(), net_in.data_ptr(), n_steps, d_bf.data_ptr(), 0, H.f32(0.0)))
         check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), net_in.data_ptr(), 7, n_alive * n_steps, net_out.data_ptr(), 4))
         check(ngp.ngp_hip_composite(None, n_alive, i, aabb.ctypes.data, cam.ctypes.data, rgba[cur].data_ptr(), dep[cur].data_ptr(), pay[cur].data_ptr(), net_in.data_ptr(),
-                                    net_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01)))
+                                    net_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 1, H.f32(1.0), -1, None))
         i += n_steps
     n_hit = int(H.to_host(hcnt, np.uint32)[0])
-    check(ngp.ngp_hip_shade(None, n_hit, hr.data_ptr(), hd.data_ptr(), hp.data_ptr(), 0, fb.data_ptr(), db.data_ptr()))
+    check(ngp.ngp_hip_shade(None, n_hit, hr.data_ptr(), hd.data_ptr(), hp.data_ptr(), 0, fb.data_ptr(), db.data_ptr(), 1))
     torch.cuda.synchronize()
     got = H.to_host(fb, np.float32).reshape(n, 4)
     assert (fb_ref[:, 3] > 0.5).sum() > 100  # there is an object in view
@@ -312,7 +312,7 @@ def test_init_rays_lens_models(ngp, oracle, cuda, lens_mode, params):
                          0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None)
     d_pay, d_depth = H.dev_zeros(n * 40, cuda), H.dev_zeros(n * 4, cuda)
     check(ngp.ngp_hip_init_rays(None, 2, d_pay.data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data,
-                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0), None))
+                                zero3.ctypes.data, 0, aabb.ctypes.data, ident.ctypes.data, H.f32(0.05), lens_mode, lp.ctypes.data, d_depth.data_ptr(), H.f32(1.0), H.f32(0.0), None, None))
     g = H.to_host(d_pay, H.PAYLOAD)
     same = g["alive"] == pay["alive"]
     assert same.mean() > 0.995                      # a ray grazing the box may flip with a 1-ulp different direction
