@@ -71,7 +71,22 @@ class CLib:
             fn.argtypes = argtypes
 
     def __getattr__(self, name):
-        return getattr(self.lib, name)
+        fn = getattr(self.lib, name)
+        proto = self.protos.get(name)
+        if proto is None:
+            return fn
+        argtypes = proto[1]
+        n_required = len(argtypes)
+        while n_required and argtypes[n_required - 1] is ctypes.c_void_p:
+            n_required -= 1
+
+        def call(*args):   # the optional trailing pointers of an entry point (events, dL_dinput, NgpNetVariant*, NgpRenderExtras* ...) default to NULL
+            if n_required <= len(args) < len(argtypes):
+                args = args + (None,) * (len(argtypes) - len(args))
+            return fn(*args)
+        call.__name__ = name
+        self.__dict__[name] = call
+        return call
 
 
 def ptr(x):
@@ -137,6 +152,7 @@ RENDER_CAMERA = np.dtype([("transform", "<f4", 12), ("model", "<i4"), ("focal_le
                           ("qh_front", "<f4", 12), ("qh_back", "<f4", 12), ("near_distance", "<f4"), ("aperture_size", "<f4"), ("focus_z", "<f4")])
 assert GLOBAL_RAY.itemsize == 52 and PROXY_RAY.itemsize == 40 and MASK3D.itemsize == 168 and NERF_PROPS.itemsize == 224
 assert DOWNSAMPLE_INFO.itemsize == 32 and RENDER_CAMERA.itemsize == 176
+NET_VARIANT = np.dtype([("n_extra_dims", "<u4"), ("n_rgb_hidden_layers", "<u4"), ("extra_dims", "<u8"), ("sample_slot", "<u8"), ("dL_dextra", "<u8")], align=True)   # NgpNetVariant
 LOSS_EXTRAS = np.dtype([("envmap_data", "<u8"), ("envmap_gradient", "<u8"), ("envmap_res", "<i4", 2), ("envmap_loss_type", "<i4")], align=True)   # NgpLossExtras
 RENDER_EXTRAS = np.dtype([("render_masks", "<u8"), ("n_render_masks", "<u4"), ("glow_mode", "<i4"), ("glow_y_cutoff", "<f4"), ("envmap", "<u8"), ("envmap_res", "<i4", 2),
                           ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8"),

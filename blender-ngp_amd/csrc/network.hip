@@ -1897,11 +1897,26 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	return 0;
 }
 
+#include "network_generic.cuh"
+
+// NgpNetVariant -> what the generic kernels take; returns false for the base family (which stays on the fused kernels)
+static bool variant_is_generic(const NgpNetVariant* v) { return v && (v->n_extra_dims != 0 || v->n_rgb_hidden_layers != 2); }
+static int variant_check(const NgpNetVariant* v, const char* who) {
+	if (v && (v->n_extra_dims > 16 || v->n_rgb_hidden_layers > 3)) { set_last_error(who, hipErrorInvalidValue); return -1; }
+	return 0;
+}
+static int gen_grid(uint32_t n_groups) { const uint32_t b = div_up(n_groups, 4u); return (int)(b < 2048u ? (b ? b : 1u) : 2048u); }
+
 } // namespace ngp
 
 using namespace ngp;
 
 extern "C" {
+
+uint32_t ngp_hip_net_mlp_params_host(const NgpNetVariant* variant) {
+	if (!variant) return NGP_MLP_N_PARAMS;
+	return gen_layout(variant->n_extra_dims, variant->n_rgb_hidden_layers).n_mlp;
+}
 
 int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* d) {
 	if (n_levels != 16 || !d) { set_last_error("ngp_hip_net_make_desc_host: n_levels must be 16", hipErrorInvalidValue); return -1; }
@@ -1926,38 +1941,65 @@ int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, ui
 
 uint32_t ngp_hip_net_n_params_host(const NgpNetDesc* d) { return NGP_MLP_N_PARAMS + 2u * d->n_grid_entries; }
 
-int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params) {
+int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params, const NgpNetVariant* variant) {
 	// pcg32(initstate = seed, initseq = 1)
 	uint64_t state = 0u, inc = (1ull << 1u) | 1u;
 	state = state * 0x5851f42d4c957f2dULL + inc;
 	state += seed;
 	state = state * 0x5851f42d4c957f2dULL + inc;
+	if (variant_check(variant, "ngp_hip_nerf_init_params: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_is_generic(variant)) {
+		const GenLayout L = gen_layout(variant->n_extra_dims, variant->n_rgb_hidden_layers);
+		const uint32_t n = L.n_mlp + 2u * desc_host->n_grid_entries;
+		hipLaunchKernelGGL(gen_init_params_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, L, n, state, inc, master, (half_t*)params, (half_t*)inference_params);
+		NGP_LAUNCH_CHECK("gen_init_params_kernel");
+		return 0;
+	}
 	const uint32_t n = ngp_hip_net_n_params_host(desc_host);
 	hipLaunchKernelGGL(init_params_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, state, inc, master, (half_t*)params, (half_t*)inference_params);
 	NGP_LAUNCH_CHECK("init_params_kernel");
 	return 0;
 }
 
+static int gen_forward(void* stream, int mode, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
+	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
+	GenExtra ex; ex.extra_dims = v->extra_dims; ex.sample_slot = v->sample_slot;
+	const int grid = gen_grid(div_up(n, (uint32_t)GEN_SG));
+	if (mode == 1) hipLaunchKernelGGL(gen_forward_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, desc_dev, (const half_t*)params, coords, stride, n, (half_t*)out, 1u, (half_t*)nullptr, ex);
+	else if (mode == 2) hipLaunchKernelGGL(gen_forward_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, desc_dev, (const half_t*)params, coords, stride, n, (half_t*)out, out_stride, (half_t*)x_saved, ex);
+	else hipLaunchKernelGGL(gen_forward_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, L, desc_dev, (const half_t*)params, coords, stride, n, (half_t*)out, out_stride, (half_t*)nullptr, ex);
+	NGP_LAUNCH_CHECK("gen_forward_kernel");
+	return 0;
+}
+
 int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                           uint32_t n, uint16_t* out, uint32_t out_stride) {
+                           uint32_t n, uint16_t* out, uint32_t out_stride, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	if (variant_check(variant, "ngp_hip_nerf_inference: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_is_generic(variant)) return gen_forward(stream, 0, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, nullptr);
 	hipLaunchKernelGGL((nerf_forward_kernel<0, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0>");
 	return 0;
 }
 
-int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0) {
+int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
+	if (variant_is_generic(variant)) {   // the density network is the same, the grid sits behind a different number of MLP parameters; the direction / extra dims are not read
+		NgpNetVariant v = *variant; v.extra_dims = nullptr; v.sample_slot = nullptr;
+		return gen_forward(stream, 1, &v, desc_dev, params, pos, pos_stride_floats, n, out0, 1, nullptr);
+	}
 	hipLaunchKernelGGL((nerf_forward_kernel<1, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<1>");
 	return 0;
 }
 
 int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
+                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	if (variant_check(variant, "ngp_hip_nerf_forward: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_is_generic(variant)) return gen_forward(stream, 2, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, x_saved);
 	hipLaunchKernelGGL((nerf_forward_kernel<2, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
 	return 0;
@@ -2021,8 +2063,9 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 }
 
 int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes) {
+                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
+	if (variant_is_generic(variant)) return ngp_hip_nerf_inference(stream, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, variant);   // the generic network has one path
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_inference_ws: workspace too small")) return -1;
@@ -2032,8 +2075,9 @@ int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const ui
 }
 
 int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0,
-                            void* workspace, uint64_t workspace_bytes) {
+                            void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
+	if (variant_is_generic(variant)) return ngp_hip_nerf_density(stream, desc_dev, params, pos, pos_stride_floats, n, out0, variant);
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_density_ws: workspace too small")) return -1;
 	hipLaunchKernelGGL((nerf_forward_kernel<1, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, planes, n_pad);
@@ -2042,8 +2086,9 @@ int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 }
 
 int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes) {
+                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
+	if (variant_is_generic(variant)) return ngp_hip_nerf_forward(stream, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, x_saved, variant);
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	const h2* planes; uint32_t n_pad;
 	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_forward_ws: workspace too small")) return -1;
@@ -2069,27 +2114,72 @@ static uint64_t gb_fx_bytes(uint32_t n) {   // counters + item lists + run sums 
 static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx(n) + gb_fx_bytes(n); }
 
-int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                          uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                          uint16_t* grads, void* scratch, uint64_t scratch_bytes) {
-	return ngp_hip_nerf_backward_ev(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr);
-}
-
 static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                               uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput);
 
-int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                             uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event) {
-	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, nullptr);
+static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
+                        const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
+	GenExtra ex; ex.extra_dims = v->extra_dims; ex.sample_slot = v->sample_slot;
+	float* partials = (float*)scratch;                                    // [grid][n_mlp] fp32 (<= 256 x 15 360 x 4 B: inside the fused path's 512 x 10 240 x 4 B)
+	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
+	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
+	static bool attr_set = false;
+	if (!attr_set) { NGP_HIP_TRY(hipFuncSetAttribute((const void*)gen_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEN_BWD_SMEM)); attr_set = true; }
+	const uint32_t n_iters = n / 16;
+	const uint32_t grid = n_iters < 256u ? n_iters : 256u;                // one workgroup per CU (87 KiB of LDS)
+	static_assert((uint64_t)256 * GEN_MAX_MLP <= (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS, "partials of the generic backward fit the fused path's scratch");
+	hipLaunchKernelGGL(gen_backward_kernel, dim3(grid), dim3(256), GEN_BWD_SMEM, st, L, desc_dev, (const half_t*)params, coords, stride, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
+	                   dx_planes, partials, ex, v->dL_dextra);
+	NGP_LAUNCH_CHECK("gen_backward_kernel");
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(L.n_mlp, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, L.n_mlp);
+	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + L.n_mlp), false)) return -1;
+	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
+	return 0;
 }
 
-int ngp_hip_nerf_backward_input(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, float* dL_dinput) {
-	if (!dL_dinput) { set_last_error("ngp_hip_nerf_backward_input: dL_dinput is NULL", hipErrorInvalidValue); return -1; }
-	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, nullptr, nullptr, dL_dinput);
+int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                          uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant) {
+	if (variant_check(variant, "ngp_hip_nerf_backward: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_is_generic(variant)) {
+		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is built for the base network family only", hipErrorNotSupported); return -1; }
+		return gen_backward(stream, variant, desc_dev, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
+	}
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
+}
+
+// per-image extra dims of a training step (src/testbed_nerf.cu:1136, 1246: every sample of a ray carries its image's row; :1710-1746: their gradient)
+int ngp_hip_ray_images(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_indices, uint32_t n_rays_global, uint32_t n_training_images, const float* cdf_img,
+                       uint32_t* ray_image) {
+	if (!n_rays_capacity) return 0;
+	hipLaunchKernelGGL(ray_images_kernel, dim3(div_up(n_rays_capacity, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_capacity, rays_counter, ray_indices, n_rays_global, n_training_images, cdf_img, ray_image);
+	NGP_LAUNCH_CHECK("ray_images_kernel");
+	return 0;
+}
+int ngp_hip_expand_ray_slots(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_image, const uint32_t* numsteps, uint32_t n_samples_capacity, uint32_t* sample_slot) {
+	if (!n_rays_capacity) return 0;
+	hipLaunchKernelGGL(expand_ray_slots_kernel, dim3(div_up(n_rays_capacity, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_capacity, rays_counter, ray_image, numsteps, n_samples_capacity, sample_slot);
+	NGP_LAUNCH_CHECK("expand_ray_slots_kernel");
+	return 0;
+}
+int ngp_hip_rollover_slots(void* stream, uint32_t n_elements, const uint32_t* n_input_elements, uint32_t* sample_slot) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(rollover_slots_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, n_input_elements, sample_slot);
+	NGP_LAUNCH_CHECK("rollover_slots_kernel");
+	return 0;
+}
+int ngp_hip_extra_dims_gradient(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_image, const uint32_t* numsteps, const float* dL_dextra, uint32_t n_extra_dims,
+                                float* gradient) {
+	if (!n_rays_capacity || !n_extra_dims) return 0;
+	hipLaunchKernelGGL(extra_dims_gradient_kernel, dim3(div_up(n_rays_capacity, 128)), dim3(128), 0, (hipStream_t)stream, n_rays_capacity, rays_counter, ray_image, numsteps, dL_dextra, n_extra_dims, gradient);
+	NGP_LAUNCH_CHECK("extra_dims_gradient_kernel");
+	return 0;
 }
 
 static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
@@ -2143,7 +2233,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 	float* din = (float*)((char*)scratch + ig_off_din(n));
 	hipLaunchKernelGGL(one_hot_dl_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, dim, backprop_scale, dl);
 	NGP_LAUNCH_CHECK("one_hot_dl_kernel");
-	if (ngp_hip_nerf_forward(stream, desc_dev, params, coords_inout, coord_stride_floats, n, out, 4, x_saved)) return -1;
+	if (ngp_hip_nerf_forward(stream, desc_dev, params, coords_inout, coord_stride_floats, n, out, 4, x_saved, nullptr)) return -1;
 	// the fused backward kernel with the direction gradient, then dL/dpos through the hash encoding; no parameter gradients (EGradientMode::Ignore):
 	// the per-workgroup weight-gradient partials land in scratch and are dropped, the hash-grid backward does not run
 	float* partials = (float*)scratch;

@@ -153,7 +153,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	}
 	if (result.n_images == 0) throw std::invalid_argument{"No training images were found for NeRF training!"};
 	result.xforms.resize(result.n_images);
-	result.metadata.assign(result.n_images, NgpImageMeta{});
+	result.metadata.assign(result.n_images, NgpImageMeta{}); std::vector<Vec3> light_dirs(result.n_images, Vec3{0.f, 0.f, 0.f});
 	result.pixels.resize(result.n_images);
 
 	result.image_type.assign(result.n_images, 1);
@@ -166,7 +166,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	float info_depth_scale = -1.f;   // LoadedImageInfo::depth_scale (325), set by `integer_depth_scale`
 	size_t image_idx = 0;
 	std::vector<std::future<void>> futures;
-	std::atomic<bool> any_rays{false}, any_exr{false};
+	std::atomic<bool> any_rays{false}, any_exr{false}, any_light_dirs{false};
 	for (size_t i = 0; i < jsons.size(); ++i) {
 		const Json& json = jsons[i];
 		const std::string basepath = path_parent(jsonpaths[i]);
@@ -188,7 +188,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 		if (json.contains("black_transparent")) black_transparent = json["black_transparent"].boolean();
 		if (json.contains("scale")) result.scale = (float)json["scale"].number();
 		if (json.contains("importance_sampling")) result.wants_importance_sampling = json["importance_sampling"].boolean();
-		if (json.contains("n_extra_learnable_dims") && json["n_extra_learnable_dims"].number() != 0) throw std::runtime_error{"n_extra_learnable_dims > 0 is outside the NeRF hot path of this build (SURVEY.md §8 f4)"};
+		if (json.contains("n_extra_learnable_dims")) result.n_extra_learnable_dims = (uint32_t)json["n_extra_learnable_dims"].number();   // nerf_loader.cu:480-481
 		result.sharpen_amount = sharpen_amount;
 
 		LensState lens;
@@ -236,7 +236,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 		for (size_t k = 0; k < frames_of[i].size(); ++k) {
 			const size_t i_img = k + image_idx;
 			const Json frame = frames_of[i][k];
-			futures.push_back(std::async(std::launch::async, [&result, &json, &any_rays, &any_exr, frame, basepath, i_img, k, part_after_underscore, white_transparent, black_transparent, fix_premult,
+			futures.push_back(std::async(std::launch::async, [&result, &json, &any_rays, &any_exr, &any_light_dirs, &light_dirs, frame, basepath, i_img, k, part_after_underscore, white_transparent, black_transparent, fix_premult,
 			                                                  enable_ray_loading, enable_depth_loading, info_depth_scale, lens, principal_point, rolling_shutter, scale, offset, from_mitsuba]() {
 				std::string json_provided_path = frame["file_path"].str();
 				if (json_provided_path.empty()) { char buf[256]; snprintf(buf, 256, "%s_%03d/rgba.png", part_after_underscore.c_str(), (int)k); json_provided_path = buf; }
@@ -318,9 +318,14 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 					}
 					any_rays = true;
 				}
-				if (frame.contains("driver_parameters")) {
-					static std::atomic<bool> warned{false};
-					if (!warned.exchange(true)) fprintf(stderr, "transforms.json: `driver_parameters` (per-image light directions, an extra network input) are ignored by this build\n");
+				if (frame.contains("driver_parameters")) {   // nerf_loader.cu:671-680: the frame's light direction, three extra network inputs; replaces the latent codes
+					const Json& dp = frame["driver_parameters"];
+					float l[3] = {(float)dp.value("LightX", 0.0), (float)dp.value("LightY", 0.0), (float)dp.value("LightZ", 0.0)};
+					const float n = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+					if (n > 0.f) { l[0] /= n; l[1] /= n; l[2] /= n; }
+					// nerf_direction_to_ngp (nerf_loader.h:103-111)
+					light_dirs[i_img] = from_mitsuba ? Vec3{-l[0], -l[1], -l[2]} : Vec3{l[1], l[2], l[0]};
+					any_light_dirs = true;
 				}
 
 				bool got_fl = read_focal_length(json, m.focal_length, m.res);
@@ -345,6 +350,7 @@ LoadedNerfData load_nerf_host(const std::vector<std::string>& jsonpaths, float s
 	}
 	for (auto& f : futures) f.get();
 	result.has_rays = any_rays;
+	if (any_light_dirs) { result.has_light_dirs = true; result.n_extra_learnable_dims = 0; result.light_dirs = light_dirs; }   // nerf_loader.cu:678-679
 	result.is_hdr = result.is_hdr || any_exr;   // an .exr envmap already set it (nerf_loader.cu:542 keeps it)
 	return result;
 }

@@ -28,6 +28,9 @@ struct LoadedNerfData {
 	bool from_mitsuba = false, is_hdr = false, wants_importance_sampling = true;
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
+	uint32_t n_extra_learnable_dims = 0;            // `n_extra_learnable_dims` (nerf_loader.cu:480-481)
+	bool has_light_dirs = false;                    // some frame carries `driver_parameters` (671-680): three light-direction dims, no latent codes
+	std::vector<Vec3> light_dirs;                   // per image, NGP frame, normalised
 	std::vector<float> envmap_data;                 // `envmap` key (nerf_loader.cu:533-546): linear premultiplied RGBA fp32, [h][w][4]
 	int envmap_resolution[2] = {0, 0};
 };

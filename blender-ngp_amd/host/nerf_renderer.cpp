@@ -169,9 +169,17 @@ void NeuralRadianceField::load_snapshot(void* stream) {
 	desc_gpu.resize(sizeof(NgpNetDesc));
 	desc_gpu.copy_from_host(&desc, sizeof(NgpNetDesc));
 
+	// the colour network's depth (configs/nerf/base_{0,1,2,3}layer.json): anything but two hidden layers runs the generic kernels (NgpNetVariant)
+	n_rgb_hidden_layers = 2;
+	if (config.contains("rgb_network")) {
+		const int h = config["rgb_network"].value("n_hidden_layers", 2);
+		if (h < 0 || h > 3 || (h > 0 && config["rgb_network"].value("n_neurons", 64) != 64)) throw std::runtime_error{"snapshot network not supported: rgb_network must be 64 neurons wide with 0..3 hidden layers"};
+		n_rgb_hidden_layers = (uint32_t)h;
+	}
+	NgpNetVariant nv{0u, n_rgb_hidden_layers, nullptr, nullptr, nullptr};
 	std::vector<uint16_t> p16; std::vector<float> p32;
 	snapshot_read_params(snapshot, p16, p32);
-	const size_t n_params = ngp_hip_net_n_params_host(&desc);
+	const size_t n_params = (size_t)ngp_hip_net_mlp_params_host(&nv) + 2u * (size_t)desc.n_grid_entries;
 	if (p16.size() != n_params) throw std::runtime_error{"Snapshot has " + std::to_string(p16.size()) + " parameters, its network config needs " + std::to_string(n_params) + "."};
 	params.resize(n_params * 2);
 	params.copy_from_host(p16.data(), n_params * 2);
@@ -296,8 +304,9 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 			const uint32_t* list = m_active_lists.as<uint32_t>() + (size_t)n * stride;
 			const uint32_t n_network_elements = (n_active[n] * n_steps + 127u) / 128u * 128u;
 			check(ngp_hip_multi_generate_next_inputs_list(stream, n_active[n], list, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
+			NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr};
 			check(ngp_hip_nerf_inference_ws(stream, f.desc_gpu.as<NgpNetDesc>(), f.params.as<uint16_t>(), m_net_in.as<float>(), 7, n_network_elements, m_net_out.as<uint16_t>(), OUT_STRIDE,
-			                                m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (multi)");
+			                                m_enc_ws.data(), m_enc_ws.bytes(), f.n_rgb_hidden_layers == 2 ? nullptr : &nv), "nerf_inference (multi)");
 			n_samples += n_network_elements;
 			check(ngp_hip_multi_composite_list(stream, n_active[n], list, i, g, pn, m_net_in.as<NgpCoord>(), m_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)f.rgb_activation, (int)f.density_activation,
 			                                   f.min_transmittance, props_dev + n), "multi_composite");

@@ -138,6 +138,7 @@ public:
 	std::string snapshot_path;
 	bool is_loaded = false;
 	NgpNetDesc desc{};
+	uint32_t n_rgb_hidden_layers = 2;   // of the snapshot's rgb_network
 	DeviceBuffer desc_gpu, params, density_grid, density_grid_bitfield, density_grid_mean;
 	NgpAabb train_aabb{{0, 0, 0}, {1, 1, 1}};
 	uint32_t grid_size = 128, max_cascade = 0, num_cascades = 8, aabb_scale = 1;

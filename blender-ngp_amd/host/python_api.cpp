@@ -346,6 +346,16 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("envmap_resolution", [](PyNerfDataset& d) { return std::vector<int>{d.d->envmap_resolution[0], d.d->envmap_resolution[1]}; })   // python_api.cu:797
 		.def_property_readonly("scale", [](PyNerfDataset& d) { return d.d->scale; })
 		.def_property_readonly("aabb_scale", [](PyNerfDataset& d) { return d.d->aabb_scale; })
+		// nerf_loader.h:94-99 (read from transforms.json by the loader; writable here for datasets built with create_empty_nerf_dataset — takes effect at the next reload_network / reset_network)
+		.def_property("n_extra_learnable_dims", [](PyNerfDataset& d) { return d.d->n_extra_learnable_dims; }, [](PyNerfDataset& d, uint32_t n) { d.d->n_extra_learnable_dims = n; })
+		.def_property_readonly("has_light_dirs", [](PyNerfDataset& d) { return d.d->has_light_dirs; })
+		.def_property_readonly("n_extra_dims", [](PyNerfDataset& d) { return d.d->n_extra_dims(); })
+		.def("set_light_dirs", [](PyNerfDataset& d, const py::array_t<float, py::array::c_style | py::array::forcecast>& dirs) {   // per image, NGP frame (what `driver_parameters` gives the loader)
+				if (dirs.ndim() != 2 || dirs.shape(1) != 3 || (size_t)dirs.shape(0) != d.d->n_images) throw std::runtime_error{"set_light_dirs: an (n_images, 3) array"};
+				d.d->light_dirs.resize(d.d->n_images);
+				for (size_t i = 0; i < d.d->n_images; ++i) d.d->light_dirs[i] = Vec3{dirs.at(i, 0), dirs.at(i, 1), dirs.at(i, 2)};
+				d.d->has_light_dirs = true; d.d->n_extra_learnable_dims = 0;
+			}, py::arg("light_dirs"))
 		.def_property_readonly("from_mitsuba", [](PyNerfDataset& d) { return d.d->from_mitsuba; })
 		.def_property_readonly("is_hdr", [](PyNerfDataset& d) { return d.d->is_hdr; });
 
@@ -747,6 +757,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("render_n_streams", &Nerf::render_n_streams)
 		.def_readwrite("cone_angle_constant", &Nerf::cone_angle_constant)
 		.def_readwrite("show_accel", &Nerf::show_accel)
+		.def_property("light_dir", [](Nerf& n) { return vec3_to_py(n.light_dir); }, [](Nerf& n, const py::object& v) { n.light_dir = vec3_from_py(v); })   // testbed.h:712 (GUI slider in the reference)
+		.def_readwrite("extra_dim_idx_for_inference", &Nerf::extra_dim_idx_for_inference)                                                                     // testbed.h:713
 		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)
 		.def_readwrite("glow_y_cutoff", &Nerf::glow_y_cutoff)
 		.def_readwrite("glow_mode", &Nerf::glow_mode)
@@ -776,7 +788,13 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("near_distance", &NerfTraining::near_distance)
 		.def_readwrite("optimize_exposure", &NerfTraining::optimize_exposure)                   // python_api.cu:813
 		.def_readwrite("optimize_extrinsics", &NerfTraining::optimize_extrinsics)               // python_api.cu:811
-		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)               // python_api.cu:812, 814: switches of trainables this build lacks; train() refuses while one is set
+		.def_readwrite("optimize_extra_dims", &NerfTraining::optimize_extra_dims)               // python_api.cu:812: per-image latent codes (n_extra_learnable_dims of the dataset)
+		.def("get_extra_dims", [](NerfTraining& t) {   // the latent codes / light directions as the network sees them: (n_images, n_extra_dims) fp32 (extension: tests, scripts)
+				const uint32_t ne = t.dataset.n_extra_dims();
+				py::array_t<float> a({(py::ssize_t)t.dataset.n_images, (py::ssize_t)ne});
+				if (ne && t.extra_dims_gpu.bytes() >= t.dataset.n_images * ne * 4) t.extra_dims_gpu.copy_to_host(a.mutable_data(), t.dataset.n_images * ne * 4);
+				return a;
+			})
 		.def_readwrite("optimize_distortion", &NerfTraining::optimize_distortion)
 		.def_readwrite("train_envmap", &NerfTraining::train_envmap)   // testbed.h:656 (the reference flips it from its GUI)
 		.def_readwrite("optimize_focal_length", &NerfTraining::optimize_focal_length)           // python_api.cu:815: accepted; trains nothing, like the reference (testbed.h note)

@@ -462,6 +462,7 @@ void Testbed::load_training_data(const std::string& data_path) {  // testbed.cu:
 	d.pixelmemory.clear(); d.pixelmemory.resize(d.n_images);
 	d.scale = data.scale; d.offset = data.offset; d.aabb_scale = data.aabb_scale; d.from_mitsuba = data.from_mitsuba; d.is_hdr = data.is_hdr;
 	d.render_aabb = data.render_aabb; d.up = data.up;
+	d.n_extra_learnable_dims = data.n_extra_learnable_dims; d.has_light_dirs = data.has_light_dirs; d.light_dirs = data.light_dirs;
 	d.envmap_data = data.envmap_data; d.envmap_resolution[0] = data.envmap_resolution[0]; d.envmap_resolution[1] = data.envmap_resolution[1];
 	d.has_rays = data.has_rays;
 	d.raymemory.clear(); d.raymemory.resize(d.n_images);
@@ -675,11 +676,21 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	if (config.contains("network")) {
 		require(config["network"].value("n_neurons", 64) == 64 && config["network"].value("n_hidden_layers", 1) == 1, "network must be 64 neurons x 1 hidden layer");
 	}
-	if (config.contains("rgb_network")) {
-		require(config["rgb_network"].value("n_neurons", 64) == 64 && config["rgb_network"].value("n_hidden_layers", 2) == 2, "rgb_network must be 64 neurons x 2 hidden layers");
+	m_n_rgb_hidden_layers = 2;
+	if (config.contains("rgb_network")) {   // configs/nerf/base_{0,1,2,3}layer.json: 0 hidden layers = one linear map ([tcnn] CutlassMLP), else 64-wide hidden layers
+		const int h = config["rgb_network"].value("n_hidden_layers", 2);
+		require(h >= 0 && h <= 3, "rgb_network.n_hidden_layers must be 0..3");
+		require(h == 0 || config["rgb_network"].value("n_neurons", 64) == 64, "rgb_network must be 64 neurons wide");
+		m_n_rgb_hidden_layers = (uint32_t)h;
 	}
+	// per-image extra dims (testbed.cu:2353-2357): the dataset decides
+	m_n_extra_dims = tr.dataset.n_extra_dims();
+	require(m_n_extra_dims <= 16, "at most 16 extra dims (n_extra_learnable_dims, or 3 light-direction dims)");
 	check(ngp_hip_net_make_desc_host(m_num_levels, log2_hashmap_size, m_base_grid_resolution, m_per_level_scale, &m_desc), "ngp_hip_net_make_desc_host");
-	m_n_params = ngp_hip_net_n_params_host(&m_desc);
+	NgpNetVariant nv;
+	m_n_matrix_params = ngp_hip_net_mlp_params_host(net_variant(nv));
+	m_n_params = (size_t)m_n_matrix_params + 2u * (size_t)m_desc.n_grid_entries;
+	tr.reset_extra_dims(m_rng);   // testbed.cu:2347
 	m_desc_gpu.resize(sizeof(NgpNetDesc));
 	m_desc_gpu.copy_from_host(&m_desc, sizeof(NgpNetDesc));
 
@@ -690,7 +701,7 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	m_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize((m_n_params + DP_PARAM_SLACK) * 2);
 	m_master.resize((m_n_params + DP_PARAM_SLACK) * 4); m_first_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_second_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_ema.resize(m_n_params * 4);
 	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream); m_params.memset(0, m_stream); m_master.memset(0, m_stream);
-	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>()), "ngp_hip_nerf_init_params");
+	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>(), net_variant(nv)), "ngp_hip_nerf_init_params");
 
 	{   // distortion map model (testbed.cu:2386-2396) and envmap model (2447-2462): their own optimizers, else the network's
 		int dres[2] = {32, 32};
@@ -814,7 +825,8 @@ void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t
 	tr.density_grid_rng.advance();
 	// density pass on the TRAINING weights (use_inference_params = false, testbed_nerf.cu:2833)
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_samples));
-	check(ngp_hip_nerf_density_ws(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes()), "nerf_density");
+	NgpNetVariant nv_density;
+	check(ngp_hip_nerf_density_ws(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes(), net_variant(nv_density)), "nerf_density");
 	check(ngp_hip_splat_grid_samples_max(m_stream, n_samples, m_grid_indices.as<uint32_t>(), m_grid_mlp_out.as<uint16_t>(), m_grid_tmp.as<float>(), (int)m_nerf.density_activation), "splat");
 	check(ngp_hip_ema_grid_samples(m_stream, n_elements, decay, grid, m_grid_tmp.as<float>()), "ema");
 	++m_nerf.density_grid_ema_step;
@@ -830,6 +842,50 @@ void Testbed::update_density_grid_mean_and_bitfield() {  // testbed_nerf.cu:2844
 	m_nerf.bitfield_brick_summary.enlarge(GRID_CELLS / 64 / 32 * 4);
 	check(ngp_hip_bitfield_brick_summary(m_stream, m_nerf.density_grid_bitfield.as<uint8_t>(), m_nerf.bitfield_brick_summary.as<uint32_t>()), "bitfield_brick_summary");
 	m_nerf.brick_summary_valid = true;
+}
+
+void NerfTraining::reset_extra_dims(Pcg32& rng) {  // testbed_nerf.cu:2297-2318
+	const uint32_t ne = dataset.n_extra_dims();
+	extra_dims_opt.clear();
+	if (ne == 0) return;
+	std::vector<float> cpu((size_t)ne * (dataset.n_images + 1), 0.f);   // n_images + 1: the extra slot of the inference latent code
+	extra_dims_opt.resize(dataset.n_images);
+	for (size_t i = 0; i < dataset.n_images; ++i) {
+		NerfTraining::ExtraDimsAdam& a = extra_dims_opt[i];
+		a.iter = 0; a.m.assign(ne, 0.f); a.v.assign(ne, 0.f); a.x.assign(ne, 0.f);
+		Vec3 ld{0.f, 0.f, 0.f};
+		if (dataset.has_light_dirs && i < dataset.light_dirs.size()) {   // warp_direction(light_dir.normalized()) = (d + 1) / 2
+			const Vec3 d = dataset.light_dirs[i];
+			const float n = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+			if (n > 0.f) ld = Vec3{(d.x / n + 1.f) * 0.5f, (d.y / n + 1.f) * 0.5f, (d.z / n + 1.f) * 0.5f}; else ld = Vec3{0.5f, 0.5f, 0.5f};
+		}
+		const float l3[3] = {ld.x, ld.y, ld.z};
+		for (uint32_t j = 0; j < ne; ++j) {
+			const float v = (dataset.has_light_dirs && j < 3) ? l3[j] : rng.next_float() * 2.f - 1.f;
+			cpu[i * ne + j] = v; a.x[j] = v;
+		}
+	}
+	extra_dims_gpu.resize(cpu.size() * 4);
+	extra_dims_gpu.copy_from_host(cpu.data(), cpu.size() * 4);
+}
+
+const float* Testbed::get_inference_extra_dims() {  // testbed_nerf.cu:2320-2337
+	if (m_n_extra_dims == 0) return nullptr;
+	NerfTraining& tr = m_nerf.training;
+	const uint32_t ne = tr.dataset.n_extra_dims();
+	if (ne != m_n_extra_dims || tr.extra_dims_gpu.bytes() < (size_t)ne * (tr.dataset.n_images + 1) * 4) throw std::runtime_error{"the dataset's extra dims changed after the network was built: call reload_network_from_file / reset_network"};
+	const uint32_t idx = std::min<uint32_t>(m_nerf.extra_dim_idx_for_inference, tr.dataset.n_images ? (uint32_t)tr.dataset.n_images - 1 : 0u);
+	const float* src = tr.extra_dims_gpu.as<float>() + (size_t)idx * ne;
+	if (!tr.dataset.has_light_dirs) return src;
+	// the dataset has light directions: the scratch slot behind the images' rows gets the chosen row with the requested light direction in front
+	float* dst = tr.extra_dims_gpu.as<float>() + tr.dataset.n_images * ne;
+	HIP_CHECK_THROW(hipMemcpyAsync(dst, src, (size_t)ne * 4, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+	const Vec3 d = m_nerf.light_dir;
+	const float n = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+	const float ld[3] = {(d.x / n + 1.f) * 0.5f, (d.y / n + 1.f) * 0.5f, (d.z / n + 1.f) * 0.5f};
+	HIP_CHECK_THROW(hipMemcpyAsync(dst, ld, std::min<size_t>((size_t)ne * 4, 12), hipMemcpyHostToDevice, (hipStream_t)m_stream));
+	HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));   // `ld` is a stack array
+	return dst;
 }
 
 void Testbed::set_distributed(uint32_t rank, uint32_t world_size) {
@@ -872,9 +928,6 @@ void Testbed::shutdown_data_parallel() {
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
-	if (m_nerf.training.optimize_extra_dims)
-		throw std::runtime_error{"nerf.training.optimize_extra_dims: per-image latent codes (testbed_nerf.cu:1710-1746, 3029-3054) widen the network input and are not part of this build "
-		                         "(optimize_extrinsics, optimize_exposure, optimize_distortion and the environment map are; optimize_focal_length trains nothing in the reference either)"};
 	if (m_dp_comm) {
 		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
 		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
@@ -1066,8 +1119,21 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		                                OUT_STRIDE, m_x_all.as<uint16_t>(), (int)m_nerf.density_activation, getenv("NGP_HIP_FWD_STOP") ? (float)atof(getenv("NGP_HIP_FWD_STOP")) : 0.5f * 1e-4f /* half of EPSILON (testbed_nerf.cu:1345) */, gen_counters + 3), "nerf_forward_rays");
 	} else {
 		static const bool fwd_ws = getenv("NGP_HIP_FWD_WS") != nullptr;   // dev: the two-kernel pass (encode into level planes, then the MLP kernel) instead of the fused one
-		if (fwd_ws) check(ngp_hip_nerf_forward_ws(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes()), "nerf_inference (ws)");
-		else check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>()), "nerf_inference");
+		NgpNetVariant nv;
+		const NgpNetVariant* variant = nullptr;
+		if (!net_is_base_family()) {
+			if (m_n_extra_dims) {   // every sample carries its image's extra dims (testbed_nerf.cu:1136, 1246): here as a row index per sample, expanded from the kept rays' runs
+				NgpErrorMapCdf cdf_slots;
+				const NgpErrorMapCdf* cdfp = tr.error_map_cdf(cdf_slots);
+				m_ray_image.enlarge((size_t)R * 4); m_sample_slot_all.enlarge((size_t)max_inference * 4);
+				HIP_CHECK_THROW(hipMemsetAsync(m_sample_slot_all.data(), 0, (size_t)max_inference * 4, (hipStream_t)m_stream));   // padding rows of the batch: any valid row
+				check(ngp_hip_ray_images(m_stream, R, gen_counters + 0, m_ray_indices.as<uint32_t>(), n_rays_global, (uint32_t)tr.n_images_for_training, cdfp ? cdfp->cdf_img : nullptr, m_ray_image.as<uint32_t>()), "ray_images");
+				check(ngp_hip_expand_ray_slots(m_stream, R, gen_counters + 0, m_ray_image.as<uint32_t>(), m_numsteps.as<uint32_t>(), max_inference, m_sample_slot_all.as<uint32_t>()), "expand_ray_slots");
+			}
+			variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot_all.as<uint32_t>() : nullptr);
+		}
+		if (fwd_ws && !variant) check(ngp_hip_nerf_forward_ws(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes(), nullptr), "nerf_inference (ws)");
+		else check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), variant), "nerf_inference");
 	}
 	profile_end(PK_INFERENCE, max_inference);
 	if (tr.optimize_exposure) {
@@ -1126,6 +1192,16 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		HIP_CHECK_THROW(hipMemcpyAsync((char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay), m_numsteps.data(), (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
 		HIP_CHECK_THROW(hipMemcpyAsync(m_cam_ray_indices.data(), m_ray_indices.data(), (size_t)R * 4, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
 	}
+	if (m_n_extra_dims) {
+		// the compacted batch's extra-dims rows: the kept rays' compacted runs, then the roll-over rule for the padded tail; the compacted (count, base) pairs are set
+		// aside for the latent-code gradient kernel behind the backward pass (the next step's march, launched once the host has seen the counters posted below,
+		// overwrites m_numsteps) — all in stream order before the post
+		m_sample_slot.enlarge((size_t)target_batch_size * 4); m_extra_numsteps.enlarge((size_t)R * 8);
+		HIP_CHECK_THROW(hipMemsetAsync(m_sample_slot.data(), 0, (size_t)target_batch_size * 4, (hipStream_t)m_stream));
+		check(ngp_hip_expand_ray_slots(m_stream, R, gen_counters + 0, m_ray_image.as<uint32_t>(), m_numsteps.as<uint32_t>(), target_batch_size, m_sample_slot.as<uint32_t>()), "expand_ray_slots (compacted)");
+		check(ngp_hip_rollover_slots(m_stream, target_batch_size, compacted_counter, m_sample_slot.as<uint32_t>()), "rollover_slots");
+		HIP_CHECK_THROW(hipMemcpyAsync(m_extra_numsteps.data(), m_numsteps.data(), (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
+	}
 	const float* loss_sum_dev = nullptr;
 	if (get_loss_scalar) {
 		check(ngp_hip_reduce_sum_f32(m_stream, c.loss.as<float>(), R, m_loss_scalar_gpu.as<float>()), "reduce_sum");
@@ -1159,7 +1235,9 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// the compacted batch is the encoding that arrived with the compaction above; m_separate_forward restores the second pass (same bits).
 	if (m_separate_forward) {
 		profile_begin(PK_FORWARD);
-		check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>()), "nerf_forward");
+		NgpNetVariant nvf;
+		check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_saved.as<uint16_t>(),
+		                           net_variant(nvf, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr)), "nerf_forward");
 		profile_end(PK_FORWARD, target_batch_size);
 	}
 	profile_begin(PK_BACKWARD);
@@ -1168,8 +1246,9 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		// prepare_input_gradients (3327-3330): the backward pass also writes dL/d(pos, dir) of every compacted sample; compute_cam_gradient_train_nerf (3350-3378)
 		// folds them into per-image position / rotation gradients.  The ray counter of this step's slot is stable until the step after next.
 		m_coords_gradient.enlarge((size_t)target_batch_size * 6 * sizeof(float));
-		check(ngp_hip_nerf_backward_input(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-		                                  OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), m_coords_gradient.as<float>()), "nerf_backward_input");
+		if (!net_is_base_family()) throw std::runtime_error{"optimize_extrinsics / optimize_distortion need the network's input gradient, which is built for the base network family (no extra dims, two hidden colour layers)"};
+		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), nullptr), "nerf_backward (with input gradient)");
 		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
 		profile_end(PK_BACKWARD, target_batch_size);
 		check(ngp_hip_compute_cam_gradient_ex(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
@@ -1180,10 +1259,21 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		                                      tr.optimize_distortion ? m_distortion.gradients.as<float>() : nullptr, tr.optimize_distortion ? m_distortion.gradient_weights.as<float>() : nullptr,
 		                                      m_distortion.resolution), "compute_cam_gradient");
 	} else {
-		check(ngp_hip_nerf_backward_ev(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-		                               OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
-		                               m_want_grid_grad_event ? m_grid_grad_event : nullptr), "nerf_backward");
+		NgpNetVariant nv;
+		const bool train_extra_dims = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;   // testbed_nerf.cu:2925
+		if (train_extra_dims) m_dl_dextra.enlarge((size_t)target_batch_size * m_n_extra_dims * 4);
+		const NgpNetVariant* variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims ? m_dl_dextra.as<float>() : nullptr);
+		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
+		                            m_want_grid_grad_event ? m_grid_grad_event : nullptr, nullptr, variant), "nerf_backward");
 		profile_end(PK_BACKWARD, target_batch_size);
+		if (train_extra_dims) {   // compute_extra_dims_gradient_train_nerf (2925-2931, 3333-3346): per image, the sum over its rays' compacted samples
+			const size_t n = (size_t)m_n_extra_dims * (size_t)tr.n_images_for_training;
+			tr.extra_dims_gradient_gpu.enlarge(n * 4);
+			HIP_CHECK_THROW(hipMemsetAsync(tr.extra_dims_gradient_gpu.data(), 0, n * 4, (hipStream_t)m_stream));
+			check(ngp_hip_extra_dims_gradient(m_stream, R, gen_counters + 0, m_ray_image.as<uint32_t>(), m_extra_numsteps.as<uint32_t>(), m_dl_dextra.as<float>(), m_n_extra_dims,
+			                                  tr.extra_dims_gradient_gpu.as<float>()), "extra_dims_gradient");
+		}
 	}
 	m_grid_grad_event_recorded = m_want_grid_grad_event;
 	m_rng.advance();  // 3380 (the generator and the loss kernel of this step both used the pre-advance state)
@@ -1306,6 +1396,29 @@ void Testbed::train_nerf_dp_end() {
 		m_loss_scalar = 0.f;
 		fprintf(stderr, "Nerf training generated 0 samples. Aborting training.\n");
 		m_train = false;
+	}
+	if (tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims && m_n_extra_dims) {   // 3029-3054: one host Adam per image on its latent code, every step
+		const uint32_t n_img = (uint32_t)tr.n_images_for_training, ne = m_n_extra_dims;
+		if (m_dp_comm) check(ngp_rccl_allreduce_f32(m_dp_comm, m_stream, tr.extra_dims_gradient_gpu.as<float>(), (uint64_t)n_img * ne), "ngp_rccl_allreduce_f32 (latent-code gradients)");
+		std::vector<float> grad((size_t)n_img * ne);
+		HIP_CHECK_THROW(hipMemcpyAsync(grad.data(), tr.extra_dims_gradient_gpu.data(), grad.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
+		for (uint32_t i = 0; i < n_img; ++i) {
+			NerfTraining::ExtraDimsAdam& a = tr.extra_dims_opt[i];
+			// set_learning_rate(max(1e-3 * 0.33^(step / 128), lr / 1000)) with the optimizer's step count BEFORE this step (3043), then AdamOptimizer::step (adam_optimizer.h:38-45)
+			const float lr0 = std::max(1e-3f * std::pow(0.33f, (float)(a.iter / 128)), m_learning_rate / 1000.0f);
+			++a.iter;
+			const float beta1 = 0.9f, beta2 = 0.99f, eps = 1e-8f;
+			const float lr = lr0 * std::sqrt(1 - std::pow(beta2, (float)a.iter)) / (1 - std::pow(beta1, (float)a.iter));
+			for (uint32_t j = 0; j < ne; ++j) {
+				const float g = grad[(size_t)i * ne + j] / LOSS_SCALE;
+				a.m[j] = beta1 * a.m[j] + (1 - beta1) * g;
+				a.v[j] = beta2 * a.v[j] + (1 - beta2) * g * g;
+				a.x[j] -= lr * a.m[j] / (std::sqrt(a.v[j]) + eps);
+				grad[(size_t)i * ne + j] = a.x[j];   // "extra_dims_new_values" aliases the gradient array (3031)
+			}
+		}
+		tr.extra_dims_gpu.copy_from_host(grad.data(), grad.size() * 4);
 	}
 	// camera-side trainables (3026, 3056-3135): only the per-image exposure is built
 	tr.n_steps_since_cam_update += 1;
@@ -1589,12 +1702,17 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	                           &m_render_aabb, m_render_aabb_to_local, m_render_near_distance, lens_mode, m_nerf.render_lens_proxy.lens_params, rb.depth_buffer.as<float>(),
 	                           plane_z, m_aperture_size, m_render_camera_models.model ? &m_render_camera_models : nullptr, &ex), "init_rays");
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
+	// the latent code / light direction presented at inference time: one row for every sample of the frame (get_inference_extra_dims, 2362)
+	NgpNetVariant render_variant_storage;
+	const NgpNetVariant* render_variant = net_variant(render_variant_storage, get_inference_extra_dims(), nullptr);
+	if (render_variant && (render_mode == (int)ERenderMode::Normals || render_mode == 8))
+		throw std::runtime_error{"the Normals / EncodingVis render modes run the network's input gradient / activation read-out, which are built for the base network family only"};
 	if (m_render_mode == ERenderMode::Slice) {   // 2445-2476: the network where every ray meets the slice plane; all rays of the frame are shaded
 		const uint32_t n_hit = n_pixels, n_elements = (uint32_t)next_multiple(n_hit, BATCH_SIZE_GRANULARITY);
 		m_tr_vis_rgba.enlarge((size_t)n_elements * 16);
 		check(ngp_hip_generate_inputs_at_current_position(m_stream, n_hit, &m_aabb, m_tr_payload[0].as<NgpPayload>(), m_tr_net_in.as<NgpCoord>()), "generate_inputs_at_current_position");
 		if (m_visualized_dimension == -1) {
-			check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>() /* m_network->inference: the training weights (2459) */, m_tr_net_in.as<float>(), 7, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE), "nerf_inference (slice)");
+			check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>() /* m_network->inference: the training weights (2459) */, m_tr_net_in.as<float>(), 7, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, render_variant), "nerf_inference (slice)");
 			check(ngp_hip_compute_nerf_rgba(m_stream, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_tr_vis_rgba.as<float>(), (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, 0.01f, 0), "compute_nerf_rgba");
 		} else {
 			check(ngp_hip_nerf_visualize_activation(m_stream, desc, m_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, m_tr_net_in.as<float>(), 7, n_hit, m_tr_vis_rgba.as<float>(), 4), "visualize_activation (slice)");
@@ -1677,8 +1795,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
 			static const bool fused_render = getenv("NGP_HIP_RENDER_FUSED") != nullptr;   // dev: the fused kernel instead of encode + MLP (re-measurement knob)
-			if (fused_render) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE), "nerf_inference (render, fused)");
-			else check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes()), "nerf_inference (render)");
+			if (fused_render) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, render_variant), "nerf_inference (render, fused)");
+			else check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes(), render_variant), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
 			if (render_mode == (int)ERenderMode::Normals) {   // 2225-2226: network.input_gradient(stream, 3, positions, positions) — on the inference weights like the pass above
 				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);

@@ -104,6 +104,11 @@ struct NerfDataset {
 	bool has_rays = false;
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
+	// per-image extra network inputs (nerf_loader.h:94-99): `n_extra_learnable_dims` latent codes, or 3 light-direction dims when frames carry `driver_parameters`
+	uint32_t n_extra_learnable_dims = 0;
+	bool has_light_dirs = false;
+	std::vector<Vec3> light_dirs;                // per image, NGP frame, normalised (TrainingImageMetadata::light_dir)
+	uint32_t n_extra_dims() const { return (has_light_dirs ? 3u : 0u) + n_extra_learnable_dims; }
 	std::vector<float> envmap_data;              // `envmap` key of transforms.json (nerf_loader.h envmap_data; host copy, uploaded by reset_network like testbed.cu:2459-2461)
 	int envmap_resolution[2] = {0, 0};
 
@@ -169,9 +174,13 @@ struct NerfTraining {
 	// the reference's Adam step sees a zero gradient on a zero variable and the offset stays exactly 0 — and nothing reads the offset.  The switch is accepted and
 	// trains nothing, like there.
 	bool optimize_focal_length = false;
-	// camera-side trainables of testbed.h:653-662 that this build does not train: the switches exist so that a script setting them fails loudly
-	// in train() instead of silently training something else (python_api.cu:804-812)
+	// per-image latent codes (testbed.h:637-641, 660; testbed_nerf.cu:2297-2318, 2925-2931, 3029-3054): [(n_images + 1)][n_extra_dims] fp32, the last row is the
+	// scratch slot of get_inference_extra_dims; every image has its own host Adam (AdamOptimizer<ArrayXf>, lr 1e-4 at construction, reset per step)
 	bool optimize_extra_dims = false, optimize_distortion = false;
+	DeviceBuffer extra_dims_gpu, extra_dims_gradient_gpu;
+	struct ExtraDimsAdam { uint32_t iter = 0; std::vector<float> m, v, x; };
+	std::vector<ExtraDimsAdam> extra_dims_opt;
+	void reset_extra_dims(Pcg32& rng);
 	bool distortion_gradient_window_open = false;                  // the distortion gradients of the current n_steps_between_cam_updates window are being accumulated
 	bool train_envmap = false;                                     // testbed.h:656 (the reference sets it from its GUI only; exposed on pyngp here)
 	bool include_sharpness_in_error = false;                       // testbed.h:670 (the sharpness map is not computed by this loader)
@@ -229,6 +238,8 @@ struct Nerf {
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
+	Vec3 light_dir{0.5f, 0.5f, 0.5f};        // testbed.h:712: the light direction presented at inference time when the dataset has light directions
+	uint32_t extra_dim_idx_for_inference = 0; // testbed.h:713: which training image's latent code is presented at inference time
 	bool visualize_cameras = false;          // GUI-side (stored)
 	float glow_y_cutoff = 0.f; int glow_mode = 0;   // testbed.h:730-731; the glow shading of composite_kernel_nerf (testbed_nerf.cu:843-939)
 	NgpImageMeta render_lens_proxy{};        // only lens_mode / lens_params are used (render_lens)
@@ -336,7 +347,18 @@ public:
 	float compute_image_mse(bool quantize_to_byte);                                   // testbed_image.cu:461-523
 	uint32_t gridmlp_n_dims() const { return m_testbed_mode == ETestbedMode::Image ? 2u : 3u; }
 	void gridmlp_training_step(const float* pos, uint32_t n_dims, const float* targets, uint32_t dims, uint32_t n, bool get_loss_scalar);
-	uint32_t m_n_matrix_params = NGP_MLP_N_PARAMS;     // parameters that get weight decay (the MLPs): 10240 NeRF, 7168 grid -> MLP
+	uint32_t m_n_matrix_params = NGP_MLP_N_PARAMS;     // parameters that get weight decay (the MLPs): 10240 NeRF (base family), 7168 grid -> MLP
+	// the network the config + dataset ask for (src/testbed.cu:2337-2363): extra dims behind the direction encoding, hidden layers of the colour network.  The base
+	// family (0, 2) runs the fused kernels; anything else the generic ones (NgpNetVariant, include/ngp_hip.h)
+	uint32_t m_n_extra_dims = 0, m_n_rgb_hidden_layers = 2;
+	bool net_is_base_family() const { return m_n_extra_dims == 0 && m_n_rgb_hidden_layers == 2; }
+	const NgpNetVariant* net_variant(NgpNetVariant& storage, const float* extra_dims = nullptr, const uint32_t* sample_slot = nullptr, float* dL_dextra = nullptr) const {
+		if (net_is_base_family()) return nullptr;
+		storage.n_extra_dims = m_n_extra_dims; storage.n_rgb_hidden_layers = m_n_rgb_hidden_layers; storage.extra_dims = extra_dims; storage.sample_slot = sample_slot; storage.dL_dextra = dL_dextra;
+		return &storage;
+	}
+	const float* get_inference_extra_dims();           // testbed_nerf.cu:2320-2337
+	DeviceBuffer m_ray_image, m_sample_slot_all, m_sample_slot, m_dl_dextra, m_extra_numsteps;   // per kept ray: its image; per sample (pre-compaction / compacted): the extra-dims row; dL/d(extra dims) [B][n_extra]
 	DeviceBuffer m_gm_out, m_gm_values;
 
 	// ---- Blender multi-NeRF requests (python_api.cu:192-260, testbed.cu:2675-2693)

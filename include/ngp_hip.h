@@ -89,27 +89,42 @@ const char* ngp_hip_last_error(void);
 
 /* tcnn GridEncoding ctor (level scale / resolution / offset table); per_level_scale per src/testbed.cu:2313-2325. Host only. */
 int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, uint32_t base_resolution, float per_level_scale, NgpNetDesc* desc_host);
-/* number of parameters: 10240 + 2*n_grid_entries; order density MLP, rgb MLP, grid (nerf_network.h:361-394). Host only. */
+/* number of parameters of the base family: 10240 + 2*n_grid_entries; order density MLP, rgb MLP, grid (nerf_network.h:361-394). Host only. */
 uint32_t ngp_hip_net_n_params_host(const NgpNetDesc* desc_host);
+
+/* NerfNetwork as the reference BUILDS it from other configs (src/testbed.cu:2337-2363; nerf_network.h:76-101).  Every network entry point below takes an optional
+ * trailing `const NgpNetVariant*`; NULL (or {0 extra dims, 2 hidden colour layers}) is configs/nerf/base.json — the fused MFMA kernels.  Anything else runs the
+ * generic kernels of csrc/network_generic.cuh (bit-compatible with oracle/orc_netx.c; functional, not tuned):
+ *   n_extra_dims 1..16     per-image latent codes (`n_extra_learnable_dims`) or light directions (`driver_parameters`): an Identity-encoded block behind the SH
+ *                          block of the direction encoding (configs/nerf/base.json:37-51) — the colour network's input grows from 32 to 48;
+ *   n_rgb_hidden_layers    0..3: configs/nerf/base_{0,1,2,3}layer.json (0 = one [16][in] matrix, no activation; h >= 1: [64][in], (h - 1) x [64][64], [16][64]).
+ * Parameter order: density MLP [64][32], [16][64]; the colour matrices in layer order; the grid.  Host struct, device pointers. */
+typedef struct {
+	uint32_t n_extra_dims, n_rgb_hidden_layers;
+	const float* extra_dims;       /* [rows][n_extra_dims] fp32 (Testbed::Nerf::Training::extra_dims_gpu, src/testbed_nerf.cu:2297-2318) or NULL */
+	const uint32_t* sample_slot;   /* [n]: the row of extra_dims each sample uses (its ray's image, :1136); NULL: row 0 for all (rendering: get_inference_extra_dims, :2320-2337) */
+	float* dL_dextra;              /* backward only, or NULL: [n][n_extra_dims] fp32 = the extra-dim rows of the network's dL_dinput (coords_gradient(j)->get_extra_dims(), :1741) */
+} NgpNetVariant;
+uint32_t ngp_hip_net_mlp_params_host(const NgpNetVariant* variant);   /* 10240 for NULL / the base family; the grid follows behind */
 
 /* NerfNetwork::initialize_params (nerf_network.h:396-441) driven by Trainer(seed) (src/testbed.cu:2445): fills the fp32 master
  * copy and the fp16 training + inference copies. */
-int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params);
+int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t seed, float* master, uint16_t* params, uint16_t* inference_params, const NgpNetVariant* variant);
 
 /* NerfNetwork::inference_mixed_precision_impl (nerf_network.h:103-137); call sites src/testbed_nerf.cu:2223, 3256,
  * src/nerf_renderer.cu:763.  coords: n records of `coord_stride_floats` floats (pos at 0..2, dir at 4..6).
  * out: fp16, sample i at out[i*out_stride + 0..3] = (r, g, b, sigma) raw network outputs.  `desc_dev` is a device copy of the desc. */
 int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                           uint32_t n, uint16_t* out, uint32_t out_stride);
+                           uint32_t n, uint16_t* out, uint32_t out_stride, const NgpNetVariant* variant);
 
 /* NerfNetwork::density (nerf_network.h:268-284); call site src/testbed_nerf.cu:2833.  out0[i] = density-net output channel 0 (fp16). */
 int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
-                         uint32_t n, uint16_t* out0);
+                         uint32_t n, uint16_t* out0, const NgpNetVariant* variant);
 
 /* NerfNetwork::forward_impl (nerf_network.h:143-185); call site src/testbed_nerf.cu:3330.  Same outputs as inference plus the
  * encoded features x_saved [n][32] fp16 that backward consumes (the tcnn ForwardContext). */
 int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+                         uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, const NgpNetVariant* variant);
 /* The training step's pre-compaction network pass (src/testbed_nerf.cu:3256) restricted to what the loss kernel can keep.  The reference evaluates every marched
  * sample and lets compute_loss_kernel_train_nerf stop at the first sample whose transmittance fell below 1e-4 (:1341-1374); this entry point walks each ray
  * (numsteps: the ray generator's (count, base) pairs, *rays_counter of them) in tiles of 32 consecutive samples, multiplies the tile's (1 - alpha) — alpha from the
@@ -126,37 +141,43 @@ int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const ui
  * (training, occupancy-grid update, render passes); the single-kernel entry points need no workspace. */
 uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n);
 int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes);
+                              uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant);
 int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
-                            uint32_t n, uint16_t* out0, void* workspace, uint64_t workspace_bytes);
+                            uint32_t n, uint16_t* out0, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant);
 int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
-                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes);
+                            uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant);
 
 /* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only. */
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
 
 /* NerfNetwork::backward_impl (nerf_network.h:187-266) with EGradientMode::Overwrite; call site src/testbed_nerf.cu:3331.
  * dL_dout: fp16 [n][dl_stride] with channels 0..3 consumed (extract_rgb 46-60, add_density_gradient 63-74).
- * grads: fp16 [n_params]; the whole vector is overwritten (MLP part written, grid part zeroed then scatter-added). */
+ * grads: fp16 [n_params]; the whole vector is overwritten (every entry written exactly once: no memset, no global float atomics).
+ * Optional trailing arguments (each may be NULL):
+ *   mlp_done_event        a caller-owned hipEvent_t recorded right behind the fused MLP kernel (dgrad + weight gradients; the 256-register kernel of the pass) — a host
+ *                         that runs other work next to the backward can hold that work back until this kernel is through;
+ *   grid_gradients_event  recorded once all of `grads` is final (the hash-grid part — everything behind the MLP parameters — last): a data-parallel host starts
+ *                         its exchange on another stream at that point;
+ *   dL_dinput             fp32 [n][6]: the gradient with respect to the network INPUT — NerfNetwork::backward_impl with a dL_dinput matrix, which the training step
+ *                         requests when camera parameters train (prepare_input_gradients, src/testbed_nerf.cu:3324-3346): d/d(pos x, y, z) through the hash encoding
+ *                         ([tcnn] GridEncoding backward to the input: fp32 sum over levels and features of dL/dy * dy/dx of the trilinear interpolation) and
+ *                         d/d(dir x, y, z) through the SH basis, both in the warped [0, 1] coordinates of NgpCoord; dt carries no gradient (base family only);
+ *   variant               see NgpNetVariant (its dL_dextra receives the extra-dim gradients). */
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                          uint16_t* grads, void* scratch, uint64_t scratch_bytes);
-/* Same; additionally records up to two caller-owned hipEvent_t's (either may be NULL) on the stream:
- *   mlp_done_event        right behind the fused MLP kernel (dgrad + weight gradients; the 256-register kernel of the pass) — a host that runs
- *                         other work next to the backward can hold that work back until this kernel is through;
- *   grid_gradients_event  once all of `grads` is final (the MLP part is final one small kernel after mlp_done_event, the hash-grid part — everything
- *                         behind the first 10240 parameters — last): a data-parallel host starts its all-reduce on another stream at that point. */
-int ngp_hip_nerf_backward_ev(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                             uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                             uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event);
-/* The same backward pass PLUS the gradient with respect to the network INPUT — NerfNetwork::backward_impl with a dL_dinput matrix
- * (nerf_network.h:187-266), which the training step requests when camera parameters train (prepare_input_gradients, src/testbed_nerf.cu:3324-3346).
- * dL_dinput: fp32 [n][6] = d/d(pos x, y, z) through the hash encoding (tcnn GridEncoding backward to the input: fp32 sum over levels and
- * features of dL/dy * dy/dx of the trilinear interpolation) and d/d(dir x, y, z) through the SH basis, both in the warped [0, 1] coordinates of
- * NgpCoord; dt carries no gradient. */
-int ngp_hip_nerf_backward_input(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
-                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, float* dL_dinput);
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant);
+/* Per-image extra dims of a training step.  ray_image[i] = the image of kept ray i (what image_idx gives the ray generator, src/testbed_nerf.cu:1131-1136);
+ * numsteps = (count, base) pairs of the kept rays (the ray generator's before compaction, the loss kernel's after).
+ *   ngp_hip_ray_images            ray_image[i] = image_idx(ray_indices[i], ...) for the kept rays (:1062-1083);
+ *   ngp_hip_expand_ray_slots      sample_slot[base + j] = ray_image[i] for every sample of every kept ray (the reference appends the image's row to every coordinate, :1246);
+ *   ngp_hip_rollover_slots        sample_slot[k] = sample_slot[k % *n_input_elements] for the padded tail of a compacted batch (fill_rollover, :3314-3322);
+ *   ngp_hip_extra_dims_gradient   compute_extra_dims_gradient_train_nerf (:1710-1746): gradient[ray_image[i]][k] += sum over the ray's compacted samples of dL_dextra. */
+int ngp_hip_ray_images(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_indices, uint32_t n_rays_global, uint32_t n_training_images,
+                       const float* cdf_img /* NgpErrorMapCdf.cdf_img or NULL */, uint32_t* ray_image);
+int ngp_hip_expand_ray_slots(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_image, const uint32_t* numsteps, uint32_t n_samples_capacity, uint32_t* sample_slot);
+int ngp_hip_rollover_slots(void* stream, uint32_t n_elements, const uint32_t* n_input_elements, uint32_t* sample_slot);
+int ngp_hip_extra_dims_gradient(void* stream, uint32_t n_rays_capacity, const uint32_t* rays_counter, const uint32_t* ray_image, const uint32_t* numsteps, const float* dL_dextra, uint32_t n_extra_dims,
+                                float* gradient);
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */

@@ -70,6 +70,16 @@ void orc_nerf_forward_backward(const orc_net* net, const uint16_t* params, const
 void orc_nerf_input_gradient(const orc_net* net, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, float* dL_dinput /* [n][6] */);
 void orc_nerf_visualize_activation(const orc_net* net, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords, uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats);
 void orc_nerf_init_params(const orc_net* net, uint64_t seed, float* params_fp32);
+uint32_t orc_grid_index_export(const orc_grid_level* lv, uint32_t x, uint32_t y, uint32_t z);
+/* orc_netx.c — NerfNetwork for configs other than configs/nerf/base.json: per-image extra dims (latent codes / light directions) behind the direction encoding, and
+ * 0..3 hidden layers in the colour network.  extra_dims: [rows][n_extra_dims] fp32; sample_slot: per sample the row to use (NULL: row 0 for every sample) */
+typedef struct { uint32_t n_extra_dims, n_rgb_hidden_layers; const float* extra_dims; const uint32_t* sample_slot; } orc_netx;
+uint32_t orc_netx_mlp_params(const orc_netx* x);
+uint32_t orc_netx_n_params(const orc_net* net, const orc_netx* x);
+void orc_nerf_inference_x(const orc_net* net, const orc_netx* x, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, uint16_t* out, uint32_t out_stride);
+void orc_nerf_forward_backward_x(const orc_net* net, const orc_netx* x, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, uint32_t n, const uint16_t* dL_dout, uint16_t* out_rgbsigma, double* grads_out, uint16_t* dL_dx_out, float* dL_dextra_out);
+void orc_nerf_init_params_x(const orc_net* net, const orc_netx* x, uint64_t seed, float* params_fp32);
+void orc_compute_extra_dims_gradient(uint32_t n_rays_alive, const uint32_t* ray_image, const uint32_t* numsteps, const float* dL_dextra, uint32_t n_extra_dims, float* gradient);
 void orc_f32_to_f16(const float* in, uint16_t* out, uint32_t n);
 void orc_f16_to_f32(const uint16_t* in, float* out, uint32_t n);
 void orc_adam_ema_step(uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float base_lr_after_decay, float beta1, float beta2, float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads_fp16, float* master, uint16_t* params_fp16, float* m1, float* m2, float* ema_fp32, uint16_t* inference_fp16);

@@ -60,6 +60,8 @@ static inline uint32_t orc_grid_index(const orc_grid_level* lv, uint32_t x, uint
 }
 
 /* [tcnn] kernel_grid forward, one sample: pos in [0,1]^3 -> 2*L fp16 features (returned as fp16 bits) */
+uint32_t orc_grid_index_export(const orc_grid_level* lv, uint32_t x, uint32_t y, uint32_t z) { return orc_grid_index(lv, x, y, z); }
+
 void orc_grid_encode_one(const orc_net* net, const uint16_t* grid /* fp16 [entries][2] */, const float pos_in[3], uint16_t* out) {
 	for (uint32_t l = 0; l < net->n_levels; ++l) {
 		const orc_grid_level* lv = &net->levels[l];

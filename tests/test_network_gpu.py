@@ -131,7 +131,7 @@ def test_backward_matches_oracle(ngp, oracle, cuda):
 
 
 def test_backward_input_gradient_matches_oracle(ngp, oracle, cuda):
-    """ngp_hip_nerf_backward_input: the same parameter gradients as ngp_hip_nerf_backward plus dL/d(pos, dir) per sample (what tcnn's backward writes when the
+    """ngp_hip_nerf_backward with dL_dinput: the same parameter gradients as ngp_hip_nerf_backward plus dL/d(pos, dir) per sample (what tcnn's backward writes when the
     caller passes dL_dinput, testbed_nerf.cu:3329-3330).  The position gradient runs through 16 levels of fp16 feature gradients, the direction gradient
     through the SH polynomials' derivatives: norm-relative 2e-2 like the grid gradients, plus a per-element bound."""
     n = 2048
@@ -149,8 +149,8 @@ def test_backward_input_gradient_matches_oracle(ngp, oracle, cuda):
     d_in = H.to_dev(np.full((n, 6), 7.0, np.float32), cuda)                   # poison: every element is overwritten
     check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
                                     g_plain.data_ptr(), scratch.data_ptr(), sb))
-    check(ngp.ngp_hip_nerf_backward_input(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
-                                          g_input.data_ptr(), scratch.data_ptr(), sb, d_in.data_ptr()))
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                          g_input.data_ptr(), scratch.data_ptr(), sb, None, None, d_in.data_ptr()))
     a, b = H.to_host(g_plain, np.float16).astype(np.float64), H.to_host(g_input, np.float16).astype(np.float64)
     np.testing.assert_array_equal(a[:10240], b[:10240])                       # MLP part: same arithmetic, fixed reduction order
     assert np.linalg.norm(a[10240:] - b[10240:]) <= 2e-3 * np.linalg.norm(a[10240:])   # grid part: fp16 atomics, order varies between launches
@@ -168,8 +168,8 @@ def test_backward_input_gradient_matches_oracle(ngp, oracle, cuda):
     # a prefix of the batch gives the prefix of the result (n is a multiple of 256, like ngp_hip_nerf_backward)
     for m_ in (256, 768):
         d_in2 = H.dev_zeros(m_ * 24, cuda)
-        check(ngp.ngp_hip_nerf_backward_input(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, m_, xs.data_ptr(), d_dl.data_ptr(), 4,
-                                              g_input.data_ptr(), scratch.data_ptr(), sb, d_in2.data_ptr()))
+        check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, m_, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                              g_input.data_ptr(), scratch.data_ptr(), sb, None, None, d_in2.data_ptr()))
         g2 = H.to_host(d_in2, np.float32).reshape(m_, 6)
         np.testing.assert_allclose(g2, got[:m_], rtol=1e-3, atol=1e-3 * np.abs(got).max())
 
@@ -199,7 +199,7 @@ def test_backward_linearity(ngp, cuda):
 
 
 def test_backward_back_to_back_calls_and_events(ngp, cuda):
-    """ngp_hip_nerf_backward_ev: calls that follow each other without a host sync share one scratch (the partials / planes of call k + 1 must not
+    """ngp_hip_nerf_backward with its optional events: calls that follow each other without a host sync share one scratch (the partials / planes of call k + 1 must not
     overtake the reduce of call k — everything is stream-ordered), with and without the two optional events: same bits."""
     import torch
     n = 1 << 16
@@ -217,7 +217,7 @@ def test_backward_back_to_back_calls_and_events(ngp, cuda):
     for with_events in (0, 1):
         gs = [H.dev_zeros(H.n_params(desc) * 2, cuda) for _ in dls]
         for d_dl, g in zip(dls, gs):   # back to back, no sync in between
-            check(ngp.ngp_hip_nerf_backward_ev(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+            check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
                                                g.data_ptr(), scratch.data_ptr(), sb, evs[0].cuda_event if with_events else None, evs[1].cuda_event if with_events else None))
         if with_events:
             evs[1].synchronize()   # "all of grads final" of the last call
