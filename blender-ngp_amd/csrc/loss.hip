@@ -51,6 +51,7 @@ struct LossArgs {
 	float depth_supervision_lambda; int depth_loss_type;  // testbed.h:654, 680 (off by default)
 	float* exposure_gradient;                             // [n_images][3] or NULL (optimize_exposure off)
 	const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int envmap_loss_type;   // 1289-1292: fp32 [h][w][4] (TrainableBuffer<4,2,float>) or NULL
+	const float* sharpness_data; int32_t sharpness_res[2]; float* sharpness_grid;                    // 1321-1323 (include_sharpness_in_error) or NULL
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 	}
 
 	// ---- pass 1: transmittance, ray colour, number of samples before T < EPSILON (1341-1374)
+	v3 hitpoint = mk(0.f, 0.f, 0.f);
 	{
 		float T_carry = 1.f;
 		bool done = false;
@@ -176,6 +178,11 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			rgb_ray[0] += wave_sum(weight * rgb[0]);
 			rgb_ray[1] += wave_sum(weight * rgb[1]);
 			rgb_ray[2] += wave_sum(weight * rgb[2]);
+			if (a.sharpness_data) {   // hitpoint += weight * pos (1367)
+				v3 pos = mk(0.f, 0.f, 0.f);
+				if (valid) { const NgpCoord cc = ci[j]; pos = unwarp_position(mk(cc.pos[0], cc.pos[1], cc.pos[2]), a.aabb); }
+				hitpoint.x += wave_sum(weight * pos.x); hitpoint.y += wave_sum(weight * pos.y); hitpoint.z += wave_sum(weight * pos.z);
+			}
 			if (a.depth_supervision_lambda > 0.0f) {   // depth_ray += weight * cur_depth (1366-1368)
 				float cur_depth = 0.f;
 				if (valid) {
@@ -269,10 +276,27 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			int ix = pix < img_res[0] - 2 ? pix : img_res[0] - 2; ix = ix > 0 ? ix : 0; // 1470 clamps with the IMAGE resolution
 			int iy = piy < img_res[1] - 2 ? piy : img_res[1] - 2; iy = iy > 0 ? iy : 0;
 			float* em = a.error_map + (size_t)img * (size_t)a.error_map_res[0] * (size_t)a.error_map_res[1];
-			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix], (1 - wx) * (1 - wy) * mean_loss);
-			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix + 1], wx * (1 - wy) * mean_loss);
-			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix], (1 - wx) * wy * mean_loss);
-			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix + 1], wx * wy * mean_loss);
+			float em_loss = mean_loss;
+			if (a.sharpness_data) {   // 1476-1485: scale the deposited error by the tile's sharpness relative to the sharpest tile that has seen the ray's hit cell
+				const float inv = 1.0f / (1.0f - T_final);   // hitpoint /= 1 - T (1374)
+				const v3 hp = mk(hitpoint.x * inv, hitpoint.y * inv, hitpoint.z * inv);
+				if (aabb_contains(a.aabb, hp)) {
+					int sx = (int)(xy[0] * (float)a.sharpness_res[0]), sy = (int)(xy[1] * (float)a.sharpness_res[1]);
+					sx = sx > 0 ? sx : 0; sx = sx < a.sharpness_res[0] - 1 ? sx : a.sharpness_res[0] - 1;
+					sy = sy > 0 ? sy : 0; sy = sy < a.sharpness_res[1] - 1 ? sy : a.sharpness_res[1] - 1;
+					const float sharp = a.sharpness_data[(size_t)img * a.sharpness_res[0] * a.sharpness_res[1] + (size_t)sy * a.sharpness_res[0] + sx] + 1e-6f;
+					const uint32_t mip = (uint32_t)mip_from_pos(hp);
+					uint32_t* cell = (uint32_t*)&a.sharpness_grid[cascaded_grid_idx_at(hp, mip) + (size_t)NGP_NERF_GRID_N_CELLS * mip];
+					// the maximum of positive floats in uint format is the maximum of the floats
+					float grid_sharp = __uint_as_float(atomicMax(cell, __float_as_uint(sharp)));
+					grid_sharp = fmaxf(sharp, grid_sharp);   // atomicMax returns the old value
+					em_loss *= fmaxf(sharp / grid_sharp, 0.01f);
+				}
+			}
+			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix], (1 - wx) * (1 - wy) * em_loss);
+			atomicAdd(&em[(size_t)iy * a.error_map_res[0] + ix + 1], wx * (1 - wy) * em_loss);
+			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix], (1 - wx) * wy * em_loss);
+			atomicAdd(&em[(size_t)(iy + 1) * a.error_map_res[0] + ix + 1], wx * wy * em_loss);
 		}
 	}
 
@@ -526,6 +550,33 @@ __global__ void image_mse_kernel(uint32_t n_elements, const float* __restrict__ 
 	result[i] = acc / 3.0f;
 }
 
+// compute_sharpness (src/nerf_loader.cu:129-169)
+__global__ void compute_sharpness_kernel(int srx, int sry, int irx, int iry, const void* __restrict__ pixels, int image_data_type, float* __restrict__ sharpness_data) {
+	const int x = threadIdx.x + blockIdx.x * blockDim.x, y = threadIdx.y + blockIdx.y * blockDim.y;
+	if (x >= srx || y >= sry) return;
+	int x1 = (x * irx) / srx, x2 = ((x + 1) * irx) / srx, y1 = (y * iry) / sry, y2 = ((y + 1) * iry) / sry;
+	x1 = max(x1, 1); y1 = max(y1, 1); x2 = min(x2, irx - 2); y2 = min(y2, iry - 2);   // clamp to 1 pixel in from the edge
+	const int32_t res[2] = {irx, iry};
+	float tot_lap = 0.f, tot_lap2 = 0.f, tot_lum = 0.f;
+	const float scal = 1.f / (float)((x2 - x1) * (y2 - y1));
+	auto luma_at = [&](int px, int py) {
+		float c[4];
+		read_rgba(((float)px + 0.5f) / (float)irx, ((float)py + 0.5f) / (float)iry, res, pixels, image_data_type, c);
+		return c[0] * 0.2126f + c[1] * 0.7152f + c[2] * 0.0722f;
+	};
+	for (int yy = y1; yy < y2; ++yy) for (int xx = x1; xx < x2; ++xx) {
+		const float lum = luma_at(xx, yy);
+		const float lap = lum * 4.f - luma_at(xx, yy - 1) - luma_at(xx + 1, yy) - luma_at(xx, yy + 1) - luma_at(xx - 1, yy);
+		tot_lap += lap; tot_lap2 += lap * lap; tot_lum += lum;
+	}
+	tot_lap *= scal; tot_lap2 *= scal; tot_lum *= scal;
+	sharpness_data[x + (size_t)y * srx] = tot_lap2 - tot_lap * tot_lap;
+}
+__global__ void decay_grid_kernel(uint32_t n, float decay, float* __restrict__ grid) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) grid[i] *= decay;
+}
+
 } // namespace ngp
 
 // ---- error-map CDFs (testbed_nerf.cu:1982-2037).  One thread per (image, row) / per image like the reference: the running sums are
@@ -722,23 +773,6 @@ int ngp_hip_compute_loss(
 	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
 	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
 	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
-	float* exposure_gradient) {
-	return ngp_hip_compute_loss_ex(stream, n_rays, aabb_host, rng_state, rng_inc, max_samples_compacted, rays_counter, loss_scale, mlp_stride, background_color_host, color_space,
-	                               train_with_random_bg_color, train_in_linear_colors, n_training_images, metadata, network_output, numsteps_counter, ray_indices_in, rays_in_unnormalized,
-	                               numsteps_in, coords_in, coords_out, dloss_doutput, dl_stride, loss_type, loss_output, max_level_rand_training, max_level_compacted, rgb_activation,
-	                               density_activation, snap_to_pixel_centers, error_map, error_map_res_host, mean_density, exposure, near_distance, cdf_host, encoded_in, encoded_out,
-	                               depth_supervision_lambda, depth_loss_type, exposure_gradient, nullptr);
-}
-
-int ngp_hip_compute_loss_ex(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
-	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
-	int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const NgpImageMeta* metadata,
-	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const NgpRay* rays_in_unnormalized,
-	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
-	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
-	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
 	float* exposure_gradient, const NgpLossExtras* extras_host) {
 	if (!n_rays) return 0;
 	if ((encoded_in == nullptr) != (encoded_out == nullptr)) { set_last_error("ngp_hip_compute_loss: encoded_in and encoded_out go together", hipErrorInvalidValue); return -1; }
@@ -762,9 +796,29 @@ int ngp_hip_compute_loss_ex(
 		a.envmap_data = extras_host->envmap_data; a.envmap_gradient = extras_host->envmap_gradient;
 		a.envmap_res[0] = extras_host->envmap_res[0]; a.envmap_res[1] = extras_host->envmap_res[1]; a.envmap_loss_type = extras_host->envmap_loss_type;
 	}
+	a.sharpness_data = nullptr; a.sharpness_grid = nullptr; a.sharpness_res[0] = a.sharpness_res[1] = 0;
+	if (extras_host && extras_host->sharpness_data && extras_host->sharpness_grid && extras_host->sharpness_res[0] > 0 && extras_host->sharpness_res[1] > 0) {
+		a.sharpness_data = extras_host->sharpness_data; a.sharpness_grid = extras_host->sharpness_grid;
+		a.sharpness_res[0] = extras_host->sharpness_res[0]; a.sharpness_res[1] = extras_host->sharpness_res[1];
+	}
 	// n_rays upper-bounds *rays_counter (the number of ray slots the generator filled); one wave per slot
 	hipLaunchKernelGGL(compute_loss_kernel, dim3(div_up(n_rays, LOSS_RAYS_PER_BLOCK)), dim3(LOSS_RAYS_PER_BLOCK * 64), 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("compute_loss_kernel");
+	return 0;
+}
+
+// nerf_loader.cu:121-169 compute_sharpness: one thread per tile of the sharpness grid; variance of the Laplacian of the luma of read_rgba, one pixel in from the edge
+int ngp_hip_compute_sharpness(void* stream, const int32_t* sharpness_res_host, const int32_t* image_res_host, const void* pixels, int image_data_type, float* sharpness_out) {
+	const dim3 threads(16, 8, 1), blocks(div_up((uint32_t)sharpness_res_host[0], 16), div_up((uint32_t)sharpness_res_host[1], 8), 1);
+	hipLaunchKernelGGL(compute_sharpness_kernel, blocks, threads, 0, (hipStream_t)stream, sharpness_res_host[0], sharpness_res_host[1], image_res_host[0], image_res_host[1], pixels, image_data_type, sharpness_out);
+	NGP_LAUNCH_CHECK("compute_sharpness_kernel");
+	return 0;
+}
+// decay_sharpness_grid_nerf (src/testbed_nerf.cu:557-561)
+int ngp_hip_decay_grid(void* stream, uint32_t n_elements, float decay, float* grid) {
+	if (!n_elements) return 0;
+	hipLaunchKernelGGL(decay_grid_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, decay, grid);
+	NGP_LAUNCH_CHECK("decay_grid_kernel");
 	return 0;
 }
 

@@ -817,6 +817,12 @@ PYBIND11_MODULE(pyngp, m) {
 			})
 		.def_readwrite("n_steps_between_cam_updates", &NerfTraining::n_steps_between_cam_updates)
 		.def_readwrite("include_sharpness_in_error", &NerfTraining::include_sharpness_in_error)
+		.def("get_sharpness_data", [](NerfTraining& t) {   // (n_images, 72, 128) tile sharpness as the loss kernel reads it (extension: tests)
+				t.dataset.update_sharpness();
+				py::array_t<float> a({(py::ssize_t)t.dataset.n_images, (py::ssize_t)t.dataset.sharpness_resolution[1], (py::ssize_t)t.dataset.sharpness_resolution[0]});
+				if (t.dataset.n_images) t.dataset.sharpness_data.copy_to_host(a.mutable_data(), (size_t)a.size() * 4);
+				return a;
+			})
 		.def_readwrite("extrinsic_l2_reg", &NerfTraining::extrinsic_l2_reg)
 		.def_readwrite("extrinsic_learning_rate", &NerfTraining::extrinsic_learning_rate)
 		.def_readwrite("intrinsic_l2_reg", &NerfTraining::intrinsic_l2_reg)

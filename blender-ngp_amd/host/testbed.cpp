@@ -93,6 +93,7 @@ void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pi
 	const size_t stride = image_data_type == 1 ? 4 : (image_data_type == 2 ? 8 : 16);
 	pixelmemory[frame_idx].resize(px * stride);
 	pixelmemory[frame_idx].copy_from_host(pixels_host, px * stride);
+	sharpness_valid = false;
 	NgpImageMeta& m = metadata[frame_idx];
 	m.pixels = pixelmemory[frame_idx].data();
 	m.image_data_type = image_data_type;
@@ -111,7 +112,23 @@ void NerfDataset::set_training_image(int frame_idx, int w, int h, const void* pi
 	}
 	update_metadata(frame_idx, frame_idx + 1);
 }
+void NerfDataset::update_sharpness() {   // nerf_loader.cu:829-834, for every image
+	if (sharpness_valid || n_images == 0) return;
+	const size_t per = (size_t)sharpness_resolution[0] * sharpness_resolution[1];
+	sharpness_data.resize(per * n_images * 4);
+	sharpness_data.memset(0, nullptr);
+	for (size_t i = 0; i < n_images; ++i) {
+		const NgpImageMeta& m = metadata[i];
+		if (!m.pixels) continue;
+		if (ngp_hip_compute_sharpness(nullptr, sharpness_resolution, m.res, m.pixels, m.image_data_type, sharpness_data.as<float>() + per * i) != 0)
+			throw std::runtime_error{std::string{"compute_sharpness failed: "} + ngp_hip_last_error()};
+	}
+	if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error{"compute_sharpness: device error"};
+	sharpness_valid = true;
+}
+
 void NerfDataset::sharpen_training_image(int frame_idx, float sharpen_amount) {
+	sharpness_valid = false;
 	if (!(sharpen_amount > 0.f)) return;
 	if (frame_idx < 0 || (size_t)frame_idx >= n_images) throw std::runtime_error{"NerfDataset::sharpen_training_image: invalid frame index"};
 	NgpImageMeta& m = metadata[frame_idx];
@@ -1160,13 +1177,22 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		m_envmap.clear_gradients(m_stream, false);   // 2941-2944: every step
 	}
 	NgpLossExtras loss_extras{};
+	if (tr.include_sharpness_in_error) {   // 2901-2912: the grid of the sharpest tile per cell, zeroed at step 0, decayed by 0.95 every step; 3303-3305
+		tr.dataset.update_sharpness();
+		const size_t n_cells = (size_t)GRID_CELLS * NGP_NERF_CASCADES;
+		if (tr.sharpness_grid.bytes() < n_cells * 4) { tr.sharpness_grid.resize(n_cells * 4); tr.sharpness_grid.memset(0, m_stream); }
+		if (m_training_step == 0) tr.sharpness_grid.memset(0, m_stream);
+		else check(ngp_hip_decay_grid(m_stream, (uint32_t)n_cells, 0.95f, tr.sharpness_grid.as<float>()), "decay_sharpness_grid");
+		loss_extras.sharpness_data = tr.dataset.sharpness_data.as<float>(); loss_extras.sharpness_grid = tr.sharpness_grid.as<float>();
+		loss_extras.sharpness_res[0] = tr.dataset.sharpness_resolution[0]; loss_extras.sharpness_res[1] = tr.dataset.sharpness_resolution[1];
+	}
 	if (m_envmap.n_params() > 0) {   // 3219-3222: the training copy of the map, its gradient buffer only while it trains
 		loss_extras.envmap_data = m_envmap.params.as<float>(); loss_extras.envmap_gradient = train_envmap ? m_envmap.gradients.as<float>() : nullptr;
 		loss_extras.envmap_res[0] = m_envmap.resolution[0]; loss_extras.envmap_res[1] = m_envmap.resolution[1]; loss_extras.envmap_loss_type = (int)m_envmap.loss_type;
 	}
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
-	check(ngp_hip_compute_loss_ex(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
+	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
 	                           (int)m_color_space, tr.random_bg_color, tr.linear_colors, (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                           m_mlp_out.as<uint16_t>(), compacted_counter, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(), m_numsteps.as<uint32_t>(),
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),

@@ -105,6 +105,12 @@ struct NerfDataset {
 	NgpAabb render_aabb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
 	Vec3 up{0.0f, 1.0f, 0.0f};
 	// per-image extra network inputs (nerf_loader.h:94-99): `n_extra_learnable_dims` latent codes, or 3 light-direction dims when frames carry `driver_parameters`
+	// per image a 128 x 72 grid of tile sharpness (variance of the Laplacian; nerf_loader.cu:129-169, 178-179, 829-834), computed on the device when
+	// include_sharpness_in_error first asks for it and again after an image changed
+	DeviceBuffer sharpness_data;
+	int sharpness_resolution[2] = {128, 72};
+	bool sharpness_valid = false;
+	void update_sharpness();
 	uint32_t n_extra_learnable_dims = 0;
 	bool has_light_dirs = false;
 	std::vector<Vec3> light_dirs;                // per image, NGP frame, normalised (TrainingImageMetadata::light_dir)
@@ -183,7 +189,8 @@ struct NerfTraining {
 	void reset_extra_dims(Pcg32& rng);
 	bool distortion_gradient_window_open = false;                  // the distortion gradients of the current n_steps_between_cam_updates window are being accumulated
 	bool train_envmap = false;                                     // testbed.h:656 (the reference sets it from its GUI only; exposed on pyngp here)
-	bool include_sharpness_in_error = false;                       // testbed.h:670 (the sharpness map is not computed by this loader)
+	bool include_sharpness_in_error = false;                       // testbed.h:670; 1476-1485, 2901-2912
+	DeviceBuffer sharpness_grid;                                   // cascaded 128^3 x NERF_CASCADES grid of the sharpest image tile that has seen each cell
 	float extrinsic_l2_reg = 1e-4f, extrinsic_learning_rate = 1e-3f, intrinsic_l2_reg = 1e-4f;   // testbed.h:673-678
 	int view = 0;                                                  // current training view of the GUI navigation (testbed.h:636)
 	uint32_t n_steps_between_cam_updates = 16, n_steps_since_cam_update = 0;

@@ -258,6 +258,17 @@ int ngp_hip_image_sharpen(void* stream, uint64_t n_pixels, uint32_t width, const
 int ngp_hip_construct_cdf_2d(void* stream, uint32_t n_images, uint32_t height, uint32_t width, const float* data, float* cdf_x_cond_y, float* cdf_y);
 int ngp_hip_construct_cdf_1d(void* stream, uint32_t n_images, uint32_t height, float* cdf_y, float* cdf_img);
 
+/* The loss kernel with the environment map (compute_loss_kernel_train_nerf's envmap_data / envmap_gradient / envmap_resolution / envmap_loss_type,
+ * :1289-1292): the map (fp32 rgba [h][w][4], TrainableBuffer<4,2,float>::params) is composited in front of the background colour of every ray
+ * (:1394-1401); with envmap_gradient (train_envmap; the caller clears it every step, :2941-2944) rays whose every sample was kept deposit
+ * loss_scale * T * dL/drgb [/ srgb'(background)] bilinearly (:1573-1596, envmap.cuh:65-103; alpha gets no gradient).  extras_host NULL: no environment map, no sharpness weighting. */
+typedef struct {
+	const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type;
+	/* include_sharpness_in_error (testbed.h:670; :1321-1323, 1476-1485): per image a sharpness_res grid of tile sharpness (ngp_hip_compute_sharpness) and a cascaded
+	 * 128^3 grid of the sharpest tile that has seen each cell (decayed by ngp_hip_decay_grid every training_prep, :2901-2912); the error a ray deposits into the error
+	 * map is scaled by max(sharp / grid_sharp, 0.01).  NULL: off */
+	const float* sharpness_data; int32_t sharpness_res[2]; float* sharpness_grid;
+} NgpLossExtras;
 /* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================
  * Forward pass.  The reference runs inference on all samples (:3256), compacts, then runs m_network->forward on the compacted batch
  * (:3330) only to rebuild the activations backward needs; the network outputs of that second pass are never read.  ngp_hip_nerf_backward
@@ -280,10 +291,11 @@ int ngp_hip_compute_loss(
 	ngp_hip_nerf_forward wrote for coords_in) is copied next to coords_out — see "forward pass" below */,
 	float depth_supervision_lambda /* 0: off (testbed.h:680) */, int depth_loss_type /* ELossType for the depth term, reference default L1 (testbed.h:654);
 	target = |ray.d| * metadata[img].depth at the ray's pixel, rays of images without depth are unaffected (:1450-1452, 1536-1541) */,
-	float* exposure_gradient /* NULL, or [n_images][3] floats that receive (atomicAdd; the caller clears them) the gradient of the loss with
-	respect to the per-image exposures (:1558-1572, optimize_exposure) */);
+	float* exposure_gradient /* NULL, or [n_images][3] floats that receive (atomicAdd, the caller clears them) the gradient of the loss with
+	respect to the per-image exposures (:1558-1572, optimize_exposure) */,
+	const NgpLossExtras* extras_host /* NULL: no environment map, no sharpness weighting (NgpLossExtras above) */);
 /* compute_cam_gradient_train_nerf (:1600-1712, call site :3350-3378), the extrinsics outputs: per kept ray, the network's input gradient of its COMPACTED samples
- * (coords_gradient: [sample][6] fp32 as ngp_hip_nerf_backward_input writes it; numsteps_in holds the compacted (count, base) pairs ngp_hip_compute_loss left) is
+ * (coords_gradient: [sample][6] fp32 as ngp_hip_nerf_backward writes its dL_dinput; numsteps_in holds the compacted (count, base) pairs ngp_hip_compute_loss left) is
  * folded into a ray-origin and a ray-direction gradient and added (atomicAdd; the caller clears them every n_steps_between_cam_updates, :2916-2918) to
  * cam_pos_gradient[img] and, as the angle-axis ray.d x grad_d, to cam_rot_gradient[img] ([n_images][3] floats each; either may be NULL), both divided by the pixel
  * pdf of the ray's draw.  rng / cdf_host must be what ngp_hip_compute_loss got.  The lens-distortion branch (:1671-1683) is out of scope; the reference kernel
@@ -292,21 +304,9 @@ int ngp_hip_compute_cam_gradient(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
 	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host);
-/* The loss kernel with the environment map (compute_loss_kernel_train_nerf's envmap_data / envmap_gradient / envmap_resolution / envmap_loss_type,
- * :1289-1292): the map (fp32 rgba [h][w][4], TrainableBuffer<4,2,float>::params) is composited in front of the background colour of every ray
- * (:1394-1401); with envmap_gradient (train_envmap; the caller clears it every step, :2941-2944) rays whose every sample was kept deposit
- * loss_scale * T * dL/drgb [/ srgb'(background)] bilinearly (:1573-1596, envmap.cuh:65-103; alpha gets no gradient).  extras_host NULL = ngp_hip_compute_loss. */
-typedef struct { const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type; } NgpLossExtras;
-int ngp_hip_compute_loss_ex(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted,
-	const uint32_t* rays_counter, float loss_scale, uint32_t mlp_stride, const float* background_color_host, int color_space,
-	int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const NgpImageMeta* metadata,
-	const uint16_t* network_output, uint32_t* numsteps_counter, const uint32_t* ray_indices_in, const NgpRay* rays_in_unnormalized,
-	uint32_t* numsteps_in, const NgpCoord* coords_in, NgpCoord* coords_out, uint16_t* dloss_doutput, uint32_t dl_stride, int loss_type,
-	float* loss_output, int max_level_rand_training, float* max_level_compacted, int rgb_activation, int density_activation,
-	int snap_to_pixel_centers, float* error_map, const int32_t* error_map_res_host, const float* mean_density, const float* exposure,
-	float near_distance, const NgpErrorMapCdf* cdf_host, const uint16_t* encoded_in, uint16_t* encoded_out, float depth_supervision_lambda, int depth_loss_type,
-	float* exposure_gradient, const NgpLossExtras* extras_host);
+/* compute_sharpness (src/nerf_loader.cu:129-169): sharpness_out[y][x] = variance of the Laplacian of the luma over tile (x, y) of a sharpness_res grid laid over the image */
+int ngp_hip_compute_sharpness(void* stream, const int32_t* sharpness_res_host, const int32_t* image_res_host, const void* pixels, int image_data_type, float* sharpness_out);
+int ngp_hip_decay_grid(void* stream, uint32_t n_elements, float decay, float* grid);   /* decay_sharpness_grid_nerf (:557-561) */
 /* compute_cam_gradient_train_nerf with its lens-distortion branch (:1671-1685): the ray-direction gradient minus its component along the ray, rotated by
  * the inverse of the image's camera rotation (xforms[img].start), is splatted (x, y; divided by the pixel pdf) into distortion_gradient at the ray's pixel and
  * the bilinear weights into distortion_gradient_weight (both fp32 [h][w][2], atomicAdd; the caller clears them every n_steps_between_cam_updates, :2919-2920). */

@@ -115,7 +115,9 @@ void orc_compute_cam_gradient(
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const orc_image_meta* metadata, const uint32_t* ray_indices_in,
 	const orc_ray* rays_in_unnormalized, const uint32_t* numsteps_in, const orc_coord* coords_all, const float* coords_gradient_all /* [sample][6] */,
 	const orc_error_map_cdf* cdf);
-typedef struct { const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type; } orc_loss_extras;   /* NgpLossExtras */
+typedef struct { const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int32_t envmap_loss_type;
+                 const float* sharpness_data; int32_t sharpness_res[2]; float* sharpness_grid; } orc_loss_extras;   /* NgpLossExtras */
+void orc_compute_sharpness(const int32_t sharpness_res[2], const int32_t image_res[2], const void* pixels, int image_data_type, float* sharpness_out);
 void orc_compute_loss_ex(
 	uint32_t n_rays, const orc_aabb* aabb, uint64_t rng_state, uint64_t rng_inc, uint32_t max_samples_compacted, uint32_t n_rays_alive, float loss_scale, uint32_t mlp_stride,
 	const float background_color_in[3], int color_space_srgb, int train_with_random_bg_color, int train_in_linear_colors, uint32_t n_training_images, const orc_image_meta* metadata,

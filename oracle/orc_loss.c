@@ -93,6 +93,7 @@ void orc_compute_loss_ex(
 		float T = 1.f;
 		const float EPSILON = 1e-4f;
 		float rgb_ray[3] = {0, 0, 0};
+		orc_vec3 hitpoint = orc_v3(0.f, 0.f, 0.f);
 		float depth_ray = 0.f;
 		uint32_t compacted_numsteps = 0;
 		orc_vec3 ray_o = rays_in_unnormalized[i].o;
@@ -109,9 +110,11 @@ void orc_compute_loss_ex(
 			float alpha = 1.f - expf(-density * dt);
 			float weight = alpha * T;
 			for (int c = 0; c < 3; ++c) rgb_ray[c] += weight * rgb[c];
+			hitpoint = orc_add(hitpoint, orc_scale(pos, weight));   /* :1367 */
 			depth_ray += weight * cur_depth;
 			T *= (1.f - alpha);
 		}
+		hitpoint = orc_scale(hitpoint, 1.0f / (1.0f - T));          /* :1374 (hitpoint /= 1 - T) */
 
 		uint32_t ray_idx = ray_indices_in[i];
 		orc_pcg32 rng = {rng_state, rng_inc};
@@ -209,6 +212,18 @@ void orc_compute_loss_ex(
 			int ix = pix < md->res[0] - 2 ? pix : md->res[0] - 2; ix = ix > 0 ? ix : 0;
 			int iy = piy < md->res[1] - 2 ? piy : md->res[1] - 2; iy = iy > 0 ? iy : 0;
 			size_t b = (size_t)img * (size_t)error_map_res[0] * (size_t)error_map_res[1];
+			if (ex && ex->sharpness_data && orc_aabb_contains(aabb, hitpoint)) {   /* :1476-1485: the error a ray deposits is scaled by how sharp its image tile is relative to the sharpest one that saw the cell */
+				int sx = (int)(xy[0] * (float)ex->sharpness_res[0]), sy = (int)(xy[1] * (float)ex->sharpness_res[1]);
+				sx = sx > 0 ? sx : 0; sx = sx < ex->sharpness_res[0] - 1 ? sx : ex->sharpness_res[0] - 1;
+				sy = sy > 0 ? sy : 0; sy = sy < ex->sharpness_res[1] - 1 ? sy : ex->sharpness_res[1] - 1;
+				const float sharp = ex->sharpness_data[(size_t)img * ex->sharpness_res[0] * ex->sharpness_res[1] + (size_t)sy * ex->sharpness_res[0] + sx] + 1e-6f;
+				const uint32_t mip = (uint32_t)orc_mip_from_pos(hitpoint, ORC_NERF_CASCADES - 1);
+				float* cell = &ex->sharpness_grid[orc_cascaded_grid_idx_at(hitpoint, mip) + (size_t)ORC_NERF_GRIDSIZE * ORC_NERF_GRIDSIZE * ORC_NERF_GRIDSIZE * mip];
+				float grid_sharp = *cell;
+				if (sharp > grid_sharp) *cell = sharp;        /* atomicMax on the bit pattern of positive floats */
+				grid_sharp = fmaxf(sharp, grid_sharp);
+				mean_loss *= fmaxf(sharp / grid_sharp, 0.01f);
+			}
 			error_map[b + (size_t)iy * error_map_res[0] + ix] += (1 - wx) * (1 - wy) * mean_loss;
 			error_map[b + (size_t)iy * error_map_res[0] + ix + 1] += wx * (1 - wy) * mean_loss;
 			error_map[b + (size_t)(iy + 1) * error_map_res[0] + ix] += (1 - wx) * wy * mean_loss;
@@ -440,4 +455,36 @@ void orc_image_sharpen(uint64_t n_pixels, uint32_t w, const void* pix, void* des
 		}
 	}
 #undef ORC_PX
+}
+
+/* read_rgba(Vector2i px, ...) (common_device.cuh:677-705) through the float-position reader: the centre of pixel px maps back to px */
+static void orc_read_rgba_px(const int32_t px[2], const int32_t res[2], const void* pixels, int type, float out[4]) {
+	const float xy[2] = {((float)px[0] + 0.5f) / (float)res[0], ((float)px[1] + 0.5f) / (float)res[1]};
+	orc_read_rgba(xy, res, pixels, type, out);
+}
+
+/* nerf_loader.cu:121-169 compute_sharpness: per tile of a sharpness_res grid over the image, the variance of the Laplacian of the luma of read_rgba (one pixel in from the edge) */
+void orc_compute_sharpness(const int32_t sharpness_res[2], const int32_t image_res[2], const void* pixels, int image_data_type, float* sharpness_out) {
+	for (int y = 0; y < sharpness_res[1]; ++y) for (int x = 0; x < sharpness_res[0]; ++x) {
+		int x1 = (x * image_res[0]) / sharpness_res[0], x2 = ((x + 1) * image_res[0]) / sharpness_res[0];
+		int y1 = (y * image_res[1]) / sharpness_res[1], y2 = ((y + 1) * image_res[1]) / sharpness_res[1];
+		x1 = x1 > 1 ? x1 : 1; y1 = y1 > 1 ? y1 : 1;
+		x2 = x2 < image_res[0] - 2 ? x2 : image_res[0] - 2; y2 = y2 < image_res[1] - 2 ? y2 : image_res[1] - 2;
+		float tot_lap = 0.f, tot_lap2 = 0.f, tot_lum = 0.f;
+		const float scal = 1.f / (float)((x2 - x1) * (y2 - y1));
+		for (int yy = y1; yy < y2; ++yy) for (int xx = x1; xx < x2; ++xx) {
+			float c[4], n[4], e[4], s_[4], w[4];
+			const int32_t pc[2] = {xx, yy}, pn[2] = {xx, yy - 1}, pw[2] = {xx - 1, yy}, ps[2] = {xx, yy + 1}, pe[2] = {xx + 1, yy};
+			orc_read_rgba_px(pc, image_res, pixels, image_data_type, c); orc_read_rgba_px(pn, image_res, pixels, image_data_type, n);
+			orc_read_rgba_px(pw, image_res, pixels, image_data_type, w); orc_read_rgba_px(ps, image_res, pixels, image_data_type, s_);
+			orc_read_rgba_px(pe, image_res, pixels, image_data_type, e);
+#define ORC_LUMA(v) ((v)[0] * 0.2126f + (v)[1] * 0.7152f + (v)[2] * 0.0722f)
+			const float lum = ORC_LUMA(c);
+			const float lap = lum * 4.f - ORC_LUMA(n) - ORC_LUMA(e) - ORC_LUMA(s_) - ORC_LUMA(w);
+#undef ORC_LUMA
+			tot_lap += lap; tot_lap2 += lap * lap; tot_lum += lum;
+		}
+		tot_lap *= scal; tot_lap2 *= scal; tot_lum *= scal;
+		sharpness_out[x + (size_t)y * sharpness_res[0]] = tot_lap2 - tot_lap * tot_lap;
+	}
 }

@@ -49,11 +49,16 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
     o = dict(cnt=np.zeros(1, np.uint32), ns=I["r"]["ns"].copy(), co=np.zeros(B, H.COORD), dl=np.zeros((B, 4), np.float16), loss=np.zeros(n_rays, np.float32),
              em=np.zeros(n_img * 16 * 12, np.float32), enc=np.zeros((B, 32), np.uint16), expg=np.zeros((n_img, 3), np.float32))
     env = I.get("envmap")      # dict(data fp32 [h][w][4], res (w, h), loss_type, train): the *_ex entry points (environment map in front of the background)
+    sharp = I.get("sharp")     # dict(data fp32 [n_img][sry][srx], res (srx, sry)): include_sharpness_in_error
     o_loss_fn, o_tail = oracle.orc_compute_loss, ()
-    if env is not None:
-        o["envg"] = np.zeros_like(env["data"])
+    if env is not None or sharp is not None:
         ex_o = np.zeros(1, capi.LOSS_EXTRAS)
-        ex_o["envmap_data"], ex_o["envmap_gradient"], ex_o["envmap_res"][0], ex_o["envmap_loss_type"] = env["data"].ctypes.data, o["envg"].ctypes.data if env["train"] else 0, env["res"], env["loss_type"]
+        if env is not None:
+            o["envg"] = np.zeros_like(env["data"])
+            ex_o["envmap_data"], ex_o["envmap_gradient"], ex_o["envmap_res"][0], ex_o["envmap_loss_type"] = env["data"].ctypes.data, o["envg"].ctypes.data if env["train"] else 0, env["res"], env["loss_type"]
+        if sharp is not None:
+            o["sgrid"] = sharp["grid0"].copy()
+            ex_o["sharpness_data"], ex_o["sharpness_res"][0], ex_o["sharpness_grid"] = sharp["data"].ctypes.data, sharp["res"], o["sgrid"].ctypes.data
         o_loss_fn, o_tail = oracle.orc_compute_loss_ex, (ex_o.ctypes.data,)
     o_loss_fn(n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, n_alive, H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear, n_img,
                             I["md_host"].ctypes.data, I["mlp"].ctypes.data, o["cnt"].ctypes.data, I["r"]["idx"].ctypes.data, I["r"]["rays"].ctypes.data, o["ns"].ctypes.data,
@@ -73,11 +78,15 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
         d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
         c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if m & 1 else 0, d_cy.data_ptr() if m & 1 else 0, d_ci.data_ptr() if m & 2 else 0, C["res"])
     d_loss_fn, d_tail = ngp.ngp_hip_compute_loss, ()
-    if env is not None:
-        d_env, d["envg"] = H.to_dev(env["data"], cuda), H.dev_zeros(env["data"].nbytes, cuda)
+    if env is not None or sharp is not None:
         ex_d = np.zeros(1, capi.LOSS_EXTRAS)
-        ex_d["envmap_data"], ex_d["envmap_gradient"], ex_d["envmap_res"][0], ex_d["envmap_loss_type"] = d_env.data_ptr(), d["envg"].data_ptr() if env["train"] else 0, env["res"], env["loss_type"]
-        d_loss_fn, d_tail = ngp.ngp_hip_compute_loss_ex, (ex_d.ctypes.data,)
+        if env is not None:
+            d_env, d["envg"] = H.to_dev(env["data"], cuda), H.dev_zeros(env["data"].nbytes, cuda)
+            ex_d["envmap_data"], ex_d["envmap_gradient"], ex_d["envmap_res"][0], ex_d["envmap_loss_type"] = d_env.data_ptr(), d["envg"].data_ptr() if env["train"] else 0, env["res"], env["loss_type"]
+        if sharp is not None:
+            d_sd, d["sgrid"] = H.to_dev(sharp["data"], cuda), H.to_dev(sharp["grid0"], cuda)
+            ex_d["sharpness_data"], ex_d["sharpness_res"][0], ex_d["sharpness_grid"] = d_sd.data_ptr(), sharp["res"], d["sgrid"].data_ptr()
+        d_loss_fn, d_tail = ngp.ngp_hip_compute_loss, (ex_d.ctypes.data,)
     check(d_loss_fn(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], B, d_rc.data_ptr(), H.f32(128.0), 4, bg.ctypes.data, color_space, random_bg, linear,
                                    n_img, d_md.data_ptr(), d_mlp.data_ptr(), d["cnt"].data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(), d["ns"].data_ptr(), d_co.data_ptr(),
                                    d["co"].data_ptr(), d["dl"].data_ptr(), 4, loss_type, d["loss"].data_ptr(), 0, None, rgb_act, 3, 0, d["em"].data_ptr(), em_res.ctypes.data,
@@ -87,6 +96,8 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
              loss=H.to_host(d["loss"], np.float32), em=H.to_host(d["em"], np.float32), enc=H.to_host(d["enc"], np.uint16).reshape(B, 32), d_co=d["co"], expg=H.to_host(d["expg"], np.float32).reshape(n_img, 3))
     if env is not None:
         g["envg"] = H.to_host(d["envg"], np.float32).reshape(env["data"].shape)
+    if sharp is not None:
+        g["sgrid"] = H.to_host(d["sgrid"], np.float32)
     return o, g
 
 
@@ -493,3 +504,48 @@ def test_trainable_buffer_optimizer_step(ngp, oracle, cuda, use_ema):
     if use_ema:
         assert np.abs(ema - p).max() > 0 and np.abs(ema - p).max() < 0.2
     assert ngp.ngp_hip_optimizer_step_f32(None, n, 0, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-10), H.f32(128.0), H.f32(0.99), d_p.data_ptr(), d_p.data_ptr(), d_m1.data_ptr(), d_m2.data_ptr(), None) != 0
+
+
+def test_loss_with_sharpness_in_error(ngp, oracle, cuda):
+    """include_sharpness_in_error (testbed_nerf.cu:1321-1323, 1346, 1367, 1374, 1476-1485): the error a ray deposits is scaled by its image tile's sharpness relative to the
+    sharpest tile that has seen the cell of the ray's expected hit point (a cascaded grid, atomicMax on float bits); everything else of the kernel is untouched.  Rays race
+    for the cells like in the reference: the grid's final content (a max) is order-independent, a ray's scale factor is not when two rays share a cell — so the error map is
+    held to the oracle where the grid started at its final values (second pass), bit-level agreement of the grid itself in the first."""
+    I = _inputs(oracle, cuda, n_rays=1024, seed=21)
+    n_img = len(I["xf"])
+    rs = np.random.RandomState(3)
+    sharp = dict(data=(rs.rand(n_img, 9, 16).astype(np.float32) * 0.01), res=(16, 9), grid0=np.zeros(128 ** 3 * 8, np.float32))
+    base_o, base_g = _run(ngp, oracle, cuda, dict(I), 0, B=I["n_samples"] + 64)
+    I1 = dict(I); I1["sharp"] = sharp
+    o, g = _run(ngp, oracle, cuda, I1, 0, B=I["n_samples"] + 64)
+    # the max over the rays of each cell is order-independent: bit for bit, except where a ray's expected hit point (a wave reduction here, a sequential sum in the
+    # oracle) sits on a cell boundary and lands next door
+    assert (g["sgrid"] != o["sgrid"]).sum() <= 8 and (o["sgrid"] > 0).sum() > 100
+    np.testing.assert_array_equal(g["loss"], base_g["loss"])                   # only the error-map deposit is scaled (per-ray losses: same bits)
+    # second pass on the converged grid: every ray's factor is sharp / max(sharp, grid) whatever the order
+    I2 = dict(I); I2["sharp"] = dict(sharp, grid0=o["sgrid"].copy())
+    o2, g2 = _run(ngp, oracle, cuda, I2, 0, B=I["n_samples"] + 64)
+    assert (g2["sgrid"] != o2["sgrid"]).sum() <= 8
+    assert np.linalg.norm(g2["em"] - o2["em"]) < 5e-3 * np.linalg.norm(o2["em"])
+    assert 0 < o2["em"].sum() < base_o["em"].sum()                             # rays that share a cell with a sharper tile's ray count for less, nobody for more
+
+
+def test_compute_sharpness_matches_oracle(ngp, oracle, cuda):
+    """compute_sharpness (nerf_loader.cu:129-169): variance of the Laplacian of the luma per tile, Byte and Half images"""
+    rs = np.random.RandomState(8)
+    w, h = 200, 120
+    img8 = rs.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    img8[: h // 2] = 128                                                        # a flat half: zero sharpness
+    img8[10:20, 10:20] = [255, 0, 255, 0]                                       # the "masked-away" colour reads as -1 (common_device.cuh:685-687)
+    img16 = rs.rand(h, w, 4).astype(np.float16)
+    for img, typ in ((img8, 1), (img16, 2)):
+        sres, ires = np.array([16, 9], np.int32), np.array([w, h], np.int32)
+        want = np.zeros((9, 16), np.float32)
+        oracle.orc_compute_sharpness(sres.ctypes.data, ires.ctypes.data, img.ctypes.data, typ, want.ctypes.data)
+        d_img, d_out = H.to_dev(img, cuda), H.dev_zeros(9 * 16 * 4, cuda)
+        check(ngp.ngp_hip_compute_sharpness(None, sres.ctypes.data, ires.ctypes.data, d_img.data_ptr(), typ, d_out.data_ptr()))
+        got = H.to_host(d_out, np.float32).reshape(9, 16)
+        assert want.max() > 1e-3
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
+        if typ == 1:
+            assert abs(got[1, 8]) < 1e-6                                        # inside the flat half

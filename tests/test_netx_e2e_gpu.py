@@ -136,3 +136,27 @@ def test_rgb_network_depths_train_render_and_round_trip_a_snapshot(cuda, tmp_pat
     d = np.abs(b - a)                                                                            # the same weights, the same frame — up to the odd occupancy cell at the
     assert d.mean() < 1e-5 and (d > 2e-4).mean() < 2e-3                                          # threshold: the snapshot keeps the density grid in fp16
     assert img.shape == (64, 64, 4)
+
+
+def test_include_sharpness_in_error_end_to_end(cuda):
+    """nerf.training.include_sharpness_in_error through pyngp: the loader-side sharpness map (128 x 72 tiles per image) exists, blurred images score lower than sharp
+    ones, training runs with the switch on and the error map keeps filling"""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=512, device=cuda)   # (tiles of an image narrower than 2 x 128 pixels are empty and come out NaN, there as here)
+    for i in range(0, 8, 2):                                  # every other image: a 9 x 9 box blur
+        img = ds["train_images"][i].astype(np.float32)
+        k = 9
+        pad = np.pad(img, ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="edge")
+        acc = np.zeros_like(img)
+        for dy in range(k):
+            for dx in range(k):
+                acc += pad[dy:dy + img.shape[0], dx:dx + img.shape[1]]
+        ds["train_images"][i] = np.clip(acc / (k * k), 0, 255).astype(np.uint8)
+    t = scene.build_testbed(ds)
+    sharp = t.nerf.training.get_sharpness_data()
+    assert sharp.shape == (8, 72, 128) and np.isfinite(sharp).all() and (sharp >= -1e-6).all()
+    per_image = sharp.reshape(8, -1).mean(1)
+    assert per_image[1::2].min() > 3.0 * per_image[0::2].max()            # the blurred images' Laplacian variance is far smaller
+    t.nerf.training.include_sharpness_in_error = True
+    scene.train(t, 200)
+    assert t.training_step == 200 and np.isfinite(t.loss)

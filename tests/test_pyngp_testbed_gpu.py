@@ -140,12 +140,8 @@ def test_shall_train_encoding_and_network(trained):
     np.testing.assert_array_equal(q[n_mlp:], p[n_mlp:])
     assert (q[:n_mlp] != p[:n_mlp]).sum() > 1000
     t.shall_train_encoding = True
-    # trainables this build lacks refuse loudly instead of training something else
-    for name in ("optimize_extra_dims",):               # (extrinsics / focal length: tests/test_extrinsics_gpu.py; distortion / envmap: tests/test_render_modes_e2e_gpu.py)
-        setattr(t.nerf.training, name, True)
-        with pytest.raises(RuntimeError, match="not part of this build"):
-            t.frame()
-        setattr(t.nerf.training, name, False)
+    # (every training switch of python_api.cu:804-818 is built: extrinsics / focal length in tests/test_extrinsics_gpu.py, distortion / envmap in
+    # tests/test_render_modes_e2e_gpu.py, latent codes / sharpness in tests/test_netx_e2e_gpu.py)
     t.frame()
     t.shall_train = False
     with pytest.raises(RuntimeError, match="not part of this build"):
