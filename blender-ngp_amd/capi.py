@@ -157,7 +157,7 @@ LOSS_EXTRAS = np.dtype([("envmap_data", "<u8"), ("envmap_gradient", "<u8"), ("en
                         ("sharpness_data", "<u8"), ("sharpness_res", "<i4", 2), ("sharpness_grid", "<u8")], align=True)   # NgpLossExtras
 RENDER_EXTRAS = np.dtype([("render_masks", "<u8"), ("n_render_masks", "<u4"), ("glow_mode", "<i4"), ("glow_y_cutoff", "<f4"), ("envmap", "<u8"), ("envmap_res", "<i4", 2),
                           ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8"),
-                          ("row_begin", "<i4"), ("row_end", "<i4")], align=True)   # NgpRenderExtras
+                          ("row_begin", "<i4"), ("row_end", "<i4"), ("tile_order", "<i4")], align=True)   # NgpRenderExtras
 
 assert AABB.itemsize == 24 and RAY.itemsize == 24 and XFORM.itemsize == 96 and COORD.itemsize == 28 and PAYLOAD.itemsize == 40
 assert NET_DESC.itemsize == 8 + 16 * 16

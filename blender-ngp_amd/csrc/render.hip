@@ -13,6 +13,7 @@ struct RenderExtras {
 	const NgpMask3D* render_masks; uint32_t n_render_masks; int glow_mode; float glow_y_cutoff;
 	const float* envmap; int envmap_res[2]; const float* distortion; int distortion_res[2]; int quilting_dims[2]; int render_mode; float4* frame_buffer;
 	int row_begin, row_end;   // the rows this launch sets up (a shard of the frame, or 0 .. res[1])
+	int tile_order;           // payload slots in 8 x 8 pixel tiles (one wave = one tile) instead of row-major
 };
 
 struct InitRaysArgs {
@@ -27,7 +28,10 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	uint32_t x = threadIdx.x + blockDim.x * blockIdx.x, y = threadIdx.y + blockDim.y * blockIdx.y + (uint32_t)a.ex.row_begin;
 	if (x >= (uint32_t)a.res[0] || y >= (uint32_t)a.ex.row_end) return;
 	// idx: the pixel in the WHOLE frame (frame / depth buffer slot, key of every per-pixel random number); slot: its payload in this launch's ray array
-	const uint32_t idx = x + (uint32_t)a.res[0] * y, slot = idx - (uint32_t)a.res[0] * (uint32_t)a.ex.row_begin;
+	uint32_t idx = x + (uint32_t)a.res[0] * y, slot = idx - (uint32_t)a.res[0] * (uint32_t)a.ex.row_begin;
+	// tile order: the launch's blocks are 8 x 8 pixels = one wave; slot = block-linear, so that a wave of every later kernel holds a SQUARE of neighbouring pixels (until
+	// compaction thins it): their samples share hash-grid cells on the coarse and middle levels, a 64 x 1 strip of pixels does not
+	if (a.ex.tile_order) slot = (blockIdx.y * gridDim.x + blockIdx.x) * 64u + threadIdx.y * 8u + threadIdx.x;
 	float parallax_shift[3] = {a.parallax_shift[0], a.parallax_shift[1], a.parallax_shift[2]};
 	const int qx = a.ex.quilting_dims[0], qy = a.ex.quilting_dims[1];
 	if (qx != 1 || qy != 1) {   // apply_quilting (common_device.cuh:541-560): the pixel inside its panel, the panel's parallax
@@ -141,34 +145,65 @@ __global__ void __launch_bounds__(128) init_rays_kernel(const InitRaysArgs a) {
 	a.payloads[slot] = p;
 }
 
-template <bool CONST_DT>   // cone_angle == 0: see calc_dt_t
-__global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
-                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel) {
-	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_elements) return;
-	NgpPayload& payload = payloads[i];
-	if (!payload.alive) return;
-	const v3 origin = ld3(payload.origin), dir = ld3(payload.dir);
-	const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-	const float cone_angle = cone_angle_constant;
-	float t = payload.t;
-	float dt = calc_dt(t, cone_angle);
-	t += ld_random_val(sample_index, (i + first_pixel) * 786433u) * dt;   // keyed by the pixel's index in the whole frame: a sharded frame jitters like the whole one
-	v3 pos;
-	OccBrick occ;
-	while (1) {
-		pos = origin + dir * t;
-		if (!aabb_contains(render_aabb, mat3_mul(to_local.m, pos))) { payload.alive = 0; break; }
-		dt = calc_dt_t<CONST_DT>(t, cone_angle);
-		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
-		mip = mip < min_mip ? min_mip : mip;
-		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
-		t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+struct Payload40 { uint32_t w[10]; };
+static_assert(sizeof(NgpPayload) == sizeof(Payload40), "payload");
+
+// compact_kernel_nerf (src/testbed_nerf.cu:1784-1807) at the END of the kernel that decides a ray's fate (advance_pos, composite) instead of as a pass of its own: the
+// ray's payload, colour and depth are still in registers, so they are written once — to their compacted slot (alive), to the finished list (dead with alpha > 0.001)
+// or nowhere — and the tracer loses a launch and a 60-byte read + write per ray and pass.  One atomic per wave and counter (ballots).  counter == NULL: off.
+struct CompactOut { float4* dst_rgba; float* dst_depth; Payload40* dst_payloads; float4* fin_rgba; float* fin_depth; Payload40* fin_payloads; uint32_t* counter; uint32_t* final_counter; };
+__device__ __forceinline__ void compact_store(bool alive, bool hit, const NgpPayload& payload, float4 c, float d, const CompactOut& co) {
+	const uint32_t lane = lane_id();
+	const unsigned long long am = __ballot(alive), hm = __ballot(hit);
+	uint32_t abase = 0, hbase = 0;
+	if (lane == 0) {
+		if (am) abase = atomicAdd(co.counter, (uint32_t)__popcll(am));
+		if (hm) hbase = atomicAdd(co.final_counter, (uint32_t)__popcll(hm));
 	}
-	payload.t = t;
+	abase = __shfl(abase, 0, 64); hbase = __shfl(hbase, 0, 64);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	const Payload40& p = *(const Payload40*)&payload;
+	if (alive) {
+		const uint32_t idx = abase + (uint32_t)__popcll(am & below);
+		co.dst_payloads[idx] = p; co.dst_rgba[idx] = c; co.dst_depth[idx] = d;
+	} else if (hit) {
+		const uint32_t idx = hbase + (uint32_t)__popcll(hm & below);
+		co.fin_payloads[idx] = p; co.fin_rgba[idx] = c; co.fin_depth[idx] = d;
+	}
 }
 
-struct Payload40 { uint32_t w[10]; };
+template <bool CONST_DT>   // cone_angle == 0: see calc_dt_t
+__global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
+                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant, const CompactOut co) {
+	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	NgpPayload payload;
+	payload.alive = 0;
+	if (i < n_elements) payload = payloads[i];
+	const bool was_alive = i < n_elements && payload.alive;
+	if (was_alive) {
+		const v3 origin = ld3(payload.origin), dir = ld3(payload.dir);
+		const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		const float cone_angle = cone_angle_constant;
+		float t = payload.t;
+		float dt = calc_dt(t, cone_angle);
+		t += ld_random_val(sample_index, payload.idx * 786433u) * dt;   // keyed by the pixel's index in the whole frame (= the ray's index when the frame is traced at once, :625): shards and tile-ordered rays jitter like the whole frame
+		v3 pos;
+		OccBrick occ;
+		while (1) {
+			pos = origin + dir * t;
+			if (!aabb_contains(render_aabb, mat3_mul(to_local.m, pos))) { payload.alive = 0; break; }
+			dt = calc_dt_t<CONST_DT>(t, cone_angle);
+			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+			mip = mip < min_mip ? min_mip : mip;
+			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
+			t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+		}
+		payload.t = t;
+	}
+	if (!co.counter) { if (was_alive) payloads[i] = payload; return; }
+	// (a ray has no colour yet: zeros; a ray that died here has alpha 0 and is dropped)
+	compact_store(was_alive && payload.alive, false, payload, make_float4(0.f, 0.f, 0.f, 0.f), 0.f, co);
+}
 
 __global__ void __launch_bounds__(256) compact_rays_kernel(uint32_t n_elements, const float4* __restrict__ src_rgba, const float* __restrict__ src_depth, const Payload40* __restrict__ src_payloads,
                                                            float4* __restrict__ dst_rgba, float* __restrict__ dst_depth, Payload40* __restrict__ dst_payloads,
@@ -293,14 +328,17 @@ __device__ __forceinline__ void glow_shading(int glow_mode, float glow_y_cutoff,
 __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aabb aabb, Mat34 camera_matrix, float4* __restrict__ rgba, float* __restrict__ depth,
                                  NgpPayload* __restrict__ payloads, const NgpCoord* __restrict__ network_input, const uint16_t* __restrict__ network_output, uint32_t out_stride,
                                  uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel,
-                                 const RenderExtras ex) {
+                                 const RenderExtras ex, const CompactOut co) {
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-	if (i >= n_elements) return;
-	NgpPayload& payload = payloads[i];
-	if (!payload.alive) return;
+	NgpPayload payload;
+	payload.alive = 0;
+	if (i < n_elements) payload = payloads[i];
+	const bool was_alive = i < n_elements && payload.alive;
+	float4 local_rgba = make_float4(0.f, 0.f, 0.f, 0.f);
+	float local_depth = 0.f;
+	if (i < n_elements && (was_alive || co.counter)) { local_rgba = rgba[i]; local_depth = depth[i]; }
+	if (was_alive) {
 	const v3 ray_origin = ld3(payload.origin);
-	float4 local_rgba = rgba[i];
-	float local_depth = depth[i];
 	const v3 cam_fwd = col(camera_matrix.m, 2), cam_pos = col(camera_matrix.m, 3);
 	const uint32_t actual_n_steps = payload.n_steps;
 	float max_weight = payload.max_weight;
@@ -361,8 +399,13 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 	}
 	payload.max_weight = max_weight;
 	if (j < n_steps) { payload.alive = 0; payload.n_steps = (uint16_t)(j + current_step); }
-	rgba[i] = local_rgba;
-	depth[i] = local_depth;
+	}
+	if (!co.counter) {
+		if (was_alive) { payloads[i] = payload; rgba[i] = local_rgba; depth[i] = local_depth; }
+		return;
+	}
+	const bool alive = i < n_elements && payload.alive;
+	compact_store(alive, i < n_elements && !alive && local_rgba.w > 0.001f, payload, local_rgba, local_depth, co);
 }
 
 __global__ void shade_kernel(uint32_t n_elements, const float4* __restrict__ rgba, const float* __restrict__ depth, const NgpPayload* __restrict__ payloads,
@@ -462,6 +505,14 @@ __global__ void tonemap_kernel(uint32_t n, float exposure, float4 background_col
 	surface[idx] = make_float4(c3[0], c3[1], c3[2], color.w);
 }
 
+static CompactOut compact_from_host(const NgpCompactOut* c) {
+	CompactOut o{};
+	if (!c || !c->counter) return o;
+	o.dst_rgba = (float4*)c->dst_rgba; o.dst_depth = c->dst_depth; o.dst_payloads = (Payload40*)c->dst_payloads;
+	o.fin_rgba = (float4*)c->dst_final_rgba; o.fin_depth = c->dst_final_depth; o.fin_payloads = (Payload40*)c->dst_final_payloads;
+	o.counter = c->counter; o.final_counter = c->final_counter;
+	return o;
+}
 static Mat34 mat34_from_host(const float* m) { Mat34 r; for (int i = 0; i < 12; ++i) r.m[i] = m[i]; return r; }
 static Mat33 mat33_from_host(const float* m) { Mat33 r; for (int i = 0; i < 9; ++i) r.m[i] = m ? m[i] : ((i % 4 == 0) ? 1.0f : 0.0f); return r; }
 
@@ -474,9 +525,9 @@ extern "C" {
 static int extras_from_host(const NgpRenderExtras* e, RenderExtras& x, const char* who) {
 	x.render_masks = nullptr; x.n_render_masks = 0; x.glow_mode = 0; x.glow_y_cutoff = 0.f; x.envmap = nullptr; x.envmap_res[0] = x.envmap_res[1] = 0;
 	x.distortion = nullptr; x.distortion_res[0] = x.distortion_res[1] = 0; x.quilting_dims[0] = x.quilting_dims[1] = 1; x.render_mode = 1; x.frame_buffer = nullptr;
-	x.row_begin = x.row_end = 0;
+	x.row_begin = x.row_end = 0; x.tile_order = 0;
 	if (!e) return 0;
-	x.row_begin = e->row_begin; x.row_end = e->row_end;
+	x.row_begin = e->row_begin; x.row_end = e->row_end; x.tile_order = e->tile_order;
 	x.render_masks = e->n_render_masks ? e->render_masks : nullptr; x.n_render_masks = e->render_masks ? e->n_render_masks : 0;
 	x.glow_mode = e->glow_mode; x.glow_y_cutoff = e->glow_y_cutoff;
 	if (e->envmap && e->envmap_res[0] > 0 && e->envmap_res[1] > 0) { x.envmap = e->envmap; x.envmap_res[0] = e->envmap_res[0]; x.envmap_res[1] = e->envmap_res[1]; }
@@ -515,18 +566,20 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
 	a.near_distance = near_distance; a.lens_mode = lens_mode;
 	for (int i = 0; i < 7; ++i) a.lens_params[i] = lens_params_host ? lens_params_host[i] : 0.0f;
 	a.depthbuffer = depthbuffer;
-	const dim3 threads(16, 8, 1);
-	const dim3 blocks(div_up((uint32_t)res_host[0], 16), div_up((uint32_t)(a.ex.row_end - a.ex.row_begin), 8), 1);
+	if (a.ex.tile_order && ((res_host[0] & 7) || ((a.ex.row_end - a.ex.row_begin) & 7))) { set_last_error("ngp_hip_init_rays: tile_order needs a width and a row count that are multiples of 8", hipErrorInvalidValue); return -1; }
+	const dim3 threads = a.ex.tile_order ? dim3(8, 8, 1) : dim3(16, 8, 1);
+	const dim3 blocks(div_up((uint32_t)res_host[0], threads.x), div_up((uint32_t)(a.ex.row_end - a.ex.row_begin), 8), 1);
 	hipLaunchKernelGGL(init_rays_kernel, blocks, threads, 0, (hipStream_t)stream, a);
 	NGP_LAUNCH_CHECK("init_rays_kernel");
 	return 0;
 }
 
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host, uint32_t sample_index,
-                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel) {
+                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, const NgpCompactOut* compact_host) {
 	if (!n_elements) return 0;
-	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, first_pixel);
-	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, first_pixel);
+	const CompactOut co = compact_from_host(compact_host);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co);
+	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co);
 	NGP_LAUNCH_CHECK("advance_pos_kernel");
 	return 0;
 }
@@ -551,14 +604,14 @@ int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAab
 
 int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host, float* rgba, float* depth,
                       NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation,
-                      int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host) {
+                      int density_activation, float min_transmittance, int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host, const NgpCompactOut* compact_host) {
 	if (render_mode < 0 || render_mode > 8) { set_last_error("ngp_hip_composite: render mode out of range (ERenderMode 0..7, EncodingVis 8)", hipErrorInvalidValue); return -1; }
 	RenderExtras ex;
 	extras_from_host(nullptr, ex, "");
 	if (extras_host) { RenderExtras t; extras_from_host(extras_host, t, ""); ex.render_masks = t.render_masks; ex.n_render_masks = t.n_render_masks; ex.glow_mode = t.glow_mode; ex.glow_y_cutoff = t.glow_y_cutoff; }
 	if (!n_elements) return 0;
 	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
-	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel, ex);
+	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel, ex, compact_from_host(compact_host));
 	NGP_LAUNCH_CHECK("composite_kernel");
 	return 0;
 }

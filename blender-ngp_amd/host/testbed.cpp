@@ -1697,7 +1697,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	// render_to_cpu gathers them.  n_pixels below = the pixels THIS rank traces.
 	int row_begin = 0, row_end = rb.res[1];
 	render_shard_rows(rb.res[1], row_begin, row_end);
-	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)(row_end - row_begin), first_pixel = (uint32_t)rb.res[0] * (uint32_t)row_begin;
+	const uint32_t n_pixels = (uint32_t)rb.res[0] * (uint32_t)(row_end - row_begin);
 	if (n_pixels == 0) return;
 	const size_t n_el = next_multiple(n_pixels, BATCH_SIZE_GRANULARITY) + 256;   // + 256: the input-gradient pass of the Normals mode works on multiples of 256
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
@@ -1722,6 +1722,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	ex.quilting_dims[0] = m_quilting_dims[0]; ex.quilting_dims[1] = m_quilting_dims[1];
 	ex.render_mode = render_mode; ex.frame_buffer = rb.frame_buffer.as<float>();
 	ex.row_begin = row_begin; ex.row_end = row_end;
+	ex.tile_order = (m_nerf.render_tile_order && !(rb.res[0] & 7) && !((row_end - row_begin) & 7)) ? 1 : 0;
 	float parallax_shift[3] = {m_parallax_shift[0], m_parallax_shift[1], m_parallax_shift[2]};
 	if ((m_quilting_dims[0] != 1 || m_quilting_dims[1] != 1) && !(m_quilting_dims[0] == 2 && m_quilting_dims[1] == 1)) parallax_shift[2] = 1.0f / m_scale;   // testbed.cu:2703-2706 (lenticular display)
 	check(ngp_hip_init_rays(m_stream, sample_index, m_tr_payload[0].as<NgpPayload>(), rb.res, focal_length, cam0.m, cam1.m, rolling_shutter, screen_center, parallax_shift, m_snap_to_pixel_centers,
@@ -1751,10 +1752,71 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_rgba[0].data(), 0, (size_t)n_pixels * 16, (hipStream_t)m_stream));
 	HIP_CHECK_THROW(hipMemsetAsync(m_tr_depth[0].data(), 0, (size_t)n_pixels * 4, (hipStream_t)m_stream));
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;
-	check(ngp_hip_advance_pos(m_stream, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
-	                          min_mip, m_nerf.cone_angle_constant, first_pixel), "advance_pos");
-
 	HIP_CHECK_THROW(hipMemsetAsync(hit_counter, 0, 4, (hipStream_t)m_stream));
+	const bool fused_compaction = m_nerf.render_fused_compaction && std::max(1u, std::min(m_nerf.render_n_streams, 8u)) == 1;
+	if (fused_compaction) {
+		// The tracer with the compaction folded into advance_pos / composite (NgpCompactOut): per pass  march n_steps -> network -> composite+compact -> read n_alive back.
+		// Same per-ray sample sequence, same pixels as the loop below (tests/test_dp_gpu.py); one launch and one 60-byte read + write per ray and pass less.
+		if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocDefault));
+		if (m_tr_enc_ws.empty()) m_tr_enc_ws.emplace_back();
+		uint32_t* alive_counter = m_tr_counters.as<uint32_t>() + 2;
+		volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
+		hipStream_t st = (hipStream_t)m_stream;
+		static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;
+		auto compact_into = [&](int dst) {
+			NgpCompactOut co;
+			co.dst_rgba = m_tr_rgba[dst].as<float>(); co.dst_depth = m_tr_depth[dst].as<float>(); co.dst_payloads = m_tr_payload[dst].as<NgpPayload>();
+			co.dst_final_rgba = m_tr_hit_rgba.as<float>(); co.dst_final_depth = m_tr_hit_depth.as<float>(); co.dst_final_payloads = m_tr_hit_payload.as<NgpPayload>();
+			co.counter = alive_counter; co.final_counter = hit_counter;
+			return co;
+		};
+		auto read_alive = [&]() {
+			HIP_CHECK_THROW(hipMemcpyAsync((void*)host_alive, alive_counter, 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK_THROW(hipStreamSynchronize(st));
+			return (uint32_t)host_alive[0];
+		};
+		HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, st));
+		NgpCompactOut co = compact_into(1);
+		check(ngp_hip_advance_pos(st, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
+		                          min_mip, m_nerf.cone_angle_constant, &co), "advance_pos (+ compaction)");
+		int cur = 1;
+		uint32_t n_alive = read_alive(), i = 1;
+		while (n_alive > 0 && i < MARCH_ITER) {
+			const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), m_nerf.render_max_steps_per_pass);   // NerfTracer::trace (2231), cap raised (see below)
+			if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u\n", i, n_alive, n_steps);
+			NgpPayload* payloads = m_tr_payload[cur].as<NgpPayload>();
+			NgpCoord* net_in = m_tr_net_in.as<NgpCoord>();
+			uint16_t* net_out = m_tr_net_out.as<uint16_t>();
+			check(ngp_hip_generate_next_inputs(st, n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+			const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
+			m_tr_enc_ws[0].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, n_pixels)));
+			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[0].data(), m_tr_enc_ws[0].bytes(), render_variant), "nerf_inference (render)");
+			m_render_samples_evaluated += n_elements;
+			if (render_mode == (int)ERenderMode::Normals) {
+				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);
+				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
+				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes()), "nerf_input_gradient (normals)");
+			} else if (render_mode == 8) {
+				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
+			}
+			HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, st));
+			co = compact_into(cur ^ 1);
+			check(ngp_hip_composite(st, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), payloads, net_in, net_out, OUT_STRIDE, n_steps,
+			                        (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,
+			                        1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel, &ex, &co), "composite (+ compaction)");
+			i += n_steps;
+			cur ^= 1;
+			n_alive = read_alive();
+		}
+		uint32_t n_hit = 0;
+		HIP_CHECK_THROW(hipMemcpyAsync(&n_hit, hit_counter, 4, hipMemcpyDeviceToHost, st));
+		sync();
+		check(ngp_hip_shade(m_stream, n_hit, m_tr_hit_rgba.as<float>(), m_tr_hit_depth.as<float>(), m_tr_hit_payload.as<NgpPayload>(), m_nerf.training.linear_colors,
+		                    rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(), (int)m_render_mode), "shade");
+		return;
+	}
+	check(ngp_hip_advance_pos(m_stream, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
+	                          min_mip, m_nerf.cone_angle_constant, nullptr), "advance_pos");
 
 	// NerfTracer::trace (2140-2267).  The reference walks all rays of the frame in lock step on one stream: compact -> read n_alive back ->
 	// march n_steps -> network -> composite, ~40 times per frame, and every pass pays a host round trip plus a march that is bound by the
@@ -1833,7 +1895,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			}
 			check(ngp_hip_composite(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
 			                           (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,
-			                           1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel, &ex), "composite");
+			                           1.0f / m_nerf.training.dataset.scale /* 2415 */, m_nerf.show_accel, &ex, nullptr), "composite");
 			pt.i += n_steps;
 		}
 	}

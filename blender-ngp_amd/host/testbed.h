@@ -245,6 +245,8 @@ struct Nerf {
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
+	bool render_fused_compaction = true;     // compaction folded into advance_pos / composite (NgpCompactOut) instead of a pass of its own; off: the reference's loop
+	bool render_tile_order = true;           // the tracer's rays in 8 x 8 pixel tiles (NgpRenderExtras.tile_order) when the frame's size allows: same pixels, more coherent gathers
 	Vec3 light_dir{0.5f, 0.5f, 0.5f};        // testbed.h:712: the light direction presented at inference time when the dataset has light directions
 	uint32_t extra_dim_idx_for_inference = 0; // testbed.h:713: which training image's latent code is presented at inference time
 	bool visualize_cameras = false;          // GUI-side (stored)

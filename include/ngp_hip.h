@@ -372,7 +372,17 @@ typedef struct {
 	                                                             payloads[i] is pixel row_begin * width + i, payload.idx stays the pixel's index in the WHOLE frame (what
 	                                                             shade writes to and every per-pixel random number is keyed by), so a frame cut into row ranges — one per
 	                                                             rank — has the pixels of the frame rendered at once, bit for bit */
+	int32_t tile_order;                                       /* 1: payload slots in 8 x 8 pixel tiles (slot = tile-linear) instead of row-major, so that a wave of the later
+	                                                             kernels holds a square of neighbouring pixels; needs width and row count multiples of 8.  Same pixels. */
 } NgpRenderExtras;
+/* compact_kernel_nerf (:1784-1807) folded into the kernel that decides a ray's fate: with a NgpCompactOut, ngp_hip_advance_pos / ngp_hip_composite write every ray
+ * ONCE — alive rays to dst_* at counter++, dead rays with alpha > 0.001 to dst_final_* at final_counter++, the others nowhere — instead of updating payloads / rgba /
+ * depth in place for a ngp_hip_compact_rays pass to re-read.  The destination arrays must not alias the kernel's own arrays; the counters are bumped (the caller zeroes
+ * `counter` per pass).  Ray order inside the compacted arrays differs from the separate pass (rays are independent: same pixels).  NULL: in place, as the reference. */
+typedef struct {
+	float* dst_rgba; float* dst_depth; NgpPayload* dst_payloads; float* dst_final_rgba; float* dst_final_depth; NgpPayload* dst_final_payloads;
+	uint32_t* counter; uint32_t* final_counter;
+} NgpCompactOut;
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
                       const float* screen_center_host, const float* parallax_shift_host, int snap_to_pixel_centers, const NgpAabb* render_aabb_host,
@@ -380,9 +390,10 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
                       float* depthbuffer, float plane_z /* focus distance; < 0: slice plane at -plane_z */, float aperture_size /* 0: pinhole */,
                       const NgpRenderCamera* camera_models_host /* NULL or model 0: Perspective; else only model / sq_* / qh_* are read (:1868-1908) */,
                       const NgpRenderExtras* extras_host);                                                                       /* :1809 */
-/* first_pixel: index in the whole frame of the pixel payloads[0] belongs to (row_begin * width of a sharded frame, else 0): the start jitter is keyed by it */
+/* (the start jitter is keyed by payload.idx, the pixel's index in the whole frame — the reference's ray index i, :625, when the frame is traced at once) */
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
-                        uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel); /* :612 */
+                        uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant,
+                        const NgpCompactOut* compact_host /* NULL: in place */); /* :612 */
 int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,
                          float* dst_rgba, float* dst_depth, NgpPayload* dst_payloads, float* dst_final_rgba, float* dst_final_depth,
                          NgpPayload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);                          /* :1784 */
@@ -397,7 +408,7 @@ int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAab
 int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, const NgpAabb* aabb_host, const float* camera_matrix_host,
                       float* rgba, float* depth, NgpPayload* payloads, const NgpCoord* network_input, const uint16_t* network_output,
                       uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance,
-                      int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host);                  /* :767 */
+                      int render_mode, float depth_scale, int show_accel, const NgpRenderExtras* extras_host, const NgpCompactOut* compact_host);   /* :767 */
 int ngp_hip_shade(void* stream, uint32_t n_elements, const float* rgba, const float* depth, const NgpPayload* payloads,
                   int train_in_linear_colors, float* frame_buffer, float* depth_buffer, int render_mode);                      /* :1748 */
 int ngp_hip_accumulate(void* stream, const int32_t* res_host, const float* frame_buffer, float* accumulate_buffer, float sample_count, int color_space); /* render_buffer.cu:235 */

@@ -141,7 +141,7 @@ void orc_fill_rollover_f32(uint32_t n_elements, uint32_t stride, uint32_t n_inpu
 void orc_extra_camera_model_pixel_to_ray(int model, uint32_t spp, uint32_t x, uint32_t y, float rx, float ry, const float* c, float sq_width, float sq_height, float sq_curvature,
                                          const float* qh_front, const float* qh_back, float near_distance, float focus_z, float aperture_size, orc_vec3* origin, orc_vec3* dir);
 void orc_init_rays(uint32_t sample_index, orc_payload* payloads, const int32_t res[2], const float focal_length[2], const float* camera_matrix0, const float* camera_matrix1, const float rolling_shutter[4], const float screen_center[2], const float parallax_shift[3], int snap_to_pixel_centers, const orc_aabb* render_aabb, const float* render_aabb_to_local, float near_distance, int lens_mode, const float* lens_params, float* depthbuffer, float plane_z, float aperture_size, const orc_render_camera* camera_models);
-void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index, orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel);
+void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index, orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant);
 void orc_compact_rays(uint32_t n_elements, const float* src_rgba, const float* src_depth, const orc_payload* src_payloads, float* dst_rgba, float* dst_depth, orc_payload* dst_payloads, float* dst_final_rgba, float* dst_final_depth, orc_payload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);
 void orc_generate_next_inputs(uint32_t n_elements, const orc_aabb* render_aabb, const orc_aabb* train_aabb, orc_payload* payloads, orc_coord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant);
 void orc_composite(uint32_t n_elements, uint32_t current_step, const orc_aabb* aabb, const float* camera_matrix, float* rgba, float* depth, orc_payload* payloads, const orc_coord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation, float min_transmittance);
@@ -155,6 +155,7 @@ typedef struct {   /* NgpRenderExtras of include/ngp_hip.h */
 	const orc_mask3d* render_masks; uint32_t n_render_masks; int32_t glow_mode; float glow_y_cutoff; const float* envmap; int32_t envmap_res[2];
 	const float* distortion; int32_t distortion_res[2]; int32_t quilting_dims[2]; int32_t render_mode; float* frame_buffer;
 	int32_t row_begin, row_end;   /* {0,0}: the whole frame; else init_rays sets up the rows [row_begin, row_end) only (a shard of the frame) */
+	int32_t tile_order;           /* (the product's 8 x 8 tile slot order; the oracle keeps row-major slots) */
 } orc_render_extras;
 void orc_read_image2(const float* data, const int32_t res[2], const float pos[2], float out[2]);
 void orc_read_envmap(const float* data, const int32_t res[2], const float dir[3], float out[4]);

@@ -225,7 +225,7 @@ void orc_init_rays_ex(uint32_t sample_index, orc_payload* payloads, const int32_
 
 /* testbed_nerf.cu:612-664 */
 void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const float* render_aabb_to_local, uint32_t sample_index,
-                     orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t first_pixel /* of a row shard, else 0 */) {
+                     orc_payload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
 	for (uint32_t i = 0; i < n_elements; ++i) {
 		orc_payload* p = &payloads[i];
 		if (!p->alive) continue;
@@ -234,7 +234,7 @@ void orc_advance_pos(uint32_t n_elements, const orc_aabb* render_aabb, const flo
 		float cone_angle = cone_angle_constant;
 		float t = p->t;
 		float dt = orc_calc_dt(t, cone_angle);
-		t += orc_ld_random_val(sample_index, (i + first_pixel) * 786433u, 0) * dt;
+		t += orc_ld_random_val(sample_index, p->idx * 786433u, 0) * dt;   /* the reference keys by the ray index i = the pixel index of a frame traced at once (:625) */
 		orc_vec3 pos;
 		while (1) {
 			pos = orc_add(origin, orc_scale(dir, t));
@@ -575,7 +575,7 @@ uint64_t orc_render_nerf_rows(const orc_net* net, const uint16_t* inference_para
                               float near_distance, const uint8_t* density_grid, float cone_angle_constant, int rgb_activation, int density_activation,
                               float min_transmittance, int train_in_linear_colors, float* frame_buffer, float* depth_buffer, int row_begin, int row_end) {
 	if (row_end <= row_begin) return 0;
-	const uint32_t n_pixels = (uint32_t)res[0] * (uint32_t)(row_end - row_begin), first_pixel = (uint32_t)res[0] * (uint32_t)row_begin;
+	const uint32_t n_pixels = (uint32_t)res[0] * (uint32_t)(row_end - row_begin);
 	orc_render_extras rows_ex;
 	memset(&rows_ex, 0, sizeof(rows_ex));
 	rows_ex.quilting_dims[0] = rows_ex.quilting_dims[1] = 1; rows_ex.render_mode = 1; rows_ex.row_begin = row_begin; rows_ex.row_end = row_end;
@@ -594,7 +594,7 @@ uint64_t orc_render_nerf_rows(const orc_net* net, const uint16_t* inference_para
 
 	orc_init_rays_ex(sample_index, payload[0], res, focal_length, camera_matrix0, camera_matrix1, zero4, screen_center, zero3,
 	                 snap_to_pixel_centers, render_aabb, render_aabb_to_local, near_distance, 0, NULL, depth_buffer, 1.0f, 0.0f, NULL, &rows_ex);
-	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant, first_pixel);
+	orc_advance_pos(n_pixels, render_aabb, render_aabb_to_local, sample_index, payload[0], density_grid, 0, cone_angle_constant);
 
 	uint32_t n_alive = n_pixels, n_hit = 0, i = 1, dbi = 0;
 	uint64_t n_samples = 0;

@@ -191,3 +191,42 @@ def test_data_parallel_step_replicated_optimizer_still_runs(cuda):
     scene.train(b, 40)
     assert b.training_step == 40 and np.isfinite(b.loss)
     b.shutdown_data_parallel()
+
+
+@pytest.mark.parametrize("snap,spp", [(True, 1), (False, 2)])
+def test_tile_ordered_rays_render_the_same_pixels(trained, snap, spp):
+    """nerf.render_tile_order (NgpRenderExtras.tile_order): the tracer's ray slots in 8 x 8 pixel tiles instead of row-major — a different order of independent rays,
+    every random number keyed by the pixel: bit-identical frames; sizes that are not multiples of 8 fall back to row-major"""
+    ds, tb = trained
+    tb.set_render_shard(0, 1)
+    tb.snap_to_pixel_centers = snap
+    for (w, h) in ((96, 64), (100, 50)):
+        tb.nerf.render_tile_order = False
+        a = tb.render(w, h, spp, True)
+        tb.nerf.render_tile_order = True
+        b = tb.render(w, h, spp, True)
+        np.testing.assert_array_equal(a, b)
+    assert (a[..., 3] > 0.5).any()
+
+
+@pytest.mark.parametrize("mode", ["Shade", "Depth", "AO"])
+def test_fused_compaction_renders_the_same_pixels(trained, mode):
+    """nerf.render_fused_compaction (NgpCompactOut): compaction folded into advance_pos / composite vs the reference's separate compact pass — the rays land in another
+    order in the compacted arrays, every ray sees the same samples: identical frames, also in the other render modes and with several spp"""
+    import pyngp
+    ds, tb = trained
+    tb.set_render_shard(0, 1)
+    tb.snap_to_pixel_centers = False
+    tb.render_mode = getattr(pyngp.RenderMode, mode)
+    try:
+        tb.nerf.render_fused_compaction = False
+        a = tb.render(104, 72, 2, True)
+        n_a = tb.render_samples_evaluated
+        tb.nerf.render_fused_compaction = True
+        b = tb.render(104, 72, 2, True)
+        assert tb.render_samples_evaluated == n_a
+    finally:
+        tb.render_mode = pyngp.RenderMode.Shade
+        tb.nerf.render_fused_compaction = True
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(a[..., :3]).max() > 0

@@ -147,7 +147,7 @@ def _march_inputs(oracle, n_steps=4):
     pay, depth = np.zeros(n, H.PAYLOAD), np.zeros(n, np.float32)
     oracle.orc_init_rays(0, pay.ctypes.data, res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
                          1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, depth.ctypes.data, H.f32(1.0), H.f32(0.0), None)
-    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, 0, pay.ctypes.data, bf.ctypes.data, 0, H.f32(0.0), 0)
+    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, 0, pay.ctypes.data, bf.ctypes.data, 0, H.f32(0.0))
     alive = pay[pay["alive"] == 1].copy()
     na = len(alive)
     coords = np.zeros(na * n_steps, H.COORD)

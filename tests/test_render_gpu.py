@@ -57,9 +57,9 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plan
         np.testing.assert_array_equal(g["dir"], pay["dir"])
         return dict(pay=pay, g=g, depth=depth)
 
-    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone), 0)
+    oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone))
     d_bf = H.to_dev(bf, cuda)
-    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone), 0))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone)))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
     np.testing.assert_array_equal(g["alive"], pay["alive"])
     al = pay["alive"] == 1
@@ -263,7 +263,7 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
     cnt, hcnt = H.dev_zeros(4, cuda), H.dev_zeros(4, cuda)
     check(ngp.ngp_hip_init_rays(None, 0, pay[0].data_ptr(), res.ctypes.data, focal.ctypes.data, cam.ctypes.data, cam.ctypes.data, zero4.ctypes.data, sc.ctypes.data, zero3.ctypes.data,
                                 1, aabb.ctypes.data, ident.ctypes.data, H.f32(0.0), 0, None, db.data_ptr(), H.f32(1.0), H.f32(0.0), None, None))
-    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0), 0))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, 0, pay[0].data_ptr(), d_bf.data_ptr(), 0, H.f32(0.0)))
     n_alive, i, dbi = n, 1, 0
     while i < 10000:
         cur, tmp = (dbi + 1) % 2, dbi % 2

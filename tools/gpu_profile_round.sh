@@ -4,7 +4,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 mkdir -p $out
-timeout 300 python -m pytest tests -m gpu -x -q > $out/${tag}_pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q > $out/${tag}_pytest_gpu.log 2>&1
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1
 timeout 600 python bench.py > $out/${tag}_bench.log 2>&1
 grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench_line.json

@@ -21,3 +21,12 @@ for _ in range(n):
     tb.render(res, res, 1, True)
 dt = (time.perf_counter() - t0) / n
 print("psnr %.2f  eval wall per frame %.2f ms" % (psnr, dt * 1e3), per)
+for tile, fused in ((False, False), (True, False), (False, True), (True, True), (False, False), (True, True)):
+    tb.nerf.render_fused_compaction = fused
+    tb.nerf.render_tile_order = tile
+    tb.render(res, res, 1, True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tb.render(res, res, 1, True)
+    dt = (time.perf_counter() - t0) / n
+    print("tile_order %s fused_compaction %s: %.2f ms / frame, %d network samples" % (tile, fused, dt * 1e3, tb.render_samples_evaluated))
