@@ -447,7 +447,7 @@ def main():
             t = torch.tensor([n_render_samples], dtype=torch.float64, device=dev)
             dist.all_reduce(t)
             n_render_samples = float(t.item())
-        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_network_samples_per_frame": int(n_render_samples),
+        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
                  "render_ranks": world if render_sharded else 1, "render_rows_per_rank": (a.res + world - 1) // world if render_sharded else a.res,
                  "psnr_db": round(psnr, 2), "ssim": round(ssim, 4), "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
 

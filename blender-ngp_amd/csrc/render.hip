@@ -151,16 +151,37 @@ static_assert(sizeof(NgpPayload) == sizeof(Payload40), "payload");
 // compact_kernel_nerf (src/testbed_nerf.cu:1784-1807) at the END of the kernel that decides a ray's fate (advance_pos, composite) instead of as a pass of its own: the
 // ray's payload, colour and depth are still in registers, so they are written once — to their compacted slot (alive), to the finished list (dead with alpha > 0.001)
 // or nowhere — and the tracer loses a launch and a 60-byte read + write per ray and pass.  One atomic per wave and counter (ballots).  counter == NULL: off.
-struct CompactOut { float4* dst_rgba; float* dst_depth; Payload40* dst_payloads; float4* fin_rgba; float* fin_depth; Payload40* fin_payloads; uint32_t* counter; uint32_t* final_counter; };
+struct CompactOut { float4* dst_rgba; float* dst_depth; Payload40* dst_payloads; float4* fin_rgba; float* fin_depth; Payload40* fin_payloads; uint32_t* counter; uint32_t* final_counter;
+                    uint32_t* blocks_done; uint32_t* host_mailbox; uint32_t sequence; };
+// (every thread of the workgroup calls this; at most COMPACT_MAX_WAVES waves per workgroup.  The two counters are device-scope atomics on ONE address each, which the
+// memory side serialises: one atomic per workgroup and counter — wave ballots summed through LDS — instead of one per wave.)
+constexpr uint32_t COMPACT_MAX_WAVES = 4;
 __device__ __forceinline__ void compact_store(bool alive, bool hit, const NgpPayload& payload, float4 c, float d, const CompactOut& co) {
-	const uint32_t lane = lane_id();
+	__shared__ uint32_t s_count[2][COMPACT_MAX_WAVES], s_base[2];
+	const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
 	const unsigned long long am = __ballot(alive), hm = __ballot(hit);
-	uint32_t abase = 0, hbase = 0;
-	if (lane == 0) {
-		if (am) abase = atomicAdd(co.counter, (uint32_t)__popcll(am));
-		if (hm) hbase = atomicAdd(co.final_counter, (uint32_t)__popcll(hm));
+	if (lane == 0) { s_count[0][wave] = (uint32_t)__popcll(am); s_count[1][wave] = (uint32_t)__popcll(hm); }
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		uint32_t total = 0;
+		for (uint32_t w = 0; w < n_waves; ++w) total += s_count[threadIdx.x][w];
+		uint32_t base = total ? atomicAdd(threadIdx.x == 0 ? co.counter : co.final_counter, total) : 0u;
+		s_base[threadIdx.x] = base;
+		// The last workgroup to get here posts the pass's alive count to the caller's mailbox in host memory — one 8-byte store {count, sequence number the caller waits
+		// for} — so the host learns it while the kernel drains, without a copy command and a stream synchronisation between two passes.  No fences (a device-scope release
+		// writes the XCD's L2 back): the counter update above has returned, i.e. happened at the memory side, before the ticket is drawn, and all three are device-scope atomics.
+		if (threadIdx.x == 0 && co.host_mailbox) {
+			asm volatile("" : "+v"(base));
+			if (atomicAdd(co.blocks_done, 1u + (base & 0u)) == gridDim.x - 1u) {
+				const uint32_t n_alive = __hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(co.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store((unsigned long long*)co.host_mailbox, (unsigned long long)n_alive | ((unsigned long long)co.sequence << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
 	}
-	abase = __shfl(abase, 0, 64); hbase = __shfl(hbase, 0, 64);
+	__syncthreads();
+	uint32_t abase = s_base[0], hbase = s_base[1];
+	for (uint32_t w = 0; w < wave; ++w) { abase += s_count[0][w]; hbase += s_count[1][w]; }
 	const unsigned long long below = (1ull << lane) - 1ull;
 	const Payload40& p = *(const Payload40*)&payload;
 	if (alive) {
@@ -172,9 +193,20 @@ __device__ __forceinline__ void compact_store(bool alive, bool hit, const NgpPay
 	}
 }
 
+// The 4 KiB cascade-0 brick summary (ngp_hip_bitfield_brick_summary) staged in LDS when the caller has one: the walk through empty space — most iterations of
+// advance_pos, and the exit walk of every ray in generate_next_inputs — answers "empty" without a dependent global load per brick.  Same bits, same samples.
+__device__ __forceinline__ void stage_brick_summary(const uint32_t* __restrict__ brick_summary, uint32_t* __restrict__ s_brick_any) {
+	if (!brick_summary) return;   // (uniform)
+	const uint4* src = (const uint4*)brick_summary;
+	for (uint32_t q = threadIdx.x; q < NGP_NERF_GRID_N_CELLS / 64u / 32u / 4u; q += blockDim.x) ((uint4*)s_brick_any)[q] = src[q];
+	__syncthreads();
+}
+
 template <bool CONST_DT>   // cone_angle == 0: see calc_dt_t
-__global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
-                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant, const CompactOut co) {
+__global__ void __launch_bounds__(256) advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 to_local, uint32_t sample_index, NgpPayload* __restrict__ payloads,
+                                   const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant, const CompactOut co, const uint32_t* __restrict__ brick_summary) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
+	stage_brick_summary(brick_summary, s_brick_any);
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
 	NgpPayload payload;
 	payload.alive = 0;
@@ -195,7 +227,7 @@ __global__ void advance_pos_kernel(uint32_t n_elements, Aabb render_aabb, Mat33 
 			dt = calc_dt_t<CONST_DT>(t, cone_angle);
 			uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 			mip = mip < min_mip ? min_mip : mip;
-			if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) break;
+			if (!density_grid || (brick_summary ? density_grid_occupied_at(pos, density_grid, mip, occ, s_brick_any) : density_grid_occupied_at(pos, density_grid, mip, occ))) break;
 			t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
 		payload.t = t;
@@ -241,9 +273,13 @@ __global__ void __launch_bounds__(256) compact_rays_kernel(uint32_t n_elements, 
 // the object and walks ~150 empty voxels to the box boundary no longer holds the other 63 lanes of its wave at every one of the
 // n_steps steps: the wave runs max-over-lanes(n_steps + skips) iterations, not sum-over-steps(max-over-lanes skips).
 template <bool CONST_DT>
-__global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aabb, Aabb train_aabb, NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input,
-                                            uint32_t n_steps, const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant) {
+__global__ void __launch_bounds__(128) generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aabb, Aabb train_aabb, NgpPayload* __restrict__ payloads, NgpCoord* __restrict__ network_input,
+                                            uint32_t n_steps, const uint8_t* __restrict__ density_grid, uint32_t min_mip, float cone_angle_constant,
+                                            const uint32_t* __restrict__ brick_summary, uint32_t* __restrict__ zero_word, uint32_t max_skips) {
+	__shared__ __attribute__((aligned(16))) uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
+	stage_brick_summary(brick_summary, s_brick_any);
 	const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+	if (zero_word && i == 0) *zero_word = 0;   // the caller's next compaction counter (stream order puts this before the kernel that bumps it): saves it a memset per pass
 	if (i >= n_elements) return;
 	NgpPayload& payload = payloads[i];
 	if (!payload.alive) return;
@@ -253,14 +289,17 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 	const float cone_angle = cone_angle_constant;
 	float t = payload.t;
 	OccBrick occ;
-	uint32_t j = 0;
+	uint32_t j = 0, skips = 0;
 	while (j < n_steps) {
 		const v3 pos = origin + dir * t;
 		if (!aabb_contains(render_aabb, pos)) { payload.n_steps = (uint16_t)j; return; }
+		// A ray that has spent its allowance of empty voxels for this pass hands in the j samples it has and rests (alive = NGP_RAY_PAUSED, t kept): composite leaves it
+		// alive and the next pass resumes the same march.  Without this every pass lasts as long as the longest walk to the box boundary among its rays.
+		if (max_skips && skips >= max_skips) { payload.t = t; payload.n_steps = (uint16_t)j; payload.alive = NGP_RAY_PAUSED; return; }
 		const float dt = calc_dt_t<CONST_DT>(t, cone_angle);
 		uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		mip = mip < min_mip ? min_mip : mip;
-		if (!density_grid || density_grid_occupied_at(pos, density_grid, mip, occ)) {
+		if (!density_grid || (brick_summary ? density_grid_occupied_at(pos, density_grid, mip, occ, s_brick_any) : density_grid_occupied_at(pos, density_grid, mip, occ))) {
 			const v3 wp = aabb_relative_pos(train_aabb, pos);
 			NgpCoord c;
 			c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt); c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
@@ -269,6 +308,7 @@ __global__ void generate_next_inputs_kernel(uint32_t n_elements, Aabb render_aab
 			++j;
 		} else {
 			t = advance_to_next_voxel<CONST_DT>(t, cone_angle, pos, dir, idir, NGP_NERF_GRIDSIZE >> mip);
+			++skips;
 		}
 	}
 	payload.t = t;
@@ -334,6 +374,7 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 	payload.alive = 0;
 	if (i < n_elements) payload = payloads[i];
 	const bool was_alive = i < n_elements && payload.alive;
+	const bool paused = payload.alive == NGP_RAY_PAUSED;   // (ngp_hip_generate_next_inputs with an allowance of empty voxels)
 	float4 local_rgba = make_float4(0.f, 0.f, 0.f, 0.f);
 	float local_depth = 0.f;
 	if (i < n_elements && (was_alive || co.counter)) { local_rgba = rgba[i]; local_depth = depth[i]; }
@@ -343,10 +384,25 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 	const uint32_t actual_n_steps = payload.n_steps;
 	float max_weight = payload.max_weight;
 	uint32_t j = 0;
-	for (; j < actual_n_steps; ++j) {
-		const size_t s = (size_t)i + (size_t)j * n_elements;
-		const us4 lo = *(const us4*)(network_output + s * out_stride);
-		const NgpCoord in = network_input[s];
+	// The samples of a ray are one n_elements-strided load apart and the loop may stop at any of them, so the compiler issues each step's loads after the previous step's
+	// exit test — n_steps dependent trips to memory.  Four steps' loads are issued together here (all inside [0, actual_n_steps): nothing is read that the plain loop could
+	// not have read) and then consumed in order; same arithmetic, same exit.
+	bool done = false, saturated = false;
+	for (uint32_t j0 = 0; j0 < actual_n_steps && !done; j0 += 4) {
+		us4 lo4[4]; NgpCoord in4[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			if (j0 + k < actual_n_steps) {
+				const size_t s = (size_t)i + (size_t)(j0 + k) * n_elements;
+				lo4[k] = __builtin_nontemporal_load((const us4*)(network_output + s * out_stride));
+				in4[k] = network_input[s];
+			}
+		}
+#pragma unroll
+	for (uint32_t k = 0; k < 4; ++k) {
+		if (j0 + k >= actual_n_steps) { done = true; break; }
+		const us4 lo = lo4[k];
+		const NgpCoord in = in4[k];
 		const v3 pos = unwarp_position(mk(in.pos[0], in.pos[1], in.pos[2]), aabb);
 		const float T = 1.f - local_rgba.w;
 		const float dt = unwarp_dt(in.dt);
@@ -394,11 +450,15 @@ __global__ void composite_kernel(uint32_t n_elements, uint32_t current_step, Aab
 		if (local_rgba.w > (1.0f - min_transmittance)) {
 			const float w = local_rgba.w;
 			local_rgba.x /= w; local_rgba.y /= w; local_rgba.z /= w; local_rgba.w /= w;
+			done = saturated = true;
 			break;
 		}
+		++j;
+	}
 	}
 	payload.max_weight = max_weight;
-	if (j < n_steps) { payload.alive = 0; payload.n_steps = (uint16_t)(j + current_step); }
+	if (saturated || (j < n_steps && !paused)) { payload.alive = 0; payload.n_steps = (uint16_t)(j + current_step); }
+	else payload.alive = 1;
 	}
 	if (!co.counter) {
 		if (was_alive) { payloads[i] = payload; rgba[i] = local_rgba; depth[i] = local_depth; }
@@ -511,6 +571,7 @@ static CompactOut compact_from_host(const NgpCompactOut* c) {
 	o.dst_rgba = (float4*)c->dst_rgba; o.dst_depth = c->dst_depth; o.dst_payloads = (Payload40*)c->dst_payloads;
 	o.fin_rgba = (float4*)c->dst_final_rgba; o.fin_depth = c->dst_final_depth; o.fin_payloads = (Payload40*)c->dst_final_payloads;
 	o.counter = c->counter; o.final_counter = c->final_counter;
+	o.blocks_done = c->blocks_done; o.host_mailbox = c->blocks_done ? c->host_mailbox : nullptr; o.sequence = c->sequence;
 	return o;
 }
 static Mat34 mat34_from_host(const float* m) { Mat34 r; for (int i = 0; i < 12; ++i) r.m[i] = m[i]; return r; }
@@ -575,11 +636,11 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
 }
 
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host, uint32_t sample_index,
-                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, const NgpCompactOut* compact_host) {
+                        NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, const NgpCompactOut* compact_host, const uint32_t* brick_summary) {
 	if (!n_elements) return 0;
 	const CompactOut co = compact_from_host(compact_host);
-	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co);
-	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co);
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(advance_pos_kernel<true>, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co, brick_summary);
+	else hipLaunchKernelGGL(advance_pos_kernel<false>, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), mat33_from_host(render_aabb_to_local_host), sample_index, payloads, density_grid, min_mip, cone_angle_constant, co, brick_summary);
 	NGP_LAUNCH_CHECK("advance_pos_kernel");
 	return 0;
 }
@@ -594,10 +655,10 @@ int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgb
 }
 
 int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host, NgpPayload* payloads, NgpCoord* network_input,
-                                 uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant) {
-	if (!n_elements) return 0;
-	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_next_inputs_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
-	else hipLaunchKernelGGL(generate_next_inputs_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant);
+                                 uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant, uint32_t max_skips_per_pass, const uint32_t* brick_summary, uint32_t* zero_word) {
+	if (!n_elements) { if (zero_word) NGP_HIP_TRY(hipMemsetAsync(zero_word, 0, 4, (hipStream_t)stream)); return 0; }
+	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_next_inputs_kernel<true>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant, brick_summary, zero_word, max_skips_per_pass);
+	else hipLaunchKernelGGL(generate_next_inputs_kernel<false>, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, aabb_from_host(render_aabb_host), aabb_from_host(train_aabb_host), payloads, network_input, n_steps, density_grid, min_mip, cone_angle_constant, brick_summary, zero_word, max_skips_per_pass);
 	NGP_LAUNCH_CHECK("generate_next_inputs_kernel");
 	return 0;
 }
@@ -610,7 +671,7 @@ int ngp_hip_composite(void* stream, uint32_t n_elements, uint32_t current_step, 
 	extras_from_host(nullptr, ex, "");
 	if (extras_host) { RenderExtras t; extras_from_host(extras_host, t, ""); ex.render_masks = t.render_masks; ex.n_render_masks = t.n_render_masks; ex.glow_mode = t.glow_mode; ex.glow_y_cutoff = t.glow_y_cutoff; }
 	if (!n_elements) return 0;
-	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 128)), dim3(128), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
+	hipLaunchKernelGGL(composite_kernel, dim3(div_up(n_elements, 256)), dim3(256), 0, (hipStream_t)stream, n_elements, current_step, aabb_from_host(aabb_host), mat34_from_host(camera_matrix_host), (float4*)rgba, depth,
 	                   payloads, network_input, network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, render_mode, depth_scale, show_accel, ex, compact_from_host(compact_host));
 	NGP_LAUNCH_CHECK("composite_kernel");
 	return 0;

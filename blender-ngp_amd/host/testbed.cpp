@@ -750,6 +750,7 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 		m_nerf.density_grid.memset(0, m_stream);
 		m_nerf.density_grid_bitfield.resize((size_t)GRID_CELLS);  // grid_mip_offset(NERF_CASCADES)/8
 		m_nerf.density_grid_bitfield.memset(0, m_stream);
+		m_nerf.brick_summary_valid = false;
 		m_nerf.density_grid_mean.resize(4);
 		m_nerf.density_grid_mean.memset(0, m_stream);
 	}
@@ -1703,7 +1704,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	for (int b = 0; b < 2; ++b) { m_tr_payload[b].enlarge(n_el * sizeof(NgpPayload)); m_tr_rgba[b].enlarge(n_el * 16); m_tr_depth[b].enlarge(n_el * 4); }
 	m_tr_hit_payload.enlarge(n_el * sizeof(NgpPayload)); m_tr_hit_rgba.enlarge(n_el * 16); m_tr_hit_depth.enlarge(n_el * 4);
 	m_tr_net_in.enlarge(n_el * 8 * sizeof(NgpCoord)); m_tr_net_out.enlarge(n_el * 8 * OUT_STRIDE * 2);
-	m_tr_counters.enlarge((2 + 8) * 4);
+	m_tr_counters.enlarge((2 + 8 + 2) * 4);   // [1] finished rays, [2..9] alive rays per range, [10] NgpCompactOut::blocks_done
 	uint32_t* hit_counter = m_tr_counters.as<uint32_t>() + 1;
 
 	const int lens_mode = m_nerf.render_with_lens_distortion ? m_nerf.render_lens_proxy.lens_mode : 0;   // testbed_nerf.cu:2381
@@ -1754,40 +1755,70 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	const uint32_t min_mip = m_nerf.show_accel >= 0 ? (uint32_t)m_nerf.show_accel : 0;
 	HIP_CHECK_THROW(hipMemsetAsync(hit_counter, 0, 4, (hipStream_t)m_stream));
 	const bool fused_compaction = m_nerf.render_fused_compaction && std::max(1u, std::min(m_nerf.render_n_streams, 8u)) == 1;
+	if (!m_nerf.brick_summary_valid && m_nerf.density_grid_bitfield.bytes() >= (size_t)GRID_CELLS / 8) {   // a bitfield that did not come from update_density_grid_mean_and_bitfield (snapshot, reset)
+		m_nerf.bitfield_brick_summary.enlarge(GRID_CELLS / 64 / 32 * 4);
+		check(ngp_hip_bitfield_brick_summary(m_stream, m_nerf.density_grid_bitfield.as<uint8_t>(), m_nerf.bitfield_brick_summary.as<uint32_t>()), "bitfield_brick_summary");
+		m_nerf.brick_summary_valid = true;
+	}
+	const uint32_t* brick_summary = m_nerf.brick_summary_valid ? m_nerf.bitfield_brick_summary.as<uint32_t>() : nullptr;
 	if (fused_compaction) {
 		// The tracer with the compaction folded into advance_pos / composite (NgpCompactOut): per pass  march n_steps -> network -> composite+compact -> read n_alive back.
 		// Same per-ray sample sequence, same pixels as the loop below (tests/test_dp_gpu.py); one launch and one 60-byte read + write per ray and pass less.
-		if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocDefault));
+		if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
 		if (m_tr_enc_ws.empty()) m_tr_enc_ws.emplace_back();
 		uint32_t* alive_counter = m_tr_counters.as<uint32_t>() + 2;
 		volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
 		hipStream_t st = (hipStream_t)m_stream;
 		static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;
+		// The alive count of a pass comes back through a mailbox in host memory that the pass's last workgroup writes (NgpCompactOut::host_mailbox) and this thread polls:
+		// no copy command, no stream synchronisation (an interrupt and a wake-up) between two passes.
+		uint32_t* blocks_done = m_tr_counters.as<uint32_t>() + 10;
+		uint32_t* mailbox = (uint32_t*)m_render_host_words + 4;
+		uint32_t* mailbox_dev = nullptr;
+		HIP_CHECK_THROW(hipHostGetDevicePointer((void**)&mailbox_dev, mailbox, 0));
+		HIP_CHECK_THROW(hipMemsetAsync(blocks_done, 0, 4, st));
 		auto compact_into = [&](int dst) {
 			NgpCompactOut co;
 			co.dst_rgba = m_tr_rgba[dst].as<float>(); co.dst_depth = m_tr_depth[dst].as<float>(); co.dst_payloads = m_tr_payload[dst].as<NgpPayload>();
 			co.dst_final_rgba = m_tr_hit_rgba.as<float>(); co.dst_final_depth = m_tr_hit_depth.as<float>(); co.dst_final_payloads = m_tr_hit_payload.as<NgpPayload>();
 			co.counter = alive_counter; co.final_counter = hit_counter;
+			co.blocks_done = blocks_done; co.host_mailbox = mailbox_dev; co.sequence = ++m_render_sequence;
 			return co;
 		};
 		auto read_alive = [&]() {
-			HIP_CHECK_THROW(hipMemcpyAsync((void*)host_alive, alive_counter, 4, hipMemcpyDeviceToHost, st));
-			HIP_CHECK_THROW(hipStreamSynchronize(st));
-			return (uint32_t)host_alive[0];
+			const uint32_t want = m_render_sequence;
+			const auto t0 = std::chrono::steady_clock::now();
+			uint64_t word;
+			for (uint32_t spins = 1; (uint32_t)((word = __atomic_load_n((const uint64_t*)mailbox, __ATOMIC_ACQUIRE)) >> 32) != want; ++spins) {
+				if ((spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // a kernel that died posts nothing: ask the stream
+					HIP_CHECK_THROW(hipStreamSynchronize(st));
+					if ((uint32_t)((word = __atomic_load_n((const uint64_t*)mailbox, __ATOMIC_ACQUIRE)) >> 32) != want) throw std::runtime_error{"render: the tracer pass finished without posting its alive count"};
+					break;
+				}
+				__builtin_ia32_pause();
+			}
+			return (uint32_t)word;
 		};
+		(void)host_alive;
+		// (Cost mode paints the steps a ray took, counted per pass: every ray must take the pass's n_steps there)
+		const uint32_t skip_allowance = render_mode == (int)ERenderMode::Cost ? 0u : m_nerf.render_max_skips_per_pass;
+		// (n_alive * n_steps never exceeds a pass's sample budget: the workspace is sized once, not grown — a hipFree + hipMalloc — when a later pass or view needs more)
+		const uint32_t pass_samples = (uint32_t)((float)n_pixels * std::min(std::max(m_nerf.render_pass_samples_factor, 1.0f), 4.0f));
+		m_tr_enc_ws[0].enlarge(ngp_hip_nerf_encode_workspace_bytes(next_multiple(pass_samples, BATCH_SIZE_GRANULARITY) + BATCH_SIZE_GRANULARITY));
 		HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, st));
 		NgpCompactOut co = compact_into(1);
 		check(ngp_hip_advance_pos(st, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
-		                          min_mip, m_nerf.cone_angle_constant, &co), "advance_pos (+ compaction)");
+		                          min_mip, m_nerf.cone_angle_constant, &co, brick_summary), "advance_pos (+ compaction)");
 		int cur = 1;
 		uint32_t n_alive = read_alive(), i = 1;
 		while (n_alive > 0 && i < MARCH_ITER) {
-			const uint32_t n_steps = std::min(std::max(n_pixels / n_alive, 1u), m_nerf.render_max_steps_per_pass);   // NerfTracer::trace (2231), cap raised (see below)
+			const uint32_t n_steps = std::min(std::max(pass_samples / n_alive, 1u), m_nerf.render_max_steps_per_pass);   // NerfTracer::trace (2231), cap raised (see below)
 			if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u\n", i, n_alive, n_steps);
 			NgpPayload* payloads = m_tr_payload[cur].as<NgpPayload>();
 			NgpCoord* net_in = m_tr_net_in.as<NgpCoord>();
 			uint16_t* net_out = m_tr_net_out.as<uint16_t>();
-			check(ngp_hip_generate_next_inputs(st, n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+			check(ngp_hip_generate_next_inputs(st, n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant,
+			                                   skip_allowance, brick_summary, alive_counter /* read back above; composite below bumps it */), "generate_next_inputs");
 			const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 			m_tr_enc_ws[0].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, n_pixels)));
 			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[0].data(), m_tr_enc_ws[0].bytes(), render_variant), "nerf_inference (render)");
@@ -1799,7 +1830,6 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			} else if (render_mode == 8) {
 				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
 			}
-			HIP_CHECK_THROW(hipMemsetAsync(alive_counter, 0, 4, st));
 			co = compact_into(cur ^ 1);
 			check(ngp_hip_composite(st, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), payloads, net_in, net_out, OUT_STRIDE, n_steps,
 			                        (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,
@@ -1816,7 +1846,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		return;
 	}
 	check(ngp_hip_advance_pos(m_stream, n_pixels, &m_render_aabb, m_render_aabb_to_local, sample_index, m_tr_payload[0].as<NgpPayload>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
-	                          min_mip, m_nerf.cone_angle_constant, nullptr), "advance_pos");
+	                          min_mip, m_nerf.cone_angle_constant, nullptr, brick_summary), "advance_pos");
 
 	// NerfTracer::trace (2140-2267).  The reference walks all rays of the frame in lock step on one stream: compact -> read n_alive back ->
 	// march n_steps -> network -> composite, ~40 times per frame, and every pass pays a host round trip plus a march that is bound by the
@@ -1827,7 +1857,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	const uint32_t K = std::max(1u, std::min(m_nerf.render_n_streams, 8u));
 	while (m_render_streams.size() < K) { hipStream_t st; HIP_CHECK_THROW(hipStreamCreate(&st)); m_render_streams.push_back(st); }
 	if (!m_render_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m_render_event = e; }
-	if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocDefault));
+	if (!m_render_host_words) HIP_CHECK_THROW(hipHostMalloc(&m_render_host_words, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
 	m_tr_counters.enlarge((2 + 8) * 4);
 	while (m_tr_enc_ws.size() < K) m_tr_enc_ws.emplace_back();
 	struct Part { uint32_t start, count, n_alive, i, dbi; bool done; };
@@ -1878,7 +1908,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			NgpPayload* payloads = (NgpPayload*)buf(m_tr_payload[cur], sizeof(NgpPayload), pt.start);
 			NgpCoord* net_in = (NgpCoord*)buf(m_tr_net_in, 8 * sizeof(NgpCoord), pt.start);
 			uint16_t* net_out = (uint16_t*)buf(m_tr_net_out, 8 * OUT_STRIDE * 2, pt.start);
-			check(ngp_hip_generate_next_inputs(st, pt.n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant), "generate_next_inputs");
+			check(ngp_hip_generate_next_inputs(st, pt.n_alive, &m_render_aabb, &m_aabb, payloads, net_in, n_steps, m_nerf.density_grid_bitfield.as<uint8_t>(), min_mip, m_nerf.cone_angle_constant, 0, brick_summary, nullptr), "generate_next_inputs");
 			const uint32_t n_elements = next_multiple(pt.n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 			// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
@@ -2070,6 +2100,7 @@ void Testbed::load_snapshot(const std::string& path) {
 		update_density_grid_mean_and_bitfield();
 	} else {
 		m_nerf.density_grid.memset(0, m_stream); m_nerf.density_grid_bitfield.memset(0, m_stream); m_nerf.density_grid_mean.memset(0, m_stream);
+		m_nerf.brick_summary_valid = false;
 	}
 
 	m_training_step = (uint32_t)snapshot.at("training_step").number();

@@ -241,6 +241,8 @@ struct Nerf {
 	float cone_angle_constant = 1.f / 256.f;
 	float render_min_transmittance = 0.01f;  // testbed.h:725
 	uint32_t render_n_streams = 1;           // >1 traces the frame as independent pixel ranges on separate streams (measured slower on ROCm 7.0: 16 -> 28 ms at 2)
+	uint32_t render_max_skips_per_pass = 96; // fused-compaction tracer: empty voxels a ray may step over per pass before it rests until the next one (ngp_hip_generate_next_inputs); 0: no limit, as the reference.  Same image.
+	float render_pass_samples_factor = 3.0f; // fused-compaction tracer: network samples per pass = this x the frame's pixels (the reference: 1); [1, 4].  Same image; 800x800 on MI355X: 1 -> 7.3 ms, 2 -> 5.8, 3 -> 5.4, 4 -> 5.35 (fewer, larger passes: tools/render_probe.py)
 	uint32_t render_max_steps_per_pass = 64; // the reference's m_max_steps_inbetween_compactions is 8 (testbed.h NerfTracer)
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
@@ -561,6 +563,7 @@ private:
 	std::vector<void*> m_render_streams;
 	void* m_render_event = nullptr;
 	void* m_render_host_words = nullptr;
+	uint32_t m_render_sequence = 0;   // NgpCompactOut::sequence of the last tracer pass issued
 	std::vector<DeviceBuffer> m_tr_enc_ws;
 	DeviceBuffer m_render_masks_gpu, m_tr_vis_scratch, m_tr_vis_rgba;
 	DeviceBuffer m_tr_payload[2], m_tr_rgba[2], m_tr_depth[2], m_tr_hit_payload, m_tr_hit_rgba, m_tr_hit_depth, m_tr_net_in, m_tr_net_out, m_tr_counters;

@@ -43,6 +43,7 @@ typedef struct { float pos[3]; float dt; float dir[3]; } NgpCoord;   /* nerf.h:8
 typedef struct {                                                     /* nerf.h:28-36 NerfPayload (40 B) */
 	float origin[3]; float dir[3]; float t; float max_weight; uint32_t idx; uint16_t n_steps; uint8_t alive; uint8_t pad_;
 } NgpPayload;
+#define NGP_RAY_PAUSED 2 /* NgpPayload.alive between ngp_hip_generate_next_inputs (max_skips_per_pass > 0) and ngp_hip_composite; not in the reference */
 typedef struct {                                                     /* nerf_loader.h:30-45 TrainingImageMetadata */
 	const void* pixels;       /* device: RGBA8 (1), half4 (2), float4 (3) — common_device.cuh:621-626 */
 	int32_t image_data_type;
@@ -382,6 +383,10 @@ typedef struct {
 typedef struct {
 	float* dst_rgba; float* dst_depth; NgpPayload* dst_payloads; float* dst_final_rgba; float* dst_final_depth; NgpPayload* dst_final_payloads;
 	uint32_t* counter; uint32_t* final_counter;
+	/* optional (both or neither): the workgroup that finishes last stores {*counter, sequence} to host_mailbox — two words, 8-byte aligned, of host memory the
+	 * device can write (hipHostMalloc, coherent), written with ONE 8-byte store — so the caller can poll for `sequence` in the second word instead of copying
+	 * *counter back behind a stream synchronisation.  blocks_done: a device word, zero before the first call; the kernel leaves it zero. */
+	uint32_t* blocks_done; uint32_t* host_mailbox; uint32_t sequence;
 } NgpCompactOut;
 int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads, const int32_t* res_host, const float* focal_length_host,
                       const float* camera_matrix0_host, const float* camera_matrix1_host, const float* rolling_shutter_host,
@@ -393,13 +398,21 @@ int ngp_hip_init_rays(void* stream, uint32_t sample_index, NgpPayload* payloads,
 /* (the start jitter is keyed by payload.idx, the pixel's index in the whole frame — the reference's ray index i, :625, when the frame is traced at once) */
 int ngp_hip_advance_pos(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const float* render_aabb_to_local_host,
                         uint32_t sample_index, NgpPayload* payloads, const uint8_t* density_grid, uint32_t min_mip, float cone_angle_constant,
-                        const NgpCompactOut* compact_host /* NULL: in place */); /* :612 */
+                        const NgpCompactOut* compact_host /* NULL: in place */,
+                        const uint32_t* brick_summary /* NULL, or what ngp_hip_bitfield_brick_summary wrote for density_grid: empty-space lookups of cascade 0
+                                                         are answered from a copy of it in LDS instead of global memory (same bits, same march) */); /* :612 */
 int ngp_hip_compact_rays(void* stream, uint32_t n_elements, const float* src_rgba, const float* src_depth, const NgpPayload* src_payloads,
                          float* dst_rgba, float* dst_depth, NgpPayload* dst_payloads, float* dst_final_rgba, float* dst_final_depth,
                          NgpPayload* dst_final_payloads, uint32_t* counter, uint32_t* final_counter);                          /* :1784 */
 int ngp_hip_generate_next_inputs(void* stream, uint32_t n_elements, const NgpAabb* render_aabb_host, const NgpAabb* train_aabb_host,
                                  NgpPayload* payloads, NgpCoord* network_input, uint32_t n_steps, const uint8_t* density_grid, uint32_t min_mip,
-                                 float cone_angle_constant);                                                                   /* :705 */
+                                 float cone_angle_constant,
+                                 uint32_t max_skips_per_pass /* 0: as the reference.  > 0: a ray that has stepped over this many empty voxels in one call stops with the
+                                    samples it has (payload.n_steps < n_steps) and payload.alive = NGP_RAY_PAUSED; ngp_hip_composite composites them and keeps the ray
+                                    alive, and the next call resumes the march where it stopped — the ray's samples, and so its pixel, are those of the reference's
+                                    schedule, but a pass no longer lasts as long as its longest walk through empty space.  (Cost mode counts steps per pass: use 0.) */,
+                                 const uint32_t* brick_summary /* as ngp_hip_advance_pos */,
+                                 uint32_t* zero_word /* NULL, or a device word the kernel sets to 0 (the caller's next compaction counter) */); /* :705 */
 /* render_mode = ERenderMode (common.h:80-91): AO 0, Shade 1, Normals 2 (network_input.pos holds d(density output)/d(pos), written there by
  * ngp_hip_nerf_input_gradient: the colour is normalize(-density'(out[3]) * that), :941-946), Positions 3 (show_accel >= 0: the occupancy-cell colouring),
  * Depth 4 (depth_scale = 1 / dataset scale, :2415), Distortion 5 (painted by init_rays), Cost 6 (n_steps / 128, in shade), Slice 7 (shade only),

@@ -218,15 +218,51 @@ def test_fused_compaction_renders_the_same_pixels(trained, mode):
     tb.set_render_shard(0, 1)
     tb.snap_to_pixel_centers = False
     tb.render_mode = getattr(pyngp.RenderMode, mode)
+    skips, factor = tb.nerf.render_max_skips_per_pass, tb.nerf.render_pass_samples_factor
     try:
         tb.nerf.render_fused_compaction = False
         a = tb.render(104, 72, 2, True)
         n_a = tb.render_samples_evaluated
         tb.nerf.render_fused_compaction = True
+        tb.nerf.render_max_skips_per_pass = 0          # the reference's schedule: every ray takes the pass's n_steps, one frame's pixels of samples per pass
+        tb.nerf.render_pass_samples_factor = 1.0
         b = tb.render(104, 72, 2, True)
         assert tb.render_samples_evaluated == n_a
+        tb.nerf.render_max_skips_per_pass, tb.nerf.render_pass_samples_factor = skips, factor
+        c = tb.render(104, 72, 2, True)                # ... and the shipped schedule
     finally:
         tb.render_mode = pyngp.RenderMode.Shade
         tb.nerf.render_fused_compaction = True
+        tb.nerf.render_max_skips_per_pass, tb.nerf.render_pass_samples_factor = skips, factor
     np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    assert np.abs(a[..., :3]).max() > 0
+
+
+@pytest.mark.parametrize("mode", ["Shade", "Depth", "Cost"])
+def test_resting_rays_render_the_same_pixels(trained, mode):
+    """nerf.render_max_skips_per_pass / render_pass_samples_factor: a ray that has stepped over its allowance of empty voxels rests until the next pass (NGP_RAY_PAUSED) instead of holding the
+    pass until it reaches the box boundary.  Every ray still sees its own sample sequence: the frame is identical for any allowance, 1 included (Cost mode counts
+    steps per pass, so the host switches the allowance off there)."""
+    import pyngp
+    ds, tb = trained
+    tb.set_render_shard(0, 1)
+    tb.snap_to_pixel_centers = False
+    tb.render_mode = getattr(pyngp.RenderMode, mode)
+    skips, factor = tb.nerf.render_max_skips_per_pass, tb.nerf.render_pass_samples_factor
+    assert skips > 0 and factor > 1.0  # the shipped defaults rest rays and run fewer, larger passes
+    try:
+        tb.nerf.render_max_skips_per_pass = 0
+        tb.nerf.render_pass_samples_factor = 1.0
+        a = tb.render(104, 72, 2, True)
+        frames = []
+        for allowance, f in ((1, 1.0), (5, 1.0), (24, 1.0), (0, 2.0), (7, 4.0)):
+            tb.nerf.render_max_skips_per_pass = allowance
+            tb.nerf.render_pass_samples_factor = f
+            frames.append(tb.render(104, 72, 2, True))
+    finally:
+        tb.render_mode = pyngp.RenderMode.Shade
+        tb.nerf.render_max_skips_per_pass, tb.nerf.render_pass_samples_factor = skips, factor
+    for b in frames:
+        np.testing.assert_array_equal(a, b)
     assert np.abs(a[..., :3]).max() > 0

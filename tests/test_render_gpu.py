@@ -59,11 +59,19 @@ def _init_and_advance(ngp, oracle, cuda, spp, snap, n_cascades=1, cone=0.0, plan
 
     oracle.orc_advance_pos(n, aabb.ctypes.data, ident.ctypes.data, spp, pay.ctypes.data, bf.ctypes.data, 0, H.f32(cone))
     d_bf = H.to_dev(bf, cuda)
+    d_pay_s = d_pay.clone()
     check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone)))
     g = H.to_host(d_pay, H.PAYLOAD).copy()
     np.testing.assert_array_equal(g["alive"], pay["alive"])
     al = pay["alive"] == 1
     np.testing.assert_array_equal(g["t"][al], pay["t"][al])
+    # ... and with the cascade-0 brick summary staged in LDS: the same march, bit for bit
+    d_sum = H.dev_zeros(1024 * 4, cuda)
+    check(ngp.ngp_hip_bitfield_brick_summary(None, d_bf.data_ptr(), d_sum.data_ptr()))
+    check(ngp.ngp_hip_advance_pos(None, n, aabb.ctypes.data, ident.ctypes.data, spp, d_pay_s.data_ptr(), d_bf.data_ptr(), 0, H.f32(cone), None, d_sum.data_ptr()))
+    gs = H.to_host(d_pay_s, H.PAYLOAD)
+    np.testing.assert_array_equal(gs["alive"], g["alive"])
+    np.testing.assert_array_equal(gs["t"][al], g["t"][al])
     return dict(pay=pay, d_pay=d_pay, bf=bf, d_bf=d_bf, aabb=aabb, cam=cam, focal=focal, res=res, sc=sc, n=n)
 
 
@@ -146,10 +154,11 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
     # ---- next inputs on the ORACLE-ordered compacted rays (upload them so both sides see one order)
     n_steps = 4
     d_pay2 = H.to_dev(o_pay[:n_alive], cuda)
+    pay_before_inputs = o_pay[:n_alive].copy()
     o_in = np.zeros(n_alive * n_steps, H.COORD)
     oracle.orc_generate_next_inputs(n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, o_pay.ctypes.data, o_in.ctypes.data, n_steps, S["bf"].ctypes.data, 0, H.f32(0.0))
     d_in = H.dev_zeros(n_alive * n_steps * 28, cuda)
-    check(ngp.ngp_hip_generate_next_inputs(None, n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, d_pay2.data_ptr(), d_in.data_ptr(), n_steps, S["d_bf"].data_ptr(), 0, H.f32(0.0)))
+    check(ngp.ngp_hip_generate_next_inputs(None, n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, d_pay2.data_ptr(), d_in.data_ptr(), n_steps, S["d_bf"].data_ptr(), 0, H.f32(0.0), 0))
     g_pay2 = H.to_host(d_pay2, H.PAYLOAD)
     np.testing.assert_array_equal(g_pay2["n_steps"], o_pay["n_steps"][:n_alive])
     np.testing.assert_array_equal(g_pay2["t"], o_pay["t"][:n_alive])
@@ -157,6 +166,20 @@ def test_compact_next_inputs_composite(ngp, oracle, cuda):
     for j in range(n_steps):
         m = o_pay["n_steps"][:n_alive] > j
         assert g_in[j * n_alive:(j + 1) * n_alive][m].tobytes() == o_in[j * n_alive:(j + 1) * n_alive][m].tobytes()
+    # ... with the brick summary in LDS and the caller's counter zeroed by the kernel: same samples
+    d_sum = H.dev_zeros(1024 * 4, cuda)
+    check(ngp.ngp_hip_bitfield_brick_summary(None, S["d_bf"].data_ptr(), d_sum.data_ptr()))
+    d_pay3 = H.to_dev(pay_before_inputs, cuda)
+    d_in3 = H.dev_zeros(n_alive * n_steps * 28, cuda)
+    d_word = H.to_dev(np.array([77, 78], np.uint32), cuda)
+    check(ngp.ngp_hip_generate_next_inputs(None, n_alive, S["aabb"].ctypes.data, S["aabb"].ctypes.data, d_pay3.data_ptr(), d_in3.data_ptr(), n_steps, S["d_bf"].data_ptr(), 0, H.f32(0.0), 0,
+                                           d_sum.data_ptr(), d_word.data_ptr()))
+    assert H.to_host(d_pay3, H.PAYLOAD).tobytes() == g_pay2.tobytes()
+    g_in3 = H.to_host(d_in3, H.COORD)
+    for j in range(n_steps):
+        m = o_pay["n_steps"][:n_alive] > j
+        assert g_in3[j * n_alive:(j + 1) * n_alive][m].tobytes() == g_in[j * n_alive:(j + 1) * n_alive][m].tobytes()
+    assert H.to_host(d_word, np.uint32).tolist() == [0, 78]
 
     # ---- composite with random network outputs
     pay_before = o_pay[:n_alive].copy()             # state after next-inputs, before composite
@@ -275,7 +298,7 @@ def test_full_frame_matches_oracle(ngp, oracle, cuda):
         if n_alive == 0:
             break
         n_steps = min(max(n // n_alive, 1), 8)
-        check(ngp.ngp_hip_generate_next_inputs(None, n_alive, aabb.ctypes.data, aabb.ctypes.data, pay[cur].data_ptr(), net_in.data_ptr(), n_steps, d_bf.data_ptr(), 0, H.f32(0.0)))
+        check(ngp.ngp_hip_generate_next_inputs(None, n_alive, aabb.ctypes.data, aabb.ctypes.data, pay[cur].data_ptr(), net_in.data_ptr(), n_steps, d_bf.data_ptr(), 0, H.f32(0.0), 0))
         check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), net_in.data_ptr(), 7, n_alive * n_steps, net_out.data_ptr(), 4))
         check(ngp.ngp_hip_composite(None, n_alive, i, aabb.ctypes.data, cam.ctypes.data, rgba[cur].data_ptr(), dep[cur].data_ptr(), pay[cur].data_ptr(), net_in.data_ptr(),
                                     net_out.data_ptr(), 4, n_steps, 2, 3, H.f32(0.01), 1, H.f32(1.0), -1, None))

@@ -15,13 +15,18 @@ if os.environ.get("NGP_RENDER_STREAMS"):
     tb.nerf.render_n_streams = int(os.environ["NGP_RENDER_STREAMS"])
 if os.environ.get("NGP_RENDER_CAP"):
     tb.nerf.render_max_steps_per_pass = int(os.environ["NGP_RENDER_CAP"])
+if os.environ.get("NGP_RENDER_FACTOR"):
+    tb.nerf.render_pass_samples_factor = float(os.environ["NGP_RENDER_FACTOR"])
+if os.environ.get("NGP_RENDER_SKIPS"):
+    tb.nerf.render_max_skips_per_pass = int(os.environ["NGP_RENDER_SKIPS"])
 tb.render(res, res, 1, True)
 t0 = time.perf_counter()
 for _ in range(n):
     tb.render(res, res, 1, True)
 dt = (time.perf_counter() - t0) / n
 print("psnr %.2f  eval wall per frame %.2f ms" % (psnr, dt * 1e3), per)
-for tile, fused in ((False, False), (True, False), (False, True), (True, True), (False, False), (True, True)):
+variants = ((True, True),) if os.environ.get("NGP_PROBE_PLAIN") else ((False, False), (True, False), (False, True), (True, True), (False, False), (True, True))
+for tile, fused in variants:
     tb.nerf.render_fused_compaction = fused
     tb.nerf.render_tile_order = tile
     tb.render(res, res, 1, True)
@@ -30,3 +35,20 @@ for tile, fused in ((False, False), (True, False), (False, True), (True, True), 
         tb.render(res, res, 1, True)
     dt = (time.perf_counter() - t0) / n
     print("tile_order %s fused_compaction %s: %.2f ms / frame, %d network samples" % (tile, fused, dt * 1e3, tb.render_samples_evaluated))
+
+if os.environ.get("NGP_PROBE_SWEEP"):   # one model, many tracer settings: "factor:skips:cap,..."
+    tb.nerf.render_fused_compaction = True
+    tb.nerf.render_tile_order = True
+    for item in os.environ["NGP_PROBE_SWEEP"].split(","):
+        f, k, c = item.split(":")
+        tb.nerf.render_pass_samples_factor = float(f)
+        tb.nerf.render_max_skips_per_pass = int(k)
+        tb.nerf.render_max_steps_per_pass = int(c)
+        tb.render(res, res, 1, True)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            tb.render(res, res, 1, True)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print("factor %s skips %s cap %s: median %.2f ms  min %.2f ms / frame, %d network samples" % (f, k, c, ts[len(ts) // 2] * 1e3, ts[0] * 1e3, tb.render_samples_evaluated))
