@@ -199,7 +199,7 @@ def cpu_baseline(tb, ds, res, budget_s=12.0):
     scaled to the whole ray batch.  Second leg: the oracle's renderer on a 96 x 96 crop-resolution frame of a test view (MP/s)."""
     import helpers as H
     import fullstep as F
-    orc = H.load_oracle()
+    orc, orc_build = H.load_oracle_native()   # -O3 -march=native for the host this runs on (BASELINE.md §3); contraction off: the results of the portable build
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     tb.shall_train = True
     tb.debug_capture_next_step()
@@ -224,7 +224,8 @@ def cpu_baseline(tb, ds, res, budget_s=12.0):
     out = {"value": kept_full / t_step, "unit": "samples/s", "cores": cores, "kind": "port",
            "sample": "oracle on %d of the %d rays of one captured 2^18-sample step (march %d samples -> inference -> loss/compaction %d samples -> forward/backward), %d x in %.1f s, "
                      "scaled to the whole batch + one Adam/Ema pass over %.1f M parameters (%.2f s)" % (n_rays, R, det["samples"], det["compacted"], det["reps"], det["seconds"], npar / 1e6, t_adam),
-           "stage_seconds": det["stage_seconds"], "cpu_ms_per_step": round(1000.0 * t_step, 1)}
+           "stage_seconds": det["stage_seconds"], "cpu_ms_per_step": round(1000.0 * t_step, 1),
+           "build": "gcc -O3 -march=native -fopenmp -ffp-contract=off (oracle/Makefile `native`, built on this host)" if orc_build == "native" else "gcc -O2 -msse2 -fopenmp (%s)" % orc_build}
     # ---- render leg: orc_render_nerf (the NerfTracer loop of src/testbed_nerf.cu:2140-2267 on the CPU), EMA weights
     try:
         rr = 96
@@ -486,7 +487,7 @@ def main():
             meta = tj.get("_meta", {})
             if meta.get("kernel_set") == KERNEL_SET:
                 traffic = tj.get(dom)
-                traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '%s' on kernel set '%s' (another run of this command on another box)" % (meta.get("tag"), meta.get("kernel_set"))
+                traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '%s' on kernel set '%s' (another run of this command on another box); these count L2->fabric bytes (Infinity-Cache hits included), an upper bound on HBM bytes" % (meta.get("tag"), meta.get("kernel_set"))
             else:
                 traffic_source = "profiles/pmc_traffic.json is from kernel set '%s', this build is '%s': not quoted" % (meta.get("kernel_set"), KERNEL_SET)
         except Exception:

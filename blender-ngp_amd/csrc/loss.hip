@@ -825,19 +825,11 @@ int ngp_hip_decay_grid(void* stream, uint32_t n_elements, float decay, float* gr
 int ngp_hip_compute_cam_gradient(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
-	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host) {
-	return ngp_hip_compute_cam_gradient_ex(stream, n_rays, aabb_host, rng_state, rng_inc, rays_counter, snap_to_pixel_centers, cam_pos_gradient, cam_rot_gradient, n_training_images, metadata,
-	                                       ray_indices_in, rays_in_unnormalized, numsteps_in, coords_compacted, coords_gradient, cdf_host, nullptr, nullptr, nullptr, nullptr);
-}
-
-int ngp_hip_compute_cam_gradient_ex(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
-	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
 	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host,
 	const NgpXForm* xforms, float* distortion_gradient, float* distortion_gradient_weight, const int32_t* distortion_resolution_host) {
 	if (!n_rays || (!cam_pos_gradient && !cam_rot_gradient && !distortion_gradient)) return 0;
 	if (distortion_gradient && (!xforms || !distortion_gradient_weight || !distortion_resolution_host || distortion_resolution_host[0] <= 0 || distortion_resolution_host[1] <= 0)) {
-		set_last_error("ngp_hip_compute_cam_gradient_ex: the distortion gradient needs the training transforms, a weight buffer and a resolution", hipErrorInvalidValue); return -1;
+		set_last_error("ngp_hip_compute_cam_gradient: the distortion gradient needs the training transforms, a weight buffer and a resolution", hipErrorInvalidValue); return -1;
 	}
 	Pcg32 rng; rng.state = rng_state; rng.inc = rng_inc;
 	hipLaunchKernelGGL(compute_cam_gradient_kernel, dim3(div_up(n_rays * CAMGRAD_LANES, 256u)), dim3(256), 0, (hipStream_t)stream, n_rays, aabb_from_host(aabb_host), rng,

@@ -365,90 +365,6 @@ __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const Ng
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Training forward pass that walks RAYS: the reference evaluates the network on every marched sample and only then lets the loss kernel drop what lies
-// behind each ray's termination (transmittance < 1e-4, src/testbed_nerf.cu:1341-1374) — on a trained scene half of the samples.  Here one wave takes a
-// ray (dynamic queue) and walks it in tiles of 32 consecutive samples — the same per-sample arithmetic as nerf_forward_kernel<2>, so evaluated samples
-// are bit-identical — accumulating the ray's transmittance from the tile's density outputs, and stops behind the first tile that ends below
-// `stop_transmittance` (half the loss kernel's threshold: a factor-two margin over the rounding differences between the two evaluations, so every
-// sample the loss kernel keeps has been evaluated).  The outputs of the samples it skips are ZEROED (finite density and colour: the loss kernel's
-// first pass may read them but can never include them, and writes nothing from them); their saved encodings stay unwritten (never read).
-__global__ void __launch_bounds__(256, 2) nerf_forward_rays_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params,
-                                                                   const float* __restrict__ coords, uint32_t coord_stride, const uint32_t* __restrict__ numsteps /* [ray](count, base) */,
-                                                                   const uint32_t* __restrict__ rays_counter, uint32_t max_samples, half_t* __restrict__ out, uint32_t out_stride,
-                                                                   half_t* __restrict__ x_saved, int density_activation, float stop_transmittance, uint32_t* __restrict__ queue) {
-	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_FWD_TILES * 64];
-	stage_weights(lds_tiles, params, 0, N_FWD_TILES);
-	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
-	const uint32_t n_rays = *rays_counter;
-	typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-	// next ray of the queue with at least one sample inside the budget; false when the queue is empty (all wave-uniform)
-	auto pop = [&](uint32_t& n, uint32_t& base) -> bool {
-		while (true) {
-			uint32_t ray = 0;
-			if (lane == 0) ray = atomicAdd(queue, 1u);
-			ray = __builtin_amdgcn_readfirstlane(ray);
-			if (ray >= n_rays) return false;
-			n = __builtin_amdgcn_readfirstlane(numsteps[2 * ray]); base = __builtin_amdgcn_readfirstlane(numsteps[2 * ray + 1]);
-			if (base >= max_samples) continue;
-			if (n > max_samples - base) n = max_samples - base;
-			if (n) return true;
-		}
-	};
-	auto zero_rest = [&](uint32_t base, uint32_t from, uint32_t n) {
-		for (uint32_t k = from + (uint32_t)lane; k < n; k += 64) { const h4 z = {}; *(h4*)(out + (size_t)(base + k) * out_stride) = z; }
-	};
-	// A tile holds the next (up to 32) samples of the current ray and, when the ray ends inside it, the first samples of the next ray of the queue, so that
-	// only the last tile a wave ever builds can be partly empty.
-	uint32_t n0 = 0, b0 = 0, p0 = 0;   // current ray: count, base, samples done
-	float T0 = 1.0f;
-	bool have = pop(n0, b0);
-	while (have) {
-		const uint32_t a = n0 - p0 < 32u ? n0 - p0 : 32u;
-		uint32_t n1 = 0, b1 = 0, c = 0;
-		bool have1 = false;
-		if (a < 32u) { have1 = pop(n1, b1); if (have1) c = n1 < 32u - a ? n1 : 32u - a; }
-		const bool in0 = (uint32_t)j < a, in1 = !in0 && (uint32_t)j < a + c, valid = in0 || in1;
-		const uint32_t s = in0 ? b0 + p0 + (uint32_t)j : in1 ? b1 + ((uint32_t)j - a) : b0 + p0;
-		const float* cp = coords + (size_t)s * coord_stride;
-		h8 x0, x1;
-		encode_half(desc, grid, g, cp[0], cp[1], cp[2], x0, x1);
-		if (valid) {
-			h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g);
-			dst[0] = x0; dst[1] = x1;
-		}
-		const h8 sh = sh4_half(g, cp[4], cp[5], cp[6]);
-		f32x16 dd, oo;
-		uint32_t lt_off = 0;
-		asm volatile("" : "+s"(lt_off));
-		mlp_forward<false, false>(lds_tiles + lt_off, lane, x0, x1, sh, dd, oo, nullptr);
-		const half_t sigma = (half_t)dd[0];
-		if (valid && g == 0) {
-			h4 o; o[0] = (half_t)oo[0]; o[1] = (half_t)oo[1]; o[2] = (half_t)oo[2]; o[3] = sigma;
-			*(h4*)(out + (size_t)s * out_stride) = o;
-		}
-		// transmittance behind the tile, per ray segment: product of (1 - alpha) over its samples (lanes 0..31 hold the density outputs), alpha as the loss kernel forms it
-		float keep = 1.0f;
-		if (valid && g == 0) keep = 1.0f - (1.0f - __expf(-network_to_density((float)sigma, density_activation) * unwarp_dt(cp[3])));
-		float k0 = in0 ? keep : 1.0f, k1 = in1 ? keep : 1.0f;
-#pragma unroll
-		for (int off = 16; off > 0; off >>= 1) { k0 *= __shfl_xor(k0, off, 64); k1 *= __shfl_xor(k1, off, 64); }
-		T0 *= __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k0)));
-		p0 += a;
-		if (a == 32u && p0 < n0 && !(T0 < stop_transmittance)) continue;   // the ray goes on alone in the next tile
-		if (p0 < n0) zero_rest(b0, p0, n0);                                 // terminated: what is left of it is skipped
-		// the next ray becomes the current one (its first c samples are done); one that is already through, or terminated, is finished on the spot
-		have = have1; n0 = n1; b0 = b1; p0 = c;
-		T0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, k1)));
-		if (a == 32u) { have = pop(n0, b0); p0 = 0; T0 = 1.0f; }
-		while (have && (p0 >= n0 || T0 < stop_transmittance)) {
-			if (p0 < n0) zero_rest(b0, p0, n0);
-			have = pop(n0, b0); p0 = 0; T0 = 1.0f;
-		}
-	}
-}
-
-// ----------------------------------------------------------------------------------------------------------------
 // XCD-affine hash encode.  The 11 hashed levels are 2 MiB each (22 MiB together), the L2 of one XCD is 4 MiB: in the fused
 // kernel every XCD touches every level and 60 % of the L2 requests miss (rocprof: TCC_MISS / TCC_REQ), i.e. go over the
 // fabric, whose random-64-B-request rate (~75 G/s chip-wide, tools/gather_probe.hip) is 3.6x below the L2-hit rate (~270 G/s).
@@ -2005,20 +1921,6 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	return 0;
 }
 
-int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, const uint32_t* numsteps,
-                              const uint32_t* rays_counter, uint32_t n_rays_max, uint32_t max_samples, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, int density_activation,
-                              float stop_transmittance, uint32_t* queue_counter) {
-	if (!n_rays_max || !max_samples) return 0;
-	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward_rays: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	if (!x_saved || !queue_counter || !numsteps || !rays_counter) { set_last_error("ngp_hip_nerf_forward_rays: x_saved, numsteps, rays_counter and queue_counter are required", hipErrorInvalidValue); return -1; }
-	// one wave per ray at a time: no more workgroups than rays / 4, at most what the chip holds (2 workgroups of 4 waves per CU at this register count)
-	static const uint32_t cap_env = getenv("NGP_HIP_FWD_RAYS_CAP") ? (uint32_t)atoi(getenv("NGP_HIP_FWD_RAYS_CAP")) : 0u;   // dev-only
-	const uint32_t cap = cap_env ? cap_env : 384 /* sweep 256 / 384 / 512 / 768: 173 / 166 / 177 / 178 us */, want = div_up(n_rays_max, 4);
-	hipLaunchKernelGGL(nerf_forward_rays_kernel, dim3(want < cap ? want : cap), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, numsteps,
-	                   rays_counter, max_samples, (half_t*)out, out_stride, (half_t*)x_saved, density_activation, stop_transmittance, queue_counter);
-	NGP_LAUNCH_CHECK("nerf_forward_rays_kernel");
-	return 0;
-}
 
 // ---- two-kernel variants: XCD-affine encode into level planes (workspace), then the MLP kernel
 uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n) { return ENC_QUEUE_BYTES + (uint64_t)16 * next_multiple_u32(n, ENC_CHUNK) * 4u; }
@@ -2377,13 +2279,6 @@ int ngp_hip_f32_to_f16(void* stream, uint32_t n, const float* src, uint16_t* dst
 }
 
 int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
-                           float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
-                           float* first_moments, float* second_moments, float* ema, uint16_t* inference_params) {
-	return ngp_hip_optimizer_step_masked(stream, n_params, n_matrix_params, step, learning_rate, beta1, beta2, epsilon, l2_reg, loss_scale, ema_decay, grads, master, params,
-	                                     first_moments, second_moments, ema, inference_params, 3u);
-}
-
-int ngp_hip_optimizer_step_masked(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
                                   float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
                                   float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask) {
 	const float lr = learning_rate * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));

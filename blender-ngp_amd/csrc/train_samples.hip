@@ -701,20 +701,8 @@ extern "C" int ngp_hip_generate_training_samples(
 	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
-	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary) {
-	return generate_training_samples_impl(stream, n_rays, aabb_host, max_samples, rng_state, rng_inc, ray_counter, numsteps_counter, ray_indices_out, rays_out_unnormalized, numsteps_out,
-	                                      coords_out, n_training_images, metadata, xforms, density_grid, max_level_rand_training, max_level_ptr, snap_to_pixel_centers, train_envmap,
-	                                      cone_angle_constant, distortion_data, distortion_resolution_host, ray_offset, n_rays_global, cdf_host, brick_summary, NGP_MARCH_AUTO);
-}
-
-extern "C" int ngp_hip_generate_training_samples_mode(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
-	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
-	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
-	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
-	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
 	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode) {
-	if (march_mode > NGP_MARCH_WAVE_PER_RAY_SHARED) { set_last_error("ngp_hip_generate_training_samples_mode: unknown march_mode", hipErrorInvalidValue); return -1; }
+	if (march_mode > NGP_MARCH_WAVE_PER_RAY_SHARED) { set_last_error("ngp_hip_generate_training_samples: unknown march_mode", hipErrorInvalidValue); return -1; }
 	return generate_training_samples_impl(stream, n_rays, aabb_host, max_samples, rng_state, rng_inc, ray_counter, numsteps_counter, ray_indices_out, rays_out_unnormalized, numsteps_out,
 	                                      coords_out, n_training_images, metadata, xforms, density_grid, max_level_rand_training, max_level_ptr, snap_to_pixel_centers, train_envmap,
 	                                      cone_angle_constant, distortion_data, distortion_resolution_host, ray_offset, n_rays_global, cdf_host, brick_summary, march_mode);

@@ -723,7 +723,6 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("set_distortion_map", [](Testbed& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
 				if ((size_t)a.size() != t.m_distortion.n_params()) throw std::runtime_error{"set_distortion_map: expected resolution[1] x resolution[0] x 2 floats"};
 				t.sync(); t.m_distortion.set_params(a.data(), (size_t)a.size()); t.invalidate_training_inputs(); }, py::arg("map"))
-		.def_readwrite("forward_walks_rays", &Testbed::m_forward_walks_rays)   // extension, experimental
 		.def_property("quilting_dims", [](Testbed& t) { return std::vector<int>{t.m_quilting_dims[0], t.m_quilting_dims[1]}; },   // testbed.h:549 (GUI-only in the reference)
 			[](Testbed& t, const std::vector<int>& v) { if (v.size() != 2 || v[0] < 1 || v[1] < 1) throw std::runtime_error{"quilting_dims: two positive integers"}; t.m_quilting_dims[0] = v[0]; t.m_quilting_dims[1] = v[1]; })
 		.def("set_camera_to_training_view", &Testbed::set_camera_to_training_view, py::arg("trainview"))

@@ -1005,7 +1005,7 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	// run ahead on stream B the march shares the chip with the backward pass: the wave-per-ray kernel on two workgroups per CU (more of it costs the
 	// backward pass more than it gains the march).  In stream order (first steps, the step after every occupancy update, a discarded prefetch)
 	// nothing runs beside it: all workgroups at once.  With cone stepping the library runs its lane-per-ray kernels whatever the mode
-	check(ngp_hip_generate_training_samples_mode(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
+	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, tr.train_envmap,
 	                                        m_nerf.cone_angle_constant, m_distortion.params.as<float>() /* map->params(), 3241 */, dist_res, ray_offset, n_rays_global, tr.error_map_cdf(cdf_storage),
@@ -1128,14 +1128,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	// pass over the compacted batch (3330) — its only product that backward consumes is that encoding (ngp_hip.h "Forward pass").
 	m_x_all.enlarge((size_t)max_inference * 32 * 2);
 	profile_begin(PK_INFERENCE);
-	// The reference evaluates every marched sample (3256) and lets the loss kernel drop what lies behind each ray's termination.  m_forward_walks_rays: the pass walks the
-	// rays instead and stops behind the 32-sample tile in which a ray's transmittance fell below half the loss kernel's threshold — the kept samples get the same
-	// bits, the others (half of the batch on a trained scene) are never gathered (ngp_hip_nerf_forward_rays).
-	static const int fwd_rays_env = getenv("NGP_HIP_FWD_RAYS") ? atoi(getenv("NGP_HIP_FWD_RAYS")) : -1;   // dev: A / B (1 on, 0 off)
-	if (fwd_rays_env >= 0 ? fwd_rays_env != 0 : m_forward_walks_rays) {
-		check(ngp_hip_nerf_forward_rays(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, m_numsteps.as<uint32_t>(), gen_counters + 0, R, max_inference, m_mlp_out.as<uint16_t>(),
-		                                OUT_STRIDE, m_x_all.as<uint16_t>(), (int)m_nerf.density_activation, getenv("NGP_HIP_FWD_STOP") ? (float)atof(getenv("NGP_HIP_FWD_STOP")) : 0.5f * 1e-4f /* half of EPSILON (testbed_nerf.cu:1345) */, gen_counters + 3), "nerf_forward_rays");
-	} else {
+	{
 		static const bool fwd_ws = getenv("NGP_HIP_FWD_WS") != nullptr;   // dev: the two-kernel pass (encode into level planes, then the MLP kernel) instead of the fused one
 		NgpNetVariant nv;
 		const NgpNetVariant* variant = nullptr;
@@ -1278,7 +1271,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), nullptr), "nerf_backward (with input gradient)");
 		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
 		profile_end(PK_BACKWARD, target_batch_size);
-		check(ngp_hip_compute_cam_gradient_ex(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
+		check(ngp_hip_compute_cam_gradient(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
 		                                      tr.optimize_extrinsics ? tr.cam_pos_gradient_gpu.as<float>() : nullptr, tr.optimize_extrinsics ? tr.cam_rot_gradient_gpu.as<float>() : nullptr,
 		                                      (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(), m_cam_ray_indices.as<uint32_t>(),
 		                                      m_cam_rays.as<NgpRay>(), (const uint32_t*)((const char*)m_cam_rays.data() + (size_t)R * sizeof(NgpRay)), m_coords_compacted.as<NgpCoord>(),
@@ -1382,14 +1375,14 @@ void Testbed::optimizer_step_sharded() {
 	check(ngp_hip_f32_to_f16(m_stream, shard, m_dp_shard_f32.as<float>(), m_grads.as<uint16_t>() + off), "f32_to_f16 (gradient shard)");
 	profile_end(PK_GRAD_EXCHANGE, m_n_params);
 	profile_begin(PK_OPTIMIZER);
-	if (mine) check(ngp_hip_optimizer_step_masked(m_stream, mine, m_n_matrix_params > off ? m_n_matrix_params - off : 0u, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	if (mine) check(ngp_hip_optimizer_step(m_stream, mine, m_n_matrix_params > off ? m_n_matrix_params - off : 0u, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
 	                                              ema_decay, m_grads.as<uint16_t>() + off, m_master.as<float>() + off, m_params.as<uint16_t>() + off, m_first_moments.as<float>() + off,
 	                                              m_second_moments.as<float>() + off, nullptr, nullptr, mask | NGP_OPT_NO_EMA), "optimizer_step (Adam, this rank's shard)");
 	profile_end(PK_OPTIMIZER, mine);
 	profile_begin(PK_PARAM_GATHER);
 	check(ngp_rccl_allgather_f16(m_dp_comm, m_stream, m_params.as<uint16_t>(), shard), "ngp_rccl_allgather_f16 (weights)");
 	profile_end(PK_PARAM_GATHER, m_n_params);
-	check(ngp_hip_optimizer_step_masked(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
+	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
 	                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema, all parameters)");
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
 		m_learning_rate *= m_decay_base;
@@ -1400,7 +1393,7 @@ void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE)
 	if (m_dp_comm && m_dp_sharded_optimizer) { optimizer_step_sharded(); return; }
 	++m_optimizer_step;
 	profile_begin(PK_OPTIMIZER);
-	check(ngp_hip_optimizer_step_masked(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
+	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
 	                                    m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
 	                                    m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>(), (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u)), "optimizer_step");
 	profile_end(PK_OPTIMIZER, m_n_params);

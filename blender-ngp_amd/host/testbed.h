@@ -385,7 +385,6 @@ public:
 	void bl_wait_for_renders();
 	std::mutex m_render_mutex; std::condition_variable m_render_cv; int m_render_workers = 0;
 	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
-	bool m_forward_walks_rays = false;                 // experimental: the pre-compaction network pass walks the rays and stops behind each one's termination (ngp_hip_nerf_forward_rays)
 	                                                   // instead of evaluating every marched sample; same kept samples, measured at par with the flat pass (its tiles pack worse), so off
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well

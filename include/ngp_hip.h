@@ -126,16 +126,6 @@ int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_
  * encoded features x_saved [n][32] fp16 that backward consumes (the tcnn ForwardContext). */
 int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                          uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, const NgpNetVariant* variant);
-/* The training step's pre-compaction network pass (src/testbed_nerf.cu:3256) restricted to what the loss kernel can keep.  The reference evaluates every marched
- * sample and lets compute_loss_kernel_train_nerf stop at the first sample whose transmittance fell below 1e-4 (:1341-1374); this entry point walks each ray
- * (numsteps: the ray generator's (count, base) pairs, *rays_counter of them) in tiles of 32 consecutive samples, multiplies the tile's (1 - alpha) — alpha from the
- * density output and the sample's dt exactly as the loss kernel forms it — into the ray's transmittance and stops behind the first tile that ends below
- * stop_transmittance (pass half the loss kernel's threshold).  Evaluated samples get the same bits as ngp_hip_nerf_forward (out, x_saved); the outputs of skipped
- * samples are zeroed (finite, and behind the termination: the loss kernel cannot include them), their x_saved rows are left unwritten.  queue_counter: one device
- * word, zero at launch (the ray queue); samples at or beyond max_samples are ignored. */
-int ngp_hip_nerf_forward_rays(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats, const uint32_t* numsteps,
-                              const uint32_t* rays_counter, uint32_t n_rays_max, uint32_t max_samples, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, int density_activation,
-                              float stop_transmittance, uint32_t* queue_counter);
 /* Two-kernel variants of the three forward passes above (same results, bit for bit): an XCD-affine hash-encode kernel writes the
  * 32 features of every sample into level planes inside `workspace` (each XCD of the MI355X walks at most two 2-MiB level tables,
  * so its 4-MiB L2 holds them), then the MLP kernel reads the planes.  Faster whenever n is large enough to fill the chip
@@ -182,15 +172,12 @@ int ngp_hip_extra_dims_gradient(void* stream, uint32_t n_rays_capacity, const ui
 
 /* Trainer::optimizer_step(stream, loss_scale) (src/testbed_nerf.cu:2950) with Ema{decay} o ExponentialDecay o Adam as configured by
  * configs/nerf/base.json:5-22.  `step` = 1-based optimizer step; `learning_rate` = base lr after ExponentialDecay (host applies it). */
-int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
-                           float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
-                           float* first_moments, float* second_moments, float* ema, uint16_t* inference_params);
-/* The same step with tcnn Adam's `optimize_matrix_params` (bit 0 of optimize_mask: the MLP weights) and `optimize_non_matrix_params` (bit 1: the
+/* optimize_mask: tcnn Adam's `optimize_matrix_params` (bit 0: the MLP weights) and `optimize_non_matrix_params` (bit 1: the
  * encoding) switches — what Testbed::train sets from `shall_train_network` / `shall_train_encoding` every step (src/testbed.cu:2556-2563).  A
  * parameter class that is switched off keeps its weights and moments; the Ema copy is updated for every parameter either way. */
-int ngp_hip_optimizer_step_masked(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
-                                  float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
-                                  float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask);
+int ngp_hip_optimizer_step(void* stream, uint32_t n_params, uint32_t n_matrix_params, uint32_t step, float learning_rate, float beta1, float beta2,
+                           float epsilon, float l2_reg, float loss_scale, float ema_decay, const uint16_t* grads, float* master, uint16_t* params,
+                           float* first_moments, float* second_moments, float* ema, uint16_t* inference_params, uint32_t optimize_mask /* 3: the whole step */);
 /* Two more bits of optimize_mask split the step into its stages, for the SHARDED optimizer step of the data-parallel path: a rank runs the Adam stage
  * on its 1 / world of the parameters (pointers advanced to the shard, n_matrix_params counted from there), the fp16 weights are all-gathered, and the Ema stage — which
  * reads the fp16 weights only — runs over all parameters on every rank.  Element-wise the same arithmetic as the unsplit step, bit for bit. */
@@ -221,6 +208,14 @@ int ngp_hip_bitfield_brick_summary(void* stream, const uint8_t* bitfield, uint32
 /* ============================ training rays (src/testbed_nerf.cu:1085-1260) ============================ */
 /* generate_training_samples_nerf.  ray_offset / n_rays_global are the data-parallel extension: thread i marches global ray
  * ray_offset+i out of n_rays_global (image choice, rng stream); pass (0, n_rays) for the reference's single-GPU behaviour. */
+/* march_mode: the marching kernel (same rays, same samples, bit for bit; slot order aside):
+ *   NGP_MARCH_AUTO          wave-per-ray whenever cone_angle_constant == 0
+ *   NGP_MARCH_LANE_PER_RAY  one lane per ray + a wave-per-ray expansion kernel: a latency-bound serial chain (~330 us at 2^14 rays) that costs
+ *                           few issue slots; the only kernels for cone stepping (cone_angle_constant != 0)
+ *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once on the closed-form step sequence (cone_angle_constant == 0 only, otherwise
+ *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order
+ *   NGP_MARCH_WAVE_PER_RAY_SHARED  the same kernel on two persistent workgroups per CU (~220 us): the one to run NEXT TO the backward pass */
+enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2, NGP_MARCH_WAVE_PER_RAY_SHARED = 3 };
 int ngp_hip_generate_training_samples(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
 	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
@@ -228,22 +223,7 @@ int ngp_hip_generate_training_samples(
 	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
 	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
 	const NgpErrorMapCdf* cdf_host /* NULL: uniform image / pixel choice */,
-	const uint32_t* brick_summary /* NULL, or what ngp_hip_bitfield_brick_summary wrote for density_grid (same samples either way) */);
-/* The same call with the marching kernel chosen by the caller (same rays, same samples, bit for bit; slot order aside):
- *   NGP_MARCH_AUTO          what ngp_hip_generate_training_samples does: wave-per-ray whenever cone_angle_constant == 0
- *   NGP_MARCH_LANE_PER_RAY  one lane per ray + a wave-per-ray expansion kernel: a latency-bound serial chain (~330 us at 2^14 rays) that costs
- *                           few issue slots; the only kernels for cone stepping (cone_angle_constant != 0)
- *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once on the closed-form step sequence (cone_angle_constant == 0 only, otherwise
- *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order
- *   NGP_MARCH_WAVE_PER_RAY_SHARED  the same kernel on two persistent workgroups per CU (~220 us): the one to run NEXT TO the backward pass */
-enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2, NGP_MARCH_WAVE_PER_RAY_SHARED = 3 };
-int ngp_hip_generate_training_samples_mode(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,
-	uint32_t* ray_counter, uint32_t* numsteps_counter, uint32_t* ray_indices_out, NgpRay* rays_out_unnormalized, uint32_t* numsteps_out,
-	NgpCoord* coords_out, uint32_t n_training_images, const NgpImageMeta* metadata, const NgpXForm* xforms, const uint8_t* density_grid,
-	int max_level_rand_training, float* max_level_ptr, int snap_to_pixel_centers, int train_envmap, float cone_angle_constant,
-	const float* distortion_data, const int32_t* distortion_resolution_host, uint32_t ray_offset, uint32_t n_rays_global,
-	const NgpErrorMapCdf* cdf_host, const uint32_t* brick_summary, uint32_t march_mode);
+	const uint32_t* brick_summary /* NULL, or what ngp_hip_bitfield_brick_summary wrote for density_grid (same samples either way) */, uint32_t march_mode);
 
 /* ============================ load-time image sharpening (src/nerf_loader.cu:102-123, 803-825) ============================
  * NerfDataset::set_training_image with sharpen_amount > 0: Byte images first become premultiplied linear half4 (from_rgba32<__half>,
@@ -299,19 +279,14 @@ int ngp_hip_compute_loss(
  * (coords_gradient: [sample][6] fp32 as ngp_hip_nerf_backward writes its dL_dinput; numsteps_in holds the compacted (count, base) pairs ngp_hip_compute_loss left) is
  * folded into a ray-origin and a ray-direction gradient and added (atomicAdd; the caller clears them every n_steps_between_cam_updates, :2916-2918) to
  * cam_pos_gradient[img] and, as the angle-axis ray.d x grad_d, to cam_rot_gradient[img] ([n_images][3] floats each; either may be NULL), both divided by the pixel
- * pdf of the ray's draw.  rng / cdf_host must be what ngp_hip_compute_loss got.  The lens-distortion branch (:1671-1683) is out of scope; the reference kernel
- * takes a cam_focal_length_gradient pointer and never writes it. */
-int ngp_hip_compute_cam_gradient(
-	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
-	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
-	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host);
+ * pdf of the ray's draw.  rng / cdf_host must be what ngp_hip_compute_loss got.  The reference kernel takes a cam_focal_length_gradient pointer and never writes it.
 /* compute_sharpness (src/nerf_loader.cu:129-169): sharpness_out[y][x] = variance of the Laplacian of the luma over tile (x, y) of a sharpness_res grid laid over the image */
 int ngp_hip_compute_sharpness(void* stream, const int32_t* sharpness_res_host, const int32_t* image_res_host, const void* pixels, int image_data_type, float* sharpness_out);
 int ngp_hip_decay_grid(void* stream, uint32_t n_elements, float decay, float* grid);   /* decay_sharpness_grid_nerf (:557-561) */
-/* compute_cam_gradient_train_nerf with its lens-distortion branch (:1671-1685): the ray-direction gradient minus its component along the ray, rotated by
+/* The lens-distortion branch (:1671-1685; xforms .. distortion_resolution_host, all NULL: off): the ray-direction gradient minus its component along the ray, rotated by
  * the inverse of the image's camera rotation (xforms[img].start), is splatted (x, y; divided by the pixel pdf) into distortion_gradient at the ray's pixel and
  * the bilinear weights into distortion_gradient_weight (both fp32 [h][w][2], atomicAdd; the caller clears them every n_steps_between_cam_updates, :2919-2920). */
-int ngp_hip_compute_cam_gradient_ex(
+int ngp_hip_compute_cam_gradient(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint64_t rng_state, uint64_t rng_inc, const uint32_t* rays_counter, int snap_to_pixel_centers,
 	float* cam_pos_gradient, float* cam_rot_gradient, uint32_t n_training_images, const NgpImageMeta* metadata, const uint32_t* ray_indices_in,
 	const NgpRay* rays_in_unnormalized, const uint32_t* numsteps_in, const NgpCoord* coords_compacted, const float* coords_gradient, const NgpErrorMapCdf* cdf_host,

@@ -18,6 +18,18 @@ def load_oracle():
     return _oracle
 
 
+def load_oracle_native():
+    """The oracle built -O3 -march=native ON THIS MACHINE (bench.py's cpu_baseline leg; `make -C oracle native` into a temporary directory, so a library built for
+    another host's CPU is never picked up).  Returns (library, "native") or, when the compiler is missing or fails, (the portable build, "portable: <why>")."""
+    import subprocess, tempfile
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="ngp_oracle_native_"), "libngp_oracle_native.so")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native", "NATIVE_OUT=" + out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return capi.CLib(out, os.path.join(ROOT, "oracle", "ngp_oracle.h"), "orc_"), "native"
+    except Exception as e:   # noqa: BLE001 - any build problem falls back to the checked-in recipe's portable library
+        return load_oracle(), "portable: %s" % type(e).__name__
+
+
 def f32(x):
     return ctypes.c_float(float(x))
 

@@ -158,7 +158,7 @@ def test_sharded_optimizer_stages_equal_the_whole_step_bit_for_bit(ngp, cuda, n,
     args = (H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95))
     step = 11
     whole = [H.to_dev(a, cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
-    check(ngp.ngp_hip_optimizer_step(None, n, min(nm, n), step, *args, *[t.data_ptr() for t in whole]))
+    check(ngp.ngp_hip_optimizer_step(None, n, min(nm, n), step, *args, *[t.data_ptr() for t in whole], 3))
     parts = [H.to_dev(a, cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
     size = [2, 4, 2, 4, 4, 4, 2]
     shard = ((n + world - 1) // world + 7) // 8 * 8
@@ -167,8 +167,8 @@ def test_sharded_optimizer_stages_equal_the_whole_step_bit_for_bit(ngp, cuda, n,
         mine = min(shard, n - off) if off < n else 0
         if mine:
             p = [t.data_ptr() + off * sz for t, sz in zip(parts, size)]
-            check(ngp.ngp_hip_optimizer_step_masked(None, mine, max(min(nm, n) - off, 0), step, *args, p[0], p[1], p[2], p[3], p[4], None, None, 3 | 4))
-    check(ngp.ngp_hip_optimizer_step_masked(None, n, min(nm, n), step, *args, None, None, parts[2].data_ptr(), None, None, parts[5].data_ptr(), parts[6].data_ptr(), 8))
+            check(ngp.ngp_hip_optimizer_step(None, mine, max(min(nm, n) - off, 0), step, *args, p[0], p[1], p[2], p[3], p[4], None, None, 3 | 4))
+    check(ngp.ngp_hip_optimizer_step(None, n, min(nm, n), step, *args, None, None, parts[2].data_ptr(), None, None, parts[5].data_ptr(), parts[6].data_ptr(), 8))
     torch.cuda.synchronize()
     for name, a, b in zip(("grads", "master", "params", "m1", "m2", "ema", "inference"), whole, parts):
         assert torch.equal(a, b), name

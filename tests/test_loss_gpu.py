@@ -461,7 +461,7 @@ def test_cam_gradient_distortion_branch(ngp, oracle, cuda):
     d_g, d_w = H.dev_zeros(ref_g.nbytes, cuda), H.dev_zeros(ref_w.nbytes, cuda)
     d_rc = H.to_dev(np.array([n_alive], np.uint32), cuda)
     d_md, d_idx, d_rays, d_ns, d_co, d_cg, d_xf = (H.to_dev(a, cuda) for a in (I["md_dev"], I["r"]["idx"], I["r"]["rays"], o["ns"], o["co"], cg, I["xf"]))
-    check(ngp.ngp_hip_compute_cam_gradient_ex(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
+    check(ngp.ngp_hip_compute_cam_gradient(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
                                               d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), None, d_xf.data_ptr(), d_g.data_ptr(), d_w.data_ptr(), dres.ctypes.data))
     got_g, got_w = H.to_host(d_g, np.float32).reshape(ref_g.shape), H.to_host(d_w, np.float32).reshape(ref_w.shape)
     assert ref_w.min() >= 0 and ref_w.sum() > 100 and np.abs(ref_g).max() > 0
@@ -476,7 +476,7 @@ def test_cam_gradient_distortion_branch(ngp, oracle, cuda):
     np.testing.assert_array_equal(H.to_host(d_div, np.float32), ref_div)
     assert (ref_div[::7] == 0).all()
     # the distortion outputs need the transforms and the weight buffer
-    assert ngp.ngp_hip_compute_cam_gradient_ex(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
+    assert ngp.ngp_hip_compute_cam_gradient(None, n_rays, I["aabb"].ctypes.data, I["st"], I["inc"], d_rc.data_ptr(), 0, None, None, n_img, d_md.data_ptr(), d_idx.data_ptr(), d_rays.data_ptr(),
                                                d_ns.data_ptr(), d_co.data_ptr(), d_cg.data_ptr(), None, None, d_g.data_ptr(), d_w.data_ptr(), dres.ctypes.data) != 0
 
 

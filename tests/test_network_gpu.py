@@ -257,7 +257,7 @@ def test_optimizer_step_bit_exact(ngp, oracle, cuda, n, nm, off):
     d_all = [H.to_dev(np.concatenate([np.zeros(off, a.dtype), a]), cuda) for a in (grads, master, p16, m1, m2, ema, inf)]
     ptr = [t.data_ptr() + off * a.dtype.itemsize for t, a in zip(d_all, (grads, master, p16, m1, m2, ema, inf))]
     step = 7
-    check(ngp.ngp_hip_optimizer_step(None, n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95), *ptr))
+    check(ngp.ngp_hip_optimizer_step(None, n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95), *ptr, 3))
     d = [None] + [H.to_host(t, a.dtype)[off:] for t, a in zip(d_all[1:], (master, p16, m1, m2, ema, inf))]
     oracle.orc_adam_ema_step(n, nm, step, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95),
                              grads.ctypes.data, master.ctypes.data, p16.ctypes.data, m1.ctypes.data, m2.ctypes.data, ema.ctypes.data, inf.ctypes.data)
@@ -300,95 +300,3 @@ def test_ws_rejects_small_workspace(ngp, cuda):
     out = H.dev_zeros(2048 * 8, cuda)
     assert ngp.ngp_hip_nerf_inference_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, 2048, out.data_ptr(), 4, ws.data_ptr(), 1024) != 0
     assert b"workspace" in ngp.ngp_hip_last_error()
-
-
-def test_forward_rays_evaluates_what_the_loss_kernel_can_keep(ngp, cuda):
-    """ngp_hip_nerf_forward_rays (experimental pre-compaction pass): per ray, tiles of 32 consecutive samples (the head of a ray may share a tile with the tail of the previous one) until the ray's transmittance falls below stop_transmittance.
-    Evaluated samples carry the bits of ngp_hip_nerf_forward (outputs and saved encodings), skipped ones are zero; every sample in front of a ray's
-    termination at the loss kernel's threshold (twice the stop value) is evaluated."""
-    desc = H.make_desc(ngp, log2_hashmap_size=15)
-    params = H.random_params(desc, seed=4)
-    rs = np.random.RandomState(12)
-    n_rays = 700
-    counts = rs.choice([1, 5, 31, 32, 33, 64, 100, 257, 400], n_rays).astype(np.uint32)
-    counts[rs.rand(n_rays) < 0.05] = 0
-    base = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint32)
-    n = int(counts.sum())
-    order = rs.permutation(n_rays)                                   # slot order is scheduling dependent in the march: the ray list is not sorted by base
-    numsteps = np.stack([counts[order], base[order]], 1).reshape(-1).astype(np.uint32)
-    coords = H.random_coords(n, seed=6)
-    coords["dt"] = 0.0                                               # aabb_scale 1: constant step
-    d_desc, d_p, d_c = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(coords, cuda)
-    ref_out, ref_x = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda)
-    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_p.data_ptr(), d_c.data_ptr(), 7, n, ref_out.data_ptr(), 4, ref_x.data_ptr()))
-    ref_out_h = H.to_host(ref_out, np.uint16).reshape(n, 4).copy()
-    # random weights give little density: shift the logits so that rays terminate at different depths (the shift goes into the reference too)
-    sig = ref_out_h[:, 3].view(np.float16).astype(np.float32)
-    d_ns, d_rc = H.to_dev(numsteps, cuda), H.to_dev(np.array([n_rays], np.uint32), cuda)
-    got_out, got_x, d_q = H.to_dev(np.full((n, 4), 0x7e00, np.uint16), cuda), H.to_dev(np.full((n, 32), 0x7e00, np.uint16), cuda), H.dev_zeros(4, cuda)
-    MIN_STEP = np.float32(1.73205080757 / 1024)
-    # pick the threshold so that a good part of the rays terminates early with these densities: T after k samples = exp(-sum exp(sigma) * dt)
-    od = np.exp(sig.astype(np.float64)) * float(MIN_STEP)
-    stop = float(np.exp(-np.median([od[b:b + c].sum() for c, b in zip(counts, base) if c >= 64]) * 0.4))
-    check(ngp.ngp_hip_nerf_forward_rays(None, d_desc.data_ptr(), d_p.data_ptr(), d_c.data_ptr(), 7, d_ns.data_ptr(), d_rc.data_ptr(), n_rays, n, got_out.data_ptr(), 4, got_x.data_ptr(), 3,
-                                        H.f32(stop), d_q.data_ptr()))
-    out, x, ref_x_h = H.to_host(got_out, np.uint16).reshape(n, 4), H.to_host(got_x, np.uint16).reshape(n, 32), H.to_host(ref_x, np.uint16).reshape(n, 32)
-    assert int(H.to_host(d_q, np.uint32)[0]) >= n_rays                # every ray was taken from the queue
-    n_eval = n_skip = 0
-    for c, b in zip(counts, base):
-        c, b = int(c), int(b)
-        if c == 0:
-            continue
-        T = np.cumprod(np.exp(-od[b:b + c]))                          # transmittance BEHIND each sample (float64)
-        zero = (out[b:b + c] == 0).all(axis=1)
-        k = int(np.argmax(zero)) if zero.any() else c                 # first skipped sample
-        assert zero[k:].all() and not zero[:k].any()
-        np.testing.assert_array_equal(out[b:b + k], ref_out_h[b:b + k])
-        np.testing.assert_array_equal(x[b:b + k], ref_x_h[b:b + k])
-        assert (x[b + k:b + c] == 0x7e00).all()                       # skipped rows are not written
-        if k < c:
-            assert T[k - 1] < stop * 1.001                            # it only stops behind a tile that ends below the threshold ...
-            if k > 32:
-                assert T[k - 33] >= stop * 0.999                      # ... and at the first such tile (a ray's first segment may share its tile with the tail of another ray)
-        # everything the loss kernel could keep at 2 x stop is there: samples whose transmittance IN FRONT of them is >= 2 * stop
-        in_front = np.concatenate([[1.0], T[:-1]])
-        assert not zero[in_front >= 2 * stop].any()
-        n_eval += k; n_skip += c - k
-    assert n_skip > 0.15 * n and n_eval > 0.15 * n
-    # samples beyond max_samples are ignored (the march's overflow case)
-    d_q2 = H.dev_zeros(4, cuda)
-    check(ngp.ngp_hip_nerf_forward_rays(None, d_desc.data_ptr(), d_p.data_ptr(), d_c.data_ptr(), 7, d_ns.data_ptr(), d_rc.data_ptr(), n_rays, n // 2, got_out.data_ptr(), 4, got_x.data_ptr(), 3,
-                                        H.f32(-1.0), d_q2.data_ptr()))
-    np.testing.assert_array_equal(H.to_host(got_out, np.uint16).reshape(n, 4)[: n // 2], ref_out_h[: n // 2])   # stop < 0: never stops, i.e. the flat pass
-
-
-def test_loss_kernel_sees_the_same_step_behind_either_forward_pass(ngp, oracle, cuda):
-    """The loss kernel (compaction counts, per-ray loss, gradients of the kept samples) gives the same results on the outputs of ngp_hip_nerf_forward and of
-    ngp_hip_nerf_forward_rays at half its threshold: what the ray-walking pass skips lies behind every ray's termination."""
-    import test_loss_gpu as TL
-    I = TL._inputs(oracle, cuda, n_rays=2048, seed=3)
-    desc = H.make_desc(ngp, log2_hashmap_size=15)
-    params = H.random_params(desc, seed=9, grid_amp=6.0, mlp_gain=1.6)          # strong density contrasts: many rays terminate well before their last sample
-    n, n_rays = I["n_samples"], I["n_alive"]
-    d_desc, d_p, d_c = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(I["r"]["co"], cuda)
-    d_ns, d_rc, d_q = H.to_dev(I["r"]["ns"], cuda), H.to_dev(np.array([n_rays], np.uint32), cuda), H.dev_zeros(4, cuda)
-    flat, walked, x1, x2 = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda), H.dev_zeros(n * 64, cuda)
-    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_p.data_ptr(), d_c.data_ptr(), 7, n, flat.data_ptr(), 4, x1.data_ptr()))
-    check(ngp.ngp_hip_nerf_forward_rays(None, d_desc.data_ptr(), d_p.data_ptr(), d_c.data_ptr(), 7, d_ns.data_ptr(), d_rc.data_ptr(), n_rays, n, walked.data_ptr(), 4, x2.data_ptr(), 3,
-                                        H.f32(0.5e-4), d_q.data_ptr()))
-    a, b = H.to_host(flat, np.float16).reshape(n, 4).copy(), H.to_host(walked, np.float16).reshape(n, 4).copy()
-    skipped = (b.view(np.uint16) == 0).all(axis=1) & ~(a.view(np.uint16) == 0).all(axis=1)
-    assert 0.1 * n < skipped.sum() < 0.9 * n, skipped.sum() / n
-    B = 1 << 17
-    res = []
-    for mlp in (a, b):
-        I["mlp"] = mlp
-        _, g = TL._run(ngp, oracle, cuda, I, 4, B)
-        res.append(g)
-    f, w = res
-    assert int(f["cnt"][0]) == int(w["cnt"][0]) > 0
-    np.testing.assert_array_equal(f["ns"][0::2][:n_rays], w["ns"][0::2][:n_rays])     # per-ray kept counts
-    np.testing.assert_array_equal(f["loss"], w["loss"])
-    for i in range(n_rays):                                                            # bases depend on the order the atomics were served in: compare ray by ray
-        c, bf_, bw = int(f["ns"][2 * i]), int(f["ns"][2 * i + 1]), int(w["ns"][2 * i + 1])
-        assert f["dl"][bf_:bf_ + c].tobytes() == w["dl"][bw:bw + c].tobytes() and f["co"][bf_:bf_ + c].tobytes() == w["co"][bw:bw + c].tobytes()

@@ -137,10 +137,8 @@ def _run_train_samples(ngp, oracle, cuda, n_rays, n_cascades, cone_angle, lens_m
     args = (None, n_rays, aabb.ctypes.data, max_samples, st, inc, d["rc"].data_ptr(), d["nc"].data_ptr(), d["idx"].data_ptr(),
             d["rays"].data_ptr(), d["ns"].data_ptr(), d["co"].data_ptr(), len(xf), d_md.data_ptr(), d_xf.data_ptr(), d_bf.data_ptr(),
             0, None, snap, 0, H.f32(cone_angle), H.ptr(d_dist), dres.ctypes.data, ray_offset, nrg, c_dev.ctypes.data if cdf_mode else None, d_summary.data_ptr() if brick_summary else None)
-    if march_mode is None:
-        check(ngp.ngp_hip_generate_training_samples(*args))
-    else:   # 1: lane-per-ray kernels (what the Testbed runs ahead beside the backward pass), 2: wave-per-ray (in stream order)
-        check(ngp.ngp_hip_generate_training_samples_mode(*args, march_mode))
+    # march_mode 0 / None: the library's choice, 1: lane-per-ray kernels, 2: wave-per-ray (in stream order), 3: wave-per-ray on shared CUs (what the Testbed runs ahead beside the backward pass)
+    check(ngp.ngp_hip_generate_training_samples(*args, march_mode or 0))
     g = dict(rc=H.to_host(d["rc"], np.uint32), nc=H.to_host(d["nc"], np.uint32), idx=H.to_host(d["idx"], np.uint32), rays=H.to_host(d["rays"], H.RAY),
              ns=H.to_host(d["ns"], np.uint32), co=H.to_host(d["co"], H.COORD))
     return r, g

@@ -81,7 +81,7 @@ def main():
                                                                                        grads.data_ptr(), scratch.data_ptr(), sb)), n, 1100)
     os.environ["NGP_HIP_BWD_ABLATE"] = "0"
     timeit("optimizer_step", lambda: check(ngp.ngp_hip_optimizer_step(st, npar, 10240, 5, H.f32(1e-2), H.f32(0.9), H.f32(0.99), H.f32(1e-15), H.f32(1e-6), H.f32(128.0), H.f32(0.95), grads.data_ptr(),
-                                                                      master.data_ptr(), d_P.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(), inf.data_ptr())), npar, 36)
+                                                                      master.data_ptr(), d_P.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(), inf.data_ptr(), 3)), npar, 36)
 
 
 if __name__ == "__main__":

@@ -45,7 +45,7 @@ def main():
         bufs["rc"].zero_(); bufs["nc"].zero_()
         check(ngp.ngp_hip_generate_training_samples(st, R, aabb.ctypes.data, max_samples, int(P["rng_state"]), int(P["rng_inc"]), bufs["rc"].data_ptr(), bufs["nc"].data_ptr(),
                                                     bufs["idx"].data_ptr(), bufs["rays"].data_ptr(), bufs["ns"].data_ptr(), bufs["co"].data_ptr(), int(P["n_images"]), int(P["metadata"]),
-                                                    int(P["xforms"]), int(P["bitfield"]), 0, None, 0, 0, H.f32(P["cone_angle_constant"]), dist.data_ptr(), dres.ctypes.data, 0, R, None, None))
+                                                    int(P["xforms"]), int(P["bitfield"]), 0, None, 0, 0, H.f32(P["cone_angle_constant"]), dist.data_ptr(), dres.ctypes.data, 0, R, None, None, 0))
 
     for v in a.variants.split(","):
         os.environ["NGP_HIP_GEN_VARIANT"] = v
