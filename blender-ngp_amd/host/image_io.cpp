@@ -19,7 +19,12 @@ void read_image_rgba8(const std::string& path, int& w, int& h, std::vector<uint8
 		catch (const std::exception& e) { throw std::runtime_error{std::string{e.what()} + " (" + path + ")"}; }
 		return;
 	}
-	throw std::runtime_error{"Could not open image file: unknown image type (PNG and JPEG are decoded; BMP / TGA / GIF / HDR / PSD / PIC / PNM are not): " + path};
+	if (is_hdr_signature(bytes.data(), bytes.size())) {
+		try { decode_hdr_rgba8(bytes.data(), bytes.size(), w, h, pixels); }
+		catch (const std::exception& e) { throw std::runtime_error{std::string{e.what()} + " (" + path + ")"}; }
+		return;
+	}
+	throw std::runtime_error{"Could not open image file: unknown image type (PNG, JPEG and Radiance HDR are decoded; BMP / TGA / GIF / PSD / PIC / PNM are not): " + path};
 }
 
 } // namespace ngp

@@ -46,37 +46,80 @@ static void png_unfilter(const uint8_t* d, size_t n, PngRaw& R) {
 		p += 12 + (size_t)len;
 	}
 	if (!have_ihdr || w <= 0 || h <= 0) throw std::runtime_error("PNG: missing IHDR");
-	if (interlace) throw std::runtime_error("PNG: Adam7 interlacing is not supported");
+	if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
 	int channels;
 	switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: throw std::runtime_error("PNG: bad colour type"); }
 	if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw std::runtime_error("PNG: unsupported bit depth");
 	if (ctype == 3 && palette.empty()) throw std::runtime_error("PNG: palette image without PLTE");
-	const size_t row_bytes = ((size_t)w * channels * depth + 7) / 8;
-	const size_t bpp = std::max<size_t>(1, (size_t)channels * depth / 8);
-	std::vector<uint8_t>& raw = R.raw; raw.assign((row_bytes + 1) * (size_t)h, 0);
-	uLongf raw_len = (uLongf)raw.size();
-	const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
-	if (zr != Z_OK || raw_len != raw.size()) throw std::runtime_error("PNG: zlib stream is corrupt or has the wrong size");
-	// unfilter in place (PNG spec 9.2)
-	std::vector<uint8_t> prev(row_bytes, 0);
-	for (int y = 0; y < h; ++y) {
-		uint8_t* row = raw.data() + (size_t)y * (row_bytes + 1);
-		const int f = row[0];
-		uint8_t* cur = row + 1;
-		for (size_t i = 0; i < row_bytes; ++i) {
-			const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-			int v = cur[i];
-			switch (f) {
-				case 0: break;
-				case 1: v += a; break;
-				case 2: v += b; break;
-				case 3: v += (a + b) >> 1; break;
-				case 4: v += paeth(a, b, c); break;
-				default: throw std::runtime_error("PNG: bad filter type");
+	if ((uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28)) throw std::runtime_error("PNG: image larger than 2^28 pixels");
+	const size_t bits_per_pixel = (size_t)channels * depth;
+	const size_t row_bytes = ((size_t)w * bits_per_pixel + 7) / 8;
+	const size_t bpp = std::max<size_t>(1, bits_per_pixel / 8);
+	// unfilter `rows` scanlines of `rb` sample bytes each, in place (PNG spec 9.2); every scanline starts with its filter byte
+	auto unfilter = [&](uint8_t* data, int rows, size_t rb) {
+		std::vector<uint8_t> prev(rb, 0);
+		for (int y = 0; y < rows; ++y) {
+			uint8_t* row = data + (size_t)y * (rb + 1);
+			const int f = row[0];
+			uint8_t* cur = row + 1;
+			for (size_t i = 0; i < rb; ++i) {
+				const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+				int v = cur[i];
+				switch (f) {
+					case 0: break;
+					case 1: v += a; break;
+					case 2: v += b; break;
+					case 3: v += (a + b) >> 1; break;
+					case 4: v += paeth(a, b, c); break;
+					default: throw std::runtime_error("PNG: bad filter type");
+				}
+				cur[i] = (uint8_t)v;
 			}
-			cur[i] = (uint8_t)v;
+			memcpy(prev.data(), cur, rb);
 		}
-		memcpy(prev.data(), cur, row_bytes);
+	};
+	std::vector<uint8_t>& raw = R.raw; raw.assign((row_bytes + 1) * (size_t)h, 0);
+	if (!interlace) {
+		uLongf raw_len = (uLongf)raw.size();
+		const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
+		if (zr != Z_OK || raw_len != raw.size()) throw std::runtime_error("PNG: zlib stream is corrupt or has the wrong size");
+		unfilter(raw.data(), h, row_bytes);
+	} else {
+		// Adam7 (PNG spec 8.2): the stream holds seven reduced images — pass p takes the pixels (x0 + i dx, y0 + j dy) — each filtered on its own; empty passes
+		// (narrow images) are absent.  They are unfiltered one by one and their pixels dropped into the rows of the full image, which the converters below read.
+		static const int X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+		size_t total = 0;
+		int pw[7], ph[7]; size_t prb[7];
+		for (int k = 0; k < 7; ++k) {
+			pw[k] = (w - X0[k] + DX[k] - 1) / DX[k]; ph[k] = (h - Y0[k] + DY[k] - 1) / DY[k];
+			if (pw[k] <= 0 || ph[k] <= 0) { pw[k] = ph[k] = 0; prb[k] = 0; continue; }
+			prb[k] = ((size_t)pw[k] * bits_per_pixel + 7) / 8;
+			total += (prb[k] + 1) * (size_t)ph[k];
+		}
+		std::vector<uint8_t> passes(total);
+		uLongf got = (uLongf)total;
+		const int zr = uncompress(passes.data(), &got, idat.data(), (uLong)idat.size());
+		if (zr != Z_OK || got != total) throw std::runtime_error("PNG: zlib stream is corrupt or has the wrong size");
+		size_t at = 0;
+		for (int k = 0; k < 7; ++k) {
+			if (!ph[k]) continue;
+			uint8_t* pd = passes.data() + at;
+			unfilter(pd, ph[k], prb[k]);
+			for (int j = 0; j < ph[k]; ++j) {
+				const uint8_t* src = pd + (size_t)j * (prb[k] + 1) + 1;
+				uint8_t* dst = raw.data() + (size_t)(Y0[k] + j * DY[k]) * (row_bytes + 1) + 1;
+				for (int i = 0; i < pw[k]; ++i) {
+					const size_t x = (size_t)X0[k] + (size_t)i * DX[k];
+					if (bits_per_pixel >= 8) memcpy(dst + x * bpp, src + (size_t)i * bpp, bpp);
+					else {
+						const size_t sb = (size_t)i * depth, db = x * depth;
+						const uint32_t v = (src[sb >> 3] >> (8 - depth - (sb & 7))) & ((1u << depth) - 1u);
+						dst[db >> 3] |= (uint8_t)(v << (8 - depth - (db & 7)));
+					}
+				}
+			}
+			at += (prb[k] + 1) * (size_t)ph[k];
+		}
 	}
 	R.w = w; R.h = h; R.depth = depth; R.ctype = ctype; R.channels = channels; R.row_bytes = row_bytes;
 }

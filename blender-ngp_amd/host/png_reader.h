@@ -1,7 +1,7 @@
 // png_reader.h — PNG -> RGBA8 for the transforms.json loader.  The reference decodes images with the vendored stb_image
 // (`stbi_load(path, &w, &h, &comp, 4)`, src/nerf_loader.cu:581); this build links zlib and implements the PNG container, the five
 // scanline filters and the conversion to 4 x 8 bit the same way stb_image's 4-channel request does (grey -> rgb replicate, opaque alpha,
-// 16 bit -> high byte, palette + tRNS).  Adam7-interlaced files and JPEG are rejected with an error.
+// 16 bit -> high byte, palette + tRNS).  Adam7-interlaced files are de-interlaced (the seven passes are unfiltered one by one).
 #pragma once
 #include <cstdint>
 #include <string>

@@ -104,12 +104,13 @@ def test_fox_frames_decode_like_libjpeg():
 
 
 # ---------------------------------------------------------------------------------------------------------------- OpenEXR
-def _write_exr(path, img, compression, pixel_type, channel_names="ABGR"):
-    """scanline OpenEXR writer (test-side): img (H, W, C) float32, channels stored in alphabetical order of their names"""
+def _write_exr(path, img, compression, pixel_type, channel_names="ABGR", tile=None, extra_levels=0):
+    """scanline / tiled (tile=(tw, th), ONE_LEVEL or, with extra_levels, MIPMAP_LEVELS whose further levels hold zeros) OpenEXR writer (test-side): img (H, W, C)
+    float32, channels stored in alphabetical order of their names"""
     h, w, _ = img.shape
     names = sorted(channel_names)
     src_index = {"R": 0, "G": 1, "B": 2, "A": 3, "Y": 0}
-    head = struct.pack("<II", 20000630, 2)
+    head = struct.pack("<II", 20000630, 2 | (0x200 if tile else 0))
 
     def attr(name, typ, val):
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
@@ -117,12 +118,20 @@ def _write_exr(path, img, compression, pixel_type, channel_names="ABGR"):
     head += attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression]))
     head += attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1))
     head += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
-    head += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    head += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if tile:
+        head += attr("tiles", "tiledesc", struct.pack("<IIB", tile[0], tile[1], 1 if extra_levels else 0))
+    head += b"\0"
     lines = 16 if compression == 3 else 1
     dt = np.float16 if pixel_type == 1 else np.float32
     blocks = []
-    for y0 in range(0, h, lines):
-        raw = b"".join(img[y, :, src_index[n]].astype(dt).tobytes() for y in range(y0, min(h, y0 + lines)) for n in names)
+    if tile:
+        regions = [(struct.pack("<iiii", tx, ty, 0, 0), tx * tile[0], ty * tile[1], min(tile[0], w - tx * tile[0]), min(tile[1], h - ty * tile[1]))
+                   for ty in range((h + tile[1] - 1) // tile[1]) for tx in range((w + tile[0] - 1) // tile[0])]
+    else:
+        regions = [(struct.pack("<i", y0), 0, y0, w, min(lines, h - y0)) for y0 in range(0, h, lines)]
+    for prefix, x0, y0, nx, ny in regions:
+        raw = b"".join(img[y, x0:x0 + nx, src_index[n]].astype(dt).tobytes() for y in range(y0, y0 + ny) for n in names)
         data = raw
         if compression:
             a = np.frombuffer(raw, np.uint8)
@@ -148,7 +157,14 @@ def _write_exr(path, img, compression, pixel_type, channel_names="ABGR"):
             else:
                 comp = zlib.compress(pb)
             data = comp if len(comp) < len(raw) else raw
-        blocks.append(struct.pack("<ii", y0, len(data)) + data)
+        blocks.append(prefix + struct.pack("<i", len(data)) + data)
+    for lvl in range(1, extra_levels + 1):   # one zero tile per further mip level (the reader takes level (0, 0) only; its tiles come first in the offset table)
+        lw, lh = max(1, w >> lvl), max(1, h >> lvl)
+        for ty in range((lh + tile[1] - 1) // tile[1]):
+            for tx in range((lw + tile[0] - 1) // tile[0]):
+                nx, ny = min(tile[0], lw - tx * tile[0]), min(tile[1], lh - ty * tile[1])
+                data = bytes(nx * ny * len(names) * (2 if pixel_type == 1 else 4))
+                blocks.append(struct.pack("<iiii", tx, ty, lvl, lvl) + struct.pack("<i", len(data)) + data)
     off = len(head) + 8 * len(blocks)
     table = b""
     for b in blocks:
@@ -190,13 +206,13 @@ def test_exr_rgb_without_alpha_and_luminance(tmp_path):
 def test_exr_rejects_what_it_cannot_read(tmp_path):
     import pyngp
     img = np.zeros((4, 4, 4), np.float32)
-    p = str(tmp_path / "piz.exr")
+    p = str(tmp_path / "pxr24.exr")
     _write_exr(p, img, 0, 2)
     raw = bytearray(open(p, "rb").read())
     i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    raw[i] = 4    # PIZ
+    raw[i] = 5    # PXR24
     open(p, "wb").write(bytes(raw))
-    with pytest.raises(RuntimeError, match="PIZ"):
+    with pytest.raises(RuntimeError, match="PXR24"):
         pyngp.decode_exr(p)
     open(p, "wb").write(b"not an exr file at all")
     with pytest.raises(RuntimeError):
@@ -327,3 +343,242 @@ def test_exr_hostile_headers_and_blocks_raise(tmp_path):
     open(q, "wb").write(bad)
     with pytest.raises(RuntimeError, match="RLE"):
         pyngp.decode_exr(q)
+
+
+# ---------------------------------------------------------------------------------------------------------------- PIZ, tiles, Adam7, Radiance HDR
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_imageio.so")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref_imageio.so (the reference's vendored stb_image + tinyexr, `make -C oracle ref`) is built in the build container")
+
+
+def _ref():
+    import ctypes
+    ref = ctypes.CDLL(REF_SO)
+    for f in ("ref_stbi_load_rgba8", "ref_stbi_load_16_gray", "ref_load_exr_rgba"):
+        getattr(ref, f).restype = ctypes.c_void_p
+
+    def grab(fn, path, ctype, ch):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        p = getattr(ref, fn)(str(path).encode(), ctypes.byref(w), ctypes.byref(h))
+        assert p, path
+        shape = (h.value, w.value, ch) if ch > 1 else (h.value, w.value)
+        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctype)), shape).copy()
+        ref.ref_free(ctypes.c_void_p(p))
+        return a
+    return ref, grab
+
+
+def test_exr_piz_fixtures_written_by_the_references_tinyexr():
+    """tests/golden/images/piz_*.exr: PIZ files the reference's vendored tinyexr wrote (tests/golden/make_image_fixtures.py) from closed-form images — HALF and FLOAT
+    channels, odd sizes (the wavelet's odd row / column steps), and a block with more than 2^14 different values (the modulo-2^16 wavelet).  Decoded bit for bit."""
+    import pyngp
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_image_fixtures import EXR_FIXTURES, exr_fixture_image
+    for name, (w, h, pt, kind) in EXR_FIXTURES.items():
+        got = pyngp.decode_exr(os.path.join(ROOT, "tests", "golden", "images", name))
+        want = exr_fixture_image(w, h, pt, kind)
+        assert got.shape == (h, w, 4)
+        assert np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32)), name
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (33, 65), (130, 33), (64, 64), (7, 100)])
+def test_exr_piz_matches_the_references_tinyexr(tmp_path, w, h):
+    """files written AND read back by the reference's tinyexr vs this build's PIZ decoder: smooth, noisy (stored raw when PIZ does not shrink the block) and
+    heavy-tailed images, HALF and FLOAT"""
+    import ctypes
+    import pyngp
+    ref, grab = _ref()
+    rs = np.random.RandomState(w * 131 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    images = [np.stack([np.sin(xx * 0.1) + 1.5, yy * 0.01 + 0.1, (xx + yy) * 0.005, np.ones_like(xx) * 1.0], -1), rs.rand(h, w, 4), rs.randn(h, w, 4) ** 3 * 100,
+              np.where(rs.rand(h, w, 4) < 0.9, 0.25, rs.rand(h, w, 4))]
+    for k, img in enumerate(images):
+        for pt in (1, 2):
+            p = str(tmp_path / "t.exr")
+            img32 = np.ascontiguousarray(img.astype(np.float32))
+            assert ref.ref_save_exr_rgba(p.encode(), img32.ctypes.data_as(ctypes.c_void_p), w, h, 4, pt) == 0
+            want = grab("ref_load_exr_rgba", p, ctypes.c_float, 4)
+            got = np.asarray(pyngp.decode_exr(p))
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, pt)
+
+
+@pytest.mark.parametrize("compression,pixel_type,tile,levels", [(0, 2, (16, 16), 0), (3, 1, (32, 8), 0), (2, 2, (64, 64), 0), (1, 1, (5, 7), 0), (3, 2, (16, 16), 2)])
+def test_exr_tiled_files(tmp_path, compression, pixel_type, tile, levels):
+    """tiled files (single part, level (0, 0)): tiles cropped at the right / bottom edge, every compression of the scanline reader (a tile is ONE compressed block),
+    and a mip-mapped file whose further levels are ignored; same pixels as the scanline file of the same image — and as the reference's tinyexr where it is built"""
+    import pyngp
+    rs = np.random.RandomState(7)
+    h, w = 45, 70
+    img = (rs.rand(h, w, 4) ** 3 * 4.0).astype(np.float32)
+    img[5:20, 3:30] = 0.25
+    p = str(tmp_path / "tiled.exr")
+    _write_exr(p, img, compression, pixel_type, tile=tile, extra_levels=levels)
+    got = np.asarray(pyngp.decode_exr(p))
+    want = img.astype(np.float16).astype(np.float32) if pixel_type == 1 else img
+    np.testing.assert_array_equal(got, want)
+    if os.path.exists(REF_SO) and not levels:
+        import ctypes
+        _, grab = _ref()
+        np.testing.assert_array_equal(got, grab("ref_load_exr_rgba", p, ctypes.c_float, 4))
+
+
+def test_exr_piz_corruption_never_crashes():
+    """a PIZ block with flipped bytes raises or decodes (to whatever the damaged code says) — it never reads or writes out of bounds (run under the same process: a crash fails the suite)"""
+    import pyngp
+    import tempfile
+    data = open(os.path.join(ROOT, "tests", "golden", "images", "piz_half_37x45.exr"), "rb").read()
+    rs = np.random.RandomState(3)
+    start = data.index(b"\0", data.index(b"screenWindowWidth")) + 1   # somewhere behind the header attributes
+    raised = 0
+    with tempfile.TemporaryDirectory() as d:
+        for trial in range(150):
+            b = bytearray(data)
+            for _ in range(1 + trial % 4):
+                i = rs.randint(start, len(b))
+                b[i] = rs.randint(0, 256)
+            if trial % 10 == 0:
+                b = b[:rs.randint(start, len(b))]
+            p = os.path.join(d, "c.exr")
+            open(p, "wb").write(bytes(b))
+            try:
+                out = pyngp.decode_exr(p)
+                assert out.shape == (45, 37, 4)
+            except RuntimeError:
+                raised += 1
+    assert raised > 20
+
+
+def _adam7_png(w, h, color_type, depth, pixel_rows, bits_per_pixel, palette=None, trns=None):
+    """interlaced PNG from UNFILTERED full-image rows (bytes, packed at `depth`): the seven passes, each filtered with the cyclic filter choice of _filter_rows"""
+    from test_loader_cpu import _filter_rows
+    X0, Y0, DX, DY = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+
+    def pixel(y, x):
+        if bits_per_pixel >= 8:
+            b = bits_per_pixel // 8
+            return pixel_rows[y][x * b:(x + 1) * b]
+        bit = x * depth
+        return (pixel_rows[y][bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)
+    stream = b""
+    for k in range(7):
+        xs, ys = range(X0[k], w, DX[k]), range(Y0[k], h, DY[k])
+        if not len(xs) or not len(ys):
+            continue
+        rows = []
+        for y in ys:
+            if bits_per_pixel >= 8:
+                rows.append(b"".join(pixel(y, x) for x in xs))
+            else:
+                acc = bytearray((len(xs) * depth + 7) // 8)
+                for i, x in enumerate(xs):
+                    bit = i * depth
+                    acc[bit >> 3] |= pixel(y, x) << (8 - depth - (bit & 7))
+                rows.append(bytes(acc))
+        stream += b"".join(_filter_rows(rows, max(1, bits_per_pixel // 8)))
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 1))
+    if palette is not None:
+        out += chunk(b"PLTE", palette)
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    return out + chunk(b"IDAT", zlib.compress(stream, 6)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 3), (5, 5), (8, 8), (9, 17), (33, 20)])
+@pytest.mark.parametrize("color_type,depth", [(6, 8), (2, 8), (2, 16), (0, 8), (0, 1), (0, 4), (3, 2), (3, 8), (4, 16)])
+def test_png_adam7_matches_the_progressive_scan_free_file(tmp_path, w, h, color_type, depth):
+    """Adam7-interlaced PNGs (every colour type, sub-byte depths, sizes where some of the seven passes are empty) decode to the pixels of the non-interlaced file of the
+    same image — RGBA8 and the 16-bit grey depth read — and to what the reference's stb_image returns where it is built"""
+    import pyngp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_loader_cpu import _filter_rows, _png_bytes
+    rs = np.random.RandomState(w * 7 + h + color_type * 100 + depth)
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    bpp = channels * depth
+    row_bytes = (w * bpp + 7) // 8
+    rows = []
+    for _ in range(h):
+        r = bytearray(rs.randint(0, 256, row_bytes).astype(np.uint8).tobytes())
+        if bpp < 8 and (w * bpp) % 8:
+            r[-1] &= (0xff << (8 - (w * bpp) % 8)) & 0xff   # padding bits zero
+        rows.append(bytes(r))
+    palette = rs.randint(0, 256, 3 * (1 << depth)).astype(np.uint8).tobytes() if color_type == 3 else None
+    trns = rs.randint(0, 256, 1 << depth).astype(np.uint8).tobytes() if color_type == 3 else None
+    flat = tmp_path / "flat.png"
+    flat.write_bytes(_png_bytes(w, h, color_type, depth, _filter_rows(rows, max(1, bpp // 8)), palette, trns))
+    inter = tmp_path / "adam7.png"
+    inter.write_bytes(_adam7_png(w, h, color_type, depth, rows, bpp, palette, trns))
+    np.testing.assert_array_equal(pyngp.decode_image(str(inter)), pyngp.decode_image(str(flat)))
+    np.testing.assert_array_equal(pyngp.decode_png_gray16(str(inter)), pyngp.decode_png_gray16(str(flat)))
+    if os.path.exists(REF_SO):
+        import ctypes
+        _, grab = _ref()
+        np.testing.assert_array_equal(pyngp.decode_image(str(inter)), grab("ref_stbi_load_rgba8", inter, ctypes.c_ubyte, 4))
+        np.testing.assert_array_equal(pyngp.decode_png_gray16(str(inter)), grab("ref_stbi_load_16_gray", inter, ctypes.c_ushort, 1))
+
+
+def _hdr_bytes(rgbe, rle, magic=b"#?RADIANCE"):
+    """Radiance file from an (H, W, 4) uint8 RGBE array: new-style run-length scanlines (runs where a byte repeats >= 3 times, dumps otherwise) or flat quadruples"""
+    h, w, _ = rgbe.shape
+    out = magic + b"\n# test file\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n" + ("-Y %d +X %d\n" % (h, w)).encode()
+    if not rle:
+        return out + rgbe.tobytes()
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            plane = rgbe[y, :, k].tobytes()
+            i = 0
+            while i < w:
+                j = i
+                while j + 1 < w and plane[j + 1] == plane[i] and j - i < 126:
+                    j += 1
+                if j - i >= 2:
+                    out += bytes([128 + (j - i + 1), plane[i]])
+                    i = j + 1
+                else:
+                    k2 = i
+                    while k2 < w and k2 - i < 128 and not (k2 + 2 < w and plane[k2] == plane[k2 + 1] == plane[k2 + 2]):
+                        k2 += 1
+                    k2 = max(k2, i + 1)
+                    out += bytes([k2 - i]) + plane[i:k2]
+                    i = k2
+    return out
+
+
+@pytest.mark.parametrize("w,h,rle", [(8, 3, True), (40, 11, True), (300, 4, True), (7, 5, False), (40, 11, False), (1, 1, False)])
+def test_radiance_hdr_as_stbi_load_sees_it(tmp_path, w, h, rle):
+    """.hdr goes through stbi_load(.., 4) in the reference's loader (src/nerf_loader.cu:581): RGBE -> float -> (float)pow(v, 1 / 2.2) * 255 + 0.5, clamped, truncated;
+    alpha 255.  Run-length and flat files, both magic lines; bit-identical to the reference's stb_image where it is built."""
+    import pyngp
+    rs = np.random.RandomState(w + h)
+    rgbe = rs.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    rgbe[..., 3] = rs.randint(118, 134, (h, w))        # exponents around 2^-10 .. 2^6: dark to far above 1
+    rgbe[0, 0] = (0, 0, 0, 0)                          # e = 0: black
+    rgbe[h // 2, : max(1, w // 3)] = rgbe[h // 2, 0]   # runs
+    p = tmp_path / "t.hdr"
+    p.write_bytes(_hdr_bytes(rgbe, rle, b"#?RGBE" if (w + h) % 2 else b"#?RADIANCE"))
+    got = pyngp.decode_image(str(p))
+    assert got.shape == (h, w, 4)
+    f = np.where(rgbe[..., 3:4] > 0, np.ldexp(np.float32(1.0), rgbe[..., 3:4].astype(np.int32) - 136), np.float32(0)).astype(np.float32)
+    lin = (rgbe[..., :3].astype(np.float32) * f).astype(np.float32)
+    z = (np.power(lin.astype(np.float64), np.float64(np.float32(1.0 / 2.2))).astype(np.float32) * np.float32(255) + np.float32(0.5)).astype(np.float32)
+    want = np.clip(z, 0, 255).astype(np.int32)
+    assert np.abs(got[..., :3].astype(np.int32) - want).max() <= 1      # numpy's pow against libm's: the last place may differ at a rounding boundary
+    assert (got[..., 3] == 255).all()
+    if os.path.exists(REF_SO):
+        import ctypes
+        _, grab = _ref()
+        np.testing.assert_array_equal(got, grab("ref_stbi_load_rgba8", p, ctypes.c_ubyte, 4))
+
+
+def test_radiance_hdr_errors(tmp_path):
+    import pyngp
+    p = tmp_path / "bad.hdr"
+    good = _hdr_bytes(np.full((4, 16, 4), 128, np.uint8), True)
+    for blob, what in ((good.replace(b"FORMAT=32-bit_rle_rgbe", b"FORMAT=32-bit_rle_xyze"), "format"), (good.replace(b"-Y 4 +X 16", b"+Y 4 +X 16"), "layout"),
+                       (good[:-5], "truncated"), (good.replace(b"-Y 4 +X 16", b"-Y 4 +X 17"), "scanline length")):
+        p.write_bytes(blob)
+        with pytest.raises(RuntimeError, match="HDR"):
+            pyngp.decode_image(str(p))
