@@ -557,7 +557,7 @@ __global__ void compute_sharpness_kernel(int srx, int sry, int irx, int iry, con
 	int x1 = (x * irx) / srx, x2 = ((x + 1) * irx) / srx, y1 = (y * iry) / sry, y2 = ((y + 1) * iry) / sry;
 	x1 = max(x1, 1); y1 = max(y1, 1); x2 = min(x2, irx - 2); y2 = min(y2, iry - 2);   // clamp to 1 pixel in from the edge
 	const int32_t res[2] = {irx, iry};
-	float tot_lap = 0.f, tot_lap2 = 0.f, tot_lum = 0.f;
+	float tot_lap = 0.f, tot_lap2 = 0.f;
 	const float scal = 1.f / (float)((x2 - x1) * (y2 - y1));
 	auto luma_at = [&](int px, int py) {
 		float c[4];
@@ -567,9 +567,9 @@ __global__ void compute_sharpness_kernel(int srx, int sry, int irx, int iry, con
 	for (int yy = y1; yy < y2; ++yy) for (int xx = x1; xx < x2; ++xx) {
 		const float lum = luma_at(xx, yy);
 		const float lap = lum * 4.f - luma_at(xx, yy - 1) - luma_at(xx + 1, yy) - luma_at(xx, yy + 1) - luma_at(xx - 1, yy);
-		tot_lap += lap; tot_lap2 += lap * lap; tot_lum += lum;
+		tot_lap += lap; tot_lap2 += lap * lap;
 	}
-	tot_lap *= scal; tot_lap2 *= scal; tot_lum *= scal;
+	tot_lap *= scal; tot_lap2 *= scal;
 	sharpness_data[x + (size_t)y * srx] = tot_lap2 - tot_lap * tot_lap;
 }
 __global__ void decay_grid_kernel(uint32_t n, float decay, float* __restrict__ grid) {

@@ -280,6 +280,7 @@ int ngp_hip_compute_loss(
  * folded into a ray-origin and a ray-direction gradient and added (atomicAdd; the caller clears them every n_steps_between_cam_updates, :2916-2918) to
  * cam_pos_gradient[img] and, as the angle-axis ray.d x grad_d, to cam_rot_gradient[img] ([n_images][3] floats each; either may be NULL), both divided by the pixel
  * pdf of the ray's draw.  rng / cdf_host must be what ngp_hip_compute_loss got.  The reference kernel takes a cam_focal_length_gradient pointer and never writes it.
+ * (declaration below, behind the sharpness helpers) */
 /* compute_sharpness (src/nerf_loader.cu:129-169): sharpness_out[y][x] = variance of the Laplacian of the luma over tile (x, y) of a sharpness_res grid laid over the image */
 int ngp_hip_compute_sharpness(void* stream, const int32_t* sharpness_res_host, const int32_t* image_res_host, const void* pixels, int image_data_type, float* sharpness_out);
 int ngp_hip_decay_grid(void* stream, uint32_t n_elements, float decay, float* grid);   /* decay_sharpness_grid_nerf (:557-561) */
