@@ -670,6 +670,8 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 // 2048 samples in LDS (coalesced loads), then every thread walks 8 CONSECUTIVE samples and sums the 8 corner terms in registers while the
 // cell stays the same; a record per corner leaves when the cell changes.  (Padded LDS index i + i/8: the walk is bank-conflict free.)
 constexpr uint32_t GB_STAGE = GB_FX_CHUNK + GB_FX_CHUNK / 8;
+// levels whose slices fit the 256 bins are binned; larger dense tables (log2_hashmap_size >= 21: res^3 above 2^20 entries) take the float path of the owners
+__host__ __device__ __forceinline__ bool gb_dense_binned(uint32_t level_size) { return (level_size + GB_FX_SLICE - 1) / GB_FX_SLICE <= GB_FX_MAX_SLICES; }
 template <int D, bool WRITE>
 __device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, const float* __restrict__ s_px, const float* __restrict__ s_py, const float* __restrict__ s_pz,
                                               uint32_t* __restrict__ counter, const NgpGridLevel& lv, uint32_t chunk_bin0, uint32_t n_live,
@@ -769,9 +771,9 @@ __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __rest
 	const uint32_t level = blockIdx.y;
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
 	const NgpGridLevel lv = desc->levels[level];
-	const bool dense = level_is_dense<D>(lv);
-	const bool fx = gb_uses_fx(lv.size, lv.resolution, dense);
-	if (!fx && !dense) return;   // float fallback: no binning
+	const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
+	const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
+	if (!fx && !dense) return;   // float path of the owners: no binning
 	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[4 * GB_STAGE];
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
@@ -892,7 +894,7 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
 	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, coords, coord_stride, n, dx_planes, ctr, items, grid_grad, &s_start); return; }
-	if (dense) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad, &s_start); return; }
+	if (dense && gb_dense_binned(lv.size)) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad, &s_start); return; }
 	h2* __restrict__ slice = (h2*)slice64;
 	h2* __restrict__ partials = (h2*)partials_raw;
 	const GbSplit sp = gb_split(lv.size);
@@ -935,7 +937,7 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 #pragma unroll
 				for (int k = 0; k < NC; ++k) {
 					const uint32_t h = hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[(k >> 2) & 1];
-					const uint32_t rel = (pow2 ? (h & hmask) : (h % lv.size)) - lo;
+					const uint32_t rel = (dense ? grid_index_nd<D>(lv, p.gx + (k & 1), p.gy + ((k >> 1) & 1), p.gz + ((k >> 2) & 1)) : pow2 ? (h & hmask) : (h % lv.size)) - lo;
 					if (rel < cnt) {
 						float w = (k & 1) ? p.fx : (1.0f - p.fx);
 						w *= ((k >> 1) & 1) ? p.fy : (1.0f - p.fy);
@@ -950,7 +952,8 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 		}
 	}
 	__syncthreads();
-	h2* __restrict__ dst = partials + (size_t)level * (GB_PARTIAL_LEVEL_BYTES / 4u) + (size_t)item * GB_SLICE;
+	// one owner per slice (tables above 2^20 entries: more slices than private-copy slots): the table itself; else a private copy for grid_combine_kernel
+	h2* __restrict__ dst = sp.n_slices > GB_ITEMS ? grid_grad + lv.offset + lo : partials + (size_t)level * (GB_PARTIAL_LEVEL_BYTES / 4u) + (size_t)item * GB_SLICE;
 	for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = slice[i];
 }
 
@@ -961,7 +964,7 @@ __global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __r
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = (dims == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
 	if (gb_uses_fx(lv.size, lv.resolution, dense)) return;   // written directly by the owners
-	if (dense) {
+	if (dense && gb_dense_binned(lv.size)) {
 		const GbSplit sp = gb_dense_split(lv.size);
 		if (sp.k_chunks == 1) return;                        // likewise
 		const ulonglong2* __restrict__ partials = (const ulonglong2*)partials_raw;
@@ -979,6 +982,7 @@ __global__ void __launch_bounds__(256) grid_combine_kernel(const NgpNetDesc* __r
 	}
 	const h2* __restrict__ partials = (const h2*)partials_raw;
 	const GbSplit sp = gb_split(lv.size);
+	if (sp.n_slices > GB_ITEMS) return;                      // likewise
 	for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < lv.size; e += gridDim.x * blockDim.x) {
 		const uint32_t sl = e / GB_SLICE, rel = e % GB_SLICE;
 		float a0 = 0.0f, a1 = 0.0f;
@@ -1848,6 +1852,8 @@ int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, ui
 		const uint32_t hashmap = 1u << log2_hashmap_size;
 		const uint32_t size = cnt < hashmap ? cnt : hashmap;
 		d->levels[l].scale = scale; d->levels[l].resolution = res; d->levels[l].offset = offset; d->levels[l].size = size;
+		// the hash-grid backward's owners cover at most 256 slices of 16384 entries per level (log2_hashmap_size <= 22); refused here rather than trained wrongly
+		if (size > GB_FX_MAX_SLICES * GB_SLICE) { set_last_error("make_desc: a level above 2^22 entries (log2_hashmap_size > 22) is outside what the hash-grid backward covers", hipErrorInvalidValue); return -1; }
 		offset += size;
 	}
 	d->n_levels = n_levels;
@@ -2193,6 +2199,8 @@ int ngp_hip_gridmlp_make_desc_host(uint32_t n_dims, uint32_t n_levels, uint32_t 
 		const uint32_t hashmap = 1u << log2_hashmap_size;
 		const uint32_t size = cnt < hashmap ? cnt : hashmap;
 		d->levels[l].scale = scale; d->levels[l].resolution = res; d->levels[l].offset = offset; d->levels[l].size = size;
+		// the hash-grid backward's owners cover at most 256 slices of 16384 entries per level (log2_hashmap_size <= 22); refused here rather than trained wrongly
+		if (size > GB_FX_MAX_SLICES * GB_SLICE) { set_last_error("make_desc: a level above 2^22 entries (log2_hashmap_size > 22) is outside what the hash-grid backward covers", hipErrorInvalidValue); return -1; }
 		offset += size;
 	}
 	d->n_levels = n_levels;

@@ -119,3 +119,30 @@ def test_grid_backward_rejects_bad_arguments(ngp, cuda):
     assert ngp.ngp_hip_grid_backward(None, 4, d_desc.data_ptr(), buf.data_ptr(), 3, 256, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 1 << 40) != 0
     assert ngp.ngp_hip_grid_backward(None, 3, d_desc.data_ptr(), buf.data_ptr(), 3, 256, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), 16) != 0
     assert b"scratch" in ngp.ngp_hip_last_error()
+
+
+def test_grid_backward_big_table(ngp, oracle, cuda):
+    """configs/nerf/big.json (log2_hashmap_size 21): level 6 (res 112) is dense with 343 slices of 4096 entries — more than the 256 bins of the counting sort — and
+    the hashed levels have 512: both take the owners' float path (fp16 LDS atomics), the smaller dense levels stay exact"""
+    n = 4096
+    desc = H.make_desc(ngp, 21)
+    rs = np.random.RandomState(21)
+    pos = _ray_positions(n, 3, rs)
+    pl = _planes(n, rs, special=False)
+    got = _run(ngp, cuda, 3, desc, pos, pl.view(np.uint16)).view(np.float16).astype(np.float64)
+    ref = np.zeros(got.size, np.uint16)
+    oracle.orc_grid_backward_exact(3, desc.ctypes.data, pos.ctypes.data, 3, n, pl.view(np.uint16).ctypes.data, ref.ctypes.data)
+    ref = ref.view(np.float16).astype(np.float64)
+    assert np.isfinite(got).all()
+    lv = desc["levels"][0]
+    n_float = 0
+    for l in range(16):
+        o, sz, res = int(lv[l]["offset"]) * 2, int(lv[l]["size"]) * 2, int(lv[l]["resolution"])
+        exact = sz // 2 <= 256 * 4096 and (res ** 3 <= sz // 2)
+        if exact:
+            np.testing.assert_array_equal(got[o:o + sz], ref[o:o + sz])
+        else:
+            n_float += 1
+            assert np.linalg.norm(ref[o:o + sz]) > 0
+            assert np.linalg.norm(got[o:o + sz] - ref[o:o + sz]) < 2e-3 * np.linalg.norm(ref[o:o + sz]), l
+    assert n_float >= 2
