@@ -471,12 +471,6 @@ __global__ void __launch_bounds__(256) encode_levels_planes_kernel(const NgpNetD
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Activation / delta planes [row][sample] fp16 between a backward kernel and nerf_wgrad_kernel (the GridMLP path; the NeRF backward contracts in-kernel)
-__device__ __forceinline__ void store_plane(half_t* __restrict__ planes, uint32_t n, int row0, int map, int kb, int g, uint32_t s, const h8& v) {
-#pragma unroll
-	for (int e = 0; e < 8; ++e) *(half_t*)((char*)planes + (size_t)((((uint32_t)(row0 + slot_feature(map, kb, g, e))) * n + s) * 2u)) = v[e];
-}
-
 __device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8& fwd_act) {
 	h8 r;
 #pragma unroll
@@ -1478,42 +1472,74 @@ __global__ void __launch_bounds__(256, 2) gridmlp_forward_kernel(const NgpNetDes
 	}
 }
 
-// activation / delta planes of the GridMLP backward: [row][sample] fp16
-constexpr int GP_DOUT = 0, GP_H2 = 16, GP_DH2 = 80, GP_H1 = 144, GP_DH1 = 208, GP_X = 272, GM_PLANE_ROWS = 304;
+// backward: recompute the MLP from the saved encoding, dgrad chain (channels 0..3 of dL_dout) and the weight-gradient contraction in the SAME kernel, operands
+// transposed through LDS one layer at a time — the scheme of nerf_backward_fused_kernel with one network instead of two (the [304][n] fp16 activation / delta
+// planes and the second kernel that read them back are gone).  The 8 output tiles of the three matrices over the 4 waves: the 64 x 64 hidden matrix one tile per
+// wave; waves 0 / 1 the two N tiles of the 16 x 64 output matrix, waves 2 / 3 the two M tiles of the 64 x 32 input matrix: 32 accumulator registers per wave.
+__device__ __forceinline__ void gm_flush(float* __restrict__ red /* [4][16][64] */, const f32x16& acc, int w, int lane, int kind, float* __restrict__ dst /* this workgroup's [7168] */) {
+#pragma unroll
+	for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
+	__syncthreads();
+	for (int idx = threadIdx.x; idx < 4 * 16 * 64; idx += 256) {
+		const int t = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
+		const float v = red[idx];
+		const int row_in_tile = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col_in_tile = l & 31;
+		int o, i, n_out, n_in, off;
+		if (kind == 0)  { o = (t >> 1) * 32 + row_in_tile; i = (t & 1) * 32 + col_in_tile; n_out = 64; n_in = 64; off = (int)GM_L1_OFF; }
+		else if (t < 2) { o = row_in_tile; i = (t & 1) * 32 + col_in_tile; n_out = 16; n_in = 64; off = (int)GM_L2_OFF; }
+		else            { o = (t & 1) * 32 + row_in_tile; i = col_in_tile; n_out = 64; n_in = 32; off = (int)GM_L0_OFF; }
+		if (o < n_out && i < n_in) dst[off + o * n_in + i] = v;
+	}
+	__syncthreads();
+}
 
-// backward: recompute the MLP from the saved encoding, dgrad chain (channels 0..3 of dL_dout), planes for the weight gradients, dL/dx planes
-__global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* __restrict__ params, uint32_t n, const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout,
-                                                                  uint32_t dl_stride, h2* __restrict__ dx_planes, half_t* __restrict__ planes, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
+__global__ void __launch_bounds__(256, 2) gridmlp_backward_fused_kernel(const half_t* __restrict__ params, uint32_t n, const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout,
+                                                                        uint32_t dl_stride, h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][7168] */,
+                                                                        uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_ALL_TILES * 64];
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_kernel
+	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_fused_kernel
 	gm_stage_weights(lds_tiles, params, GM_ALL_TILES);
-	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
-	const uint32_t n_tiles = n / 32;
-	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
+	const uint32_t n_quads = n / 128;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
 	const f32x16 zero = {};
-	for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-		const uint32_t s = tile * 32 + j;
+	f32x16 acc_l1 = zero, acc_a = zero /* waves 0, 1: output matrix | waves 2, 3: input matrix */;
+	const int col = w * 32 + j;
+	const bool low_pair = __builtin_amdgcn_readfirstlane(w) < 2;
+	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+		const uint32_t s = (quad * 4 + w) * 32 + j;
 		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
 		const h8 x0 = xs[0], x1 = xs[1];
 		GmActs a;
 		f32x16 oo;
 		uint32_t lt_off = 0;
-		asm volatile("" : "+s"(lt_off));
+		asm volatile("" : "+s"(lt_off));   // keep the LDS weight reads inside the loop
 		const h8* lt = lds_tiles + lt_off;
 		gm_mlp_forward<true>(lt, lane, x0, x1, oo, &a);
 		const half_t* dl = dL_dout + (size_t)s * dl_stride;
 		h8 dout = {};
 		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; dout[3] = dl[3]; }
-		// output layer: d_h2 = relu'(h2) * (L2^T dout)
+
+		// ---- output matrix: dY = dout (16 rows), H = h2
+		fb_put(stage, 0, MAP_CH, 0, g, col, dout);
+#pragma unroll
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 16, MAP_HID, kb, g, col, a.h2[kb]);
+		__syncthreads();
+		if (low_pair) fb_job_m1n2(stage, 0, 16, w, lane, acc_a);
+		// d_h2 = relu'(h2) * (L2^T dout)
 		f32x16 t0 = NGP_MFMA(lt[(G_L2T + 0) * 64 + lane], dout, zero);
 		f32x16 t1 = NGP_MFMA(lt[(G_L2T + 1) * 64 + lane], dout, zero);
 		h8 dh[4];
 		dh[0] = mask_delta(t0, 0, a.h2[0]); dh[1] = mask_delta(t0, 1, a.h2[1]);
 		dh[2] = mask_delta(t1, 0, a.h2[2]); dh[3] = mask_delta(t1, 1, a.h2[3]);
-		store_plane(planes, n, GP_DOUT, MAP_CH, 0, g, s, dout);
+		__syncthreads();
+
+		// ---- hidden matrix: dY = d_h2, H = h1
 #pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, GP_H2, MAP_HID, kb, g, s, a.h2[kb]); store_plane(planes, n, GP_DH2, MAP_HID, kb, g, s, dh[kb]); }
-		// hidden layer: d_h1 = relu'(h1) * (L1^T d_h2)
+		for (int kb = 0; kb < 4; ++kb) { fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]); fb_put(stage, 64, MAP_HID, kb, g, col, a.h1[kb]); }
+		__syncthreads();
+		fb_job_m2n2(stage, 0, 64, w, lane, acc_l1);
+		// d_h1 = relu'(h1) * (L1^T d_h2)
 		t0 = zero; t1 = zero;
 #pragma unroll
 		for (int kb = 0; kb < 4; ++kb) {
@@ -1522,16 +1548,21 @@ __global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* 
 		}
 		dh[0] = mask_delta(t0, 0, a.h1[0]); dh[1] = mask_delta(t0, 1, a.h1[1]);
 		dh[2] = mask_delta(t1, 0, a.h1[2]); dh[3] = mask_delta(t1, 1, a.h1[3]);
+		__syncthreads();
+
+		// ---- input matrix: dY = d_h1, H = x (the saved encoding)
 #pragma unroll
-		for (int kb = 0; kb < 4; ++kb) { store_plane(planes, n, GP_H1, MAP_HID, kb, g, s, a.h1[kb]); store_plane(planes, n, GP_DH1, MAP_HID, kb, g, s, dh[kb]); }
-		store_plane(planes, n, GP_X, MAP_ENC, 0, g, s, x0);
-		store_plane(planes, n, GP_X, MAP_ENC, 1, g, s, x1);
-		// input layer: d_x = L0^T d_h1
+		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]);
+		fb_put(stage, 64, MAP_ENC, 0, g, col, x0);
+		fb_put(stage, 64, MAP_ENC, 1, g, col, x1);
+		__syncthreads();
+		if (!low_pair) fb_job_m2n1(stage, 0, 64, w - 2, lane, acc_a);
+		// d_x = L0^T d_h1
 		t0 = zero;
 #pragma unroll
 		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(G_L0T + kb) * 64 + lane], dh[kb], t0);
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {   // same row -> level mapping as nerf_backward_kernel
+		for (int q = 0; q < 4; ++q) {   // same row -> level mapping as nerf_backward_fused_kernel
 			const int lvl = 4 * q + 2 * g;
 			h2 u, v;
 			u[0] = (half_t)t0[4 * q + 0]; u[1] = (half_t)t0[4 * q + 1];
@@ -1539,80 +1570,12 @@ __global__ void __launch_bounds__(256, 2) gridmlp_backward_kernel(const half_t* 
 			dx_planes[(size_t)lvl * n + s] = u;
 			dx_planes[(size_t)(lvl + 1) * n + s] = v;
 		}
+		__syncthreads();
 	}
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// Weight gradients: dW[o][i] = sum_s dY[o][s] * H[i][s].  Contraction over samples: both operands are read straight from
-// the [row][sample] planes (64 B per lane per 64-sample step, a full 128-B line per row), K-slot <-> sample mapping is
-// identical for A and B so it never has to be made explicit.  Jobs of 2 output tiles and 3 operand row groups each.
-struct WgradJob { int dy_row, dy_rows, h_row, h_rows, w_off, n_in, two_mt; int mt0; };
-template <int NET>
-__device__ __forceinline__ WgradJob wgrad_job(int job) {
-	// GridMLP: 0/1: hidden layer rows 0..31 / 32..63, 2: output layer, 3: input layer (both row tiles)
-	switch (job) {
-		case 0: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 0};
-		case 1: return {GP_DH2, 64, GP_H1, 64, (int)GM_L1_OFF, 64, 0, 1};
-		case 2: return {GP_DOUT, 16, GP_H2, 64, (int)GM_L2_OFF, 64, 0, 0};
-		default: break;
-	}
-	return {GP_DH1, 64, GP_X, 32, (int)GM_L0_OFF, 32, 1, 0};
-}
-
-// grid (n_chunks, 6); block 256 = 4 waves; wave w handles samples [chunk*chunk_len + w*chunk_len/4, ...) in steps of 64.
-template <int NET>
-__global__ void __launch_bounds__(256) nerf_wgrad_kernel(const half_t* __restrict__ planes, uint32_t n, uint32_t chunk_len, float* __restrict__ partials /* [n_chunks][n_mlp_params] */) {
-	constexpr uint32_t N_MLP = NGP_GRIDMLP_N_PARAMS;
-	static_assert(NET == 1, "the planes path serves the GridMLP network; the NeRF backward contracts in-kernel");
-	__shared__ float red[4][2][16][64];
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r32 = lane & 31, g = lane >> 5;
-	const WgradJob jb = wgrad_job<NET>(blockIdx.y);
-	const uint32_t per_wave = chunk_len / 4;
-	const uint32_t s_begin = blockIdx.x * chunk_len + w * per_wave, s_end = s_begin + per_wave;
-
-	// operand row groups: R0, R1, R2.  two_mt: A rows (mt 0,1) + one B group;  else: one A group + B groups (nt 0,1)
-	const half_t* rowp[3]; bool rowok[3];
-	if (jb.two_mt) {
-		rowp[0] = planes + (size_t)(jb.dy_row + r32) * n;       rowok[0] = true;
-		rowp[1] = planes + (size_t)(jb.dy_row + 32 + r32) * n;  rowok[1] = true;
-		rowp[2] = planes + (size_t)(jb.h_row + r32) * n;        rowok[2] = true;
-	} else {
-		const int ar = jb.mt0 * 32 + r32;
-		rowok[0] = ar < jb.dy_rows;
-		rowp[0] = planes + (size_t)(jb.dy_row + (rowok[0] ? ar : 0)) * n;
-		rowp[1] = planes + (size_t)(jb.h_row + r32) * n;        rowok[1] = true;
-		rowp[2] = planes + (size_t)(jb.h_row + 32 + r32) * n;   rowok[2] = true;
-	}
-	f32x16 acc0 = {}, acc1 = {};
-	for (uint32_t s = s_begin; s < s_end; s += 64) {
-		h8 op[3][4];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			const h8* p = (const h8*)(rowp[k] + s + 32 * g);
-#pragma unroll
-			for (int kb = 0; kb < 4; ++kb) { h8 v = p[kb]; if (!rowok[k]) { const h8 z = {}; v = z; } op[k][kb] = v; }
-		}
-#pragma unroll
-		for (int kb = 0; kb < 4; ++kb) {
-			if (jb.two_mt) { acc0 = NGP_MFMA(op[0][kb], op[2][kb], acc0); acc1 = NGP_MFMA(op[1][kb], op[2][kb], acc1); }
-			else           { acc0 = NGP_MFMA(op[0][kb], op[1][kb], acc0); acc1 = NGP_MFMA(op[0][kb], op[2][kb], acc1); }
-		}
-	}
-	// cross-wave reduction in LDS, then one partial per block
-#pragma unroll
-	for (int r = 0; r < 16; ++r) { red[w][0][r][lane] = acc0[r]; red[w][1][r][lane] = acc1[r]; }
-	__syncthreads();
-	float* dst = partials + (size_t)blockIdx.x * N_MLP + jb.w_off;
-	for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
-		const int t = idx >> 10, r = (idx >> 6) & 15, l = idx & 63;
-		const float v = red[0][t][r][l] + red[1][t][r][l] + red[2][t][r][l] + red[3][t][r][l];
-		const int lg = l >> 5, lc = l & 31;
-		const int row_in_tile = (r & 3) + 8 * (r >> 2) + 4 * lg;
-		int o, i;
-		if (jb.two_mt) { o = t * 32 + row_in_tile; i = lc; }
-		else           { o = jb.mt0 * 32 + row_in_tile; i = t * 32 + lc; }
-		if (o < jb.dy_rows && i < jb.n_in) dst[o * jb.n_in + i] = v;
-	}
+	float* __restrict__ dst = partials + (size_t)blockIdx.x * NGP_GRIDMLP_N_PARAMS;
+	float* red = (float*)stage;   // 4 x 16 x 64 floats = 16 KiB
+	gm_flush(red, acc_l1, w, lane, 0, dst);
+	gm_flush(red, acc_a, w, lane, 1, dst);
 }
 
 // sums the per-chunk partial weight gradients.  64 parameters x 4 chunk groups per block; every thread keeps 8 independent loads in
@@ -2005,13 +1968,6 @@ int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 	return 0;
 }
 
-static uint32_t wgrad_chunks(uint32_t n) {
-	// chunk_len must be a multiple of 256 (4 waves x 64-sample steps); aim for <= 128 chunks
-	uint32_t chunk_len = 256;
-	while (n / chunk_len > 128 && (n % (chunk_len * 2) == 0)) chunk_len *= 2;
-	return n / chunk_len;
-}
-
 // scratch layout: [weight-gradient partials 512 x 10240 fp32][dL/dx planes 16 x n half2][grid partials 16 x 4 MiB][binned path: counters, item lists, run sums]
 constexpr uint32_t FB_MAX_WORKGROUPS = 512;   // two resident workgroups per CU
 static uint64_t scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS * 4u; }
@@ -2232,8 +2188,8 @@ int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* des
 	return 0;
 }
 
-static uint64_t gm_scratch_off_wgrad(uint32_t n) { return (uint64_t)GM_PLANE_ROWS * n * 2u; }
-static uint64_t gm_scratch_off_dx(uint32_t n) { return gm_scratch_off_wgrad(n) + (uint64_t)wgrad_chunks(n) * NGP_GRIDMLP_N_PARAMS * 4u; }
+// scratch layout: [weight-gradient partials 512 x 7168 fp32][dL/dx planes 16 x n half2][grid partials 16 x 4 MiB][binned path: counters, item lists, run sums]
+static uint64_t gm_scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_GRIDMLP_N_PARAMS * 4u; }
 static uint64_t gm_scratch_off_gb(uint32_t n) { return gm_scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
 static uint64_t gm_scratch_off_fx(uint32_t n) { return gm_scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
 uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n) { return gm_scratch_off_fx(n) + gb_fx_bytes(n); }
@@ -2244,20 +2200,18 @@ int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* de
 	if (n_dims != 2 && n_dims != 3) { set_last_error("ngp_hip_gridmlp_backward: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
 	if (scratch_bytes < ngp_hip_gridmlp_backward_scratch_bytes(n)) { set_last_error("ngp_hip_gridmlp_backward: scratch too small", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
-	half_t* planes = (half_t*)scratch;
-	float* partials = (float*)((char*)scratch + gm_scratch_off_wgrad(n));
+	float* partials = (float*)scratch;
 	h2* dx_planes = (h2*)((char*)scratch + gm_scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + gm_scratch_off_gb(n));
-	hipLaunchKernelGGL(gridmlp_backward_kernel, dim3(fwd_grid(n)), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, planes,
+	const uint32_t n_quads = n / 128;
+	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
+	hipLaunchKernelGGL(gridmlp_backward_fused_kernel, dim3(grid), dim3(256), 0, st, (const half_t*)params, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, partials,
 	                   (uint32_t*)((char*)scratch + gm_scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4));
-	NGP_LAUNCH_CHECK("gridmlp_backward_kernel");
+	NGP_LAUNCH_CHECK("gridmlp_backward_fused_kernel");
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
+	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	if (n_dims == 2) { if (launch_grid_backward<2>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS), true)) return -1; }
 	else { if (launch_grid_backward<3>(st, desc_dev, pos, pos_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + gm_scratch_off_fx(n), (h2*)(grads + NGP_GRIDMLP_N_PARAMS), true)) return -1; }
-	const uint32_t n_chunks = wgrad_chunks(n);
-	hipLaunchKernelGGL(nerf_wgrad_kernel<1>, dim3(n_chunks, 4), dim3(256), 0, st, (const half_t*)planes, n, n / n_chunks, partials);
-	NGP_LAUNCH_CHECK("nerf_wgrad_kernel<1>");
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_GRIDMLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, n_chunks, (half_t*)grads, (uint32_t)NGP_GRIDMLP_N_PARAMS);
-	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
 	return 0;
 }
 
