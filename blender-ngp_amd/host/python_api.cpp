@@ -760,6 +760,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("render_max_skips_per_pass", &Nerf::render_max_skips_per_pass)
 		.def_readwrite("render_pass_samples_factor", &Nerf::render_pass_samples_factor)
 		.def_readwrite("render_fused_compaction", &Nerf::render_fused_compaction)
+		.def_readwrite("render_fused_network", &Nerf::render_fused_network)
 		.def_property("light_dir", [](Nerf& n) { return vec3_to_py(n.light_dir); }, [](Nerf& n, const py::object& v) { n.light_dir = vec3_from_py(v); })   // testbed.h:712 (GUI slider in the reference)
 		.def_readwrite("extra_dim_idx_for_inference", &Nerf::extra_dim_idx_for_inference)                                                                     // testbed.h:713
 		.def_readwrite("visualize_cameras", &Nerf::visualize_cameras)

@@ -1814,7 +1814,8 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			                                   skip_allowance, brick_summary, alive_counter /* read back above; composite below bumps it */), "generate_next_inputs");
 			const uint32_t n_elements = next_multiple(n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 			m_tr_enc_ws[0].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, n_pixels)));
-			check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[0].data(), m_tr_enc_ws[0].bytes(), render_variant), "nerf_inference (render)");
+			if (m_nerf.render_fused_network) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, render_variant), "nerf_inference (render, fused)");
+			else check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[0].data(), m_tr_enc_ws[0].bytes(), render_variant), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
 			if (render_mode == (int)ERenderMode::Normals) {
 				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);

@@ -247,6 +247,7 @@ struct Nerf {
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
+	bool render_fused_network = false;       // the tracer's network pass through the fused kernel (gathers inside) instead of XCD-affine encode + MLP kernel: same samples, same bits
 	bool render_fused_compaction = true;     // compaction folded into advance_pos / composite (NgpCompactOut) instead of a pass of its own; off: the reference's loop
 	bool render_tile_order = true;           // the tracer's rays in 8 x 8 pixel tiles (NgpRenderExtras.tile_order) when the frame's size allows: same pixels, more coherent gathers
 	Vec3 light_dir{0.5f, 0.5f, 0.5f};        // testbed.h:712: the light direction presented at inference time when the dataset has light directions

@@ -58,7 +58,14 @@ def compare_march(r, g, max_samples=None):
     bumped (testbed_nerf.cu:1225-1228) — which ones depends on the order the atomics were served in, in the reference as much as here — so the kept
     sets may then differ by a few rays; every ray kept by both must still agree bit for bit and every kept run must fit the budget."""
     n_ref, n_got = int(r["rc"][0]), int(g["rc"][0])
-    assert int(g["nc"][0]) == int(r["nc"][0]), (int(g["nc"][0]), int(r["nc"][0]))                 # bit-exact sample count
+    if int(g["nc"][0]) != int(r["nc"][0]):                                                         # bit-exact sample count; say which rays disagree
+        ref = {int(r["idx"][k]): int(r["ns"][2 * k]) for k in range(n_ref)}
+        got = {int(g["idx"][k]): int(g["ns"][2 * k]) for k in range(n_got)}
+        only_r, only_g = sorted(set(ref) - set(got)), sorted(set(got) - set(ref))
+        diff = [(k, ref[k], got[k]) for k in ref if k in got and ref[k] != got[k]]
+        raise AssertionError("sample counter: device %d, oracle %d (budget %s); rays kept: device %d, oracle %d; only oracle %d rays / %d samples, only device %d rays / %d samples; "
+                             "kept by both with different counts: %d %s" % (int(g["nc"][0]), int(r["nc"][0]), max_samples, n_got, n_ref, len(only_r), sum(ref[k] for k in only_r),
+                                                                          len(only_g), sum(got[k] for k in only_g), len(diff), diff[:8]))
     overflow = max_samples is not None and int(r["nc"][0]) > max_samples
     if not overflow:
         assert n_got == n_ref, (n_got, n_ref)                                                      # bit-exact ray count

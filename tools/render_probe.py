@@ -25,6 +25,9 @@ for _ in range(n):
     tb.render(res, res, 1, True)
 dt = (time.perf_counter() - t0) / n
 print("psnr %.2f  eval wall per frame %.2f ms" % (psnr, dt * 1e3), per)
+if os.environ.get("NGP_PROBE_ONLY"):   # tools/render_kstats.sh: exactly 1 evaluation frame + 1 warm frame + n timed frames were rendered
+    print("frames_rendered %d  wall per frame %.2f ms  network samples %d" % (n + 2, dt * 1e3, tb.render_samples_evaluated))
+    sys.exit(0)
 variants = ((True, True),) if os.environ.get("NGP_PROBE_PLAIN") else ((False, False), (True, False), (False, True), (True, True), (False, False), (True, True))
 for tile, fused in variants:
     tb.nerf.render_fused_compaction = fused
@@ -35,6 +38,21 @@ for tile, fused in variants:
         tb.render(res, res, 1, True)
     dt = (time.perf_counter() - t0) / n
     print("tile_order %s fused_compaction %s: %.2f ms / frame, %d network samples" % (tile, fused, dt * 1e3, tb.render_samples_evaluated))
+
+if os.environ.get("NGP_PROBE_FUSED"):   # the network pass: XCD-affine encode + MLP kernel vs the fused kernel, alternating on one model
+    tb.nerf.render_fused_compaction = True
+    tb.nerf.render_tile_order = True
+    for fused in (False, True, False, True):
+        tb.nerf.render_fused_network = fused
+        tb.render(res, res, 1, True)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            tb.render(res, res, 1, True)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print("fused network pass %s: median %.2f ms  min %.2f ms / frame, %d network samples" % (fused, ts[len(ts) // 2] * 1e3, ts[0] * 1e3, tb.render_samples_evaluated))
+    tb.nerf.render_fused_network = False
 
 if os.environ.get("NGP_PROBE_SWEEP"):   # one model, many tracer settings: "factor:skips:cap,..."
     tb.nerf.render_fused_compaction = True
