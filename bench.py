@@ -31,7 +31,7 @@ OPT_BYTES_PER_PARAM = 36       # grads 2 + master 4+4 + m 4+4 + v 4+4 + fp16 2 +
 BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
 MARCH_BYTES_PER_SAMPLE = 28    # one NerfCoordinate written per sample (nerf.h:62-107)
 MARCH_BYTES_PER_RAY = 40       # ray index 4 + Ray 24 + numsteps 8 written, one RGBA8 pixel read (testbed_nerf.cu:1232-1258)
-KERNEL_SET = "r03c"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
+KERNEL_SET = "r03d"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
 GROUP_KERNELS = {"grad_exchange": "data-parallel step: fp16 -> fp32 copy, RCCL reduce-scatter (fp32 sums), fp32 -> fp16 of this rank's shard", "param_gather": "data-parallel step: RCCL all-gather of the fp16 weights",
                  "nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
                  "nerf_inference": "one ngp_hip_nerf_forward call: fused hash-grid encode + both MLPs (single kernel)", "optimizer_step": "adam_ema_vec4_kernel (single kernel)"}
@@ -430,7 +430,10 @@ def main():
         psnr, ssim, per = scene.eval_test_views(tb, ds, spp=a.eval_spp, max_views=a.n_test)
         n_frames = 9
         tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
-        tb.render(a.res, a.res, 1, True)     # untimed: the PSNR / SSIM arithmetic above ran on the host, the GPU's clocks have dropped (the first frame after it takes up to twice as long)
+        # untimed: the PSNR / SSIM arithmetic above ran on the host for seconds and the GPU's clocks have dropped — the first frames after it take 3-5x as long
+        # (r03_d: 28.2 ms, then 5.3-6.0 ms), so the leg warms up with a fixed number of frames before the timed ones, like the training leg's warm-up steps
+        for _ in range(4):
+            tb.render(a.res, a.res, 1, True)
         if render_sharded:
             dist.barrier()
         frame_ms = []
@@ -448,7 +451,7 @@ def main():
             t = torch.tensor([n_render_samples], dtype=torch.float64, device=dev)
             dist.all_reduce(t)
             n_render_samples = float(t.item())
-        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
+        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_warmup_frames": 4, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
                  "render_ranks": world if render_sharded else 1, "render_rows_per_rank": (a.res + world - 1) // world if render_sharded else a.res,
                  "psnr_db": round(psnr, 2), "ssim": round(ssim, 4), "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
 
