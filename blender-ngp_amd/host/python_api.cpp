@@ -583,6 +583,8 @@ PYBIND11_MODULE(pyngp, m) {
 				d["coords"] = f32(c.coords, (size_t)c.max_inference * 7);
 				d["gen_counters"] = u32(c.gen_counters, 2);                         // {rays kept, samples (may exceed max_inference)}
 				d["density_grid_mean"] = f32(c.density_grid_mean, 1);
+				d["bitfield"] = bytes(c.bitfield, c.bitfield.bytes());
+				d["prefetch_hit"] = c.prefetch_hit;
 				d["numsteps_compacted"] = u32(c.numsteps_compacted, (size_t)c.R * 2);
 				d["coords_compacted"] = f32(c.coords_compacted, (size_t)c.target_batch_size * 7);   // before the roll-over
 				d["dloss"] = u16(c.dloss, (size_t)c.target_batch_size * 4);                       // before the roll-over / rescale

@@ -1118,6 +1118,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		capture_copy(cap.coords, m_coords.data(), (size_t)max_inference * sizeof(NgpCoord));
 		capture_copy(cap.gen_counters, gen_counters, 8);
 		capture_copy(cap.density_grid_mean, m_nerf.density_grid_mean.data(), 4);
+		capture_copy(cap.bitfield, m_nerf.density_grid_bitfield.data(), m_nerf.density_grid_bitfield.bytes());   // the occupancy bits as the step's first kernels see them
+		cap.prefetch_hit = hit;
 	}
 	if (m_compact_slot_zeroed == m_gen_slot) m_compact_slot_zeroed = -1;   // cleared by the previous step's post_words launch
 	else HIP_CHECK_THROW(hipMemsetAsync(compacted_counter, 0, 8, (hipStream_t)m_stream));   // word 2: the compaction counter, word 3: the ray queue of the forward pass

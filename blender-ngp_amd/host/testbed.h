@@ -399,7 +399,8 @@ public:
 		bool armed = false, valid = false;
 		uint32_t step = 0, R = 0, max_inference = 0, n_rays_global = 0, ray_offset = 0, target_batch_size = 0;
 		uint64_t rng_state = 0, rng_inc = 0;
-		DeviceBuffer params, ray_indices, rays, numsteps, coords, gen_counters, numsteps_compacted, coords_compacted, dloss, density_grid_mean;
+		DeviceBuffer params, ray_indices, rays, numsteps, coords, gen_counters, numsteps_compacted, coords_compacted, dloss, density_grid_mean, bitfield;
+		bool prefetch_hit = false;
 	} m_capture;
 	void debug_capture_next_step() { m_capture.armed = true; m_capture.valid = false; }
 	const DeviceBuffer& debug_buffer(const std::string& name) const;   // step scratch by name: "mlp_out", "coords_compacted", "dloss", "x_saved", "grads", "coords"

@@ -52,7 +52,7 @@ def device_march(cap):
                 co=cap["coords"].view(H.COORD))
 
 
-def compare_march(r, g, max_samples=None):
+def compare_march(r, g, max_samples=None, note=""):
     """bit-exact: the sample counter, and per ray the kept-ray record and every sample record (slot order is scheduling-dependent).
     When the step's demand exceeds its budget (numsteps counter > max_samples) the rays whose run would not fit are dropped AFTER the counter was
     bumped (testbed_nerf.cu:1225-1228) — which ones depends on the order the atomics were served in, in the reference as much as here — so the kept
@@ -64,8 +64,8 @@ def compare_march(r, g, max_samples=None):
         only_r, only_g = sorted(set(ref) - set(got)), sorted(set(got) - set(ref))
         diff = [(k, ref[k], got[k]) for k in ref if k in got and ref[k] != got[k]]
         raise AssertionError("sample counter: device %d, oracle %d (budget %s); rays kept: device %d, oracle %d; only oracle %d rays / %d samples, only device %d rays / %d samples; "
-                             "kept by both with different counts: %d %s" % (int(g["nc"][0]), int(r["nc"][0]), max_samples, n_got, n_ref, len(only_r), sum(ref[k] for k in only_r),
-                                                                          len(only_g), sum(got[k] for k in only_g), len(diff), diff[:8]))
+                             "kept by both with different counts: %d %s %s" % (int(g["nc"][0]), int(r["nc"][0]), max_samples, n_got, n_ref, len(only_r), sum(ref[k] for k in only_r),
+                                                                             len(only_g), sum(got[k] for k in only_g), len(diff), diff[:8], note))
     overflow = max_samples is not None and int(r["nc"][0]) > max_samples
     if not overflow:
         assert n_got == n_ref, (n_got, n_ref)                                                      # bit-exact ray count
@@ -153,11 +153,23 @@ def borderline_rays(cap):
     out = set()
     for i in range(n_alive):
         n, b = int(ns[2 * i]), int(ns[2 * i + 1])
-        dt = dt_w[b:b + n] * (MIN_STEP * 1024 - MIN_STEP) + MIN_STEP    # unwarp_dt (testbed_nerf.cu:284-289): MAX_CONE_STEPSIZE = 1024 * MIN_CONE_STEPSIZE (:61)
+        dt = dt_w[b:b + n] * (MIN_STEP * 128 - MIN_STEP) + MIN_STEP     # unwarp_dt (testbed_nerf.cu:313-316): max_stepsize = MIN_CONE_STEPSIZE * 2^(NERF_CASCADES - 1) — NOT MAX_CONE_STEPSIZE
         T = np.cumprod(np.exp(-np.exp(np.minimum(sig[b:b + n], 15.0)) * dt))
         if np.any(np.abs(T - 1e-4) < 2e-7):
             out.add(i)
     return out
+
+
+def describe_compaction_mismatch(cap, o_ns, slot):
+    """why did ray slot `slot` keep different sample counts?  (float64 replay of its transmittance around the oracle's and the device's cut)"""
+    ns = cap["numsteps"]
+    n, b = int(ns[2 * slot]), int(ns[2 * slot + 1])
+    sig = cap["mlp_out"].view(np.float16).reshape(-1, 4)[b:b + n, 3].astype(np.float64)
+    dt = cap["coords"].reshape(-1, 7)[b:b + n, 3].astype(np.float64) * (MIN_STEP * 128 - MIN_STEP) + MIN_STEP
+    T = np.cumprod(np.exp(-np.exp(np.minimum(sig, 15.0)) * dt))
+    ko, kd = int(o_ns[2 * slot]), int(cap["numsteps_compacted"][2 * slot])
+    lo, hi = max(0, min(ko, kd) - 3), min(n, max(ko, kd) + 2)
+    return "slot %d: %d marched samples, oracle keeps %d, device keeps %d; T[%d:%d] = %s; sigma = %s" % (slot, n, ko, kd, lo, hi, ["%.4g" % t for t in T[lo:hi]], ["%.3f" % x for x in sig[lo:hi]])
 
 
 def oracle_backward(orc, S, cap, n=None):
