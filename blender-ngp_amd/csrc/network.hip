@@ -534,15 +534,19 @@ __device__ __forceinline__ bool level_is_dense(const NgpGridLevel& lv) {
 
 // one term of tcnn's kernel_grid_backward, half(w * dL/dx), as an exact multiple of 2^-24 (integer part * 2^24 + fraction * 2^24, both native
 // fp32 -> int32 conversions); inf / nan terms (a step the loss scaler is about to skip) would poison the integer sums and are dropped
-__device__ __forceinline__ long long gb_term_fixed(float w_times_g) {
+__device__ __forceinline__ half_t gb_term_half(float w_times_g) {
 	// tcnn: (T)(weight * grad) = fp32 product, THEN fp16.  The compiler would fold the caller's multiply into v_fma_mixlo_f16, which rounds
 	// the exact product once; the empty asm keeps the fp32 rounding
 	asm("" : "+v"(w_times_g));
-	const float t = (float)(half_t)w_times_g;
+	return (half_t)w_times_g;
+}
+__device__ __forceinline__ long long gb_half_fixed(half_t term) {
+	const float t = (float)term;
 	if (!(fabsf(t) < 65520.0f)) return 0ll;
 	const float fl = floorf(t);
 	return (long long)(int)fl * 16777216ll + (long long)(uint32_t)((t - fl) * 16777216.0f);
 }
+__device__ __forceinline__ long long gb_term_fixed(float w_times_g) { return gb_half_fixed(gb_term_half(w_times_g)); }
 // exact fixed-point sum -> fp16 with ONE rounding: round to odd at 24 bits, then nearest-even to 11
 __device__ __forceinline__ half_t gb_fixed_to_half(unsigned long long bits) {
 	const long long a = (long long)bits;
@@ -601,13 +605,18 @@ __device__ __forceinline__ uint32_t gb_owner_start(const GbFxCounters* __restric
 	return *s_start;
 }
 
+// what a hashed level's item carries to its owner (12 bytes, in the level's run-sum region of the scratch): the two x-corner entries inside the slice, 12 bits each, and
+// the four terms half(w_x0 * g0), half(w_x0 * g1), half(w_x1 * g0), half(w_x1 * g1)
+struct GbRecord { uint32_t entries; half_t t[4]; };
+static_assert(sizeof(GbRecord) == 12 && 4u * sizeof(GbRecord) <= GB_ITEMS_PER_SAMPLE * 16u, "records of a sample fit the level's run-sum slots");
+
 // passes 1 and 3 of the counting sort.  grid (ceil(n / GB_FX_CHUNK), 16 levels), block 256.  SCATTER = false: per-bin totals;
 // SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
 // hashed level: item = sample << 3 | (y, z) pair, bin = slice.
 template <int D, bool SCATTER>
 __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, const NgpGridLevel& lv, uint32_t level,
                                               const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                              GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items) {
+                                              GbFxCounters* __restrict__ ctr, ulonglong2* __restrict__ sums) {
 	constexpr int NI = D == 3 ? 4 : 2;
 	constexpr int PER = GB_FX_CHUNK / 256;
 	const uint32_t hmask = lv.size - 1;
@@ -648,14 +657,31 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 		base[threadIdx.x] = hist[threadIdx.x] ? start + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
 	}
 	__syncthreads();
-	uint32_t* __restrict__ out = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE;
+	// An item leaves as a finished RECORD: the two x-corner entries inside the slice and their four fp16 terms half(w * dL/dx) — this pass has the position and dL/dx in
+	// registers anyway.  The owners then stream 12-byte records instead of gathering a position and a dL/dx pair per item (two random L2 requests each: what bound them).
+	GbRecord* __restrict__ out = (GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
-		const uint32_t s = blockIdx.x * GB_FX_CHUNK + u * 256 + threadIdx.x;
+		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
+		const float g0 = (float)gq[u][0], g1 = (float)gq[u][1];
 #pragma unroll
 		for (int m = 0; m < NI; ++m) {
 			const uint32_t c = code[u][m];
-			if (c != 0xffffffffu) out[base[c >> 16] + (c & 0xffffu)] = (s << 3) | (uint32_t)m;
+			if (c == 0xffffffffu) continue;
+			const uint32_t yb = m & 1u, zb = m >> 1;
+			const uint32_t hb = ((p.gy + yb) * 2654435761u) ^ (D == 3 ? (p.gz + zb) * 805459861u : 0u);
+			const float wy = yb ? p.fy : (1.0f - p.fy), wz = zb ? p.fz : (1.0f - p.fz);
+			GbRecord r;
+			uint32_t e[2];
+#pragma unroll
+			for (uint32_t xb = 0; xb < 2; ++xb) {
+				e[xb] = ((hb ^ (p.gx + xb)) & hmask) & (GB_FX_SLICE - 1);
+				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
+				if (D == 3) w *= wz;
+				r.t[2 * xb] = gb_term_half(w * g0); r.t[2 * xb + 1] = gb_term_half(w * g1);
+			}
+			r.entries = e[0] | (e[1] << 12);
+			out[base[c >> 16] + (c & 0xffffu)] = r;
 		}
 	}
 }
@@ -772,14 +798,13 @@ __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __rest
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
 	if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums, wg_hist);
-	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, items);
+	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
 }
 
 // pass 4: the owner of (level, slice) adds its items into 8192 x 2 64-bit fixed-point words in LDS and writes the final fp16 gradients
 template <int D>
-__device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t sl,
-                                                 const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                                 const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, h2* __restrict__ grid_grad, uint32_t* __restrict__ s_start) {
+__device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict__ slice64, const NgpGridLevel& lv, uint32_t level, uint32_t sl, uint32_t n,
+                                                 const GbFxCounters* __restrict__ ctr, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t* __restrict__ s_start) {
 	if (sl >= lv.size / GB_FX_SLICE) return;
 	h2* __restrict__ dst = grid_grad + lv.offset + (size_t)sl * GB_FX_SLICE;
 	const uint32_t count = ctr->totals[level][sl];
@@ -790,38 +815,20 @@ __device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict_
 	}
 	for (uint32_t i = threadIdx.x; i < 2 * GB_FX_SLICE; i += blockDim.x) slice64[i] = 0ull;
 	__syncthreads();
-	const uint32_t hmask = lv.size - 1;
-	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	const uint32_t* __restrict__ my = items + (size_t)level * n * GB_ITEMS_PER_SAMPLE + gb_owner_start(ctr, level, sl, s_start);
+	const GbRecord* __restrict__ my = (const GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE) + gb_owner_start(ctr, level, sl, s_start);
 	constexpr uint32_t UN = 8;
 	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
-		uint32_t it[UN]; h2 gq[UN]; float px[UN], py[UN], pz[UN];
+		GbRecord r[UN];
 #pragma unroll
-		for (uint32_t u = 0; u < UN; ++u) { const uint32_t i = i0 + u * blockDim.x; it[u] = my[i < count ? i : 0]; }
-#pragma unroll
-		for (uint32_t u = 0; u < UN; ++u) {
-			const uint32_t s = it[u] >> 3;
-			gq[u] = dxl[s];
-			const float* c = coords + (size_t)s * coord_stride;
-			if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
-		}
+		for (uint32_t u = 0; u < UN; ++u) { const uint32_t i = i0 + u * blockDim.x; r[u] = my[i < count ? i : 0]; }
 #pragma unroll
 		for (uint32_t u = 0; u < UN; ++u) {
 			if (i0 + u * blockDim.x >= count) continue;
-			const uint32_t m = it[u] & 3u;
-			const float g0 = (float)gq[u][0], g1 = (float)gq[u][1];
-			const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
-			const uint32_t yb = m & 1u, zb = m >> 1;
-			const uint32_t base = ((p.gy + yb) * 2654435761u) ^ (D == 3 ? (p.gz + zb) * 805459861u : 0u);
-			const float wy = yb ? p.fy : (1.0f - p.fy), wz = zb ? p.fz : (1.0f - p.fz);
 #pragma unroll
 			for (uint32_t xb = 0; xb < 2; ++xb) {
-				const uint32_t idx = (base ^ (p.gx + xb)) & hmask;
-				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
-				if (D == 3) w *= wz;
-				// tcnn kernel_grid_backward adds half2(w * dL/dx): the terms are rounded to fp16 like there, their sum is exact
-				const long long v0 = gb_term_fixed(w * g0), v1 = gb_term_fixed(w * g1);
-				const uint32_t e = idx & (GB_FX_SLICE - 1);
+				// tcnn kernel_grid_backward adds half2(w * dL/dx): the terms were rounded to fp16 like there (by the binning pass), their sum is exact
+				const long long v0 = gb_half_fixed(r[u].t[2 * xb]), v1 = gb_half_fixed(r[u].t[2 * xb + 1]);
+				const uint32_t e = (r[u].entries >> (12u * xb)) & (GB_FX_SLICE - 1);
 				if (v0) atomicAdd(&slice64[2 * e], (unsigned long long)v0);
 				if (v1) atomicAdd(&slice64[2 * e + 1], (unsigned long long)v1);
 			}
@@ -887,7 +894,7 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation (tools/gb_level_probe.py); all ones in production
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
-	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, coords, coord_stride, n, dx_planes, ctr, items, grid_grad, &s_start); return; }
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, n, ctr, sums, grid_grad, &s_start); return; }
 	if (dense && gb_dense_binned(lv.size)) { gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad, &s_start); return; }
 	h2* __restrict__ slice = (h2*)slice64;
 	h2* __restrict__ partials = (h2*)partials_raw;
