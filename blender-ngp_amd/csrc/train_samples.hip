@@ -676,11 +676,12 @@ static int generate_training_samples_impl(
 	if (mode_env) march_mode = (uint32_t)mode_env;
 	if (cone_angle_constant == 0.0f && march_mode != NGP_MARCH_LANE_PER_RAY) {
 		// all workgroups resident at once (4 per CU): the kernel has the chip to itself in this mode
-		// NGP_MARCH_WAVE_PER_RAY: all workgroups resident at once (the kernel has the chip to itself).  NGP_MARCH_WAVE_PER_RAY_SHARED: two persistent
-		// workgroups per CU — beside the step's backward pass every further march wave costs that pass more than it gains the march
-		// (sweep 192 ... 4096 workgroups: step 0.75 / 0.61 at 512 / 0.64 ms)
+		// NGP_MARCH_WAVE_PER_RAY: all workgroups resident at once (the kernel has the chip to itself).  NGP_MARCH_WAVE_PER_RAY_SHARED: 2.5 persistent
+		// workgroups per CU — beside the step's backward pass every further march wave costs that pass more than it gains the march.  The optimum moves with the
+		// balance of the step's two chains (round 2, backward group 245 us: sweep 192 ... 4096 workgroups, step 0.75 / 0.61 at 512 / 0.64 ms; round 3, group 210 us:
+		// 512 -> 0.572-0.595, 640 -> 0.546-0.557, 768 -> 0.555-0.562, 1024 -> 0.552-0.555 ms: the march had become the longer chain)
 		static const uint32_t wg_cap_env = getenv("NGP_HIP_GEN_WGS") ? (uint32_t)atoi(getenv("NGP_HIP_GEN_WGS")) : 0u;   // dev: sweep
-		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 512u : 4096u);
+		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 640u : 4096u);
 		hipLaunchKernelGGL(generate_training_samples_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
 		NGP_LAUNCH_CHECK("generate_training_samples_wave_kernel");
 		return 0;
