@@ -498,6 +498,23 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source, "launch_group": GROUP_KERNELS.get(dom),
                 "algorithmic_bytes_per_unit": bytes_per_unit[dom], "units_per_launch": kernels[dom]["units_per_launch"], "avg_launch_us": kernels[dom]["avg_us"]}
+    # the longest SINGLE kernel on the step's critical chain that has a byte model: the network pass (one C-ABI call = one kernel, nerf_forward_kernel<2, 0>: fused hash
+    # encode + both MLPs over every marched sample).  `roofline` above is quoted for the largest launch GROUP (seven kernels behind one call) as in rounds 1-2; this is the
+    # per-kernel view next to it, HIP events on the launch stream over the untimed survey steps (inside the timed region only the dominant group is bracketed).
+    if "nerf_inference" in kernels and "algorithmic_GBps" in kernels["nerf_inference"]:
+        fk = kernels["nerf_inference"]
+        f_traffic = None
+        try:
+            tj2 = json.load(open(tpath))
+            if tj2.get("_meta", {}).get("kernel_set") == KERNEL_SET:
+                f_traffic = tj2.get("nerf_inference")
+        except Exception:
+            pass
+        line_single = {"kernel": "nerf_forward_kernel<2,0>", "bound": "hbm", "achieved": fk["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fk["algorithmic_GBps"] / HBM_PEAK_GBS, 4),
+                       "traffic": f_traffic, "algorithmic_bytes_per_unit": bytes_per_unit["nerf_inference"], "units_per_launch": fk["units_per_launch"], "avg_launch_us": fk["avg_us"],
+                       "measured": "HIP events on the launch stream, %d untimed survey steps" % SURVEY_STEPS}
+    else:
+        line_single = None
     mpath = os.path.join(ROOT, "profiles", "mfma_util.json")
     if os.path.exists(mpath):
         try:
@@ -524,7 +541,7 @@ def main():
                    "global_batch": B if a.scaling == "strong" else B * world, "parallelism": "dp%d" % world if use_dp else "single", "dp_impl": dp_impl},
         "rays_per_s": round(rays / dt, 1), "pre_compaction_samples_per_s": round(pre_compaction / dt, 1),
         "pretrain_steps": pretrain_steps, "timed_from_training_step": int(timed_from), "psnr_at_bench": None if psnr_at_bench is None else round(psnr_at_bench, 2),
-        "roofline": roofline, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
+        "roofline": roofline, "roofline_longest_single_kernel": line_single, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
     if use_dp:   # what the communicator itself says, and what the step's exchanges cost (HIP events on the training stream, survey steps)

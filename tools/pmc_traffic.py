@@ -13,7 +13,8 @@ import re
 import sys
 
 # kernel-name substring -> stage (one stage = one ngp_hip_* entry point as bench.py times it)
-STAGES = [("nerf_forward_kernelILi0ELb0E", "nerf_inference"), ("nerf_forward_kernelILi2ELb0E", "nerf_forward"), ("nerf_forward_kernelILi1E", "density_grid_prep"),
+STAGES = [("nerf_forward_kernelILi2ELi0E", "nerf_inference"),   # the training step's one network pass (MODE 2 = forward with saved encodings, PRE 0 = gathers inside); bench.py's group name
+          ("nerf_forward_kernelILi1E", "density_grid_prep"),
           ("encode_planes_kernel", "density_grid_prep"),
           ("nerf_backward_fused_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("gb_fx_bin_kernel", "nerf_backward"), ("gb_fx_scan_kernel", "nerf_backward"),
