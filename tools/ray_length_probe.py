@@ -35,3 +35,16 @@ print("histogram of marched per ray:", np.histogram(ns[:, 0], bins=[0, 1, 8, 16,
 print("histogram of kept per ray:   ", np.histogram(kept, bins=[0, 1, 8, 16, 32, 64, 128, 256, 1025])[0].tolist())
 full = kept == ns[:, 0]
 print("rays that keep every sample: %d (%.1f %%), their samples: %d" % (full.sum(), 100.0 * full.mean(), ns[full, 0].sum()))
+# two-pass schemes: pass 1 evaluates the first K samples of every ray, pass 2 the rest of the rays whose optical depth after K samples has not passed -ln(1e-4) + 0.5
+tau_stop = -np.log(1e-4) + 0.5
+for K in (32, 48, 64, 96):
+    ev = 0
+    for i in range(n_rays):
+        n, b = ns[i]
+        dt = dtw[b:b + n] * (MIN_STEP * 128 - MIN_STEP) + MIN_STEP
+        tau = np.cumsum(np.exp(sig[b:b + n]) * dt)
+        first = min(n, K)
+        ev += first
+        if n > K and tau[K - 1] < tau_stop:
+            ev += n - K
+    print("two passes, K = %3d: evaluate %d samples = %.3f of marched" % (K, ev, ev / tot))
