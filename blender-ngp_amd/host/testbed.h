@@ -242,7 +242,7 @@ struct Nerf {
 	float render_min_transmittance = 0.01f;  // testbed.h:725
 	uint32_t render_n_streams = 1;           // >1 traces the frame as independent pixel ranges on separate streams (measured slower on ROCm 7.0: 16 -> 28 ms at 2)
 	uint32_t render_max_skips_per_pass = 96; // fused-compaction tracer: empty voxels a ray may step over per pass before it rests until the next one (ngp_hip_generate_next_inputs); 0: no limit, as the reference.  Same image.
-	float render_pass_samples_factor = 3.0f; // fused-compaction tracer: network samples per pass = this x the frame's pixels (the reference: 1); [1, 4].  Same image; 800x800 on MI355X: 1 -> 7.3 ms, 2 -> 5.8, 3 -> 5.4, 4 -> 5.35 (fewer, larger passes: tools/render_probe.py)
+	float render_pass_samples_factor = 4.0f; // fused-compaction tracer: network samples per pass = this x the frame's pixels (the reference: 1); [1, 4].  Same image; 800x800 on MI355X: 1 -> 7.3 ms, 2 -> 5.8, 3 -> 5.4, 4 -> 5.35 (fewer, larger passes: tools/render_probe.py)  Round 3 re-sweep at HEAD (tools/render_probe.py NGP_PROBE_SWEEP): 3 -> 5.63 ms, 4 -> 5.48 ms: 4.
 	uint32_t render_max_steps_per_pass = 64; // the reference's m_max_steps_inbetween_compactions is 8 (testbed.h NerfTracer)
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
