@@ -286,6 +286,8 @@ def main():
                     "counters, its own RCCL communicator), frame() as on one GPU; torch: the same exchanges driven from this script through torch.distributed (dp_step). product falls back to torch if it cannot initialise")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: 2^18 compacted samples per GPU and step (N x the global batch); strong: 2^18 per step over all GPUs (the reference's convergence per step)")
     ap.add_argument("--min_train_step", type=int, default=1000, help="BASELINE.md M1 quotes the metric on steps [1000, 2000): the timed region never starts before this training step, whatever --warmup says")
+    ap.add_argument("--legs", default="fox,bl_render,plumbing", help="comma list of the extra legs of a one-GPU run (bench_legs.py): fox = BASELINE config #2 on the fox photographs, bl_render = the Blender "
+                    "multi-NeRF renderer next to the stock tracer, plumbing = configs #1 / #5 at 2^18; 'none' switches them off")
     ap.add_argument("--psnr_gate", type=float, default=35.0, help="BASELINE config #3 'train to 35 PSNR then render': keep pre-training (untimed) until the held-out PSNR reaches this")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -554,6 +556,25 @@ def main():
         line["data_parallel"] = dp_info
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(tb, ds, a.res)
+    # ---- the other configs BASELINE names and the fork's own renderer, measured inside this run (bench_legs.py); a leg that fails says why and does not take the line down
+    legs = [x for x in a.legs.split(",") if x and x != "none"] if world == 1 else []
+    if legs:
+        import bench_legs
+        tb.set_profiling(False)
+        for leg in legs:
+            t_leg = time.perf_counter()
+            try:
+                if leg == "fox":
+                    line["fox"] = bench_legs.fox_leg(max(a.steps, 100), BYTES_PER_UNIT, a.min_train_step)
+                elif leg == "bl_render" and not a.no_render:
+                    line["bl_render"] = bench_legs.bl_render_leg(tb, ds, a.res)
+                elif leg == "plumbing":
+                    line["plumbing"] = bench_legs.plumbing_leg()
+                else:
+                    continue
+            except Exception as e:
+                line[leg] = {"failed": repr(e)}
+            line[leg]["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
     print(json.dumps(line), flush=True)
     if use_dp:
         dist.barrier()

@@ -1,0 +1,225 @@
+"""bench_legs.py — the legs of the default `python bench.py` line that are not its headline: every performance figure README / DESIGN quote outside the
+lego stand-in is measured HERE, inside the driver's run, or not quoted at all.
+
+    fox        BASELINE config #2 on its own data (the reference's data/nerf/fox photographs, staged by build() under tests/golden/_generated/fox):
+               aabb_scale 4 => three cascades, cone stepping (cone_angle_constant 1/256, src/testbed_nerf.cu:2730), OpenCV lens; train samples/s, ms/step, the
+               launch-group table, the march's own time, render MP/s at the photographs' 1080 x 1920
+    bl_render  the fork's Blender multi-NeRF renderer (src/nerf_renderer.cu:565-791) on the trained headline model: ms per 800 x 800 frame for one and two
+               instances next to the stock tracer's ms for the same view
+    plumbing   BASELINE configs #1 (image, 1024^2) and #5 (SDF) at the reference batch 2^18: ms/step, samples/s and the MFMA TFLOP/s the step's FLOP model gives
+
+All legs run on rank 0 of a one-GPU run, after the headline's timed region, each bounded to a few seconds.
+"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "blender-ngp_amd")
+CFG = os.path.join(PKG, "configs")
+FOX = os.path.join(ROOT, "tests", "golden", "_generated", "fox", "transforms.json")
+MFMA_PEAK_F16_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
+
+# FLOP model of one gridmlp step per sample (DESIGN.md 8 "Plumbing configs"): the MLP 32 -> 64 -> 64 -> 16 (padded output) forward = 2 * (32*64 + 64*64 + 64*16) = 14 336;
+# the fused backward recomputes the forward (14 336), runs dgrad through the three matrices (14 336) and the three weight-gradient contractions (14 336)
+GRIDMLP_FLOP_PER_SAMPLE = 4 * 2 * (32 * 64 + 64 * 64 + 64 * 16)
+
+
+def _group_table(prof, bytes_per_unit):
+    out = {}
+    for name, e in prof.items():
+        if e["launches"]:
+            k = {"launches": int(e["launches"]), "avg_us": round(1000.0 * e["ms"] / e["launches"], 2), "units_per_launch": round(e["units"] / e["launches"], 1)}
+            if name in bytes_per_unit:
+                k["algorithmic_GBps"] = round(bytes_per_unit[name] * e["units"] / (e["ms"] * 1e-3) / 1e9, 1)
+            out[name] = k
+    return out
+
+
+def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_peak=8000.0):
+    """config #2: the fox photographs through `load_training_data` (host/nerf_loader.cpp + jpeg_reader.cpp), default base.json, B = 2^18."""
+    if not os.path.exists(FOX):
+        return {"skipped": "tests/golden/_generated/fox is staged by build() where /root/reference exists; not present in this checkout"}
+    import pyngp
+    B = 1 << 18
+    t_load = time.perf_counter()
+    tb = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    tb.load_training_data(FOX)
+    tb.reload_network_from_file(os.path.join(CFG, "nerf", "base.json"))
+    t_load = time.perf_counter() - t_load
+    tr = tb.nerf.training
+    tb.async_training_steps = True
+    tb.shall_train = True
+    while tb.training_step < min_train_step:
+        tb.frame()
+    tb.set_profiling(True)
+    tb.reset_profile()
+    for _ in range(survey_steps):
+        tb.frame()
+    survey = tb.profile()
+    tb.set_profiling(False)
+    tb.sync()
+    timed_from = tb.training_step
+    samples = rays = pre = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rays += tr.rays_per_batch
+        tb.frame()
+        samples += min(tr.measured_batch_size, B)
+        pre += tr.measured_batch_size_before_compaction
+    tb.sync()
+    dt = time.perf_counter() - t0
+    kernels = _group_table(survey, bytes_per_unit)
+    out = {"workload": "data/nerf/fox of the reference: %d photographs 1080 x 1920 (.jpg), aabb_scale 4 (3 cascades), cone_angle_constant 1/256, OpenCV lens, configs/nerf/base.json, batch 2^18" % len(list(tr.paths)),
+           "value": round(samples / dt, 1), "unit": "samples/s", "ms_per_step": round(1000.0 * dt / steps, 4), "steps": steps, "timed_from_training_step": int(timed_from),
+           "rays_per_step": round(rays / steps, 1), "pre_compaction_samples_per_step": round(pre / steps, 1), "load_s": round(t_load, 2), "loss": round(float(tb.loss), 5),
+           "n_params": int(tb.n_params()), "kernels": kernels, "kernels_note": "HIP events on the launch streams, %d untimed survey steps" % survey_steps}
+    if "nerf_backward" in kernels and "algorithmic_GBps" in kernels["nerf_backward"]:
+        k = kernels["nerf_backward"]
+        out["roofline"] = {"kernel": "nerf_backward", "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": hbm_peak, "unit": "GB/s", "frac": round(k["algorithmic_GBps"] / hbm_peak, 4), "traffic": None}
+    # render at the photographs' size from a training view (pose, intrinsics and lens of the view: testbed.cu:273-281)
+    tb.shall_train = False
+    tb.background_color = [0.0, 0.0, 0.0, 1.0]
+    tb.snap_to_pixel_centers = True
+    tb.nerf.render_min_transmittance = 1e-4
+    w, h = 1080, 1920
+    for i in range(3):
+        tb.set_camera_to_training_view(i)
+        tb.render(w, h, 1, True)
+    ms = []
+    for i in range(6):
+        tb.set_camera_to_training_view((7 * i) % 50)
+        t1 = time.perf_counter()
+        tb.render(w, h, 1, True)
+        ms.append((time.perf_counter() - t1) * 1e3)
+    out.update({"render_MP_per_s": round(w * h / (sum(ms) / len(ms) * 1e-3) / 1e6, 2), "render_ms_per_frame": round(sum(ms) / len(ms), 2), "render_ms_frames": [round(x, 2) for x in ms],
+                "render_res": [w, h], "render_network_samples_per_frame": int(tb.render_samples_evaluated)})
+    return out
+
+
+def bl_render_leg(tb, ds, res, frames=6):
+    """the Blender add-on's path on the headline model: snapshot -> NerfDescriptor -> request_nerf_render_sync (src/python_api.cu:306-330, src/nerf_renderer.cu:565-791)"""
+    import pyngp
+    tmp = tempfile.mkdtemp()
+    snap = os.path.join(tmp, "bench_lego.msgpack")
+    try:
+        tb.save_snapshot(snap, False)
+        tb.shall_train = False
+        tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+        tb.render(res, res, 1, True)
+        ms = []
+        for _ in range(frames):
+            t0 = time.perf_counter()
+            tb.render(res, res, 1, True)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        out = {"res": res, "frames": frames, "stock_render_ms": round(sum(ms) / frames, 2), "stock_network_samples": int(tb.render_samples_evaluated)}
+        focal = float(ds["focal"])
+
+        def request(n_nerfs):
+            dsi = pyngp.DownsampleInfo.MakeFromMip([res, res], 0)
+            outp = pyngp.RenderOutputProperties([res, res], dsi, 1, pyngp.ColorSpace.SRGB, pyngp.TonemapCurve.Identity, 0.0, [0.0, 0.0, 0.0, 1.0], False)
+            cam = pyngp.RenderCameraProperties(tb.camera_matrix, pyngp.CameraModel.Perspective, focal, 0.0, 0.0, 1.0, pyngp.SphericalQuadrilateralConfig.Zero(), pyngp.QuadrilateralHexahedronConfig.Zero())
+            box = pyngp.BoundingBox([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+            nerfs = []
+            for k in range(n_nerfs):
+                xf = np.eye(4, dtype=np.float32)
+                xf[0, 3] = 0.45 * k
+                nerfs.append(pyngp.NerfDescriptor(snap, box, xf, pyngp.RenderModifiers([]), 1.0))
+            big = pyngp.BoundingBox([-1.0, -1.0, -1.0], [2.0, 2.0, 2.0])
+            return pyngp.RenderRequest(outp, cam, pyngp.RenderModifiers([]), nerfs, big)
+
+        bl = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+        for n in (1, 2):
+            req = request(n)
+            img = bl.request_nerf_render_sync(req)   # loads the snapshot(s), warms up
+            bl.request_nerf_render_sync(req)
+            ms = []
+            for _ in range(frames):
+                t0 = time.perf_counter()
+                img = bl.request_nerf_render_sync(req)
+                ms.append((time.perf_counter() - t0) * 1e3)
+            out["bl_render_ms_%dnerf" % n] = round(sum(ms) / frames, 2)
+            out["bl_render_ms_min_%dnerf" % n] = round(min(ms), 2)
+            out["bl_network_samples_%dnerf" % n] = int(bl.bl_render_samples)
+            out["bl_coverage_%dnerf" % n] = round(float((img[..., 3] > 0.5).mean()), 3)
+        out["bl_over_stock_1nerf"] = round(out["bl_render_ms_1nerf"] / out["stock_render_ms"], 3)
+        return out
+    finally:
+        try:
+            os.unlink(snap)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
+def _albert():
+    gen = os.path.join(ROOT, "tests", "golden", "_generated", "albert.bin")
+    if os.path.exists(gen):
+        import struct
+        raw = open(gen, "rb").read()
+        h, w = struct.unpack("ii", raw[:8])
+        return np.frombuffer(raw[8:], np.float16).reshape(h, w, 4).astype(np.float32), "data/image/albert.exr of the reference (1024 x 1024)"
+    crop = np.load(os.path.join(ROOT, "tests", "golden", "albert_crop_128.npy")).astype(np.float32)
+    return np.tile(crop, (8, 8, 1)), "albert.exr 128 x 128 crop tiled to 1024 x 1024"
+
+
+def plumbing_leg(steps=200, warmup=100):
+    """configs #1 (image) and #5 (SDF): hash-grid encode + one 64-wide MLP, no ray marching, B = 2^18 (src/testbed_image.cu:220-291, src/testbed_sdf.cu training step)"""
+    import pyngp
+    B = 1 << 18
+    out = {}
+    rs = np.random.RandomState(0)
+    for mode in ("image", "sdf"):
+        tb = pyngp.Testbed(pyngp.TestbedMode.Image if mode == "image" else pyngp.TestbedMode.Sdf)
+        if mode == "image":
+            img, what = _albert()
+            tb.set_image_data(np.ascontiguousarray(img))
+        else:
+            pts = rs.rand(1 << 20, 3).astype(np.float32)
+            tb.override_sdf_training_data(pts, (np.linalg.norm(pts - 0.5, axis=1) - 0.3).astype(np.float32))
+            what = "analytic sphere SDF, 2^20 surface-free samples (the armadillo mesh + BVH sampler are out of scope: SURVEY row P2)"
+        tb.reload_network_from_file(os.path.join(CFG, mode, "base.json"))
+        tb.shall_train = True
+        for _ in range(warmup):
+            tb.train(B)
+        tb.set_profiling(True)
+        tb.reset_profile()
+        for _ in range(16):
+            tb.train(B)
+        prof = tb.profile()
+        tb.set_profiling(False)
+        tb.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tb.train(B)
+        tb.sync()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {"workload": what, "ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "steps": steps, "batch": B, "loss": round(float(tb.loss), 6),
+                     "mfma_TFLOPs": round(GRIDMLP_FLOP_PER_SAMPLE * B / dt / 1e12, 2), "mfma_frac_of_peak": round(GRIDMLP_FLOP_PER_SAMPLE * B / dt / 1e12 / MFMA_PEAK_F16_TFLOPS, 4),
+                     "flop_per_sample": GRIDMLP_FLOP_PER_SAMPLE, "groups_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in prof.items() if v["launches"]}}
+        del tb
+    return out
+
+
+if __name__ == "__main__":   # dev: one leg on its own, e.g. under rocprofv3:  python bench_legs.py fox 200
+    for p in (PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import json
+    import torch  # noqa: F401  (first: one HIP runtime per process)
+    which = sys.argv[1] if len(sys.argv) > 1 else "fox"
+    if which == "fox":
+        import bench
+        print(json.dumps(fox_leg(int(sys.argv[2]) if len(sys.argv) > 2 else 200, bench.BYTES_PER_UNIT)))
+    elif which == "plumbing":
+        print(json.dumps(plumbing_leg()))
+    elif which == "bl_render":
+        import scene
+        dev = torch.device("cuda", 0)
+        ds = scene.make_dataset(100, 1, 800, dev)
+        tb = scene.build_testbed(ds)
+        scene.train(tb, int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
+        print(json.dumps(bl_render_leg(tb, ds, 800)))

@@ -25,6 +25,57 @@ struct TrainSampleArgs {
 	int dev_variant; // dev-only timing variants (NGP_HIP_GEN_VARIANT): 0 product path, 2 no sample writes, 3 no march
 };
 
+
+// Per-ray setup of generate_training_samples_nerf (testbed_nerf.cu:1107-1200): image, pixel, camera ray, box entry, jittered start.  One copy for the three march kernels.
+struct TrainRaySetup { bool pixel_ok; float startt, max_level; v3 ro, rd_unnorm, rd, idir; };
+__device__ __forceinline__ TrainRaySetup setup_training_ray(const TrainSampleArgs& a, uint32_t i) {
+	TrainRaySetup r;
+	r.pixel_ok = false; r.startt = 0.f; r.max_level = 1.0f;
+	r.ro = mk(0, 0, 0); r.rd_unnorm = mk(0, 0, 1); r.rd = mk(0, 0, 1); r.idir = mk(1, 1, 1);
+	const uint32_t img = image_idx(i, a.n_rays_global, a.n_training_images, a.cdf.cdf_img, nullptr);
+	const NgpImageMeta& md = a.metadata[img];
+	Pcg32 rng = a.rng;
+	rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
+	float u, v;
+	nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, u, v, nullptr);
+	if (pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) return r;
+	r.pixel_ok = true;
+	r.max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
+	const float motionblur_time = rng.next_float();
+	float xform[12];
+	get_xform_given_rolling_shutter(a.xforms[img], md.rolling_shutter, u, v, motionblur_time, xform);
+	if (md.rays) {
+		int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
+		px = px < md.res[0] - 1 ? px : md.res[0] - 1; px = px > 0 ? px : 0;
+		py = py < md.res[1] - 1 ? py : md.res[1] - 1; py = py > 0 ? py : 0;
+		const NgpRay ray = md.rays[(uint64_t)px + (uint64_t)py * (uint64_t)md.res[0]];
+		r.ro = ld3(ray.o); r.rd_unnorm = ld3(ray.d);
+	} else {
+		r.ro = col(xform, 3);
+		v3 d;
+		if (md.lens_mode == 2) d = f_theta_undistortion(u - md.principal_point[0], v - md.principal_point[1], md.lens_params, mk(0.f, 0.f, 1.f));
+		else if (md.lens_mode == 3) d = latlong_to_dir(u, v);
+		else {
+			d = mk((u - md.principal_point[0]) * (float)md.res[0] / md.focal_length[0], (v - md.principal_point[1]) * (float)md.res[1] / md.focal_length[1], 1.0f);
+			if (md.lens_mode == 1) iterative_opencv_lens_undistortion(md.lens_params, d.x, d.y);
+		}
+		if (a.distortion_data) {
+			float o0, o1;
+			read_image2(a.distortion_data, a.distortion_res[0], a.distortion_res[1], u, v, o0, o1);
+			d.x += o0; d.y += o1;
+		}
+		r.rd_unnorm = mat3_mul(xform, d); // NOT normalized (1189)
+	}
+	r.rd = normalized(r.rd_unnorm);
+	float tmin, tmax;
+	aabb_ray_intersect(a.aabb, r.ro, r.rd, tmin, tmax);
+	tmin = fmaxf(tmin, 0.0f);
+	r.startt = tmin;
+	r.startt += calc_dt(r.startt, a.cone_angle_constant) * rng.next_float();   // cone_angle 0: clamp(+-0, MIN, MAX) = MIN_CONE_STEPSIZE
+	r.idir = mk(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+	return r;
+}
+
 template <bool CONST_DT>
 __global__ void __launch_bounds__(256) generate_training_samples_kernel(const TrainSampleArgs a) {
 	const uint32_t li = threadIdx.x + blockIdx.x * blockDim.x;
@@ -47,46 +98,9 @@ __global__ void __launch_bounds__(256) generate_training_samples_kernel(const Tr
 	v3 ro = mk(0, 0, 0), rd_unnorm = mk(0, 0, 1), rd = mk(0, 0, 1), idir = mk(1, 1, 1);
 
 	if (in_range) {
-		const uint32_t img = image_idx(i, a.n_rays_global, a.n_training_images, a.cdf.cdf_img, nullptr);
-		const NgpImageMeta& md = a.metadata[img];
-		Pcg32 rng = a.rng;
-		rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
-		float u, v;
-		nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, u, v, nullptr);
-		if (!pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) {
-			max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
-			const float motionblur_time = rng.next_float();
-			float xform[12];
-			get_xform_given_rolling_shutter(a.xforms[img], md.rolling_shutter, u, v, motionblur_time, xform);
-			if (md.rays) {
-				int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
-				px = px < md.res[0] - 1 ? px : md.res[0] - 1; px = px > 0 ? px : 0;
-				py = py < md.res[1] - 1 ? py : md.res[1] - 1; py = py > 0 ? py : 0;
-				const NgpRay r = md.rays[(uint64_t)px + (uint64_t)py * (uint64_t)md.res[0]];
-				ro = ld3(r.o); rd_unnorm = ld3(r.d);
-			} else {
-				ro = col(xform, 3);
-				v3 d;
-				if (md.lens_mode == 2) d = f_theta_undistortion(u - md.principal_point[0], v - md.principal_point[1], md.lens_params, mk(0.f, 0.f, 1.f));
-				else if (md.lens_mode == 3) d = latlong_to_dir(u, v);
-				else {
-					d = mk((u - md.principal_point[0]) * (float)md.res[0] / md.focal_length[0], (v - md.principal_point[1]) * (float)md.res[1] / md.focal_length[1], 1.0f);
-					if (md.lens_mode == 1) iterative_opencv_lens_undistortion(md.lens_params, d.x, d.y);
-				}
-				if (a.distortion_data) {
-					float o0, o1;
-					read_image2(a.distortion_data, a.distortion_res[0], a.distortion_res[1], u, v, o0, o1);
-					d.x += o0; d.y += o1;
-				}
-				rd_unnorm = mat3_mul(xform, d); // NOT normalized (1189)
-			}
-			rd = normalized(rd_unnorm);
-			float tmin, tmax;
-			aabb_ray_intersect(a.aabb, ro, rd, tmin, tmax);
-			tmin = fmaxf(tmin, 0.0f);
-			startt = tmin;
-			startt += calc_dt(startt, cone_angle) * rng.next_float();
-			idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+		const TrainRaySetup rs = setup_training_ray(a, i);
+		if (rs.pixel_ok) {
+			max_level = rs.max_level; ro = rs.ro; rd_unnorm = rs.rd_unnorm; rd = rs.rd; idir = rs.idir; startt = rs.startt;
 
 			// pass 1: count occupied steps (1204-1219).  The march is a serial, latency-bound chain (one dependent bitfield byte per
 			// iteration); instead of repeating it for the write pass, the occupied RUNS (start t, length) are recorded in LDS: inside a
@@ -382,47 +396,10 @@ __global__ void __launch_bounds__(256) generate_training_samples_wave_kernel(con
 		uint32_t n_segs = 0;
 		bool serial = false;
 		if (in_range) {
-			const uint32_t img = image_idx(i, a.n_rays_global, a.n_training_images, a.cdf.cdf_img, nullptr);
-			const NgpImageMeta& md = a.metadata[img];
-			Pcg32 rng = a.rng;
-			rng.advance((uint64_t)(uint32_t)(i * NGP_N_MAX_RANDOM_SAMPLES_PER_RAY));
-			float u, v;
-			nerf_random_image_pos_training(rng, md.res, a.snap_to_pixel_centers, a.cdf, img, u, v, nullptr);
-			if (!pixel_is_masked(u, v, md.res, md.pixels, md.image_data_type)) {
+			const TrainRaySetup rs = setup_training_ray(a, i);
+			if (rs.pixel_ok) {
 				pixel_ok = true;
-				max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
-				const float motionblur_time = rng.next_float();
-				float xform[12];
-				get_xform_given_rolling_shutter(a.xforms[img], md.rolling_shutter, u, v, motionblur_time, xform);
-				if (md.rays) {
-					int px = (int)(u * (float)md.res[0]), py = (int)(v * (float)md.res[1]);
-					px = px < md.res[0] - 1 ? px : md.res[0] - 1; px = px > 0 ? px : 0;
-					py = py < md.res[1] - 1 ? py : md.res[1] - 1; py = py > 0 ? py : 0;
-					const NgpRay r = md.rays[(uint64_t)px + (uint64_t)py * (uint64_t)md.res[0]];
-					ro = ld3(r.o); rd_unnorm = ld3(r.d);
-				} else {
-					ro = col(xform, 3);
-					v3 d;
-					if (md.lens_mode == 2) d = f_theta_undistortion(u - md.principal_point[0], v - md.principal_point[1], md.lens_params, mk(0.f, 0.f, 1.f));
-					else if (md.lens_mode == 3) d = latlong_to_dir(u, v);
-					else {
-						d = mk((u - md.principal_point[0]) * (float)md.res[0] / md.focal_length[0], (v - md.principal_point[1]) * (float)md.res[1] / md.focal_length[1], 1.0f);
-						if (md.lens_mode == 1) iterative_opencv_lens_undistortion(md.lens_params, d.x, d.y);
-					}
-					if (a.distortion_data) {
-						float o0, o1;
-						read_image2(a.distortion_data, a.distortion_res[0], a.distortion_res[1], u, v, o0, o1);
-						d.x += o0; d.y += o1;
-					}
-					rd_unnorm = mat3_mul(xform, d); // NOT normalized (1189)
-				}
-				rd = normalized(rd_unnorm);
-				float tmin, tmax;
-				aabb_ray_intersect(a.aabb, ro, rd, tmin, tmax);
-				tmin = fmaxf(tmin, 0.0f);
-				startt = tmin;
-				startt += dt * rng.next_float();
-				idir = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+				max_level = rs.max_level; ro = rs.ro; rd_unnorm = rs.rd_unnorm; rd = rs.rd; idir = rs.idir; startt = rs.startt;
 				valid = aabb_contains(a.aabb, ro + rd * startt);   // otherwise the reference's loop ends before its first iteration
 				if (valid && a.dev_variant != 3) serial = !wm_build_segments(startt, ro, rd, a.aabb, s_segs[w * WM_RAYS_PER_WAVE + lane], n_segs);
 			}
