@@ -339,13 +339,14 @@ __device__ __forceinline__ uint32_t wm_lane_u(uint32_t v, uint32_t l) { return (
 __device__ __forceinline__ v3 wm_lane_v3(v3 v, uint32_t l) { return mk(wm_lane_f(v.x, l), wm_lane_f(v.y, l), wm_lane_f(v.z, l)); }
 
 // the reference's own march, one lane (rays whose bookkeeping does not fit: > WM_MAX_SEGS binades or > WM_MAX_WINDOWS sample windows)
+template <bool CONST_DT = true>
 __device__ __forceinline__ uint32_t wm_serial_march(const TrainSampleArgs& a, v3 ro, v3 rd, v3 idir, float startt, NgpCoord* __restrict__ co, v3 warped_dir, uint32_t limit) {
 	uint32_t j = 0;
 	float t = startt;
 	v3 pos;
 	OccBrick occ;
 	while (aabb_contains(a.aabb, pos = ro + rd * t) && j < limit) {
-		const float dt = MIN_CONE_STEPSIZE();
+		const float dt = calc_dt_t<CONST_DT>(t, a.cone_angle_constant);
 		const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
 		if (density_grid_occupied_at(pos, a.density_grid, mip, occ)) {
 			if (co) {
@@ -357,7 +358,7 @@ __device__ __forceinline__ uint32_t wm_serial_march(const TrainSampleArgs& a, v3
 			}
 			++j; t += dt;
 		} else {
-			t = advance_to_next_voxel<true>(t, 0.0f, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
+			t = advance_to_next_voxel<CONST_DT>(t, a.cone_angle_constant, pos, rd, idir, NGP_NERF_GRIDSIZE >> mip);
 		}
 	}
 	return j;
@@ -605,6 +606,255 @@ __global__ void __launch_bounds__(256) generate_training_samples_wave_kernel(con
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Wave-per-ray march for CONE stepping (cone_angle != 0: every dataset with aabb_scale > 1, testbed_nerf.cu:2730 — the fox photographs, every real capture).
+//
+// dt = clamp(t * cone_angle, MIN, MAX) has no closed form, but the candidate sequence t_{k+1} = fl(t_k + calc_dt(t_k)) is still ONE sequence per ray,
+// independent of the occupancy grid: an occupied sample steps by calc_dt(t), and advance_to_next_voxel (testbed_nerf.cu:201-213) walks the very same additions
+// until t >= t_target.  So the sequence is GENERATED instead of written down: the ray's own lane runs the recurrence once (three dependent VALU
+// instructions per step and no memory access: ~5 us for a 700-candidate ray, all rays of the workgroup at the same time) and leaves every 8th t in
+// LDS (1 KiB per ray: 2048 candidates, more than a ray through an aabb_scale-128 box has).  After that the wave handles its rays one after the other, 64
+// CONSECUTIVE candidates at once: lane l takes checkpoint (64 w + l) / 8 and replays l mod 8 additions — the same fp32 additions in the same order, so the
+// same bits — then evaluates position, box test, mip (per candidate: it depends on dt), occupancy bit and, for an empty candidate, the skip target
+// t + distance_to_next_voxel.  The successor "first k' > k with t_k' >= t_target" is found among the window's own t by an estimate ((t_target - t) / dt)
+// settled on the neighbours' exact values (wave shuffles); a target beyond the window is carried into the next window as `pending` (candidates below it are
+// passed over — whole windows by one checkpoint compare).  The walk over the window is the pointer doubling of the constant-step kernel, entered at the
+// first candidate that reaches `pending`.  Windows are therefore always the aligned blocks [64 w, 64 w + 64): at most 32 per ray, no overflow path.
+// Same visited candidates, same t, same samples as the serial march, bit for bit (tests/test_sampling_gpu.py runs every cone case on both).
+constexpr uint32_t CW_STRIDE = 8, CW_MAX_CP = 256;   // checkpoints: t of every 8th candidate; CW_STRIDE * CW_MAX_CP = 2048 candidates = WM_MAX_WINDOWS windows of 64
+
+// t_{k + n} from t_k, n < CW_STRIDE: the reference's own additions
+__device__ __forceinline__ float cw_replay(float t, uint32_t n, float cone_angle) {
+#pragma unroll
+	for (uint32_t i = 0; i + 1 < CW_STRIDE; ++i) if (i < n) t += calc_dt(t, cone_angle);
+	return t;
+}
+
+__global__ void __launch_bounds__(256) generate_training_samples_cone_wave_kernel(const TrainSampleArgs a) {
+	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
+	__shared__ float s_cp[WM_RAYS_PER_WG][CW_MAX_CP];
+	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
+	__shared__ uint8_t s_win_w[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
+	__shared__ uint32_t s_n_windows[WM_RAYS_PER_WG], s_numsteps[WM_RAYS_PER_WG], s_base[WM_RAYS_PER_WG], s_slot[WM_RAYS_PER_WG];
+	__shared__ uint8_t s_serial[WM_RAYS_PER_WG];
+	__shared__ uint32_t s_spread[128];   // expand_bits of the 7-bit cell coordinates (morton3D by three LDS reads)
+	static_assert(CW_STRIDE * CW_MAX_CP == 64u * WM_MAX_WINDOWS, "one emit-mask slot per window of the checkpoint table");
+	if (threadIdx.x < 128u) s_spread[threadIdx.x] = expand_bits(threadIdx.x);
+	if (a.brick_summary) { for (uint32_t q = threadIdx.x; q < NGP_NERF_GRID_N_CELLS / 64 / 32; q += blockDim.x) s_brick_any[q] = a.brick_summary[q]; }
+	else load_brick_summary(a.density_grid, s_brick_any);
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	const float cone = a.cone_angle_constant;
+	const float INF = __uint_as_float(0x7f800000u);
+
+	const uint32_t n_groups = (a.n_rays + WM_RAYS_PER_WG - 1) / WM_RAYS_PER_WG;
+	for (uint32_t group = blockIdx.x; group < n_groups; group += gridDim.x) {
+		// ---- per-ray setup + generation of the candidate sequence on lanes 0..3 of every wave
+		const uint32_t li = group * WM_RAYS_PER_WG + w * WM_RAYS_PER_WAVE + lane;
+		const bool setup_lane = lane < WM_RAYS_PER_WAVE;
+		const bool in_range = setup_lane && li < a.n_rays;
+		const uint32_t i = li + a.ray_offset;
+		bool valid = false, pixel_ok = false, serial = false;
+		float startt = 0.f, max_level = 1.0f;
+		v3 ro = mk(0, 0, 0), rd_unnorm = mk(0, 0, 1), rd = mk(0, 0, 1), idir = mk(1, 1, 1);
+		uint32_t n_cp = 0;
+		if (in_range) {
+			const TrainRaySetup rs = setup_training_ray(a, i);
+			if (rs.pixel_ok) {
+				pixel_ok = true;
+				max_level = rs.max_level; ro = rs.ro; rd_unnorm = rs.rd_unnorm; rd = rs.rd; idir = rs.idir; startt = rs.startt;
+				valid = aabb_contains(a.aabb, ro + rd * startt);   // otherwise the reference's loop ends before its first iteration
+				if (valid && a.dev_variant != 3) {
+					// positions move monotonically along every axis: once a candidate is outside the (convex) box all later ones are, so the table ends with the
+					// first block whose first candidate is outside
+					float* __restrict__ cp = s_cp[w * WM_RAYS_PER_WAVE + lane];
+					float t = startt;
+					for (;;) {
+						if (n_cp == CW_MAX_CP) { serial = true; break; }   // still inside after 2048 candidates: the reference's own loop, one lane
+						cp[n_cp++] = t;
+#pragma unroll
+						for (uint32_t s = 0; s < CW_STRIDE; ++s) t += calc_dt(t, cone);
+						if (!aabb_contains(a.aabb, ro + rd * t)) break;
+					}
+				}
+			}
+		}
+		const v3 warped_dir = warp_direction(rd);
+
+		// ---- march: the wave takes its rays one after the other; ray parameters become scalars
+	#pragma unroll 1
+		for (uint32_t q = 0; q < WM_RAYS_PER_WAVE; ++q) {
+			const uint32_t rl = w * WM_RAYS_PER_WAVE + q;
+			const bool r_valid = wm_lane_u(valid, q) != 0 && a.dev_variant != 3;
+			const bool r_serial = wm_lane_u(serial, q) != 0;
+			uint32_t j = 0, n_windows = 0;
+			if (r_valid && !r_serial) {
+				const v3 o = wm_lane_v3(ro, q), d = wm_lane_v3(rd, q), id = wm_lane_v3(idir, q);
+				const uint32_t ncp = wm_lane_u(n_cp, q);
+				const float* __restrict__ cp = s_cp[rl];
+				const uint32_t n_win = (ncp + 7u) >> 3;   // windows that hold at least one checkpoint
+				float pending = -INF;                     // skip target carried over from the previous window (wave-uniform)
+				bool done = false;
+	#pragma unroll 1
+				for (uint32_t win = 0; win < n_win && !done; ++win) {
+					// a whole window below the pending target: its successor's first t decides
+					if ((win + 1u) * 8u < ncp && cp[(win + 1u) * 8u] < pending) continue;
+					const uint32_t k = win * 64u + lane;
+					const uint32_t ci = k >> 3;
+					const bool have = ci < ncp;
+					const float t = cw_replay(cp[have ? ci : 0u], k & 7u, cone);
+					const float dt = calc_dt(t, cone);
+					const v3 pos = o + d * t;
+					const bool inside = have && aabb_contains(a.aabb, pos);
+					const uint32_t mip = (uint32_t)mip_from_dt(dt, pos);
+					int ix, iy, iz;
+					cascaded_grid_coords(pos, mip, ix, iy, iz);
+					const uint32_t idx = s_spread[ix] | (s_spread[iy] << 1) | (s_spread[iz] << 2);   // morton3D
+					const uint32_t brick = (idx >> 6) + (NGP_NERF_GRID_N_CELLS / 64u) * mip;
+					bool occ = false;
+					if (inside && !(mip == 0 && !((s_brick_any[brick >> 5] >> (brick & 31u)) & 1u))) occ = (((const uint64_t*)a.density_grid)[brick] >> (idx & 63u)) & 1ull;
+					// the walk is entered at the first candidate that reaches the pending target; a candidate outside the box ends the ray whatever its t
+					// (everything behind it is outside as well), so outside candidates count as t = +inf everywhere below
+					const float te = inside ? t : INF;
+					const uint64_t reach_m = __ballot(te >= pending);
+					if (!reach_m) continue;   // (cannot happen after the checkpoint test above unless the table ended inside the window; then lanes past it are +inf)
+					const uint32_t entry = (uint32_t)__builtin_ctzll(reach_m);
+					// ---- successor of every candidate, window-relative: occupied -> lane + 1; empty -> first lane r > lane with te_r >= t_target (64 = beyond the window)
+					float t_target = 0.0f;
+					uint32_t r = lane + 1u;
+					const bool skip = inside && !occ;
+					if (skip) {
+						const float dist = distance_to_next_voxel(pos, d, id, NGP_NERF_GRIDSIZE >> mip);
+						t_target = t + dist;
+						const float est = ceilf(dist * __builtin_amdgcn_rcpf(dt));   // do { t += dt } while (t < t_target): at least one step
+						uint32_t n = est >= 1.0f ? (est < 64.0f ? (uint32_t)est : 64u) : 1u;
+						r = lane + n; r = r < 64u ? r : 64u;
+					}
+					bool settled = !skip;
+	#pragma unroll 1
+					while (__ballot(!settled)) {
+						const float ta = __shfl(te, (int)((r - 1u) & 63u), 64), tb = __shfl(te, (int)(r & 63u), 64);
+						if (!settled) {
+							if (r > lane + 1u && ta >= t_target) --r;
+							else if (r < 64u && tb < t_target) ++r;
+							else settled = true;
+						}
+					}
+					// ---- the walk by pointer doubling: reach = candidates on the path from this lane, jmp = where the path stands after 2^i hops (64 = it left the window or the ray ended)
+					uint32_t jmp = inside ? r : 64u;
+					uint32_t r_lo = lane < 32u ? (1u << lane) : 0u, r_hi = lane >= 32u ? (1u << (lane - 32u)) : 0u;
+	#pragma unroll 1
+					for (int it = 0; it < 6; ++it) {
+						if (wm_lane_u(jmp, entry) >= 64u) break;   // only the entry lane's path matters
+						const bool live = jmp < 64u;
+						const int src = (int)((live ? jmp : lane) << 2);
+						const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_lo), pb = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)r_hi);
+						const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)jmp);
+						if (live) { r_lo |= pa; r_hi |= pb; jmp = pj; }
+					}
+					const uint64_t visited = (uint64_t)wm_lane_u(r_lo, entry) | ((uint64_t)wm_lane_u(r_hi, entry) << 32);
+					const uint32_t last = 63u - (uint32_t)__builtin_clzll(visited);   // the entry lane is always visited
+					const uint64_t in_m = __ballot(inside), occ_m = __ballot(occ);
+					uint64_t emit = visited & occ_m;
+					if (!((in_m >> last) & 1ull)) done = true;   // the walk reached a candidate outside the box (1204)
+					if (j + (uint32_t)__popcll(emit) >= NGP_NERF_STEPS) {   // j < NERF_STEPS (1204): the ray ends with its 1024th sample
+						const uint32_t room = NGP_NERF_STEPS - j;
+						while ((uint32_t)__popcll(emit) > room) emit &= ~(1ull << (63u - (uint32_t)__builtin_clzll(emit)));
+						done = true;
+					}
+					j += (uint32_t)__popcll(emit);
+					if (emit) {
+						if (lane == 0) { s_win_mask[rl][n_windows] = emit; s_win_w[rl][n_windows] = (uint8_t)win; }
+						++n_windows;
+					}
+					// an occupied last candidate is lane 63 (otherwise the walk went on): the next window starts fresh; an empty one carries its target
+					pending = ((occ_m >> last) & 1ull) ? -INF : wm_lane_f(t_target, last);
+				}
+			}
+			if (r_valid && r_serial) {
+				// count with the reference's own loop (one lane); the write pass repeats it
+				uint32_t cnt = 0;
+				if (lane == q) cnt = wm_serial_march<false>(a, ro, rd, idir, startt, nullptr, warped_dir, NGP_NERF_STEPS);
+				j = wm_lane_u(cnt, q);
+			}
+			const bool r_pixel_ok = wm_lane_u(pixel_ok, q) != 0;
+			if (lane == 0) { s_numsteps[rl] = j; s_n_windows[rl] = n_windows; s_serial[rl] = (r_serial ? 1 : 0) | (r_pixel_ok ? 2 : 0); }
+		}
+		__syncthreads();
+
+		// ---- slot reservation, once per workgroup (the reference: two atomics per ray, 1225 / 1232)
+		if (w == 0) {
+			const bool has = lane < WM_RAYS_PER_WG;
+			uint32_t numsteps = has ? s_numsteps[lane] : 0u;
+			bool keep = has && (s_serial[lane < WM_RAYS_PER_WG ? lane : 0] & 2) && !(numsteps == 0 && !a.train_envmap);
+			if (!keep) numsteps = 0;
+			const uint32_t incl = wave_inclusive_scan(numsteps);
+			const uint32_t total = __shfl(incl, 63, 64);
+			uint32_t wg_base = 0;
+			if (lane == 63 && total) wg_base = atomicAdd(a.numsteps_counter, total);
+			wg_base = __shfl(wg_base, 63, 64);
+			const uint32_t base = wg_base + incl - numsteps;
+			if (keep && base + numsteps > a.max_samples) keep = false;   // dropped AFTER the counter was bumped (1225-1228)
+			const unsigned long long kept_mask = __ballot(keep);
+			const uint32_t n_kept = (uint32_t)__popcll(kept_mask);
+			uint32_t ray_base = 0;
+			if (lane == 0 && n_kept) ray_base = atomicAdd(a.ray_counter, n_kept);
+			ray_base = __shfl(ray_base, 0, 64);
+			if (has) { s_base[lane] = base; s_slot[lane] = keep ? ray_base + (uint32_t)__popcll(kept_mask & ((1ull << lane) - 1ull)) : 0xffffffffu; }
+		}
+		__syncthreads();
+
+		// ---- write pass
+	#pragma unroll 1
+		for (uint32_t q = 0; q < WM_RAYS_PER_WAVE; ++q) {
+			const uint32_t rl = w * WM_RAYS_PER_WAVE + q;
+			const uint32_t slot = s_slot[rl];
+			if (slot == 0xffffffffu) continue;
+			const uint32_t numsteps = s_numsteps[rl], base = s_base[rl];
+			if (lane == q) {
+				a.ray_indices_out[slot] = i;
+				NgpRay ray_out; ray_out.o[0] = ro.x; ray_out.o[1] = ro.y; ray_out.o[2] = ro.z; ray_out.d[0] = rd_unnorm.x; ray_out.d[1] = rd_unnorm.y; ray_out.d[2] = rd_unnorm.z;
+				a.rays_out[slot] = ray_out;
+				a.numsteps_out[slot * 2 + 0] = numsteps;
+				a.numsteps_out[slot * 2 + 1] = base;
+			}
+			if (numsteps == 0 || a.dev_variant == 2) continue;
+			NgpCoord* __restrict__ co = a.coords_out + base;
+			const float ml = wm_lane_f(max_level, q);
+			if (s_serial[rl] & 1) {
+				if (lane == q) wm_serial_march<false>(a, ro, rd, idir, startt, co, warped_dir, numsteps);
+				if (a.max_level_rand_training) for (uint32_t jj = lane; jj < numsteps; jj += 64u) a.max_level_ptr[base + jj] = ml;
+				continue;
+			}
+			const v3 o = wm_lane_v3(ro, q);
+			const v3 d = wm_lane_v3(rd, q);
+			const v3 wd = wm_lane_v3(warped_dir, q);
+			const float* __restrict__ cp = s_cp[rl];
+			const uint32_t n_windows = s_n_windows[rl];
+			uint32_t j0 = 0;
+			for (uint32_t wi = 0; wi < n_windows; ++wi) {
+				const uint64_t mask = s_win_mask[rl][wi];
+				const uint32_t k = (uint32_t)s_win_w[rl][wi] * 64u + lane;
+				if ((mask >> lane) & 1ull) {
+					const float t = cw_replay(cp[k >> 3], k & 7u, cone);
+					const float dt = calc_dt(t, cone);
+					const v3 wp = aabb_relative_pos(a.aabb, o + d * t);
+					const uint32_t jj = j0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+					NgpCoord c;
+					c.pos[0] = wp.x; c.pos[1] = wp.y; c.pos[2] = wp.z; c.dt = warp_dt(dt);
+					c.dir[0] = wd.x; c.dir[1] = wd.y; c.dir[2] = wd.z;
+					co[jj] = c;
+					if (a.max_level_rand_training) a.max_level_ptr[base + jj] = ml;
+				}
+				j0 += (uint32_t)__popcll(mask);
+			}
+		}
+		__syncthreads();   // the next group's setup lanes overwrite s_cp / the per-ray slots
+	}
+}
+
 } // namespace ngp
 
 using namespace ngp;
@@ -661,6 +911,14 @@ static int generate_training_samples_impl(
 		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 640u : 4096u);
 		hipLaunchKernelGGL(generate_training_samples_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
 		NGP_LAUNCH_CHECK("generate_training_samples_wave_kernel");
+		return 0;
+	}
+	if (march_mode != NGP_MARCH_LANE_PER_RAY) {
+		// cone stepping (every aabb_scale > 1 dataset): wave-per-ray on the generated candidate sequence, same throttle as above
+		static const uint32_t wg_cap_env = getenv("NGP_HIP_GEN_WGS") ? (uint32_t)atoi(getenv("NGP_HIP_GEN_WGS")) : 0u;   // dev: sweep
+		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 640u : 4096u);
+		hipLaunchKernelGGL(generate_training_samples_cone_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
+		NGP_LAUNCH_CHECK("generate_training_samples_cone_wave_kernel");
 		return 0;
 	}
 	if (cone_angle_constant == 0.0f) hipLaunchKernelGGL(generate_training_samples_kernel<true>, dim3(div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);

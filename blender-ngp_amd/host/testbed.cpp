@@ -1004,7 +1004,7 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 	profile_begin(PK_GEN_SAMPLES, stream);
 	// run ahead on stream B the march shares the chip with the backward pass: the wave-per-ray kernel on two workgroups per CU (more of it costs the
 	// backward pass more than it gains the march).  In stream order (first steps, the step after every occupancy update, a discarded prefetch)
-	// nothing runs beside it: all workgroups at once.  With cone stepping the library runs its lane-per-ray kernels whatever the mode
+	// nothing runs beside it: all workgroups at once.  With cone stepping the same two modes select the wave-per-ray kernel on the generated candidate sequence
 	check(ngp_hip_generate_training_samples(stream, R, &m_aabb, max_inference, rng.state, rng.inc, counters + 0, counters + 1, m_ray_indices.as<uint32_t>(), m_rays.as<NgpRay>(),
 	                                        m_numsteps.as<uint32_t>(), m_coords.as<NgpCoord>(), (uint32_t)tr.n_images_for_training, tr.dataset.metadata_gpu.as<NgpImageMeta>(),
 	                                        tr.transforms_gpu.as<NgpXForm>(), m_nerf.density_grid_bitfield.as<uint8_t>(), m_max_level_rand_training, nullptr, tr.snap_to_pixel_centers, tr.train_envmap,

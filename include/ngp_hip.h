@@ -209,12 +209,13 @@ int ngp_hip_bitfield_brick_summary(void* stream, const uint8_t* bitfield, uint32
 /* generate_training_samples_nerf.  ray_offset / n_rays_global are the data-parallel extension: thread i marches global ray
  * ray_offset+i out of n_rays_global (image choice, rng stream); pass (0, n_rays) for the reference's single-GPU behaviour. */
 /* march_mode: the marching kernel (same rays, same samples, bit for bit; slot order aside):
- *   NGP_MARCH_AUTO          wave-per-ray whenever cone_angle_constant == 0
+ *   NGP_MARCH_AUTO          wave-per-ray, all workgroups at once
  *   NGP_MARCH_LANE_PER_RAY  one lane per ray + a wave-per-ray expansion kernel: a latency-bound serial chain (~330 us at 2^14 rays) that costs
- *                           few issue slots; the only kernels for cone stepping (cone_angle_constant != 0)
- *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once on the closed-form step sequence (cone_angle_constant == 0 only, otherwise
- *                           the lane-per-ray kernels run): ~110 us on its own, twice the instructions — the one to run IN stream order
- *   NGP_MARCH_WAVE_PER_RAY_SHARED  the same kernel on two persistent workgroups per CU (~220 us): the one to run NEXT TO the backward pass */
+ *                           few issue slots (rounds 1-3: the only kernels for cone stepping)
+ *   NGP_MARCH_WAVE_PER_RAY  64 step candidates per wave at once — on the closed-form step sequence when cone_angle_constant == 0 (~110 us on its own),
+ *                           on the sequence the ray's own lane generates into LDS first when it is not (cone stepping: every aabb_scale > 1 dataset);
+ *                           the one to run IN stream order
+ *   NGP_MARCH_WAVE_PER_RAY_SHARED  the same kernels on 2.5 persistent workgroups per CU: the one to run NEXT TO the backward pass */
 enum { NGP_MARCH_AUTO = 0, NGP_MARCH_LANE_PER_RAY = 1, NGP_MARCH_WAVE_PER_RAY = 2, NGP_MARCH_WAVE_PER_RAY_SHARED = 3 };
 int ngp_hip_generate_training_samples(
 	void* stream, uint32_t n_rays, const NgpAabb* aabb_host, uint32_t max_samples, uint64_t rng_state, uint64_t rng_inc,

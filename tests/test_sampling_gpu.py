@@ -175,9 +175,45 @@ def test_training_samples_bit_exact_unit_scene(ngp, oracle, cuda, brick_summary,
     _compare_per_ray(r, g)
 
 
-def test_training_samples_bit_exact_cascaded_cone(ngp, oracle, cuda):
-    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=3, cone_angle=1.0 / 256.0, snap=1)
+@pytest.mark.parametrize("march_mode", [1, 2, 3])
+def test_training_samples_bit_exact_cascaded_cone(ngp, oracle, cuda, march_mode):
+    """cone stepping (aabb_scale 4: the fox configuration): lane-per-ray kernels and the wave-per-ray kernel on the generated candidate sequence"""
+    r, g = _run_train_samples(ngp, oracle, cuda, n_rays=4096, n_cascades=3, cone_angle=1.0 / 256.0, snap=1, march_mode=march_mode)
     _compare_per_ray(r, g)
+
+
+@pytest.mark.parametrize("march_mode", [1, 2])
+@pytest.mark.parametrize("case", ["inside", "full", "sparse", "huge", "odd_angle", "capped"])
+def test_training_samples_cone_corner_cases(ngp, oracle, cuda, march_mode, case):
+    """The cone-stepping march where the wave-per-ray kernel leaves its common path: cameras INSIDE the box (t starts near 0: the constant-step prefix, then
+    the geometric part), a fully occupied grid (rays that end with their 1024th sample), isolated cells (every window has skips that land in later
+    windows), an aabb_scale-32 box with a narrow cone (rays with more than 2048 candidates: the kernel's serial path), a cone angle that is not a power of two (t * cone_angle
+    rounds) and a sample budget that drops rays.  Both kernels against the oracle, bit for bit."""
+    kw = dict(n_rays=2048, n_cascades=3, cone_angle=1.0 / 256.0, max_samples=2048 * 1100)
+    if case == "inside":
+        kw.update(radius=0.4)
+    elif case == "full":
+        kw.update(grid_fill="full", radius=0.4, cone_angle=1.0 / 512.0)   # 512 + 512 ln(t_exit / 0.87) candidates, all occupied: the 1024-sample cap
+    elif case == "sparse":
+        kw.update(grid_fill="sparse")
+    elif case == "huge":
+        kw.update(n_cascades=6, n_rays=1024, radius=0.6, grid_fill="sparse", cone_angle=1.0 / 1024.0)   # 1024 + 1024 ln(t_exit / 1.73) candidates: > 2048 for most rays
+    elif case == "odd_angle":
+        kw.update(cone_angle=0.00317)
+    elif case == "capped":
+        kw.update(max_samples=30000)
+    r, g = _run_train_samples(ngp, oracle, cuda, march_mode=march_mode, **kw)
+    if case == "capped":
+        assert int(g["nc"][0]) == int(r["nc"][0]) > 30000
+        n = int(g["rc"][0])
+        assert 0 < n < 2048
+        for k in range(n):
+            assert int(g["ns"][2 * k]) + int(g["ns"][2 * k + 1]) <= 30000
+        return
+    _compare_per_ray(r, g)
+    ns = r["ns"][0:2 * int(r["rc"][0]):2]
+    if case == "full":
+        assert ns.max() == 1024
 
 
 @pytest.mark.parametrize("cdf_mode", [1, 2, 3])
