@@ -520,8 +520,9 @@ constexpr uint32_t GB_FX_MAX_SLICES = 256;       // tables up to 2^20 entries
 #define NGP_GB_FX_CHUNK 2048
 #endif
 constexpr uint32_t GB_FX_CHUNK = NGP_GB_FX_CHUNK;   // samples per binning workgroup
+constexpr uint32_t GB_FX_MAX_RESOLUTION = 1u << 20;   // (grid coordinates are exact in fp32 far beyond; the reference's finest level at aabb_scale 128 is 2^18)
 __host__ __device__ __forceinline__ bool gb_uses_fx(uint32_t level_size, uint32_t resolution, bool dense) {
-	return !dense && (level_size & (level_size - 1)) == 0 && level_size >= GB_FX_SLICE && level_size / GB_FX_SLICE <= GB_FX_MAX_SLICES && resolution < GB_FX_SLICE;
+	return !dense && (level_size & (level_size - 1)) == 0 && level_size >= GB_FX_SLICE && level_size / GB_FX_SLICE <= GB_FX_MAX_SLICES && resolution <= GB_FX_MAX_RESOLUTION;
 }
 // scratch of the binned path: per level and slice {total, cursor, start} u32, then the item lists (one u32 per (sample, pair))
 struct GbFxCounters { uint32_t totals[16][GB_FX_MAX_SLICES], cursors[16][GB_FX_MAX_SLICES]; };
@@ -612,7 +613,7 @@ static_assert(sizeof(GbRecord) == 12 && 4u * sizeof(GbRecord) <= GB_ITEMS_PER_SA
 
 // passes 1 and 3 of the counting sort.  grid (ceil(n / GB_FX_CHUNK), 16 levels), block 256.  SCATTER = false: per-bin totals;
 // SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
-// hashed level: item = sample << 3 | (y, z) pair, bin = slice.
+// hashed level: item = (sample, (y, z) pair) -> one GbRecord (two when the x corners straddle a slice boundary), bin = slice.
 template <int D, bool SCATTER>
 __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, const NgpGridLevel& lv, uint32_t level,
                                               const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
@@ -621,7 +622,11 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 	constexpr int PER = GB_FX_CHUNK / 256;
 	const uint32_t hmask = lv.size - 1;
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	uint32_t code[PER][NI];   // bin << 16 | rank inside this workgroup, or ~0
+	// rank of the pair's record inside this workgroup's share of its bin (15 bits: at most 2 * 4 * GB_FX_CHUNK records per workgroup), a second rank in bits 15-29 and
+	// bit 30 when the two x corners fall into DIFFERENT slices, or ~0 (no record).  The x term of the hash is x itself: below 4096 it never reaches the slice bits, and at
+	// finer levels (resolution >= 4096: aabb_scale >= 4 with base.json, e.g. the fox scene's levels 14 and 15) corner x + 1 leaves corner x's slice only when x + 1 is a
+	// multiple of 4096 — such a pair leaves as TWO records, one per corner, each with the other corner's terms zeroed.  The bins are recomputed where they are needed.
+	uint32_t code[PER][NI];
 	h2 gq[PER]; float px[PER], py[PER], pz[PER];
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
@@ -641,8 +646,14 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 		const uint32_t hz[2] = {D == 3 ? p.gz * 805459861u : 0u, D == 3 ? (p.gz + 1u) * 805459861u : 0u};
 #pragma unroll
 		for (int m = 0; m < NI; ++m) {
-			const uint32_t bin = ((hy[m & 1] ^ hz[m >> 1]) & hmask) / GB_FX_SLICE;
-			code[u][m] = live ? ((bin << 16) | atomicAdd(&hist[bin], 1u)) : 0xffffffffu;
+			const uint32_t hb = hy[m & 1] ^ hz[m >> 1];
+			const uint32_t bin0 = ((hb ^ p.gx) & hmask) / GB_FX_SLICE, bin1 = ((hb ^ (p.gx + 1u)) & hmask) / GB_FX_SLICE;
+			uint32_t c = 0xffffffffu;
+			if (live) {
+				c = atomicAdd(&hist[bin0], 1u);
+				if (bin1 != bin0) c |= (atomicAdd(&hist[bin1], 1u) << 15) | (1u << 30);
+			}
+			code[u][m] = c;
 		}
 	}
 	__syncthreads();
@@ -672,16 +683,25 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 			const uint32_t hb = ((p.gy + yb) * 2654435761u) ^ (D == 3 ? (p.gz + zb) * 805459861u : 0u);
 			const float wy = yb ? p.fy : (1.0f - p.fy), wz = zb ? p.fz : (1.0f - p.fz);
 			GbRecord r;
-			uint32_t e[2];
+			uint32_t e[2], bin[2];
 #pragma unroll
 			for (uint32_t xb = 0; xb < 2; ++xb) {
-				e[xb] = ((hb ^ (p.gx + xb)) & hmask) & (GB_FX_SLICE - 1);
+				const uint32_t idx = (hb ^ (p.gx + xb)) & hmask;
+				e[xb] = idx & (GB_FX_SLICE - 1); bin[xb] = idx / GB_FX_SLICE;
 				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
 				if (D == 3) w *= wz;
 				r.t[2 * xb] = gb_term_half(w * g0); r.t[2 * xb + 1] = gb_term_half(w * g1);
 			}
-			r.entries = e[0] | (e[1] << 12);
-			out[base[c >> 16] + (c & 0xffffu)] = r;
+			if (!((c >> 30) & 1u)) {
+				r.entries = e[0] | (e[1] << 12);
+				out[base[bin[0]] + (c & 0x7fffu)] = r;
+			} else {   // the x corners straddle a slice boundary: one record per corner
+				GbRecord r0 = r, r1 = r;
+				r0.entries = e[0] | (e[0] << 12); r0.t[2] = (half_t)0.0f; r0.t[3] = (half_t)0.0f;
+				r1.entries = e[1] | (e[1] << 12); r1.t[0] = (half_t)0.0f; r1.t[1] = (half_t)0.0f;
+				out[base[bin[0]] + (c & 0x7fffu)] = r0;
+				out[base[bin[1]] + ((c >> 15) & 0x7fffu)] = r1;
+			}
 		}
 	}
 }
@@ -787,7 +807,7 @@ template <int D, bool SCATTER>
 __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask) {
 	NGP_RAISE_CHAIN_PRIORITY();
-	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
+	static_assert(GB_FX_CHUNK * 8 <= 32768, "rank fields: 15 bits");
 	const uint32_t level = blockIdx.y;
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
 	const NgpGridLevel lv = desc->levels[level];

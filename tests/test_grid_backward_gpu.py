@@ -1,8 +1,8 @@
 """Hash-grid backward on its own (ngp_hip_grid_backward = tcnn kernel_grid_backward, EGradientMode::Overwrite) against the oracle's EXACT sum.
 
 Dense levels and hashed levels with a power-of-two table are accumulated in 64-bit fixed point on the device: the result is the exact sum of the
-fp16 terms half(w * dL/dx), rounded to fp16 once — the comparison is BIT-EXACT and does not depend on the scheduling of the adds.  Hashed levels
-whose resolution reaches the slice size (aabb_scale 16) take the float fallback (fp16 LDS atomics) and are compared with a tolerance."""
+fp16 terms half(w * dL/dx), rounded to fp16 once — the comparison is BIT-EXACT and does not depend on the scheduling of the adds.  Only tables with more
+than 2^20 entries per level (big.json) take the float fallback (fp16 LDS atomics) and are compared with a tolerance."""
 import numpy as np
 import pytest
 
@@ -88,27 +88,34 @@ def test_grid_backward_schedule_independent(ngp, cuda):
     np.testing.assert_array_equal(a, c)
 
 
-def test_grid_backward_float_fallback(ngp, oracle, cuda):
-    """aabb_scale 16: the finest levels have resolution >= 4096, the x term of the hash reaches the slice bits -> fp16 LDS-atomic fallback"""
-    n = 4096
-    desc = H.make_desc(ngp, 19, aabb_scale=16)
+@pytest.mark.parametrize("aabb_scale", [4, 16])
+def test_grid_backward_fine_levels_straddle_slices(ngp, oracle, cuda, aabb_scale):
+    """aabb_scale >= 4 (4: the fox scene): the finest levels have resolution >= 4096, so the x term of the hash reaches the slice bits and the two x corners of a cell
+    with x + 1 a multiple of 4096 fall into different slices (two records per pair).  Rounds 1-3 sent such levels to an fp16 LDS-atomic fallback; they are exact now.
+    A third of the samples sit ON such cells of every fine level."""
+    n = 6144
+    desc = H.make_desc(ngp, 19, aabb_scale=aabb_scale)
     rs = np.random.RandomState(9)
     pos = rs.rand(n, 3).astype(np.float32)
+    lv = desc["levels"][0]
+    fine = [l for l in range(16) if int(lv[l]["resolution"]) >= 4096]
+    assert fine                                          # the case exists in this configuration
+    k = 2048
+    for q, l in enumerate(fine):
+        sc, res = float(lv[l]["scale"]), int(lv[l]["resolution"])
+        sel = slice(k + q * (2048 // len(fine)), k + (q + 1) * (2048 // len(fine)))
+        m = pos[sel].shape[0]
+        bx = 4096 * rs.randint(1, max(2, res // 4096), size=m) - 1     # cell x = 4095, 8191, ...: x + 1 crosses a slice boundary
+        pos[sel, 0] = ((bx + rs.rand(m) * 0.98 + 0.01) - 0.5) / sc     # level_pos: floor(x * scale + 0.5)
+    pos = np.clip(pos, 0.0, 1.0).astype(np.float32)
     pl = _planes(n, rs, special=False)
-    got = _run(ngp, cuda, 3, desc, pos, pl.view(np.uint16)).view(np.float16).astype(np.float64)
+    got = _run(ngp, cuda, 3, desc, pos, pl.view(np.uint16))
     ref = np.zeros(got.size, np.uint16)
     oracle.orc_grid_backward_exact(3, desc.ctypes.data, pos.ctypes.data, 3, n, pl.view(np.uint16).ctypes.data, ref.ctypes.data)
-    ref = ref.view(np.float16).astype(np.float64)
-    assert np.isfinite(got).all()
-    lv = desc["levels"][0]
-    fallback = [l for l in range(16) if int(lv[l]["resolution"]) >= 4096]
-    assert fallback                                      # the case exists in this configuration
-    for l in range(16):
-        o, sz = int(lv[l]["offset"]) * 2, int(lv[l]["size"]) * 2
-        if l in fallback:
-            assert np.linalg.norm(got[o:o + sz] - ref[o:o + sz]) < 2e-3 * np.linalg.norm(ref[o:o + sz])   # fp16 accumulation noise
-        else:
-            np.testing.assert_array_equal(got[o:o + sz], ref[o:o + sz])
+    for l in fine:   # the crafted samples do straddle: cell x = 4095 mod 4096 on their level
+        gx = np.floor(pos[:, 0].astype(np.float32) * np.float32(lv[l]["scale"]) + np.float32(0.5)).astype(np.int64)
+        assert ((gx % 4096) == 4095).sum() > 100
+    np.testing.assert_array_equal(got, ref)
 
 
 def test_grid_backward_rejects_bad_arguments(ngp, cuda):
