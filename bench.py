@@ -7,8 +7,9 @@
 A "step" is one Testbed::train() call (src/testbed.cu:2527-2587): occupancy-grid prep on its schedule + ray marching +
 inference + loss/compaction + forward/backward + optimizer at the reference's batch of 2^18 compacted samples.
 value = sum over the K timed steps and all ranks of measured_batch_size (src/testbed_nerf.cu:2883) / wall time (max over ranks).
-N > 1: weak scaling — every rank trains its own 2^18-sample batch on a disjoint ray slice; one fp16 RCCL all-reduce of the
-gradient vector per step (hash table + MLP), replicated optimizer step.
+N > 1: strong scaling is the headline (the batch of 2^18 compacted samples per step is split over the ranks — the reference's convergence per
+step); the weak-scaled figure (2^18 per rank) is measured in the same run and printed beside it (`weak_scaling`).  Per step: fp32 reduce-scatter of the gradients,
+Adam on each rank's shard, fp16 all-gather of the weights (RCCL over xGMI).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -284,7 +285,8 @@ def main():
     ap.add_argument("--force_dp", action="store_true", help="run the data-parallel step path (RCCL all-reduce) even with one rank")
     ap.add_argument("--dp_impl", choices=["product", "torch"], default="product", help="product: Testbed.init_data_parallel — the step's two exchanges inside the C++ Testbed (shared-memory "
                     "counters, its own RCCL communicator), frame() as on one GPU; torch: the same exchanges driven from this script through torch.distributed (dp_step). product falls back to torch if it cannot initialise")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: 2^18 compacted samples per GPU and step (N x the global batch); strong: 2^18 per step over all GPUs (the reference's convergence per step)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong", help="strong (default, SURVEY 8e): 2^18 compacted samples per step over ALL GPUs — the reference's convergence per step; with N > 1 the line also carries a "
+                    "`weak_scaling` object measured in the same run (2^18 per GPU and step, N x the global batch).  weak: the weak-scaled run as the headline")
     ap.add_argument("--min_train_step", type=int, default=1000, help="BASELINE.md M1 quotes the metric on steps [1000, 2000): the timed region never starts before this training step, whatever --warmup says")
     ap.add_argument("--legs", default="fox,bl_render,plumbing", help="comma list of the extra legs of a one-GPU run (bench_legs.py): fox = BASELINE config #2 on the fox photographs, bl_render = the Blender "
                     "multi-NeRF renderer next to the stock tracer, plumbing = configs #1 / #5 at 2^18; 'none' switches them off")
@@ -337,12 +339,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)   # all ranks or none
         if float(t.item()) == 1.0:
             dp_impl = "product"
+            tb.render_sharded = True   # every render() of this script is issued by all ranks: rows per rank + RCCL all-gather (opt-in since round 4)
         else:
             tb.shutdown_data_parallel()
             tb.set_distributed(rank, world)
     if use_dp and dp_impl is None:
         if a.scaling == "strong":
-            raise SystemExit("--scaling strong needs the product data-parallel path")
+            print("rank %d: the torch.distributed driver only knows the weak split; reporting weak scaling" % rank, file=sys.stderr, flush=True)
+            a.scaling = "weak"
         dp_impl = "torch"
         grads = torch.as_tensor(CudaArray(tb.gradients_ptr(), tb.n_params(), "<f2"), device=dev)
         assert grads.data_ptr() == tb.gradients_ptr()
@@ -424,6 +428,25 @@ def main():
         dist.all_reduce(s)
         samples, rays, pre_compaction = (float(x) for x in s.tolist())
 
+    # ---- N > 1, strong-scaled headline: the weak-scaled figure from the same run, beside it (2^18 per rank and step; rays_per_batch re-adapts through the counter feedback)
+    weak = None
+    if world > 1 and dp_impl == "product" and a.scaling == "strong":
+        tb.strong_scaling = False
+        for _ in range(96):
+            one_step()
+        tb.sync(); torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        w_samples = 0
+        for _ in range(a.steps):
+            w_samples += min(one_step(), B)
+        tb.sync(); torch.cuda.synchronize(); dist.barrier()
+        w_dt = time.perf_counter() - t1
+        t = torch.tensor([w_dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); w_dt = float(t.item())
+        t = torch.tensor([w_samples], dtype=torch.float64, device=dev); dist.all_reduce(t); w_samples = float(t.item())
+        weak = {"value": round(w_samples / w_dt, 1), "unit": "samples/s", "ms_per_step": round(1000.0 * w_dt / a.steps, 4), "steps": a.steps, "global_batch": B * world,
+                "note": "same run, after the strong-scaled timed region: 2^18 compacted samples per GPU and step, 96 untimed steps for rays_per_batch to re-adapt"}
+        tb.strong_scaling = True
+
     # ---- render MP/s + PSNR on the trained model, outside the timed region.  With the product's data-parallel communicator every render() is a collective: rank r traces
     # the rows [r * ceil(H / N), ...) of the frame and the rows are all-gathered over RCCL (Testbed::fetch_render_surface), so ALL ranks run this leg
     extra = {}
@@ -481,6 +504,18 @@ def main():
 
     kernels = table(survey)            # all groups, from the untimed survey steps
     kernels.update(table(prof))        # the dominant group, from the timed region
+    if "optimizer_step" in kernels:
+        # 36 B / parameter is the DENSE model (every parameter has a gradient); hash-grid entries nobody touched skip their 24 B of moments and master weight, so the
+        # model over-counts and can exceed what the chip copies at.  The figure to read is the counters' (L2 <-> fabric bytes of a separate rocprofv3 --pmc run)
+        o = kernels["optimizer_step"]
+        o["dense_model_GBps_upper_bound"] = o.pop("algorithmic_GBps")
+        try:
+            tj0 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if tj0.get("_meta", {}).get("kernel_set") == KERNEL_SET and tj0.get("optimizer_step"):
+                o["counter_bytes_per_launch"] = tj0["optimizer_step"]
+                o["counter_GBps"] = round(float(tj0["optimizer_step"]) / (o["avg_us"] * 1e-6) / 1e9, 1)
+        except Exception:
+            pass
     achieved = kernels[dom]["algorithmic_GBps"]
     # traffic: HBM bytes per launch from the PMC passes of tools/gpu_profile_round.sh — a SEPARATE rocprofv3 run (counters cannot be read inside
     # this process); the file names the run it came from and the kernel set it was taken on.  Stale (other kernel set) => null.
@@ -546,6 +581,8 @@ def main():
         "roofline": roofline, "roofline_longest_single_kernel": line_single, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
+    if weak is not None:
+        line["weak_scaling"] = weak
     if use_dp:   # what the communicator itself says, and what the step's exchanges cost (HIP events on the training stream, survey steps)
         dp_info = {"impl": dp_impl, "world_size_env": world, "rccl_comm_ranks": int(tb.dp_comm_size) if dp_impl == "product" else int(dist.get_world_size()),
                    "sharded_optimizer": bool(tb.dp_sharded_optimizer) if dp_impl == "product" else False}

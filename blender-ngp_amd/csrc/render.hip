@@ -171,8 +171,12 @@ __device__ __forceinline__ void compact_store(bool alive, bool hit, const NgpPay
 		// for} — so the host learns it while the kernel drains, without a copy command and a stream synchronisation between two passes.  No fences (a device-scope release
 		// writes the XCD's L2 back): the counter update above has returned, i.e. happened at the memory side, before the ticket is drawn, and all three are device-scope atomics.
 		if (threadIdx.x == 0 && co.host_mailbox) {
-			asm volatile("" : "+v"(base));
-			if (atomicAdd(co.blocks_done, 1u + (base & 0u)) == gridDim.x - 1u) {
+			// The ticket's operand is computed FROM the counter atomic's return value by an instruction the compiler cannot fold (`base & 0u` it could): a true data
+			// dependency, so the ticket is not issued before this workgroup's counter add has been performed at the memory side, and whoever draws the last ticket reads
+			// a counter that holds every workgroup's add
+			uint32_t zero;
+			asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(base));
+			if (__hip_atomic_fetch_add(co.blocks_done, 1u + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
 				const uint32_t n_alive = __hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(co.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store((unsigned long long*)co.host_mailbox, (unsigned long long)n_alive | ((unsigned long long)co.sequence << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

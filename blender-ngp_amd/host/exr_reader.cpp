@@ -285,6 +285,16 @@ void decode_exr_rgba_f32(const uint8_t* data, size_t n_bytes, int& w, int& h, st
 	}
 	if (slot[0] < 0 && channels.size() == 1) slot[0] = slot[1] = slot[2] = 0;
 	if (slot[0] < 0 || slot[1] < 0 || slot[2] < 0) throw std::runtime_error{"EXR: no R, G, B channels"};
+	{
+		// before any allocation sized by the header: the file must at least hold the offset table of its blocks (8 bytes each) and one block header per entry — a
+		// few-byte header cannot force a 4 GiB pixel buffer or a 2 GiB offset table (1 x 1 tiles)
+		const uint64_t n_blk = tiled ? (uint64_t)((w64 + tile_w - 1) / tile_w) * (uint64_t)((h64 + tile_h - 1) / tile_h)
+		                             : (uint64_t)((h64 + (compression == 3 ? 16 : compression == 4 ? 32 : 1) - 1) / (compression == 3 ? 16 : compression == 4 ? 32 : 1));
+		const uint64_t left = (uint64_t)(c.end - c.p);
+		if (n_blk > left / (tiled ? 28u : 16u)) throw std::runtime_error{"EXR: the file is too short for the offset table and block headers its data window implies"};
+		// ... nor can its payload expand beyond what DEFLATE (1032 : 1 at best), RLE (128 : 1) or PIZ could have packed into the file
+		if ((uint64_t)w64 * (uint64_t)h64 * bytes_per_pixel / 2048u > (uint64_t)n_bytes) throw std::runtime_error{"EXR: data window far larger than the file could encode"};
+	}
 	rgba.assign((size_t)w * h * 4, 1.0f);
 	std::vector<uint8_t> block, tmp;
 	// one compressed block of nx x ny pixels at (x0, y0): decompress to the scanline layout, then pick R, G, B, A

@@ -414,7 +414,10 @@ PYBIND11_MODULE(pyngp, m) {
 			py::arg("filename"), py::arg("resolution") = py::none(), py::arg("aabb") = py::none(), py::arg("thresh") = 2.5f)
 		.def("n_params", &Testbed::n_params)
 		.def("n_encoding_params", &Testbed::n_encoding_params)
-		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float, float, float, float) {
+		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float start_t, float end_t, float, float) {
+				// python_api.cu:131-165: start_t >= 0 animates along the loaded camera path (set_camera_from_time, smoothing, per-spp shutter interpolation).  Camera
+				// paths are not part of this build (load_camera_path throws): a still frame returned for a path request would be silently wrong
+				if (start_t >= 0.f || end_t >= 0.f) throw std::runtime_error{"render(start_t >= 0): camera-path animation is not part of this build; set the camera per frame with set_nerf_camera_matrix and call render() with start_t = end_t = -1"};
 				std::vector<float> px;
 				{ py::gil_scoped_release rel; px = t.render_to_cpu(width, height, spp, linear); }
 				py::array_t<float> result({height, width, 4});
@@ -502,15 +505,18 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("init_data_parallel", &Testbed::init_data_parallel, py::call_guard<py::gil_scoped_release>(), py::arg("rank"), py::arg("world_size"), py::arg("key") = std::string("0"), py::arg("strong_scaling") = false,
 			"One process per GPU of one node: after this call frame() / train() run the data-parallel step (shared-memory counter exchange, RCCL gradient all-reduce over xGMI). "
 			"`key` names the rendezvous and must be the same on every rank of the job (e.g. MASTER_PORT). strong_scaling: train(B) back-propagates B / world_size samples per rank.")
-		.def("shutdown_data_parallel", &Testbed::shutdown_data_parallel, py::call_guard<py::gil_scoped_release>())
+		.def("shutdown_data_parallel", &Testbed::shutdown_data_parallel, py::call_guard<py::gil_scoped_release>(), "tears the communicator down; NO collective (a rank may leave alone).  Call dp_gather_optimizer_state() on all ranks first if the Testbed is to train on or to save its optimizer state")
+		.def("dp_gather_optimizer_state", &Testbed::dp_gather_optimizer_state, py::call_guard<py::gil_scoped_release>(), "COLLECTIVE (every rank): all-gather of the fp32 master weights and Adam moments the sharded optimizer step keeps current only inside each rank's shard; required before save_snapshot(include_optimizer_state=True) and before training on after shutdown_data_parallel")
 		.def("set_render_shard", &Testbed::set_render_shard, py::arg("rank"), py::arg("world_size"),
 			"render() traces only the rows of shard `rank` of `world_size` (rows [rank * ceil(H / world), ...)); the rest of the returned frame is background. With init_data_parallel the split and the gather happen inside render().")
 		.def("render_shard_rows", [](Testbed& t, int height) { int a, b; t.render_shard_rows(height, a, b); return py::make_tuple(a, b); }, py::arg("height"))
-		.def_readwrite("dp_sharded_optimizer", &Testbed::m_dp_sharded_optimizer, "data-parallel step: reduce-scatter (fp32 sums) -> Adam on this rank's 1 / world of the parameters -> all-gather of the fp16 weights (default); False: fp16 all-reduce of the gradients, the whole optimizer step on every rank")
+		.def_property("dp_sharded_optimizer", [](Testbed& t) { return t.m_dp_sharded_optimizer; }, &Testbed::set_dp_sharded_optimizer, "data-parallel step: reduce-scatter (fp32 sums) -> Adam on this rank's 1 / world of the parameters -> all-gather of the fp16 weights (default); False: fp16 all-reduce of the gradients, the whole optimizer step on every rank.  Settable only while no communicator is live (before init_data_parallel)")
+		.def_readwrite("render_sharded", &Testbed::m_render_sharded, "opt-in: under init_data_parallel render() / render_to_cpu() become COLLECTIVES (rows per rank, RCCL all-gather, every rank returns the whole frame) — set it on every rank and call render() on every rank with the same arguments.  Default False: render() is local and traces the whole frame, so one rank alone can render")
 		.def_property_readonly("dp_comm_size", [](Testbed& t) { return t.m_dp_comm ? ngp_rccl_comm_size(t.m_dp_comm) : 0; }, "ranks of the RCCL communicator of init_data_parallel (ncclCommCount), 0 without one")
 		.def_readonly("world_size", &Testbed::m_world_size)
 		.def_readonly("rank", &Testbed::m_rank)
-		.def_readonly("strong_scaling", &Testbed::m_dp_strong_scaling)
+		.def_property("strong_scaling", [](Testbed& t) { return t.m_dp_strong_scaling; }, &Testbed::set_dp_strong_scaling,
+			"data-parallel batch split: True = train(B) back-propagates B / world per rank (the reference's convergence per step), False = B per rank (world x the global batch).  Set it on every rank between two steps; rays_per_batch re-adapts through the counter feedback within a few steps")
 		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss, bool wait) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss, wait); } return py::make_tuple(c[0], c[1]); },
 			py::arg("batch_size"), py::arg("get_loss_scalar") = false, py::arg("wait_for_counters") = true)
 		.def("set_dp_counter_buffer", [](Testbed& t, uintptr_t p) { t.set_dp_counter_buffer((void*)p); })                 // 3 doubles on the device

@@ -931,21 +931,33 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 // The sharded optimizer step leaves the fp32 state (master weights, Adam moments) of other ranks' shards stale.  Whoever needs the whole state — a snapshot with
 // optimizer state, training on after shutdown_data_parallel — gathers it first.  Collective: every rank of the communicator calls it.
 void Testbed::dp_gather_optimizer_state() {
-	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) return;
+	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) { m_dp_state_stale = false; return; }
 	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_master.as<float>(), shard), "ngp_rccl_allgather_f32 (master weights)");
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_first_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (first moments)");
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_second_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (second moments)");
 	sync();
+	m_dp_state_stale = false;
 }
+void Testbed::set_dp_sharded_optimizer(bool on) {
+	if (on == m_dp_sharded_optimizer) return;
+	// switching under a live communicator would either run the replicated step on fp32 state that is stale outside this rank's shard (sharded -> replicated) or
+	// need a collective inside a property setter: choose before init_data_parallel, or gather (all ranks) and shut the communicator down first
+	if (m_dp_comm) throw std::runtime_error{"dp_sharded_optimizer can only be changed before init_data_parallel (or after dp_gather_optimizer_state() + shutdown_data_parallel())"};
+	m_dp_sharded_optimizer = on;
+}
+// No collective here: a rank that leaves alone (an exception, a test that ends) must not hang in an all-gather the others never enter.  A Testbed that is to train
+// on, or to save its optimizer state, after sharded data-parallel steps calls dp_gather_optimizer_state() on ALL ranks first; otherwise the state stays marked stale.
 void Testbed::shutdown_data_parallel() {
-	if (m_dp_comm && m_stream) { try { dp_gather_optimizer_state(); } catch (...) {} }
 	if (m_dp_comm) { if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream); ngp_rccl_finalize(m_dp_comm); m_dp_comm = nullptr; }
 	m_dp_shm.reset();
 }
 
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
+	// refuse before anything is queued (the check used to sit behind the step's forward and loss launches)
+	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && !net_is_base_family())
+		throw std::runtime_error{"optimize_extrinsics / optimize_distortion need the network's input gradient, which is built for the base network family (no extra dims, two hidden colour layers)"};
 	if (m_dp_comm) {
 		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
 		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
@@ -1364,6 +1376,7 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 void Testbed::optimizer_step_sharded() {
 	++m_optimizer_step;
 	const uint32_t world = m_world_size, rank = m_rank;
+	if (world > 1) m_dp_state_stale = true;
 	const uint32_t shard = next_multiple(((uint32_t)m_n_params + world - 1) / world, 8u);
 	if ((uint64_t)shard * world > m_n_params + DP_PARAM_SLACK) throw std::runtime_error{"optimizer_step_sharded: world size too large for the parameter buffers' slack"};
 	m_dp_grads_f32.enlarge((size_t)shard * world * 4); m_dp_shard_f32.enlarge((size_t)shard * 4);
@@ -1393,6 +1406,7 @@ void Testbed::optimizer_step_sharded() {
 
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
 	if (m_dp_comm && m_dp_sharded_optimizer) { optimizer_step_sharded(); return; }
+	if (m_dp_state_stale) throw std::runtime_error{"optimizer step on fp32 state that sharded data-parallel steps left stale outside this rank's shard: call dp_gather_optimizer_state() on all ranks before shutdown_data_parallel()"};
 	++m_optimizer_step;
 	profile_begin(PK_OPTIMIZER);
 	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
@@ -1607,15 +1621,16 @@ std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& came
 }
 
 // ---- a frame rendered by several ranks -------------------------------------------------------------------------------------
-// Rows [r * ceil(H / P), (r + 1) * ceil(H / P)) go to rank r (the last rank's range is cut at H; equal chunks keep the gather one collective).  With a
-// data-parallel communicator (init_data_parallel) every render() is sharded over its ranks and every rank returns the whole frame; set_render_shard is the
-// same split without a communicator: the caller renders (rank, world) and owns the gather (tests; a host with its own transport).
+// Rows [r * ceil(H / P), (r + 1) * ceil(H / P)) go to rank r (the last rank's range is cut at H; equal chunks keep the gather one collective).  OPT-IN: with
+// `render_sharded` set on every rank of a data-parallel communicator (init_data_parallel) render() is a COLLECTIVE — sharded over the ranks, every rank returns the
+// whole frame.  Without the flag (the default) render() is local and traces the whole frame, so one rank alone may render a screenshot or an eval frame during or
+// after data-parallel training.  set_render_shard is the same split without a communicator: the caller renders (rank, world) and owns the gather (tests; a host with its own transport).
 void Testbed::set_render_shard(uint32_t rank, uint32_t world) {
 	if (world == 0 || rank >= world) throw std::runtime_error{"set_render_shard: bad rank / world"};
 	m_render_shard_rank = rank; m_render_shard_world = world;
 }
 void Testbed::render_shard_rows(int height, int& row_begin, int& row_end) const {
-	const bool dp = m_dp_comm && m_world_size > 1;
+	const bool dp = render_is_collective();
 	const uint32_t world = dp ? m_world_size : m_render_shard_world, rank = dp ? m_rank : m_render_shard_rank;
 	const int rows_per = (height + (int)world - 1) / (int)world;
 	row_begin = std::min(height, (int)rank * rows_per);
@@ -1623,7 +1638,7 @@ void Testbed::render_shard_rows(int height, int& row_begin, int& row_end) const 
 }
 void Testbed::fetch_render_surface(RenderBuffer& rb, std::vector<float>& out) {
 	const int W = rb.res[0], H = rb.res[1];
-	if (!(m_dp_comm && m_world_size > 1)) { rb.surface.copy_to_host(out.data(), out.size() * 4); return; }
+	if (!render_is_collective()) { rb.surface.copy_to_host(out.data(), out.size() * 4); return; }
 	// all-gather of the ranks' row ranges (RCCL over xGMI, in place in a buffer of world equal chunks), then one copy to the host
 	int row_begin, row_end;
 	render_shard_rows(H, row_begin, row_end);
@@ -1728,8 +1743,9 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	// the latent code / light direction presented at inference time: one row for every sample of the frame (get_inference_extra_dims, 2362)
 	NgpNetVariant render_variant_storage;
 	const NgpNetVariant* render_variant = net_variant(render_variant_storage, get_inference_extra_dims(), nullptr);
-	if (render_variant && (render_mode == (int)ERenderMode::Normals || render_mode == 8))
-		throw std::runtime_error{"the Normals / EncodingVis render modes run the network's input gradient / activation read-out, which are built for the base network family only"};
+	// (render_mode 8 = m_visualized_dimension > -1, whatever m_render_mode says: that covers the Slice mode's activation read-out below as well)
+	if (render_variant && (render_mode == (int)ERenderMode::Normals || render_mode == 8 || m_visualized_dimension > -1))
+		throw std::runtime_error{"the Normals / EncodingVis render modes (and Slice with visualized_dimension set) run the network's input gradient / activation read-out, which are built for the base network family only"};
 	if (m_render_mode == ERenderMode::Slice) {   // 2445-2476: the network where every ray meets the slice plane; all rays of the frame are shaded
 		const uint32_t n_hit = n_pixels, n_elements = (uint32_t)next_multiple(n_hit, BATCH_SIZE_GRANULARITY);
 		m_tr_vis_rgba.enlarge((size_t)n_elements * 16);
@@ -1996,7 +2012,8 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	if (m_n_params == 0) throw std::runtime_error{"save_snapshot: no network"};
 	drop_prefetch();
 	sync();
-	if (include_optimizer_state) dp_gather_optimizer_state();   // data-parallel with the sharded optimizer: a collective — every rank calls save_snapshot (it may write to its own path)
+	if (include_optimizer_state && m_dp_state_stale)   // sharded data-parallel steps left master weights / moments current only inside this rank's shard
+		throw std::runtime_error{"save_snapshot(include_optimizer_state=True): the fp32 optimizer state is sharded over the data-parallel ranks — call dp_gather_optimizer_state() on ALL ranks first (a collective), then save on whichever rank"};
 	Json snapshot = Json::object();
 	// Trainer::serialize [tcnn]: the inference (EMA) weights in the network precision
 	snapshot["n_params"] = Json((unsigned long long)m_n_params);

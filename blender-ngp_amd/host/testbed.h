@@ -317,12 +317,17 @@ public:
 	DeviceBuffer m_render_gather;
 	// the data-parallel optimizer step (testbed.cpp optimizer_step_sharded): reduce-scatter -> Adam on the rank's shard -> all-gather; false: fp16 all-reduce + replicated step
 	bool m_dp_sharded_optimizer = true;
+	void set_dp_sharded_optimizer(bool on);   // only without a live communicator
+	bool m_dp_state_stale = false;            // sharded steps ran since the last dp_gather_optimizer_state: fp32 state outside this rank's shard is old
+	bool m_render_sharded = false;            // render() is a collective over the data-parallel ranks (rows per rank + all-gather); off: local, whole frame
+	bool render_is_collective() const { return m_dp_comm && m_render_sharded; }   // (a one-rank communicator runs the same path: split, gather buffer, RCCL call)
 	static constexpr size_t DP_PARAM_SLACK = 1024;   // elements behind the weights / gradients: world x shard (shard a multiple of 8) may exceed n_params by < 8 x world
 	DeviceBuffer m_dp_grads_f32, m_dp_shard_f32;
 	void optimizer_step_sharded();
 	void dp_gather_optimizer_state();   // collective: the whole fp32 optimizer state on every rank (before a snapshot with optimizer state / leaving data-parallel mode)
 	void shutdown_data_parallel();
 	bool m_dp_strong_scaling = false;
+	void set_dp_strong_scaling(bool on) { drop_prefetch(); m_dp_strong_scaling = on; }   // every rank, between two steps
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
 	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)
 	//      -> [all-reduce gradients] -> end (optimizer, bookkeeping)

@@ -116,10 +116,44 @@ def test_render_through_a_one_rank_communicator_gathers_the_frame(trained):
     tb.init_data_parallel(0, 1, "render_%d" % os.getpid(), False)
     try:
         assert tb.dp_comm_size == 1
+        assert tb.render_sharded is False           # opt-in: under a communicator render() stays LOCAL (one rank alone may render) ...
+        local = tb.render(64, 40, 1, True)
+        tb.render_sharded = True                    # ... until every rank asks for the collective
         got = tb.render(64, 40, 1, True)
     finally:
+        tb.render_sharded = False
         tb.shutdown_data_parallel()
+    np.testing.assert_array_equal(local, whole)
     np.testing.assert_array_equal(got, whole)
+
+
+def test_sharded_optimizer_switch_is_frozen_under_a_live_communicator(cuda, tmp_path):
+    """flipping dp_sharded_optimizer mid-run would run the replicated step on fp32 state that is stale outside the rank's shard; shutdown and
+    save_snapshot must not start collectives on their own"""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    b = scene.build_testbed(ds)
+    b.init_data_parallel(0, 1, "t_frozen_%d" % os.getpid(), False)
+    try:
+        with pytest.raises(RuntimeError, match="before init_data_parallel"):
+            b.dp_sharded_optimizer = False
+        b.dp_sharded_optimizer = True               # (no change: accepted)
+        scene.train(b, 5)
+        b.dp_gather_optimizer_state()               # the explicit collective (a no-op on one rank), then the snapshot is a local operation
+        b.save_snapshot(str(tmp_path / "dp.msgpack"), True)
+    finally:
+        b.shutdown_data_parallel()
+    b.dp_sharded_optimizer = False                  # no communicator: free to choose
+    scene.train(b, 8)
+    assert b.training_step == 8 and np.isfinite(b.loss)
+
+
+def test_render_refuses_camera_path_arguments(trained):
+    """python_api.cu:131-165 animates along the camera path when start_t >= 0; camera paths are out of scope, so the call must fail instead of returning a still frame"""
+    ds, tb = trained
+    with pytest.raises(RuntimeError, match="camera-path"):
+        tb.render(32, 32, 1, True, 0.0, 1.0, 30.0, 1.0)
+    assert tb.render(32, 32, 1, True, -1.0, -1.0, 30.0, 1.0).shape == (32, 32, 4)
 
 
 def test_rccl_allgather_and_reduce_scatter_on_one_rank(ngp, cuda):
