@@ -108,14 +108,23 @@ def bl_render_leg(tb, ds, res, frames=6):
     try:
         tb.save_snapshot(snap, False)
         tb.shall_train = False
+        # the same view, field of view, background and termination threshold for both renderers: the Blender path reads min_transmittance from the field (0.01, the
+        # reference's default for both: testbed.h:725, neural_radiance_field.cuh:63); bench.py's PSNR evaluation had set the stock tracer's to run.py's 1e-4
+        tb.background_color = [0.0, 0.0, 0.0, 1.0]
+        tb.fov_axis = 0
+        tb.fov = ds["camera_angle_x"] * 180 / np.pi
+        min_t_before = tb.nerf.render_min_transmittance
+        tb.nerf.render_min_transmittance = 0.01
         tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
-        tb.render(res, res, 1, True)
+        for _ in range(3):
+            tb.render(res, res, 1, True)
         ms = []
         for _ in range(frames):
             t0 = time.perf_counter()
             tb.render(res, res, 1, True)
             ms.append((time.perf_counter() - t0) * 1e3)
-        out = {"res": res, "frames": frames, "stock_render_ms": round(sum(ms) / frames, 2), "stock_network_samples": int(tb.render_samples_evaluated)}
+        tb.nerf.render_min_transmittance = min_t_before
+        out = {"res": res, "frames": frames, "min_transmittance": 0.01, "stock_render_ms": round(sum(ms) / frames, 2), "stock_render_ms_frames": [round(x, 2) for x in ms], "stock_network_samples": int(tb.render_samples_evaluated)}
         focal = float(ds["focal"])
 
         def request(n_nerfs):
@@ -132,10 +141,14 @@ def bl_render_leg(tb, ds, res, frames=6):
             return pyngp.RenderRequest(outp, cam, pyngp.RenderModifiers([]), nerfs, big)
 
         bl = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+        for knob, env in (("bl_max_skips_per_pass", "BL_SKIPS"), ("bl_pass_samples_factor", "BL_FACTOR"), ("bl_fused_passes", "BL_FUSED")):   # dev: schedule sweeps
+            if os.environ.get(env):
+                setattr(bl, knob, type(getattr(bl, knob))(float(os.environ[env])))
+        out["bl_schedule"] = {"fused_passes": bool(bl.bl_fused_passes), "max_skips_per_pass": int(bl.bl_max_skips_per_pass), "pass_samples_factor": float(bl.bl_pass_samples_factor), "max_steps_per_pass": int(bl.bl_max_steps_per_pass)}
         for n in (1, 2):
             req = request(n)
-            img = bl.request_nerf_render_sync(req)   # loads the snapshot(s), warms up
-            bl.request_nerf_render_sync(req)
+            for _ in range(5):                        # loads the snapshot(s), warms up (the 4th request of a fresh renderer takes 20-30 ms once: tools/bl_outlier_probe.py)
+                img = bl.request_nerf_render_sync(req)
             ms = []
             for _ in range(frames):
                 t0 = time.perf_counter()
@@ -143,7 +156,9 @@ def bl_render_leg(tb, ds, res, frames=6):
                 ms.append((time.perf_counter() - t0) * 1e3)
             out["bl_render_ms_%dnerf" % n] = round(sum(ms) / frames, 2)
             out["bl_render_ms_min_%dnerf" % n] = round(min(ms), 2)
+            out["bl_render_ms_frames_%dnerf" % n] = [round(x, 2) for x in ms]
             out["bl_network_samples_%dnerf" % n] = int(bl.bl_render_samples)
+            out["bl_passes_%dnerf" % n] = int(bl.bl_render_passes)
             out["bl_coverage_%dnerf" % n] = round(float((img[..., 3] > 0.5).mean()), 3)
         out["bl_over_stock_1nerf"] = round(out["bl_render_ms_1nerf"] / out["stock_render_ms"], 3)
         return out

@@ -286,6 +286,137 @@ __global__ void multi_generate_next_inputs_kernel(uint32_t n_elements, const uin
 	p.n_steps = (uint16_t)n_steps;
 }
 
+
+// ---- one launch at the head of every pass: march_active_rays + cull_global_rays_and_set_proxy_rays_active + compact_rays (nerf_renderer.cu:675-733), plus the
+// per-NeRF lists of the rays that sample each NeRF in this pass and the pass's counts posted to the host.
+// The reference compacts FIRST (on the alive flags the previous pass's cull left) and marches / culls the survivors; here the ray is marched and culled and THEN
+// compacted, so a ray whose last proxy died leaves one pass earlier — it would have idled through that pass (no active proxy, nothing sampled), its colour is the same
+// and it reaches the finished list with the same rgba.  The march may REST: after `max_skips` empty voxels the proxy keeps its t (every DDA iteration is a function of t
+// alone, so pausing between two iterations changes nothing) and the whole ray sits this pass out — no cull before all its marched proxies stand at their hit points, no
+// samples — instead of holding the 63 other lanes of its wave for the ~150 voxels to the far side of the box.  Same per-ray sequence of samples, same pixels.
+constexpr uint32_t MULTI_MAX_LISTS = 30;   // NeRFs with a block-aggregated list counter (2 + 30 LDS words); requests with more take the unfused loop
+
+__device__ __forceinline__ int hit_test_and_march_bounded(v3 origin, v3 dir, v3 idir, float& t_io, const NgpNerfProps* __restrict__ props, uint32_t max_skips, OccBrick& occ) {
+	const Aabb render_aabb = aabb_of(props->render_aabb);
+	const float cone = props->cone_angle, mn = props->min_cone_stepsize, mx = props->max_cone_stepsize;
+	const uint8_t* __restrict__ bitfield = props->density_grid_bitfield;
+	const uint32_t grid_size = props->grid_size, grid_volume = props->grid_volume, max_cascade = props->nerf_cascades - 1;
+	float t = t_io, prev_t = t;
+	uint32_t skips = 0;
+	while (1) {
+		const v3 pos = origin + dir * t;
+		if (!aabb_contains(render_aabb, pos)) { t_io = prev_t; return 0; }   // (hit_test_and_march leaves the t before the last advance)
+		const float dt = get_dt(t, cone, mn, mx);
+		const int mipi = get_mip_from_dt(dt, pos, grid_size, max_cascade);
+		const uint32_t mip = (uint32_t)(mipi < 0 ? 0 : mipi);
+		if (!bitfield) break;
+		if (get_is_occupied(pos, bitfield, mip, grid_size, grid_volume, occ)) break;
+		if (max_skips && skips == max_skips) { t_io = t; return 2; }
+		++skips;
+		prev_t = t;
+		t = get_t_advanced_to_next_voxel(t, cone, pos, dir, idir, grid_size >> mip, mn, mx);
+	}
+	t_io = t;
+	return 1;
+}
+
+struct MultiAdvanceArgs {
+	uint32_t n_prev, n_nerfs, stride, max_skips;
+	NgpGlobalRay* g_src; NgpProxyRay* p_src; NgpGlobalRay* g_dst; NgpProxyRay* p_dst; NgpGlobalRay* g_final;   // (the sources are updated in place before they are copied)
+	v3 cam_pos; const NgpNerfProps* props;
+	uint32_t* counters;        // [0] alive rays, [1 + n] rays that sample NeRF n in this pass; all zero at launch
+	uint32_t* next_counters;   // the other set: zeroed by this launch's last workgroup for the next pass
+	uint32_t* final_counter;   // finished rays (runs over the whole frame)
+	uint32_t* active_lists;    // [n_nerfs][stride] compacted indices
+	uint32_t* blocks_done; unsigned long long* host_mailbox; uint32_t sequence;
+	uint32_t tile_w, tile_h;   // > 0: thread order = 8 x 8 pixel tiles of a tile_w x tile_h image whose ray i is pixel (i % tile_w, i / tile_w) (the first pass)
+};
+
+__global__ void __launch_bounds__(256) multi_advance_kernel(const MultiAdvanceArgs a) {
+	__shared__ uint32_t s_cnt[2 + MULTI_MAX_LISTS], s_base[2 + MULTI_MAX_LISTS];
+	if (threadIdx.x < 2u + MULTI_MAX_LISTS) s_cnt[threadIdx.x] = 0u;
+	__syncthreads();
+	const uint32_t tid = threadIdx.x + blockIdx.x * blockDim.x;
+	uint32_t i = tid;
+	bool in = tid < a.n_prev;
+	if (a.tile_w) {
+		const uint32_t tpr = (a.tile_w + 7u) >> 3, tile = tid >> 6, within = tid & 63u;
+		const uint32_t x = (tile % tpr) * 8u + (within & 7u), y = (tile / tpr) * 8u + (within >> 3);
+		in = x < a.tile_w && y < a.tile_h;
+		i = x + a.tile_w * y;
+		in = in && i < a.n_prev;
+	}
+	NgpGlobalRay g;
+	bool alive = false, fin = false;
+	int32_t active_nerf = -1;
+	if (in) {
+		g = a.g_src[i];
+		if (g.alive) {
+			// march_active_rays (nerf_renderer.cu:271-314)
+			bool rested = false;
+			for (uint32_t n = 0; n < a.n_nerfs; ++n) {
+				NgpProxyRay p = a.p_src[i + n * a.stride];
+				if (p.alive && p.active) {
+					const v3 origin = ld3(p.origin), dir = ld3(p.dir);
+					const v3 idir = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+					float t = p.t;
+					OccBrick occ;
+					const int r = hit_test_and_march_bounded(origin, dir, idir, t, a.props + n, a.max_skips, occ);
+					a.p_src[i + n * a.stride].t = t;
+					if (r == 0) a.p_src[i + n * a.stride].alive = 0;
+					rested = rested || r == 2;
+				}
+			}
+			if (rested) alive = true;   // sits this pass out: flags untouched, the marched proxies go on next pass (one that already stands at its hit returns at once)
+			else {
+				active_nerf = cull_one_ray(i, a.n_nerfs, a.g_src, a.p_src, a.stride, a.cam_pos, a.props);
+				alive = active_nerf >= 0;   // cull clears g.alive when no proxy is left
+			}
+		}
+		fin = !alive && g.rgba[3] > 0.001f;
+	}
+	// compact_rays (nerf_renderer.cu:94-146) + the per-NeRF lists: ranks inside the workgroup by LDS atomics, one global atomic per workgroup and counter
+	uint32_t rank = 0, lrank = 0;
+	if (alive) rank = atomicAdd(&s_cnt[0], 1u); else if (fin) rank = atomicAdd(&s_cnt[1], 1u);
+	if (active_nerf >= 0) lrank = atomicAdd(&s_cnt[2 + active_nerf], 1u);
+	__syncthreads();
+	if (threadIdx.x < 2u + a.n_nerfs) {
+		const uint32_t c = s_cnt[threadIdx.x];
+		uint32_t* ctr = threadIdx.x == 0 ? a.counters : threadIdx.x == 1 ? a.final_counter : a.counters + (threadIdx.x - 1u);
+		s_base[threadIdx.x] = c ? atomicAdd(ctr, c) : 0u;
+	}
+	__syncthreads();
+	if (alive) {
+		const uint32_t idx = s_base[0] + rank;
+		g.alive = 1;
+		a.g_dst[idx] = g;
+		for (uint32_t n = 0; n < a.n_nerfs; ++n) a.p_dst[idx + n * a.stride] = a.p_src[i + n * a.stride];
+		if (active_nerf >= 0) a.active_lists[(size_t)active_nerf * a.stride + s_base[2 + active_nerf] + lrank] = idx;
+	} else if (fin) {
+		g.alive = 0;
+		a.g_final[s_base[1] + rank] = g;
+	}
+	// the last workgroup posts {n_alive, n_active[0 .. n_nerfs)} to the host, one self-tagged 8-byte word each (no ordering between them needed), and clears the
+	// counters of the next pass.  (Ticket after this workgroup's counter atomics have returned: see compact_store in render.hip.)
+	if (a.host_mailbox) {
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t dep = 0;
+			for (uint32_t k = 0; k < 2u + a.n_nerfs; ++k) dep |= s_base[k];
+			uint32_t zero;
+			asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"(dep));
+			if (__hip_atomic_fetch_add(a.blocks_done, 1u + zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+				__hip_atomic_store(a.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				for (uint32_t k = 0; k < 1u + a.n_nerfs; ++k) {
+					const uint32_t v = __hip_atomic_load(a.counters + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(a.next_counters + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(a.host_mailbox + k, (unsigned long long)v | ((unsigned long long)a.sequence << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+			}
+		}
+	}
+}
+
 typedef uint16_t us4m __attribute__((ext_vector_type(4)));
 
 __global__ void multi_composite_kernel(uint32_t n_global_rays, const uint32_t* __restrict__ list, uint32_t current_step, NgpGlobalRay* __restrict__ global_rays, NgpProxyRay* __restrict__ proxy_rays,
@@ -424,6 +555,28 @@ int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uin
 	hipLaunchKernelGGL(multi_composite_kernel, dim3(div_up(n_global_rays, 128)), dim3(128), 0, (hipStream_t)stream, n_global_rays, list, current_step, global_rays, proxy_rays, network_input,
 	                   network_output, out_stride, n_steps, rgb_activation, density_activation, min_transmittance, props);
 	NGP_LAUNCH_CHECK("multi_composite_kernel");
+	return 0;
+}
+
+int ngp_hip_multi_advance(void* stream, uint32_t n_prev, uint32_t n_nerfs, const NgpGlobalRay* global_src, NgpProxyRay* proxy_src, NgpGlobalRay* global_dst, NgpProxyRay* proxy_dst,
+                          uint32_t stride, NgpGlobalRay* global_final, const float* cam_pos, const NgpNerfProps* props, uint32_t max_skips, uint32_t* counters, uint32_t* next_counters,
+                          uint32_t* final_counter, uint32_t* active_lists, uint32_t* blocks_done, uint64_t* host_mailbox, uint32_t sequence, uint32_t tile_w, uint32_t tile_h) {
+	if (!n_prev) return 0;
+	if (n_nerfs == 0 || n_nerfs > MULTI_MAX_LISTS) { set_last_error("ngp_hip_multi_advance: between 1 and 30 NeRFs", hipErrorInvalidValue); return -1; }
+	if (!counters || !final_counter || !active_lists || (host_mailbox && (!blocks_done || !next_counters))) { set_last_error("ngp_hip_multi_advance: counters / lists missing", hipErrorInvalidValue); return -1; }
+	MultiAdvanceArgs a;
+	a.n_prev = n_prev; a.n_nerfs = n_nerfs; a.stride = stride; a.max_skips = max_skips;
+	a.g_src = const_cast<NgpGlobalRay*>(global_src); a.p_src = proxy_src; a.g_dst = global_dst; a.p_dst = proxy_dst; a.g_final = global_final;
+	a.cam_pos.x = cam_pos[0]; a.cam_pos.y = cam_pos[1]; a.cam_pos.z = cam_pos[2]; a.props = props;
+	a.counters = counters; a.next_counters = next_counters; a.final_counter = final_counter; a.active_lists = active_lists;
+	a.blocks_done = blocks_done; a.host_mailbox = (unsigned long long*)host_mailbox; a.sequence = sequence; a.tile_w = tile_w; a.tile_h = tile_h;
+	uint32_t n_threads = n_prev;
+	if (tile_w) {
+		if ((uint64_t)tile_w * tile_h < n_prev) { set_last_error("ngp_hip_multi_advance: tile_w x tile_h smaller than n_prev", hipErrorInvalidValue); return -1; }
+		n_threads = ((tile_w + 7u) / 8u) * ((tile_h + 7u) / 8u) * 64u;
+	}
+	hipLaunchKernelGGL(multi_advance_kernel, dim3(div_up(n_threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
+	NGP_LAUNCH_CHECK("multi_advance_kernel");
 	return 0;
 }
 

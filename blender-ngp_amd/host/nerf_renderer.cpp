@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -258,7 +259,7 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 	m_hit.enlarge((size_t)stride * sizeof(NgpGlobalRay));
 	m_net_in.enlarge((size_t)stride * 8 * sizeof(NgpCoord));
 	m_net_out.enlarge((size_t)stride * 8 * OUT_STRIDE * 2);
-	m_counters.enlarge(8);
+	m_counters.enlarge((size_t)(2 + 2 * (1 + n_nerfs)) * 4 + 8);   // (both loops' words: sized once, the pointers below stay valid)
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(stride * 8));
 	uint32_t* alive_counter = m_counters.as<uint32_t>();
 	uint32_t* hit_counter = alive_counter + 1;
@@ -276,9 +277,103 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 	uint64_t n_samples = 0;
 	HIP_TRY(hipMemsetAsync(hit_counter, 0, 4, st));
 	const float cam_pos[3] = {cam.transform[9], cam.transform[10], cam.transform[11]};
+	last_n_passes = 0;
+	if (fused_passes && n_nerfs <= 30) {
+		// ---- fused pass loop.  Per pass: advance (march the proxies that moved, cull, compact, per-NeRF lists, counts to the host mailbox) -> poll -> per NeRF that is sampled
+		// { next inputs, network, composite }.  n_steps follows the stock tracer's budget (pass_samples_factor x pixels per pass).  The fork's sampler is NOT independent
+		// of how a ray is cut into passes: inside a pass it emits the sample at t + dt BEFORE testing that position (nerf_renderer.cu:350-366), at a pass boundary
+		// march_active_rays moves the ray to the next occupied voxel first — so a boundary that falls next to an empty voxel trades one sample in the gap for one at the
+		// landing point, and where NeRFs overlap the cull between two passes decides who samples next.  The reference's own schedule (clamp(n_rays / n_alive, 1, 8))
+		// depends on resolution and content in the same way; `reference_schedule` reproduces the unfused loop's frame bit for bit, the default differs from it in < 1 %
+		// of the pixels by < 0.03 (tests/test_bl_render_gpu.py).
+		const uint32_t n_words = 1 + n_nerfs;
+		if (m_host_words_n < n_words) {
+			if (m_host_words) (void)hipHostFree(m_host_words);
+			m_host_words = nullptr; m_host_words_n = 0;
+			HIP_TRY(hipHostMalloc((void**)&m_host_words, (size_t)n_words * 8, hipHostMallocMapped | hipHostMallocCoherent));
+			memset(m_host_words, 0, (size_t)n_words * 8);
+			m_host_words_n = n_words;
+		}
+		uint64_t* mailbox_dev = nullptr;
+		HIP_TRY(hipHostGetDevicePointer((void**)&mailbox_dev, m_host_words, 0));
+		// device words: [0] finished rays, [1] workgroups done, then two sets of {alive, active per NeRF}
+		uint32_t* words = m_counters.as<uint32_t>();
+		HIP_TRY(hipMemsetAsync(words, 0, (size_t)(2 + 2 * n_words) * 4, st));
+		uint32_t* final_counter = words, *blocks_done = words + 1;
+		uint32_t* sets[2] = {words + 2, words + 2 + n_words};
+		m_active_lists.enlarge((size_t)stride * n_nerfs * 4);
+		const float factor = reference_schedule ? 1.0f : std::min(std::max(pass_samples_factor, 1.0f), 6.0f);
+		const uint32_t pass_samples = (uint32_t)((float)n_pixels * factor);
+		const size_t max_elems = (size_t)pass_samples + 128u * n_nerfs + 128u;
+		m_net_in.enlarge(max_elems * sizeof(NgpCoord));
+		m_net_out.enlarge(max_elems * OUT_STRIDE * 2);
+		m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes((uint32_t)max_elems));
+		std::vector<uint32_t> n_active(n_nerfs);
+		auto read_mailbox = [&]() {
+			const uint32_t want = m_sequence;
+			const auto t0 = std::chrono::steady_clock::now();
+			for (uint32_t k = 0; k < n_words; ++k) {
+				uint64_t word;
+				for (uint32_t spins = 1; (uint32_t)((word = __atomic_load_n(m_host_words + k, __ATOMIC_ACQUIRE)) >> 32) != want; ++spins) {
+					if ((spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // a launch that died posts nothing: ask the stream
+						HIP_TRY(hipStreamSynchronize(st));
+						if ((uint32_t)((word = __atomic_load_n(m_host_words + k, __ATOMIC_ACQUIRE)) >> 32) != want) throw std::runtime_error{"multi render: the advance launch finished without posting its counts"};
+						break;
+					}
+					__builtin_ia32_pause();
+				}
+				if (k == 0) n_alive = (uint32_t)word; else n_active[k - 1] = (uint32_t)word;
+			}
+		};
+		uint32_t n_prev = n_pixels;
+		int src = 0;
+		bool first = true;
+		while (i < 10000 && n_prev > 0) {
+			const int dst = src ^ 1;
+			const uint32_t n_entered = n_prev;
+			++m_sequence;
+			check(ngp_hip_multi_advance(stream, n_prev, n_nerfs, m_global[src].as<NgpGlobalRay>(), m_proxy[src].as<NgpProxyRay>(), m_global[dst].as<NgpGlobalRay>(), m_proxy[dst].as<NgpProxyRay>(), stride,
+			                            m_hit.as<NgpGlobalRay>(), cam_pos, props_dev, reference_schedule ? 0u : max_skips_per_pass, sets[last_n_passes & 1], sets[(last_n_passes + 1) & 1], final_counter, m_active_lists.as<uint32_t>(),
+			                            blocks_done, mailbox_dev, m_sequence, first ? (uint32_t)ds.scaled_res[0] : 0u, first ? (uint32_t)ds.scaled_res[1] : 0u), "multi_advance");
+			first = false;
+			++last_n_passes;
+			read_mailbox();
+			if (trace) fprintf(stderr, "multi render (fused): pass %u i=%u n_alive=%u n_active[0]=%u\n", last_n_passes, i, n_alive, n_active[0]);
+			src = dst;
+			n_prev = n_alive;
+			if (n_alive == 0) break;
+			NgpGlobalRay* g = m_global[src].as<NgpGlobalRay>();
+			NgpProxyRay* px = m_proxy[src].as<NgpProxyRay>();
+			const uint32_t n_steps = reference_schedule ? std::min(std::max(n_pixels / n_entered, 1u), max_steps) : std::min(std::max(pass_samples / n_alive, 1u), std::max(max_steps_per_pass, 1u));
+			bool sampled = false;
+			for (uint32_t n = 0; n < n_nerfs; ++n) {
+				if (n_active[n] == 0) continue;
+				sampled = true;
+				const NeuralRadianceField& f = *field_of[n];
+				NgpProxyRay* pn = px + (size_t)n * stride;
+				const uint32_t* list = m_active_lists.as<uint32_t>() + (size_t)n * stride;
+				const uint32_t n_network_elements = (n_active[n] * n_steps + 127u) / 128u * 128u;
+				check(ngp_hip_multi_generate_next_inputs_list(stream, n_active[n], list, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
+				NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr};
+				check(ngp_hip_nerf_inference_ws(stream, f.desc_gpu.as<NgpNetDesc>(), f.params.as<uint16_t>(), m_net_in.as<float>(), 7, n_network_elements, m_net_out.as<uint16_t>(), OUT_STRIDE,
+				                                m_enc_ws.data(), m_enc_ws.bytes(), f.n_rgb_hidden_layers == 2 ? nullptr : &nv), "nerf_inference (multi)");
+				n_samples += n_network_elements;
+				check(ngp_hip_multi_composite_list(stream, n_active[n], list, i, g, pn, m_net_in.as<NgpCoord>(), m_net_out.as<uint16_t>(), OUT_STRIDE, n_steps, (int)f.rgb_activation, (int)f.density_activation,
+				                                   f.min_transmittance, props_dev + n), "multi_composite");
+			}
+			if (sampled) i += n_steps;   // (a pass in which every ray rested samples nothing)
+		}
+		uint32_t n_hit = 0;
+		HIP_TRY(hipMemcpyAsync(&n_hit, final_counter, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		check(ngp_hip_multi_shade(stream, n_hit, m_hit.as<NgpGlobalRay>(), 0 /* :602 passes train_in_linear_colors = false */, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(), &ds,
+		                          request.output.flip_y ? 1 : 0), "multi_shade");
+		return n_samples;
+	}
 	while (i < 10000) {
 		const int tmp = dbi % 2, cur = (dbi + 1) % 2;
 		++dbi;
+		++last_n_passes;
 		HIP_TRY(hipMemsetAsync(alive_counter, 0, 4, st));
 		check(ngp_hip_multi_compact_rays(stream, n_alive, m_global[tmp].as<NgpGlobalRay>(), m_global[cur].as<NgpGlobalRay>(), m_proxy[tmp].as<NgpProxyRay>(), m_proxy[cur].as<NgpProxyRay>(),
 		                                 n_nerfs, stride, m_hit.as<NgpGlobalRay>(), alive_counter, hit_counter), "multi_compact_rays");
@@ -320,5 +415,7 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 	                          request.output.flip_y ? 1 : 0), "multi_shade");
 	return n_samples;
 }
+
+NerfRenderer::~NerfRenderer() { if (m_host_words) (void)hipHostFree(m_host_words); }
 
 } // namespace ngp

@@ -154,7 +154,18 @@ public:
 	// returns the number of network samples evaluated; rb.frame_buffer / depth_buffer must be cleared by the caller (bl_render_frame)
 	uint64_t render(RenderBuffer& rb, const RenderRequest& request, void* stream);
 	size_t n_loaded_fields() const { return m_fields.size(); }
+	~NerfRenderer();
+	// the pass loop: fused (default) = one ngp_hip_multi_advance launch (march + cull + compact + lists) and one host-mailbox poll per pass, the stock tracer's
+	// sample budget per pass; unfused = the launch sequence of nerf_renderer.cu:664-791 with its two blocking read-backs (kept as the checker: same pixels)
+	bool fused_passes = true;
+	uint32_t max_skips_per_pass = 96;     // empty voxels a marched proxy may cross in the advance launch before the ray sits the pass out (0: never rests)
+	float pass_samples_factor = 4.0f;     // network samples per pass = factor x pixels (the reference: 1 x, at most 8 steps)
+	uint32_t max_steps_per_pass = 64;
+	bool reference_schedule = false;      // fused loop on the unfused loop's schedule: n_steps from the rays that ENTERED the pass (clamp(pixels / n, 1, max_steps)), no rest — the same frame, bit for bit
+	uint32_t last_n_passes = 0;
 private:
+	uint64_t* m_host_words = nullptr;     // mapped host memory: the advance launch's mailbox
+	uint32_t m_host_words_n = 0, m_sequence = 0;
 	std::vector<std::unique_ptr<NeuralRadianceField>> m_fields;
 	DeviceBuffer m_global[2], m_proxy[2], m_hit, m_net_in, m_net_out, m_counters, m_props_gpu, m_masks_gpu, m_enc_ws, m_active_lists, m_active_counts;
 };

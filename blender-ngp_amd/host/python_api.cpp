@@ -497,6 +497,12 @@ PYBIND11_MODULE(pyngp, m) {
 			}, "Requests a nerf render frame.", py::arg("render_request"), py::arg("render_callback"))
 		.def("wait_for_render", [](Testbed& t) { py::gil_scoped_release rel; t.bl_wait_for_renders(); })
 		.def_readonly("bl_render_samples", &Testbed::m_bl_render_samples)
+		.def_readonly("bl_render_passes", &Testbed::m_bl_render_passes)
+		.def_readwrite("bl_fused_passes", &Testbed::m_bl_fused_passes, "Blender renderer pass loop: True (default) = one fused launch (march + cull + compact + per-NeRF lists) and one host-mailbox poll per pass on the stock tracer's sample budget; False = the reference's launch sequence with its two blocking read-backs per pass (same pixels)")
+		.def_readwrite("bl_reference_schedule", &Testbed::m_bl_reference_schedule, "fused pass loop on the unfused loop's schedule (n_steps from the rays that entered the pass, no resting rays): the same frame bit for bit; the fork's sampler depends on where the pass boundaries fall")
+		.def_readwrite("bl_max_skips_per_pass", &Testbed::m_bl_max_skips_per_pass)
+		.def_readwrite("bl_max_steps_per_pass", &Testbed::m_bl_max_steps_per_pass)
+		.def_readwrite("bl_pass_samples_factor", &Testbed::m_bl_pass_samples_factor)
 		.def("set_nerf_camera_matrix", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& cam) { t.set_nerf_camera_matrix(mat34_from_py(cam)); })
 		.def("reset_camera", &Testbed::reset_camera)
 		.def("reset_accumulation", [](Testbed& t, bool, bool) { t.m_windowless_render_surface.reset_accumulation(); }, py::arg("due_to_camera_movement") = false, py::arg("immediate_redraw") = true)

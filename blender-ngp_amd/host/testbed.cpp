@@ -1953,7 +1953,10 @@ void Testbed::bl_render_frame(RenderBuffer& rb, const RenderRequest& request) { 
 	if (!m_renderer) m_renderer.reset(new NerfRenderer());
 	rb.frame_buffer.memset(0, m_stream);   // CudaRenderBuffer::clear_frame
 	rb.depth_buffer.memset(0, m_stream);
+	m_renderer->fused_passes = m_bl_fused_passes; m_renderer->reference_schedule = m_bl_reference_schedule; m_renderer->max_skips_per_pass = m_bl_max_skips_per_pass;
+	m_renderer->pass_samples_factor = m_bl_pass_samples_factor; m_renderer->max_steps_per_pass = m_bl_max_steps_per_pass;
 	m_bl_render_samples = m_renderer->render(rb, request, m_stream);
+	m_bl_render_passes = m_renderer->last_n_passes;
 	rb.color_space = request.output.color_space;
 	rb.tonemap_curve = request.output.tonemap_curve;
 	if (rb.spp == 0) rb.accumulate_buffer.memset(0, m_stream);

@@ -384,6 +384,11 @@ public:
 	bool bl_try_begin_render();                                                        // false if a render is already in flight
 	void bl_end_render();
 	uint64_t m_bl_render_samples = 0;
+	uint32_t m_bl_render_passes = 0;
+	bool m_bl_fused_passes = true;            // NerfRenderer::fused_passes and its schedule knobs (nerf_renderer.h)
+	uint32_t m_bl_max_skips_per_pass = 96, m_bl_max_steps_per_pass = 64;
+	float m_bl_pass_samples_factor = 4.0f;
+	bool m_bl_reference_schedule = false;
 	RenderBuffer m_bl_render_surface;
 	// request_nerf_render_async workers: detached like the reference's (python_api.cu:228-229), but counted, so that the Testbed can wait for them
 	// (a worker may itself queue the next request from its callback — nobody ever joins a thread, least of all itself)

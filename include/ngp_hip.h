@@ -497,6 +497,16 @@ int ngp_hip_multi_generate_next_inputs_list(void* stream, uint32_t n_elements, c
 int ngp_hip_multi_composite_list(void* stream, uint32_t n_global_rays, const uint32_t* list, uint32_t current_step, NgpGlobalRay* global_rays, NgpProxyRay* proxy_rays,
                                  const NgpCoord* network_input, const uint16_t* network_output, uint32_t out_stride, uint32_t n_steps, int rgb_activation, int density_activation,
                                  float min_transmittance, const NgpNerfProps* props);
+/* One launch at the head of a pass = march_active_rays + cull_global_rays_and_set_proxy_rays_active + compact_rays (nerf_renderer.cu:675-733, in that order: a ray
+ * whose last proxy dies leaves one pass earlier than in the reference, where it idles through that pass; same colours) + the per-NeRF lists of
+ * ngp_hip_multi_cull_rays_collect (indices into the COMPACTED arrays) + the pass's counts.  proxy_src is updated in place (t, alive, active) before it is copied.
+ * max_skips > 0: a proxy that has walked that many empty voxels keeps its t and the ray sits this pass out (no cull, no samples; the walk resumes next pass at the
+ * same DDA iteration).  counters: [0] alive, [1 + n] rays that sample NeRF n — zero at launch; next_counters: the set the launch's last workgroup clears for the next
+ * pass; host_mailbox (optional, device pointer to 1 + n_nerfs mapped host words): word k = counters[k] | sequence << 32, written by the last workgroup.
+ * tile_w, tile_h > 0: the threads visit the rays in 8 x 8 pixel tiles of a tile_w x tile_h image (ray i = pixel (i % tile_w, i / tile_w)): the first pass. */
+int ngp_hip_multi_advance(void* stream, uint32_t n_prev, uint32_t n_nerfs, const NgpGlobalRay* global_src, NgpProxyRay* proxy_src, NgpGlobalRay* global_dst, NgpProxyRay* proxy_dst,
+                          uint32_t stride, NgpGlobalRay* global_final, const float* cam_pos, const NgpNerfProps* props, uint32_t max_skips, uint32_t* counters, uint32_t* next_counters,
+                          uint32_t* final_counter, uint32_t* active_lists, uint32_t* blocks_done, uint64_t* host_mailbox, uint32_t sequence, uint32_t tile_w, uint32_t tile_h);
 int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays, int train_in_linear_colors, float* frame_buffer, float* depth_buffer,
                         const NgpDownsampleInfo* ds_host, int flip_y);                                                        /* :512-563 */
 
