@@ -615,18 +615,18 @@ static_assert(sizeof(GbRecord) == 12 && 4u * sizeof(GbRecord) <= GB_ITEMS_PER_SA
 // SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
 // hashed level: item = (sample, (y, z) pair) -> one GbRecord (two when the x corners straddle a slice boundary), bin = slice.
 template <int D, bool SCATTER>
-__device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, const NgpGridLevel& lv, uint32_t level,
+__device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint32_t* __restrict__ base, uint32_t* __restrict__ side /* NI * GB_FX_CHUNK words of LDS */, const NgpGridLevel& lv, uint32_t level,
                                               const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
                                               GbFxCounters* __restrict__ ctr, ulonglong2* __restrict__ sums) {
 	constexpr int NI = D == 3 ? 4 : 2;
 	constexpr int PER = GB_FX_CHUNK / 256;
 	const uint32_t hmask = lv.size - 1;
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	// rank of the pair's record inside this workgroup's share of its bin (15 bits: at most 2 * 4 * GB_FX_CHUNK records per workgroup), a second rank in bits 15-29 and
-	// bit 30 when the two x corners fall into DIFFERENT slices, or ~0 (no record).  The x term of the hash is x itself: below 4096 it never reaches the slice bits, and at
-	// finer levels (resolution >= 4096: aabb_scale >= 4 with base.json, e.g. the fox scene's levels 14 and 15) corner x + 1 leaves corner x's slice only when x + 1 is a
-	// multiple of 4096 — such a pair leaves as TWO records, one per corner, each with the other corner's terms zeroed.  The bins are recomputed where they are needed.
-	uint32_t code[PER][NI];
+	// The x term of the hash is x itself: below 4096 it never reaches the slice bits, so the slice of a pair is fixed by (y, z).  At finer levels (resolution >= 4096:
+	// aabb_scale >= 4 with base.json, e.g. the fox scene's levels 14 and 15) corner x + 1 leaves corner x's slice only when x + 1 is a multiple of 4096 — such a pair
+	// leaves as TWO records, one per corner, each with the other corner's terms zeroed (bit 31 of its code; the second record's rank waits in `side`).
+	const bool straddle = lv.resolution >= GB_FX_SLICE;   // (uniform per workgroup)
+	uint32_t code[PER][NI];   // bin << 16 | rank inside this workgroup, or ~0
 	h2 gq[PER]; float px[PER], py[PER], pz[PER];
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
@@ -644,14 +644,15 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
 		const uint32_t hy[2] = {p.gy * 2654435761u, (p.gy + 1u) * 2654435761u};
 		const uint32_t hz[2] = {D == 3 ? p.gz * 805459861u : 0u, D == 3 ? (p.gz + 1u) * 805459861u : 0u};
+		const uint32_t xs = straddle ? p.gx : 0u;   // (x < 4096 cannot reach the slice bits)
 #pragma unroll
 		for (int m = 0; m < NI; ++m) {
 			const uint32_t hb = hy[m & 1] ^ hz[m >> 1];
-			const uint32_t bin0 = ((hb ^ p.gx) & hmask) / GB_FX_SLICE, bin1 = ((hb ^ (p.gx + 1u)) & hmask) / GB_FX_SLICE;
-			uint32_t c = 0xffffffffu;
-			if (live) {
-				c = atomicAdd(&hist[bin0], 1u);
-				if (bin1 != bin0) c |= (atomicAdd(&hist[bin1], 1u) << 15) | (1u << 30);
+			const uint32_t bin = ((hb ^ xs) & hmask) / GB_FX_SLICE;
+			uint32_t c = live ? ((bin << 16) | atomicAdd(&hist[bin], 1u)) : 0xffffffffu;
+			if (straddle && live) {
+				const uint32_t bin1 = ((hb ^ (p.gx + 1u)) & hmask) / GB_FX_SLICE;
+				if (bin1 != bin) { side[(u * NI + m) * 256 + threadIdx.x] = (bin1 << 16) | atomicAdd(&hist[bin1], 1u); c |= 0x80000000u; }
 			}
 			code[u][m] = c;
 		}
@@ -683,25 +684,23 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 			const uint32_t hb = ((p.gy + yb) * 2654435761u) ^ (D == 3 ? (p.gz + zb) * 805459861u : 0u);
 			const float wy = yb ? p.fy : (1.0f - p.fy), wz = zb ? p.fz : (1.0f - p.fz);
 			GbRecord r;
-			uint32_t e[2], bin[2];
+			uint32_t e[2];
 #pragma unroll
 			for (uint32_t xb = 0; xb < 2; ++xb) {
-				const uint32_t idx = (hb ^ (p.gx + xb)) & hmask;
-				e[xb] = idx & (GB_FX_SLICE - 1); bin[xb] = idx / GB_FX_SLICE;
+				e[xb] = ((hb ^ (p.gx + xb)) & hmask) & (GB_FX_SLICE - 1);
 				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
 				if (D == 3) w *= wz;
 				r.t[2 * xb] = gb_term_half(w * g0); r.t[2 * xb + 1] = gb_term_half(w * g1);
 			}
-			if (!((c >> 30) & 1u)) {
-				r.entries = e[0] | (e[1] << 12);
-				out[base[bin[0]] + (c & 0x7fffu)] = r;
-			} else {   // the x corners straddle a slice boundary: one record per corner
-				GbRecord r0 = r, r1 = r;
-				r0.entries = e[0] | (e[0] << 12); r0.t[2] = (half_t)0.0f; r0.t[3] = (half_t)0.0f;
-				r1.entries = e[1] | (e[1] << 12); r1.t[0] = (half_t)0.0f; r1.t[1] = (half_t)0.0f;
-				out[base[bin[0]] + (c & 0x7fffu)] = r0;
-				out[base[bin[1]] + ((c >> 15) & 0x7fffu)] = r1;
+			if (straddle && (c & 0x80000000u)) {   // one cell in 4096: the x + 1 corner's record goes to its own slice, this one keeps the x corner
+				const uint32_t c1 = side[(u * NI + m) * 256 + threadIdx.x];
+				GbRecord q;
+				q.entries = e[1] | (e[1] << 12); q.t[0] = (half_t)0.0f; q.t[1] = (half_t)0.0f; q.t[2] = r.t[2]; q.t[3] = r.t[3];
+				out[base[c1 >> 16] + (c1 & 0xffffu)] = q;
+				e[1] = e[0]; r.t[2] = (half_t)0.0f; r.t[3] = (half_t)0.0f;
 			}
+			r.entries = e[0] | (e[1] << 12);
+			out[base[(c >> 16) & 0xffu] + (c & 0xffffu)] = r;
 		}
 	}
 }
@@ -804,10 +803,12 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 }
 
 template <int D, bool SCATTER>
-__global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+// (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask) {
 	NGP_RAISE_CHAIN_PRIORITY();
-	static_assert(GB_FX_CHUNK * 8 <= 32768, "rank fields: 15 bits");
+	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
+	static_assert(4 * GB_FX_CHUNK <= 4 * GB_STAGE, "the hashed path's side ranks fit the dense path's staging words");
 	const uint32_t level = blockIdx.y;
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
 	const NgpGridLevel lv = desc->levels[level];
@@ -818,7 +819,7 @@ __global__ void __launch_bounds__(256) gb_fx_bin_kernel(const NgpNetDesc* __rest
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
 	if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums, wg_hist);
-	else gb_bin_hashed<D, SCATTER>(hist, base, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
+	else gb_bin_hashed<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
 }
 
 // pass 4: the owner of (level, slice) adds its items into 8192 x 2 64-bit fixed-point words in LDS and writes the final fp16 gradients

@@ -364,7 +364,7 @@ __device__ __forceinline__ uint32_t wm_serial_march(const TrainSampleArgs& a, v3
 	return j;
 }
 
-__global__ void __launch_bounds__(256) generate_training_samples_wave_kernel(const TrainSampleArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) generate_training_samples_wave_kernel(const TrainSampleArgs a) {
 	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
 	__shared__ WmSeg s_segs[WM_RAYS_PER_WG][WM_MAX_SEGS];
 	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
@@ -631,7 +631,7 @@ __device__ __forceinline__ float cw_replay(float t, uint32_t n, float cone_angle
 	return t;
 }
 
-__global__ void __launch_bounds__(256) generate_training_samples_cone_wave_kernel(const TrainSampleArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) generate_training_samples_cone_wave_kernel(const TrainSampleArgs a) {
 	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
 	__shared__ float s_cp[WM_RAYS_PER_WG][CW_MAX_CP];
 	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
