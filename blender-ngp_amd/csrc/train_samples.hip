@@ -12,6 +12,12 @@
 
 namespace ngp {
 
+// The wave-per-ray marches run BESIDE the backward chain: every register they hold is one the chain's waves cannot have (a march at 137 registers took the binning
+// kernels beside it from 35 + 67 us to 64 + 75).  Minimum waves per SIMD the compiler must leave room for = the register cap (4 -> 128, 5 -> 102, 6 -> 85).
+#ifndef NGP_MARCH_WAVES_PER_EU
+#define NGP_MARCH_WAVES_PER_EU 4
+#endif
+
 // occupied runs a ray may have before the write pass falls back to a serial re-march (LDS: 6 B x 256 threads per run slot)
 #define NGP_MAX_RUNS 24
 
@@ -364,7 +370,7 @@ __device__ __forceinline__ uint32_t wm_serial_march(const TrainSampleArgs& a, v3
 	return j;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) generate_training_samples_wave_kernel(const TrainSampleArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NGP_MARCH_WAVES_PER_EU, 8))) generate_training_samples_wave_kernel(const TrainSampleArgs a) {
 	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
 	__shared__ WmSeg s_segs[WM_RAYS_PER_WG][WM_MAX_SEGS];
 	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
@@ -631,7 +637,7 @@ __device__ __forceinline__ float cw_replay(float t, uint32_t n, float cone_angle
 	return t;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) generate_training_samples_cone_wave_kernel(const TrainSampleArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NGP_MARCH_WAVES_PER_EU, 8))) generate_training_samples_cone_wave_kernel(const TrainSampleArgs a) {
 	__shared__ uint32_t s_brick_any[NGP_NERF_GRID_N_CELLS / 64 / 32];
 	__shared__ float s_cp[WM_RAYS_PER_WG][CW_MAX_CP];
 	__shared__ uint64_t s_win_mask[WM_RAYS_PER_WG][WM_MAX_WINDOWS];
