@@ -521,6 +521,8 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property_readonly("dp_comm_size", [](Testbed& t) { return t.m_dp_comm ? ngp_rccl_comm_size(t.m_dp_comm) : 0; }, "ranks of the RCCL communicator of init_data_parallel (ncclCommCount), 0 without one")
 		.def_readonly("world_size", &Testbed::m_world_size)
 		.def_readonly("rank", &Testbed::m_rank)
+		.def_property("dp_march_behind_exchange", [](Testbed& t) { return t.m_dp_march_behind_exchange; }, &Testbed::set_dp_march_behind_exchange,
+			"data-parallel step: hold the next step's march (second stream) until this step's gradients are final, so that it runs beside the RCCL exchange instead of beside the backward pass.  On by default when init_data_parallel is called with more than one rank; same samples either way")
 		.def_property("strong_scaling", [](Testbed& t) { return t.m_dp_strong_scaling; }, &Testbed::set_dp_strong_scaling,
 			"data-parallel batch split: True = train(B) back-propagates B / world per rank (the reference's convergence per step), False = B per rank (world x the global batch).  Set it on every rank between two steps; rays_per_batch re-adapts through the counter feedback within a few steps")
 		.def("train_nerf_dp_begin", [](Testbed& t, uint32_t batch, bool get_loss, bool wait) { uint32_t c[2]; { py::gil_scoped_release rel; t.train_nerf_dp_begin(batch, c, get_loss, wait); } return py::make_tuple(c[0], c[1]); },

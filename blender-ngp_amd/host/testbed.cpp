@@ -927,6 +927,9 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 	m_dp_comm = ngp_rccl_init((int)rank, (int)world_size, id);
 	if (!m_dp_comm) { m_dp_shm.reset(); set_distributed(0, 1); throw std::runtime_error{std::string{"ngp_rccl_init failed: "} + ngp_hip_last_error()}; }
 	m_dp_shm->barrier();
+	// with more than one rank the run-ahead march waits for the gradients and runs beside the exchange (maybe_prefetch_next): that needs the event behind the backward pass
+	m_dp_march_behind_exchange = world_size > 1;
+	if (m_dp_march_behind_exchange) m_want_grid_grad_event = true;
 }
 // The sharded optimizer step leaves the fp32 state (master weights, Adam moments) of other ranks' shards stale.  Whoever needs the whole state — a snapshot with
 // optimizer state, training on after shutdown_data_parallel — gathers it first.  Collective: every rank of the communicator calls it.
@@ -1054,7 +1057,13 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_counters_event, 0));
 	}
 	// (holding the march back until the step's MLP backward kernel is through was measured: no gain, 0.587 -> 0.593 ms)
-	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng, true);
+	// Data parallel over more than one rank: the gradient exchange (reduce-scatter, all-gather: RCCL kernels on a few workgroups, bound by the xGMI links) follows the
+	// backward pass on stream A and leaves the chip idle for as long as the march takes on its own (~140 us vs 61-370 us of wire time at 8-2 ranks).  The
+	// march is therefore held back until the gradients are final and runs BESIDE THE EXCHANGE with all its workgroups: the backward pass loses the neighbour that costs it
+	// ~45 us (183 us alone, 229 beside the march), the march costs nothing.  Same kernel, same inputs, same samples.
+	const bool behind_exchange = m_dp_comm && m_dp_march_behind_exchange && m_grid_grad_event_recorded;
+	if (behind_exchange) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_grid_grad_event, 0));
+	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng, !behind_exchange);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
 	m_prefetch = p;

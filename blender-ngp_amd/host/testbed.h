@@ -327,6 +327,8 @@ public:
 	void dp_gather_optimizer_state();   // collective: the whole fp32 optimizer state on every rank (before a snapshot with optimizer state / leaving data-parallel mode)
 	void shutdown_data_parallel();
 	bool m_dp_strong_scaling = false;
+	bool m_dp_march_behind_exchange = false;   // set by init_data_parallel when world_size > 1 (pyngp: dp_march_behind_exchange, settable for one-rank tests)
+	void set_dp_march_behind_exchange(bool on) { drop_prefetch(); m_dp_march_behind_exchange = on; if (on) m_want_grid_grad_event = true; }
 	void set_dp_strong_scaling(bool on) { drop_prefetch(); m_dp_strong_scaling = on; }   // every rank, between two steps
 	// step = begin (samples, inference, loss/compaction; returns the LOCAL counters) -> [all-reduce counters + loss]
 	//      -> backward (counter feedback with the GLOBAL sums, next step's march on stream B, forward + backward; gradients ready)

@@ -300,3 +300,30 @@ def test_resting_rays_render_the_same_pixels(trained, mode):
     for b in frames:
         np.testing.assert_array_equal(a, b)
     assert np.abs(a[..., :3]).max() > 0
+
+
+def test_march_behind_the_exchange_trains_the_same_model(cuda):
+    """init_data_parallel with more than one rank holds the next step's march until the gradients are final, so that it runs beside the RCCL exchange instead of beside
+    the backward pass (Testbed::maybe_prefetch_next).  On one rank the switch is off by default; set by hand, the same schedule runs: same counter trajectory for the
+    first steps (before the unordered compaction slots let two runs drift, tests/test_step_schedule_gpu.py), a finite loss, the same picture up to training noise."""
+    import scene
+    runs = []
+    for behind in (False, True):
+        ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+        tb = scene.build_testbed(ds)
+        tb.async_training_steps = True
+        tb.init_data_parallel(0, 1, "t_behind_%d_%d" % (os.getpid(), behind), False)
+        assert tb.dp_march_behind_exchange is False      # one rank: nothing to hide the march behind
+        tb.dp_march_behind_exchange = behind
+        sizes = []
+        for _ in range(40):
+            tb.frame()
+            sizes.append(tb.nerf.training.measured_batch_size)
+        tb.sync()
+        tb.shutdown_data_parallel()
+        runs.append((tb.loss, np.array(sizes)))
+        assert tb.training_step == 40 and np.isfinite(tb.loss)
+    (la, sa), (lb, sb) = runs
+    assert sa[0] == sb[0]
+    np.testing.assert_allclose(sa[:12], sb[:12], rtol=0.05)
+    assert abs(la - lb) < 0.5 * max(la, lb)
