@@ -54,6 +54,7 @@ __device__ __forceinline__ int slot_feature(int map, int kb, int g, int e) {
 		case MAP_ENC: return 16 * g + 8 * kb + e;                         // hash features: levels 8g..8g+7
 		case MAP_HID: return 16 * kb + 8 * (e >> 2) + 4 * g + (e & 3);    // rows of a 32x32 D tile pair
 		case MAP_RGBIN: return kb == 0 ? (8 * (e >> 2) + 4 * g + (e & 3)) : (16 + 8 * g + e); // [density out | SH]
+		case 4: return 32 + 8 * g + e;                                    // MAP_XTRA (network_netx_mfma.cuh): the extra-dims block behind [density out | SH]
 		default: return 8 * g + e;                                        // 16 output channels
 	}
 }
@@ -380,7 +381,7 @@ constexpr uint32_t ENC_QUEUE_BYTES = 8 * ENC_QUEUE_STRIDE * 4;
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
 
 __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
-                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model) {
+                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model, uint32_t grid_off) {
 	__shared__ uint32_t s_first[9];
 	__shared__ uint32_t s_item;
 	const uint32_t n_chunks = (n + ENC_CHUNK - 1) / ENC_CHUNK;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 		s_first[threadIdx.x] = first;
 	}
 	__syncthreads();
-	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	const h2* __restrict__ grid = (const h2*)(params + grid_off);   // GRID_OFF for the base family
 	const uint32_t home = xcc_id();
 	for (uint32_t q = 0; q < 8; ++q) {
 		const uint32_t k = (home + q) & 7u;
@@ -454,8 +455,8 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 // together.  Between two launches nothing else touches the tables, so each XCD fetches a level's 2 MiB once and serves every further touch from its L2.
 template <bool PAIR>
 __global__ void __launch_bounds__(256) encode_levels_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
-                                                                   uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t l0, uint32_t l1) {
-	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+                                                                   uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t l0, uint32_t l1, uint32_t grid_off) {
+	const h2* __restrict__ grid = (const h2*)(params + grid_off);
 	for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) {
 		const float* c = coords + (size_t)s * coord_stride;
 		// the positions stream through once per launch: keep them from displacing table lines in the L2
@@ -1275,12 +1276,12 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 // backward kernel left.  Only run when camera parameters train.
 #pragma clang fp contract(off)
 __global__ void __launch_bounds__(256) nerf_input_pos_gradient_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
-                                                                      uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes, float* __restrict__ dL_dinput) {
+                                                                      uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes, float* __restrict__ dL_dinput, uint32_t grid_off) {
 	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n) return;
 	const float* c = coords + (size_t)s * coord_stride;
 	const f3_t pv = load_pos3(c);
-	const h2* __restrict__ grid = (const h2*)(params + GRID_OFF);
+	const h2* __restrict__ grid = (const h2*)(params + grid_off);
 	float gp[3] = {0.0f, 0.0f, 0.0f};
 	for (int l = 0; l < 16; ++l) {
 		const NgpGridLevel lv = desc->levels[l];
@@ -1809,6 +1810,7 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 }
 
 #include "network_generic.cuh"
+#include "network_netx_mfma.cuh"
 
 // NgpNetVariant -> what the generic kernels take; returns false for the base family (which stays on the fused kernels)
 static bool variant_is_generic(const NgpNetVariant* v) { return v && (v->n_extra_dims != 0 || v->n_rgb_hidden_layers != 2); }
@@ -1874,6 +1876,28 @@ int ngp_hip_nerf_init_params(void* stream, const NgpNetDesc* desc_host, uint64_t
 	return 0;
 }
 
+// ---- the variants on the MFMA kernels of network_netx_mfma.cuh.  NgpNetVariant::flags & NGP_NETX_SCALAR keeps the scalar kernels of network_generic.cuh (the checker).
+static bool variant_scalar(const NgpNetVariant* v) { return v && (v->flags & NGP_NETX_SCALAR); }
+// mode 0 inference, 1 density, 2 training forward; planes != NULL: the features were encoded into level planes (the _ws entry points)
+static int nx_forward(void* stream, int mode, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride,
+                      uint16_t* x_saved, const h2* planes, uint32_t n_pad) {
+	NxFwdArgs a{desc_dev, (const half_t*)params, coords, stride, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad, v->extra_dims, v->sample_slot, v->n_extra_dims,
+	            gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers).n_mlp};
+	const dim3 grid(fwd_grid(n));
+	hipStream_t st = (hipStream_t)stream;
+	int rc = 0;
+	if (mode == 1) { if (planes) nx_fwd_launch<1, 1, 0, 0>(grid, st, a); else nx_fwd_launch<1, 0, 0, 0>(grid, st, a); }
+	else if (mode == 2) {
+		if (planes) { set_last_error("nx_forward: the training forward of a network variant has no plane path", hipErrorInvalidValue); return -1; }
+		rc = nx_fwd_dispatch<2, 0>(v->n_rgb_hidden_layers, v->n_extra_dims != 0, grid, st, a);
+	}
+	else if (planes) rc = nx_fwd_dispatch<0, 1>(v->n_rgb_hidden_layers, v->n_extra_dims != 0, grid, st, a);
+	else rc = nx_fwd_dispatch<0, 0>(v->n_rgb_hidden_layers, v->n_extra_dims != 0, grid, st, a);
+	if (rc) { set_last_error("network variant outside 0..3 hidden colour layers x extra dims or not", hipErrorInvalidValue); return -1; }
+	NGP_LAUNCH_CHECK("nx_forward_kernel");
+	return 0;
+}
+
 static int gen_forward(void* stream, int mode, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
 	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
 	GenExtra ex; ex.extra_dims = v->extra_dims; ex.sample_slot = v->sample_slot;
@@ -1890,7 +1914,8 @@ int ngp_hip_nerf_inference(void* stream, const NgpNetDesc* desc_dev, const uint1
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	if (variant_check(variant, "ngp_hip_nerf_inference: at most 16 extra dims and 3 hidden colour layers")) return -1;
-	if (variant_is_generic(variant)) return gen_forward(stream, 0, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, nullptr);
+	if (variant_is_generic(variant)) return variant_scalar(variant) ? gen_forward(stream, 0, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, nullptr)
+	                                                                 : nx_forward(stream, 0, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, nullptr, nullptr, 0u);
 	hipLaunchKernelGGL((nerf_forward_kernel<0, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0>");
 	return 0;
@@ -1900,6 +1925,7 @@ int ngp_hip_nerf_density(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	if (n == 0) return 0;
 	if (variant_is_generic(variant)) {   // the density network is the same, the grid sits behind a different number of MLP parameters; the direction / extra dims are not read
 		NgpNetVariant v = *variant; v.extra_dims = nullptr; v.sample_slot = nullptr;
+		if (!variant_scalar(variant)) return nx_forward(stream, 1, &v, desc_dev, params, pos, pos_stride_floats, n, out0, 1, nullptr, nullptr, 0u);
 		return gen_forward(stream, 1, &v, desc_dev, params, pos, pos_stride_floats, n, out0, 1, nullptr);
 	}
 	hipLaunchKernelGGL((nerf_forward_kernel<1, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, (const h2*)nullptr, 0u);
@@ -1912,7 +1938,8 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	if (variant_check(variant, "ngp_hip_nerf_forward: at most 16 extra dims and 3 hidden colour layers")) return -1;
-	if (variant_is_generic(variant)) return gen_forward(stream, 2, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, x_saved);
+	if (variant_is_generic(variant)) return variant_scalar(variant) ? gen_forward(stream, 2, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, x_saved)
+	                                                                 : nx_forward(stream, 2, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, x_saved, nullptr, 0u);
 	hipLaunchKernelGGL((nerf_forward_kernel<2, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<2>");
 	return 0;
@@ -1923,7 +1950,7 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
 uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n) { return ENC_QUEUE_BYTES + (uint64_t)16 * next_multiple_u32(n, ENC_CHUNK) * 4u; }
 
 static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, void* workspace, uint64_t workspace_bytes,
-                         const h2** planes_out, uint32_t* n_pad_out, const char* who, const NgpNetDesc* desc_host_for_groups = nullptr) {
+                         const h2** planes_out, uint32_t* n_pad_out, const char* who, const NgpNetDesc* desc_host_for_groups = nullptr, uint32_t grid_off = GRID_OFF) {
 	if (!workspace || workspace_bytes < ngp_hip_nerf_encode_workspace_bytes(n)) { set_last_error(who, hipErrorInvalidValue); return -1; }
 	const uint32_t n_pad = next_multiple_u32(n, ENC_CHUNK);
 	uint32_t* queues = (uint32_t*)workspace;
@@ -1943,8 +1970,8 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 			uint64_t bytes = (uint64_t)desc_host_for_groups->levels[l0].size * 4u;
 			uint32_t l1 = l0 + 1;
 			while (l1 < 16 && bytes + (uint64_t)desc_host_for_groups->levels[l1].size * 4u <= (uint64_t)cap_kib * 1024u) { bytes += (uint64_t)desc_host_for_groups->levels[l1].size * 4u; ++l1; }
-			if (pair) hipLaunchKernelGGL(encode_levels_planes_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1);
-			else hipLaunchKernelGGL(encode_levels_planes_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1);
+			if (pair) hipLaunchKernelGGL(encode_levels_planes_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1, grid_off);
+			else hipLaunchKernelGGL(encode_levels_planes_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, l0, l1, grid_off);
 			NGP_LAUNCH_CHECK("encode_levels_planes_kernel");
 			l0 = l1;
 		}
@@ -1955,7 +1982,7 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
 	const uint32_t blocks = items < 2048u ? items : 2048u;  // persistent: 8 workgroups per CU
 	static const uint32_t cost_model = getenv("NGP_HIP_ENC_COST") ? (uint32_t)atoi(getenv("NGP_HIP_ENC_COST")) : 0u;   // dev: A / B of the queue cut
-	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model);
+	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
 	NGP_LAUNCH_CHECK("encode_planes_kernel");
 	*planes_out = planes; *n_pad_out = n_pad;
 	return 0;
@@ -1964,9 +1991,14 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                               uint32_t n, uint16_t* out, uint32_t out_stride, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
-	if (variant_is_generic(variant)) return ngp_hip_nerf_inference(stream, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, variant);   // the generic network has one path
+	if (variant_scalar(variant)) return ngp_hip_nerf_inference(stream, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, variant);   // the scalar checker has one path
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_nerf_inference_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
 	const h2* planes; uint32_t n_pad;
+	if (variant_is_generic(variant)) {   // same two kernels, the grid behind the variant's MLP parameters, the variant's MLP kernel over the planes
+		if (variant_check(variant, "ngp_hip_nerf_inference_ws: at most 16 extra dims and 3 hidden colour layers")) return -1;
+		if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_inference_ws: workspace too small", nullptr, ngp_hip_net_mlp_params_host(variant))) return -1;
+		return nx_forward(stream, 0, variant, desc_dev, params, coords, coord_stride_floats, n, out, out_stride, nullptr, planes, n_pad);
+	}
 	if (launch_encode(stream, desc_dev, params, coords, coord_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_inference_ws: workspace too small")) return -1;
 	hipLaunchKernelGGL((nerf_forward_kernel<0, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (half_t*)out, out_stride, (half_t*)nullptr, planes, n_pad);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<0, pre>");
@@ -1976,8 +2008,12 @@ int ngp_hip_nerf_inference_ws(void* stream, const NgpNetDesc* desc_dev, const ui
 int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n, uint16_t* out0,
                             void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant) {
 	if (n == 0) return 0;
-	if (variant_is_generic(variant)) return ngp_hip_nerf_density(stream, desc_dev, params, pos, pos_stride_floats, n, out0, variant);
+	if (variant_scalar(variant)) return ngp_hip_nerf_density(stream, desc_dev, params, pos, pos_stride_floats, n, out0, variant);
 	const h2* planes; uint32_t n_pad;
+	if (variant_is_generic(variant)) {
+		if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_density_ws: workspace too small", nullptr, ngp_hip_net_mlp_params_host(variant))) return -1;
+		return nx_forward(stream, 1, variant, desc_dev, params, pos, pos_stride_floats, n, out0, 1, nullptr, planes, n_pad);
+	}
 	if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_nerf_density_ws: workspace too small")) return -1;
 	hipLaunchKernelGGL((nerf_forward_kernel<1, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out0, 1u, (half_t*)nullptr, planes, n_pad);
 	NGP_LAUNCH_CHECK("nerf_forward_kernel<1, pre>");
@@ -2035,12 +2071,42 @@ static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* 
 	return 0;
 }
 
+// recompute + dgrad + weight gradients of a network variant on the MFMA kernels (one or two launches of nx_backward_kernel), then the hash-grid backward
+static int nx_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
+                       const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput) {
+	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	hipStream_t st = (hipStream_t)stream;
+	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
+	float* partials = (float*)scratch;                                    // [grid][n_mlp] fp32 (<= 256 x 15 360 x 4 B: inside the fused path's 512 x 10 240 x 4 B)
+	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
+	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
+	uint32_t* zero_words = (uint32_t*)((char*)scratch + scratch_off_fx(n));
+	const uint32_t n_quads = n / 128;
+	const uint32_t grid = n_quads < 256u ? n_quads : 256u;                // one workgroup per CU (up to 100 KiB of LDS)
+	NxBwdArgs a{desc_dev, (const half_t*)params, coords, stride, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, partials, zero_words, (uint32_t)(sizeof(GbFxCounters) / 4),
+	            v->extra_dims, v->sample_slot, v->n_extra_dims, v->dL_dextra, dL_dinput};
+	if (nx_bwd_dispatch(v->n_rgb_hidden_layers, v->n_extra_dims != 0, dim3(grid), st, a)) { set_last_error("nx_backward: launch set-up failed", hipErrorInvalidValue); return -1; }
+	NGP_LAUNCH_CHECK("nx_backward_kernel");
+	if (dL_dinput) {
+		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, stride, n, (const h2*)dx_planes, dL_dinput, L.n_mlp);
+		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
+	}
+	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
+	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(L.n_mlp, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, L.n_mlp);
+	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
+	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + L.n_mlp), true)) return -1;
+	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
+	return 0;
+}
+
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant) {
 	if (variant_check(variant, "ngp_hip_nerf_backward: at most 16 extra dims and 3 hidden colour layers")) return -1;
 	if (variant_is_generic(variant)) {
-		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is built for the base network family only", hipErrorNotSupported); return -1; }
+		if (!variant_scalar(variant)) return nx_backward(stream, variant, desc_dev, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
+		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }
 		return gen_backward(stream, variant, desc_dev, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
 	}
 	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
@@ -2092,7 +2158,7 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
 	if (dL_dinput) {
-		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const h2*)dx_planes, dL_dinput);
+		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const h2*)dx_planes, dL_dinput, (uint32_t)GRID_OFF);
 		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
 	}
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
@@ -2136,7 +2202,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 	hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u,
 	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel (input gradient)");
-	hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din);
+	hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din, (uint32_t)GRID_OFF);
 	NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
 	hipLaunchKernelGGL(input_gradient_writeback_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, 1.0f / backprop_scale, (const float*)din, coords_inout, coord_stride_floats);
 	NGP_LAUNCH_CHECK("input_gradient_writeback_kernel");

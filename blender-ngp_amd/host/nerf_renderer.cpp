@@ -177,7 +177,7 @@ void NeuralRadianceField::load_snapshot(void* stream) {
 		if (h < 0 || h > 3 || (h > 0 && config["rgb_network"].value("n_neurons", 64) != 64)) throw std::runtime_error{"snapshot network not supported: rgb_network must be 64 neurons wide with 0..3 hidden layers"};
 		n_rgb_hidden_layers = (uint32_t)h;
 	}
-	NgpNetVariant nv{0u, n_rgb_hidden_layers, nullptr, nullptr, nullptr};
+	NgpNetVariant nv{0u, n_rgb_hidden_layers, nullptr, nullptr, nullptr, 0u};
 	std::vector<uint16_t> p16; std::vector<float> p32;
 	snapshot_read_params(snapshot, p16, p32);
 	const size_t n_params = (size_t)ngp_hip_net_mlp_params_host(&nv) + 2u * (size_t)desc.n_grid_entries;
@@ -354,7 +354,7 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 				const uint32_t* list = m_active_lists.as<uint32_t>() + (size_t)n * stride;
 				const uint32_t n_network_elements = (n_active[n] * n_steps + 127u) / 128u * 128u;
 				check(ngp_hip_multi_generate_next_inputs_list(stream, n_active[n], list, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
-				NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr};
+				NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr, 0u};
 				check(ngp_hip_nerf_inference_ws(stream, f.desc_gpu.as<NgpNetDesc>(), f.params.as<uint16_t>(), m_net_in.as<float>(), 7, n_network_elements, m_net_out.as<uint16_t>(), OUT_STRIDE,
 				                                m_enc_ws.data(), m_enc_ws.bytes(), f.n_rgb_hidden_layers == 2 ? nullptr : &nv), "nerf_inference (multi)");
 				n_samples += n_network_elements;
@@ -399,7 +399,7 @@ uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, vo
 			const uint32_t* list = m_active_lists.as<uint32_t>() + (size_t)n * stride;
 			const uint32_t n_network_elements = (n_active[n] * n_steps + 127u) / 128u * 128u;
 			check(ngp_hip_multi_generate_next_inputs_list(stream, n_active[n], list, g, pn, m_net_in.as<NgpCoord>(), n_steps, props_dev + n), "multi_generate_next_inputs");
-			NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr};
+			NgpNetVariant nv{0u, f.n_rgb_hidden_layers, nullptr, nullptr, nullptr, 0u};
 			check(ngp_hip_nerf_inference_ws(stream, f.desc_gpu.as<NgpNetDesc>(), f.params.as<uint16_t>(), m_net_in.as<float>(), 7, n_network_elements, m_net_out.as<uint16_t>(), OUT_STRIDE,
 			                                m_enc_ws.data(), m_enc_ws.bytes(), f.n_rgb_hidden_layers == 2 ? nullptr : &nv), "nerf_inference (multi)");
 			n_samples += n_network_elements;

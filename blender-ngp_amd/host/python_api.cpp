@@ -496,6 +496,7 @@ PYBIND11_MODULE(pyngp, m) {
 				} catch (...) { t.bl_end_render(); throw; }
 			}, "Requests a nerf render frame.", py::arg("render_request"), py::arg("render_callback"))
 		.def("wait_for_render", [](Testbed& t) { py::gil_scoped_release rel; t.bl_wait_for_renders(); })
+		.def_readwrite("netx_scalar_kernels", &Testbed::m_netx_scalar_kernels, "network variants (extra dims, 0 / 1 / 3 hidden colour layers): True runs the scalar checker kernels (bit-compatible with the oracle's restatement) instead of the MFMA kernels")
 		.def_readonly("bl_render_samples", &Testbed::m_bl_render_samples)
 		.def_readonly("bl_render_passes", &Testbed::m_bl_render_passes)
 		.def_readwrite("bl_fused_passes", &Testbed::m_bl_fused_passes, "Blender renderer pass loop: True (default) = one fused launch (march + cull + compact + per-NeRF lists) and one host-mailbox poll per pass on the stock tracer's sample budget; False = the reference's launch sequence with its two blocking read-backs per pass (same pixels)")

@@ -370,10 +370,12 @@ public:
 	// the network the config + dataset ask for (src/testbed.cu:2337-2363): extra dims behind the direction encoding, hidden layers of the colour network.  The base
 	// family (0, 2) runs the fused kernels; anything else the generic ones (NgpNetVariant, include/ngp_hip.h)
 	uint32_t m_n_extra_dims = 0, m_n_rgb_hidden_layers = 2;
+	bool m_netx_scalar_kernels = false;                // network variants on the scalar checker kernels (NGP_NETX_SCALAR) instead of the MFMA kernels
 	bool net_is_base_family() const { return m_n_extra_dims == 0 && m_n_rgb_hidden_layers == 2; }
 	const NgpNetVariant* net_variant(NgpNetVariant& storage, const float* extra_dims = nullptr, const uint32_t* sample_slot = nullptr, float* dL_dextra = nullptr) const {
 		if (net_is_base_family()) return nullptr;
 		storage.n_extra_dims = m_n_extra_dims; storage.n_rgb_hidden_layers = m_n_rgb_hidden_layers; storage.extra_dims = extra_dims; storage.sample_slot = sample_slot; storage.dL_dextra = dL_dextra;
+		storage.flags = m_netx_scalar_kernels ? (uint32_t)NGP_NETX_SCALAR : 0u;
 		return &storage;
 	}
 	const float* get_inference_extra_dims();           // testbed_nerf.cu:2320-2337

@@ -94,8 +94,10 @@ int ngp_hip_net_make_desc_host(uint32_t n_levels, uint32_t log2_hashmap_size, ui
 uint32_t ngp_hip_net_n_params_host(const NgpNetDesc* desc_host);
 
 /* NerfNetwork as the reference BUILDS it from other configs (src/testbed.cu:2337-2363; nerf_network.h:76-101).  Every network entry point below takes an optional
- * trailing `const NgpNetVariant*`; NULL (or {0 extra dims, 2 hidden colour layers}) is configs/nerf/base.json — the fused MFMA kernels.  Anything else runs the
- * generic kernels of csrc/network_generic.cuh (bit-compatible with oracle/orc_netx.c; functional, not tuned):
+ * trailing `const NgpNetVariant*`; NULL (or {0 extra dims, 2 hidden colour layers}) is configs/nerf/base.json — the fused MFMA kernels of csrc/network.hip.  Anything else
+ * runs the same scheme with the layer list as a template parameter (csrc/network_netx_mfma.cuh: one more K-block for the extra dims, 0 / 1 / 3 hidden colour layers; MFMA
+ * forward, fused dgrad + wgrad backward, dL_dinput for the camera-side trainables), or — flags & NGP_NETX_SCALAR — the scalar kernels of csrc/network_generic.cuh, which
+ * are bit-compatible with oracle/orc_netx.c and serve as the checker:
  *   n_extra_dims 1..16     per-image latent codes (`n_extra_learnable_dims`) or light directions (`driver_parameters`): an Identity-encoded block behind the SH
  *                          block of the direction encoding (configs/nerf/base.json:37-51) — the colour network's input grows from 32 to 48;
  *   n_rgb_hidden_layers    0..3: configs/nerf/base_{0,1,2,3}layer.json (0 = one [16][in] matrix, no activation; h >= 1: [64][in], (h - 1) x [64][64], [16][64]).
@@ -105,7 +107,9 @@ typedef struct {
 	const float* extra_dims;       /* [rows][n_extra_dims] fp32 (Testbed::Nerf::Training::extra_dims_gpu, src/testbed_nerf.cu:2297-2318) or NULL */
 	const uint32_t* sample_slot;   /* [n]: the row of extra_dims each sample uses (its ray's image, :1136); NULL: row 0 for all (rendering: get_inference_extra_dims, :2320-2337) */
 	float* dL_dextra;              /* backward only, or NULL: [n][n_extra_dims] fp32 = the extra-dim rows of the network's dL_dinput (coords_gradient(j)->get_extra_dims(), :1741) */
+	uint32_t flags;                /* NGP_NETX_SCALAR: run the scalar checker kernels (csrc/network_generic.cuh) instead of the MFMA kernels (csrc/network_netx_mfma.cuh) */
 } NgpNetVariant;
+enum { NGP_NETX_SCALAR = 1 };
 uint32_t ngp_hip_net_mlp_params_host(const NgpNetVariant* variant);   /* 10240 for NULL / the base family; the grid follows behind */
 
 /* NerfNetwork::initialize_params (nerf_network.h:396-441) driven by Trainer(seed) (src/testbed.cu:2445): fills the fp32 master
