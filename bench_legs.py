@@ -219,6 +219,57 @@ def plumbing_leg(steps=200, warmup=100):
     return out
 
 
+def variants_leg(ds, steps=120, warmup=300):
+    """network variants on the headline scene at B = 2^18: configs/nerf/base_3layer.json and 4 per-image latent dims (`n_extra_learnable_dims`,
+    optimize_extra_dims), each on the MFMA kernels (csrc/network_netx_mfma.cuh) and — 10 steps — on the scalar checker kernels they replaced"""
+    import pyngp
+    out = {}
+    for name, cfg, n_extra in (("base_3layer", "base_3layer.json", 0), ("latent4", "base.json", 4), ("base_0layer", "base_0layer.json", 0)):
+        row = {}
+        for scalar in (False, True):
+            t = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+            n = len(ds["train_images"])
+            t.create_empty_nerf_dataset(n, ds["aabb_scale"], False)
+            t.nerf.training.set_dataset_transform(ds["scale"], ds["offset"])
+            w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
+            for i in range(n):
+                t.nerf.training.set_image_rgba8(i, ds["train_images"][i])
+                t.nerf.training.set_camera_intrinsics(i, ds["focal"], ds["focal"], 0.5 * w, 0.5 * h)
+                t.nerf.training.set_camera_extrinsics(i, ds["train_poses"][i][:3, :], True)
+            t.nerf.training.n_images_for_training = n
+            if n_extra:
+                t.nerf.training.dataset.n_extra_learnable_dims = n_extra
+            t.reload_network_from_file(os.path.join(CFG, "nerf", cfg))
+            if n_extra:
+                t.nerf.training.optimize_extra_dims = True
+            t.netx_scalar_kernels = scalar
+            t.async_training_steps = True
+            t.shall_train = True
+            k_warm, k_steps = (warmup, steps) if not scalar else (20, 10)
+            for _ in range(k_warm):
+                t.frame()
+            t.set_profiling(True)
+            t.reset_profile()
+            for _ in range(8):
+                t.frame()
+            prof = t.profile()
+            t.set_profiling(False)
+            t.sync()
+            t0 = time.perf_counter()
+            samples = 0
+            for _ in range(k_steps):
+                t.frame()
+                samples += min(t.nerf.training.measured_batch_size, 1 << 18)
+            t.sync()
+            dt = time.perf_counter() - t0
+            row["scalar_checker" if scalar else "mfma"] = {"ms_per_step": round(1000.0 * dt / k_steps, 4), "samples_per_s": round(samples / dt, 1), "steps": k_steps, "loss": round(float(t.loss), 5),
+                                                             "groups_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in prof.items() if v["launches"]}}
+            row["n_mlp_params"] = int(t.n_mlp_params)
+            del t
+        out[name] = row
+    return out
+
+
 if __name__ == "__main__":   # dev: one leg on its own, e.g. under rocprofv3:  python bench_legs.py fox 200
     for p in (PKG, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -231,6 +282,10 @@ if __name__ == "__main__":   # dev: one leg on its own, e.g. under rocprofv3:  p
         print(json.dumps(fox_leg(int(sys.argv[2]) if len(sys.argv) > 2 else 200, bench.BYTES_PER_UNIT)))
     elif which == "plumbing":
         print(json.dumps(plumbing_leg()))
+    elif which == "variants":
+        import scene
+        ds = scene.make_dataset(100, 1, 800, torch.device("cuda", 0))
+        print(json.dumps(variants_leg(ds)))
     elif which == "bl_render":
         import scene
         dev = torch.device("cuda", 0)

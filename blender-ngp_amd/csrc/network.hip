@@ -2178,7 +2178,9 @@ static uint64_t ig_off_din(uint32_t n) { return ig_off_out(n) + (uint64_t)n * 4 
 uint64_t ngp_hip_nerf_input_gradient_scratch_bytes(uint32_t n) { return ig_off_din(n) + (uint64_t)n * 6 * 4; }
 
 int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, uint32_t dim, float* coords_inout,
-                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes) {
+                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes, const NgpNetVariant* variant) {
+	if (variant_check(variant, "ngp_hip_nerf_input_gradient: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_scalar(variant)) { set_last_error("ngp_hip_nerf_input_gradient: not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_input_gradient: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
 	if (dim >= 4) { set_last_error("ngp_hip_nerf_input_gradient: dim must be 0..3 (the padded outputs 4..15 carry nothing)", hipErrorInvalidValue); return -1; }
 	if (coord_stride_floats < 7) { set_last_error("ngp_hip_nerf_input_gradient: coords are NgpCoord records (>= 7 floats)", hipErrorInvalidValue); return -1; }
@@ -2191,7 +2193,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 	float* din = (float*)((char*)scratch + ig_off_din(n));
 	hipLaunchKernelGGL(one_hot_dl_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, dim, backprop_scale, dl);
 	NGP_LAUNCH_CHECK("one_hot_dl_kernel");
-	if (ngp_hip_nerf_forward(stream, desc_dev, params, coords_inout, coord_stride_floats, n, out, 4, x_saved, nullptr)) return -1;
+	if (ngp_hip_nerf_forward(stream, desc_dev, params, coords_inout, coord_stride_floats, n, out, 4, x_saved, variant)) return -1;
 	// the fused backward kernel with the direction gradient, then dL/dpos through the hash encoding; no parameter gradients (EGradientMode::Ignore):
 	// the per-workgroup weight-gradient partials land in scratch and are dropped, the hash-grid backward does not run
 	float* partials = (float*)scratch;
@@ -2199,6 +2201,17 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
 	(void)desc_host;
+	if (variant_is_generic(variant)) {   // the same three steps on the variant's kernels: first launch only (the second one of a deep network only adds weight-gradient tiles)
+		NxBwdArgs a{desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u, dx_planes, partials,
+		            (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), variant->extra_dims, variant->sample_slot, variant->n_extra_dims, nullptr, din};
+		if (nx_bwd_dispatch(variant->n_rgb_hidden_layers, variant->n_extra_dims != 0, dim3(n_quads < 256u ? n_quads : 256u), st, a, true)) { set_last_error("ngp_hip_nerf_input_gradient: launch set-up failed", hipErrorInvalidValue); return -1; }
+		NGP_LAUNCH_CHECK("nx_backward_kernel (input gradient)");
+		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din, ngp_hip_net_mlp_params_host(variant));
+		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
+		hipLaunchKernelGGL(input_gradient_writeback_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, n, 1.0f / backprop_scale, (const float*)din, coords_inout, coord_stride_floats);
+		NGP_LAUNCH_CHECK("input_gradient_writeback_kernel");
+		return 0;
+	}
 	hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u,
 	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel (input gradient)");

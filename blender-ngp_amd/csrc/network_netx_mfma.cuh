@@ -436,21 +436,21 @@ static int nx_bwd_launch(dim3 grid, hipStream_t st, const NxBwdArgs& a) {
 	return 0;
 }
 template <int NH, int XK>
-static int nx_bwd_passes(dim3 grid, hipStream_t st, const NxBwdArgs& a) {
+static int nx_bwd_passes(dim3 grid, hipStream_t st, const NxBwdArgs& a, bool first_only) {
 	if (nx_bwd_launch<NH, XK, 0>(grid, st, a)) return -1;
-	if constexpr (NxL<NH, XK>::N_PASS > 1) { if (nx_bwd_launch<NH, XK, 1>(grid, st, a)) return -1; }
+	if constexpr (NxL<NH, XK>::N_PASS > 1) { if (!first_only && nx_bwd_launch<NH, XK, 1>(grid, st, a)) return -1; }
 	static_assert(NxL<NH, XK>::N_PASS <= 2, "two launches cover 24 weight-gradient tiles");
 	return 0;
 }
-static int nx_bwd_dispatch(uint32_t n_hidden, bool extra, dim3 grid, hipStream_t st, const NxBwdArgs& a) {
+static int nx_bwd_dispatch(uint32_t n_hidden, bool extra, dim3 grid, hipStream_t st, const NxBwdArgs& a, bool first_only = false) {
 	switch (n_hidden * 2u + (extra ? 1u : 0u)) {
-		case 0: return nx_bwd_passes<0, 0>(grid, st, a);
-		case 1: return nx_bwd_passes<0, 1>(grid, st, a);
-		case 2: return nx_bwd_passes<1, 0>(grid, st, a);
-		case 3: return nx_bwd_passes<1, 1>(grid, st, a);
-		case 5: return nx_bwd_passes<2, 1>(grid, st, a);
-		case 6: return nx_bwd_passes<3, 0>(grid, st, a);
-		case 7: return nx_bwd_passes<3, 1>(grid, st, a);
+		case 0: return nx_bwd_passes<0, 0>(grid, st, a, first_only);
+		case 1: return nx_bwd_passes<0, 1>(grid, st, a, first_only);
+		case 2: return nx_bwd_passes<1, 0>(grid, st, a, first_only);
+		case 3: return nx_bwd_passes<1, 1>(grid, st, a, first_only);
+		case 5: return nx_bwd_passes<2, 1>(grid, st, a, first_only);
+		case 6: return nx_bwd_passes<3, 0>(grid, st, a, first_only);
+		case 7: return nx_bwd_passes<3, 1>(grid, st, a, first_only);
 		default: return -1;
 	}
 }

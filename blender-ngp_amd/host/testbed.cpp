@@ -959,8 +959,8 @@ void Testbed::shutdown_data_parallel() {
 void Testbed::train_nerf(uint32_t target_batch_size, bool get_loss_scalar) {  // testbed_nerf.cu:2896-3023
 	if (m_nerf.training.n_images_for_training == 0) return;
 	// refuse before anything is queued (the check used to sit behind the step's forward and loss launches)
-	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && !net_is_base_family())
-		throw std::runtime_error{"optimize_extrinsics / optimize_distortion need the network's input gradient, which is built for the base network family (no extra dims, two hidden colour layers)"};
+	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && !net_is_base_family() && m_netx_scalar_kernels)
+		throw std::runtime_error{"optimize_extrinsics / optimize_distortion need the network's input gradient, which the scalar checker kernels (netx_scalar_kernels) do not have"};
 	if (m_dp_comm) {
 		// the data-parallel step: every rank marches its slice of the step's rays; {samples, compacted samples, loss} are summed over
 		// the ranks right behind the loss kernel (hosts, shared memory), the gradient vector between backward and optimizer (RCCL, stream order);
@@ -1289,9 +1289,12 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		// prepare_input_gradients (3327-3330): the backward pass also writes dL/d(pos, dir) of every compacted sample; compute_cam_gradient_train_nerf (3350-3378)
 		// folds them into per-image position / rotation gradients.  The ray counter of this step's slot is stable until the step after next.
 		m_coords_gradient.enlarge((size_t)target_batch_size * 6 * sizeof(float));
-		if (!net_is_base_family()) throw std::runtime_error{"optimize_extrinsics / optimize_distortion need the network's input gradient, which is built for the base network family (no extra dims, two hidden colour layers)"};
+		NgpNetVariant nvc;
+		const bool train_extra_dims_c = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;
+		if (train_extra_dims_c) m_dl_dextra.enlarge((size_t)target_batch_size * m_n_extra_dims * 4);
+		const NgpNetVariant* variant_c = net_variant(nvc, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims_c ? m_dl_dextra.as<float>() : nullptr);
 		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), nullptr), "nerf_backward (with input gradient)");
+		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), variant_c), "nerf_backward (with input gradient)");
 		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
 		profile_end(PK_BACKWARD, target_batch_size);
 		check(ngp_hip_compute_cam_gradient(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
@@ -1301,6 +1304,13 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		                                      m_coords_gradient.as<float>(), tr.error_map_cdf(cdf_storage), tr.transforms_gpu.as<NgpXForm>(),
 		                                      tr.optimize_distortion ? m_distortion.gradients.as<float>() : nullptr, tr.optimize_distortion ? m_distortion.gradient_weights.as<float>() : nullptr,
 		                                      m_distortion.resolution), "compute_cam_gradient");
+		if (train_extra_dims_c) {   // as below: compute_extra_dims_gradient_train_nerf
+			const size_t n = (size_t)m_n_extra_dims * (size_t)tr.n_images_for_training;
+			tr.extra_dims_gradient_gpu.enlarge(n * 4);
+			HIP_CHECK_THROW(hipMemsetAsync(tr.extra_dims_gradient_gpu.data(), 0, n * 4, (hipStream_t)m_stream));
+			check(ngp_hip_extra_dims_gradient(m_stream, R, gen_counters + 0, m_ray_image.as<uint32_t>(), m_extra_numsteps.as<uint32_t>(), m_dl_dextra.as<float>(), m_n_extra_dims,
+			                                  tr.extra_dims_gradient_gpu.as<float>()), "extra_dims_gradient");
+		}
 	} else {
 		NgpNetVariant nv;
 		const bool train_extra_dims = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;   // testbed_nerf.cu:2925
@@ -1753,8 +1763,10 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	NgpNetVariant render_variant_storage;
 	const NgpNetVariant* render_variant = net_variant(render_variant_storage, get_inference_extra_dims(), nullptr);
 	// (render_mode 8 = m_visualized_dimension > -1, whatever m_render_mode says: that covers the Slice mode's activation read-out below as well)
-	if (render_variant && (render_mode == (int)ERenderMode::Normals || render_mode == 8 || m_visualized_dimension > -1))
-		throw std::runtime_error{"the Normals / EncodingVis render modes (and Slice with visualized_dimension set) run the network's input gradient / activation read-out, which are built for the base network family only"};
+	if (render_variant && (render_mode == 8 || m_visualized_dimension > -1))
+		throw std::runtime_error{"the EncodingVis render mode (and Slice with visualized_dimension set) runs the network's activation read-out, which is built for the base network family only"};
+	if (render_variant && m_netx_scalar_kernels && render_mode == (int)ERenderMode::Normals)
+		throw std::runtime_error{"the Normals render mode needs the network's input gradient, which the scalar checker kernels (netx_scalar_kernels) do not have"};
 	if (m_render_mode == ERenderMode::Slice) {   // 2445-2476: the network where every ray meets the slice plane; all rays of the frame are shaded
 		const uint32_t n_hit = n_pixels, n_elements = (uint32_t)next_multiple(n_hit, BATCH_SIZE_GRANULARITY);
 		m_tr_vis_rgba.enlarge((size_t)n_elements * 16);
@@ -1847,7 +1859,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			if (render_mode == (int)ERenderMode::Normals) {
 				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);
 				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
-				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes()), "nerf_input_gradient (normals)");
+				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes(), render_variant), "nerf_input_gradient (normals)");
 			} else if (render_mode == 8) {
 				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
 			}
@@ -1940,7 +1952,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			if (render_mode == (int)ERenderMode::Normals) {   // 2225-2226: network.input_gradient(stream, 3, positions, positions) — on the inference weights like the pass above
 				const uint32_t n_grad = (uint32_t)next_multiple(n_elements, 256u);
 				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
-				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes()), "nerf_input_gradient (normals)");
+				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes(), render_variant), "nerf_input_gradient (normals)");
 			} else if (render_mode == 8) {                    // 2227-2228: network.visualize_activation(stream, layer, dim, positions, positions)
 				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
 			}

@@ -522,7 +522,7 @@ int ngp_hip_multi_shade(void* stream, uint32_t n_rays, const NgpGlobalRay* rays,
  * to it).  coords: [n] NgpCoord, overwritten in place.  n must be a multiple of 256.  scratch: ngp_hip_nerf_input_gradient_scratch_bytes(n). */
 uint64_t ngp_hip_nerf_input_gradient_scratch_bytes(uint32_t n);
 int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, uint32_t dim, float* coords_inout,
-                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes);
+                                uint32_t coord_stride_floats, uint32_t n, void* scratch, uint64_t scratch_bytes, const NgpNetVariant* variant /* NULL: base family */);
 /* [tcnn] Network::visualize_activation(stream, layer, dimension, input, output): forward pass, then extract_dimension_pos_neg_kernel on
  * forward_activations(layer) — NerfNetwork's layer map (nerf_network.h:474-501): 0 = hash encoding (32), 1 = density hidden layer (64),
  * 2 = colour network input [density output 16 | SH 16], 3.. = colour hidden layers (64).  Output row 0 = max(-v, 0), row 1 = max(v, 0),

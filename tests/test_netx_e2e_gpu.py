@@ -138,6 +138,57 @@ def test_rgb_network_depths_train_render_and_round_trip_a_snapshot(cuda, tmp_pat
     assert img.shape == (64, 64, 4)
 
 
+@pytest.mark.parametrize("h,n_extra", [(1, 0), (3, 4)])
+def test_variants_render_normals_and_register_cameras(cuda, h, n_extra):
+    """Round 4: the variants run on MFMA kernels that also hand out the network's input gradient, so the Normals render mode ([tcnn] input_gradient) and the camera-side
+    trainables (optimize_extrinsics) work for them like for the base family (rounds 2-3 refused both)."""
+    import pyngp
+    import scene
+    from scipy.spatial.transform import Rotation
+    n = 18
+    ds = scene.make_dataset(n_train=n, n_test=1, res=64, device=cuda)
+    t = _build(ds, n_extra=n_extra, cfg="base_%dlayer.json" % h)
+    tr = t.nerf.training
+    scene.train(t, 900)
+    t.sync()
+    # ---- Normals
+    t.shall_train = False
+    t.background_color = [0.0, 0.0, 0.0, 0.0]                                                # (alpha = accumulated opacity)
+    t.snap_to_pixel_centers = True
+    t.fov_axis = 0
+    t.fov = ds["camera_angle_x"] * 180 / np.pi
+    t.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    t.render_mode = pyngp.RenderMode.Normals
+    nrm = t.render(48, 48, 1, True)
+    t.render_mode = pyngp.RenderMode.Shade
+    assert np.isfinite(nrm).all()
+    hit = nrm[..., 3] > 0.97
+    assert hit.sum() > 60
+    nv = nrm[hit][:, :3] / nrm[hit][:, 3:4] * 2.0 - 1.0
+    ln = np.linalg.norm(nv, axis=1)
+    assert abs(np.median(ln) - 1.0) < 3e-2 and (np.abs(ln - 1.0) < 8e-2).mean() > 0.85
+    assert (nv @ np.asarray(t.camera_matrix)[:, 2] < 0.25).mean() > 0.8                        # visible surfaces face the camera
+    # ---- registration: a third of the cameras displaced, only the extrinsics train
+    true_pos = np.array([np.asarray(a)[:, 3] for a, _ in tr.transforms])
+    rs = np.random.RandomState(4)
+    moved = np.arange(0, n, 3)
+    for i in moved:
+        m = np.array(ds["train_poses"][i], np.float64)
+        m[:3, 3] += rs.randn(3) / np.sqrt(3) * 0.06
+        m[:3, :3] = Rotation.from_rotvec(rs.randn(3) / np.sqrt(3) * np.deg2rad(1.0)).as_matrix() @ m[:3, :3]
+        tr.set_camera_extrinsics(int(i), m[:3, :].astype(np.float32), True)
+    err = lambda: np.linalg.norm(np.array([np.asarray(a)[:, 3] for a, _ in tr.transforms]) - true_pos, axis=1)
+    e0 = err()
+    t.shall_train = True
+    t.shall_train_network = False
+    t.shall_train_encoding = False
+    tr.optimize_extrinsics = True
+    scene.train(t, 1700)
+    e1 = err()
+    print("variant h=%d extra=%d: displaced cameras %.4f -> %.4f, others drift %.4f" % (h, n_extra, e0[moved].mean(), e1[moved].mean(), np.delete(e1, moved).max()))
+    assert e1[moved].mean() < 0.85 * e0[moved].mean() and np.delete(e1, moved).max() < 0.5 * e0[moved].mean()
+
+
 def test_include_sharpness_in_error_end_to_end(cuda):
     """nerf.training.include_sharpness_in_error through pyngp: the loader-side sharpness map (128 x 72 tiles per image) exists, blurred images score lower than sharp
     ones, training runs with the switch on and the error map keeps filling"""

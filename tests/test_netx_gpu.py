@@ -142,6 +142,47 @@ def test_backward_against_the_oracle(ngp, oracle, cuda, n_extra, n_hidden, kerne
         np.testing.assert_allclose(ge, dext, rtol=2e-2, atol=2e-3 * np.abs(dext).max())
 
 
+@pytest.mark.parametrize("n_extra,n_hidden", [(0, 1), (6, 3), (4, 0)])
+def test_input_gradient_of_a_variant(ngp, oracle, cuda, n_extra, n_hidden):
+    """ngp_hip_nerf_input_gradient on the variants' kernels ([tcnn] input_gradient: the Normals render mode; the same backward path feeds the camera-side trainables).
+    The density network and the grid are the base family's, so d(sigma)/d(position) of a variant must be the base family's for the same W1, W2 and grid — checked
+    against the oracle's orc_nerf_input_gradient on a base-family parameter vector that shares them; d(red)/d(direction) must be non-zero and finite."""
+    n = 1024
+    desc = H.make_desc(ngp, log2_hashmap_size=12)
+    coords = H.random_coords(n, seed=21)
+    rs = np.random.RandomState(3)
+    table = (rs.rand(4, max(n_extra, 1)) * 2 - 1).astype(np.float32)
+    slot = rs.randint(0, 4, n).astype(np.uint32)
+    x = netx(n_extra, n_hidden, table if n_extra else None, slot if n_extra else None)
+    params, npar, n_mlp = _params(oracle, desc, x, 17)
+    base = H.random_params(desc, seed=2)                                     # base family: [W1 | W2 | W3 W4 W5 | grid]
+    base = base.view(np.uint16).copy()
+    base[:3072] = params[:3072]                                              # the density network ...
+    base[10240:] = params[n_mlp:]                                            # ... and the grid
+    flat = coords.view(np.float32).reshape(n, 7).copy()
+    dl = np.zeros((n, 4), np.float16); dl[:, 3] = 128.0
+    din = np.zeros((n, 6), np.float32)
+    oracle.orc_nerf_input_gradient(desc.ctypes.data, base.ctypes.data, flat.ctypes.data, 7, n, dl.ctypes.data, din.ctypes.data)
+    ref = din[:, 0:3] / 128.0
+    d_desc, d_P, d_c = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(flat, cuda)
+    d_tab, d_slot = H.to_dev(table, cuda), H.to_dev(slot, cuda)
+    v = _variant(n_extra, n_hidden, d_tab if n_extra else None, d_slot if n_extra else None)
+    sb = ngp.ngp_hip_nerf_input_gradient_scratch_bytes(n)
+    d_s = H.dev_zeros(sb, cuda)
+    check(ngp.ngp_hip_nerf_input_gradient(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), 3, d_c.data_ptr(), 7, n, d_s.data_ptr(), sb, v.ctypes.data))
+    got = H.to_host(d_c, np.float32).reshape(n, 7)
+    scale = np.abs(ref).max()
+    assert scale > 1e-3
+    assert np.linalg.norm(got[:, 0:3] - ref) < 1e-2 * np.linalg.norm(ref) and np.abs(got[:, 0:3] - ref).max() < 3e-2 * scale
+    assert np.abs(got[:, 4:7]).max() == 0.0                                  # sigma does not depend on the direction
+    d_c2 = H.to_dev(flat, cuda)
+    check(ngp.ngp_hip_nerf_input_gradient(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), 0, d_c2.data_ptr(), 7, n, d_s.data_ptr(), sb, v.ctypes.data))
+    got0 = H.to_host(d_c2, np.float32).reshape(n, 7)
+    assert np.isfinite(got0).all() and np.abs(got0[:, 4:7]).max() > 0        # red does
+    vs = _variant(n_extra, n_hidden, d_tab if n_extra else None, d_slot if n_extra else None, kernels="scalar")
+    assert ngp.ngp_hip_nerf_input_gradient(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), 3, d_c.data_ptr(), 7, n, d_s.data_ptr(), sb, vs.ctypes.data) != 0   # the checker kernels have none
+
+
 def test_slot_expansion_rollover_and_latent_code_gradient(ngp, oracle, cuda):
     """ngp_hip_ray_images / _expand_ray_slots / _rollover_slots / _extra_dims_gradient against their definitions"""
     import torch
