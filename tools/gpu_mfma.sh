@@ -4,7 +4,7 @@ tag=${1:-r02_mfma}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 mkdir -p $out
-small="python bench.py --steps 40 --warmup 280 --no_cpu_baseline --no_render"
+small="python bench.py --steps 40 --warmup 280 --no_cpu_baseline --no_render --legs none"
 i=0; dirs=""
 while read -r group; do
   [ -z "$group" ] && continue
