@@ -412,11 +412,15 @@ int ngp_hip_tonemap(void* stream, const int32_t* res_host, float exposure, const
 /* [tcnn] GridEncodingTemplated::backward_impl -> kernel_grid_backward (tiny-cuda-nn encodings/grid.h; the reference reaches it through
  * m_network->backward, src/testbed_nerf.cu:3331): grid_grad[entry][f] = sum over samples and corners of half(w * dL/dx[level][f]),
  * EGradientMode::Overwrite.  dL_dx_planes: fp16 [16 levels][n] x 2 features (level-major planes, the layout ngp_hip_nerf_backward produces
- * internally); grid_grad: fp16 [n_grid_entries][2], every entry written.  Levels that are dense or hashed with a power-of-two table and a
- * resolution below 4096 are summed EXACTLY (64-bit fixed point, one rounding to fp16, independent of the order of the adds); tcnn rounds
+ * internally); grid_grad: fp16 [n_grid_entries][2], every entry written.  Levels that are dense or hashed with a power-of-two table of at most 2^20 entries
+ * are summed EXACTLY (64-bit fixed point, one rounding to fp16, independent of the order of the adds); tcnn rounds
  * after every atomicAdd(half2), so results agree to fp16 accumulation noise, not bit for bit.  n must be a multiple of 256. */
 uint64_t ngp_hip_grid_backward_scratch_bytes(uint32_t n);
 int ngp_hip_grid_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                          const uint16_t* dL_dx_planes, uint16_t* grid_grad, void* scratch, uint64_t scratch_bytes);
+/* the same sums for a batch that is NOT in ray order (image fitting, SDF: stratified / random positions): dense levels are binned as pair records like hashed ones instead of by the
+ * run-merging walk, which finds nothing to merge there (what ngp_hip_gridmlp_backward runs).  Bit-identical results: the sums are exact either way. */
+int ngp_hip_grid_backward_unordered(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const float* pos, uint32_t pos_stride_floats, uint32_t n,
                           const uint16_t* dL_dx_planes, uint16_t* grid_grad, void* scratch, uint64_t scratch_bytes);
 
 /* ============================ plumbing configs P1 (2-D image) / P2 (SDF): grid encoding -> one FullyFusedMLP ============================

@@ -31,14 +31,15 @@ def _ray_positions(n, n_dims, rs, run=40):
     return np.clip(pos, 0.0, 1.0).astype(np.float32)
 
 
-def _run(ngp, cuda, n_dims, desc, pos, planes):
+def _run(ngp, cuda, n_dims, desc, pos, planes, unordered=False):
     n = pos.shape[0]
     d_desc, d_pos, d_pl = H.to_dev(desc, cuda), H.to_dev(pos, cuda), H.to_dev(planes, cuda)
     n_entries = int(desc["n_grid_entries"][0])
     sb = ngp.ngp_hip_grid_backward_scratch_bytes(n)
     scratch, grad = H.dev_zeros(sb, cuda), H.dev_zeros(n_entries * 4, cuda)
     grad[:] = 0x3c                                      # poison: Overwrite mode must write every entry
-    check(ngp.ngp_hip_grid_backward(None, n_dims, d_desc.data_ptr(), d_pos.data_ptr(), pos.shape[1], n, d_pl.data_ptr(), grad.data_ptr(), scratch.data_ptr(), sb))
+    fn = ngp.ngp_hip_grid_backward_unordered if unordered else ngp.ngp_hip_grid_backward   # unordered: dense levels binned as pair records (batches without ray order: image, SDF)
+    check(fn(None, n_dims, d_desc.data_ptr(), d_pos.data_ptr(), pos.shape[1], n, d_pl.data_ptr(), grad.data_ptr(), scratch.data_ptr(), sb))
     return H.to_host(grad, np.uint16)
 
 
@@ -58,13 +59,14 @@ CASES = [("nerf", 3, 19, 2048.0), ("image", 2, 24, 512.0), ("sdf", 3, 19, 2048.0
 
 @pytest.mark.parametrize("name,n_dims,log2,desired", CASES)
 @pytest.mark.parametrize("coherent", [True, False])
-def test_grid_backward_is_the_exact_sum(ngp, oracle, cuda, name, n_dims, log2, desired, coherent):
+@pytest.mark.parametrize("unordered", [False, True])
+def test_grid_backward_is_the_exact_sum(ngp, oracle, cuda, name, n_dims, log2, desired, coherent, unordered):
     n = 8192
     desc = H.make_desc(ngp, log2) if name == "nerf" else _gm_desc(ngp, n_dims, log2, desired)
     rs = np.random.RandomState(n_dims * 100 + log2 + coherent)
     pos = _ray_positions(n, n_dims, rs) if coherent else rs.rand(n, n_dims).astype(np.float32)
     pl = _planes(n, rs)
-    got = _run(ngp, cuda, n_dims, desc, pos, pl.view(np.uint16))
+    got = _run(ngp, cuda, n_dims, desc, pos, pl.view(np.uint16), unordered)
     ref = np.zeros(got.size, np.uint16)
     oracle.orc_grid_backward_exact(n_dims, desc.ctypes.data, pos.ctypes.data, n_dims, n, pl.view(np.uint16).ctypes.data, ref.ctypes.data)
     assert (ref != 0).sum() > 1000
