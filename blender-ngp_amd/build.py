@@ -43,7 +43,7 @@ def _run(cmd):
 def build_kernels(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "ngp_device.cuh"), os.path.join(CSRC, "ngp_masks.cuh"), os.path.join(ROOT, "include", "ngp_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".cuh")] + [os.path.join(ROOT, "include", "ngp_hip.h")]   # (network_generic.cuh / network_netx_mfma.cuh are included by network.hip)
     objs, jobs = [], []
     for s in KERNEL_SOURCES:
         src = os.path.join(CSRC, s)
