@@ -1941,6 +1941,51 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 #include "network_generic.cuh"
 #include "network_netx_mfma.cuh"
 
+// the same read-out for a network variant (layer map of NerfNetwork::width, nerf_network.h:474-484: 0 encoding, 1 density hidden layer, 2 colour-network input
+// [density out | SH | extra dims], 3 .. 2 + n_hidden the colour network's hidden layers); layout from gen_layout.  One thread per sample, activations rounded to fp16 between layers.
+__global__ void __launch_bounds__(256) netx_visualize_activation_kernel(GenLayout L, const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, uint32_t layer, uint32_t dim,
+                                                                        const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, float* __restrict__ out, uint32_t out_stride,
+                                                                        const float* __restrict__ extra_dims, const uint32_t* __restrict__ sample_slot) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const float* c = coords + (size_t)s * coord_stride;
+	const f3_t pv = load_pos3(c);
+	const h2* __restrict__ grid = (const h2*)(params + L.n_mlp);
+	half_t x[32];
+	for (int l = 0; l < 16; ++l) encode_level<false>(desc->levels[l], grid, pv.x, pv.y, pv.z, x[2 * l], x[2 * l + 1]);
+	float v = 0.0f;
+	if (layer == 0) v = (float)x[dim & 31];
+	else {
+		half_t cur[64], nxt[64];
+		for (int o = 0; o < 64; ++o) nxt[o] = (half_t)fmaxf(vis_dot(params + L.off[0] + o * 32, x, 32), 0.0f);
+		if (layer == 1) v = (float)nxt[dim & 63];
+		else {
+			for (int o = 0; o < 16; ++o) cur[o] = (half_t)vis_dot(params + L.off[1] + o * 64, nxt, 64);
+			const h8 a = sh4_half(0, c[4], c[5], c[6]), b = sh4_half(1, c[4], c[5], c[6]);
+			for (int o = 0; o < 8; ++o) { cur[16 + o] = a[o]; cur[24 + o] = b[o]; }
+			for (uint32_t o = 32; o < 64; ++o) cur[o] = (half_t)0.0f;
+			if (L.n_extra && extra_dims) {
+				const float* row = extra_dims + (size_t)(sample_slot ? sample_slot[s] : 0u) * L.n_extra;
+				for (uint32_t o = 0; o < L.n_extra; ++o) cur[32 + o] = (half_t)row[o];
+			}
+			if (layer == 2) v = (float)cur[dim < L.rgb_in ? dim : 0];
+			else {
+				uint32_t width = L.rgb_in;
+				for (uint32_t m = 2; m + 1 < L.n_mats; ++m) {   // the colour network's hidden matrices (the last matrix is the output layer)
+					for (int o = 0; o < 64; ++o) nxt[o] = (half_t)fmaxf(vis_dot(params + L.off[m] + o * width, cur, (int)width), 0.0f);
+					if (layer == m + 1) { v = (float)nxt[dim & 63]; break; }
+					for (int o = 0; o < 64; ++o) cur[o] = nxt[o];
+					width = 64;
+				}
+			}
+		}
+	}
+	float* o = out + (size_t)s * out_stride;
+	if (out_stride == 1) { o[0] = v; return; }
+	for (uint32_t k = 0; k < out_stride; ++k) o[k] = k == 0 ? fmaxf(-v, 0.0f) : k == 1 ? fmaxf(v, 0.0f) : k == 2 ? 0.0f : 1.0f;
+}
+
+
 // NgpNetVariant -> what the generic kernels take; returns false for the base family (which stays on the fused kernels)
 static bool variant_is_generic(const NgpNetVariant* v) { return v && (v->n_extra_dims != 0 || v->n_rgb_hidden_layers != 2); }
 static int variant_check(const NgpNetVariant* v, const char* who) {
@@ -2352,7 +2397,19 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 }
 
 int ngp_hip_nerf_visualize_activation(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords,
-                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats) {
+                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats, const NgpNetVariant* variant) {
+	if (variant_check(variant, "ngp_hip_nerf_visualize_activation: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (variant_is_generic(variant)) {
+		const GenLayout L = gen_layout(variant->n_extra_dims, variant->n_rgb_hidden_layers);
+		const uint32_t n_layers = 3u + variant->n_rgb_hidden_layers;   // encoding, density hidden, colour input, colour hidden layers
+		const uint32_t width = layer == 0 ? 32u : layer == 1 ? 64u : layer == 2 ? L.rgb_in : 64u;
+		if (layer >= n_layers || dimension >= width) { set_last_error("ngp_hip_nerf_visualize_activation: layer / dimension outside the variant's activations (32, 64, colour input width, 64 per hidden colour layer)", hipErrorInvalidValue); return -1; }
+		if (!n) return 0;
+		hipLaunchKernelGGL(netx_visualize_activation_kernel, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, L, desc_dev, (const half_t*)params, layer, dimension, coords, coord_stride_floats, n, out, out_stride_floats,
+		                   variant->extra_dims, variant->sample_slot);
+		NGP_LAUNCH_CHECK("netx_visualize_activation_kernel");
+		return 0;
+	}
 	static const uint32_t widths[5] = {32, 64, 32, 64, 64};   // NerfNetwork::width(layer) (nerf_network.h:474-484)
 	if (layer >= 5 || dimension >= widths[layer]) { set_last_error("ngp_hip_nerf_visualize_activation: layer 0..4, dimension below the layer's width (32, 64, 32, 64, 64)", hipErrorInvalidValue); return -1; }
 	if (!n) return 0;

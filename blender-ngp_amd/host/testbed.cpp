@@ -1763,8 +1763,6 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	NgpNetVariant render_variant_storage;
 	const NgpNetVariant* render_variant = net_variant(render_variant_storage, get_inference_extra_dims(), nullptr);
 	// (render_mode 8 = m_visualized_dimension > -1, whatever m_render_mode says: that covers the Slice mode's activation read-out below as well)
-	if (render_variant && (render_mode == 8 || m_visualized_dimension > -1))
-		throw std::runtime_error{"the EncodingVis render mode (and Slice with visualized_dimension set) runs the network's activation read-out, which is built for the base network family only"};
 	if (render_variant && m_netx_scalar_kernels && render_mode == (int)ERenderMode::Normals)
 		throw std::runtime_error{"the Normals render mode needs the network's input gradient, which the scalar checker kernels (netx_scalar_kernels) do not have"};
 	if (m_render_mode == ERenderMode::Slice) {   // 2445-2476: the network where every ray meets the slice plane; all rays of the frame are shaded
@@ -1775,7 +1773,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			check(ngp_hip_nerf_inference(m_stream, desc, m_params.as<uint16_t>() /* m_network->inference: the training weights (2459) */, m_tr_net_in.as<float>(), 7, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, render_variant), "nerf_inference (slice)");
 			check(ngp_hip_compute_nerf_rgba(m_stream, n_hit, m_tr_net_out.as<uint16_t>(), OUT_STRIDE, m_tr_vis_rgba.as<float>(), (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, 0.01f, 0), "compute_nerf_rgba");
 		} else {
-			check(ngp_hip_nerf_visualize_activation(m_stream, desc, m_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, m_tr_net_in.as<float>(), 7, n_hit, m_tr_vis_rgba.as<float>(), 4), "visualize_activation (slice)");
+			check(ngp_hip_nerf_visualize_activation(m_stream, desc, m_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, m_tr_net_in.as<float>(), 7, n_hit, m_tr_vis_rgba.as<float>(), 4, render_variant), "visualize_activation (slice)");
 		}
 		m_render_samples_evaluated += n_elements;
 		check(ngp_hip_shade(m_stream, n_hit, m_tr_vis_rgba.as<float>(), nullptr, m_tr_payload[0].as<NgpPayload>(), m_nerf.training.linear_colors, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(),
@@ -1861,7 +1859,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
 				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes(), render_variant), "nerf_input_gradient (normals)");
 			} else if (render_mode == 8) {
-				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
+				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7, render_variant), "visualize_activation");
 			}
 			co = compact_into(cur ^ 1);
 			check(ngp_hip_composite(st, n_alive, i, &m_aabb, cam1.m, m_tr_rgba[cur].as<float>(), m_tr_depth[cur].as<float>(), payloads, net_in, net_out, OUT_STRIDE, n_steps,
@@ -1954,7 +1952,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 				m_tr_vis_scratch.enlarge(ngp_hip_nerf_input_gradient_scratch_bytes(n_grad));
 				check(ngp_hip_nerf_input_gradient(st, desc, &m_desc, m_inference_params.as<uint16_t>(), 3, (float*)net_in, 7, n_grad, m_tr_vis_scratch.data(), m_tr_vis_scratch.bytes(), render_variant), "nerf_input_gradient (normals)");
 			} else if (render_mode == 8) {                    // 2227-2228: network.visualize_activation(stream, layer, dim, positions, positions)
-				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7), "visualize_activation");
+				check(ngp_hip_nerf_visualize_activation(st, desc, m_inference_params.as<uint16_t>(), m_visualized_layer, (uint32_t)m_visualized_dimension, (const float*)net_in, 7, n_elements, (float*)net_in, 7, render_variant), "visualize_activation");
 			}
 			check(ngp_hip_composite(st, pt.n_alive, pt.i, &m_aabb, cam1.m, (float*)buf(m_tr_rgba[cur], 16, pt.start), (float*)buf(m_tr_depth[cur], 4, pt.start), payloads, net_in, net_out, OUT_STRIDE, n_steps,
 			                           (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, m_nerf.render_min_transmittance, render_mode,

@@ -533,7 +533,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
  * row 2 = 0, every further row = 1; out_stride_floats = 7 writes over the NgpCoord it read (the tracer's EncodingVis, src/testbed_nerf.cu:2227-2228),
  * 4 gives the rgba of the Slice mode (:2462). */
 int ngp_hip_nerf_visualize_activation(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, uint32_t layer, uint32_t dimension, const float* coords,
-                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats);
+                                      uint32_t coord_stride_floats, uint32_t n, float* out, uint32_t out_stride_floats, const NgpNetVariant* variant /* NULL: base family */);
 /* Slice mode (src/testbed_nerf.cu:2445-2476): network inputs at payload.origin + dir * t (generate_nerf_network_inputs_at_current_position, :676-682),
  * fp16 network outputs -> fp32 rgba with alpha = clamp(1 - exp(-density * depth), 0, 1) and colours premultiplied (compute_nerf_rgba, :684-703). */
 int ngp_hip_generate_inputs_at_current_position(void* stream, uint32_t n_elements, const NgpAabb* aabb_host, const NgpPayload* payloads, NgpCoord* network_input);

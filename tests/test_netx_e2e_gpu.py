@@ -168,6 +168,11 @@ def test_variants_render_normals_and_register_cameras(cuda, h, n_extra):
     ln = np.linalg.norm(nv, axis=1)
     assert abs(np.median(ln) - 1.0) < 3e-2 and (np.abs(ln - 1.0) < 8e-2).mean() > 0.85
     assert (nv @ np.asarray(t.camera_matrix)[:, 2] < 0.25).mean() > 0.8                        # visible surfaces face the camera
+    # ---- EncodingVis (visualized_dimension > -1): the colour network's last hidden layer of the variant
+    t.visualized_layer, t.visualized_dimension = 2 + h, 5
+    vis = t.render(48, 48, 1, True)
+    t.visualized_dimension = -1
+    assert np.isfinite(vis).all() and vis[..., :2].max() > 0 and np.abs(vis[..., 2]).max() == 0       # (negative part, positive part, 0) composited
     # ---- registration: a third of the cameras displaced, only the extrinsics train
     true_pos = np.array([np.asarray(a)[:, 3] for a, _ in tr.transforms])
     rs = np.random.RandomState(4)

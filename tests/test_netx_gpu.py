@@ -183,6 +183,54 @@ def test_input_gradient_of_a_variant(ngp, oracle, cuda, n_extra, n_hidden):
     assert ngp.ngp_hip_nerf_input_gradient(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), 3, d_c.data_ptr(), 7, n, d_s.data_ptr(), sb, vs.ctypes.data) != 0   # the checker kernels have none
 
 
+@pytest.mark.parametrize("n_extra,n_hidden", [(0, 1), (5, 3), (4, 0), (8, 2)])
+def test_visualize_activation_of_a_variant(ngp, oracle, cuda, n_extra, n_hidden):
+    """ngp_hip_nerf_visualize_activation with an NgpNetVariant ([tcnn] visualize_activation: the EncodingVis render mode).  Layer map of NerfNetwork::width
+    (nerf_network.h:474-484): 0 encoding, 1 density hidden, 2 colour input, 3.. colour hidden layers.  Self-consistency with the inference kernels: the encoding read-out is
+    the saved encoding of the training forward; the LAST layer's read-out, pushed through the network's last matrix on the host, is the inference output's colour."""
+    import torch
+    n = 512
+    desc = H.make_desc(ngp, log2_hashmap_size=12)
+    coords = H.random_coords(n, seed=31)
+    rs = np.random.RandomState(8)
+    table = (rs.rand(3, max(n_extra, 1)) * 2 - 1).astype(np.float32)
+    x = netx(n_extra, n_hidden, table if n_extra else None, None)
+    params, npar, n_mlp = _params(oracle, desc, x, 23)
+    d_desc, d_P, d_c, d_tab = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(coords, cuda), H.to_dev(table, cuda)
+    v = _variant(n_extra, n_hidden, d_tab if n_extra else None, None)            # sample_slot NULL: row 0 for every sample (rendering)
+
+    def read(layer, width):
+        cols = []
+        for dim in range(width):
+            o = torch.zeros(n, device=cuda, dtype=torch.float32)
+            check(ngp.ngp_hip_nerf_visualize_activation(None, d_desc.data_ptr(), d_P.data_ptr(), layer, dim, d_c.data_ptr(), 7, n, o.data_ptr(), 1, v.ctypes.data))
+            cols.append(H.to_host(o, np.float32))
+        return np.stack(cols, 1)
+
+    out, xs = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr(), v.ctypes.data))
+    enc = H.to_host(xs, np.float16).reshape(n, 32).astype(np.float32)
+    got_enc = read(0, 32)
+    assert (np.abs(got_enc - enc) <= np.abs(enc) * 2e-3 + 1e-6).mean() > 0.995          # (contraction mode of the two encoders: one fp16 ulp in a few features)
+    rgb_in = 32 + (16 if n_extra else 0)
+    last_layer, last_width = (2, rgb_in) if n_hidden == 0 else (2 + n_hidden, 64)
+    act = read(last_layer, last_width)
+    P = params.view(np.float16).astype(np.float32)
+    w_last = P[n_mlp - 16 * last_width:n_mlp].reshape(16, last_width)             # the network's last matrix: [16][64], or [16][rgb_in] without hidden layers
+    want = act @ w_last.T
+    got = H.to_host(out, np.float16).reshape(n, 4).astype(np.float32)
+    assert np.abs(want[:, :3]).max() > 1e-2
+    np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=2e-2, atol=4e-3)
+    if n_hidden:
+        assert (act >= 0).all()                                                   # behind a ReLU
+    if n_extra:                                                                   # the colour input's extra block is the table's row 0, padded with zeros
+        rin = read(2, rgb_in)
+        np.testing.assert_allclose(rin[:, 32:32 + n_extra], np.tile(table[0].astype(np.float16).astype(np.float32), (n, 1)), rtol=0, atol=0)
+        assert (rin[:, 32 + n_extra:] == 0).all()
+    o = torch.zeros(n, device=cuda, dtype=torch.float32)
+    assert ngp.ngp_hip_nerf_visualize_activation(None, d_desc.data_ptr(), d_P.data_ptr(), 3 + n_hidden, 0, d_c.data_ptr(), 7, n, o.data_ptr(), 1, v.ctypes.data) != 0   # no such layer
+
+
 def test_slot_expansion_rollover_and_latent_code_gradient(ngp, oracle, cuda):
     """ngp_hip_ray_images / _expand_ray_slots / _rollover_slots / _extra_dims_gradient against their definitions"""
     import torch
