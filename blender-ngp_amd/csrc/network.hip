@@ -1159,6 +1159,9 @@ constexpr int FB_PITCH = 128 * 2 + 16;       // bytes per staged row: 128 sample
 constexpr int FB_STAGE_ROWS = 128;
 constexpr int FB_STAGE_BYTES = FB_STAGE_ROWS * FB_PITCH;   // 34 816 B
 
+// (Measured in round 4 and dropped: lanes j and j ^ 1 swapping half of every feature pair through DPP so that each writes one dword — two samples of one feature — instead of two
+// halves, i.e. 4 ds_write_b32 per K-block and lane instead of 8 ds_write_b16: the fused backward kernel went 63.6 -> 83.1 us.  The kernel is bound by VALU issue and
+// dependent-instruction latency at 2 waves per SIMD, not by its LDS writes; the DPP moves and the 16-bit merges cost more than the halved writes save.)
 __device__ __forceinline__ void fb_put(char* __restrict__ stage, int row0, int map, int kb, int g, int col, const h8& v) {
 #pragma unroll
 	for (int e = 0; e < 8; ++e) *(half_t*)(stage + (row0 + slot_feature(map, kb, g, e)) * FB_PITCH + col * 2) = v[e];
