@@ -151,6 +151,8 @@ def train(testbed, n_steps, log_every=0):
     while testbed.frame():
         if testbed.training_step >= n_steps:
             break
+        if not testbed.shall_train:   # the Testbed switched training off itself ("Nerf training generated 0 samples. Aborting training.", testbed_nerf.cu:2966-2970): run.py's loop would spin here for ever
+            raise RuntimeError("scene.train: training stopped at step %d (the step generated no samples)" % testbed.training_step)
         if log_every and testbed.training_step % log_every == 0:
             print("step %d loss %.5f rays %d (%.1fs)" % (testbed.training_step, testbed.loss, testbed.nerf.training.rays_per_batch, time.time() - t0), flush=True)
 
