@@ -69,6 +69,8 @@ void decode_hdr_rgba8(const uint8_t* data, size_t n_bytes, int& w, int& h, std::
 	const long ww = strtol(q + 3, nullptr, 10);
 	if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24) || (int64_t)ww * hh > ((int64_t)1 << 28)) throw std::runtime_error{"HDR: bad image size"};
 	w = (int)ww; h = (int)hh;
+	// before the allocation: a run-length scanline costs at least 4 marker bytes + 2 bytes per 127-pixel run and channel, a flat one 4 bytes per pixel
+	if ((uint64_t)h * (4u + 8u * (((uint64_t)w + 126u) / 127u)) > (uint64_t)n_bytes + 64u) throw std::runtime_error{"HDR: the header promises more pixels than the file could encode"};
 	pixels.assign((size_t)w * h * 4, 0);
 	bool flat = w < 8 || w >= 32768;
 	std::vector<uint8_t> scan;

@@ -54,6 +54,9 @@ static void png_unfilter(const uint8_t* d, size_t n, PngRaw& R) {
 	if ((uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28)) throw std::runtime_error("PNG: image larger than 2^28 pixels");
 	const size_t bits_per_pixel = (size_t)channels * depth;
 	const size_t row_bytes = ((size_t)w * bits_per_pixel + 7) / 8;
+	// before any allocation sized by IHDR: DEFLATE expands at most 1032 : 1, so a header that promises more filtered bytes than the IDAT chunks could hold is hostile
+	// (a 60-byte file must not force a multi-GiB buffer)
+	if ((uint64_t)h * (uint64_t)(row_bytes + 1) / 1032u > (uint64_t)idat.size() + 64u) throw std::runtime_error("PNG: IHDR promises more pixels than the IDAT data could encode");
 	const size_t bpp = std::max<size_t>(1, bits_per_pixel / 8);
 	// unfilter `rows` scanlines of `rb` sample bytes each, in place (PNG spec 9.2); every scanline starts with its filter byte
 	auto unfilter = [&](uint8_t* data, int rows, size_t rb) {

@@ -582,3 +582,34 @@ def test_radiance_hdr_errors(tmp_path):
         p.write_bytes(blob)
         with pytest.raises(RuntimeError, match="HDR"):
             pyngp.decode_image(str(p))
+
+
+def test_tiny_files_cannot_promise_huge_images(tmp_path):
+    """a header of a few bytes must not force a multi-GiB allocation — EXR (data window / 1 x 1 tiles), PNG (IHDR) and Radiance .hdr (resolution line)
+    are checked against what the file could encode before anything is sized by them."""
+    import zlib
+    import pyngp
+    # ---- EXR: a valid 8 x 8 file whose data window is rewritten to 16384 x 16384 (2^28 pixels: inside the pixel cap, 4 GiB of floats)
+    img = np.random.RandomState(0).rand(8, 8, 4).astype(np.float32)
+    p = str(tmp_path / "src.exr")
+    _write_exr(p, img, 1, 2)
+    raw = open(p, "rb").read()
+    key = b"dataWindow\0box2i\0" + struct.pack("<I", 16)
+    i = raw.index(key) + len(key)
+    q = str(tmp_path / "huge.exr")
+    open(q, "wb").write(raw[:i] + struct.pack("<iiii", 0, 0, 16383, 16383) + raw[i + 16:])
+    with pytest.raises(RuntimeError, match="too short|could encode"):
+        pyngp.decode_exr(q)
+    # ---- PNG: IHDR 16384 x 16384 RGBA with a 30-byte IDAT
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 16384, 16384, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    q = str(tmp_path / "huge.png")
+    open(q, "wb").write(png)
+    with pytest.raises(RuntimeError, match="could encode"):
+        pyngp.decode_image(q)
+    # ---- Radiance: a 16384 x 16384 resolution line over a few bytes of data
+    q = str(tmp_path / "huge.hdr")
+    open(q, "wb").write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 16384 +X 16384\n" + b"\x02\x02\x40\x00" + b"\x81\x10" * 8)
+    with pytest.raises(RuntimeError, match="could encode"):
+        pyngp.decode_image(q)
