@@ -76,27 +76,45 @@ constexpr int T_W2T = 38; // + mt          (2)   A[i = h1 feat][slot = density-o
 constexpr int T_W1T = 40; // + kb          (4)   A[i = x feat][slot = h1 feat]
 constexpr int N_ALL_TILES = 44;
 
-// one A-operand tile of a row-major [n_out][n_in] weight matrix at P + w_off: element (i = mt*32 + lane&31, K-slot (kb, lane>>5, e))
-__device__ __forceinline__ h8 gather_tile_spec(const half_t* __restrict__ P, int w_off, int n_out, int n_in, int mt, int kb, int map, bool transposed, int lane) {
-	const int i32 = lane & 31, g = lane >> 5;
-	const half_t* W = P + w_off;
-	const int i = mt * 32 + i32;
+// Staging, measured in round 4 (tools/mlp_fixed_cost_probe.py): gathering the tiles straight from global memory — 8 two-byte loads per lane and tile, every lane of a
+// forward tile in a different 64-byte line — cost 17.7 us of the fused backward kernel's 59 (44 tiles) and ~10 us of every forward launch: the same vector-L1 look-up
+// rate that bounds the hash gather (profiles/r04_forward_counters.md).  Now the raw row-major matrices come in ONCE with coalesced 16-byte loads into the LDS region
+// the tiles will occupy, the lanes pick their tile elements out of LDS (branch-free, tile geometry in scalar registers) into registers, and after a barrier the tiles
+// overwrite the raw copy.
+// Raw half k of the parameter block sits at LDS half k + 2 * (k >> 5): one dword of padding per 64 bytes, so that the 32 rows a forward tile reads at one column
+// fall into 32 different banks (row pitch 17 or 34 dwords instead of 16 or 32).
+__device__ __forceinline__ int raw_slot(int k) { return k + 2 * (k >> 5); }
+
+// one A-operand tile of a row-major [n_out][n_in] weight matrix at raw offset w_off, out of the LDS copy R: element (i = mt*32 + lane&31, K-slot (kb, lane>>5, e)).
+// Tile geometry (everything but `lane`) is wave-uniform.
+__device__ __forceinline__ h8 gather_tile_spec(const half_t* R, int w_off, int n_out, int n_in, int mt, int kb, int map, bool transposed, int lane) {
+	const int i = mt * 32 + (lane & 31), g = lane >> 5;
+	// slot_feature(map, kb, g, e) == base + cg * g + ch * (e >> 2) + (e & 3) for every map
+	int base, cg, ch;
+	switch (map) {
+		case MAP_ENC: base = 8 * kb; cg = 16; ch = 4; break;
+		case MAP_HID: base = 16 * kb; cg = 4; ch = 8; break;
+		case MAP_RGBIN: base = kb == 0 ? 0 : 16; cg = kb == 0 ? 4 : 8; ch = kb == 0 ? 8 : 4; break;
+		case 4: base = 32; cg = 8; ch = 4; break;
+		default: base = 0; cg = 8; ch = 4; break;
+	}
+	const int si = transposed ? 1 : n_in, sf = transposed ? n_in : 1;            // A[i = out][slot = in feature f] | A[i = in][slot = out feature f]
+	const int lim_i = transposed ? n_in : n_out, lim_f = transposed ? n_out : n_in;
+	const int fg = base + cg * g, k0 = w_off + i * si;
+	const bool i_ok = i < lim_i;
 	h8 r;
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
-		const int f = slot_feature(map, kb, g, e);
-		half_t v = (half_t)0.0f;
-		if (!transposed) { if (i < n_out && f < n_in) v = W[i * n_in + f]; }     // A[i = out][slot = in feature f]
-		else             { if (f < n_out && i < n_in) v = W[f * n_in + i]; }     // A[i = in][slot = out feature f]
-		r[e] = v;
+		const int f = fg + ch * (e >> 2) + (e & 3);
+		const bool ok = i_ok && f < lim_f;
+		const half_t v = R[raw_slot(ok ? k0 + f * sf : 0)];
+		r[e] = ok ? v : (half_t)0.0f;
 	}
 	return r;
 }
 
-// element of forward tile: W[row i][col slot_feature]
-__device__ __forceinline__ h8 gather_tile(const half_t* __restrict__ P, int tile, int lane) {
-	const int i32 = lane & 31, g = lane >> 5;
-	h8 r;
+// tile of the base network's parameter block
+__device__ __forceinline__ h8 gather_tile(const half_t* R, int tile, int lane) {
 	int w_off, n_out, n_in, mt, kb, map; bool transposed = false;
 	if (tile < T_W2)       { w_off = W1_OFF; n_out = 64; n_in = 32; mt = (tile - T_W1) >> 1; kb = (tile - T_W1) & 1; map = MAP_ENC; }
 	else if (tile < T_W3)  { w_off = W2_OFF; n_out = 16; n_in = 64; mt = 0; kb = tile - T_W2; map = MAP_HID; }
@@ -108,33 +126,60 @@ __device__ __forceinline__ h8 gather_tile(const half_t* __restrict__ P, int tile
 	else if (tile < T_W2T) { w_off = W3_OFF; n_out = 64; n_in = 32; mt = 0; kb = tile - T_W3T; map = MAP_HID; transposed = true; }
 	else if (tile < T_W1T) { w_off = W2_OFF; n_out = 16; n_in = 64; mt = tile - T_W2T; kb = 0; map = MAP_RGBIN; transposed = true; }
 	else                   { w_off = W1_OFF; n_out = 64; n_in = 32; mt = 0; kb = tile - T_W1T; map = MAP_HID; transposed = true; }
-	const half_t* W = P + w_off;
-	const int i = mt * 32 + i32;
-#pragma unroll
-	for (int e = 0; e < 8; ++e) {
-		const int f = slot_feature(map, kb, g, e);
-		half_t v = (half_t)0.0f;
-		if (!transposed) { if (i < n_out && f < n_in) v = W[i * n_in + f]; }     // A[i = out][slot = in feature f]
-		else             { if (f < n_out && i < n_in) v = W[f * n_in + i]; }     // A[i = in][slot = out feature f]
-		r[e] = v;
-	}
-	return r;
+	return gather_tile_spec(R, w_off, n_out, n_in, mt, kb, map, transposed, lane);
 }
 
-__device__ __forceinline__ void stage_weights(h8* lds_tiles, const half_t* __restrict__ params, int first_tile, int n_tiles) {
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	for (int t = w; t < n_tiles; t += nw) lds_tiles[t * 64 + lane] = gather_tile(params, first_tile + t, lane);
+// The first N_RAW halves of `params` (the network's matrices) -> N_TILES A-operand tiles in lds_tiles, by the 4 waves of a 256-thread workgroup.
+// tile_of(R, tile, lane) names the network: gather_tile, gm_gather_tile, nx_gather_tile<NH, XK>.
+template <int N_RAW, int N_TILES, class TileOf>
+__device__ __forceinline__ void stage_tiles(h8* lds_tiles, const half_t* __restrict__ params, TileOf tile_of) {
+	static_assert(N_RAW % 8 == 0 && (N_RAW + 2 * (N_RAW / 32)) * 2 <= N_TILES * 1024, "the raw copy fits the region its tiles take");
+	half_t* R = (half_t*)lds_tiles;
+	if (((uintptr_t)params & 15u) == 0) {
+		for (int c = threadIdx.x; c < N_RAW / 8; c += 256) {
+			const uint4 v = ((const uint4*)params)[c];
+			uint32_t* d = (uint32_t*)(R + raw_slot(8 * c));   // 8 | 32: a chunk never straddles a padding dword; 4-byte aligned
+			d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+		}
+	} else {
+		for (int k = threadIdx.x; k < N_RAW; k += 256) R[raw_slot(k)] = params[k];
+	}
+	__syncthreads();
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	constexpr int PER_WAVE = (N_TILES + 3) / 4;
+	h8 regs[PER_WAVE];
+#pragma unroll
+	for (int q = 0; q < PER_WAVE; ++q)
+		if (w + 4 * q < N_TILES) regs[q] = tile_of((const half_t*)R, w + 4 * q, lane);
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < PER_WAVE; ++q)
+		if (w + 4 * q < N_TILES) lds_tiles[(w + 4 * q) * 64 + lane] = regs[q];
 	__syncthreads();
 }
 
 // f32 D tile (32 rows) -> two f16 K-blocks (B operand of the next layer), optional ReLU, optional positive-mask output
+// Converted two at a time (v_cvt_pk_f16_f32, round to nearest even like the scalar conversion) and clamped AFTER the conversion with one packed
+// SIGNED-INTEGER max on the fp16 bit patterns: rounding is monotone and maps 0 to 0, so this is fp16(max(v, 0)) bit for bit in half the instructions,
+// and everything with the sign bit set (-0 included) becomes +0 — mask_delta below relies on "positive" == "bits != 0".
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2v __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 relu_pk(h2 v) {
+	const i16x2v nil = {0, 0};
+	return __builtin_bit_cast(h2, __builtin_elementwise_max(__builtin_bit_cast(i16x2v, v), nil));
+}
+__device__ __forceinline__ h2 cvt_pk_f16(float a, float b) {
+	f32x2v v; v[0] = a; v[1] = b;
+	return __builtin_convertvector(v, h2);
+}
 template <bool RELU>
 __device__ __forceinline__ void d_to_b(const f32x16& d, h8& b0, h8& b1) {
 #pragma unroll
-	for (int e = 0; e < 8; ++e) {
-		float v0 = d[e], v1 = d[8 + e];
-		if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-		b0[e] = (half_t)v0; b1[e] = (half_t)v1;
+	for (int e = 0; e < 8; e += 2) {
+		h2 p0 = cvt_pk_f16(d[e], d[e + 1]), p1 = cvt_pk_f16(d[8 + e], d[9 + e]);
+		if (RELU) { p0 = relu_pk(p0); p1 = relu_pk(p1); }
+		b0[e] = p0[0]; b0[e + 1] = p0[1]; b1[e] = p1[0]; b1[e + 1] = p1[1];
 	}
 }
 
@@ -319,7 +364,7 @@ __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const Ng
                                                            half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved,
                                                            const h2* __restrict__ x_planes, uint32_t n_pad) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_FWD_TILES * 64];
-	stage_weights(lds_tiles, params, 0, MODE == 1 ? T_W3 : N_FWD_TILES);
+	stage_tiles<(MODE == 1 ? W3_OFF : GRID_OFF), (MODE == 1 ? T_W3 : N_FWD_TILES)>(lds_tiles, params, gather_tile);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
 	const uint32_t n_tiles = (n + 31) / 32;
@@ -472,12 +517,18 @@ __global__ void __launch_bounds__(256) encode_levels_planes_kernel(const NgpNetD
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// dL/d(pre-activation) of a ReLU layer as fp16: the fp32 gradient where the forward activation was positive, 0 elsewhere.  Activations are
+// post-ReLU (>= +0), so "positive" is "bit pattern != 0": per PAIR of elements one packed conversion, min(bits, 1), 0 - that (0x0000 / 0xffff) and an AND.
 __device__ __forceinline__ h8 mask_delta(const f32x16& t, int half_idx, const h8& fwd_act) {
 	h8 r;
+	const u16x2v one = {1, 1}, nil = {0, 0};
 #pragma unroll
-	for (int e = 0; e < 8; ++e) {
-		float v = t[8 * half_idx + e];
-		r[e] = ((float)fwd_act[e] > 0.0f) ? (half_t)v : (half_t)0.0f;
+	for (int e = 0; e < 8; e += 2) {
+		h2 a; a[0] = fwd_act[e]; a[1] = fwd_act[e + 1];
+		const u16x2v keep = nil - __builtin_elementwise_min(__builtin_bit_cast(u16x2v, a), one);
+		const u16x2v bits = __builtin_bit_cast(u16x2v, cvt_pk_f16(t[8 * half_idx + e], t[8 * half_idx + e + 1])) & keep;
+		const h2 v = __builtin_bit_cast(h2, bits);
+		r[e] = v[0]; r[e + 1] = v[1];
 	}
 	return r;
 }
@@ -1263,7 +1314,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // the counters of the hash-grid backward that follows are cleared here instead of by a memset launch of their own
-	stage_weights(lds_tiles, params, 0, N_ALL_TILES);
+	stage_tiles<GRID_OFF, N_ALL_TILES>(lds_tiles, params, gather_tile);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
 	const uint32_t n_quads = n / 128;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
@@ -1532,18 +1583,13 @@ constexpr int G_L1T = 18;  // + mt*4 + kb (8)   A[i = h1 feat][slot = h2 feat]
 constexpr int G_L0T = 26;  // + kb        (4)   A[i = x feat][slot = h1 feat]
 constexpr int GM_ALL_TILES = 30;
 
-__device__ __forceinline__ h8 gm_gather_tile(const half_t* __restrict__ P, int tile, int lane) {
+__device__ __forceinline__ h8 gm_gather_tile(const half_t* P, int tile, int lane) {
 	if (tile < G_L1)  return gather_tile_spec(P, GM_L0_OFF, 64, 32, (tile - G_L0) >> 1, (tile - G_L0) & 1, MAP_ENC, false, lane);
 	if (tile < G_L2)  return gather_tile_spec(P, GM_L1_OFF, 64, 64, (tile - G_L1) >> 2, (tile - G_L1) & 3, MAP_HID, false, lane);
 	if (tile < G_L2T) return gather_tile_spec(P, GM_L2_OFF, 16, 64, 0, tile - G_L2, MAP_HID, false, lane);
 	if (tile < G_L1T) return gather_tile_spec(P, GM_L2_OFF, 16, 64, tile - G_L2T, 0, MAP_CH, true, lane);
 	if (tile < G_L0T) return gather_tile_spec(P, GM_L1_OFF, 64, 64, (tile - G_L1T) >> 2, (tile - G_L1T) & 3, MAP_HID, true, lane);
 	return gather_tile_spec(P, GM_L0_OFF, 64, 32, 0, tile - G_L0T, MAP_HID, true, lane);
-}
-__device__ __forceinline__ void gm_stage_weights(h8* lds_tiles, const half_t* __restrict__ params, int n_tiles) {
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	for (int t = w; t < n_tiles; t += nw) lds_tiles[t * 64 + lane] = gm_gather_tile(params, t, lane);
-	__syncthreads();
 }
 
 template <int D>
@@ -1598,7 +1644,7 @@ template <int D>
 __global__ void __launch_bounds__(256, 2) gridmlp_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ pos, uint32_t pos_stride,
                                                                  uint32_t n, half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_FWD_TILES * 64];
-	gm_stage_weights(lds_tiles, params, GM_FWD_TILES);
+	stage_tiles<GM_GRID_OFF, GM_FWD_TILES>(lds_tiles, params, gm_gather_tile);
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
 	const uint32_t n_tiles = (n + 31) / 32;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1657,7 +1703,7 @@ __global__ void __launch_bounds__(256, 2) gridmlp_backward_fused_kernel(const ha
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // see nerf_backward_fused_kernel
-	gm_stage_weights(lds_tiles, params, GM_ALL_TILES);
+	stage_tiles<GM_GRID_OFF, GM_ALL_TILES>(lds_tiles, params, gm_gather_tile);
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
 	const uint32_t n_quads = n / 128;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
 	const f32x16 zero = {};

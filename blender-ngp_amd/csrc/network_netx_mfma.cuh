@@ -47,7 +47,7 @@ struct NxL {
 
 // one A-operand tile of the variant's parameter block (runtime tile id; staging only)
 template <int NH, int XK>
-__device__ __forceinline__ h8 nx_gather_tile(const half_t* __restrict__ P, int tile, int lane) {
+__device__ __forceinline__ h8 nx_gather_tile(const half_t* P, int tile, int lane) {
 	typedef NxL<NH, XK> L;
 	if (tile < L::T_W2) return gather_tile_spec(P, L::OFF_W1, 64, 32, (tile - L::T_W1) >> 1, (tile - L::T_W1) & 1, MAP_ENC, false, lane);
 	if (tile < L::T_C0) return gather_tile_spec(P, L::OFF_W2, 16, 64, 0, tile - L::T_W2, MAP_HID, false, lane);
@@ -62,12 +62,6 @@ __device__ __forceinline__ h8 nx_gather_tile(const half_t* __restrict__ P, int t
 	if (tile < L::T_W2T) { const int q = tile - L::T_C0T; return gather_tile_spec(P, L::OFF_C0, L::C0_OUT, L::RIN, q / L::C0T_KB, q % L::C0T_KB, NH == 0 ? MAP_CH : MAP_HID, true, lane); }
 	if (tile < L::T_W1T) return gather_tile_spec(P, L::OFF_W2, 16, 64, tile - L::T_W2T, 0, MAP_RGBIN, true, lane);
 	return gather_tile_spec(P, L::OFF_W1, 64, 32, 0, tile - L::T_W1T, MAP_HID, true, lane);
-}
-template <int NH, int XK>
-__device__ __forceinline__ void nx_stage_weights(h8* lds_tiles, const half_t* __restrict__ params, int n_tiles) {
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	for (int t = w; t < n_tiles; t += nw) lds_tiles[t * 64 + lane] = nx_gather_tile<NH, XK>(params, t, lane);
-	__syncthreads();
 }
 
 // activations of one 32-sample tile in B-operand form, kept for the backward recompute
@@ -142,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) nx_forward_kernel(const NgpNetDesc* __
                                                             const float* __restrict__ extra_dims, const uint32_t* __restrict__ sample_slot, uint32_t n_extra, uint32_t grid_off) {
 	typedef NxL<NH, XK> L;
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[(MODE == 1 ? 8 : L::N_FWD) * 64];
-	nx_stage_weights<NH, XK>(lds_tiles, params, MODE == 1 ? 8 : L::N_FWD);
+	stage_tiles<(MODE == 1 ? L::OFF_C0 : L::N_MLP), (MODE == 1 ? 8 : L::N_FWD)>(lds_tiles, params, nx_gather_tile<NH, XK>);
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
 	const uint32_t n_tiles = (n + 31) / 32;
 	const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -241,7 +235,7 @@ __global__ void __launch_bounds__(256) nx_backward_kernel(const NgpNetDesc* __re
 	h8* lds_tiles = (h8*)nx_smem;
 	char* stage = nx_smem + (size_t)L::N_ALL * 1024;
 	if (PASS == 0) for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero_words; k += gridDim.x * blockDim.x) zero_words[k] = 0u;   // the hash-grid backward's counters
-	nx_stage_weights<NH, XK>(lds_tiles, params, L::N_ALL);
+	stage_tiles<L::N_MLP, L::N_ALL>(lds_tiles, params, nx_gather_tile<NH, XK>);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t n_quads = n / 128;

@@ -10,7 +10,12 @@ rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 fw=[i for i,r in enumerate(rows) if "nerf_forward_kernelILi2" in r["Kernel_Name"] or "nerf_forward_rays_kernel" in r["Kernel_Name"]]
 # three consecutive steps near the end that have no occupancy update in between
-for k in range(len(fw)-8, len(fw)-5):
+import os
+ks=list(range(len(fw)-8, len(fw)-5))
+if os.environ.get("TIMELINE_UPDATE"):   # the steps around an occupancy-grid update instead
+    upd=[k for k in range(len(fw)-40, len(fw)-2) if any("encode_planes" in r["Kernel_Name"] for r in rows[fw[k]:fw[k+1]])]
+    ks=sorted(set(j for k in upd[-1:] for j in (k-1,k,k+1,k+2)))
+for k in ks:
     a,b=fw[k],fw[k+1]
     t0=int(rows[a]["Start_Timestamp"])
     print("---- step, period %.1f us" % ((int(rows[b]["Start_Timestamp"])-t0)/1000))
