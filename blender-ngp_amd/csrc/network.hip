@@ -704,7 +704,10 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 			uint32_t c = live ? ((bin << 16) | atomicAdd(&hist[bin], 1u)) : 0xffffffffu;
 			if (straddle && live) {
 				const uint32_t bin1 = ((hb ^ (p.gx + 1u)) & hmask) / GB_FX_SLICE;
-				if (bin1 != bin) { side[(u * NI + m) * 256 + threadIdx.x] = (bin1 << 16) | atomicAdd(&hist[bin1], 1u); c |= 0x80000000u; }
+				if (bin1 != bin) {
+					const uint32_t r1 = atomicAdd(&hist[bin1], 1u);
+					if (SCATTER) { side[(u * NI + m) * 256 + threadIdx.x] = (bin1 << 16) | r1; c |= 0x80000000u; }   // (the count pass has no `side`: its LDS is the histogram and one word per sample)
+				}
 			}
 			code[u][m] = c;
 		}
@@ -763,20 +766,65 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 constexpr uint32_t GB_STAGE = GB_FX_CHUNK + GB_FX_CHUNK / 8;
 // levels whose slices fit the 256 bins are binned; larger dense tables (log2_hashmap_size >= 21: res^3 above 2^20 entries) take the float path of the owners
 __host__ __device__ __forceinline__ bool gb_dense_binned(uint32_t level_size) { return (level_size + GB_FX_SLICE - 1) / GB_FX_SLICE <= GB_FX_MAX_SLICES; }
+// The walk's notion of "same cell", shared by the two passes (they must emit the same records): the cell coordinates packed 10 bits each — every dense level the
+// binning takes has a resolution below 1024 — or, for a coordinate outside that (a position far outside the unit cube), a key of its own that merges with nothing.
+__device__ __forceinline__ uint32_t gb_cell_key(const LevelPos& p, uint32_t i) {
+	return (p.gx | p.gy | p.gz) < 1024u ? (p.gx | (p.gy << 10) | (p.gz << 20)) : (0x80000000u | i);
+}
+// the 2^D corner entries of a cell of a DENSE level: grid_index_nd's x + y res + z res^2 (same uint32 arithmetic, same wrap) for corner 0 plus a per-corner offset
+template <int D>
+__device__ __forceinline__ uint32_t gb_dense_corner(const NgpGridLevel& lv, uint32_t raw0, int k) {
+	uint32_t raw = raw0 + (uint32_t)(k & 1) + (((k >> 1) & 1) ? lv.resolution : 0u);
+	if (D == 3 && ((k >> 2) & 1)) raw += lv.resolution * lv.resolution;
+	return raw >= lv.size ? raw % lv.size : raw;   // (power-of-two sizes: the same value as grid_index's mask)
+}
+template <int D>
+__device__ __forceinline__ uint32_t gb_dense_raw0(const NgpGridLevel& lv, uint32_t gx, uint32_t gy, uint32_t gz) {
+	return gx + gy * lv.resolution + (D == 3 ? gz * lv.resolution * lv.resolution : 0u);
+}
+// count pass: the keys of the chunk's samples sit in LDS (~0 = nothing to add); one flush per run and thread, 2^D histogram increments each
+template <int D>
+__device__ __forceinline__ void gb_dense_count_walk(const uint32_t* __restrict__ s_key, uint32_t* __restrict__ counter, const NgpGridLevel& lv, uint32_t chunk_bin0,
+                                                    const float* __restrict__ chunk_coords, uint32_t coord_stride) {
+	constexpr int NC = 1 << D;
+	constexpr uint32_t RUN = GB_FX_CHUNK / 256;
+	uint32_t cur = 0xffffffffu;
+	auto flush = [&]() {
+		uint32_t gx = cur & 1023u, gy = (cur >> 10) & 1023u, gz = cur >> 20;
+		if (cur & 0x80000000u) {   // (rare) a sample outside the packable range: its cell from the position itself
+			const float* c = chunk_coords + (size_t)(cur & 0x7fffffffu) * coord_stride;
+			const LevelPos p = level_pos(lv, c[0], c[1], D == 3 ? c[2] : 0.f);
+			gx = p.gx; gy = p.gy; gz = p.gz;
+		}
+		const uint32_t raw0 = gb_dense_raw0<D>(lv, gx, gy, gz);
+#pragma unroll
+		for (int k = 0; k < NC; ++k) atomicAdd(&counter[chunk_bin0 + gb_dense_corner<D>(lv, raw0, k) / GB_FX_SLICE], 1u);
+	};
+#pragma unroll
+	for (uint32_t u = 0; u < RUN; ++u) {
+		const uint32_t i = threadIdx.x * RUN + u;
+		const uint32_t key = s_key[i + (i >> 3)];
+		if (key == 0xffffffffu) continue;
+		if (key != cur) { if (cur != 0xffffffffu) flush(); cur = key; }
+	}
+	if (cur != 0xffffffffu) flush();
+}
+
 template <int D, bool WRITE>
 __device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, const float* __restrict__ s_px, const float* __restrict__ s_py, const float* __restrict__ s_pz,
                                               uint32_t* __restrict__ counter, const NgpGridLevel& lv, uint32_t chunk_bin0, uint32_t n_live,
                                               uint32_t* __restrict__ out_e, ulonglong2* __restrict__ out_v) {
 	constexpr int NC = 1 << D;
 	constexpr uint32_t RUN = GB_FX_CHUNK / 256;
-	uint32_t cgx = 0xffffffffu, cgy = 0, cgz = 0;
+	uint32_t cgx = 0, cgy = 0, cgz = 0, cur = 0xffffffffu;
 	long long a0[NC], a1[NC];
 #pragma unroll
 	for (int k = 0; k < NC; ++k) { a0[k] = 0; a1[k] = 0; }
 	auto flush = [&]() {
+		const uint32_t raw0 = gb_dense_raw0<D>(lv, cgx, cgy, cgz);
 #pragma unroll
 		for (int k = 0; k < NC; ++k) {
-			const uint32_t idx = grid_index_nd<D>(lv, cgx + (k & 1), cgy + ((k >> 1) & 1), cgz + ((k >> 2) & 1));
+			const uint32_t idx = gb_dense_corner<D>(lv, raw0, k);
 			const uint32_t pos = atomicAdd(&counter[chunk_bin0 + idx / GB_FX_SLICE], 1u);
 			if (WRITE) { out_e[pos] = idx % GB_FX_SLICE; out_v[pos] = make_ulonglong2((unsigned long long)a0[k], (unsigned long long)a1[k]); }
 		}
@@ -787,9 +835,10 @@ __device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, 
 		const uint32_t gbits = s_g[ip];
 		if (i >= n_live || (gbits & 0x7fff7fffu) == 0) continue;   // adding +-0 never changes a sum
 		const LevelPos p = level_pos(lv, s_px[ip], s_py[ip], D == 3 ? s_pz[ip] : 0.f);
-		if (p.gx != cgx || p.gy != cgy || p.gz != cgz) {
-			if (cgx != 0xffffffffu) flush();
-			cgx = p.gx; cgy = p.gy; cgz = p.gz;
+		const uint32_t key = gb_cell_key(p, i);
+		if (key != cur) {
+			if (cur != 0xffffffffu) flush();
+			cur = key; cgx = p.gx; cgy = p.gy; cgz = p.gz;
 #pragma unroll
 			for (int k = 0; k < NC; ++k) { a0[k] = 0; a1[k] = 0; }
 		}
@@ -805,7 +854,7 @@ __device__ __forceinline__ void gb_dense_walk(const uint32_t* __restrict__ s_g, 
 			}
 		}
 	}
-	if (cgx != 0xffffffffu) flush();
+	if (cur != 0xffffffffu) flush();
 }
 
 template <int D, bool SCATTER>
@@ -820,10 +869,36 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 	if (SCATTER && threadIdx.x < GB_FX_MAX_SLICES) saved = my_hist[threadIdx.x];
 	const uint32_t chunk_bin0 = (uint32_t)(((uint64_t)blockIdx.x * sp.k_chunks) / gridDim.x) * sp.n_slices;
 	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	uint32_t* s_g = stage;
-	float* s_px = (float*)(stage + GB_STAGE); float* s_py = (float*)(stage + 2 * GB_STAGE); float* s_pz = (float*)(stage + 3 * GB_STAGE);
 	const uint32_t s_first = blockIdx.x * GB_FX_CHUNK;
 	const uint32_t n_live = n - s_first < GB_FX_CHUNK ? n - s_first : GB_FX_CHUNK;
+	if (!SCATTER) {
+		// count: only the cell KEYS go through LDS (one word per sample: the pass fits 11 KiB and every workgroup of the launch is resident at once)
+#pragma unroll
+		for (int u = 0; u < PER; ++u) {
+			const uint32_t i = u * 256 + threadIdx.x;
+			uint32_t key = 0xffffffffu;
+			if (i < n_live) {
+				const uint32_t gbits = __builtin_bit_cast(uint32_t, dxl[s_first + i]);
+				if (gbits & 0x7fff7fffu) {   // adding +-0 never changes a sum
+					const float* c = coords + (size_t)(s_first + i) * coord_stride;
+					float x, y, z = 0.f;
+					if (D == 3) { const f3_t v = load_pos3(c); x = v.x; y = v.y; z = v.z; } else { x = c[0]; y = c[1]; }
+					key = gb_cell_key(level_pos(lv, x, y, z), i);
+				}
+			}
+			stage[i + (i >> 3)] = key;
+		}
+		__syncthreads();
+		gb_dense_count_walk<D>(stage, hist, lv, chunk_bin0, coords + (size_t)s_first * coord_stride, coord_stride);
+		__syncthreads();
+		if (threadIdx.x < GB_FX_MAX_SLICES) {
+			my_hist[threadIdx.x] = hist[threadIdx.x];
+			if (hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
+		}
+		return;
+	}
+	uint32_t* s_g = stage;
+	float* s_px = (float*)(stage + GB_STAGE); float* s_py = (float*)(stage + 2 * GB_STAGE); float* s_pz = (float*)(stage + 3 * GB_STAGE);
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
 		const uint32_t i = u * 256 + threadIdx.x, ip = i + (i >> 3);
@@ -834,15 +909,6 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 	}
 	if (SCATTER && threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = saved;
 	__syncthreads();
-	if (!SCATTER) {
-		gb_dense_walk<D, false>(s_g, s_px, s_py, s_pz, hist, lv, chunk_bin0, n_live, nullptr, nullptr);
-		__syncthreads();
-		if (threadIdx.x < GB_FX_MAX_SLICES) {
-			my_hist[threadIdx.x] = hist[threadIdx.x];
-			if (hist[threadIdx.x]) atomicAdd(&ctr->totals[level][threadIdx.x], hist[threadIdx.x]);
-		}
-		return;
-	}
 	// reserve the ranges (base[] then serves as the running cursor of each bin), walk again with the sums
 	{
 		static_assert(GB_FX_MAX_SLICES == 256, "one thread per bin");
@@ -887,7 +953,10 @@ __device__ __forceinline__ void gb_bin_dense_pairs(uint32_t* __restrict__ hist, 
 			const uint32_t i0 = grid_index_nd<D>(lv, p.gx, p.gy + (m & 1), p.gz + (m >> 1)), i1 = grid_index_nd<D>(lv, p.gx + 1u, p.gy + (m & 1), p.gz + (m >> 1));
 			const uint32_t bin = chunk_bin0 + i0 / GB_FX_SLICE, bin1 = chunk_bin0 + i1 / GB_FX_SLICE;
 			uint32_t c = live ? ((bin << 16) | atomicAdd(&hist[bin], 1u)) : 0xffffffffu;
-			if (live && bin1 != bin) { side[(u * NI + m) * 256 + threadIdx.x] = (bin1 << 16) | atomicAdd(&hist[bin1], 1u); c |= 0x80000000u; }
+			if (live && bin1 != bin) {
+				const uint32_t r1 = atomicAdd(&hist[bin1], 1u);
+				if (SCATTER) { side[(u * NI + m) * 256 + threadIdx.x] = (bin1 << 16) | r1; c |= 0x80000000u; }
+			}
 			code[u][m] = c;
 		}
 	}
@@ -948,7 +1017,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 	const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
 	const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
 	if (!fx && !dense) return;   // float path of the owners: no binning
-	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[4 * GB_STAGE];
+	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[SCATTER ? 4 * GB_STAGE : GB_STAGE];   // count: 11 KiB, every workgroup of the launch resident at once; scatter: 38 KiB
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
 	if (dense && !ORDERED) gb_bin_dense_pairs<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
