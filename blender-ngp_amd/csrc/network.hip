@@ -1004,20 +1004,72 @@ __device__ __forceinline__ void gb_bin_dense_pairs(uint32_t* __restrict__ hist, 
 	}
 }
 
+// The sum of the fused MLP backward's per-workgroup weight-gradient partials rides in the count pass's launch as extra rows of workgroups (it depends on the same
+// kernel and on nothing else; as a launch of its own it was 7 us of the chain).  Same arithmetic as wgrad_reduce_kernel, bit for bit: "wave" q of 16 sums every 16th
+// partial with 8 accumulators, then the 16 sums in order — here 4 waves take 4 q each, their loads in flight together.
+struct WgradJob { const float* partials; uint32_t n_chunks; half_t* grads; uint32_t n_params; };
+__device__ __forceinline__ void wgrad_reduce_rows(const WgradJob& j, uint32_t wg, float* __restrict__ red /* [16][64] */) {
+	if (wg * 64u >= j.n_params) return;
+	const uint32_t p = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	const uint32_t i = wg * 64u + p, n = j.n_params;
+#pragma unroll 1
+	for (uint32_t half = 0; half < 2u; ++half) {   // two q at a time: 16 accumulators + 16 loads in flight keep the count pass at 8 waves per SIMD
+		float acc[2][8];
+#pragma unroll
+		for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+			for (int u = 0; u < 8; ++u) acc[qq][u] = 0.f;
+		const uint32_t q0 = w + 8u * half;   // q0 and q0 + 4
+		if (i < n) {
+			uint32_t t0 = 0;   // chunks [t0, t0 + 128) are full steps for every q
+			for (; t0 + 128u <= j.n_chunks; t0 += 128u) {
+#pragma unroll
+				for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+					for (int u = 0; u < 8; ++u) acc[qq][u] += j.partials[(size_t)(t0 + q0 + 4u * qq + 16u * u) * n + i];
+			}
+#pragma unroll
+			for (int qq = 0; qq < 2; ++qq) {
+				uint32_t c = t0 + q0 + 4u * qq;
+				for (; c + 7u * 16u < j.n_chunks; c += 128u) {
+#pragma unroll
+					for (int u = 0; u < 8; ++u) acc[qq][u] += j.partials[(size_t)(c + 16u * u) * n + i];
+				}
+				for (int u = 0; c < j.n_chunks; c += 16u, ++u) acc[qq][u & 7] += j.partials[(size_t)c * n + i];
+			}
+		}
+#pragma unroll
+		for (int qq = 0; qq < 2; ++qq) red[(q0 + 4u * qq) * 64u + p] = ((acc[qq][0] + acc[qq][1]) + (acc[qq][2] + acc[qq][3])) + ((acc[qq][4] + acc[qq][5]) + (acc[qq][6] + acc[qq][7]));
+	}
+	__syncthreads();
+	if (w == 0 && i < n) {
+		float sum = 0.0f;
+#pragma unroll
+		for (uint32_t k = 0; k < 16u; ++k) sum += red[k * 64u + p];
+		j.grads[i] = (half_t)sum;
+	}
+}
+
 template <int D, bool SCATTER, bool ORDERED = true>   // ORDERED: the batch is in ray order (NeRF training): dense levels merge runs of samples that share a cell; false: pair records
 // (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? 4 : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
+                                                        WgradJob wgrad) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
+	static_assert(GB_STAGE * 4u >= 16u * 64u * 4u, "the weight-gradient rows' 16 x 64 sums fit the count pass's LDS words");
 	static_assert(4 * GB_FX_CHUNK <= 4 * GB_STAGE, "the hashed path's side ranks fit the dense path's staging words");
+	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[SCATTER ? 4 * GB_STAGE : GB_STAGE];   // count: 11 KiB, every workgroup of the launch resident at once; scatter: 38 KiB
 	const uint32_t level = blockIdx.y;
+	if (level >= 16u) {   // rows behind the 16 levels (count pass only, when the caller handed a job over)
+		if (!SCATTER && wgrad.partials) wgrad_reduce_rows(wgrad, (level - 16u) * gridDim.x + blockIdx.x, (float*)stage);
+		return;
+	}
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
 	const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
 	if (!fx && !dense) return;   // float path of the owners: no binning
-	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[SCATTER ? 4 * GB_STAGE : GB_STAGE];   // count: 11 KiB, every workgroup of the launch resident at once; scatter: 38 KiB
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
 	if (dense && !ORDERED) gb_bin_dense_pairs<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
@@ -2030,7 +2082,8 @@ static int fwd_grid(uint32_t n) {
 // hash-grid backward for all 16 levels: binned fixed-point path for the hashed levels, LDS owner-computes path for the dense ones
 template <int D>
 static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad,
-                                bool counters_cleared = false /* by the kernel that produced dx_planes */, bool ordered = true /* the batch is in ray order: NeRF training */) {
+                                bool counters_cleared = false /* by the kernel that produced dx_planes */, bool ordered = true /* the batch is in ray order: NeRF training */,
+                                WgradJob wgrad = WgradJob{nullptr, 0u, nullptr, 0u} /* sum these weight-gradient partials in the count pass's launch */) {
 	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
 	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
@@ -2039,12 +2092,14 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xffffu;
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
+	const dim3 count_grid(bin_grid.x, 16u + (wgrad.partials ? div_up(div_up(wgrad.n_params, 64u), bin_grid.x) : 0u));
+	const WgradJob no_job{nullptr, 0u, nullptr, 0u};
 	uint32_t* wg_hist = (uint32_t*)((char*)sums + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 16u);
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	static const uint32_t owner_threads_env = getenv("NGP_HIP_GB_OWNER_THREADS") ? (uint32_t)atoi(getenv("NGP_HIP_GB_OWNER_THREADS")) : 0u;   // dev: sweep (256 / 512 / 1024)
 	const uint32_t owner_threads = owner_threads_env ? owner_threads_env : 1024u;
@@ -2454,10 +2509,10 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 		NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");
 	}
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
-	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(NGP_MLP_N_PARAMS, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS);
-	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
-	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics)
-	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true)) return -1;
+	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics).  The weight-gradient partials are summed by extra
+	// rows of the hash-grid backward's first launch.
+	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
+	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS})) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
