@@ -559,6 +559,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
 		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
+		.def_readonly("grid_prefetch_hits", &Testbed::m_grid_prefetch_hits)
 		.def("training_prep_nerf", &Testbed::training_prep_nerf, py::call_guard<py::gil_scoped_release>(), py::arg("batch_size") = 0)
 		.def("local_loss_sum", &Testbed::local_loss_sum)
 		.def("gradients_ptr", [](Testbed& t) { return (uintptr_t)t.gradients(); })
@@ -578,6 +579,18 @@ PYBIND11_MODULE(pyngp, m) {
 				d["params"] = (uintptr_t)t.m_params.data();
 				return d;
 			})
+		// test hook (tests/test_step_schedule_gpu.py): the sample positions / cell indices of the NEXT occupancy-grid update as stream B generated them ahead
+		// (regenerate = false; empty when none is pending), or generated now in stream order from the same generator state (regenerate = true; state restored)
+		.def("debug_grid_update_samples", [](Testbed& t, bool regenerate) {
+				std::vector<float> pos; std::vector<uint32_t> idx; uint32_t step = 0;
+				py::dict d;
+				d["pending"] = t.debug_grid_update_samples(regenerate, pos, idx, step);
+				d["step"] = step;
+				py::array_t<float> p((py::ssize_t)pos.size()); py::array_t<uint32_t> i((py::ssize_t)idx.size());
+				if (!pos.empty()) { memcpy(p.mutable_data(), pos.data(), pos.size() * 4); memcpy(i.mutable_data(), idx.data(), idx.size() * 4); }
+				d["positions"] = p; d["indices"] = i;
+				return d;
+			}, py::arg("regenerate") = false)
 		// test hooks (tests/test_baseline_configs_gpu.py): a stage-by-stage record of one product-path training step, and the scene as the kernels see it
 		.def("debug_capture_next_step", &Testbed::debug_capture_next_step)
 		.def("debug_captured", [](Testbed& t) {

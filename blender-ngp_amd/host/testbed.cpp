@@ -270,6 +270,7 @@ Testbed::~Testbed() {
 	if (m_host_words) (void)hipHostFree(m_host_words);
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
+	if (m_grid_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_grid_prefetch_event);
 	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
 	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
 }
@@ -780,7 +781,7 @@ void Testbed::train(uint32_t batch_size) {  // testbed.cu:2527-2587
 	if (m_training_step % n_prep_to_skip == 0) {
 		auto start = std::chrono::steady_clock::now();
 		training_prep_nerf(batch_size);
-		sync();
+		if (!m_async_training_steps) sync();   // (testbed.cu:2553 drains the stream here; nothing on the host reads what the update wrote, and the drain leaves the GPU idle for ~45 us)
 		m_stats.training_prep_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count() / n_prep_to_skip;
 	}
 	const bool get_loss_scalar = m_training_step % 16 == 0;
@@ -813,9 +814,15 @@ void Testbed::training_prep_nerf(uint32_t) {  // testbed_nerf.cu:3388-3401
 }
 
 void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform) {  // testbed_nerf.cu:2761-2842
-	drop_prefetch();     // the bitfield is about to change: samples marched ahead against the old one are void
-	++m_state_version;
 	NerfTraining& tr = m_nerf.training;
+	const PrefetchedGridSamples gp = m_grid_prefetch;   // (taken over before drop_prefetch, which would drain stream B on the host for it)
+	m_grid_prefetch.valid = false;
+	drop_prefetch();     // the bitfield is about to change: samples marched ahead against the old one are void
+	const bool grid_samples_ready = gp.valid && gp.step == m_training_step && gp.version == m_state_version && gp.n_uniform == n_uniform && gp.n_nonuniform == n_nonuniform &&
+	                                gp.ema_step == m_nerf.density_grid_ema_step && gp.rng_state == tr.density_grid_rng.state && gp.rng_inc == tr.density_grid_rng.inc &&
+	                                gp.n_images == tr.n_images_for_training && m_training_step != 0 && tr.n_images_for_training == tr.n_images_for_training_prev;
+	if (gp.valid) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_grid_prefetch_event, 0));   // used or not: stream B must be through with the buffers
+	++m_state_version;
 	const uint32_t n_elements = GRID_CELLS * (m_nerf.max_cascade + 1);
 	if (m_nerf.density_grid.bytes() != (size_t)n_elements * 4) { m_nerf.density_grid.resize((size_t)n_elements * 4); m_nerf.density_grid.memset(0, m_stream); }
 	const uint32_t n_samples = n_uniform + n_nonuniform;
@@ -833,14 +840,8 @@ void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t
 			m_nerf.density_grid.memset(0, m_stream);
 		}
 	}
-	HIP_CHECK_THROW(hipMemsetAsync(m_grid_tmp.data(), 0, (size_t)n_elements * 4, (hipStream_t)m_stream));
-	check(ngp_hip_generate_grid_samples_nonuniform(m_stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
-	                                               m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f), "generate_grid_samples (uniform)");
-	tr.density_grid_rng.advance();
-	check(ngp_hip_generate_grid_samples_nonuniform(m_stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
-	                                               m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
-	                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
-	tr.density_grid_rng.advance();
+	if (grid_samples_ready) { tr.density_grid_rng.advance(); tr.density_grid_rng.advance(); ++m_grid_prefetch_hits; }   // generated ahead on stream B (maybe_prefetch_grid_samples)
+	else launch_grid_samples(m_stream, n_uniform, n_nonuniform);
 	// density pass on the TRAINING weights (use_inference_params = false, testbed_nerf.cu:2833)
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n_samples));
 	NgpNetVariant nv_density;
@@ -1030,10 +1031,67 @@ void Testbed::launch_generate(void* stream, int slot, uint32_t R, uint32_t max_i
 }
 
 void Testbed::drop_prefetch() {
-	if (m_prefetch.valid) {
+	if (m_prefetch.valid || m_grid_prefetch.valid) {
 		HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream_b));
 		m_prefetch.valid = false;
+		m_grid_prefetch.valid = false;
 	}
+}
+
+void Testbed::launch_grid_samples(void* stream, uint32_t n_uniform, uint32_t n_nonuniform) {
+	NerfTraining& tr = m_nerf.training;
+	const uint32_t n_elements = GRID_CELLS * (m_nerf.max_cascade + 1);
+	float* grid = m_nerf.density_grid.as<float>();
+	HIP_CHECK_THROW(hipMemsetAsync(m_grid_tmp.data(), 0, (size_t)n_elements * 4, (hipStream_t)stream));
+	check(ngp_hip_generate_grid_samples_nonuniform(stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+	                                               m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f), "generate_grid_samples (uniform)");
+	tr.density_grid_rng.advance();
+	check(ngp_hip_generate_grid_samples_nonuniform(stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+	                                               m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
+	                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
+	tr.density_grid_rng.advance();
+}
+
+// The step before an occupancy-grid update has no march to run ahead (the bitfield is about to change); stream B generates the update's sample positions instead.
+// What the generators read — the density grid, its generator state, the ema step — does not change until the update itself; anything that could change it bumps
+// m_state_version (or is compared below), and a prefetch that no longer matches is simply regenerated in stream order.
+void Testbed::maybe_prefetch_grid_samples(uint32_t next_step) {
+	NerfTraining& tr = m_nerf.training;
+	if (next_step < 256 || tr.n_images_for_training == 0 || tr.n_images_for_training != tr.n_images_for_training_prev) return;   // full-grid phase / the update re-marks the grid first
+	const uint32_t n_cascades = m_nerf.max_cascade + 1, n_elements = GRID_CELLS * n_cascades;
+	const uint32_t n_uniform = GRID_CELLS / 4 * n_cascades, n_nonuniform = GRID_CELLS / 4 * n_cascades;
+	const uint32_t n_samples = n_uniform + n_nonuniform;
+	if (m_nerf.density_grid.bytes() != (size_t)n_elements * 4 || m_grid_positions.bytes() < (size_t)n_samples * 12 || m_grid_indices.bytes() < (size_t)n_samples * 4 ||
+	    m_grid_tmp.bytes() < (size_t)n_elements * 4) return;   // buffers are sized by the first update
+	PrefetchedGridSamples g;
+	g.valid = true; g.step = next_step; g.n_uniform = n_uniform; g.n_nonuniform = n_nonuniform; g.ema_step = m_nerf.density_grid_ema_step;
+	g.rng_state = tr.density_grid_rng.state; g.rng_inc = tr.density_grid_rng.inc; g.version = m_state_version; g.n_images = tr.n_images_for_training;
+	const Pcg32 keep = tr.density_grid_rng;   // the update advances the generator itself
+	launch_grid_samples(m_stream_b, n_uniform, n_nonuniform);
+	tr.density_grid_rng = keep;
+	if (!m_grid_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_grid_prefetch_event = e; }
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_prefetch_event, (hipStream_t)m_stream_b));
+	m_grid_prefetch = g;
+}
+
+bool Testbed::debug_grid_update_samples(bool regenerate, std::vector<float>& positions, std::vector<uint32_t>& indices, uint32_t& step) {
+	const bool pending = m_grid_prefetch.valid;
+	step = m_grid_prefetch.step;
+	positions.clear(); indices.clear();
+	if (!regenerate && !pending) return false;
+	const uint32_t n_cascades = m_nerf.max_cascade + 1;
+	const uint32_t n_uniform = GRID_CELLS / 4 * n_cascades, n = 2 * n_uniform;
+	HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream_b));
+	if (regenerate) {
+		const Pcg32 keep = m_nerf.training.density_grid_rng;
+		launch_grid_samples(m_stream, n_uniform, n_uniform);
+		m_nerf.training.density_grid_rng = keep;
+	}
+	sync();
+	positions.resize((size_t)n * 3); indices.resize(n);
+	m_grid_positions.copy_to_host(positions.data(), (size_t)n * 12);
+	m_grid_indices.copy_to_host(indices.data(), (size_t)n * 4);
+	return pending;
 }
 
 void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
@@ -1041,7 +1099,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	if (m_capture.valid && m_capture.step == m_training_step) return;   // a captured step keeps its scratch buffers until the test has read them
 	const uint32_t next_step = m_training_step + 1;
 	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
-	if (next_step % n_prep_to_skip == 0) return;  // an occupancy-grid update (new bitfield) precedes that step
+	if (next_step % n_prep_to_skip == 0) { maybe_prefetch_grid_samples(next_step); return; }  // an occupancy-grid update (new bitfield) precedes that step: its sample positions go ahead instead
 	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && m_nerf.training.n_steps_since_cam_update + 1 >= m_nerf.training.n_steps_between_cam_updates) return;  // new camera transforms / a new distortion map precede it (3060-3093)
 	NerfCounters& c = m_nerf.training.counters_rgb;
 	Pcg32 rng = m_rng;   // m_rng was already advanced for the next step (3380)

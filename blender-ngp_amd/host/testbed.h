@@ -404,6 +404,9 @@ public:
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
 	uint64_t m_prefetch_hits = 0;
+	uint32_t m_grid_prefetch_hits = 0;                 // occupancy-grid updates whose sample positions were generated ahead on stream B
+	// test hook: the next update's samples as stream B generated them ahead (false when none is pending), or (regenerate) generated now in stream order from the same generator state
+	bool debug_grid_update_samples(bool regenerate, std::vector<float>& positions, std::vector<uint32_t>& indices, uint32_t& step);
 	uint16_t* gradients() const { return m_grads.as<uint16_t>(); }
 	float local_loss_sum();
 	// ---- test hook: a stage-by-stage record of ONE training step of the product path (tests/test_baseline_configs_gpu.py replays it through the
@@ -550,6 +553,13 @@ private:
 	struct PrefetchedSamples { bool valid = false; uint32_t step = 0, R = 0, max_inference = 0, batch = 0, cdf_mode = 0; uint64_t rng_state = 0, version = 0; int n_images = 0; int slot = 0; };
 	PrefetchedSamples m_prefetch;
 	void* m_prefetch_event = nullptr;
+	// the occupancy-grid update's sample positions, generated ahead on stream B during the step before the update (they depend on the grid and its generator,
+	// not on the parameters that step is still training)
+	struct PrefetchedGridSamples { bool valid = false; uint32_t step = 0, n_uniform = 0, n_nonuniform = 0, ema_step = 0; uint64_t rng_state = 0, rng_inc = 0, version = 0; int n_images = 0; };
+	PrefetchedGridSamples m_grid_prefetch;
+	void* m_grid_prefetch_event = nullptr;
+	void maybe_prefetch_grid_samples(uint32_t next_step);
+	void launch_grid_samples(void* stream, uint32_t n_uniform, uint32_t n_nonuniform);   // memset of the splat buffer + the two generators; advances density_grid_rng twice
 	void* m_counters_event = nullptr;
 	bool m_want_counters_event = false, m_counters_event_recorded = false, m_want_grid_grad_event = false, m_grid_grad_event_recorded = false;
 	void* m_host_words = nullptr;                      // 4 pinned, device-mapped words: {numsteps, numsteps_compacted, loss sum, -}

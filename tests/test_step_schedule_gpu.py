@@ -78,3 +78,46 @@ def test_profiling_brackets_can_be_limited_to_named_groups(cuda):
     with pytest.raises(Exception):
         tb.set_profiling(True, ["no_such_group"])
     tb.set_profiling(False)
+
+
+def test_grid_update_samples_generated_ahead_are_the_in_order_ones(cuda):
+    """From step 256 on the step before an occupancy-grid update has no march to run ahead; stream B generates the update's sample positions instead
+    (Testbed::maybe_prefetch_grid_samples).  They depend on the density grid and its generator state only: what stream B wrote must be bit for bit what the update
+    would generate in stream order, every such update must take them, and a Testbed with the run-ahead switched off generates them itself."""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    tb = scene.build_testbed(ds)
+    tb.async_training_steps = True
+    while tb.training_step < 255:
+        tb.frame()
+    assert tb.grid_prefetch_hits == 0 and not tb.debug_grid_update_samples()["pending"]   # before step 256 the updates sample the whole grid, every step at first
+    tb.frame()                                                                            # step 255: the samples of the update before step 256 go ahead
+    ahead = tb.debug_grid_update_samples()
+    assert ahead["pending"] and ahead["step"] == 256
+    again = tb.debug_grid_update_samples(regenerate=True)
+    assert again["pending"]
+    assert ahead["positions"].size == again["positions"].size > 0
+    np.testing.assert_array_equal(ahead["indices"], again["indices"])
+    np.testing.assert_array_equal(ahead["positions"].view(np.uint32), again["positions"].view(np.uint32))
+    tb.frame()                                                                            # step 256 with its update
+    assert tb.grid_prefetch_hits == 1 and not tb.debug_grid_update_samples()["pending"]
+    while tb.training_step < 305:
+        tb.frame()
+    tb.sync()
+    assert tb.grid_prefetch_hits == 4 and np.isfinite(tb.loss)                           # 256, 272, 288, 304
+    # anything that touches the training inputs voids a pending set: the update then generates its own
+    while tb.training_step < 320:
+        tb.frame()
+    assert tb.debug_grid_update_samples()["pending"]
+    tb.nerf.training.n_images_for_training = 7
+    tb.frame()
+    tb.sync()
+    assert tb.grid_prefetch_hits == 4 and tb.training_step == 321 and np.isfinite(tb.loss)
+
+    off = scene.build_testbed(ds)
+    off.async_training_steps = True
+    off.prefetch_samples = False
+    while off.training_step < 290:
+        off.frame()
+    off.sync()
+    assert off.grid_prefetch_hits == 0 and np.isfinite(off.loss)
