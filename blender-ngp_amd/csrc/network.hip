@@ -1343,11 +1343,10 @@ __device__ __forceinline__ h8 fb_get(const char* __restrict__ stage, int row, in
 // job with a 16-row dY (padded to one 32-row M tile) and a 64-row H: N tile nt, all 8 K-blocks
 __device__ __forceinline__ void fb_job_m1n2(const char* __restrict__ stage, int dy_row0, int h_row0, int nt, int lane, f32x16& acc) {
 	const int r32 = lane & 31, g = lane >> 5;
-	const h8 zero = {};
 #pragma unroll
 	for (int kbs = 0; kbs < 8; ++kbs) {
-		h8 a = fb_get(stage, dy_row0 + (r32 & 15), kbs, g);
-		if (r32 >= 16) a = zero;
+		// rows 16 .. 31 of the padded M tile repeat rows 0 .. 15: their D rows are never read (fb_flush / gm_flush keep o < 16), and a row of D depends on its own row of A only
+		const h8 a = fb_get(stage, dy_row0 + (r32 & 15), kbs, g);
 		const h8 b = fb_get(stage, h_row0 + nt * 32 + r32, kbs, g);
 		acc = NGP_MFMA(a, b, acc);
 	}
@@ -1507,7 +1506,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 		for (int kb = 0; kb < 4; ++kb) t0 = NGP_MFMA(lt[(T_W3T + kb) * 64 + lane], dh[kb], t0);
 		h8 dden;
 #pragma unroll
-		for (int e = 0; e < 8; ++e) dden[e] = (half_t)t0[e];
+		for (int e = 0; e < 8; e += 2) { const h2 v = cvt_pk_f16(t0[e], t0[e + 1]); dden[e] = v[0]; dden[e + 1] = v[1]; }
 		if (g == 0) dden[0] = (half_t)((float)dden[0] + (float)dsigma); // add_density_gradient (nerf_network.h:63-74): fp16 += fp16
 		if (DIR_GRAD) {
 			// rows 16..31 of d_in are dL/d(SH coefficients), fp16 like the rgb network's dL_dinput matrix
