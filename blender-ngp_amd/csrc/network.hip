@@ -98,16 +98,32 @@ __device__ __forceinline__ h8 gather_tile_spec(const half_t* R, int w_off, int n
 		case 4: base = 32; cg = 8; ch = 4; break;
 		default: base = 0; cg = 8; ch = 4; break;
 	}
-	const int si = transposed ? 1 : n_in, sf = transposed ? n_in : 1;            // A[i = out][slot = in feature f] | A[i = in][slot = out feature f]
-	const int lim_i = transposed ? n_in : n_out, lim_f = transposed ? n_out : n_in;
-	const int fg = base + cg * g, k0 = w_off + i * si;
-	const bool i_ok = i < lim_i;
+	const int fg = base + cg * g;
 	h8 r;
+	if (!transposed) {
+		// A[i = out][slot = in feature f]: the four features of a half (e & 3) are neighbours in the row — two 4-byte LDS reads each (base, cg, ch, n_in and the matrix
+		// offsets are multiples of 4, and a raw slot never splits an even pair)
+		const bool i_ok = i < n_out;
+		const int k0 = w_off + i * n_in;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int f0 = fg + ch * h;
+			const bool ok = i_ok && f0 < n_in;
+			const uint32_t* q = (const uint32_t*)(R + raw_slot(ok ? k0 + f0 : 0));
+			const uint32_t lo = ok ? q[0] : 0u, hi = ok ? q[1] : 0u;
+			const h2 a = __builtin_bit_cast(h2, lo), b = __builtin_bit_cast(h2, hi);
+			r[4 * h] = a[0]; r[4 * h + 1] = a[1]; r[4 * h + 2] = b[0]; r[4 * h + 3] = b[1];
+		}
+		return r;
+	}
+	// A[i = in][slot = out feature f]: a column of the row-major matrix, one half per row
+	const bool i_ok = i < n_in;
+	const int k0 = w_off + i;
 #pragma unroll
 	for (int e = 0; e < 8; ++e) {
 		const int f = fg + ch * (e >> 2) + (e & 3);
-		const bool ok = i_ok && f < lim_f;
-		const half_t v = R[raw_slot(ok ? k0 + f * sf : 0)];
+		const bool ok = i_ok && f < n_out;
+		const half_t v = R[raw_slot(ok ? k0 + f * n_in : 0)];
 		r[e] = ok ? v : (half_t)0.0f;
 	}
 	return r;
