@@ -599,9 +599,18 @@ def main():
     legs = [x for x in a.legs.split(",") if x and x != "none"] if world == 1 else []
     if legs:
         import bench_legs
+        import gc
         tb.set_profiling(False)
+        # The legs that build their own Testbed run after this one is gone: HIP maps a process's streams onto 4 hardware queues, and with this Testbed's two streams alive
+        # the next Testbed's training stream and its run-ahead stream land on ONE queue — its march then runs inside the chain instead of beside it (fox 0.72 -> 0.79 ms per
+        # step, tools/fox_ab_probe.py + tools/fox_timeline.sh).  bl_render needs this Testbed's model and goes first.
+        legs.sort(key=lambda x: x != "bl_render")
         for leg in legs:
             t_leg = time.perf_counter()
+            if leg != "bl_render" and tb is not None and not use_dp:
+                tb.sync()
+                tb = None
+                gc.collect()
             try:
                 if leg == "fox":
                     line["fox"] = bench_legs.fox_leg(max(a.steps, 100), BYTES_PER_UNIT, a.min_train_step)
