@@ -636,7 +636,10 @@ __device__ __forceinline__ half_t gb_fixed_to_half(unsigned long long bits) {
 // grid_combine_kernel sums them.  Tens of consecutive ray samples share a cell there, i.e. the same 8 entries: the binning pass sums such
 // runs itself (same exact 2^-24 fixed point) and emits one record {entry, sum0, sum1} per run and corner.  The owners of dense levels then
 // add several times fewer, already merged, records and read them coalesced; the merging is spread over all the binning workgroups.
-constexpr uint32_t GB_D_ITEMS = 16;            // owners per dense level (slices x sample chunks) while the level has fewer slices
+#ifndef NGP_GB_D_ITEMS
+#define NGP_GB_D_ITEMS 16
+#endif
+constexpr uint32_t GB_D_ITEMS = NGP_GB_D_ITEMS;   // owners per dense level (slices x sample chunks) while the level has fewer slices
 __host__ __device__ __forceinline__ GbSplit gb_dense_split(uint32_t level_size) {
 	GbSplit s;
 	s.n_slices = (level_size + GB_FX_SLICE - 1) / GB_FX_SLICE;
