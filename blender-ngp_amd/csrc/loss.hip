@@ -56,21 +56,30 @@ struct LossArgs {
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
+// Wave-wide scans on DPP (row shifts inside the 16-lane rows, then the two row broadcasts): ~6 dependent VALU operations per scan instead of 6 trips through the LDS crossbar
+// (`__shfl_up` = ds_bpermute).  The kernel is one wave per ray and a ray's 64-sample chunks follow each other: the scans' latency is its critical path.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float identity, float v) {   // v of the lane the control names; `identity` where there is none
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
 // inclusive prefix over the wave: OP 0 = product, 1 = sum
 template <int OP>
-__device__ __forceinline__ float wave_inclusive(float v, uint32_t lane) {
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const float nb = __shfl_up(v, off, 64);
-		if (lane >= (uint32_t)off) v = OP == 0 ? v * nb : v + nb;
-	}
+__device__ __forceinline__ float wave_inclusive(float v) {
+	const float id = OP == 0 ? 1.f : 0.f;
+#define NGP_SCAN_STEP(CTRL, MASK) { const float t = dpp_take<CTRL, MASK>(id, v); v = OP == 0 ? v * t : v + t; }
+	NGP_SCAN_STEP(0x111, 0xf)   // row_shr:1
+	NGP_SCAN_STEP(0x112, 0xf)   // row_shr:2
+	NGP_SCAN_STEP(0x114, 0xf)   // row_shr:4
+	NGP_SCAN_STEP(0x118, 0xf)   // row_shr:8
+	NGP_SCAN_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+	NGP_SCAN_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef NGP_SCAN_STEP
 	return v;
 }
+__device__ __forceinline__ float wave_last(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_last(wave_inclusive<1>(v)); }
+// the value of the lane below (wave_shr:1); `identity` in lane 0
+__device__ __forceinline__ float wave_prev(float identity, float v) { return dpp_take<0x138, 0xf>(identity, v); }
 
 // one wave per ray; 4 rays per workgroup: the two block barriers around the compaction scan make every wave wait for the slowest ray of
 // its workgroup, and ~1000 workgroups of 16 rays quantise badly over 512 resident slots (measured: 16 -> 4 rays, step -3.4 %)
@@ -119,36 +128,36 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		max_level = a.max_level_rand_training ? (rng.next_float() * 2.0f) : 1.0f;
 		bg[0] = a.background_color[0]; bg[1] = a.background_color[1]; bg[2] = a.background_color[2];
 		if (a.train_with_random_bg_color) { bg[0] = rng.next_float(); bg[1] = rng.next_float(); bg[2] = rng.next_float(); }
-#pragma unroll
-		for (int c = 0; c < 3; ++c) bg[c] = srgb_to_linear(bg[c]);
+		// The three colour channels go through the same conversions (srgb_to_linear / linear_to_srgb: a powf each, nine of them plus three expf per ray) and are
+		// independent: lane c of the wave works out channel c (every lane computes; lanes 3 .. 63 repeat channel 2) and the three results are read back from lanes
+		// 0 .. 2 — a third of the instructions of walking the channels one after the other, the same arithmetic per channel.
+		const uint32_t ch = lane < 3u ? lane : 2u;
+		auto pick = [&](float v0, float v1, float v2) { return ch == 0u ? v0 : (ch == 1u ? v1 : v2); };
+		float bg_c = srgb_to_linear(pick(bg[0], bg[1], bg[2]));
 		if (a.envmap_data) {   // composit the background behind the envmap (1394-1401)
 			env_dir = normalized(ld3(a.rays_in[i].d));
 			float e[4];
 			read_envmap(a.envmap_data, a.envmap_res[0], a.envmap_res[1], env_dir, e);
-#pragma unroll
-			for (int c = 0; c < 3; ++c) bg[c] = e[c] + bg[c] * (1.0f - e[3]);
+			bg_c = pick(e[0], e[1], e[2]) + bg_c * (1.0f - e[3]);
 		}
-#pragma unroll
-		for (int c = 0; c < 3; ++c) exposure_scale[c] = expf(0.6931471805599453f * a.exposure[img * 3 + c]);
+		const float exposure_c = expf(0.6931471805599453f * a.exposure[img * 3 + ch]);
 		float texsamp[4];
 		read_rgba(xy[0], xy[1], md.res, md.pixels, md.image_data_type, texsamp);
+		const float tex_c = pick(texsamp[0], texsamp[1], texsamp[2]);
+		float target_c;
 		if (a.train_in_linear_colors || a.color_space == NGP_COLOR_LINEAR) {
-#pragma unroll
-			for (int c = 0; c < 3; ++c) rgbtarget[c] = exposure_scale[c] * texsamp[c] + (1.0f - texsamp[3]) * bg[c];
-			if (!a.train_in_linear_colors) {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) { rgbtarget[c] = linear_to_srgb(rgbtarget[c]); bg[c] = linear_to_srgb(bg[c]); }
-			}
+			target_c = exposure_c * tex_c + (1.0f - texsamp[3]) * bg_c;
+			if (!a.train_in_linear_colors) { target_c = linear_to_srgb(target_c); bg_c = linear_to_srgb(bg_c); }
 		} else {
+			bg_c = linear_to_srgb(bg_c);
+			if (texsamp[3] > 0) target_c = linear_to_srgb(exposure_c * tex_c / texsamp[3]) * texsamp[3] + (1.0f - texsamp[3]) * bg_c;
+			else target_c = bg_c;
+		}
 #pragma unroll
-			for (int c = 0; c < 3; ++c) bg[c] = linear_to_srgb(bg[c]);
-			if (texsamp[3] > 0) {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) rgbtarget[c] = linear_to_srgb(exposure_scale[c] * texsamp[c] / texsamp[3]) * texsamp[3] + (1.0f - texsamp[3]) * bg[c];
-			} else {
-#pragma unroll
-				for (int c = 0; c < 3; ++c) rgbtarget[c] = bg[c];
-			}
+		for (int c = 0; c < 3; ++c) {
+			bg[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bg_c), c));
+			rgbtarget[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, target_c), c));
+			exposure_scale[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, exposure_c), c));
 		}
 	}
 
@@ -169,9 +178,8 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 				rgb[1] = network_to_rgb(h2f(lo[1]), a.rgb_activation);
 				rgb[2] = network_to_rgb(h2f(lo[2]), a.rgb_activation);
 			}
-			const float incl = wave_inclusive<0>(1.f - alpha, lane);
-			float excl = __shfl_up(incl, 1, 64);
-			if (lane == 0) excl = 1.f;
+			const float incl = wave_inclusive<0>(1.f - alpha);
+			const float excl = wave_prev(1.f, incl);
 			const float T_before = T_carry * excl;
 			const bool include = valid && !(T_before < EPSILON);
 			const float weight = include ? alpha * T_before : 0.f;
@@ -195,7 +203,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			const uint32_t n_valid = numsteps - c0 < 64 ? numsteps - c0 : 64;
 			compacted += n_inc;
 			if (n_inc < n_valid) done = true;
-			T_carry = T_carry * __shfl(incl, 63, 64);
+			T_carry = T_carry * wave_last(incl);
 		}
 		T_final = T_carry;
 	}
@@ -330,17 +338,16 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			for (int c = 0; c < 3; ++c) rgb[c] = network_to_rgb(lof[c], a.rgb_activation);
 			alpha = 1.f - __expf(-network_to_density(lof[3], a.density_activation) * dt);
 		}
-		const float incl = wave_inclusive<0>(1.f - alpha, lane);
-		float excl = __shfl_up(incl, 1, 64);
-		if (lane == 0) excl = 1.f;
+		const float incl = wave_inclusive<0>(1.f - alpha);
+		const float excl = wave_prev(1.f, incl);
 		const float T_before = T_carry * excl;
 		const float weight = alpha * T_before;
 		const float T = T_before * (1.f - alpha);  // transmittance after this sample (1522)
 		float rgb_ray2[3];
 #pragma unroll
-		for (int c = 0; c < 3; ++c) rgb_ray2[c] = acc_carry[c] + wave_inclusive<1>(weight * rgb[c], lane);
+		for (int c = 0; c < 3; ++c) rgb_ray2[c] = acc_carry[c] + wave_inclusive<1>(weight * rgb[c]);
 		float depth_ray2 = 0.f;
-		if (a.depth_supervision_lambda > 0.0f) depth_ray2 = depth_carry + wave_inclusive<1>(weight * depth, lane);
+		if (a.depth_supervision_lambda > 0.0f) depth_ray2 = depth_carry + wave_inclusive<1>(weight * depth);
 		if (valid) {
 			us4 out;
 #pragma unroll
@@ -355,10 +362,10 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 			out[3] = f2h(ls * dloss_by_dmlp + (lof[3] < 0.0f ? -output_l1_reg_density : 0.0f) + (lof[3] > -10.0f && depth < a.near_distance ? 1e-4f : 0.0f));
 			*(us4*)(dl + (size_t)j * a.dl_stride) = out;
 		}
-		T_carry = T_carry * __shfl(incl, 63, 64);
+		T_carry = T_carry * wave_last(incl);
 #pragma unroll
-		for (int c = 0; c < 3; ++c) acc_carry[c] = __shfl(rgb_ray2[c], 63, 64);
-		depth_carry = __shfl(depth_ray2, 63, 64);
+		for (int c = 0; c < 3; ++c) acc_carry[c] = wave_last(rgb_ray2[c]);
+		depth_carry = wave_last(depth_ray2);
 	}
 }
 
