@@ -213,6 +213,19 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		for (int c = 0; c < 3; ++c) rgb_ray[c] += T_final * bg[c];
 	}
 
+	// The gradient pass's first chunk reads what pass 1 read — at addresses that do not depend on the compaction slot — so its loads are issued HERE, in front of the
+	// workgroup barriers and the slot atomic's round trip (a fifth of a wave's time, tools/loss_phase_probe.py), instead of behind them.
+	NgpCoord cin0 = {};
+	us4 lo0 = {0, 0, 0, 0};
+	uint4 enc0[4] = {};
+	if (lane < compacted) {
+		cin0 = ci[lane];
+		lo0 = *(const us4*)(no + (size_t)lane * a.mlp_stride);
+		if (a.encoded_in) {
+			const uint4* src = (const uint4*)(a.encoded_in + (size_t)(base + lane) * 32);
+			enc0[0] = src[0]; enc0[1] = src[1]; enc0[2] = src[2]; enc0[3] = src[3];
+		}
+	}
 	// ---- compaction slots: one atomic per workgroup (1434)
 	if (lane == 0) s_counts[w] = compacted;
 	__syncthreads();
@@ -320,19 +333,26 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 		const bool valid = j < compacted;
 		float alpha = 0.f, rgb[3] = {0.f, 0.f, 0.f}, lof[4] = {0.f, 0.f, 0.f, 0.f}, dt = 0.f, depth = 0.f;
 		if (valid) {
-			const NgpCoord cin = ci[j];
+			NgpCoord cin = cin0;
+			us4 lo = lo0;
+			uint4 r0 = enc0[0], r1 = enc0[1], r2 = enc0[2], r3 = enc0[3];
+			if (c0 != 0) {   // (wave-uniform) later chunks: in place
+				cin = ci[j];
+				lo = *(const us4*)(no + (size_t)j * a.mlp_stride);
+				if (a.encoded_in) {
+					const uint4* src = (const uint4*)(a.encoded_in + (size_t)(base + j) * 32);
+					r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3];
+				}
+			}
 			co[j] = cin;
 			if (a.encoded_in) {
-				const uint4* src = (const uint4*)(a.encoded_in + (size_t)(base + j) * 32);
 				uint4* dst = (uint4*)(a.encoded_out + (size_t)(compacted_base + j) * 32);
-				const uint4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
 				dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
 			}
 			if (a.max_level_rand_training) a.max_level_compacted[compacted_base + j] = max_level;
 			const v3 pos = unwarp_position(mk(cin.pos[0], cin.pos[1], cin.pos[2]), a.aabb);
 			depth = norm(pos - ray_o);
 			dt = unwarp_dt(cin.dt);
-			const us4 lo = *(const us4*)(no + (size_t)j * a.mlp_stride);
 			lof[0] = h2f(lo[0]); lof[1] = h2f(lo[1]); lof[2] = h2f(lo[2]); lof[3] = h2f(lo[3]);
 #pragma unroll
 			for (int c = 0; c < 3; ++c) rgb[c] = network_to_rgb(lof[c], a.rgb_activation);

@@ -15,9 +15,11 @@ lib = ctypes.CDLL(os.path.join(ROOT, "blender-ngp_amd", "lib_t", "libngp_hip.so"
 buf = np.zeros(8192 * 8, dtype=np.uint64)
 assert lib.ngp_hip_debug_loss_timing(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 t = buf.reshape(-1, 8)
-t = t[t[:, 7] == 1]
+t = t[t[:, 7] != 0]
+tag = t[np.argmax(t[:, 0]), 7]          # the last launch's generator state: rows of older launches (more ray slots then) are left out
+t = t[t[:, 7] == tag]
 t0 = t[:, 0].min()
-f = 100e6   # s_memrealtime / readcyclecounter: 100 MHz constant clock on gfx9
+f = 2.4e9   # s_memtime counts shader-clock cycles (~2.4 GHz under load)
 us = lambda x: x.astype(np.float64) / f * 1e6
 print("rays with stamps:", len(t), " kernel span (first start -> last end): %.1f us" % us(t[:, 4].max() - t0))
 print("start offsets (us): median %.1f  p90 %.1f  max %.1f" % tuple(np.percentile(us(t[:, 0] - t0), [50, 90, 100])))
