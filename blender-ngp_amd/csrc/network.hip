@@ -597,7 +597,7 @@ struct GbFxCounters { uint32_t totals[16][GB_FX_MAX_SLICES], cursors[16][GB_FX_M
 constexpr uint32_t GB_FX_COUNTER_BYTES = 65536;
 
 template <int D>
-__device__ __forceinline__ bool level_is_dense(const NgpGridLevel& lv) {
+__host__ __device__ __forceinline__ bool level_is_dense(const NgpGridLevel& lv) {
 	return (D == 3 ? (uint64_t)lv.resolution * lv.resolution * lv.resolution : (uint64_t)lv.resolution * lv.resolution) <= (uint64_t)lv.size;
 }
 
@@ -1217,15 +1217,35 @@ __device__ __forceinline__ void gb_dense_pairs_owner(unsigned long long* __restr
 // that their workgroups overlap: binned fixed-point owners (hashed, power-of-two tables), dense owners, and the float fallback for hashed
 // levels whose resolution exceeds the slice (the x term then reaches the slice bits).
 // partials (GB_PARTIAL_LEVEL_BYTES per level): dense [bin][GB_FX_SLICE][2] fixed point, fallback [item][GB_SLICE] half2.
+// The owners' launch, compacted: a (level, slice) grid of 16 x 256 workgroups holds ~1500 that own something for base.json (a hashed level has 128 slices, a dense one
+// at most 16 bins ...) and 2600 that read the level descriptor and leave — each of them 16 waves and 64 KiB of LDS for a microsecond, with two such workgroups per CU.
+// When the host knows the level table it launches only the owners: workgroup b belongs to the level whose [start, next start) holds b.
+struct GbOwnerMap { uint32_t start[17]; uint32_t compact; };
+template <int D>
+__host__ __device__ __forceinline__ uint32_t gb_level_owners(const NgpGridLevel& lv) {
+	const bool dense = level_is_dense<D>(lv);
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) return lv.size / GB_FX_SLICE;
+	if (dense && gb_dense_binned(lv.size)) { const GbSplit sp = gb_dense_split(lv.size); return sp.n_slices * sp.k_chunks; }
+	const GbSplit sp = gb_split(lv.size);
+	return sp.n_slices * sp.k_chunks;
+}
+
 template <int D, bool ORDERED = true>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z term); ORDERED: as gb_fx_bin_kernel
 __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                              const h2* __restrict__ dx_planes, void* __restrict__ partials_raw,
-                                                             const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask) {
+                                                             const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask,
+                                                             const GbOwnerMap map) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	constexpr int NC = 1 << D;
 	__shared__ unsigned long long slice64[2 * GB_FX_SLICE];
 	__shared__ uint32_t s_start;
-	const uint32_t level = blockIdx.y, item = blockIdx.x;
+	uint32_t level = blockIdx.y, item = blockIdx.x;
+	if (map.compact) {
+		level = 0;
+#pragma unroll
+		for (int l = 1; l < 16; ++l) level += blockIdx.x >= map.start[l] ? 1u : 0u;
+		item = blockIdx.x - map.start[level];
+	}
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation (tools/gb_level_probe.py); all ones in production
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
@@ -2101,7 +2121,8 @@ static int fwd_grid(uint32_t n) {
 template <int D>
 static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad,
                                 bool counters_cleared = false /* by the kernel that produced dx_planes */, bool ordered = true /* the batch is in ray order: NeRF training */,
-                                WgradJob wgrad = WgradJob{nullptr, 0u, nullptr, 0u} /* sum these weight-gradient partials in the count pass's launch */) {
+                                WgradJob wgrad = WgradJob{nullptr, 0u, nullptr, 0u} /* sum these weight-gradient partials in the count pass's launch */,
+                                const NgpNetDesc* desc_host = nullptr /* the level table on the host: only the owners that own something are launched */) {
 	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
 	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
@@ -2121,8 +2142,16 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	static const uint32_t owner_threads_env = getenv("NGP_HIP_GB_OWNER_THREADS") ? (uint32_t)atoi(getenv("NGP_HIP_GB_OWNER_THREADS")) : 0u;   // dev: sweep (256 / 512 / 1024)
 	const uint32_t owner_threads = owner_threads_env ? owner_threads_env : 1024u;
-	if (ordered) hipLaunchKernelGGL((grid_backward_kernel<D, true>), dim3(GB_FX_MAX_SLICES, 16), dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
-	else hipLaunchKernelGGL((grid_backward_kernel<D, false>), dim3(GB_FX_MAX_SLICES, 16), dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask);
+	GbOwnerMap map{};
+	dim3 owner_grid(GB_FX_MAX_SLICES, 16);
+	if (desc_host) {
+		uint32_t total = 0;
+		for (int l = 0; l < 16; ++l) { map.start[l] = total; total += gb_level_owners<D>(desc_host->levels[l]); }
+		map.start[16] = total; map.compact = 1u;
+		owner_grid = dim3(total ? total : 1u, 1);
+	}
+	if (ordered) hipLaunchKernelGGL((grid_backward_kernel<D, true>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask, map);
+	else hipLaunchKernelGGL((grid_backward_kernel<D, false>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask, map);
 	NGP_LAUNCH_CHECK("grid_backward_kernel");
 	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const void*)gb_partials, grid_grad, (uint32_t)D);
 	NGP_LAUNCH_CHECK("grid_combine_kernel");
@@ -2514,7 +2543,6 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	float* partials = (float*)scratch;
 	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
-	(void)desc_host;
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
 	if (dL_dinput) hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
@@ -2530,7 +2558,7 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics).  The weight-gradient partials are summed by extra
 	// rows of the hash-grid backward's first launch.
 	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
-	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS})) return -1;
+	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS}, desc_host)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
