@@ -59,6 +59,29 @@ def test_inference_matches_oracle(ngp, oracle, cuda, log2, n):
     assert np.abs(ref).max() > 0.05  # the comparison is not vacuous
 
 
+def test_parameters_at_a_4_byte_aligned_address(ngp, cuda):
+    """The kernels stage the network's matrices into LDS with 16-byte loads when the parameter block allows it and half by half otherwise (stage_tiles): a block that
+    starts 4 bytes into an allocation (the hash tables are read as 4-byte pairs: that much alignment is required) gives the same bits, forward and backward."""
+    n = 4096
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=15, n=n, grid_amp=0.5)
+    shifted = np.zeros(params.size + 8, dtype=np.float16)
+    shifted[2:2 + params.size] = params
+    d_S = H.to_dev(shifted, cuda)
+    assert d_P.data_ptr() % 16 == 0 and (d_S.data_ptr() + 4) % 16 == 4
+    res = []
+    dl = H.to_dev((np.random.RandomState(3).randn(n, 4) * 0.01).astype(np.float16), cuda)
+    for ptr in (d_P.data_ptr(), d_S.data_ptr() + 4):
+        out, xs = H.dev_zeros(n * 4 * 2, cuda), H.dev_zeros(n * 32 * 2, cuda)
+        check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), ptr, d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+        sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+        scratch, grads = H.dev_zeros(sb, cuda), H.dev_zeros(H.n_params(desc) * 2, cuda)
+        check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, ptr, d_c.data_ptr(), 7, n, xs.data_ptr(), dl.data_ptr(), 4, grads.data_ptr(), scratch.data_ptr(), sb))
+        res.append((H.to_host(out, np.uint16), H.to_host(xs, np.uint16), H.to_host(grads, np.uint16)))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    assert np.any(res[0][0] != 0) and np.any(res[0][2][:10240] != 0)
+
+
 def test_inference_ragged_and_empty(ngp, oracle, cuda):
     desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=33)
     for n in (0, 1, 31, 33):
