@@ -583,6 +583,7 @@ def main():
         "roofline": roofline, "roofline_longest_single_kernel": line_single, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
+    line["network_pass"] = dict(tb.network_pass_report)   # which organisation of the network pass the Testbed measured faster on this workload and runs (Testbed.network_pass = 'auto')
     if weak is not None:
         line["weak_scaling"] = weak
     if use_dp:   # what the communicator itself says, and what the step's exchanges cost (HIP events on the training stream, survey steps)

@@ -39,7 +39,7 @@ def _group_table(prof, bytes_per_unit):
     return out
 
 
-def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_peak=8000.0):
+def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_peak=8000.0, network_pass=None):
     """config #2: the fox photographs through `load_training_data` (host/nerf_loader.cpp + jpeg_reader.cpp), default base.json, B = 2^18."""
     if not os.path.exists(FOX):
         return {"skipped": "tests/golden/_generated/fox is staged by build() where /root/reference exists; not present in this checkout"}
@@ -51,6 +51,8 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
     tb.reload_network_from_file(os.path.join(CFG, "nerf", "base.json"))
     t_load = time.perf_counter() - t_load
     tr = tb.nerf.training
+    if network_pass:
+        tb.network_pass = network_pass          # dev A / B (bench_legs.py fox N <organisation>); the default run leaves the Testbed's own measured choice
     tb.async_training_steps = True
     tb.shall_train = True
     while tb.training_step < min_train_step:
@@ -73,10 +75,11 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
     tb.sync()
     dt = time.perf_counter() - t0
     kernels = _group_table(survey, bytes_per_unit)
+    network_pass = dict(tb.network_pass_report)
     out = {"workload": "data/nerf/fox of the reference: %d photographs 1080 x 1920 (.jpg), aabb_scale 4 (3 cascades), cone_angle_constant 1/256, OpenCV lens, configs/nerf/base.json, batch 2^18" % len(list(tr.paths)),
            "value": round(samples / dt, 1), "unit": "samples/s", "ms_per_step": round(1000.0 * dt / steps, 4), "steps": steps, "timed_from_training_step": int(timed_from),
            "rays_per_step": round(rays / steps, 1), "pre_compaction_samples_per_step": round(pre / steps, 1), "load_s": round(t_load, 2), "loss": round(float(tb.loss), 5),
-           "n_params": int(tb.n_params()), "kernels": kernels, "kernels_note": "HIP events on the launch streams, %d untimed survey steps" % survey_steps}
+           "n_params": int(tb.n_params()), "network_pass": network_pass, "kernels": kernels, "kernels_note": "HIP events on the launch streams, %d untimed survey steps" % survey_steps}
     if "nerf_backward" in kernels and "algorithmic_GBps" in kernels["nerf_backward"]:
         k = kernels["nerf_backward"]
         out["roofline"] = {"kernel": "nerf_backward", "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": hbm_peak, "unit": "GB/s", "frac": round(k["algorithmic_GBps"] / hbm_peak, 4), "traffic": None}
@@ -214,7 +217,7 @@ def plumbing_leg(steps=200, warmup=100):
         dt = (time.perf_counter() - t0) / steps
         out[mode] = {"workload": what, "ms_per_step": round(dt * 1e3, 4), "samples_per_s": round(B / dt, 1), "steps": steps, "batch": B, "loss": round(float(tb.loss), 6),
                      "mfma_TFLOPs": round(GRIDMLP_FLOP_PER_SAMPLE * B / dt / 1e12, 2), "mfma_frac_of_peak": round(GRIDMLP_FLOP_PER_SAMPLE * B / dt / 1e12 / MFMA_PEAK_F16_TFLOPS, 4),
-                     "flop_per_sample": GRIDMLP_FLOP_PER_SAMPLE, "groups_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in prof.items() if v["launches"]}}
+                     "flop_per_sample": GRIDMLP_FLOP_PER_SAMPLE, "network_pass": dict(tb.network_pass_report), "groups_us": {k: round(v["ms"] / v["launches"] * 1e3, 1) for k, v in prof.items() if v["launches"]}}
         del tb
     return out
 
@@ -279,7 +282,8 @@ if __name__ == "__main__":   # dev: one leg on its own, e.g. under rocprofv3:  p
     which = sys.argv[1] if len(sys.argv) > 1 else "fox"
     if which == "fox":
         import bench
-        print(json.dumps(fox_leg(int(sys.argv[2]) if len(sys.argv) > 2 else 200, bench.BYTES_PER_UNIT)))
+        print(json.dumps(fox_leg(int(sys.argv[2]) if len(sys.argv) > 2 else 200, bench.BYTES_PER_UNIT, min_train_step=int(os.environ.get("FOX_MIN_STEP", "1000")),
+                                 network_pass=sys.argv[3] if len(sys.argv) > 3 else None)))
     elif which == "plumbing":
         print(json.dumps(plumbing_leg()))
     elif which == "variants":

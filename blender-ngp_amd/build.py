@@ -40,22 +40,24 @@ def _run(cmd):
     return r.stdout
 
 
-def build_kernels(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".cuh")] + [os.path.join(ROOT, "include", "ngp_hip.h")]   # (network_generic.cuh / network_netx_mfma.cuh are included by network.hip)
+def build_kernels(force=False, verbose=False, dev=False):
+    """dev=True: the same sources with -DNGP_DEV_KNOBS (csrc/ngp_dev_knobs.h: the sweep / ablation environment knobs of tools/) into lib_dev/ — never what pyngp links or the tests load"""
+    libdir, objdir = (LIBDIR + "_dev", OBJDIR + "_dev") if dev else (LIBDIR, OBJDIR)
+    os.makedirs(libdir, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".cuh") or h.endswith(".h")] + [os.path.join(ROOT, "include", "ngp_hip.h")]   # (network_generic.cuh / network_netx_mfma.cuh are included by network.hip)
     objs, jobs = [], []
     for s in KERNEL_SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer([src] + headers, obj):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + HIP_FLAGS + (["-DNGP_DEV_KNOBS"] if dev else []) + ["-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         for out in ex.map(_run, jobs):
             if verbose and out.strip():
                 print(out)
-    lib = os.path.join(LIBDIR, "libngp_hip.so")
+    lib = os.path.join(libdir, "libngp_hip.so")
     if force or jobs or not os.path.exists(lib):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib, "-ldl"])
     return lib
@@ -82,7 +84,9 @@ def build_host(force=False, verbose=False):
 if __name__ == "__main__":
     force = "--force" in sys.argv
     only_kernels = "--kernels" in sys.argv
-    if only_kernels:
+    if "--dev" in sys.argv:
+        print(build_kernels(force=force, verbose=True, dev=True))
+    elif only_kernels:
         print(build_kernels(force=force, verbose=True))
     else:
         print(build_host(force=force, verbose=True))

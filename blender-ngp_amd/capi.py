@@ -116,7 +116,9 @@ def load_ngp_hip():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _ngp = CLib(os.path.join(HERE, "lib", "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), ("ngp_hip_", "ngp_rccl_"))
+        # NGP_HIP_LIBRARY_DIR: a tool that wants the development build (build.py --dev -> lib_dev/, csrc/ngp_dev_knobs.h) points here; tests and bench.py never set it
+        libdir = os.environ.get("NGP_HIP_LIBRARY_DIR") or os.path.join(HERE, "lib")
+        _ngp = CLib(os.path.join(libdir, "libngp_hip.so"), os.path.join(ROOT, "include", "ngp_hip.h"), ("ngp_hip_", "ngp_rccl_"))
     return _ngp
 
 

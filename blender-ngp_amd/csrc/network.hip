@@ -22,6 +22,7 @@
 // Roofline: the hash pass is HBM/L2-request bound (512 B gathered per sample, 4 B per request); the MLP is ~20 kFLOP per
 // sample, i.e. a few % of the MFMA peak by construction (SURVEY §7 "Tiny-N MFMA").
 #include "ngp_device.cuh"
+#include "ngp_dev_knobs.h"
 
 #pragma clang fp contract(fast)
 
@@ -280,6 +281,28 @@ __device__ __forceinline__ void encode_level(const NgpGridLevel lv, const h2* __
 	o0 = (half_t)r0; o1 = (half_t)r1;
 }
 
+// 2-D (image fitting, 4 corners) or 3-D level; PAIR (3-D only): see encode_level
+template <int D, bool PAIR = false>
+__device__ __forceinline__ void encode_level_nd(const NgpGridLevel lv, const h2* __restrict__ grid, float px, float py, float pz, half_t& o0, half_t& o1) {
+	if (D == 3) { encode_level<PAIR>(lv, grid, px, py, pz, o0, o1); return; }
+	const LevelPos p = level_pos(lv, px, py, 0.0f);
+	h2 v[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const uint32_t idx = grid_index_nd<2>(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), 0u);
+		v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
+	}
+	float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		float w = (c & 1) ? p.fx : (1.0f - p.fx);
+		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
+		r0 += w * (float)v[c][0];
+		r1 += w * (float)v[c][1];
+	}
+	o0 = (half_t)r0; o1 = (half_t)r1;
+}
+
 // (measured: 8-byte pair loads cost the fused kernels 15-20 % — more instructions at 2 waves/SIMD — and gain the stand-alone encode 16 %)
 #define NGP_FUSED_PAIR false
 // lane (j, g) encodes levels 8g..8g+7 of its sample: x0 = levels 8g..8g+3, x1 = levels 8g+4..8g+7  (MAP_ENC)
@@ -441,6 +464,7 @@ constexpr uint32_t ENC_QUEUE_BYTES = 8 * ENC_QUEUE_STRIDE * 4;
 
 __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
 
+template <int D>   // 3: NeRF / SDF positions; 2: image fitting (ngp_hip_gridmlp_forward_ws)
 __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
                                                             uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model, uint32_t grid_off) {
 	__shared__ uint32_t s_first[9];
@@ -451,7 +475,7 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 		uint32_t cost[16], total = 0;
 		for (int l = 0; l < 16; ++l) {
 			const NgpGridLevel lv = desc->levels[l];
-			const uint64_t dense = (uint64_t)lv.resolution * lv.resolution * lv.resolution;
+			const uint64_t dense = (uint64_t)lv.resolution * lv.resolution * (D == 3 ? lv.resolution : 1u);
 			// relative cost of one (level, chunk) item = its L2 requests (the vector L1 -> L2 request path, ~0.5 per clock and CU, is what bounds a gather that hits
 			// the L2): measured per level on ray-coherent samples (one launch per level, tools/fwd_path_trace.sh): dense levels 4.2 us / 2^19 samples each, hashed
 			// levels 9 us at resolution 81 rising to 15 us from resolution ~600 on, where every sample touches its four (y, z) rows' lines alone
@@ -499,7 +523,7 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 				for (int u = 0; u < PER_THREAD; ++u) {
 					const uint32_t smp = chunk * ENC_CHUNK + u * 256 + threadIdx.x;
 					const float* c = coords + (size_t)(smp < n ? smp : 0) * coord_stride;
-					encode_level<true>(lv, grid, c[0], c[1], c[2], a[u], b[u]);
+					encode_level_nd<D, true>(lv, grid, c[0], c[1], D == 3 ? c[2] : 0.0f, a[u], b[u]);
 				}
 #pragma unroll
 				for (int u = 0; u < PER_THREAD; ++u) {
@@ -1751,27 +1775,6 @@ __device__ __forceinline__ h8 gm_gather_tile(const half_t* P, int tile, int lane
 	return gather_tile_spec(P, GM_L0_OFF, 64, 32, 0, tile - G_L0T, MAP_HID, true, lane);
 }
 
-template <int D>
-__device__ __forceinline__ void encode_level_nd(const NgpGridLevel lv, const h2* __restrict__ grid, float px, float py, float pz, half_t& o0, half_t& o1) {
-	if (D == 3) { encode_level<false>(lv, grid, px, py, pz, o0, o1); return; }
-	const LevelPos p = level_pos(lv, px, py, 0.0f);
-	h2 v[4];
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		const uint32_t idx = grid_index_nd<2>(lv, p.gx + (c & 1), p.gy + ((c >> 1) & 1), 0u);
-		v[c] = *(const h2*)((const char*)grid + (size_t)((lv.offset + idx) * 4u));
-	}
-	float r0 = 0.0f, r1 = 0.0f;
-#pragma unroll
-	for (int c = 0; c < 4; ++c) {
-		float w = (c & 1) ? p.fx : (1.0f - p.fx);
-		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
-		r0 += w * (float)v[c][0];
-		r1 += w * (float)v[c][1];
-	}
-	o0 = (half_t)r0; o1 = (half_t)r1;
-}
-
 struct GmActs { h8 h1[4]; h8 h2[4]; };
 template <bool KEEP>
 __device__ __forceinline__ void gm_mlp_forward(const h8* __restrict__ lt, int lane, const h8& x0, const h8& x1, f32x16& oo, GmActs* acts) {
@@ -1799,9 +1802,11 @@ __device__ __forceinline__ void gm_mlp_forward(const h8* __restrict__ lt, int la
 }
 
 // forward: out[s*out_stride + 0..3] = network outputs 0..3 (fp16; 3 used by the image config, 1 by the SDF config); x_saved optional
-template <int D>
-__global__ void __launch_bounds__(256, 2) gridmlp_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ pos, uint32_t pos_stride,
-                                                                 uint32_t n, half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved) {
+// PRE = 1: the MLP alone over the level planes of encode_planes_kernel<D> (ngp_hip_gridmlp_forward_ws), as nerf_forward_kernel<., 1>
+template <int D, int PRE>
+__global__ void __launch_bounds__(256, PRE ? 4 : 2) gridmlp_forward_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ pos, uint32_t pos_stride,
+                                                                 uint32_t n, half_t* __restrict__ out, uint32_t out_stride, half_t* __restrict__ x_saved,
+                                                                 const h2* __restrict__ x_planes, uint32_t n_pad) {
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[GM_FWD_TILES * 64];
 	stage_tiles<GM_GRID_OFF, GM_FWD_TILES>(lds_tiles, params, gm_gather_tile);
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5;
@@ -1812,15 +1817,25 @@ __global__ void __launch_bounds__(256, 2) gridmlp_forward_kernel(const NgpNetDes
 		const uint32_t s = tile * 32 + j;
 		const bool valid = s < n;
 		const float* c = pos + (size_t)(valid ? s : 0) * pos_stride;
-		const float px = c[0], py = c[1], pz = D == 3 ? c[2] : 0.0f;
 		h8 x0, x1;
+		if (PRE == 1) {
+			const h2* xp = x_planes + (size_t)(8 * g) * n_pad + (valid ? s : 0);
 #pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			half_t a, b;
-			encode_level_nd<D>(desc->levels[8 * g + m], grid, px, py, pz, a, b);
-			x0[2 * m] = a; x0[2 * m + 1] = b;
-			encode_level_nd<D>(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
-			x1[2 * m] = a; x1[2 * m + 1] = b;
+			for (int m = 0; m < 4; ++m) {
+				const h2 a = xp[(size_t)m * n_pad], b = xp[(size_t)(4 + m) * n_pad];
+				x0[2 * m] = a[0]; x0[2 * m + 1] = a[1];
+				x1[2 * m] = b[0]; x1[2 * m + 1] = b[1];
+			}
+		} else {
+			const float px = c[0], py = c[1], pz = D == 3 ? c[2] : 0.0f;
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				half_t a, b;
+				encode_level_nd<D>(desc->levels[8 * g + m], grid, px, py, pz, a, b);
+				x0[2 * m] = a; x0[2 * m + 1] = b;
+				encode_level_nd<D>(desc->levels[8 * g + 4 + m], grid, px, py, pz, a, b);
+				x1[2 * m] = a; x1[2 * m + 1] = b;
+			}
 		}
 		if (x_saved && valid) { h8* dst = (h8*)(x_saved + (size_t)s * 32 + 16 * g); dst[0] = x0; dst[1] = x1; }
 		f32x16 oo;
@@ -2112,8 +2127,8 @@ static int fwd_grid(uint32_t n) {
 	uint32_t blocks = div_up(tiles, 4);
 	// grid-stride beyond 4 workgroups per CU: measured over the whole training step (caps 512 ... 2048 in steps of 128-256, repeated), 1024 is
 	// ~3 % ahead of the former 2048 — fewer, longer-lived workgroups leave the concurrently running march and the side stream more room
-	static const uint32_t cap_env = getenv("NGP_HIP_FWD_CAP") ? (uint32_t)atoi(getenv("NGP_HIP_FWD_CAP")) : 0u;   // dev-only
-	const uint32_t cap = cap_env ? cap_env : 256 * 4;
+	// (round 5, profiles/r05_launch_constants.md: the fox photographs do not care — 512 ... 2048 within 1.5 % —, the lego stand-in keeps its optimum at 1024)
+	static const uint32_t cap = ngp_dev_knob_u32("NGP_HIP_FWD_CAP", 256 * 4);
 	return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
@@ -2127,8 +2142,7 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
 	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
 	ulonglong2* sums = (ulonglong2*)((char*)items + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 4u);
-	const char* lm = getenv("NGP_HIP_GB_LEVELS");   // dev-only timing ablation; unset in production
-	const uint32_t level_mask = lm ? (uint32_t)strtoul(lm, nullptr, 0) : 0xffffu;
+	const uint32_t level_mask = ngp_dev_knob_u32("NGP_HIP_GB_LEVELS", 0xffffu);   // dev-only timing ablation, re-read per launch in the development build (tools/gb_level_probe.py flips it); a constant in the product library (ngp_dev_knobs.h)
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	const dim3 count_grid(bin_grid.x, 16u + (wgrad.partials ? div_up(div_up(wgrad.n_params, 64u), bin_grid.x) : 0u));
@@ -2140,8 +2154,7 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
 	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
-	static const uint32_t owner_threads_env = getenv("NGP_HIP_GB_OWNER_THREADS") ? (uint32_t)atoi(getenv("NGP_HIP_GB_OWNER_THREADS")) : 0u;   // dev: sweep (256 / 512 / 1024)
-	const uint32_t owner_threads = owner_threads_env ? owner_threads_env : 1024u;
+	static const uint32_t owner_threads = ngp_dev_knob_u32("NGP_HIP_GB_OWNER_THREADS", 1024u);   // dev: sweep (256 / 512 / 1024)
 	GbOwnerMap map{};
 	dim3 owner_grid(GB_FX_MAX_SLICES, 16);
 	if (desc_host) {
@@ -2344,20 +2357,20 @@ int ngp_hip_nerf_forward(void* stream, const NgpNetDesc* desc_dev, const uint16_
 uint64_t ngp_hip_nerf_encode_workspace_bytes(uint32_t n) { return ENC_QUEUE_BYTES + (uint64_t)16 * next_multiple_u32(n, ENC_CHUNK) * 4u; }
 
 static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, void* workspace, uint64_t workspace_bytes,
-                         const h2** planes_out, uint32_t* n_pad_out, const char* who, const NgpNetDesc* desc_host_for_groups = nullptr, uint32_t grid_off = GRID_OFF) {
+                         const h2** planes_out, uint32_t* n_pad_out, const char* who, const NgpNetDesc* desc_host_for_groups = nullptr, uint32_t grid_off = GRID_OFF, uint32_t n_dims = 3) {
 	if (!workspace || workspace_bytes < ngp_hip_nerf_encode_workspace_bytes(n)) { set_last_error(who, hipErrorInvalidValue); return -1; }
 	const uint32_t n_pad = next_multiple_u32(n, ENC_CHUNK);
 	uint32_t* queues = (uint32_t*)workspace;
 	h2* planes = (h2*)((char*)workspace + ENC_QUEUE_BYTES);
-	static const int enc_mode = getenv("NGP_HIP_ENC_MODE") ? atoi(getenv("NGP_HIP_ENC_MODE")) : 0;   // dev: 1 = one launch per group of levels (NGP_HIP_ENC_GROUP_KIB of table each)
+	static const int enc_mode = (int)ngp_dev_knob_u32("NGP_HIP_ENC_MODE", 0);   // dev: 1 = one launch per group of levels (NGP_HIP_ENC_GROUP_KIB of table each)
 	static NgpNetDesc cached_desc; static const NgpNetDesc* cached_for = nullptr;   // dev experiment: the level sizes decide the grouping
-	if (enc_mode == 1 && !desc_host_for_groups) {
+	if (enc_mode == 1 && n_dims == 3 && !desc_host_for_groups) {
 		if (cached_for != desc_dev) { NGP_HIP_TRY(hipMemcpy(&cached_desc, desc_dev, sizeof(NgpNetDesc), hipMemcpyDeviceToHost)); cached_for = desc_dev; }
 		desc_host_for_groups = &cached_desc;
 	}
-	if (enc_mode == 1 && desc_host_for_groups) {
-		static const uint32_t cap_kib = getenv("NGP_HIP_ENC_GROUP_KIB") ? (uint32_t)atoi(getenv("NGP_HIP_ENC_GROUP_KIB")) : 2560u;
-		static const int pair = getenv("NGP_HIP_ENC_PAIR") ? atoi(getenv("NGP_HIP_ENC_PAIR")) : 1;
+	if (enc_mode == 1 && n_dims == 3 && desc_host_for_groups) {
+		static const uint32_t cap_kib = ngp_dev_knob_u32("NGP_HIP_ENC_GROUP_KIB", 2560u);
+		static const int pair = (int)ngp_dev_knob_u32("NGP_HIP_ENC_PAIR", 1);
 		const uint32_t blocks = div_up(n, 256u) < 2048u ? div_up(n, 256u) : 2048u;
 		uint32_t l0 = 0;
 		while (l0 < 16) {
@@ -2375,8 +2388,9 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	NGP_HIP_TRY(hipMemsetAsync(queues, 0, ENC_QUEUE_BYTES, (hipStream_t)stream));
 	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
 	const uint32_t blocks = items < 2048u ? items : 2048u;  // persistent: 8 workgroups per CU
-	static const uint32_t cost_model = getenv("NGP_HIP_ENC_COST") ? (uint32_t)atoi(getenv("NGP_HIP_ENC_COST")) : 0u;   // dev: A / B of the queue cut
-	hipLaunchKernelGGL(encode_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
+	static const uint32_t cost_model = ngp_dev_knob_u32("NGP_HIP_ENC_COST", 0u);   // dev: A / B of the queue cut
+	if (n_dims == 2) hipLaunchKernelGGL(encode_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
+	else hipLaunchKernelGGL(encode_planes_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
 	NGP_LAUNCH_CHECK("encode_planes_kernel");
 	*planes_out = planes; *n_pad_out = n_pad;
 	return 0;
@@ -2701,10 +2715,26 @@ int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* des
                             uint16_t* out, uint32_t out_stride, uint16_t* x_saved) {
 	if (n == 0) return 0;
 	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_gridmlp_forward: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
-	if (n_dims == 2) hipLaunchKernelGGL(gridmlp_forward_kernel<2>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
-	else if (n_dims == 3) hipLaunchKernelGGL(gridmlp_forward_kernel<3>, dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved);
+	if (n_dims == 2) hipLaunchKernelGGL((gridmlp_forward_kernel<2, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
+	else if (n_dims == 3) hipLaunchKernelGGL((gridmlp_forward_kernel<3, 0>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, (const h2*)nullptr, 0u);
 	else { set_last_error("ngp_hip_gridmlp_forward: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
 	NGP_LAUNCH_CHECK("gridmlp_forward_kernel");
+	return 0;
+}
+
+// the two-kernel organisation of the same pass (the NeRF path's ngp_hip_nerf_forward_ws): XCD-affine encode into level planes, then the MLP kernel at twice the
+// occupancy.  Same bits as ngp_hip_gridmlp_forward (tests/test_gridmlp_gpu.py); faster where the positions have no order (SDF batches), not where they run along
+// a dense level's x axis (stratified image batches) — the host measures and chooses (Testbed::network_pass).
+int ngp_hip_gridmlp_forward_ws(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats, uint32_t n,
+                               uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes) {
+	if (n == 0) return 0;
+	if (out_stride < 4 || (out_stride & 3)) { set_last_error("ngp_hip_gridmlp_forward_ws: out_stride must be a multiple of 4", hipErrorInvalidValue); return -1; }
+	if (n_dims != 2 && n_dims != 3) { set_last_error("ngp_hip_gridmlp_forward_ws: n_dims must be 2 or 3", hipErrorInvalidValue); return -1; }
+	const h2* planes; uint32_t n_pad;
+	if (launch_encode(stream, desc_dev, params, pos, pos_stride_floats, n, workspace, workspace_bytes, &planes, &n_pad, "ngp_hip_gridmlp_forward_ws: workspace too small (ngp_hip_nerf_encode_workspace_bytes)", nullptr, GM_GRID_OFF, n_dims)) return -1;
+	if (n_dims == 2) hipLaunchKernelGGL((gridmlp_forward_kernel<2, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad);
+	else hipLaunchKernelGGL((gridmlp_forward_kernel<3, 1>), dim3(fwd_grid(n)), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, pos, pos_stride_floats, n, (half_t*)out, out_stride, (half_t*)x_saved, planes, n_pad);
+	NGP_LAUNCH_CHECK("gridmlp_forward_kernel<pre>");
 	return 0;
 }
 

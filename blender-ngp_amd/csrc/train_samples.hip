@@ -8,6 +8,7 @@
 // identical to the reference's; only the slot order differs (it is unordered in the reference as well).
 // Index / count arithmetic is exact (-ffp-contract=off): bit-exact against the CPU oracle.
 #include "ngp_device.cuh"
+#include "ngp_dev_knobs.h"
 #include <stdlib.h>
 
 namespace ngp {
@@ -902,10 +903,10 @@ static int generate_training_samples_impl(
 	a.distortion_res[0] = distortion_resolution_host ? distortion_resolution_host[0] : 0;
 	a.distortion_res[1] = distortion_resolution_host ? distortion_resolution_host[1] : 0;
 	a.ray_offset = ray_offset; a.n_rays_global = n_rays_global ? n_rays_global : n_rays;
-	const char* var = getenv("NGP_HIP_GEN_VARIANT");
-	a.dev_variant = var ? atoi(var) : 0;
+	static const int dev_variant = (int)ngp_dev_knob_u32("NGP_HIP_GEN_VARIANT", 0);   // dev: phases of the lane-per-ray pair knocked out (ngp_dev_knobs.h: folds to 0 in the product library)
+	a.dev_variant = dev_variant;
 	// cone_angle == 0 and not NGP_MARCH_LANE_PER_RAY: wave-per-ray march on the closed-form step sequence
-	static const int mode_env = getenv("NGP_HIP_GEN_MODE") ? atoi(getenv("NGP_HIP_GEN_MODE")) : 0;   // dev / A-B: overrides the caller's choice
+	static const int mode_env = (int)ngp_dev_knob_u32("NGP_HIP_GEN_MODE", 0);   // dev / A-B: overrides the caller's choice
 	if (mode_env) march_mode = (uint32_t)mode_env;
 	if (cone_angle_constant == 0.0f && march_mode != NGP_MARCH_LANE_PER_RAY) {
 		// all workgroups resident at once (4 per CU): the kernel has the chip to itself in this mode
@@ -913,7 +914,7 @@ static int generate_training_samples_impl(
 		// workgroups per CU — beside the step's backward pass every further march wave costs that pass more than it gains the march.  The optimum moves with the
 		// balance of the step's two chains (round 2, backward group 245 us: sweep 192 ... 4096 workgroups, step 0.75 / 0.61 at 512 / 0.64 ms; round 3, group 210 us:
 		// 512 -> 0.572-0.595, 640 -> 0.546-0.557, 768 -> 0.555-0.562, 1024 -> 0.552-0.555 ms: the march had become the longer chain)
-		static const uint32_t wg_cap_env = getenv("NGP_HIP_GEN_WGS") ? (uint32_t)atoi(getenv("NGP_HIP_GEN_WGS")) : 0u;   // dev: sweep
+		static const uint32_t wg_cap_env = ngp_dev_knob_u32("NGP_HIP_GEN_WGS", 0u);   // dev: sweep (round 5, profiles/r05_launch_constants.md: fox 384 ... 4096 within 1 %, lego's optimum stays at 640)
 		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 640u : 4096u);
 		hipLaunchKernelGGL(generate_training_samples_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
 		NGP_LAUNCH_CHECK("generate_training_samples_wave_kernel");
@@ -921,7 +922,7 @@ static int generate_training_samples_impl(
 	}
 	if (march_mode != NGP_MARCH_LANE_PER_RAY) {
 		// cone stepping (every aabb_scale > 1 dataset): wave-per-ray on the generated candidate sequence, same throttle as above
-		static const uint32_t wg_cap_env = getenv("NGP_HIP_GEN_WGS") ? (uint32_t)atoi(getenv("NGP_HIP_GEN_WGS")) : 0u;   // dev: sweep
+		static const uint32_t wg_cap_env = ngp_dev_knob_u32("NGP_HIP_GEN_WGS", 0u);   // dev: sweep (round 5, profiles/r05_launch_constants.md: fox 384 ... 4096 within 1 %, lego's optimum stays at 640)
 		const uint32_t n_groups = div_up(n_rays, WM_RAYS_PER_WG), wg_cap = wg_cap_env ? wg_cap_env : (march_mode == NGP_MARCH_WAVE_PER_RAY_SHARED ? 640u : 4096u);
 		hipLaunchKernelGGL(generate_training_samples_cone_wave_kernel, dim3(n_groups < wg_cap ? n_groups : wg_cap), dim3(256), 0, (hipStream_t)stream, a);
 		NGP_LAUNCH_CHECK("generate_training_samples_cone_wave_kernel");

@@ -70,7 +70,12 @@ void decode_hdr_rgba8(const uint8_t* data, size_t n_bytes, int& w, int& h, std::
 	if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24) || (int64_t)ww * hh > ((int64_t)1 << 28)) throw std::runtime_error{"HDR: bad image size"};
 	w = (int)ww; h = (int)hh;
 	// before the allocation: a run-length scanline costs at least 4 marker bytes + 2 bytes per 127-pixel run and channel, a flat one 4 bytes per pixel
-	if ((uint64_t)h * (4u + 8u * (((uint64_t)w + 126u) / 127u)) > (uint64_t)n_bytes + 64u) throw std::runtime_error{"HDR: the header promises more pixels than the file could encode"};
+	// (images narrower than 8 or wider than 32767 pixels are always flat — 4 w bytes per scanline, which for w = 1, 2 is LESS than a run-length line's 12)
+	{
+		const uint64_t flat_line = 4u * (uint64_t)w, rle_line = 4u + 8u * (((uint64_t)w + 126u) / 127u);
+		const uint64_t per_line = (w < 8 || w >= 32768) ? flat_line : std::min(flat_line, rle_line);
+		if ((uint64_t)h * per_line > (uint64_t)n_bytes + 64u) throw std::runtime_error{"HDR: the header promises more pixels than the file could encode"};
+	}
 	pixels.assign((size_t)w * h * 4, 0);
 	bool flat = w < 8 || w >= 32768;
 	std::vector<uint8_t> scan;

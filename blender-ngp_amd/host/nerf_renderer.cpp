@@ -192,7 +192,7 @@ void NeuralRadianceField::load_snapshot(void* stream) {
 uint64_t NerfRenderer::render(RenderBuffer& rb, const RenderRequest& request, void* stream) {
 	if (request.nerfs.empty()) return 0;
 	hipStream_t st = (hipStream_t)stream;
-	static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: stage markers on stderr
+	const bool trace = this->trace;   // stage markers on stderr (pyngp: render_trace)
 	if (trace) fprintf(stderr, "multi render: %zu nerfs\n", request.nerfs.size());
 
 	// RenderData::update_nerfs (render_data.cuh:45-82): drop fields no descriptor refers to, add new ones, one proxy per descriptor

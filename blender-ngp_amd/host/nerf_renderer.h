@@ -155,6 +155,7 @@ public:
 	uint64_t render(RenderBuffer& rb, const RenderRequest& request, void* stream);
 	size_t n_loaded_fields() const { return m_fields.size(); }
 	~NerfRenderer();
+	bool trace = false;   // stage markers / pass structure on stderr
 	// the pass loop: fused (default) = one ngp_hip_multi_advance launch (march + cull + compact + lists) and one host-mailbox poll per pass, the stock tracer's
 	// sample budget per pass; unfused = the launch sequence of nerf_renderer.cu:664-791 with its two blocking read-backs (kept as the checker: same pixels)
 	bool fused_passes = true;

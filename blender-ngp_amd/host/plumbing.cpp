@@ -22,6 +22,7 @@ static constexpr uint32_t BATCH_SIZE_GRANULARITY = 128;     // tcnn::batch_size_
 static inline uint32_t next_multiple(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 void Testbed::reset_network_gridmlp() {  // testbed.cu:2249-2470, Image / Sdf branch (2397-2445)
+	tuner_reset();
 	m_rng = Pcg32(m_seed);
 	m_windowless_render_surface.reset_accumulation();
 	const Json& config = m_network_config;
@@ -73,7 +74,14 @@ void Testbed::gridmlp_training_step(const float* pos, uint32_t n_dims, const flo
 	m_bwd_scratch.enlarge(ngp_hip_gridmlp_backward_scratch_bytes(n));
 	const NgpNetDesc* desc = m_desc_gpu.as<NgpNetDesc>();
 	profile_begin(PK_FORWARD);
-	check(ngp_hip_gridmlp_forward(m_stream, n_dims, desc, m_params.as<uint16_t>(), pos, n_dims, n, m_gm_out.as<uint16_t>(), GM_OUT_STRIDE, m_x_saved.as<uint16_t>()), "gridmlp_forward");
+	// fused or encode + MLP kernel: measured on this workload (testbed.h ENetworkPass) — random SDF points want the two-kernel pass, stratified image batches the fused one
+	if (tuner_pick(m_stream)) {
+		m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(n));
+		check(ngp_hip_gridmlp_forward_ws(m_stream, n_dims, desc, m_params.as<uint16_t>(), pos, n_dims, n, m_gm_out.as<uint16_t>(), GM_OUT_STRIDE, m_x_saved.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes()), "gridmlp_forward (two kernels)");
+	} else {
+		check(ngp_hip_gridmlp_forward(m_stream, n_dims, desc, m_params.as<uint16_t>(), pos, n_dims, n, m_gm_out.as<uint16_t>(), GM_OUT_STRIDE, m_x_saved.as<uint16_t>()), "gridmlp_forward");
+	}
+	tuner_done(m_stream);
 	profile_end(PK_FORWARD, n);
 	check(ngp_hip_loss_and_gradient(m_stream, (int)m_nerf.training.loss_type, n, dims, LOSS_SCALE, m_gm_out.as<uint16_t>(), GM_OUT_STRIDE, targets, m_gm_values.as<float>(), m_dloss.as<uint16_t>(),
 	                                GM_OUT_STRIDE), "loss_and_gradient");

@@ -417,7 +417,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("render", [](Testbed& t, int width, int height, int spp, bool linear, float start_t, float end_t, float, float) {
 				// python_api.cu:131-165: start_t >= 0 animates along the loaded camera path (set_camera_from_time, smoothing, per-spp shutter interpolation).  Camera
 				// paths are not part of this build (load_camera_path throws): a still frame returned for a path request would be silently wrong
-				if (start_t >= 0.f || end_t >= 0.f) throw std::runtime_error{"render(start_t >= 0): camera-path animation is not part of this build; set the camera per frame with set_nerf_camera_matrix and call render() with start_t = end_t = -1"};
+				if (start_t >= 0.f /* the reference's path_animation_enabled (python_api.cu:139): end_t alone is ignored there too */) throw std::runtime_error{"render(start_t >= 0): camera-path animation is not part of this build; set the camera per frame with set_nerf_camera_matrix and call render() with start_t = end_t = -1"};
 				std::vector<float> px;
 				{ py::gil_scoped_release rel; px = t.render_to_cpu(width, height, spp, linear); }
 				py::array_t<float> result({height, width, 4});
@@ -518,6 +518,7 @@ PYBIND11_MODULE(pyngp, m) {
 			"render() traces only the rows of shard `rank` of `world_size` (rows [rank * ceil(H / world), ...)); the rest of the returned frame is background. With init_data_parallel the split and the gather happen inside render().")
 		.def("render_shard_rows", [](Testbed& t, int height) { int a, b; t.render_shard_rows(height, a, b); return py::make_tuple(a, b); }, py::arg("height"))
 		.def_property("dp_sharded_optimizer", [](Testbed& t) { return t.m_dp_sharded_optimizer; }, &Testbed::set_dp_sharded_optimizer, "data-parallel step: reduce-scatter (fp32 sums) -> Adam on this rank's 1 / world of the parameters -> all-gather of the fp16 weights (default); False: fp16 all-reduce of the gradients, the whole optimizer step on every rank.  Settable only while no communicator is live (before init_data_parallel)")
+		.def_readwrite("dp_state_stale", &Testbed::m_dp_state_stale, "sharded data-parallel steps ran since the last dp_gather_optimizer_state(): the fp32 master weights / Adam moments are current only inside this rank's shard.  optimizer steps outside a communicator and save_snapshot(include_optimizer_state=True) refuse such a state; dp_gather_optimizer_state() (with the communicator still live), reset_network() and load_snapshot() clear it.  Writable as a test hook (one-GPU tests cannot run a world of two)")
 		.def_readwrite("render_sharded", &Testbed::m_render_sharded, "opt-in: under init_data_parallel render() / render_to_cpu() become COLLECTIVES (rows per rank, RCCL all-gather, every rank returns the whole frame) — set it on every rank and call render() on every rank with the same arguments.  Default False: render() is local and traces the whole frame, so one rank alone can render")
 		.def_property_readonly("dp_comm_size", [](Testbed& t) { return t.m_dp_comm ? ngp_rccl_comm_size(t.m_dp_comm) : 0; }, "ranks of the RCCL communicator of init_data_parallel (ncclCommCount), 0 without one")
 		.def_readonly("world_size", &Testbed::m_world_size)
@@ -672,6 +673,25 @@ PYBIND11_MODULE(pyngp, m) {
 				t.m_profile_enabled = on; t.m_profile_mask = mask; t.m_profile_every = every ? every : 1u;   // every: bracket the launches of every n-th training step only
 			}, py::arg("on"), py::arg("only") = std::vector<std::string>{}, py::arg("every") = 1u)
 		.def("reset_profile", &Testbed::reset_profile)
+		.def_property("network_pass", [](Testbed& t) { return std::string(t.m_network_pass == Testbed::ENetworkPass::Auto ? "auto" : t.m_network_pass == Testbed::ENetworkPass::Fused ? "fused" : "two_kernel"); },
+			[](Testbed& t, const std::string& v) {
+				if (v == "auto") t.m_network_pass = Testbed::ENetworkPass::Auto; else if (v == "fused") t.m_network_pass = Testbed::ENetworkPass::Fused; else if (v == "two_kernel") t.m_network_pass = Testbed::ENetworkPass::TwoKernel;
+				else throw std::runtime_error{"network_pass: 'auto', 'fused' or 'two_kernel'"};
+			}, "organisation of the network pass over a training batch: 'fused' (hash gathers inside the MLP kernel), 'two_kernel' (XCD-affine encode into level planes + MLP kernel), or 'auto' (default): both are timed on "
+			   "this workload for a few steps (HIP events) and the faster one runs; same bits either way.  The reference has one path (src/testbed_nerf.cu:3256, nerf_network.h:103-137)")
+		.def_property_readonly("network_pass_report", [](Testbed& t) {
+				const Testbed::NetworkPassTuner& u = t.m_pass_tuner;
+				py::dict d;
+				const bool forced = t.m_network_pass != Testbed::ENetworkPass::Auto;
+				const Testbed::ENetworkPass running = forced ? t.m_network_pass : u.chosen;
+				d["policy"] = t.m_network_pass == Testbed::ENetworkPass::Auto ? "auto" : "forced";
+				d["running"] = running == Testbed::ENetworkPass::TwoKernel ? "two_kernel" : "fused";
+				d["calibrations"] = u.n_calibrations; d["last_calibration_step"] = u.last_calibration_step;
+				d["fused_us"] = u.last_us[0]; d["two_kernel_us"] = u.last_us[1];
+				return d;
+			}, "what network_pass = 'auto' measured last (medians of the bracketed launches, microseconds) and what is running")
+		.def_readwrite("trace_sync", &Testbed::m_trace_sync, "debugging aid: drain both streams behind every launch group and name it on stderr")
+		.def_readwrite("render_trace", &Testbed::m_render_trace, "debugging aid: the tracers' pass structure (alive rays, steps per pass) on stderr")
 		.def_readwrite("async_training_steps", &Testbed::m_async_training_steps, "frame() does not drain the stream after the training step (the reference does, testbed.cu:2570): the next step's launches queue behind this one's optimizer instead of after an idle gap.  Everything the API reads afterwards is ordered by the same stream; call sync() before touching device buffers from another stream.")
 		.def("profile", [](Testbed& t) {
 				t.sync();

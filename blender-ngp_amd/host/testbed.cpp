@@ -277,8 +277,7 @@ Testbed::~Testbed() {
 
 void Testbed::check(int rc, const char* what) {
 	if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + ngp_hip_last_error());
-	static const bool trace_sync = getenv("NGP_HIP_TRACE_SYNC") != nullptr;   // dev: drain both streams behind every launch group and say which one it was (finds a kernel that never returns)
-	if (trace_sync) {
+	if (m_trace_sync) {   // debugging aid (pyngp: trace_sync): drain both streams behind every launch group and say which one it was (finds a kernel that never returns)
 		fprintf(stderr, "[ngp] step %u: %s ...", m_training_step, what); fflush(stderr);
 		if (m_stream_b) (void)hipStreamSynchronize((hipStream_t)m_stream_b);
 		if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream);
@@ -332,6 +331,68 @@ void Testbed::profile_collect(bool only_finished) {
 void Testbed::reset_profile() {
 	profile_collect();
 	for (auto& a : m_prof) a = ProfAccum{};
+}
+
+// ---- network-pass organisation: measured per workload (testbed.h ENetworkPass) ------------------------------------
+void Testbed::tuner_reset() {
+	NetworkPassTuner& t = m_pass_tuner;
+	for (auto& p : t.pending) { if (p.e0) m_prof_event_pool.push_back(p.e0); if (p.e1) m_prof_event_pool.push_back(p.e1); }
+	t = NetworkPassTuner{};
+	// NeRF: the first 16 steps update the whole occupancy grid every step and the ray batch is still growing towards the target; Image / Sdf have no such phase
+	t.next_calibration_step = m_testbed_mode == ETestbedMode::Nerf ? 48u : 8u;
+}
+void Testbed::tuner_collect(bool wait) {
+	NetworkPassTuner& t = m_pass_tuner;
+	size_t kept = 0;
+	for (auto& p : t.pending) {
+		if (!wait && (!p.e1 || hipEventQuery((hipEvent_t)p.e1) != hipSuccess)) { t.pending[kept++] = p; continue; }
+		float ms = 0.f;
+		if (p.e1 && hipEventSynchronize((hipEvent_t)p.e1) == hipSuccess && hipEventElapsedTime(&ms, (hipEvent_t)p.e0, (hipEvent_t)p.e1) == hipSuccess && t.count[p.org] < NetworkPassTuner::N_SAMPLES)
+			t.us[p.org][t.count[p.org]++] = ms * 1000.f;
+		if (p.e0) m_prof_event_pool.push_back(p.e0);
+		if (p.e1) m_prof_event_pool.push_back(p.e1);
+	}
+	t.pending.resize(kept);
+	if (t.remaining == 0 && t.pending.empty() && t.count[0] && t.count[1]) {   // a calibration is complete: decide
+		float med[2];
+		for (int o = 0; o < 2; ++o) { std::sort(t.us[o], t.us[o] + t.count[o]); med[o] = t.us[o][t.count[o] / 2]; }
+		const ENetworkPass other = t.chosen == ENetworkPass::Fused ? ENetworkPass::TwoKernel : ENetworkPass::Fused;
+		const float cur = med[t.chosen == ENetworkPass::TwoKernel], alt = med[other == ENetworkPass::TwoKernel];
+		if (alt < 0.97f * cur) t.chosen = other;
+		t.last_us[0] = med[0]; t.last_us[1] = med[1];
+		t.count[0] = t.count[1] = 0;
+		++t.n_calibrations;
+	}
+}
+bool Testbed::tuner_pick(void* stream) {
+	NetworkPassTuner& t = m_pass_tuner;
+	t.measuring = -1;
+	if (m_network_pass != ENetworkPass::Auto) return m_network_pass == ENetworkPass::TwoKernel;
+	if (!t.pending.empty() || t.count[0] || t.count[1]) tuner_collect(false);
+	if (t.remaining == 0 && t.pending.empty() && m_training_step >= t.next_calibration_step) {
+		t.remaining = 2 * NetworkPassTuner::N_SAMPLES;
+		t.count[0] = t.count[1] = 0;
+		t.last_calibration_step = m_training_step;
+		// 48 -> 320 (the update cadence has reached every 16th step, the batch its size) -> 1056 -> every 4096 steps
+		t.next_calibration_step = m_training_step < 300u ? 320u : m_training_step < 1000u ? 1056u : m_training_step + 4096u;
+	}
+	if (t.remaining > 0) {
+		t.measuring = t.remaining & 1;
+		--t.remaining;
+		NetworkPassTuner::Pending p{prof_event(), nullptr, t.measuring};
+		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e0, (hipStream_t)stream));
+		t.pending.push_back(p);
+		return t.measuring == 1;
+	}
+	return t.chosen == ENetworkPass::TwoKernel;
+}
+void Testbed::tuner_done(void* stream) {
+	NetworkPassTuner& t = m_pass_tuner;
+	if (t.measuring < 0 || t.pending.empty()) return;
+	NetworkPassTuner::Pending& p = t.pending.back();
+	p.e1 = prof_event();
+	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)p.e1, (hipStream_t)stream));
+	t.measuring = -1;
 }
 
 void Testbed::reset_camera() {  // testbed.cu:283-299
@@ -714,6 +775,8 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 
 	if (config.contains("optimizer")) parse_optimizer_config(config["optimizer"]);
 	m_optimizer_step = 0;
+	tuner_reset();
+	m_dp_state_stale = false;   // the whole fp32 state is rebuilt below (every rank of a live communicator resets alike: same seed, same bits)
 
 	// (+ DP_PARAM_SLACK elements behind the weights and the gradients: the sharded optimizer step all-gathers world equal shards in place, the last one padded)
 	m_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize((m_n_params + DP_PARAM_SLACK) * 2);
@@ -935,7 +998,11 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 // The sharded optimizer step leaves the fp32 state (master weights, Adam moments) of other ranks' shards stale.  Whoever needs the whole state — a snapshot with
 // optimizer state, training on after shutdown_data_parallel — gathers it first.  Collective: every rank of the communicator calls it.
 void Testbed::dp_gather_optimizer_state() {
-	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) { m_dp_state_stale = false; return; }
+	// a stale state whose communicator is gone cannot be made whole any more: saying "done" here would let training / save_snapshot run on fp32 state that is old outside
+	// this rank's shard.  What rebuilds the whole state clears the flag instead: reset_network, load_snapshot.
+	if (m_dp_state_stale && !m_dp_comm)
+		throw std::runtime_error{"dp_gather_optimizer_state: the fp32 optimizer state is stale outside this rank's shard and the data-parallel communicator is gone — gather on ALL ranks BEFORE shutdown_data_parallel(); now only reset_network() / load_snapshot() rebuild the state"};
+	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) { if (m_world_size < 2) m_dp_state_stale = false; return; }
 	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_master.as<float>(), shard), "ngp_rccl_allgather_f32 (master weights)");
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_first_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (first moments)");
@@ -1099,7 +1166,15 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	if (m_capture.valid && m_capture.step == m_training_step) return;   // a captured step keeps its scratch buffers until the test has read them
 	const uint32_t next_step = m_training_step + 1;
 	const uint32_t n_prep_to_skip = std::min(std::max(next_step / 16u, 1u), 16u);
-	if (next_step % n_prep_to_skip == 0) { maybe_prefetch_grid_samples(next_step); return; }  // an occupancy-grid update (new bitfield) precedes that step: its sample positions go ahead instead
+	// stream B may only overwrite what stream A's queued work still reads once the host has seen the counters posted behind it — unless the step was begun without
+	// waiting for them (a data-parallel host that reduces them in stream order): then stream B waits for the counters event itself.  Both prefetches need it: the
+	// march overwrites the rays / coords the loss kernel read, the grid-sample generators overwrite the splat buffer, positions and indices of the previous update
+	auto order_stream_b_behind_counters = [&]() {
+		if (m_counters_host_seen) return;
+		if (!m_counters_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream)); m_counters_event_recorded = true; }
+		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_counters_event, 0));
+	};
+	if (next_step % n_prep_to_skip == 0) { order_stream_b_behind_counters(); maybe_prefetch_grid_samples(next_step); return; }  // an occupancy-grid update (new bitfield) precedes that step: its sample positions go ahead instead
 	if ((m_nerf.training.optimize_extrinsics || m_nerf.training.optimize_distortion) && m_nerf.training.n_steps_since_cam_update + 1 >= m_nerf.training.n_steps_between_cam_updates) return;  // new camera transforms / a new distortion map precede it (3060-3093)
 	NerfCounters& c = m_nerf.training.counters_rgb;
 	Pcg32 rng = m_rng;   // m_rng was already advanced for the next step (3380)
@@ -1107,13 +1182,7 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	p.valid = true; p.step = next_step; p.R = c.rays_per_batch; p.max_inference = next_max_inference(target_batch_size); p.rng_state = rng.state;
 	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
 	p.cdf_mode = m_nerf.training.cdf_mode();
-	// stream B may only overwrite the rays / coords once stream A's loss kernel consumed them: the host has seen the counters the kernel behind
-	// it posted — unless the step was begun without waiting for them (a data-parallel host that reduces them in stream order), in which case
-	// stream B waits for the counters event itself
-	if (!m_counters_host_seen) {
-		if (!m_counters_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream)); m_counters_event_recorded = true; }
-		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_counters_event, 0));
-	}
+	order_stream_b_behind_counters();
 	// (holding the march back until the step's MLP backward kernel is through was measured: no gain, 0.587 -> 0.593 ms)
 	// Data parallel over more than one rank: the gradient exchange (reduce-scatter, all-gather: RCCL kernels on a few workgroups, bound by the xGMI links) follows the
 	// backward pass on stream A and leaves the chip idle for as long as the march takes on its own (~140 us vs 61-370 us of wire time at 8-2 ranks).  The
@@ -1210,7 +1279,6 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_x_all.enlarge((size_t)max_inference * 32 * 2);
 	profile_begin(PK_INFERENCE);
 	{
-		static const bool fwd_ws = getenv("NGP_HIP_FWD_WS") != nullptr;   // dev: the two-kernel pass (encode into level planes, then the MLP kernel) instead of the fused one
 		NgpNetVariant nv;
 		const NgpNetVariant* variant = nullptr;
 		if (!net_is_base_family()) {
@@ -1224,8 +1292,12 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 			}
 			variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot_all.as<uint32_t>() : nullptr);
 		}
-		if (fwd_ws && !variant) check(ngp_hip_nerf_forward_ws(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes(), nullptr), "nerf_inference (ws)");
+		// which organisation: measured on this workload (testbed.h ENetworkPass).  The network variants' training pass has the fused organisation only
+		// (ngp_hip_nerf_forward_ws hands them to it): nothing to choose there
+		const bool two_kernel = !variant && tuner_pick(m_stream);
+		if (two_kernel) check(ngp_hip_nerf_forward_ws(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes(), nullptr), "nerf_inference (two kernels)");
 		else check(ngp_hip_nerf_forward(m_stream, desc, m_params.as<uint16_t>(), m_coords.as<float>(), 7, max_inference, m_mlp_out.as<uint16_t>(), OUT_STRIDE, m_x_all.as<uint16_t>(), variant), "nerf_inference");
+		tuner_done(m_stream);
 	}
 	profile_end(PK_INFERENCE, max_inference);
 	if (tr.optimize_exposure) {
@@ -1857,7 +1929,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		uint32_t* alive_counter = m_tr_counters.as<uint32_t>() + 2;
 		volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
 		hipStream_t st = (hipStream_t)m_stream;
-		static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;
+		const bool trace = m_render_trace;   // pyngp: render_trace — the pass structure on stderr
 		// The alive count of a pass comes back through a mailbox in host memory that the pass's last workgroup writes (NgpCompactOut::host_mailbox) and this thread polls:
 		// no copy command, no stream synchronisation (an interrupt and a wake-up) between two passes.
 		uint32_t* blocks_done = m_tr_counters.as<uint32_t>() + 10;
@@ -1962,7 +2034,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 	for (uint32_t p = 0; p < K; ++p) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_render_streams[p], (hipEvent_t)m_render_event, 0));
 	uint32_t* alive_counters = m_tr_counters.as<uint32_t>() + 2;
 	volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
-	static const bool trace = getenv("NGP_HIP_RENDER_TRACE") != nullptr;  // dev: pass structure on stderr
+	const bool trace = m_render_trace;
 	auto buf = [&](DeviceBuffer& b, size_t elem_bytes, uint32_t start) { return (char*)b.data() + (size_t)start * elem_bytes; };
 	bool any = true;
 	while (any) {
@@ -2001,8 +2073,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			const uint32_t n_elements = next_multiple(pt.n_alive * n_steps, BATCH_SIZE_GRANULARITY);
 			// inference on the EMA weights (use_inference_params defaults to true at testbed_nerf.cu:2223)
 			m_tr_enc_ws[p].enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(n_elements, pt.count)));
-			static const bool fused_render = getenv("NGP_HIP_RENDER_FUSED") != nullptr;   // dev: the fused kernel instead of encode + MLP (re-measurement knob)
-			if (fused_render) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, render_variant), "nerf_inference (render, fused)");
+			if (m_nerf.render_fused_network) check(ngp_hip_nerf_inference(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, render_variant), "nerf_inference (render, fused)");
 			else check(ngp_hip_nerf_inference_ws(st, desc, m_inference_params.as<uint16_t>(), (const float*)net_in, 7, n_elements, net_out, OUT_STRIDE, m_tr_enc_ws[p].data(), m_tr_enc_ws[p].bytes(), render_variant), "nerf_inference (render)");
 			m_render_samples_evaluated += n_elements;
 			if (render_mode == (int)ERenderMode::Normals) {   // 2225-2226: network.input_gradient(stream, 3, positions, positions) — on the inference weights like the pass above
@@ -2030,6 +2101,7 @@ void Testbed::bl_render_frame(RenderBuffer& rb, const RenderRequest& request) { 
 	if (!m_renderer) m_renderer.reset(new NerfRenderer());
 	rb.frame_buffer.memset(0, m_stream);   // CudaRenderBuffer::clear_frame
 	rb.depth_buffer.memset(0, m_stream);
+	m_renderer->trace = m_render_trace;
 	m_renderer->fused_passes = m_bl_fused_passes; m_renderer->reference_schedule = m_bl_reference_schedule; m_renderer->max_skips_per_pass = m_bl_max_skips_per_pass;
 	m_renderer->pass_samples_factor = m_bl_pass_samples_factor; m_renderer->max_steps_per_pass = m_bl_max_steps_per_pass;
 	m_bl_render_samples = m_renderer->render(rb, request, m_stream);

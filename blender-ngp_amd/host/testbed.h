@@ -401,6 +401,8 @@ public:
 	std::mutex m_render_mutex; std::condition_variable m_render_cv; int m_render_workers = 0;
 	void* stream() const { return m_stream; }          // hipStream_t all training work is queued on
 	                                                   // instead of evaluating every marched sample; same kept samples, measured at par with the flat pass (its tiles pack worse), so off
+	bool m_trace_sync = false;                         // debugging aid: drain both streams behind every launch group and name it on stderr (finds a kernel that never returns)
+	bool m_render_trace = false;                       // debugging aid: the tracers' pass structure (alive rays, steps per pass) on stderr
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
 	uint64_t m_prefetch_hits = 0;
@@ -524,6 +526,32 @@ public:
 	void profile_begin(int k, void* stream = nullptr);
 	void profile_end(int k, uint64_t units, void* stream = nullptr);
 	void profile_collect(bool only_finished = false);                            // after a stream sync: fold pending event pairs into m_prof
+
+	// ---- organisation of the network pass over a training batch.  The library has two, bit for bit the same function (tests/test_network_gpu.py,
+	// tests/test_gridmlp_gpu.py): Fused = ngp_hip_nerf_forward / ngp_hip_gridmlp_forward (gathers inside the MLP kernel: the L1 serves neighbouring samples of a ray),
+	// TwoKernel = ..._ws (XCD-affine encode into level planes + MLP kernel: every XCD's L2 holds the tables it walks).  Which is faster is the WORKLOAD's property —
+	// profiles/r05_a_*: lego stand-in (constant step, one cascade) 171 us fused / 198 two-kernel; fox photographs (cone stepping, three cascades) 270 / 201; SDF batches
+	// of random points 171 / 95 — so Auto (the default) measures: a calibration brackets the pass with HIP events for 2 x N_SAMPLES consecutive steps, alternating the
+	// organisations, and keeps the one with the lower median (the other must win by 3 % to take over).  Calibrations run early (behind the first occupancy updates),
+	// again once the step cadence has settled, and then rarely; a reset_network / new data starts over.
+	enum class ENetworkPass : int { Auto = 0, Fused = 1, TwoKernel = 2 };
+	struct NetworkPassTuner {
+		static constexpr int N_SAMPLES = 6;
+		ENetworkPass chosen = ENetworkPass::Fused;
+		uint32_t next_calibration_step = 0;      // set by tuner_reset
+		uint32_t n_calibrations = 0, last_calibration_step = 0;
+		float last_us[2] = {0.f, 0.f};           // medians of the last calibration: [0] fused, [1] two-kernel
+		int remaining = 0, measuring = -1;       // launches the running calibration still has to issue; organisation bracketed right now (-1: none)
+		float us[2][N_SAMPLES]; int count[2] = {0, 0};
+		struct Pending { void* e0; void* e1; int org; };
+		std::vector<Pending> pending;
+	};
+	ENetworkPass m_network_pass = ENetworkPass::Auto;
+	NetworkPassTuner m_pass_tuner;
+	void tuner_reset();
+	bool tuner_pick(void* stream);               // true: this launch runs the two-kernel organisation; starts / continues a calibration
+	void tuner_done(void* stream);               // behind the launch
+	void tuner_collect(bool wait);
 
 	// network + optimizer state
 	NgpNetDesc m_desc{};

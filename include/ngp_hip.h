@@ -434,6 +434,12 @@ int ngp_hip_gridmlp_init_params(void* stream, const NgpNetDesc* desc_host, uint6
 /* out: fp16, sample i at out[i*out_stride + 0..3] = network outputs 0..3; x_saved: NULL (inference) or [n][32] fp16 for backward */
 int ngp_hip_gridmlp_forward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
                             uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved);
+/* The same pass as two kernels (as ngp_hip_nerf_forward_ws above: XCD-affine encode of the 16 levels into planes inside `workspace`, then the MLP kernel): same
+ * bits, faster for batches whose positions have no order (the SDF config: 2^18 random points), slower for batches that run along a dense level's x axis (the
+ * stratified image batch).  The reference has one path (tcnn NetworkWithInputEncoding::forward behind Trainer::training_step, src/testbed_sdf.cu:1229-1252,
+ * src/testbed_image.cu:277-288); which of the two runs is the host's measured choice (Testbed::network_pass).  workspace: ngp_hip_nerf_encode_workspace_bytes(n). */
+int ngp_hip_gridmlp_forward_ws(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,
+                               uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes);
 uint64_t ngp_hip_gridmlp_backward_scratch_bytes(uint32_t n);
 /* dL_dout: fp16 [n][dl_stride], channels 0..3 consumed; grads: fp16 [n_params], overwritten.  n must be a multiple of 256. */
 int ngp_hip_gridmlp_backward(void* stream, uint32_t n_dims, const NgpNetDesc* desc_dev, const uint16_t* params, const float* pos, uint32_t pos_stride_floats,

@@ -76,6 +76,33 @@ def test_forward_matches_oracle(ngp, oracle, cuda, n_dims, log2, desired, n):
 
 
 @pytest.mark.parametrize("n_dims,log2,desired", CASES)
+@pytest.mark.parametrize("n", [1, 1000, 5000, 1 << 16])
+def test_two_kernel_forward_is_the_fused_forward_bit_for_bit(ngp, cuda, n_dims, log2, desired, n):
+    """ngp_hip_gridmlp_forward_ws (XCD-affine encode into level planes + MLP kernel over them) against ngp_hip_gridmlp_forward: the same fp32 sums in the same order,
+    one fp16 rounding each — outputs AND saved encodings identical, ragged sizes included (the planes are padded to 1024-sample chunks).  The host chooses between
+    the two by measurement (Testbed.network_pass), so they must be interchangeable at any step."""
+    desc = _desc(ngp, n_dims, log2, desired)
+    P = _params(desc, 5)
+    pos = np.random.RandomState(n + n_dims).rand(n, n_dims).astype(np.float32)
+    d_desc, d_P, d_pos = H.to_dev(desc, cuda), H.to_dev(P, cuda), H.to_dev(pos, cuda)
+    out_a, xs_a = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda)
+    out_b, xs_b = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda)
+    ws_bytes = int(ngp.ngp_hip_nerf_encode_workspace_bytes(n))
+    ws = H.dev_zeros(ws_bytes, cuda)
+    check(ngp.ngp_hip_gridmlp_forward(None, n_dims, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), n_dims, n, out_a.data_ptr(), 4, xs_a.data_ptr()))
+    check(ngp.ngp_hip_gridmlp_forward_ws(None, n_dims, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), n_dims, n, out_b.data_ptr(), 4, xs_b.data_ptr(), ws.data_ptr(), ws_bytes))
+    np.testing.assert_array_equal(H.to_host(out_b, np.uint16), H.to_host(out_a, np.uint16))
+    np.testing.assert_array_equal(H.to_host(xs_b, np.uint16), H.to_host(xs_a, np.uint16))
+    assert n < 100 or np.abs(H.to_host(out_a, np.float16).astype(np.float32)).max() > 0.05
+    # inference form (no saved encoding), and a workspace that is too small is refused, not overrun
+    out_c = H.dev_zeros(n * 8, cuda)
+    check(ngp.ngp_hip_gridmlp_forward_ws(None, n_dims, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), n_dims, n, out_c.data_ptr(), 4, None, ws.data_ptr(), ws_bytes))
+    np.testing.assert_array_equal(H.to_host(out_c, np.uint16), H.to_host(out_a, np.uint16))
+    assert ngp.ngp_hip_gridmlp_forward_ws(None, n_dims, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), n_dims, n, out_c.data_ptr(), 4, None, ws.data_ptr(), ws_bytes - 1) != 0
+    assert ngp.ngp_hip_gridmlp_forward_ws(None, 4, d_desc.data_ptr(), d_P.data_ptr(), d_pos.data_ptr(), n_dims, n, out_c.data_ptr(), 4, None, ws.data_ptr(), ws_bytes) != 0
+
+
+@pytest.mark.parametrize("n_dims,log2,desired", CASES)
 def test_backward_matches_oracle(ngp, oracle, cuda, n_dims, log2, desired):
     n = 2048
     desc = _desc(ngp, n_dims, log2, desired)

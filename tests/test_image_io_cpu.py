@@ -547,7 +547,7 @@ def _hdr_bytes(rgbe, rle, magic=b"#?RADIANCE"):
     return out
 
 
-@pytest.mark.parametrize("w,h,rle", [(8, 3, True), (40, 11, True), (300, 4, True), (7, 5, False), (40, 11, False), (1, 1, False)])
+@pytest.mark.parametrize("w,h,rle", [(8, 3, True), (40, 11, True), (300, 4, True), (7, 5, False), (40, 11, False), (1, 1, False), (1, 200, False), (2, 90, False)])   # (tall 1- and 2-pixel-wide flat files: 4 w bytes per line is less than any run-length line, ADVICE r04)
 def test_radiance_hdr_as_stbi_load_sees_it(tmp_path, w, h, rle):
     """.hdr goes through stbi_load(.., 4) in the reference's loader (src/nerf_loader.cu:581): RGBE -> float -> (float)pow(v, 1 / 2.2) * 255 + 0.5, clamped, truncated;
     alpha 255.  Run-length and flat files, both magic lines; bit-identical to the reference's stb_image where it is built."""

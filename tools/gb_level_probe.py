@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-level cost of the hash-grid backward (GPU box only): times ngp_hip_nerf_backward with NGP_HIP_GB_LEVELS masks.
+"""Per-level cost of the hash-grid backward (GPU box only): times ngp_hip_nerf_backward with NGP_HIP_GB_LEVELS masks.  Needs the development build of the kernel
+library (python blender-ngp_amd/build.py --dev; NGP_HIP_LIBRARY_DIR=blender-ngp_amd/lib_dev): the product library has no environment knobs.
 
     python tools/gb_level_probe.py [--n 262144]
 """
@@ -18,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=1 << 18)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=lambda v: int(v, 0), default=None, help="run this level mask only (for rocprofv3 --kernel-trace --stats runs: per-kernel times of the group under one mask)")
     a = ap.parse_args()
     import torch
     import capi
@@ -57,6 +59,9 @@ def main():
         torch.cuda.synchronize()
         return 1000.0 * e0.elapsed_time(e1) / a.iters
 
+    if a.only is not None:
+        print("mask %s: %.1f us per call" % (hex(a.only), timeit(a.only)))
+        return
     base = timeit(0)
     print("no level: %.1f us (everything but the owner blocks)" % base)
     for name, mask in [("all", 0xffff), ("dense 0-4", 0x1f), ("hashed 5-15", 0xffe0)] + [("level %d" % l, 1 << l) for l in range(16)]:
