@@ -268,6 +268,115 @@ def self_launch(n_gpus):
     os.execv(sys.executable, cmd)
 
 
+def preflight(rank, local_rank, world, dev):
+    """`python bench.py --gpus N --preflight`: everything the multi-GPU run needs BEFORE any training — the kernel library, the RCCL it binds, the shared-memory
+    rendezvous of Testbed.init_data_parallel, a communicator over all ranks, and one 1 KiB collective of each kind the step uses (all-reduce, fp16 all-to-all, all-gather)
+    with its result checked — each stage under a 30 s watchdog that names the stage and the rank and exits, so that a first run on an 8-GPU node fails on plumbing with
+    a sentence, not with a hang.  Rank 0 prints one JSON line {"preflight": "ok", ...}; nothing is trained."""
+    import ctypes
+    import threading
+    import numpy as np
+    import torch
+    for p in (PKG,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    stage = {"name": "start", "t0": time.perf_counter()}
+    times = {}
+
+    def watchdog():
+        while True:
+            time.sleep(1.0)
+            if stage["name"] == "done":
+                return
+            if time.perf_counter() - stage["t0"] > 30.0:
+                print(json.dumps({"preflight": "failed", "rank": rank, "world": world, "stuck_in": stage["name"], "after_s": 30,
+                                  "hint": "a stage that never returns on SOME ranks usually means the others never reached it: read their lines"}), flush=True)
+                os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+
+    def enter(name):
+        now = time.perf_counter()
+        if stage["name"] not in ("start",):
+            times[stage["name"]] = round((now - stage["t0"]) * 1e3, 2)
+        stage["name"], stage["t0"] = name, now
+
+    try:
+        enter("load libngp_hip.so")
+        import capi
+        ngp = capi.load_ngp_hip()
+        enter("bind RCCL")
+        if not ngp.ngp_rccl_available():
+            raise RuntimeError("no librccl could be loaded next to the HIP runtime in use (%s)" % ngp.ngp_hip_last_error().decode())
+        enter("Testbed.init_data_parallel (shared-memory rendezvous + ncclCommInitRank)")
+        import pyngp
+        tb = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+        key = "preflight_%s" % os.environ.get("MASTER_PORT", "0")
+        tb.init_data_parallel(rank, world, key, True)
+        if int(tb.dp_comm_size) != world:
+            raise RuntimeError("the communicator reports %d ranks, WORLD_SIZE is %d" % (int(tb.dp_comm_size), world))
+        enter("Testbed.shutdown_data_parallel")
+        tb.shutdown_data_parallel()
+        del tb
+        # a communicator of this script's own for the 1 KiB collectives: the unique id travels through a file in /dev/shm (no torch.distributed involved)
+        enter("unique id exchange (/dev/shm)")
+        id_path = "/dev/shm/ngp_preflight_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            capi.check(ngp.ngp_rccl_get_unique_id(uid.ctypes.data))
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(uid.tobytes())
+            os.replace(id_path + ".tmp", id_path)
+        else:
+            while not os.path.exists(id_path):
+                time.sleep(0.01)
+            uid = np.frombuffer(open(id_path, "rb").read(), np.uint8).copy()
+        enter("ngp_rccl_init")
+        comm = ngp.ngp_rccl_init(rank, world, uid.ctypes.data)
+        if not comm:
+            raise RuntimeError("ngp_rccl_init: %s" % ngp.ngp_hip_last_error().decode())
+        st = torch.cuda.current_stream().cuda_stream
+        enter("all-reduce, 1 KiB fp32")
+        x = torch.full((256,), float(rank + 1), device=dev, dtype=torch.float32)
+        capi.check(ngp.ngp_rccl_allreduce_f32(comm, st, x.data_ptr(), x.numel()))
+        torch.cuda.synchronize()
+        if not bool((x == world * (world + 1) / 2).all()):
+            raise RuntimeError("all-reduce gave %r, expected %r" % (float(x[0]), world * (world + 1) / 2))
+        enter("all-to-all, fp16 slices (grouped ncclSend / ncclRecv)")
+        per = 512 // world // 8 * 8 or 8
+        send = torch.empty(world * per, device=dev, dtype=torch.float16)
+        for q in range(world):
+            send[q * per:(q + 1) * per] = float(rank * 16 + q)
+        recv = torch.zeros_like(send)
+        capi.check(ngp.ngp_rccl_alltoall_f16(comm, st, send.data_ptr(), recv.data_ptr(), per))
+        torch.cuda.synchronize()
+        want = torch.cat([torch.full((per,), float(q * 16 + rank), device=dev, dtype=torch.float16) for q in range(world)])
+        if not torch.equal(recv, want):
+            raise RuntimeError("all-to-all: slice from rank %d is wrong" % int((recv != want).nonzero()[0] // per))
+        out = torch.zeros(per, device=dev, dtype=torch.float16)
+        capi.check(ngp.ngp_hip_sum_slices_f16(st, world, per, recv.data_ptr(), out.data_ptr()))
+        enter("all-gather, fp16")
+        g = torch.zeros(world * per, device=dev, dtype=torch.float16)
+        g[rank * per:(rank + 1) * per] = float(rank + 1)
+        capi.check(ngp.ngp_rccl_allgather_f16(comm, st, g.data_ptr(), per))
+        torch.cuda.synchronize()
+        if not torch.equal(g, torch.cat([torch.full((per,), float(q + 1), device=dev, dtype=torch.float16) for q in range(world)])):
+            raise RuntimeError("all-gather: wrong contents")
+        enter("ngp_rccl_finalize")
+        capi.check(ngp.ngp_rccl_finalize(comm))
+        enter("done")
+        if rank == 0:
+            try:
+                os.unlink(id_path)
+            except OSError:
+                pass
+            print(json.dumps({"preflight": "ok", "n_gpus": world, "device": torch.cuda.get_device_name(local_rank), "stages_ms_rank0": times}), flush=True)
+    except Exception as e:
+        failed = stage["name"]
+        stage["name"] = "done"
+        print(json.dumps({"preflight": "failed", "rank": rank, "world": world, "stage": failed, "error": str(e)}), flush=True)
+        raise SystemExit(3)
+
+
 def main():
     if os.environ.get("BENCH_HANG_DUMP"):   # dev: dump every thread's stack and exit if the run is still going after that many seconds
         import faulthandler
@@ -290,6 +399,8 @@ def main():
     ap.add_argument("--min_train_step", type=int, default=1000, help="BASELINE.md M1 quotes the metric on steps [1000, 2000): the timed region never starts before this training step, whatever --warmup says")
     ap.add_argument("--legs", default="fox,bl_render,plumbing", help="comma list of the extra legs of a one-GPU run (bench_legs.py): fox = BASELINE config #2 on the fox photographs, bl_render = the Blender "
                     "multi-NeRF renderer next to the stock tracer, plumbing = configs #1 / #5 at 2^18; 'none' switches them off")
+    ap.add_argument("--preflight", action="store_true", help="multi-GPU plumbing check only (no training): library, RCCL binding, init_data_parallel's rendezvous, a communicator over all ranks and one "
+                    "1 KiB collective of each kind the step uses, every stage under a 30 s watchdog that names the stage and the rank; prints {\"preflight\": \"ok\"} on rank 0")
     ap.add_argument("--psnr_gate", type=float, default=35.0, help="BASELINE config #3 'train to 35 PSNR then render': keep pre-training (untimed) until the held-out PSNR reaches this")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -309,6 +420,10 @@ def main():
         raise SystemExit("rank %d of %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, world, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if a.preflight:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        preflight(rank, local_rank, world, dev)
+        return
     dist = None
     use_dp = world > 1 or a.force_dp
     if use_dp:

@@ -26,6 +26,10 @@ struct RcclApi {
 	int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
 	int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
 	int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
 	int (*CommCount)(RcclComm, int*) = nullptr;
 	int (*CommDestroy)(RcclComm) = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
@@ -64,6 +68,10 @@ RcclApi* rccl() {
 	api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclAllReduce");
 	api.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclAllGather");
 	api.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclReduceScatter");
+	api.Send = (int (*)(const void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclSend");
+	api.Recv = (int (*)(void*, size_t, int, int, RcclComm, hipStream_t))dlsym(api.handle, "ncclRecv");
+	api.GroupStart = (int (*)())dlsym(api.handle, "ncclGroupStart");
+	api.GroupEnd = (int (*)())dlsym(api.handle, "ncclGroupEnd");
 	api.CommCount = (int (*)(RcclComm, int*))dlsym(api.handle, "ncclCommCount");
 	api.CommDestroy = (int (*)(RcclComm))dlsym(api.handle, "ncclCommDestroy");
 	api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
@@ -82,7 +90,48 @@ struct Comm { RcclComm comm = nullptr; int rank = 0, world = 1; };
 
 }  // namespace
 
+namespace ngp {
+// out[i] = half( sum over q = 0 .. world - 1, in that order, of float(slices[q][i]) ): fp32 accumulation, ONE fp16 rounding — 8 elements (16 bytes) per thread and slice
+__global__ void __launch_bounds__(256) sum_slices_f16_kernel(uint32_t world, uint32_t count, const half_t* __restrict__ slices, half_t* __restrict__ out) {
+	typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+	const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 8u;
+	if (i >= count) return;
+	if (i + 8u <= count) {
+		float acc[8];
+		const h8v v0 = *(const h8v*)(slices + i);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) acc[k] = (float)v0[k];
+		for (uint32_t q = 1; q < world; ++q) {
+			const h8v v = *(const h8v*)(slices + (size_t)q * count + i);
+#pragma unroll
+			for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+		}
+		h8v r;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) r[k] = (half_t)acc[k];
+		*(h8v*)(out + i) = r;
+	} else {
+		for (uint32_t e = i; e < count; ++e) {
+			float acc = (float)slices[e];
+			for (uint32_t q = 1; q < world; ++q) acc += (float)slices[(size_t)q * count + e];
+			out[e] = (half_t)acc;
+		}
+	}
+}
+}  // namespace ngp
+
 extern "C" {
+
+// `slices`: world x count fp16 (slice q = rank q's contribution, 16-byte aligned, count a multiple of 8 or any with an unaligned tail); out: count fp16
+int ngp_hip_sum_slices_f16(void* stream, uint32_t world, uint32_t count, const uint16_t* slices, uint16_t* out) {
+	if (count == 0) return 0;
+	if (world == 0 || !slices || !out || ((uintptr_t)slices & 15u) || ((uintptr_t)out & 15u) || (world > 1 && (count & 7u))) {
+		ngp::set_last_error("ngp_hip_sum_slices_f16: world >= 1, 16-byte aligned buffers, count a multiple of 8 when world > 1", hipErrorInvalidValue); return -1;
+	}
+	hipLaunchKernelGGL(ngp::sum_slices_f16_kernel, dim3((count + 2047u) / 2048u), dim3(256), 0, (hipStream_t)stream, world, count, (const ngp::half_t*)slices, (ngp::half_t*)out);
+	NGP_LAUNCH_CHECK("sum_slices_f16_kernel");
+	return 0;
+}
 
 int ngp_rccl_available(void) { return rccl() ? 1 : 0; }
 
@@ -142,6 +191,32 @@ int ngp_rccl_reduce_scatter_f32(void* comm, void* stream, const float* in, float
 	if (count_per_rank == 0) return 0;
 	const int rc = a->ReduceScatter(in, out, (size_t)count_per_rank, RCCL_FLOAT32, RCCL_SUM, c->comm, (hipStream_t)stream);
 	return rc ? fail("ngp_rccl_reduce_scatter_f32", rc) : 0;
+}
+
+// The gradient exchange with fp16 ON THE WIRE (round 5): rank r sends slice q of `send` (world x count_per_rank fp16) to rank q and receives rank q's slice r into slice q
+// of `recv` — point-to-point over the direct xGMI links of a fully connected node, (world - 1) / world x 2 bytes per parameter per rank instead of the fp32
+// reduce-scatter's 4.  No arithmetic on the wire: the owner of a slice then sums the world fp16 vectors in RANK ORDER in fp32 and rounds once
+// (ngp_hip_sum_slices_f16) — a summation order that does not depend on the collective library's ring / tree choice.  The own slice is copied device to device.
+int ngp_rccl_alltoall_f16(void* comm, void* stream, const uint16_t* send, uint16_t* recv, uint64_t count_per_rank) {
+	RcclApi* a = rccl();
+	Comm* c = (Comm*)comm;
+	if (!a || !c) { ngp::set_last_error("ngp_rccl_alltoall_f16", hipErrorInvalidValue); return -1; }
+	if (count_per_rank == 0) return 0;
+	if (hipMemcpyAsync(recv + (size_t)c->rank * count_per_rank, send + (size_t)c->rank * count_per_rank, (size_t)count_per_rank * 2u, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+		ngp::set_last_error("ngp_rccl_alltoall_f16: device copy of the own slice failed", hipErrorUnknown); return -1;
+	}
+	if (c->world == 1) return 0;
+	if (!a->Send || !a->Recv || !a->GroupStart || !a->GroupEnd) { ngp::set_last_error("ngp_rccl_alltoall_f16: this librccl has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd", hipErrorNotSupported); return -1; }
+	int rc = a->GroupStart();
+	if (rc) return fail("ncclGroupStart", rc);
+	for (int q = 0; q < c->world && !rc; ++q) {
+		if (q == c->rank) continue;
+		rc = a->Send(send + (size_t)q * count_per_rank, (size_t)count_per_rank, RCCL_FLOAT16, q, c->comm, (hipStream_t)stream);
+		if (!rc) rc = a->Recv(recv + (size_t)q * count_per_rank, (size_t)count_per_rank, RCCL_FLOAT16, q, c->comm, (hipStream_t)stream);
+	}
+	const int rc_end = a->GroupEnd();
+	if (rc) return fail("ncclSend / ncclRecv (ngp_rccl_alltoall_f16)", rc);
+	return rc_end ? fail("ncclGroupEnd (ngp_rccl_alltoall_f16)", rc_end) : 0;
 }
 
 int ngp_rccl_comm_size(void* comm) {   // ncclCommCount: what the communicator itself says (bench.py prints it next to WORLD_SIZE)

@@ -385,11 +385,10 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("render_with_rolling_shutter", [](Testbed& t, const py::array_t<float, py::array::c_style | py::array::forcecast>& m0, const py::array_t<float, py::array::c_style | py::array::forcecast>& m1,
 		                                       const std::vector<float>& rolling_shutter, int width, int height, int spp, bool linear) {   // python_api.cu:262-275, 584-593
 				if (rolling_shutter.size() != 4) throw std::runtime_error{"rolling_shutter takes 4 floats [A, B, C, D]"};
-				std::vector<float> px;
 				const Mat34 start = mat34_from_py(m0), end = mat34_from_py(m1);   // buffer requests touch refcounts: before the GIL is released
-				{ py::gil_scoped_release rel; px = t.render_with_rolling_shutter_to_cpu(start, end, rolling_shutter.data(), width, height, spp, linear); }
-				py::array_t<float> result({height, width, 4});
-				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				py::array_t<float> result({height, width, 4});   // the frame is written straight into the array that is returned (no intermediate host copy)
+				float* dst = result.mutable_data();
+				{ py::gil_scoped_release rel; t.render_with_rolling_shutter_to_cpu(start, end, rolling_shutter.data(), width, height, spp, linear, dst); }
 				return result;
 			}, "Renders an image at the requested resolution. Does not require a window. Supports rolling shutter, with per ray time being computed as A+B*u+C*v+D*t for [A,B,C,D]",
 			py::arg("transform_matrix_start"), py::arg("transform_matrix_end"), py::arg("rolling_shutter") = std::vector<float>{0.f, 0.f, 0.f, 0.f}, py::arg("width") = 1920, py::arg("height") = 1080,
@@ -418,10 +417,9 @@ PYBIND11_MODULE(pyngp, m) {
 				// python_api.cu:131-165: start_t >= 0 animates along the loaded camera path (set_camera_from_time, smoothing, per-spp shutter interpolation).  Camera
 				// paths are not part of this build (load_camera_path throws): a still frame returned for a path request would be silently wrong
 				if (start_t >= 0.f /* the reference's path_animation_enabled (python_api.cu:139): end_t alone is ignored there too */) throw std::runtime_error{"render(start_t >= 0): camera-path animation is not part of this build; set the camera per frame with set_nerf_camera_matrix and call render() with start_t = end_t = -1"};
-				std::vector<float> px;
-				{ py::gil_scoped_release rel; px = t.render_to_cpu(width, height, spp, linear); }
-				py::array_t<float> result({height, width, 4});
-				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				py::array_t<float> result({height, width, 4});   // the frame is written straight into the array that is returned (no intermediate host copy)
+				float* dst = result.mutable_data();
+				{ py::gil_scoped_release rel; t.render_to_cpu(width, height, spp, linear, dst); }
 				return result;
 			}, py::arg("width") = 1920, py::arg("height") = 1080, py::arg("spp") = 1, py::arg("linear") = true, py::arg("start_t") = -1.f, py::arg("end_t") = -1.f,
 			py::arg("fps") = 30.f, py::arg("shutter_fraction") = 1.0f)
@@ -456,10 +454,11 @@ PYBIND11_MODULE(pyngp, m) {
 			}, py::arg("positions"))
 		.def_property_readonly("image_resolution", [](Testbed& t) { return std::vector<int>{t.m_image.resolution[0], t.m_image.resolution[1]}; })
 		.def("request_nerf_render_sync", [](Testbed& t, const RenderRequest& req) {  // python_api.cu:233-260, 581
-				std::vector<float> px;
-				{ py::gil_scoped_release rel; px = t.bl_request_nerf_render_sync(req); }
 				py::array_t<float> result({req.output.resolution[1], req.output.resolution[0], 4});
-				memcpy(result.mutable_data(), px.data(), px.size() * sizeof(float));
+				float* dst = result.mutable_data();
+				bool rendered;
+				{ py::gil_scoped_release rel; rendered = t.bl_request_nerf_render_sync(req, dst); }
+				if (!rendered) memset(dst, 0, (size_t)result.size() * sizeof(float));   // the reference returns the untouched (zero) array while another render is in flight
 				return result;
 			}, "Requests a nerf render frame.", py::arg("render_request"))
 		.def("request_nerf_render_async", [](Testbed& t, const RenderRequest& req, const py::function& render_callback) {  // python_api.cu:192-231, 577-580
@@ -478,7 +477,7 @@ PYBIND11_MODULE(pyngp, m) {
 							rb.reset_accumulation();
 							t.bl_render_frame(rb, req);
 							px.resize((size_t)req.output.resolution[0] * req.output.resolution[1] * 4);
-							rb.surface.copy_to_host(px.data(), px.size() * 4);
+							t.download(rb.surface.data(), px.size() * 4, px.data());   // through the Testbed's pinned staging buffer (testbed.cpp download)
 						} catch (const std::exception& e) { error = e.what(); } catch (...) { error = "unknown error"; }
 						end.now();   // before the callback, so that it may queue the next request (from this very thread: nothing joins it)
 						py::gil_scoped_acquire acquire;
@@ -518,6 +517,10 @@ PYBIND11_MODULE(pyngp, m) {
 			"render() traces only the rows of shard `rank` of `world_size` (rows [rank * ceil(H / world), ...)); the rest of the returned frame is background. With init_data_parallel the split and the gather happen inside render().")
 		.def("render_shard_rows", [](Testbed& t, int height) { int a, b; t.render_shard_rows(height, a, b); return py::make_tuple(a, b); }, py::arg("height"))
 		.def_property("dp_sharded_optimizer", [](Testbed& t) { return t.m_dp_sharded_optimizer; }, &Testbed::set_dp_sharded_optimizer, "data-parallel step: reduce-scatter (fp32 sums) -> Adam on this rank's 1 / world of the parameters -> all-gather of the fp16 weights (default); False: fp16 all-reduce of the gradients, the whole optimizer step on every rank.  Settable only while no communicator is live (before init_data_parallel)")
+		.def_property("dp_sharded_ema", [](Testbed& t) { return t.m_dp_sharded_ema; }, &Testbed::set_dp_sharded_ema, "sharded data-parallel step: the Ema stage runs on this rank's shard only (one launch with Adam) and the fp16 inference weights are gathered on demand — render() gathers by itself when it is a collective (render_sharded), otherwise call dp_gather_inference_params() on all ranks before render() / save_snapshot().  False: Ema over all parameters on every rank (rounds 3-4).  Settable only while no communicator is live")
+		.def_readwrite("dp_fp16_wire", &Testbed::m_dp_fp16_wire, "sharded data-parallel step: gradients cross the wire as fp16 slices (point to point, ngp_rccl_alltoall_f16) and are summed by their owner in rank order in fp32 with one fp16 rounding; False: widen -> fp32 reduce-scatter -> narrow (twice the bytes).  Set it alike on every rank, between two steps")
+		.def("dp_gather_inference_params", &Testbed::dp_gather_inference_params, py::call_guard<py::gil_scoped_release>(), "COLLECTIVE (every rank): all-gather of the fp16 inference (Ema) weights that sharded-Ema steps keep current only inside each rank's shard")
+		.def_readwrite("dp_inference_stale", &Testbed::m_dp_inference_stale, "the inference (Ema) weights outside this rank's shard are old (see dp_sharded_ema); writable as a test hook")
 		.def_readwrite("dp_state_stale", &Testbed::m_dp_state_stale, "sharded data-parallel steps ran since the last dp_gather_optimizer_state(): the fp32 master weights / Adam moments are current only inside this rank's shard.  optimizer steps outside a communicator and save_snapshot(include_optimizer_state=True) refuse such a state; dp_gather_optimizer_state() (with the communicator still live), reset_network() and load_snapshot() clear it.  Writable as a test hook (one-GPU tests cannot run a world of two)")
 		.def_readwrite("render_sharded", &Testbed::m_render_sharded, "opt-in: under init_data_parallel render() / render_to_cpu() become COLLECTIVES (rows per rank, RCCL all-gather, every rank returns the whole frame) — set it on every rank and call render() on every rank with the same arguments.  Default False: render() is local and traces the whole frame, so one rank alone can render")
 		.def_property_readonly("dp_comm_size", [](Testbed& t) { return t.m_dp_comm ? ngp_rccl_comm_size(t.m_dp_comm) : 0; }, "ranks of the RCCL communicator of init_data_parallel (ncclCommCount), 0 without one")
@@ -630,6 +633,7 @@ PYBIND11_MODULE(pyngp, m) {
 				return d;
 			})
 		.def("debug_params", [](Testbed& t, const std::string& which) {   // fp16 bits of the "training" or "inference" (EMA) weights
+				if (which == "inference") t.require_inference_params("debug_params('inference')", false);
 				const DeviceBuffer& b = which == "inference" ? t.m_inference_params : t.m_params;
 				t.sync();
 				py::array_t<uint16_t> a((py::ssize_t)t.m_n_params);

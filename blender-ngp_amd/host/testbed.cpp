@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <map>
 
 // Events of the training step order work between streams of ONE device (march on stream B -> network pass on stream A, grid gradients
 // -> the all-reduce stream) or are waited on by a host that reads host-coherent pinned words a kernel fenced itself (post_words).
@@ -241,6 +242,36 @@ void RenderBuffer::resize(int w, int h) {
 }
 
 // ------------------------------------------------------------------------------------------------ Testbed
+// ---- one stream pair per device, shared by every Testbed of the process ---------------------------------------------------
+// HIP spreads a process's streams over FOUR hardware queues in creation order.  With a stream pair per Testbed, a second live instance's training stream and run-ahead
+// stream could land on ONE queue — its march then runs inside the chain instead of beside it (fox: 0.72 -> 0.79 ms per step next to an idle lego Testbed, found in round 4;
+// GPU_MAX_HW_QUEUES=8 cured it, an environment variable the user had to know).  A Testbed's work is stream-ordered and two Testbeds of one process share the chip
+// anyway, so all of them queue on the same two streams: the chain stream and the run-ahead stream are two streams created back to back — two queues — whoever uses them.
+namespace {
+struct StreamPair { hipStream_t a = nullptr, b = nullptr; int refs = 0; };
+std::mutex g_stream_pair_mutex;
+std::map<int, StreamPair> g_stream_pairs;
+void acquire_stream_pair(int device, void*& a, void*& b) {
+	std::lock_guard<std::mutex> lock(g_stream_pair_mutex);
+	StreamPair& p = g_stream_pairs[device];
+	if (p.refs == 0) {
+		HIP_CHECK_THROW(hipStreamCreate(&p.a));
+		if (hipStreamCreate(&p.b) != hipSuccess) { (void)hipStreamDestroy(p.a); p.a = nullptr; throw std::runtime_error{"hipStreamCreate failed"}; }
+	}
+	++p.refs;
+	a = p.a; b = p.b;
+}
+void release_stream_pair(int device) {
+	std::lock_guard<std::mutex> lock(g_stream_pair_mutex);
+	auto it = g_stream_pairs.find(device);
+	if (it == g_stream_pairs.end() || it->second.refs == 0) return;
+	if (--it->second.refs == 0) {
+		(void)hipStreamDestroy(it->second.b); (void)hipStreamDestroy(it->second.a);
+		g_stream_pairs.erase(it);
+	}
+}
+}  // namespace
+
 Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 	if (mode == ETestbedMode::Volume) {
 		throw std::runtime_error{"TestbedMode.Volume is outside the scope of this build (SURVEY.md §8): Nerf, and the plumbing configs Image / Sdf"};
@@ -250,10 +281,7 @@ Testbed::Testbed(ETestbedMode mode) : m_testbed_mode(mode) {
 		throw std::runtime_error{"no MI355X / ROCm device visible: the product path has no CPU fallback"};
 	}
 	HIP_CHECK_THROW(hipGetDevice(&m_device));   // the caller's current device (one process per GPU: torch.cuda.set_device(LOCAL_RANK) came first); worker threads re-select it
-	hipStream_t st, st_b;
-	HIP_CHECK_THROW(hipStreamCreate(&st));
-	HIP_CHECK_THROW(hipStreamCreate(&st_b));
-	m_stream = st; m_stream_b = st_b;
+	acquire_stream_pair(m_device, m_stream, m_stream_b);
 	m_nerf.training.owner = this;
 	m_rng = Pcg32(m_seed);
 	reset_camera();
@@ -267,12 +295,14 @@ Testbed::~Testbed() {
 	if (m_render_host_words) (void)hipHostFree(m_render_host_words);
 	if (m_render_event) (void)hipEventDestroy((hipEvent_t)m_render_event);
 	(void)hipDeviceSynchronize();
+	if (m_pinned) (void)hipHostFree(m_pinned);
 	if (m_host_words) (void)hipHostFree(m_host_words);
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_grid_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_grid_prefetch_event);
-	if (m_stream_b) { (void)hipStreamSynchronize((hipStream_t)m_stream_b); (void)hipStreamDestroy((hipStream_t)m_stream_b); }
-	if (m_stream) { (void)hipStreamSynchronize((hipStream_t)m_stream); (void)hipStreamDestroy((hipStream_t)m_stream); }
+	if (m_stream_b) (void)hipStreamSynchronize((hipStream_t)m_stream_b);
+	if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream);
+	if (m_stream) release_stream_pair(m_device);
 }
 
 void Testbed::check(int rc, const char* what) {
@@ -776,11 +806,12 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	if (config.contains("optimizer")) parse_optimizer_config(config["optimizer"]);
 	m_optimizer_step = 0;
 	tuner_reset();
+	m_dp_inference_stale = false;
 	m_dp_state_stale = false;   // the whole fp32 state is rebuilt below (every rank of a live communicator resets alike: same seed, same bits)
 
 	// (+ DP_PARAM_SLACK elements behind the weights and the gradients: the sharded optimizer step all-gathers world equal shards in place, the last one padded)
-	m_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_inference_params.resize(m_n_params * 2); m_grads.resize((m_n_params + DP_PARAM_SLACK) * 2);
-	m_master.resize((m_n_params + DP_PARAM_SLACK) * 4); m_first_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_second_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_ema.resize(m_n_params * 4);
+	m_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_inference_params.resize((m_n_params + DP_PARAM_SLACK) * 2); m_grads.resize((m_n_params + DP_PARAM_SLACK) * 2);
+	m_master.resize((m_n_params + DP_PARAM_SLACK) * 4); m_first_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_second_moments.resize((m_n_params + DP_PARAM_SLACK) * 4); m_ema.resize((m_n_params + DP_PARAM_SLACK) * 4);
 	m_first_moments.memset(0, m_stream); m_second_moments.memset(0, m_stream); m_ema.memset(0, m_stream); m_grads.memset(0, m_stream); m_params.memset(0, m_stream); m_master.memset(0, m_stream);
 	check(ngp_hip_nerf_init_params(m_stream, &m_desc, m_seed, m_master.as<float>(), m_params.as<uint16_t>(), m_inference_params.as<uint16_t>(), net_variant(nv)), "ngp_hip_nerf_init_params");
 
@@ -1002,13 +1033,16 @@ void Testbed::dp_gather_optimizer_state() {
 	// this rank's shard.  What rebuilds the whole state clears the flag instead: reset_network, load_snapshot.
 	if (m_dp_state_stale && !m_dp_comm)
 		throw std::runtime_error{"dp_gather_optimizer_state: the fp32 optimizer state is stale outside this rank's shard and the data-parallel communicator is gone — gather on ALL ranks BEFORE shutdown_data_parallel(); now only reset_network() / load_snapshot() rebuild the state"};
-	if (!m_dp_comm || m_world_size < 2 || !m_dp_sharded_optimizer || m_n_params == 0) { if (m_world_size < 2) m_dp_state_stale = false; return; }
-	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
-	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_master.as<float>(), shard), "ngp_rccl_allgather_f32 (master weights)");
-	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_first_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (first moments)");
-	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_second_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (second moments)");
-	sync();
-	m_dp_state_stale = false;
+	if (m_dp_comm && m_world_size >= 2 && m_dp_sharded_optimizer && m_n_params != 0) {
+		const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
+		check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_master.as<float>(), shard), "ngp_rccl_allgather_f32 (master weights)");
+		check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_first_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (first moments)");
+		check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_second_moments.as<float>(), shard), "ngp_rccl_allgather_f32 (second moments)");
+		if (m_dp_sharded_ema) check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, m_ema.as<float>(), shard), "ngp_rccl_allgather_f32 (Ema)");
+		sync();
+	}
+	m_dp_state_stale = false;   // (a world of one, or the replicated step, never left anything stale)
+	dp_gather_inference_params();
 }
 void Testbed::set_dp_sharded_optimizer(bool on) {
 	if (on == m_dp_sharded_optimizer) return;
@@ -1016,6 +1050,11 @@ void Testbed::set_dp_sharded_optimizer(bool on) {
 	// need a collective inside a property setter: choose before init_data_parallel, or gather (all ranks) and shut the communicator down first
 	if (m_dp_comm) throw std::runtime_error{"dp_sharded_optimizer can only be changed before init_data_parallel (or after dp_gather_optimizer_state() + shutdown_data_parallel())"};
 	m_dp_sharded_optimizer = on;
+}
+void Testbed::set_dp_sharded_ema(bool on) {
+	if (on == m_dp_sharded_ema) return;
+	if (m_dp_comm) throw std::runtime_error{"dp_sharded_ema can only be changed before init_data_parallel (or after dp_gather_optimizer_state() + shutdown_data_parallel())"};
+	m_dp_sharded_ema = on;
 }
 // No collective here: a rank that leaves alone (an exception, a test that ends) must not hang in an all-gather the others never enter.  A Testbed that is to train
 // on, or to save its optimizer state, after sharded data-parallel steps calls dp_gather_optimizer_state() on ALL ranks first; otherwise the state stays marked stale.
@@ -1515,42 +1554,79 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 	// as a torch ExternalStream; a caller without stream ordering calls sync() before and after its collective instead
 }
 
-// The data-parallel optimizer step: reduce-scatter -> Adam on this rank's shard -> all-gather (SURVEY.md §5 "Distributed communication backend").
-//   * the ranks' fp16 gradient vectors are summed in FP32 (each is the exact sum of its rank's terms rounded once, §5.2; summing them in fp16 would round world - 1 more
-//     times) and every rank receives 1 / world of the sum — half the wire volume of the all-reduce for this half of the exchange;
-//   * Adam (28 B / parameter of fp32 state) runs on that shard only: 1 / world of the 62 us sweep;
-//   * the new fp16 weights are all-gathered in place (2 B / parameter); the Ema stage reads fp16 weights only, so every rank runs it over all parameters from the gathered
-//     weights (12 B / parameter, no wire).  The fp32 state (master weights, moments) stays sharded: rank r owns elements [r * shard, (r + 1) * shard).
-// Element for element the arithmetic of the replicated step: tests/test_dp_cpu.py (gloo, oracle) and tests/test_dp_gpu.py (shards on one GPU) compare bit for bit.
+// The data-parallel optimizer step (SURVEY.md §5 "Distributed communication backend"; round 5: fp16 on the wire, Ema sharded with the optimizer):
+//   * gradient exchange: every rank sends slice q of its fp16 gradient vector to rank q (ngp_rccl_alltoall_f16: point to point over the node's direct xGMI links, no
+//     arithmetic on the wire) and sums the world slices it receives IN RANK ORDER in fp32 with one fp16 rounding (ngp_hip_sum_slices_f16).  Each vector is the exact sum
+//     of its rank's terms rounded once (§5.2); their fp32 sum rounded once is what the round-3 path (widen -> fp32 reduce-scatter -> narrow) produced, at 2 instead of
+//     4 bytes per parameter on the wire and with a summation order that no longer depends on the library's ring (`dp_fp16_wire = False` restores that path);
+//   * Adam AND Ema (36 B / parameter of state) run on this rank's shard only, one launch: 1 / world of the 62-85 us sweep (rounds 3-4 ran the 12 B / parameter Ema stage
+//     over ALL parameters on every rank: 25 us per step that did not shrink with the ranks);
+//   * the new fp16 TRAINING weights are all-gathered in place (2 B / parameter) — the next step's network passes read all of them.  The fp16 INFERENCE (Ema) weights
+//     are read by the renderers and snapshots only: they stay sharded and are gathered when somebody needs them (dp_gather_inference_params: a collective; render()
+//     runs it by itself when it is a collective anyway — render_sharded — and refuses otherwise).  The fp32 state (master weights, moments, Ema) stays sharded: rank r
+//     owns elements [r * shard, (r + 1) * shard); dp_gather_optimizer_state makes it whole.
+// Element for element the arithmetic of the replicated step: tests/test_dp_cpu.py (gloo, oracle; worlds of 2 and 3) and tests/test_dp_gpu.py (shards on one GPU) compare bit for bit.
 void Testbed::optimizer_step_sharded() {
 	++m_optimizer_step;
 	const uint32_t world = m_world_size, rank = m_rank;
 	if (world > 1) m_dp_state_stale = true;
 	const uint32_t shard = next_multiple(((uint32_t)m_n_params + world - 1) / world, 8u);
 	if ((uint64_t)shard * world > m_n_params + DP_PARAM_SLACK) throw std::runtime_error{"optimizer_step_sharded: world size too large for the parameter buffers' slack"};
-	m_dp_grads_f32.enlarge((size_t)shard * world * 4); m_dp_shard_f32.enlarge((size_t)shard * 4);
 	const uint32_t off = shard * rank;
 	const uint32_t mine = off < m_n_params ? std::min<uint32_t>(shard, (uint32_t)m_n_params - off) : 0u;
 	const uint32_t mask = (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u);
 	const float ema_decay = m_use_ema ? m_ema_decay : 0.0f;
 	profile_begin(PK_GRAD_EXCHANGE);
-	check(ngp_hip_f16_to_f32(m_stream, (uint32_t)m_n_params, shard * world, m_grads.as<uint16_t>(), m_dp_grads_f32.as<float>()), "f16_to_f32 (gradients)");
-	check(ngp_rccl_reduce_scatter_f32(m_dp_comm, m_stream, m_dp_grads_f32.as<float>(), m_dp_shard_f32.as<float>(), shard), "ngp_rccl_reduce_scatter_f32 (gradients)");
-	check(ngp_hip_f32_to_f16(m_stream, shard, m_dp_shard_f32.as<float>(), m_grads.as<uint16_t>() + off), "f32_to_f16 (gradient shard)");
+	if (m_dp_fp16_wire) {
+		// (the gradient buffer carries DP_PARAM_SLACK elements behind the parameters: world x shard may exceed n_params by < 8 x world; what lies there is summed and never read)
+		m_dp_grads_f32.enlarge((size_t)shard * world * 2);   // here: the world fp16 slices this rank receives
+		check(ngp_rccl_alltoall_f16(m_dp_comm, m_stream, m_grads.as<uint16_t>(), m_dp_grads_f32.as<uint16_t>(), shard), "ngp_rccl_alltoall_f16 (gradients)");
+		check(ngp_hip_sum_slices_f16(m_stream, world, shard, m_dp_grads_f32.as<uint16_t>(), m_grads.as<uint16_t>() + off), "sum_slices_f16 (gradient shard)");
+	} else {
+		m_dp_grads_f32.enlarge((size_t)shard * world * 4); m_dp_shard_f32.enlarge((size_t)shard * 4);
+		check(ngp_hip_f16_to_f32(m_stream, (uint32_t)m_n_params, shard * world, m_grads.as<uint16_t>(), m_dp_grads_f32.as<float>()), "f16_to_f32 (gradients)");
+		check(ngp_rccl_reduce_scatter_f32(m_dp_comm, m_stream, m_dp_grads_f32.as<float>(), m_dp_shard_f32.as<float>(), shard), "ngp_rccl_reduce_scatter_f32 (gradients)");
+		check(ngp_hip_f32_to_f16(m_stream, shard, m_dp_shard_f32.as<float>(), m_grads.as<uint16_t>() + off), "f32_to_f16 (gradient shard)");
+	}
 	profile_end(PK_GRAD_EXCHANGE, m_n_params);
 	profile_begin(PK_OPTIMIZER);
-	if (mine) check(ngp_hip_optimizer_step(m_stream, mine, m_n_matrix_params > off ? m_n_matrix_params - off : 0u, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
-	                                              ema_decay, m_grads.as<uint16_t>() + off, m_master.as<float>() + off, m_params.as<uint16_t>() + off, m_first_moments.as<float>() + off,
-	                                              m_second_moments.as<float>() + off, nullptr, nullptr, mask | NGP_OPT_NO_EMA), "optimizer_step (Adam, this rank's shard)");
+	const uint32_t matrix_here = m_n_matrix_params > off ? m_n_matrix_params - off : 0u;
+	if (m_dp_sharded_ema) {
+		if (mine) check(ngp_hip_optimizer_step(m_stream, mine, matrix_here, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay,
+		                                              m_grads.as<uint16_t>() + off, m_master.as<float>() + off, m_params.as<uint16_t>() + off, m_first_moments.as<float>() + off,
+		                                              m_second_moments.as<float>() + off, m_ema.as<float>() + off, m_inference_params.as<uint16_t>() + off, mask), "optimizer_step (Adam + Ema, this rank's shard)");
+		if (world > 1) m_dp_inference_stale = true;
+	} else if (mine) {
+		check(ngp_hip_optimizer_step(m_stream, mine, matrix_here, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay,
+		                                    m_grads.as<uint16_t>() + off, m_master.as<float>() + off, m_params.as<uint16_t>() + off, m_first_moments.as<float>() + off,
+		                                    m_second_moments.as<float>() + off, nullptr, nullptr, mask | NGP_OPT_NO_EMA), "optimizer_step (Adam, this rank's shard)");
+	}
 	profile_end(PK_OPTIMIZER, mine);
 	profile_begin(PK_PARAM_GATHER);
 	check(ngp_rccl_allgather_f16(m_dp_comm, m_stream, m_params.as<uint16_t>(), shard), "ngp_rccl_allgather_f16 (weights)");
 	profile_end(PK_PARAM_GATHER, m_n_params);
-	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
-	                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema, all parameters)");
+	if (!m_dp_sharded_ema)
+		check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
+		                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema, all parameters)");
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
 		m_learning_rate *= m_decay_base;
 	}
+}
+
+// The inference (Ema) fp16 weights after sharded steps: current inside this rank's shard only.  COLLECTIVE (every rank of the communicator): in-place all-gather, 2 B / parameter.
+void Testbed::dp_gather_inference_params() {
+	if (!m_dp_inference_stale) return;
+	if (!m_dp_comm) throw std::runtime_error{"dp_gather_inference_params: the inference (Ema) weights are stale outside this rank's shard and the data-parallel communicator is gone — gather on ALL ranks BEFORE shutdown_data_parallel(); now only reset_network() / load_snapshot() rebuild them"};
+	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
+	check(ngp_rccl_allgather_f16(m_dp_comm, m_stream, m_inference_params.as<uint16_t>(), shard), "ngp_rccl_allgather_f16 (inference weights)");
+	sync();
+	m_dp_inference_stale = false;
+}
+// what a reader of the inference weights calls first: gathers when the call is a collective anyway (`collective`), refuses a stale copy otherwise
+void Testbed::require_inference_params(const char* who, bool collective) {
+	if (!m_dp_inference_stale) return;
+	if (collective && m_dp_comm) { dp_gather_inference_params(); return; }
+	throw std::runtime_error{std::string(who) + ": the inference (Ema) weights are sharded over the data-parallel ranks (dp_sharded_ema) and stale outside this rank's shard — call dp_gather_inference_params() on ALL ranks first (a collective), or set render_sharded on every rank so that render() is a collective and gathers by itself"};
 }
 
 void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE) (testbed_nerf.cu:2950)
@@ -1734,8 +1810,25 @@ void Testbed::update_after_training(uint32_t target_batch_size, uint32_t counter
 }
 
 // ---- rendering --------------------------------------------------------------------------------------------------
-std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool linear) {  // python_api.cu:132-190 (no camera path / motion blur)
+// The frame leaves the device through ONE pinned staging buffer that lives as long as the Testbed (download()), never by a hipMemcpy into the caller's pageable
+// array: the runtime pins such a destination for the DMA, and when the array is freed — a 1080 x 1920 frame is 33 MB, above glibc's largest mmap threshold, so every
+// frame's array is a mapping of its own — the unmap of pages the GPU had mapped stalls the process's queues for 18-25 ms.  That, not the tracer, was the fox leg's
+// "38 MP/s" of round 4 (profiles/r05_fox_render_timeline.txt: 20 ms of kernels per frame, 25-30 ms of idle GPU between two frames; 105 MP/s with the staging buffer).
+void Testbed::download(const void* device_src, size_t bytes, void* host_dst) {
+	if (m_pinned_bytes < bytes) {
+		if (m_pinned) (void)hipHostFree(m_pinned);
+		m_pinned = nullptr; m_pinned_bytes = 0;
+		HIP_CHECK_THROW(hipHostMalloc(&m_pinned, bytes, hipHostMallocDefault));
+		m_pinned_bytes = bytes;
+	}
+	HIP_CHECK_THROW(hipMemcpyAsync(m_pinned, device_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
+	sync();
+	memcpy(host_dst, m_pinned, bytes);
+}
+
+void Testbed::render_to_cpu(int width, int height, int spp, bool linear, float* out) {  // python_api.cu:132-190 (no camera path / motion blur); out: height * width * 4 floats
 	if (m_n_params == 0) throw std::runtime_error{"render(): no network"};
+	require_inference_params("render()", render_is_collective());
 	RenderBuffer& rb = m_windowless_render_surface;
 	rb.resize(width, height);
 	rb.reset_accumulation();
@@ -1744,15 +1837,22 @@ std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool l
 	auto start = std::chrono::steady_clock::now();
 	const float no_rolling_shutter[4] = {0.f, 0.f, 0.f, 0.f};   // python_api.cu:177 (Vector4f::Zero())
 	for (int i = 0; i < spp; ++i) render_frame(m_camera, m_camera, no_rolling_shutter, rb, !linear);
-	std::vector<float> out((size_t)width * height * 4);
+	const auto traced = std::chrono::steady_clock::now();
 	fetch_render_surface(rb, out);
 	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
+	if (m_render_trace) fprintf(stderr, "render: frames %.3f ms, device -> host %.3f ms\n", std::chrono::duration<float, std::milli>(traced - start).count(),
+	                            std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - traced).count());
+}
+std::vector<float> Testbed::render_to_cpu(int width, int height, int spp, bool linear) {
+	std::vector<float> out((size_t)width * height * 4);
+	render_to_cpu(width, height, spp, linear, out.data());
 	return out;
 }
 
-std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height,
-                                                               int spp, bool linear) {  // python_api.cu:262-275
+void Testbed::render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height,
+                                                 int spp, bool linear, float* out) {  // python_api.cu:262-275
 	if (m_n_params == 0) throw std::runtime_error{"render_with_rolling_shutter(): no network"};
+	require_inference_params("render_with_rolling_shutter()", render_is_collective());
 	RenderBuffer& rb = m_windowless_render_surface;
 	rb.resize(width, height);
 	rb.reset_accumulation();
@@ -1763,9 +1863,13 @@ std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& came
 		if (m_autofocus) autofocus();
 		render_frame(c0, c1, rolling_shutter, rb, !linear);
 	}
-	std::vector<float> out((size_t)width * height * 4);
 	fetch_render_surface(rb, out);
 	m_stats.render_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - start).count();
+}
+std::vector<float> Testbed::render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height,
+                                                               int spp, bool linear) {
+	std::vector<float> out((size_t)width * height * 4);
+	render_with_rolling_shutter_to_cpu(camera_transform_start, camera_transform_end, rolling_shutter, width, height, spp, linear, out.data());
 	return out;
 }
 
@@ -1785,9 +1889,10 @@ void Testbed::render_shard_rows(int height, int& row_begin, int& row_end) const 
 	row_begin = std::min(height, (int)rank * rows_per);
 	row_end = std::min(height, row_begin + rows_per);
 }
-void Testbed::fetch_render_surface(RenderBuffer& rb, std::vector<float>& out) {
+void Testbed::fetch_render_surface(RenderBuffer& rb, float* out) {
 	const int W = rb.res[0], H = rb.res[1];
-	if (!render_is_collective()) { rb.surface.copy_to_host(out.data(), out.size() * 4); return; }
+	const size_t frame_bytes = (size_t)W * H * 16;
+	if (!render_is_collective()) { download(rb.surface.data(), frame_bytes, out); return; }
 	// all-gather of the ranks' row ranges (RCCL over xGMI, in place in a buffer of world equal chunks), then one copy to the host
 	int row_begin, row_end;
 	render_shard_rows(H, row_begin, row_end);
@@ -1797,8 +1902,7 @@ void Testbed::fetch_render_surface(RenderBuffer& rb, std::vector<float>& out) {
 	float* gather = m_render_gather.as<float>();
 	if (row_end > row_begin) HIP_CHECK_THROW(hipMemcpyAsync(gather + chunk_floats * m_rank, rb.surface.as<float>() + (size_t)row_begin * W * 4, (size_t)(row_end - row_begin) * W * 16, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
 	check(ngp_rccl_allgather_f32(m_dp_comm, m_stream, gather, chunk_floats), "ngp_rccl_allgather_f32 (frame rows)");
-	HIP_CHECK_THROW(hipMemcpyAsync(out.data(), gather, out.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
-	sync();
+	download(gather, frame_bytes, out);
 }
 
 void Testbed::autofocus() {  // testbed.cu:2933-2941: focus on m_autofocus_target
@@ -1930,6 +2034,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		volatile uint32_t* host_alive = (volatile uint32_t*)m_render_host_words;
 		hipStream_t st = (hipStream_t)m_stream;
 		const bool trace = m_render_trace;   // pyngp: render_trace — the pass structure on stderr
+		const auto trace_t0 = std::chrono::steady_clock::now();
 		// The alive count of a pass comes back through a mailbox in host memory that the pass's last workgroup writes (NgpCompactOut::host_mailbox) and this thread polls:
 		// no copy command, no stream synchronisation (an interrupt and a wake-up) between two passes.
 		uint32_t* blocks_done = m_tr_counters.as<uint32_t>() + 10;
@@ -1973,7 +2078,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		uint32_t n_alive = read_alive(), i = 1;
 		while (n_alive > 0 && i < MARCH_ITER) {
 			const uint32_t n_steps = std::min(std::max(pass_samples / n_alive, 1u), m_nerf.render_max_steps_per_pass);   // NerfTracer::trace (2231), cap raised (see below)
-			if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u\n", i, n_alive, n_steps);
+			if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u t=%.3f ms\n", i, n_alive, n_steps, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - trace_t0).count());
 			NgpPayload* payloads = m_tr_payload[cur].as<NgpPayload>();
 			NgpCoord* net_in = m_tr_net_in.as<NgpCoord>();
 			uint16_t* net_out = m_tr_net_out.as<uint16_t>();
@@ -2137,19 +2242,23 @@ void Testbed::bl_wait_for_renders() {
 bool Testbed::bl_try_begin_render() { bool expected = false; return m_currently_rendering.compare_exchange_strong(expected, true); }
 void Testbed::bl_end_render() { m_currently_rendering.store(false); }
 
-std::vector<float> Testbed::bl_request_nerf_render_sync(const RenderRequest& request) {  // python_api.cu:233-260
+bool Testbed::bl_request_nerf_render_sync(const RenderRequest& request, float* out) {  // python_api.cu:233-260; out: H * W * 4 floats, untouched (false) while another render is in flight (:235-237)
 	const int w = request.output.resolution[0], h = request.output.resolution[1];
-	std::vector<float> out((size_t)w * h * 4, 0.f);
-	if (!bl_try_begin_render()) return out;   // the reference returns the untouched array while another render is in flight (:235-237)
+	if (!bl_try_begin_render()) return false;
 	try {
 		if (m_autofocus) autofocus();   // python_api.cu:240
 		RenderBuffer& rb = m_bl_render_surface;
 		rb.resize(w, h);
 		rb.reset_accumulation();
 		bl_render_frame(rb, request);
-		rb.surface.copy_to_host(out.data(), out.size() * 4);
+		download(rb.surface.data(), (size_t)w * h * 16, out);
 	} catch (...) { bl_end_render(); throw; }
 	bl_end_render();
+	return true;
+}
+std::vector<float> Testbed::bl_request_nerf_render_sync(const RenderRequest& request) {
+	std::vector<float> out((size_t)request.output.resolution[0] * request.output.resolution[1] * 4, 0.f);
+	bl_request_nerf_render_sync(request, out.data());
 	return out;
 }
 
@@ -2164,6 +2273,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 	if (m_n_params == 0) throw std::runtime_error{"save_snapshot: no network"};
 	drop_prefetch();
 	sync();
+	require_inference_params("save_snapshot", false);   // the snapshot's params_binary are the inference (Ema) weights: a rank saves alone, so no collective here
 	if (include_optimizer_state && m_dp_state_stale)   // sharded data-parallel steps left master weights / moments current only inside this rank's shard
 		throw std::runtime_error{"save_snapshot(include_optimizer_state=True): the fp32 optimizer state is sharded over the data-parallel ranks — call dp_gather_optimizer_state() on ALL ranks first (a collective), then save on whichever rank"};
 	Json snapshot = Json::object();

@@ -312,13 +312,21 @@ public:
 	// automatically; set_render_shard makes this Testbed trace the rows of (rank, world) only, the rest of the surface stays background
 	void set_render_shard(uint32_t rank, uint32_t world);
 	void render_shard_rows(int height, int& row_begin, int& row_end) const;
-	void fetch_render_surface(RenderBuffer& rb, std::vector<float>& out);
+	void fetch_render_surface(RenderBuffer& rb, float* out);
+	void download(const void* device_src, size_t bytes, void* host_dst);   // device -> pinned staging (kept) -> host_dst; never a DMA into the caller's pageable memory (testbed.cpp)
+	void* m_pinned = nullptr; size_t m_pinned_bytes = 0;
 	uint32_t m_render_shard_rank = 0, m_render_shard_world = 1;
 	DeviceBuffer m_render_gather;
 	// the data-parallel optimizer step (testbed.cpp optimizer_step_sharded): reduce-scatter -> Adam on the rank's shard -> all-gather; false: fp16 all-reduce + replicated step
 	bool m_dp_sharded_optimizer = true;
 	void set_dp_sharded_optimizer(bool on);   // only without a live communicator
 	bool m_dp_state_stale = false;            // sharded steps ran since the last dp_gather_optimizer_state: fp32 state outside this rank's shard is old
+	bool m_dp_fp16_wire = true;               // sharded step's gradient exchange: fp16 slices point to point + fp32 sum in rank order (false: widen -> fp32 reduce-scatter -> narrow, rounds 3-4)
+	bool m_dp_sharded_ema = true;             // sharded step: the Ema stage on this rank's shard only; inference weights gathered on demand (false: Ema over all parameters on every rank)
+	bool m_dp_inference_stale = false;        // sharded-Ema steps ran since the last dp_gather_inference_params: the inference weights outside this rank's shard are old
+	void set_dp_sharded_ema(bool on);         // only without a live communicator
+	void dp_gather_inference_params();        // COLLECTIVE: in-place all-gather of the fp16 inference weights
+	void require_inference_params(const char* who, bool collective);
 	bool m_render_sharded = false;            // render() is a collective over the data-parallel ranks (rows per rank + all-gather); off: local, whole frame
 	bool render_is_collective() const { return m_dp_comm && m_render_sharded; }   // (a one-rank communicator runs the same path: split, gather buffer, RCCL call)
 	static constexpr size_t DP_PARAM_SLACK = 1024;   // elements behind the weights / gradients: world x shard (shard a multiple of 8) may exceed n_params by < 8 x world
@@ -385,6 +393,7 @@ public:
 	// ---- Blender multi-NeRF requests (python_api.cu:192-260, testbed.cu:2675-2693)
 	void bl_render_frame(RenderBuffer& rb, const RenderRequest& request);
 	std::vector<float> bl_request_nerf_render_sync(const RenderRequest& request);      // H*W*4 floats; zeros while another render is running
+	bool bl_request_nerf_render_sync(const RenderRequest& request, float* out);        // into the caller's array; false (array untouched) while another render is running
 	bool bl_try_begin_render();                                                        // false if a render is already in flight
 	void bl_end_render();
 	uint64_t m_bl_render_samples = 0;
@@ -426,6 +435,7 @@ public:
 
 	// ---- rendering (python_api.cu:132-190; testbed.cu:2695-2911; testbed_nerf.cu:2047-2267, 2354-2500)
 	std::vector<float> render_to_cpu(int width, int height, int spp, bool linear);
+	void render_to_cpu(int width, int height, int spp, bool linear, float* out);      // into the caller's array (pyngp: the numpy array it returns)
 	void render_frame(const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], RenderBuffer& rb, bool to_srgb);
 	void render_nerf(RenderBuffer& rb, const float focal_length[2], const Mat34& cam0, const Mat34& cam1, const float rolling_shutter[4], const float screen_center[2]);
 	void set_nerf_camera_matrix(const Mat34& cam) { m_camera = m_nerf.training.dataset.nerf_matrix_to_ngp(cam); } // testbed.cu:219-221
@@ -449,6 +459,7 @@ public:
 	std::vector<Vec3> crop_box_corners(bool nerf_space) const;
 	// python_api.cu:262-275: spp frames between two camera poses, per-ray time A + B u + C v + D t from `rolling_shutter`
 	std::vector<float> render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height, int spp, bool linear);
+	void render_with_rolling_shutter_to_cpu(const Mat34& camera_transform_start, const Mat34& camera_transform_end, const float rolling_shutter[4], int width, int height, int spp, bool linear, float* out);
 
 	// ---- snapshots (testbed.cu:3006-3106) — next-row f1, see DESIGN.md
 	void save_snapshot(const std::string& path, bool include_optimizer_state);

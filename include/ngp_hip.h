@@ -563,6 +563,14 @@ int ngp_rccl_allgather_f16(void* comm, void* stream, uint16_t* buf, uint64_t cou
 /* sum over the ranks of in[world * count_per_rank]; rank r receives elements [r * count_per_rank, (r + 1) * count_per_rank) of the sum (fp32: the
  * gradient shards of the sharded optimizer step are summed in fp32, not in the fp16 they are stored in) */
 int ngp_rccl_reduce_scatter_f32(void* comm, void* stream, const float* in, float* out, uint64_t count_per_rank);
+/* The gradient exchange with fp16 on the wire (round 5; replaces widen -> ngp_rccl_reduce_scatter_f32 -> narrow in the sharded optimizer step): slice q of `send`
+ * (world x count_per_rank fp16) goes to rank q, rank q's slice for this rank arrives in slice q of `recv` — grouped ncclSend / ncclRecv over the node's direct xGMI
+ * links, no arithmetic on the wire, the own slice copied on the device.  ngp_hip_sum_slices_f16 then gives out[i] = half(sum_q float(slices[q][i])) with the ranks
+ * added IN RANK ORDER in fp32 and ONE fp16 rounding: the gradient a replicated step would see, independent of the collective library's reduction order, at
+ * (world - 1) / world x 2 bytes per parameter and rank instead of 4.  The reference has no counterpart (single GPU, README.md:239-241); call site: between
+ * backward (src/testbed_nerf.cu:3331) and optimizer_step (2950). */
+int ngp_rccl_alltoall_f16(void* comm, void* stream, const uint16_t* send, uint16_t* recv, uint64_t count_per_rank);
+int ngp_hip_sum_slices_f16(void* stream, uint32_t world, uint32_t count, const uint16_t* slices, uint16_t* out);
 int ngp_rccl_comm_size(void* comm);                              /* ncclCommCount; -1 on error */
 int ngp_rccl_comm_rank(void* comm);
 int ngp_rccl_finalize(void* comm);

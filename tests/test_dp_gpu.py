@@ -177,6 +177,93 @@ def test_rccl_allgather_and_reduce_scatter_on_one_rank(ngp, cuda):
         check(ngp.ngp_rccl_finalize(comm))
 
 
+@pytest.mark.parametrize("world,count", [(1, 4096), (1, 1003), (2, 4096), (3, 8 * 1237), (8, 8 * 190747)])
+def test_sum_slices_f16_adds_in_rank_order_and_rounds_once(ngp, cuda, world, count):
+    """ngp_hip_sum_slices_f16: out[i] = half(((float(s0[i]) + float(s1[i])) + float(s2[i])) + ...) — the owner's side of the fp16-wire gradient exchange
+    (Testbed::optimizer_step_sharded); magnitudes spread over many binades so that the fp32 partial sums are not all exact and the ORDER is visible."""
+    rs = np.random.RandomState(world * 31 + count % 97)
+    slices = (rs.randn(world, count) * np.exp(rs.randn(world, count) * 3)).astype(np.float16)
+    slices[rs.rand(world, count) < 0.3] = 0
+    if world == 3:   # (a + -a) + b = b, but (b + -a) + a = 0 when b is below half an fp32 ulp of a: elements on which the order of the additions shows
+        slices[0, :8], slices[1, :8], slices[2, :8] = 65504.0, -65504.0, 2.0 ** -10
+    acc = slices[0].astype(np.float32)
+    for q in range(1, world):
+        acc = (acc + slices[q].astype(np.float32)).astype(np.float32)
+    want = acc.astype(np.float16)
+    d_in, d_out = H.to_dev(slices, cuda), H.dev_zeros(count * 2, cuda)
+    check(ngp.ngp_hip_sum_slices_f16(None, world, count, d_in.data_ptr(), d_out.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_out, np.uint16), want.view(np.uint16))
+    if world == 3:   # the reversed order is a different function (else the test could not see the order)
+        rev = slices[2].astype(np.float32)
+        for q in (1, 0):
+            rev = (rev + slices[q].astype(np.float32)).astype(np.float32)
+        assert (rev.astype(np.float16)[:8] == 0).all() and (want[:8] == np.float16(2.0 ** -10)).all()
+    assert ngp.ngp_hip_sum_slices_f16(None, 2, 1003, d_in.data_ptr(), d_out.data_ptr()) != 0   # world > 1: whole 16-byte groups only (the shard length is a multiple of 8)
+
+
+def test_alltoall_f16_on_one_rank_is_the_own_slice(ngp, cuda):
+    import torch
+    uid = np.zeros(128, np.uint8)
+    check(ngp.ngp_rccl_get_unique_id(uid.ctypes.data))
+    comm = ngp.ngp_rccl_init(0, 1, uid.ctypes.data)
+    assert comm
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        send = (torch.arange(4096, device=cuda, dtype=torch.float16) * 0.25)
+        recv = torch.zeros_like(send)
+        check(ngp.ngp_rccl_alltoall_f16(comm, st, send.data_ptr(), recv.data_ptr(), send.numel()))
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+    finally:
+        check(ngp.ngp_rccl_finalize(comm))
+
+
+def test_stale_sharded_state_is_refused_not_papered_over(cuda, tmp_path):
+    """ADVICE r04 + round 5's sharded Ema: after sharded steps at world > 1 the fp32 state AND the inference weights are current only inside the rank's shard.  One GPU
+    cannot run a world of two, so the flags are set through their test hooks; what must hold: (1) with the communicator gone a 'gather' cannot succeed and says so
+    instead of clearing the flag, (2) optimizer steps, snapshots with optimizer state, render() and snapshots of the inference weights refuse the stale state,
+    (3) reset_network / load_snapshot rebuild everything and clear the flags."""
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    b = scene.build_testbed(ds)
+    b.init_data_parallel(0, 1, "t_stale_%d" % os.getpid(), False)
+    scene.train(b, 4)
+    assert b.dp_state_stale is False and b.dp_inference_stale is False     # a world of one leaves nothing stale
+    good = str(tmp_path / "good.msgpack")
+    b.save_snapshot(good, True)
+    b.dp_state_stale = True; b.dp_inference_stale = True                   # as a world of two would have left them
+    b.render_sharded = True
+    img = b.render(32, 32, 1, True)                                        # render() as a collective gathers the inference weights by itself ...
+    assert img.shape == (32, 32, 4) and b.dp_inference_stale is False
+    b.render_sharded = False
+    b.dp_inference_stale = True
+    with pytest.raises(RuntimeError, match="dp_gather_inference_params"):  # ... a local render() must not (a rank that renders alone would hang in the collective)
+        b.render(32, 32, 1, True)
+    with pytest.raises(RuntimeError, match="dp_gather_inference_params"):
+        b.save_snapshot(str(tmp_path / "x.msgpack"), False)
+    b.dp_gather_optimizer_state()                                          # live communicator: the explicit collective makes everything whole
+    assert b.dp_state_stale is False and b.dp_inference_stale is False
+    b.dp_state_stale = True; b.dp_inference_stale = True
+    b.shutdown_data_parallel()                                             # no collective here (a rank may leave alone): the flags stay
+    with pytest.raises(RuntimeError, match="communicator is gone"):
+        b.dp_gather_optimizer_state()
+    assert b.dp_state_stale is True
+    with pytest.raises(RuntimeError, match="communicator is gone"):
+        b.dp_gather_inference_params()
+    with pytest.raises(RuntimeError, match="stale"):
+        scene.train(b, 1)
+    with pytest.raises(RuntimeError):
+        b.save_snapshot(str(tmp_path / "y.msgpack"), True)
+    b.load_snapshot(good)                                                  # rebuilds the whole state
+    assert b.dp_state_stale is False and b.dp_inference_stale is False
+    b.shall_train = True
+    scene.train(b, 2)
+    assert np.isfinite(b.loss) and b.render(32, 32, 1, True).shape == (32, 32, 4)
+    b.dp_state_stale = True; b.dp_inference_stale = True
+    b.reset(True)
+    assert b.dp_state_stale is False and b.dp_inference_stale is False
+
+
 # ---------------------------------------------------------------------------------------------------------------- the sharded optimizer step
 @pytest.mark.parametrize("n,nm,world", [(10240 + 40000, 10240, 3), (10240 + 5000, 10240, 8), (3000, 5000, 2), (1 << 16, 0, 4)])
 def test_sharded_optimizer_stages_equal_the_whole_step_bit_for_bit(ngp, cuda, n, nm, world):
