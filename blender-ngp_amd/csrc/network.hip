@@ -709,211 +709,6 @@ static_assert(sizeof(GbRecord) == 12 && 4u * sizeof(GbRecord) <= GB_ITEMS_PER_SA
 // first bin of the sample chunk `chunk` (of n_chunks chunks of GB_FX_CHUNK samples) of a dense level: its k_chunks private copies are dealt to contiguous groups of chunks
 __host__ __device__ __forceinline__ uint32_t gb_chunk_bin0(const GbSplit& sp, uint32_t chunk, uint32_t n_chunks) { return (uint32_t)(((uint64_t)chunk * sp.k_chunks) / n_chunks) * sp.n_slices; }
 
-// ---- the counting sort of every level whose items leave as 12-byte pair records (hashed levels; dense levels of unordered batches), WRITE-COMBINED THROUGH LDS
-// (round 5, build knob NGP_GB_STAGED_SCATTER).  Rounds 3-4 store each record from registers: out[base[bin] + rank] = r — per store instruction 64 lanes in 64 bins, i.e.
-// ~64 partial lines; counters on the 11 hashed levels of a 2^18 batch (profiles/r05_scatter_counters.md): 51 % of the wave cycles are issue stalls behind the
-// address unit (TA busy 67 % of the kernel), 16 % instructions.  Here a workgroup takes GB_HS_CHUNK samples, lays its records out in LDS as the concatenation of what
-// goes to each bin's reserved range, and copies that image out with consecutive lanes on consecutive dwords (a store instruction = 256 contiguous bytes of LDS = the
-// tail / head of one to three bins' runs: 2.3x fewer write requests).  A first version that kept the sort's structure — every scatter workgroup scanning the level's
-// totals, reserving its ranges with returning global atomics, computing every pair twice — lost what the stores gained to that per-workgroup latency chain
-// (72 vs 62 us: profiles/r05_experiments.md).  So the bookkeeping moved out of the scatter pass:
-//   count    (gb_count_pairs, in the count launch) per GB_HS_CHUNK samples: LDS histograms of the first and of the straddling pairs' second records per bin, written
-//            out as 16-bit words; the level's totals as before
-//   scan     (gb_hs_scan_kernel, one workgroup per level) bins' starts from the totals, then per bin a running sum over the chunks: where each chunk's records of
-//            each bin go — no atomics, every range known before the scatter pass starts
-//   scatter  (gb_scatter_staged) reads its 256 bases and counts, one block scan for the LDS layout, ONE pass over the pairs (rank = returning LDS atomic, record and
-//            bin into LDS; a straddling pair's second record straight to its place in global memory), one barrier, copy-out.
-// The order of the records inside a bin is as arbitrary as before (the owners add integers).
-#ifndef NGP_GB_HS_CHUNK
-#define NGP_GB_HS_CHUNK 512
-#endif
-#ifndef NGP_GB_STAGED_SCATTER
-#define NGP_GB_STAGED_SCATTER 0   // measured slower than the register-to-global scatter of rounds 3-4 in both versions (profiles/r05_experiments.md): off; the next commit removes it
-#endif
-constexpr uint32_t GB_HS_CHUNK = NGP_GB_HS_CHUNK;   // samples per workgroup of the staged path: 512 -> 31 KiB of LDS in the scatter pass (the run-ahead march holds ~62 KiB per CU)
-static_assert(GB_FX_CHUNK % GB_HS_CHUNK == 0 && GB_HS_CHUNK % 256 == 0, "a staged chunk lies inside one chunk of the dense levels' walk");
-constexpr uint32_t GB_HS_MAXR_3D = GB_HS_CHUNK * 4u;
-constexpr uint32_t GB_HS_CTRL_WORDS = 3u * GB_FX_MAX_SLICES + 8u;
-constexpr uint32_t GB_HS_WORDS = GB_HS_CTRL_WORDS + 3u * GB_HS_MAXR_3D + GB_HS_MAXR_3D / 4u;
-// per (level, chunk, bin): records and straddle extras (16 bit each: at most 4 x GB_HS_CHUNK records per workgroup), and where the chunk's records of the bin start
-struct GbHsTables { uint16_t* hist; uint16_t* histx; uint32_t* base; uint32_t n_chunks; };
-__host__ __device__ __forceinline__ size_t gb_hs_index(uint32_t n_chunks, uint32_t level, uint32_t chunk, uint32_t bin) { return ((size_t)level * n_chunks + chunk) * GB_FX_MAX_SLICES + bin; }
-static uint64_t gb_hs_bytes(uint32_t n) { return (uint64_t)16 * ((n + GB_HS_CHUNK - 1) / GB_HS_CHUNK) * GB_FX_MAX_SLICES * (2u + 2u + 4u); }
-
-struct GbPair { uint32_t bin, bin1, e0, e1; };
-template <int D>
-struct GbHashedPairs {   // hashed level: the x term of the hash is x itself, so a pair's slice is fixed by (y, z) unless the level's resolution reaches the slice bits (see gb_bin_hashed)
-	uint32_t hmask; bool straddle;
-	__device__ __forceinline__ GbPair operator()(const NgpGridLevel&, const LevelPos& p, int m) const {
-		const uint32_t hb = ((p.gy + (uint32_t)(m & 1)) * 2654435761u) ^ (D == 3 ? (p.gz + (uint32_t)(m >> 1)) * 805459861u : 0u);
-		const uint32_t i0 = (hb ^ p.gx) & hmask, i1 = (hb ^ (p.gx + 1u)) & hmask;
-		GbPair r;
-		r.bin = (straddle ? i0 : (hb & hmask)) / GB_FX_SLICE; r.bin1 = straddle ? i1 / GB_FX_SLICE : r.bin;
-		r.e0 = i0 & (GB_FX_SLICE - 1); r.e1 = i1 & (GB_FX_SLICE - 1);
-		return r;
-	}
-};
-template <int D>
-struct GbDensePairs {    // dense level of an unordered batch: the x-neighbour entries are adjacent in the table; bins = slice + the chunk group's private copy
-	uint32_t chunk_bin0;
-	__device__ __forceinline__ GbPair operator()(const NgpGridLevel& lv, const LevelPos& p, int m) const {
-		const uint32_t i0 = grid_index_nd<D>(lv, p.gx, p.gy + (uint32_t)(m & 1), p.gz + (uint32_t)(m >> 1)), i1 = grid_index_nd<D>(lv, p.gx + 1u, p.gy + (uint32_t)(m & 1), p.gz + (uint32_t)(m >> 1));
-		GbPair r;
-		r.bin = chunk_bin0 + i0 / GB_FX_SLICE; r.bin1 = chunk_bin0 + i1 / GB_FX_SLICE;
-		r.e0 = i0 & (GB_FX_SLICE - 1); r.e1 = i1 & (GB_FX_SLICE - 1);
-		return r;
-	}
-};
-
-template <int D, class Pairs>
-__device__ __forceinline__ void gb_count_pairs(uint32_t* __restrict__ hist /* [256] */, uint32_t* __restrict__ histx /* [256] */, const Pairs pairs, const NgpGridLevel& lv, uint32_t level,
-                                               const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                               GbFxCounters* __restrict__ ctr, const GbHsTables hs) {
-	constexpr int NI = D == 3 ? 4 : 2;
-	constexpr int PER = GB_HS_CHUNK / 256;
-	hist[threadIdx.x] = 0u; histx[threadIdx.x] = 0u;
-	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	h2 gq[PER]; float px[PER], py[PER], pz[PER];
-#pragma unroll
-	for (int u = 0; u < PER; ++u) {
-		const uint32_t s = blockIdx.x * GB_HS_CHUNK + u * 256 + threadIdx.x;
-		const uint32_t sc = s < n ? s : 0;
-		gq[u] = dxl[sc];
-		const float* c = coords + (size_t)sc * coord_stride;
-		if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
-	}
-	__syncthreads();
-#pragma unroll
-	for (int u = 0; u < PER; ++u) {
-		const uint32_t s = blockIdx.x * GB_HS_CHUNK + u * 256 + threadIdx.x;
-		if (s >= n || (__builtin_bit_cast(uint32_t, gq[u]) & 0x7fff7fffu) == 0u) continue;   // adding +-0 never changes a sum
-		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
-#pragma unroll
-		for (int m = 0; m < NI; ++m) {
-			const GbPair q = pairs(lv, p, m);
-			atomicAdd(&hist[q.bin], 1u);
-			if (q.bin1 != q.bin) atomicAdd(&histx[q.bin1], 1u);
-		}
-	}
-	__syncthreads();
-	const uint32_t a = hist[threadIdx.x], x = histx[threadIdx.x];
-	const size_t k = gb_hs_index(hs.n_chunks, level, blockIdx.x, threadIdx.x);
-	hs.hist[k] = (uint16_t)a; hs.histx[k] = (uint16_t)x;
-	if (a + x) atomicAdd(&ctr->totals[level][threadIdx.x], a + x);
-}
-
-__host__ __device__ __forceinline__ bool gb_dense_binned(uint32_t level_size);   // (defined with the dense levels' binning below)
-// one workgroup of 1024 threads per level: thread (g, bin) owns the chunks of group g of 4.  base[level][chunk][bin] = start of the bin in the level's list (exclusive scan of
-// the bins' totals) + records of the bin in the chunks before this one.
-template <int D>
-__global__ void __launch_bounds__(1024) gb_hs_scan_kernel(const NgpNetDesc* __restrict__ desc, const GbHsTables hs, uint32_t level_mask, uint32_t ordered) {
-	const uint32_t level = blockIdx.x;
-	if (!((level_mask >> level) & 1u)) return;
-	{   // the same test as gb_fx_bin_kernel: a pair-record level is a binned hashed level, or a binned dense level of an unordered batch
-		const NgpGridLevel lv = desc->levels[level];
-		const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
-		const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
-		if ((!fx && !dense) || (dense && ordered)) return;
-	}
-	__shared__ uint32_t part[4][GB_FX_MAX_SLICES];
-	__shared__ uint32_t s_w[4];
-	const uint32_t bin = threadIdx.x & 255u, g = threadIdx.x >> 8;
-	const uint32_t per = (hs.n_chunks + 3u) / 4u, c0 = g * per, c1 = c0 + per < hs.n_chunks ? c0 + per : hs.n_chunks;
-	uint32_t sum = 0;
-	for (uint32_t c = c0; c < c1; ++c) { const size_t k = gb_hs_index(hs.n_chunks, level, c, bin); sum += (uint32_t)hs.hist[k] + (uint32_t)hs.histx[k]; }
-	part[g][bin] = sum;
-	__syncthreads();
-	uint32_t total = 0, before = 0;
-	for (uint32_t q = 0; q < 4u; ++q) { const uint32_t v = part[q][bin]; total += v; if (q < g) before += v; }
-	// exclusive scan of the 256 totals: every group of 256 threads computes the same (wave scans + the four wave totals of group 0)
-	const uint32_t lane = threadIdx.x & 63u, w = (threadIdx.x >> 6) & 3u;
-	uint32_t incl = total;
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if ((int)lane >= off) incl += o; }
-	if (g == 0 && lane == 63u) s_w[w] = incl;
-	__syncthreads();
-	uint32_t run = before + incl - total;
-	for (uint32_t k = 0; k < w; ++k) run += s_w[k];
-	for (uint32_t c = c0; c < c1; ++c) {
-		const size_t k = gb_hs_index(hs.n_chunks, level, c, bin);
-		hs.base[k] = run;
-		run += (uint32_t)hs.hist[k] + (uint32_t)hs.histx[k];
-	}
-}
-
-template <int D, class Pairs>
-__device__ __forceinline__ void gb_scatter_staged(uint32_t* __restrict__ lds /* GB_HS_WORDS */, const Pairs pairs, const NgpGridLevel& lv, uint32_t level,
-                                                  const float* __restrict__ coords, uint32_t coord_stride, uint32_t n, const h2* __restrict__ dx_planes,
-                                                  const GbHsTables hs, ulonglong2* __restrict__ sums) {
-	constexpr int NI = D == 3 ? 4 : 2;
-	constexpr int PER = GB_HS_CHUNK / 256;
-	constexpr uint32_t MAXR = GB_HS_CHUNK * NI;
-	uint32_t* __restrict__ lcur = lds;                              // LDS record index where the bin's run starts, bumped as the records arrive
-	uint32_t* __restrict__ gdelta = lds + GB_FX_MAX_SLICES;         // (record index of the run's first record in the level's global list) - (its LDS record index)
-	uint32_t* __restrict__ gx = lds + 2 * GB_FX_MAX_SLICES;         // global record index of the bin's next extra record
-	uint32_t* __restrict__ s_w = lds + 3 * GB_FX_MAX_SLICES;        // [4] wave totals of the scan, [4] the workgroup's record count
-	uint32_t* __restrict__ rec = lds + GB_HS_CTRL_WORDS;            // [MAXR][3]
-	uint8_t* __restrict__ binof = (uint8_t*)(rec + 3u * MAXR);      // [MAXR]
-	static_assert(GB_FX_MAX_SLICES == 256, "one thread per bin, one byte per bin index");
-	const size_t k = gb_hs_index(hs.n_chunks, level, blockIdx.x, threadIdx.x);
-	const uint32_t hcount = hs.hist[k], g0 = hs.base[k];
-	const h2* __restrict__ dxl = dx_planes + (size_t)level * n;
-	h2 gq[PER]; float px[PER], py[PER], pz[PER];
-#pragma unroll
-	for (int u = 0; u < PER; ++u) {
-		const uint32_t s = blockIdx.x * GB_HS_CHUNK + u * 256 + threadIdx.x;
-		const uint32_t sc = s < n ? s : 0;
-		gq[u] = dxl[sc];
-		const float* c = coords + (size_t)sc * coord_stride;
-		if (D == 3) { const f3_t v = load_pos3(c); px[u] = v.x; py[u] = v.y; pz[u] = v.z; } else { px[u] = c[0]; py[u] = c[1]; pz[u] = 0.f; }
-	}
-	{
-		const uint32_t l0 = gb_block_exclusive_scan_256(hcount, s_w);
-		lcur[threadIdx.x] = l0; gdelta[threadIdx.x] = g0 - l0; gx[threadIdx.x] = g0 + hcount;
-		if (threadIdx.x == 255u) s_w[4] = l0 + hcount;
-	}
-	__syncthreads();
-	GbRecord* __restrict__ out = (GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
-#pragma unroll
-	for (int u = 0; u < PER; ++u) {
-		const uint32_t s = blockIdx.x * GB_HS_CHUNK + u * 256 + threadIdx.x;
-		if (s >= n || (__builtin_bit_cast(uint32_t, gq[u]) & 0x7fff7fffu) == 0u) continue;
-		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
-		const float g0f = (float)gq[u][0], g1f = (float)gq[u][1];
-#pragma unroll
-		for (int m = 0; m < NI; ++m) {
-			const GbPair q = pairs(lv, p, m);
-			const float wy = (m & 1) ? p.fy : (1.0f - p.fy), wz = (m >> 1) ? p.fz : (1.0f - p.fz);
-			half_t t[4];
-#pragma unroll
-			for (uint32_t xb = 0; xb < 2; ++xb) {
-				float w = (xb ? p.fx : (1.0f - p.fx)) * wy;
-				if (D == 3) w *= wz;
-				t[2 * xb] = gb_term_half(w * g0f); t[2 * xb + 1] = gb_term_half(w * g1f);
-			}
-			uint32_t e1 = q.e1;
-			if (q.bin1 != q.bin) {   // the x + 1 corner's record goes to its own slice, this one keeps the x corner
-				GbRecord x;
-				x.entries = q.e1 | (q.e1 << 12); x.t[0] = (half_t)0.0f; x.t[1] = (half_t)0.0f; x.t[2] = t[2]; x.t[3] = t[3];
-				out[atomicAdd(&gx[q.bin1], 1u)] = x;
-				e1 = q.e0; t[2] = (half_t)0.0f; t[3] = (half_t)0.0f;
-			}
-			const uint32_t pos = atomicAdd(&lcur[q.bin], 1u);
-			typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-			h2v t01, t23; t01[0] = t[0]; t01[1] = t[1]; t23[0] = t[2]; t23[1] = t[3];
-			rec[3u * pos] = q.e0 | (e1 << 12); rec[3u * pos + 1] = __builtin_bit_cast(uint32_t, t01); rec[3u * pos + 2] = __builtin_bit_cast(uint32_t, t23);
-			binof[pos] = (uint8_t)q.bin;
-		}
-	}
-	__syncthreads();
-	const uint32_t n_words = 3u * s_w[4];
-	uint32_t* __restrict__ out32 = (uint32_t*)out;
-	for (uint32_t d = threadIdx.x; d < n_words; d += 256u) {
-		const uint32_t r = d / 3u;
-		out32[(size_t)(gdelta[binof[r]] + r) * 3u + (d - 3u * r)] = rec[d];
-	}
-}
-
 // passes 1 and 3 of the counting sort.  grid (ceil(n / GB_FX_CHUNK), 16 levels), block 256.  SCATTER = false: per-bin totals;
 // SCATTER = true: reserve a range per bin (one global atomic per bin and workgroup) and write the items.
 // hashed level: item = (sample, (y, z) pair) -> one GbRecord (two when the x corners straddle a slice boundary), bin = slice.
@@ -1306,13 +1101,12 @@ template <int D, bool SCATTER, bool ORDERED = true>   // ORDERED: the batch is i
 // (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? 4 : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
-                                                        WgradJob wgrad, GbHsTables hs) {
+                                                        WgradJob wgrad) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
 	static_assert(GB_STAGE * 4u >= 16u * 64u * 4u, "the weight-gradient rows' 16 x 64 sums fit the count pass's LDS words");
 	static_assert(4 * GB_FX_CHUNK <= 4 * GB_STAGE, "the hashed path's side ranks fit the dense path's staging words");
-	constexpr uint32_t STAGE_WORDS = SCATTER ? (4 * GB_STAGE > GB_HS_WORDS ? 4 * GB_STAGE : GB_HS_WORDS) : GB_STAGE;
-	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[STAGE_WORDS];   // count: 11 KiB, every workgroup of the launch resident at once; scatter: 38 KiB
+	__shared__ uint32_t hist[GB_FX_MAX_SLICES], base[GB_FX_MAX_SLICES], stage[SCATTER ? 4 * GB_STAGE : GB_STAGE];   // count: 11 KiB, every workgroup of the launch resident at once; scatter: 38 KiB
 	const uint32_t level = blockIdx.y;
 	if (level >= 16u) {   // rows behind the 16 levels (count pass only, when the caller handed a job over)
 		if (!SCATTER && wgrad.partials) wgrad_reduce_rows(wgrad, (level - 16u) * gridDim.x + blockIdx.x, (float*)stage);
@@ -1323,25 +1117,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTE
 	const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
 	const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
 	if (!fx && !dense) return;   // float path of the owners: no binning
-	if (NGP_GB_STAGED_SCATTER) {
-		// both launches' grids are cut for the pair-record levels (GB_HS_CHUNK samples per workgroup: gb_count_pairs / gb_scatter_staged); the run-merging walk of an
-		// ordered batch's dense levels keeps its GB_FX_CHUNK chunks, the surplus workgroups of such a level leave
-		if (dense && ORDERED) { if (blockIdx.x >= (n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) return; }
-		else {
-			if (blockIdx.x * GB_HS_CHUNK >= n) return;
-			if (dense) {
-				const GbSplit sp = gb_dense_split(lv.size);
-				const GbDensePairs<D> pairs{gb_chunk_bin0(sp, blockIdx.x * GB_HS_CHUNK / GB_FX_CHUNK, (n + GB_FX_CHUNK - 1) / GB_FX_CHUNK)};
-				if (SCATTER) gb_scatter_staged<D>(stage, pairs, lv, level, coords, coord_stride, n, dx_planes, hs, sums);
-				else gb_count_pairs<D>(hist, base, pairs, lv, level, coords, coord_stride, n, dx_planes, ctr, hs);
-			} else {
-				const GbHashedPairs<D> pairs{lv.size - 1u, lv.resolution >= GB_FX_SLICE};
-				if (SCATTER) gb_scatter_staged<D>(stage, pairs, lv, level, coords, coord_stride, n, dx_planes, hs, sums);
-				else gb_count_pairs<D>(hist, base, pairs, lv, level, coords, coord_stride, n, dx_planes, ctr, hs);
-			}
-			return;
-		}
-	}
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
 	if (dense && !ORDERED) gb_bin_dense_pairs<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
@@ -2373,25 +2148,17 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	ulonglong2* sums = (ulonglong2*)((char*)items + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 4u);
 	const uint32_t level_mask = ngp_dev_knob_u32("NGP_HIP_GB_LEVELS", 0xffffu);   // dev-only timing ablation, re-read per launch in the development build (tools/gb_level_probe.py flips it); a constant in the product library (ngp_dev_knobs.h)
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
-	const uint32_t grid_x = NGP_GB_STAGED_SCATTER ? div_up(n, GB_HS_CHUNK) : div_up(n, GB_FX_CHUNK);   // the pair-record levels' chunks; an ordered batch's dense levels use the first div_up(n, GB_FX_CHUNK) of them
-	const dim3 bin_grid(grid_x, 16);
+	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	const dim3 count_grid(bin_grid.x, 16u + (wgrad.partials ? div_up(div_up(wgrad.n_params, 64u), bin_grid.x) : 0u));
 	const WgradJob no_job{nullptr, 0u, nullptr, 0u};
 	uint32_t* wg_hist = (uint32_t*)((char*)sums + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 16u);
-	GbHsTables hs;
-	hs.n_chunks = div_up(n, GB_HS_CHUNK);
-	hs.base = (uint32_t*)((char*)wg_hist + (size_t)16 * div_up(n, GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u);
-	hs.hist = (uint16_t*)(hs.base + (size_t)16 * hs.n_chunks * GB_FX_MAX_SLICES);
-	hs.histx = hs.hist + (size_t)16 * hs.n_chunks * GB_FX_MAX_SLICES;
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad, hs);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad, hs);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
-	if (NGP_GB_STAGED_SCATTER) {
-		hipLaunchKernelGGL((gb_hs_scan_kernel<D>), dim3(16), dim3(1024), 0, st, desc_dev, hs, level_mask, ordered ? 1u : 0u);
-		NGP_LAUNCH_CHECK("gb_hs_scan_kernel");
-	}
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job, hs);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job, hs);
+	// (round 5: write-combining the records through LDS — ranks and a per-bin image in LDS, coalesced copy-out — was built in two versions and measured slower than these
+	// register-to-global stores: the pass is within 1.5x of the rate at which the part writes its 76-138 MB of records; profiles/r05_experiments.md)
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	static const uint32_t owner_threads = ngp_dev_knob_u32("NGP_HIP_GB_OWNER_THREADS", 1024u);   // dev: sweep (256 / 512 / 1024)
 	GbOwnerMap map{};
@@ -2684,7 +2451,7 @@ constexpr uint32_t FB_MAX_WORKGROUPS = 512;   // two resident workgroups per CU
 static uint64_t scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS * 4u; }
 static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
 static uint64_t gb_fx_bytes(uint32_t n) {   // counters + item lists + run sums of the binned path + the dense levels' per-workgroup bin counts
-	return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u) + (uint64_t)16 * ((n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u + gb_hs_bytes(n);
+	return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u) + (uint64_t)16 * ((n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u;
 }
 static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx(n) + gb_fx_bytes(n); }
