@@ -649,8 +649,10 @@ def main():
                 traffic_source = "profiles/pmc_traffic.json is from kernel set '%s', this build is '%s': not quoted" % (meta.get("kernel_set"), KERNEL_SET)
         except Exception:
             traffic = None
+    # `traffic` (and `mfma` below) are NOT measured by this run: gpurun refuses counter collection inside a traced run and a --pmc re-exec would triple the run's length.  They are
+    # static text from the profile named in traffic_source, quoted only while that profile's kernel_set tag equals this file's KERNEL_SET; `traffic_static` says so in the line.
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_source, "launch_group": GROUP_KERNELS.get(dom),
+                "traffic_static": traffic is not None, "traffic_source": traffic_source, "launch_group": GROUP_KERNELS.get(dom),
                 "algorithmic_bytes_per_unit": bytes_per_unit[dom], "units_per_launch": kernels[dom]["units_per_launch"], "avg_launch_us": kernels[dom]["avg_us"]}
     # the longest SINGLE kernel on the step's critical chain that has a byte model: the network pass (one C-ABI call = one kernel, nerf_forward_kernel<2, 0>: fused hash
     # encode + both MLPs over every marched sample).  `roofline` above is quoted for the largest launch GROUP (seven kernels behind one call) as in rounds 1-2; this is the
@@ -676,6 +678,7 @@ def main():
             if mj.get("_meta", {}).get("kernel_set") == KERNEL_SET:
                 roofline["mfma"] = {k: v for k, v in mj.items() if not k.startswith("_")}
                 roofline["mfma_source"] = "profiles/mfma_util.json (%s)" % mj["_meta"].get("tag")
+                roofline["mfma_static"] = True
         except Exception:
             pass
     # the march (stream B, hidden behind the backward): bytes it moves and how many waves it keeps resident
@@ -698,6 +701,13 @@ def main():
         "roofline": roofline, "roofline_longest_single_kernel": line_single, "kernels": kernels, "kernels_note": "%s: timed region, HIP events around the launches of every %s step; other groups: %d untimed survey steps" % (dom, "4th" if profile_every == 4 else "single", SURVEY_STEPS),
     }
     line.update(extra)
+    try:   # what this command gave on other boxes of the pool while it was developed (a static record kept by the builder): the driver's 20-step window is one draw from this
+        sp = json.load(open(os.path.join(ROOT, "profiles", "box_spread.json")))
+        if sp.get("kernel_set") == KERNEL_SET and sp.get("ms_per_step"):
+            v = sorted(sp["ms_per_step"])
+            line["ms_per_step_other_boxes"] = {"min": v[0], "max": v[-1], "runs": len(v), "static": True, "source": "profiles/box_spread.json (%s)" % sp.get("note", "")}
+    except Exception:
+        pass
     line["network_pass"] = dict(tb.network_pass_report)   # which organisation of the network pass the Testbed measured faster on this workload and runs (Testbed.network_pass = 'auto')
     if weak is not None:
         line["weak_scaling"] = weak

@@ -98,57 +98,85 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
         t1 = time.perf_counter()
         tb.render(w, h, 1, True)
         ms.append((time.perf_counter() - t1) * 1e3)
+    n_samples = int(tb.render_samples_evaluated)
     out.update({"render_MP_per_s": round(w * h / (sum(ms) / len(ms) * 1e-3) / 1e6, 2), "render_ms_per_frame": round(sum(ms) / len(ms), 2), "render_ms_frames": [round(x, 2) for x in ms],
-                "render_res": [w, h], "render_network_samples_per_frame": int(tb.render_samples_evaluated)})
+                "render_res": [w, h], "render_network_samples_per_frame": n_samples, "render_samples_per_pixel": round(n_samples / float(w * h), 1)})
+    # the tracer against the network pass's byte model (588 B per network sample) over the WHOLE frame time of the last view: host hops, march, composite and the
+    # device -> host copy included, so this is a floor for the encoder's own rate (profiles/r05_a_fox_render_kernel_stats.txt: the encode kernel is 77 % of a frame's kernel time)
+    gbps = 588.0 * n_samples / (ms[-1] * 1e-3) / 1e9
+    out["render_roofline"] = {"kernel": "tracer frame (encode_planes_kernel + MLP kernel + march + composite)", "bound": "hbm", "achieved": round(gbps, 1), "peak": hbm_peak, "unit": "GB/s",
+                              "frac": round(gbps / hbm_peak, 4), "traffic": None, "samples": n_samples, "frame_ms": round(ms[-1], 2)}
+    # the Blender add-on's renderer on THIS model (its actual input: a snapshot of a real capture), same pinhole view for both renderers
+    try:
+        def set_view():
+            tb.set_camera_to_training_view(0)
+        tb.set_camera_to_training_view(0)
+        focal_px = 0.5 * float((w, h)[int(tb.fov_axis)]) / float(np.tan(0.5 * float(tb.fov) * np.pi / 180.0))
+        lo, hi = tb.aabb
+        bl = bl_render_on(tb, w, h, set_view, focal_px, (list(lo), list(hi)), ([lo[0] - 1.0, lo[1] - 1.0, lo[2] - 1.0], [hi[0] + 1.0, hi[1] + 1.0, hi[2] + 1.0]), 0.0, frames=4, n_nerfs_list=(1,))
+        out["bl_render"] = bl
+    except Exception as e:   # the leg's other numbers stand on their own
+        out["bl_render"] = {"failed": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
 def bl_render_leg(tb, ds, res, frames=6):
     """the Blender add-on's path on the headline model: snapshot -> NerfDescriptor -> request_nerf_render_sync (src/python_api.cu:306-330, src/nerf_renderer.cu:565-791)"""
+    def set_view():
+        tb.fov_axis = 0
+        tb.fov = ds["camera_angle_x"] * 180 / np.pi
+        tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+    return bl_render_on(tb, res, res, set_view, float(ds["focal"]), ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0]), ([-1.0, -1.0, -1.0], [2.0, 2.0, 2.0]), 0.45, frames)
+
+
+def bl_render_on(tb, w, h, set_view, focal, nerf_box, scene_box, second_nerf_shift, frames=6, n_nerfs_list=(1, 2)):
+    """the stock tracer and the Blender renderer on the SAME trained model, view, pinhole camera, background and termination threshold: ms per w x h frame each"""
     import pyngp
     tmp = tempfile.mkdtemp()
-    snap = os.path.join(tmp, "bench_lego.msgpack")
+    snap = os.path.join(tmp, "bench_model.msgpack")
     try:
         tb.save_snapshot(snap, False)
         tb.shall_train = False
         # the same view, field of view, background and termination threshold for both renderers: the Blender path reads min_transmittance from the field (0.01, the
         # reference's default for both: testbed.h:725, neural_radiance_field.cuh:63); bench.py's PSNR evaluation had set the stock tracer's to run.py's 1e-4
         tb.background_color = [0.0, 0.0, 0.0, 1.0]
-        tb.fov_axis = 0
-        tb.fov = ds["camera_angle_x"] * 180 / np.pi
         min_t_before = tb.nerf.render_min_transmittance
+        lens_before = tb.nerf.render_with_lens_distortion
         tb.nerf.render_min_transmittance = 0.01
-        tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+        set_view()
+        tb.nerf.render_with_lens_distortion = False   # the Blender camera is a pinhole (CameraModel.Perspective): the stock tracer renders the same rays
         for _ in range(3):
-            tb.render(res, res, 1, True)
+            tb.render(w, h, 1, True)
         ms = []
         for _ in range(frames):
             t0 = time.perf_counter()
-            tb.render(res, res, 1, True)
+            tb.render(w, h, 1, True)
             ms.append((time.perf_counter() - t0) * 1e3)
         tb.nerf.render_min_transmittance = min_t_before
+        tb.nerf.render_with_lens_distortion = lens_before
+        res = w if w == h else [w, h]
         out = {"res": res, "frames": frames, "min_transmittance": 0.01, "stock_render_ms": round(sum(ms) / frames, 2), "stock_render_ms_frames": [round(x, 2) for x in ms], "stock_network_samples": int(tb.render_samples_evaluated)}
-        focal = float(ds["focal"])
 
         def request(n_nerfs):
-            dsi = pyngp.DownsampleInfo.MakeFromMip([res, res], 0)
-            outp = pyngp.RenderOutputProperties([res, res], dsi, 1, pyngp.ColorSpace.SRGB, pyngp.TonemapCurve.Identity, 0.0, [0.0, 0.0, 0.0, 1.0], False)
+            dsi = pyngp.DownsampleInfo.MakeFromMip([w, h], 0)
+            outp = pyngp.RenderOutputProperties([w, h], dsi, 1, pyngp.ColorSpace.SRGB, pyngp.TonemapCurve.Identity, 0.0, [0.0, 0.0, 0.0, 1.0], False)
             cam = pyngp.RenderCameraProperties(tb.camera_matrix, pyngp.CameraModel.Perspective, focal, 0.0, 0.0, 1.0, pyngp.SphericalQuadrilateralConfig.Zero(), pyngp.QuadrilateralHexahedronConfig.Zero())
-            box = pyngp.BoundingBox([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+            box = pyngp.BoundingBox(list(nerf_box[0]), list(nerf_box[1]))
             nerfs = []
             for k in range(n_nerfs):
                 xf = np.eye(4, dtype=np.float32)
-                xf[0, 3] = 0.45 * k
+                xf[0, 3] = second_nerf_shift * k
                 nerfs.append(pyngp.NerfDescriptor(snap, box, xf, pyngp.RenderModifiers([]), 1.0))
-            big = pyngp.BoundingBox([-1.0, -1.0, -1.0], [2.0, 2.0, 2.0])
+            big = pyngp.BoundingBox(list(scene_box[0]), list(scene_box[1]))
             return pyngp.RenderRequest(outp, cam, pyngp.RenderModifiers([]), nerfs, big)
 
         bl = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+        bl.render_trace = bool(tb.render_trace)
         for knob, env in (("bl_max_skips_per_pass", "BL_SKIPS"), ("bl_pass_samples_factor", "BL_FACTOR"), ("bl_fused_passes", "BL_FUSED")):   # dev: schedule sweeps
             if os.environ.get(env):
                 setattr(bl, knob, type(getattr(bl, knob))(float(os.environ[env])))
         out["bl_schedule"] = {"fused_passes": bool(bl.bl_fused_passes), "max_skips_per_pass": int(bl.bl_max_skips_per_pass), "pass_samples_factor": float(bl.bl_pass_samples_factor), "max_steps_per_pass": int(bl.bl_max_steps_per_pass)}
-        for n in (1, 2):
+        for n in n_nerfs_list:
             req = request(n)
             for _ in range(5):                        # loads the snapshot(s), warms up (the 4th request of a fresh renderer takes 20-30 ms once: tools/bl_outlier_probe.py)
                 img = bl.request_nerf_render_sync(req)
