@@ -349,3 +349,76 @@ def test_two_nerf_frame_matches_oracle(ngp, oracle, cuda, with_masks):
         oracle.orc_multi_render(2, net_ptrs, par_ptrs, rp0.ctypes.data, rgb_act.ctypes.data, dens_act.ctypes.data, min_t.ctypes.data, ds.ctypes.data, cam.ctypes.data, 1,
                                 fb0.ctypes.data, db.ctypes.data)
         assert np.abs(fb0 - fb).max() > 0.05           # the masks change the picture
+
+
+def _sparse_cascaded_bitfield(oracle, p_occ, n_cascades, seed):
+    """4 x 4 x 4 bricks occupied with probability p_occ in each of the first n_cascades grids (Morton order), coarser mips max-pooled like update_density_grid_mean_and_bitfield"""
+    vol = 128 ** 3
+    rs = np.random.RandomState(seed)
+    bf = np.zeros(vol, np.uint8)   # 8 mips x vol / 8 bytes
+    x, y, z = np.meshgrid(np.arange(128), np.arange(128), np.arange(128), indexing="ij")
+
+    def part(v):
+        v = v.astype(np.uint32); v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
+        return v
+    m = (part(x) | (part(y) << 1) | (part(z) << 2)).ravel()
+    for c in range(n_cascades):
+        cells = rs.rand(32, 32, 32) < p_occ
+        full = np.repeat(np.repeat(np.repeat(cells, 4, 0), 4, 1), 4, 2)
+        bits = np.zeros(vol, np.uint8); bits[m] = full.ravel()
+        bf[c * vol // 8:(c + 1) * vol // 8] = np.packbits(bits, bitorder="little")
+    for lvl in range(1, 8):
+        oracle.orc_bitfield_max_pool(vol // 64, bf[(lvl - 1) * vol // 8:].ctypes.data, bf[lvl * vol // 8:].ctypes.data)
+    return bf
+
+
+@pytest.mark.parametrize("p_occ", [1.0, 0.3, 0.05])
+def test_sampler_with_cone_stepping_and_cascades_matches_oracle_and_the_stock_tracer(ngp, oracle, cuda, p_occ):
+    """every real capture has aabb_scale > 1: three or more cascades and cone stepping (dt = clamp(t / 256, ...), src/nerf_renderer.cu:174, 349).  The fork's march and
+    sampler on such a field — march_active_rays, then up to 900 steps of march_proxy_rays_and_generate_next_network_inputs — bit for bit against the oracle; and, because the
+    two samplers walk the same candidate sequence through the same occupancy, ray by ray the SAME NUMBER of samples as the stock tracer's generate_next_nerf_network_inputs
+    (src/testbed_nerf.cu:705-765): the fork's sampler emits before it tests and steps once past every landing point, which moves samples, not their count (+- 2 per gap)."""
+    vol = 128 ** 3
+    bf = _sparse_cascaded_bitfield(oracle, p_occ, 3, int(p_occ * 100))
+    d_bf = H.to_dev(bf, cuda)
+    n, n_steps = 256, 900
+    rs = np.random.RandomState(7)
+    dirs = rs.randn(n, 3).astype(np.float32); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    origin = np.float32([0.45, 0.5, 0.55])
+
+    def props(ptr):
+        p = _props(np.eye(4, dtype=np.float32), ptr, 0, 0, aabb_scale=4)
+        return p
+    rp, dp = props(bf.ctypes.data), props(d_bf.data_ptr())
+    assert float(rp["cone_angle"][0]) == 1.0 / 256.0
+    g = np.zeros(n, capi.GLOBAL_RAY); g["origin"] = origin; g["dir"] = dirs; g["alive"] = 1; g["idx"] = np.arange(n)
+    px = np.zeros(n, capi.PROXY_RAY); px["origin"] = origin; px["dir"] = dirs; px["t"] = 1e-5; px["alive"] = 1; px["active"] = 1; px["idx"] = np.arange(n)
+    d_g, d_px, d_props = H.to_dev(g, cuda), H.to_dev(px, cuda), H.to_dev(dp, cuda)
+    oracle.orc_multi_march_active_rays(n, 1, g.ctypes.data, px.ctypes.data, n, rp.ctypes.data)
+    check(ngp.ngp_hip_multi_march_active_rays(None, n, 1, d_g.data_ptr(), d_px.data_ptr(), n, d_props.data_ptr()))
+    got = H.to_host(d_px, capi.PROXY_RAY)
+    for f in ("alive", "t"):
+        np.testing.assert_array_equal(got[f], px[f], err_msg=f)
+    net_in = np.zeros(n * n_steps, capi.COORD); d_in = H.dev_zeros(net_in.nbytes, cuda)
+    oracle.orc_multi_generate_next_inputs(n, g.ctypes.data, px.ctypes.data, net_in.ctypes.data, n_steps, rp.ctypes.data)
+    check(ngp.ngp_hip_multi_generate_next_inputs(None, n, d_g.data_ptr(), d_px.data_ptr(), d_in.data_ptr(), n_steps, d_props.data_ptr()))
+    got = H.to_host(d_px, capi.PROXY_RAY)
+    for f in ("n_steps", "t", "alive"):
+        np.testing.assert_array_equal(got[f], px[f], err_msg=f)
+    got_in = H.to_host(d_in, capi.COORD)
+    steps = px["n_steps"].astype(np.int64)
+    for j in (0, 1, 5, 50, 300):
+        sel = np.nonzero((px["alive"] == 1) & (steps > j))[0]
+        for f in ("pos", "dt", "dir"):
+            np.testing.assert_array_equal(got_in[f][j * n + sel], net_in[f][j * n + sel], err_msg="%s step %d" % (f, j))
+    assert (steps > 5).sum() > n // 4 and len(np.unique(net_in["dt"][:n][steps > 0])) >= 1
+    # the stock tracer over the same rays and the same grids
+    aabb = H.unit_aabb(4)
+    pay = np.zeros(n, capi.PAYLOAD); pay["origin"] = origin; pay["dir"] = dirs; pay["t"] = 1e-5; pay["alive"] = 1; pay["idx"] = np.arange(n)
+    stock_in = np.zeros(n * n_steps, capi.COORD)
+    oracle.orc_generate_next_inputs(n, aabb.ctypes.data, aabb.ctypes.data, pay.ctypes.data, stock_in.ctypes.data, n_steps, bf.ctypes.data, 0, ctypes.c_float(1.0 / 256.0))
+    stock_steps = pay["n_steps"].astype(np.int64)
+    fin = (steps < n_steps) & (stock_steps < n_steps)          # rays that left the box on both sides
+    assert fin.sum() > n // 4
+    assert np.abs(steps[fin] - stock_steps[fin]).max() <= 2 + 0.05 * stock_steps[fin].max(), (steps[fin][:16], stock_steps[fin][:16])
+    assert abs(int(steps[fin].sum()) - int(stock_steps[fin].sum())) <= 0.03 * stock_steps[fin].sum() + 2 * fin.sum()
