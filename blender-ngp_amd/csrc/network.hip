@@ -457,8 +457,10 @@ __global__ void __launch_bounds__(256, PRE ? 4 : 2) nerf_forward_kernel(const Ng
 // 2 units, dense = 1), one per XCD, and a persistent workgroup pulls from the queue of the XCD it RUNS on (HW_REG_XCC_ID), so
 // that one XCD walks at most two tables in sequence and its L2 holds them.  Empty queue => steal from the next one.  The
 // placement only affects speed; any block may process any item.
-constexpr uint32_t ENC_CHUNK = 1024;
-constexpr uint32_t ENC_ITEMS_PER_CLAIM = 2;
+#ifndef NGP_ENC_CHUNK
+#define NGP_ENC_CHUNK 1024
+#endif
+constexpr uint32_t ENC_CHUNK = NGP_ENC_CHUNK;               // samples of one level per work item (build knobs: tools/gpu_r05_enc.sh sweeps them on the fox step's own samples)
 constexpr uint32_t ENC_QUEUE_STRIDE = 64;   // uint32 words between the 8 queue counters
 constexpr uint32_t ENC_QUEUE_BYTES = 8 * ENC_QUEUE_STRIDE * 4;
 
@@ -466,7 +468,7 @@ __device__ __forceinline__ uint32_t xcc_id() { uint32_t v; asm volatile("s_getre
 
 template <int D>   // 3: NeRF / SDF positions; 2: image fitting (ngp_hip_gridmlp_forward_ws)
 __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __restrict__ desc, const half_t* __restrict__ params, const float* __restrict__ coords,
-                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model, uint32_t grid_off) {
+                                                            uint32_t coord_stride, uint32_t n, uint32_t n_pad, h2* __restrict__ planes, uint32_t* __restrict__ queues, uint32_t cost_model, uint32_t grid_off, uint32_t items_per_claim) {
 	__shared__ uint32_t s_first[9];
 	__shared__ uint32_t s_item;
 	const uint32_t n_chunks = (n + ENC_CHUNK - 1) / ENC_CHUNK;
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 		const uint32_t k = (home + q) & 7u;
 		const uint32_t begin = s_first[k], end = s_first[k + 1];
 		uint32_t* counter = queues + k * ENC_QUEUE_STRIDE;  // one counter per 256-B line: same-address atomics serialise at the memory side
-		const uint32_t n_claims = (end - begin + ENC_ITEMS_PER_CLAIM - 1) / ENC_ITEMS_PER_CLAIM;
+		const uint32_t n_claims = (end - begin + items_per_claim - 1) / items_per_claim;
 		for (;;) {
 			if (threadIdx.x == 0) {
 				// stealing (q > 0) looks before it claims, so that the 2048 x 7 visits of drained queues stay plain loads
@@ -511,8 +513,8 @@ __global__ void __launch_bounds__(256) encode_planes_kernel(const NgpNetDesc* __
 			const uint32_t claim = __builtin_amdgcn_readfirstlane(s_item);
 			__syncthreads();
 			if (claim >= n_claims) break;
-			const uint32_t item0 = begin + claim * ENC_ITEMS_PER_CLAIM;
-			const uint32_t item1 = item0 + ENC_ITEMS_PER_CLAIM < end ? item0 + ENC_ITEMS_PER_CLAIM : end;
+			const uint32_t item0 = begin + claim * items_per_claim;
+			const uint32_t item1 = item0 + items_per_claim < end ? item0 + items_per_claim : end;
 			for (uint32_t item = item0; item < item1; ++item) {
 				const uint32_t level = item / n_chunks, chunk = item - level * n_chunks;
 				const NgpGridLevel lv = desc->levels[level];
@@ -2393,10 +2395,14 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	}
 	NGP_HIP_TRY(hipMemsetAsync(queues, 0, ENC_QUEUE_BYTES, (hipStream_t)stream));
 	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
-	const uint32_t blocks = items < 2048u ? items : 2048u;  // persistent: 8 workgroups per CU
+	// persistent workgroups and items per claim by the size of the pass (round 5, profiles/r05_encoder_constants.md: swept on a fox step's own 515 k samples and on 2^18 ... 8 M random points): a
+	// small pass wants single-item claims (its tail is a third of it), a large one four items per claim; four workgroups per CU beat eight at every size
+	const uint32_t blocks_default = 1024u, claim_default = items <= 12288u ? 1u : items <= 32768u ? 2u : 4u;
+	const uint32_t blocks_cap = ngp_dev_knob_u32("NGP_HIP_ENC_BLOCKS", blocks_default), items_per_claim = ngp_dev_knob_u32("NGP_HIP_ENC_CLAIM", claim_default);
+	const uint32_t blocks = items < blocks_cap ? items : blocks_cap;
 	static const uint32_t cost_model = ngp_dev_knob_u32("NGP_HIP_ENC_COST", 0u);   // dev: A / B of the queue cut
-	if (n_dims == 2) hipLaunchKernelGGL(encode_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
-	else hipLaunchKernelGGL(encode_planes_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off);
+	if (n_dims == 2) hipLaunchKernelGGL(encode_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off, items_per_claim);
+	else hipLaunchKernelGGL(encode_planes_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, desc_dev, (const half_t*)params, coords, stride, n, n_pad, planes, queues, cost_model, grid_off, items_per_claim);
 	NGP_LAUNCH_CHECK("encode_planes_kernel");
 	*planes_out = planes; *n_pad_out = n_pad;
 	return 0;
