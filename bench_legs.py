@@ -10,6 +10,7 @@ lego stand-in is measured HERE, inside the driver's run, or not quoted at all (V
 
 All legs run on rank 0 of a one-GPU run, after the headline's timed region, each bounded to a few seconds.
 """
+import json
 import os
 import sys
 import tempfile
@@ -82,7 +83,16 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
            "n_params": int(tb.n_params()), "network_pass": network_pass, "kernels": kernels, "kernels_note": "HIP events on the launch streams, %d untimed survey steps" % survey_steps}
     if "nerf_backward" in kernels and "algorithmic_GBps" in kernels["nerf_backward"]:
         k = kernels["nerf_backward"]
-        out["roofline"] = {"kernel": "nerf_backward", "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": hbm_peak, "unit": "GB/s", "frac": round(k["algorithmic_GBps"] / hbm_peak, 4), "traffic": None}
+        traffic, traffic_source = None, None
+        try:   # static text, like the headline's: L2 <-> fabric bytes per call of the group from two separate --pmc passes over THIS leg on another box, quoted while the kernel set matches
+            import bench
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_fox.json")))
+            if tj.get("_meta", {}).get("kernel_set") == bench.KERNEL_SET:
+                traffic, traffic_source = tj.get("nerf_backward"), "profiles/pmc_traffic_fox.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench_legs.py fox`" % tj["_meta"].get("tag")
+        except Exception:
+            pass
+        out["roofline"] = {"kernel": "nerf_backward", "bound": "hbm", "achieved": k["algorithmic_GBps"], "peak": hbm_peak, "unit": "GB/s", "frac": round(k["algorithmic_GBps"] / hbm_peak, 4), "traffic": traffic,
+                           "traffic_static": traffic is not None, "traffic_source": traffic_source}
     # render at the photographs' size from a training view (pose, intrinsics and lens of the view: testbed.cu:273-281)
     tb.shall_train = False
     tb.background_color = [0.0, 0.0, 0.0, 1.0]

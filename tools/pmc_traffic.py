@@ -19,7 +19,8 @@ STAGES = [("nerf_forward_kernelILi2ELi0E", "nerf_inference"),   # the training s
           ("nerf_backward_fused_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("gb_fx_bin_kernel", "nerf_backward"), ("gb_fx_scan_kernel", "nerf_backward"),
           ("nerf_wgrad_kernel", "nerf_backward"), ("wgrad_reduce_kernel", "nerf_backward"), ("adam_ema", "optimizer_step"),
-          ("generate_training_samples_kernel", "generate_training_samples"), ("generate_training_samples_wave_kernel", "generate_training_samples"), ("expand_training_samples_kernel", "generate_training_samples"),
+          ("generate_training_samples_kernel", "generate_training_samples"), ("generate_training_samples_wave_kernel", "generate_training_samples"), ("generate_training_samples_cone_wave_kernel", "generate_training_samples"),
+          ("expand_training_samples_kernel", "generate_training_samples"),
           ("compute_loss_kernel", "compute_loss")]
 
 
