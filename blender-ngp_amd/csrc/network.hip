@@ -774,7 +774,7 @@ __device__ __forceinline__ void gb_bin_hashed(uint32_t* __restrict__ hist, uint3
 	__syncthreads();
 	// An item leaves as a finished RECORD: the two x-corner entries inside the slice and their four fp16 terms half(w * dL/dx) — this pass has the position and dL/dx in
 	// registers anyway.  The owners then stream 12-byte records instead of gathering a position and a dL/dx pair per item (two random L2 requests each: what bound them).
-	GbRecord* __restrict__ out = (GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
+	GbRecord* __restrict__ out = (GbRecord*)sums;   // the level's own record space (gb_level_records)
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
 		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
@@ -966,7 +966,7 @@ __device__ __forceinline__ void gb_bin_dense(uint32_t* __restrict__ hist, uint32
 		base[threadIdx.x] = hist[threadIdx.x] ? start + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
 	}
 	__syncthreads();
-	gb_dense_walk<D, true>(s_g, s_px, s_py, s_pz, base, lv, chunk_bin0, n_live, items + (size_t)level * n * GB_ITEMS_PER_SAMPLE, sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
+	gb_dense_walk<D, true>(s_g, s_px, s_py, s_pz, base, lv, chunk_bin0, n_live, items, sums);
 }
 
 // Dense level of a batch WITHOUT ray order (image fitting, SDF: stratified / random positions — consecutive samples share no cell, so the run-merging walk above emits 8 (4 in 2-D) 20-byte
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void gb_bin_dense_pairs(uint32_t* __restrict__ hist, 
 		base[threadIdx.x] = hist[threadIdx.x] ? start + atomicAdd(&ctr->cursors[level][threadIdx.x], hist[threadIdx.x]) : 0u;
 	}
 	__syncthreads();
-	GbRecord* __restrict__ out = (GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE);
+	GbRecord* __restrict__ out = (GbRecord*)sums;   // the level's own record space (gb_level_records)
 #pragma unroll
 	for (int u = 0; u < PER; ++u) {
 		const LevelPos p = level_pos(lv, px[u], py[u], pz[u]);
@@ -1099,10 +1099,55 @@ __device__ __forceinline__ void wgrad_reduce_rows(const WgradJob& j, uint32_t wg
 	}
 }
 
+// Record space of the binned path: the levels' records are packed back to back, each level with the worst case of ITS kind — a hashed level one 12-byte record per
+// (sample, (y, z) corner pair), two where the level is fine enough for the x corners to straddle a slice (resolution >= 4096); a dense one at most 8 merged records per
+// sample, {entry} (4 bytes, the level's first n * 8 words) and {two 64-bit sums} (16 bytes, behind them), or, for a batch that is not in ray order, its pair records (at
+// most two per pair: 96 bytes); a level of the float path nothing.  (Up to round 5 every level had the dense worst case: 160 bytes per sample and level, 671 MB at
+// n = 2^18 whatever the level table; base.json's 5 dense + 11 hashed levels need 348 MB.)  The host lays the levels out and hands the offsets to the kernels.
+template <int D>
+__host__ __device__ __forceinline__ uint64_t gb_level_record_bytes(const NgpGridLevel& lv, uint32_t n) {
+	const bool dense = level_is_dense<D>(lv);
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) return (uint64_t)n * (D == 3 ? 4u : 2u) * (lv.resolution >= GB_FX_SLICE ? 2u : 1u) * sizeof(GbRecord);
+	if (dense && gb_dense_binned(lv.size)) return (uint64_t)n * GB_ITEMS_PER_SAMPLE * (4u + 16u);
+	return 0;
+}
+struct GbRecordOffsets { uint64_t off[17]; };   // byte offset of every level's record space; [16] = the total
+template <int D>
+static GbRecordOffsets gb_record_offsets(const NgpNetDesc* desc_host, uint32_t n) {   // no level table at hand: every level at the dense worst case
+	GbRecordOffsets r;
+	uint64_t total = 0;
+	for (int l = 0; l < 16; ++l) { r.off[l] = total; total += desc_host ? gb_level_record_bytes<D>(desc_host->levels[l], n) : (uint64_t)n * GB_ITEMS_PER_SAMPLE * (4u + 16u); }
+	r.off[16] = total;
+	return r;
+}
+struct GbLevelRecords { uint32_t* items; ulonglong2* sums; };
+__device__ __forceinline__ GbLevelRecords gb_level_records(const GbRecordOffsets& offsets, uint32_t level, uint32_t n, void* records, bool dense_merged) {
+	const uint64_t off = offsets.off[level];
+	GbLevelRecords r;
+	r.items = (uint32_t*)((char*)records + off);
+	r.sums = (ulonglong2*)((char*)records + off + (dense_merged ? (uint64_t)n * GB_ITEMS_PER_SAMPLE * 4u : 0ull));
+	return r;
+}
+static uint64_t gb_wg_hist_bytes(uint32_t n) { return (uint64_t)16 * ((n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u; }
+template <int D>
+static uint64_t gb_records_bytes(const NgpNetDesc* desc_host, uint32_t n) { return gb_record_offsets<D>(desc_host, n).off[16]; }
+
+// private copies of the levels: a dense level's (level * GB_D_ITEMS + bin) fixed-point slices fill 1 MiB per level; only a level of the float path needs its 4 MiB
+template <int D>
+static uint64_t gb_partials_bytes(const NgpNetDesc* desc_host) {
+	if (!desc_host) return (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES;
+	for (int l = 0; l < 16; ++l) {
+		const NgpGridLevel& lv = desc_host->levels[l];
+		const bool dense = level_is_dense<D>(lv);
+		if (!gb_uses_fx(lv.size, lv.resolution, dense) && !(dense && gb_dense_binned(lv.size))) return (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES;
+	}
+	return (uint64_t)16 * GB_D_ITEMS * GB_FX_SLICE * 16u;
+}
+
 template <int D, bool SCATTER, bool ORDERED = true>   // ORDERED: the batch is in ray order (NeRF training): dense levels merge runs of samples that share a cell; false: pair records
 // (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? 4 : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
-                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, uint32_t* __restrict__ items, ulonglong2* __restrict__ sums, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
+                                                        const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, void* __restrict__ records, const GbRecordOffsets rec_off, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
                                                         WgradJob wgrad) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
@@ -1121,9 +1166,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTE
 	if (!fx && !dense) return;   // float path of the owners: no binning
 	if (threadIdx.x < GB_FX_MAX_SLICES) hist[threadIdx.x] = 0;
 	__syncthreads();
-	if (dense && !ORDERED) gb_bin_dense_pairs<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
-	else if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, items, sums, wg_hist);
-	else gb_bin_hashed<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, sums);
+	const GbLevelRecords rec = gb_level_records(rec_off, level, n, records, dense && ORDERED);
+	if (dense && !ORDERED) gb_bin_dense_pairs<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, rec.sums);
+	else if (dense) gb_bin_dense<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, rec.items, rec.sums, wg_hist);
+	else gb_bin_hashed<D, SCATTER>(hist, base, stage, lv, level, coords, coord_stride, n, dx_planes, ctr, rec.sums);
 }
 
 // pass 4: the owner of (level, slice) adds its items into 8192 x 2 64-bit fixed-point words in LDS and writes the final fp16 gradients
@@ -1140,7 +1186,7 @@ __device__ __forceinline__ void gb_fx_accumulate(unsigned long long* __restrict_
 	}
 	for (uint32_t i = threadIdx.x; i < 2 * GB_FX_SLICE; i += blockDim.x) slice64[i] = 0ull;
 	__syncthreads();
-	const GbRecord* __restrict__ my = (const GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE) + gb_owner_start(ctr, level, sl, s_start);
+	const GbRecord* __restrict__ my = (const GbRecord*)sums + gb_owner_start(ctr, level, sl, s_start);
 	constexpr uint32_t UN = 8;
 	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
 		GbRecord r[UN];
@@ -1178,7 +1224,7 @@ __device__ __forceinline__ void gb_dense_owner(unsigned long long* __restrict__ 
 	const uint32_t count = ctr->totals[level][bin];
 	for (uint32_t i = threadIdx.x; i < 2 * cnt; i += blockDim.x) slice64[i] = 0ull;
 	__syncthreads();
-	const size_t first = (size_t)level * n * GB_ITEMS_PER_SAMPLE + gb_owner_start(ctr, level, bin, s_start);
+	const size_t first = gb_owner_start(ctr, level, bin, s_start);
 	const uint32_t* __restrict__ my_e = items + first;
 	const ulonglong2* __restrict__ my_v = sums + first;
 	constexpr uint32_t UN = 4;
@@ -1215,7 +1261,7 @@ __device__ __forceinline__ void gb_dense_pairs_owner(unsigned long long* __restr
 	const uint32_t count = ctr->totals[level][bin];
 	for (uint32_t i = threadIdx.x; i < 2 * cnt; i += blockDim.x) slice64[i] = 0ull;
 	__syncthreads();
-	const GbRecord* __restrict__ my = (const GbRecord*)(sums + (size_t)level * n * GB_ITEMS_PER_SAMPLE) + gb_owner_start(ctr, level, bin, s_start);
+	const GbRecord* __restrict__ my = (const GbRecord*)sums + gb_owner_start(ctr, level, bin, s_start);
 	constexpr uint32_t UN = 8;
 	for (uint32_t i0 = threadIdx.x; i0 < count; i0 += blockDim.x * UN) {
 		GbRecord r[UN];
@@ -1263,7 +1309,7 @@ __host__ __device__ __forceinline__ uint32_t gb_level_owners(const NgpGridLevel&
 template <int D, bool ORDERED = true>   // D = 3: NeRF / SDF; D = 2: image fitting (4 corners, no z term); ORDERED: as gb_fx_bin_kernel
 __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                              const h2* __restrict__ dx_planes, void* __restrict__ partials_raw,
-                                                             const GbFxCounters* __restrict__ ctr, const uint32_t* __restrict__ items, const ulonglong2* __restrict__ sums, h2* __restrict__ grid_grad, uint32_t level_mask,
+                                                             const GbFxCounters* __restrict__ ctr, void* __restrict__ records, const GbRecordOffsets rec_off, h2* __restrict__ grid_grad, uint32_t level_mask,
                                                              const GbOwnerMap map) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	constexpr int NC = 1 << D;
@@ -1279,10 +1325,11 @@ __global__ void __launch_bounds__(1024, 8) grid_backward_kernel(const NgpNetDesc
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation (tools/gb_level_probe.py); all ones in production
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv);
-	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, n, ctr, sums, grid_grad, &s_start); return; }
+	if (gb_uses_fx(lv.size, lv.resolution, dense)) { gb_fx_accumulate<D>(slice64, lv, level, item, n, ctr, gb_level_records(rec_off, level, n, records, false).sums, grid_grad, &s_start); return; }
 	if (dense && gb_dense_binned(lv.size)) {
-		if (ORDERED) gb_dense_owner(slice64, lv, level, item, n, ctr, items, sums, (unsigned long long*)partials_raw, grid_grad, &s_start);
-		else gb_dense_pairs_owner(slice64, lv, level, item, n, ctr, sums, (unsigned long long*)partials_raw, grid_grad, &s_start);
+		const GbLevelRecords rec = gb_level_records(rec_off, level, n, records, ORDERED);
+		if (ORDERED) gb_dense_owner(slice64, lv, level, item, n, ctr, rec.items, rec.sums, (unsigned long long*)partials_raw, grid_grad, &s_start);
+		else gb_dense_pairs_owner(slice64, lv, level, item, n, ctr, rec.sums, (unsigned long long*)partials_raw, grid_grad, &s_start);
 		return;
 	}
 	h2* __restrict__ slice = (h2*)slice64;
@@ -2146,21 +2193,21 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
                                 const NgpNetDesc* desc_host = nullptr /* the level table on the host: only the owners that own something are launched */) {
 	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
-	uint32_t* items = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);
-	ulonglong2* sums = (ulonglong2*)((char*)items + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 4u);
+	uint32_t* wg_hist = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);   // the dense levels' per-workgroup bin counts
+	void* records = (char*)wg_hist + gb_wg_hist_bytes(n);                         // gb_level_records: the levels' record spaces, packed
+	const GbRecordOffsets rec_off = gb_record_offsets<D>(desc_host, n);          // (no host level table: every level at the worst case, as sized by the *_scratch_bytes(n) functions)
 	const uint32_t level_mask = ngp_dev_knob_u32("NGP_HIP_GB_LEVELS", 0xffffu);   // dev-only timing ablation, re-read per launch in the development build (tools/gb_level_probe.py flips it); a constant in the product library (ngp_dev_knobs.h)
 	if (!counters_cleared) NGP_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(GbFxCounters), st));
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	const dim3 count_grid(bin_grid.x, 16u + (wgrad.partials ? div_up(div_up(wgrad.n_params, 64u), bin_grid.x) : 0u));
 	const WgradJob no_job{nullptr, 0u, nullptr, 0u};
-	uint32_t* wg_hist = (uint32_t*)((char*)sums + (size_t)16 * n * GB_ITEMS_PER_SAMPLE * 16u);
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, wgrad);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
 	// (round 5: write-combining the records through LDS — ranks and a per-bin image in LDS, coalesced copy-out — was built in two versions and measured slower than these
 	// register-to-global stores: the pass is within 1.5x of the rate at which the part writes its 76-138 MB of records; profiles/r05_experiments.md)
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, items, sums, wg_hist, level_mask, no_job);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	static const uint32_t owner_threads = ngp_dev_knob_u32("NGP_HIP_GB_OWNER_THREADS", 1024u);   // dev: sweep (256 / 512 / 1024)
 	GbOwnerMap map{};
@@ -2171,8 +2218,8 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 		map.start[16] = total; map.compact = 1u;
 		owner_grid = dim3(total ? total : 1u, 1);
 	}
-	if (ordered) hipLaunchKernelGGL((grid_backward_kernel<D, true>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask, map);
-	else hipLaunchKernelGGL((grid_backward_kernel<D, false>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, (const uint32_t*)items, (const ulonglong2*)sums, grid_grad, level_mask, map);
+	if (ordered) hipLaunchKernelGGL((grid_backward_kernel<D, true>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, records, rec_off, grid_grad, level_mask, map);
+	else hipLaunchKernelGGL((grid_backward_kernel<D, false>), owner_grid, dim3(owner_threads), 0, st, desc_dev, pos, stride, n, dx_planes, (void*)gb_partials, (const GbFxCounters*)ctr, records, rec_off, grid_grad, level_mask, map);
 	NGP_LAUNCH_CHECK("grid_backward_kernel");
 	hipLaunchKernelGGL(grid_combine_kernel, dim3(128, 16), dim3(256), 0, st, desc_dev, (const void*)gb_partials, grid_grad, (uint32_t)D);
 	NGP_LAUNCH_CHECK("grid_combine_kernel");
@@ -2456,20 +2503,24 @@ int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 constexpr uint32_t FB_MAX_WORKGROUPS = 512;   // two resident workgroups per CU
 static uint64_t scratch_off_dx(uint32_t) { return (uint64_t)FB_MAX_WORKGROUPS * NGP_MLP_N_PARAMS * 4u; }
 static uint64_t scratch_off_gb(uint32_t n) { return scratch_off_dx(n) + (uint64_t)16 * n * 4u; }
-static uint64_t gb_fx_bytes(uint32_t n) {   // counters + item lists + run sums of the binned path + the dense levels' per-workgroup bin counts
-	return GB_FX_COUNTER_BYTES + (uint64_t)16 * n * GB_ITEMS_PER_SAMPLE * (4u + 16u) + (uint64_t)16 * ((n + GB_FX_CHUNK - 1) / GB_FX_CHUNK) * GB_FX_MAX_SLICES * 4u;
+// the binned path's part: counters, the dense levels' per-workgroup bin counts, the levels' record spaces (gb_level_records) — for a given level table, or (no table) for any
+static uint64_t gb_fx_bytes_for(const NgpNetDesc* desc_host, uint32_t n_dims, uint32_t n) {
+	return GB_FX_COUNTER_BYTES + gb_wg_hist_bytes(n) + (n_dims == 2 ? gb_records_bytes<2>(desc_host, n) : gb_records_bytes<3>(desc_host, n));
 }
-static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_gb(n) + (uint64_t)16 * GB_PARTIAL_LEVEL_BYTES; }
+static uint64_t gb_fx_bytes(uint32_t n) { return gb_fx_bytes_for(nullptr, 3, n); }
+static uint64_t scratch_off_fx_for(const NgpNetDesc* desc_host, uint32_t n) { return scratch_off_gb(n) + gb_partials_bytes<3>(desc_host); }
+static uint64_t scratch_off_fx(uint32_t n) { return scratch_off_fx_for(nullptr, n); }
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n) { return scratch_off_fx(n) + gb_fx_bytes(n); }
+uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, uint32_t n) { return scratch_off_fx_for(desc_host, n) + gb_fx_bytes_for(desc_host, 3, n); }
 
 static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                               uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput);
 
-static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
+static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
                         const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
-	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n)) { set_last_error("ngp_hip_nerf_backward: scratch too small (ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n), or ngp_hip_nerf_backward_scratch_bytes(n) without a host level table)", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
 	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
 	GenExtra ex; ex.extra_dims = v->extra_dims; ex.sample_slot = v->sample_slot;
@@ -2486,22 +2537,22 @@ static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* 
 	NGP_LAUNCH_CHECK("gen_backward_kernel");
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(L.n_mlp, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, L.n_mlp);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
-	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + L.n_mlp), false)) return -1;
+	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx_for(desc_host, n), (h2*)(grads + L.n_mlp), false, true, WgradJob{nullptr, 0u, nullptr, 0u}, desc_host)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
 
 // recompute + dgrad + weight gradients of a network variant on the MFMA kernels (one or two launches of nx_backward_kernel), then the hash-grid backward
-static int nx_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
+static int nx_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
                        const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
-	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n)) { set_last_error("ngp_hip_nerf_backward: scratch too small (ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n), or ngp_hip_nerf_backward_scratch_bytes(n) without a host level table)", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
 	const GenLayout L = gen_layout(v->n_extra_dims, v->n_rgb_hidden_layers);
 	float* partials = (float*)scratch;                                    // [grid][n_mlp] fp32 (<= 256 x 15 360 x 4 B: inside the fused path's 512 x 10 240 x 4 B)
 	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
 	h2* gb_partials = (h2*)((char*)scratch + scratch_off_gb(n));
-	uint32_t* zero_words = (uint32_t*)((char*)scratch + scratch_off_fx(n));
+	uint32_t* zero_words = (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n));
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < 256u ? n_quads : 256u;                // one workgroup per CU (up to 100 KiB of LDS)
 	NxBwdArgs a{desc_dev, (const half_t*)params, coords, stride, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride, dx_planes, partials, zero_words, (uint32_t)(sizeof(GbFxCounters) / 4),
@@ -2515,7 +2566,7 @@ static int nx_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* d
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
 	hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(div_up(L.n_mlp, 64)), dim3(64 * WR_WAVES), 0, st, (const float*)partials, grid, (half_t*)grads, L.n_mlp);
 	NGP_LAUNCH_CHECK("wgrad_reduce_kernel");
-	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + L.n_mlp), true)) return -1;
+	if (launch_grid_backward<3>(st, desc_dev, coords, stride, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx_for(desc_host, n), (h2*)(grads + L.n_mlp), true, true, WgradJob{nullptr, 0u, nullptr, 0u}, desc_host)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
@@ -2525,9 +2576,9 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant) {
 	if (variant_check(variant, "ngp_hip_nerf_backward: at most 16 extra dims and 3 hidden colour layers")) return -1;
 	if (variant_is_generic(variant)) {
-		if (!variant_scalar(variant)) return nx_backward(stream, variant, desc_dev, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
+		if (!variant_scalar(variant)) return nx_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
 		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }
-		return gen_backward(stream, variant, desc_dev, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
+		return gen_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
 	}
 	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
 }
@@ -2564,7 +2615,7 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                               uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
-	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes(n)) { set_last_error("ngp_hip_nerf_backward: scratch too small", hipErrorInvalidValue); return -1; }
+	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n)) { set_last_error("ngp_hip_nerf_backward: scratch too small (ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n), or ngp_hip_nerf_backward_scratch_bytes(n) without a host level table)", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
 	float* partials = (float*)scratch;
 	h2* dx_planes = (h2*)((char*)scratch + scratch_off_dx(n));
@@ -2572,9 +2623,9 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
 	if (dL_dinput) hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-	                                  dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), dL_dinput);
+	                                  dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), dL_dinput);
 	else hipLaunchKernelGGL(nerf_backward_fused_kernel<false>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr);
+	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
 	if (dL_dinput) {
 		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const h2*)dx_planes, dL_dinput, (uint32_t)GRID_OFF);
@@ -2583,7 +2634,7 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics).  The weight-gradient partials are summed by extra
 	// rows of the hash-grid backward's first launch.
-	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx(n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
+	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx_for(desc_host, n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
 	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS}, desc_host)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;

@@ -142,8 +142,14 @@ int ngp_hip_nerf_density_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint16_t* params, const float* coords, uint32_t coord_stride_floats,
                             uint32_t n, uint16_t* out, uint32_t out_stride, uint16_t* x_saved, void* workspace, uint64_t workspace_bytes, const NgpNetVariant* variant);
 
-/* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only. */
+/* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only.
+ *   ..._bytes(n)                  enough for ANY level table (every level priced as a dense one: 160 bytes of sort records per sample and level);
+ *   ..._bytes_for(desc_host, n)   what THIS level table needs: the records of the 16 levels are packed, a hashed level takes 48 bytes per sample, a dense one 160
+ *                                 (configs/nerf/base.json at n = 2^18: 453 MB instead of 776 MB).  A caller that sizes its scratch this way passes the same
+ *                                 `desc_host` to ngp_hip_nerf_backward, and `desc_dev` must be a device copy of exactly that struct: host and device derive the
+ *                                 record offsets from their own copy (desc_host == NULL: the size check falls back to ..._bytes(n)). */
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
+uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, uint32_t n);
 
 /* NerfNetwork::backward_impl (nerf_network.h:187-266) with EGradientMode::Overwrite; call site src/testbed_nerf.cu:3331.
  * dL_dout: fp16 [n][dl_stride] with channels 0..3 consumed (extract_rgb 46-60, add_density_gradient 63-74).

@@ -44,6 +44,20 @@ def test_host_only_entry_points(ngp):
     d = H.make_desc(ngp, 15, 16, 1)
     assert int(d["n_levels"][0]) == 16 and ngp.ngp_hip_net_n_params_host(d.ctypes.data) == 10240 + 2 * int(d["n_grid_entries"][0])
     assert 16 * (1 << 18) * 4 < ngp.ngp_hip_nerf_backward_scratch_bytes(1 << 18) < (1 << 30)   # dL/dx planes + binning lists; no activation planes (fused backward)
+    # sized for a level table: the 16 levels' sort records packed by kind (hashed 48 bytes per sample, dense 160), private copies only where a level needs them
+    n = 1 << 18
+    any_table = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    assert ngp.ngp_hip_nerf_backward_scratch_bytes_for(None, n) == any_table
+    for aabb_scale, n_dense in ((1, 5), (4, 4)):
+        big = H.make_desc(ngp, 19, 16, aabb_scale)
+        dense = [int(l["resolution"]) ** 3 <= int(l["size"]) for l in big["levels"][0]]
+        assert sum(dense) == n_dense
+        packed = ngp.ngp_hip_nerf_backward_scratch_bytes_for(big.ctypes.data, n)
+        fine = sum(int(l["resolution"]) >= 4096 for l in big["levels"][0])                    # a pair's x corners can straddle a 4096-entry slice there: two records per pair
+        assert fine == (2 if aabb_scale == 4 else 0)
+        # hashed levels at 48 (96 where fine) instead of 160 bytes per sample; 16 instead of 64 MiB of private copies
+        assert any_table - packed == ((16 - n_dense - fine) * (160 - 48) + fine * (160 - 96)) * n + 48 * (1 << 20)
+        assert packed < 410e6 < 770e6 < any_table
     bad = np.zeros(1, H.NET_DESC)
     assert ngp.ngp_hip_net_make_desc_host(8, 19, 16, H.f32(1.5), bad.ctypes.data) != 0  # only L = 16 is built
     assert b"n_levels" in ngp.ngp_hip_last_error()

