@@ -40,6 +40,13 @@ def _group_table(prof, bytes_per_unit):
     return out
 
 
+def dev_overrides(tb):
+    """dev A / B switches of the bench scripts (never read by the library): NGP_BENCH_SIDE_EMA=0 puts the optimizer step's Ema stage back on the training chain"""
+    if os.environ.get("NGP_BENCH_SIDE_EMA") is not None:
+        tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
+    return tb
+
+
 def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_peak=8000.0, network_pass=None):
     """config #2: the fox photographs through `load_training_data` (host/nerf_loader.cpp + jpeg_reader.cpp), default base.json, B = 2^18."""
     if not os.path.exists(FOX):
@@ -48,6 +55,7 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
     B = 1 << 18
     t_load = time.perf_counter()
     tb = pyngp.Testbed(pyngp.TestbedMode.Nerf)
+    dev_overrides(tb)
     tb.load_training_data(FOX)
     tb.reload_network_from_file(os.path.join(CFG, "nerf", "base.json"))
     t_load = time.perf_counter() - t_load
@@ -230,6 +238,7 @@ def plumbing_leg(steps=200, warmup=100):
     rs = np.random.RandomState(0)
     for mode in ("image", "sdf"):
         tb = pyngp.Testbed(pyngp.TestbedMode.Image if mode == "image" else pyngp.TestbedMode.Sdf)
+        dev_overrides(tb)
         if mode == "image":
             img, what = _albert()
             tb.set_image_data(np.ascontiguousarray(img))
@@ -333,5 +342,6 @@ if __name__ == "__main__":   # dev: one leg on its own, e.g. under rocprofv3:  p
         dev = torch.device("cuda", 0)
         ds = scene.make_dataset(100, 1, 800, dev)
         tb = scene.build_testbed(ds)
+        dev_overrides(tb)
         scene.train(tb, int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
         print(json.dumps(bl_render_leg(tb, ds, 800)))

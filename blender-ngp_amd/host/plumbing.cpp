@@ -22,6 +22,7 @@ static constexpr uint32_t BATCH_SIZE_GRANULARITY = 128;     // tcnn::batch_size_
 static inline uint32_t next_multiple(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 void Testbed::reset_network_gridmlp() {  // testbed.cu:2249-2470, Image / Sdf branch (2397-2445)
+	join_side_ema();
 	tuner_reset();
 	m_rng = Pcg32(m_seed);
 	m_windowless_render_surface.reset_accumulation();
@@ -173,6 +174,7 @@ void Testbed::render_image(RenderBuffer& rb) {  // testbed_image.cu:293-360 (no 
 	const float sc[2] = {m_screen_center[0] - 0.5f, m_screen_center[1] - 0.5f};
 	HIP_TRY(hipMemsetAsync(m_image.render_coords.data(), 0, (size_t)n_elements * 8, (hipStream_t)m_stream));
 	check(ngp_hip_image_init_coords(m_stream, m_image.render_coords.as<float>(), rb.res, m_image.resolution, m_scale, m_image.pos, sc, m_snap_to_pixel_centers, rb.spp), "image_init_coords");
+	join_side_ema();
 	check(ngp_hip_gridmlp_forward(m_stream, 2, m_desc_gpu.as<NgpNetDesc>(), m_inference_params.as<uint16_t>(), m_image.render_coords.as<float>(), 2, n_elements, m_image.render_out.as<uint16_t>(),
 	                              GM_OUT_STRIDE, nullptr), "gridmlp_forward (render)");
 	check(ngp_hip_image_shade(m_stream, rb.res, m_image.render_coords.as<float>(), m_image.render_out.as<uint16_t>(), GM_OUT_STRIDE, rb.frame_buffer.as<float>(), rb.depth_buffer.as<float>(),
@@ -191,6 +193,7 @@ float Testbed::compute_image_mse(bool quantize_to_byte) {  // testbed_image.cu:4
 		const uint32_t batch = (count + 255u) & ~255u;
 		check(ngp_hip_image_coords_from_idx(m_stream, batch, offset, pos.as<float>(), m_image.resolution), "image_coords_from_idx");
 		check(ngp_hip_image_eval_and_snap(m_stream, batch, m_image.data.data(), m_image.type, pos.as<float>(), m_image.resolution, targets.as<float>(), 3, 1, m_image.linear_colors), "eval_image_and_snap");
+		join_side_ema();
 		check(ngp_hip_gridmlp_forward(m_stream, 2, m_desc_gpu.as<NgpNetDesc>(), m_inference_params.as<uint16_t>(), pos.as<float>(), 2, batch, pred.as<uint16_t>(), GM_OUT_STRIDE, nullptr), "gridmlp_forward (mse)");
 		check(ngp_hip_image_mse(m_stream, count, targets.as<float>(), pred.as<uint16_t>(), GM_OUT_STRIDE, m_image.se.as<float>() + offset, quantize_to_byte), "image_mse");
 	}

@@ -443,6 +443,7 @@ PYBIND11_MODULE(pyngp, m) {
 				DeviceBuffer d_pos, d_out;
 				d_pos.resize((size_t)n * n_dims * 4); d_out.resize((size_t)n * 8);
 				d_pos.copy_from_host(b.ptr, (size_t)n * n_dims * 4);
+				t.join_side_ema();
 				if (ngp_hip_gridmlp_forward(t.stream(), n_dims, t.m_desc_gpu.as<NgpNetDesc>(), t.m_inference_params.as<uint16_t>(), d_pos.as<float>(), n_dims, n, d_out.as<uint16_t>(), 4, nullptr))
 					throw std::runtime_error{ngp_hip_last_error()};
 				t.sync();
@@ -498,6 +499,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readwrite("netx_scalar_kernels", &Testbed::m_netx_scalar_kernels, "network variants (extra dims, 0 / 1 / 3 hidden colour layers): True runs the scalar checker kernels (bit-compatible with the oracle's restatement) instead of the MFMA kernels")
 		.def_readonly("bl_render_samples", &Testbed::m_bl_render_samples)
 		.def_readonly("bl_render_passes", &Testbed::m_bl_render_passes)
+		.def_readwrite("ema_on_side_stream", &Testbed::m_ema_on_side_stream, "optimizer step: False (default) = one launch, Adam + Ema, on the training chain; True = the Ema stage (what renderers and snapshots read) runs on the second stream beside the next step's network pass (a gain on the fox photographs only: profiles/r05_experiments.md section 7).  The same bits either way")
 		.def_readwrite("bl_fused_passes", &Testbed::m_bl_fused_passes, "Blender renderer pass loop: True (default) = one fused launch (march + cull + compact + per-NeRF lists) and one host-mailbox poll per pass on the stock tracer's sample budget; False = the reference's launch sequence with its two blocking read-backs per pass (same pixels)")
 		.def_readwrite("bl_reference_schedule", &Testbed::m_bl_reference_schedule, "fused pass loop on the unfused loop's schedule (n_steps from the rays that entered the pass, no resting rays): the same frame bit for bit; the fork's sampler depends on where the pass boundaries fall")
 		.def_readwrite("bl_max_skips_per_pass", &Testbed::m_bl_max_skips_per_pass)

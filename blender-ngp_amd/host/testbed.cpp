@@ -300,6 +300,8 @@ Testbed::~Testbed() {
 	if (m_counters_event) (void)hipEventDestroy((hipEvent_t)m_counters_event);
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_grid_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_grid_prefetch_event);
+	if (m_adam_event) (void)hipEventDestroy((hipEvent_t)m_adam_event);
+	if (m_ema_event) (void)hipEventDestroy((hipEvent_t)m_ema_event);
 	if (m_stream_b) (void)hipStreamSynchronize((hipStream_t)m_stream_b);
 	if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream);
 	if (m_stream) release_stream_pair(m_device);
@@ -314,7 +316,12 @@ void Testbed::check(int rc, const char* what) {
 		fprintf(stderr, " done\n"); fflush(stderr);
 	}
 }
-void Testbed::sync() { HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
+void Testbed::join_side_ema() {
+	if (!m_ema_pending) return;
+	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_ema_event, 0));
+	m_ema_pending = false;
+}
+void Testbed::sync() { join_side_ema(); HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
 void Testbed::invalidate_training_inputs() { drop_prefetch(); ++m_state_version; }
 
 // ---- live kernel timing ----------------------------------------------------------------------------------------
@@ -745,6 +752,7 @@ void TrainableBuffer::optimizer_step(void* stream, float loss_scale) {
 }
 
 void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
+	join_side_ema();
 	if (m_testbed_mode != ETestbedMode::Nerf) { reset_network_gridmlp(); return; }
 	drop_prefetch();
 	++m_state_version;
@@ -1029,6 +1037,7 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 // The sharded optimizer step leaves the fp32 state (master weights, Adam moments) of other ranks' shards stale.  Whoever needs the whole state — a snapshot with
 // optimizer state, training on after shutdown_data_parallel — gathers it first.  Collective: every rank of the communicator calls it.
 void Testbed::dp_gather_optimizer_state() {
+	join_side_ema();
 	// a stale state whose communicator is gone cannot be made whole any more: saying "done" here would let training / save_snapshot run on fp32 state that is old outside
 	// this rank's shard.  What rebuilds the whole state clears the flag instead: reset_network, load_snapshot.
 	if (m_dp_state_stale && !m_dp_comm)
@@ -1567,6 +1576,7 @@ void Testbed::train_nerf_dp_backward(uint32_t target_batch_size, uint32_t global
 //     owns elements [r * shard, (r + 1) * shard); dp_gather_optimizer_state makes it whole.
 // Element for element the arithmetic of the replicated step: tests/test_dp_cpu.py (gloo, oracle; worlds of 2 and 3) and tests/test_dp_gpu.py (shards on one GPU) compare bit for bit.
 void Testbed::optimizer_step_sharded() {
+	join_side_ema();
 	++m_optimizer_step;
 	const uint32_t world = m_world_size, rank = m_rank;
 	if (world > 1) m_dp_state_stale = true;
@@ -1624,6 +1634,7 @@ void Testbed::dp_gather_inference_params() {
 }
 // what a reader of the inference weights calls first: gathers when the call is a collective anyway (`collective`), refuses a stale copy otherwise
 void Testbed::require_inference_params(const char* who, bool collective) {
+	join_side_ema();
 	if (!m_dp_inference_stale) return;
 	if (collective && m_dp_comm) { dp_gather_inference_params(); return; }
 	throw std::runtime_error{std::string(who) + ": the inference (Ema) weights are sharded over the data-parallel ranks (dp_sharded_ema) and stale outside this rank's shard — call dp_gather_inference_params() on ALL ranks first (a collective), or set render_sharded on every rank so that render() is a collective and gathers by itself"};
@@ -1633,11 +1644,37 @@ void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE)
 	if (m_dp_comm && m_dp_sharded_optimizer) { optimizer_step_sharded(); return; }
 	if (m_dp_state_stale) throw std::runtime_error{"optimizer step on fp32 state that sharded data-parallel steps left stale outside this rank's shard: call dp_gather_optimizer_state() on all ranks before shutdown_data_parallel()"};
 	++m_optimizer_step;
+	const uint32_t mask = (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u);
+	const float ema_decay = m_use_ema ? m_ema_decay : 0.0f;
+	// The Ema stage (12 of the step's 36 bytes per parameter: read the new fp16 weight and the fp32 average, write the average and the fp16 inference weight) feeds renderers
+	// and snapshots, not the next training step: `ema_on_side_stream` runs it on stream B beside the next step's network pass instead of in front of it.  Element for element the
+	// arithmetic of the one-launch step (NGP_OPT_NO_EMA / NGP_OPT_EMA_ONLY: the split of the data-parallel path, tests/test_dp_gpu.py).  OFF by default — measured
+	// (profiles/r05_experiments.md section 7): the stage leaves the chain (lego 66 -> 46 us, fox 89 -> 68) but the pass it runs beside slows by 7-14 us and the two event pairs cost
+	// the queues ~10 us: fox 0.644 -> 0.632 ms per step, lego 0.524 -> 0.528, image 0.242 -> 0.266, SDF 0.467 -> 0.502.
+	const bool side_ema = m_ema_on_side_stream && m_stream_b && !(m_capture.valid && m_capture.step == m_training_step);
 	profile_begin(PK_OPTIMIZER);
-	check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE,
-	                                    m_use_ema ? m_ema_decay : 0.0f, m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(),
-	                                    m_second_moments.as<float>(), m_ema.as<float>(), m_inference_params.as<uint16_t>(), (m_train_network ? 1u : 0u) | (m_train_encoding ? 2u : 0u)), "optimizer_step");
+	if (side_ema) {
+		join_side_ema();   // the previous Ema stage read the weights this Adam stage overwrites
+		check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay,
+		                                    m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(), m_second_moments.as<float>(), nullptr, nullptr,
+		                                    mask | NGP_OPT_NO_EMA), "optimizer_step (Adam stage)");
+	} else {
+		join_side_ema();
+		check(ngp_hip_optimizer_step(m_stream, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay,
+		                                    m_grads.as<uint16_t>(), m_master.as<float>(), m_params.as<uint16_t>(), m_first_moments.as<float>(), m_second_moments.as<float>(), m_ema.as<float>(),
+		                                    m_inference_params.as<uint16_t>(), mask), "optimizer_step");
+	}
 	profile_end(PK_OPTIMIZER, m_n_params);
+	if (side_ema) {
+		if (!m_adam_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_adam_event = e; }
+		if (!m_ema_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_ema_event = e; }
+		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_adam_event, (hipStream_t)m_stream));
+		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_adam_event, 0));
+		check(ngp_hip_optimizer_step(m_stream_b, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
+		                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema stage, stream B)");
+		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_ema_event, (hipStream_t)m_stream_b));
+		m_ema_pending = true;
+	}
 	// tcnn ExponentialDecay::step: after the nested step, lr *= decay_base whenever the step count hits start + k * interval
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
 		m_learning_rate *= m_decay_base;
@@ -2333,6 +2370,7 @@ void Testbed::save_snapshot(const std::string& path, bool include_optimizer_stat
 }
 
 void Testbed::load_snapshot(const std::string& path) {
+	join_side_ema();
 	Json config = load_network_config(path);
 	if (!config.contains("snapshot")) throw std::runtime_error{"File " + path + " does not contain a snapshot."};
 	const Json& snapshot = config["snapshot"];

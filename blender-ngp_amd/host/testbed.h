@@ -398,6 +398,8 @@ public:
 	void bl_end_render();
 	uint64_t m_bl_render_samples = 0;
 	uint32_t m_bl_render_passes = 0;
+	bool m_ema_on_side_stream = false;       // pyngp: ema_on_side_stream — the optimizer step's Ema stage on stream B (optimizer_step()); off: measured slower on three of four workloads
+	void join_side_ema();                    // stream A waits for the pending Ema stage (readers of m_ema / m_inference_params call it; so does sync())
 	bool m_bl_fused_passes = true;            // NerfRenderer::fused_passes and its schedule knobs (nerf_renderer.h)
 	uint32_t m_bl_max_skips_per_pass = 96, m_bl_max_steps_per_pass = 64;
 	float m_bl_pass_samples_factor = 4.0f;
@@ -597,6 +599,11 @@ private:
 	struct PrefetchedGridSamples { bool valid = false; uint32_t step = 0, n_uniform = 0, n_nonuniform = 0, ema_step = 0; uint64_t rng_state = 0, rng_inc = 0, version = 0; int n_images = 0; };
 	PrefetchedGridSamples m_grid_prefetch;
 	void* m_grid_prefetch_event = nullptr;
+	// the Ema stage of the optimizer step on stream B (round 5, opt-in): it reads the new fp16 weights and writes only what renderers and snapshots read, so it leaves the training
+	// chain; m_adam_event orders it behind the Adam stage, m_ema_event orders the next Adam stage (which overwrites the weights it reads) and every reader behind it
+	void* m_adam_event = nullptr;
+	void* m_ema_event = nullptr;
+	bool m_ema_pending = false;              // stream A has not yet been ordered behind the last Ema launch
 	void maybe_prefetch_grid_samples(uint32_t next_step);
 	void launch_grid_samples(void* stream, uint32_t n_uniform, uint32_t n_nonuniform);   // memset of the splat buffer + the two generators; advances density_grid_rng twice
 	void* m_counters_event = nullptr;

@@ -121,3 +121,45 @@ def test_grid_update_samples_generated_ahead_are_the_in_order_ones(cuda):
         off.frame()
     off.sync()
     assert off.grid_prefetch_hits == 0 and np.isfinite(off.loss)
+
+
+@pytest.mark.parametrize("side", [True, False])
+def test_ema_stage_on_the_second_stream_is_the_ema_of_the_weights(cuda, tmp_path, side):
+    """`ema_on_side_stream` (opt-in): the optimizer step's Ema stage — what render() and snapshots read — runs on stream B beside the next step's network pass instead of on
+    the training chain.  After a run of asynchronous steps the snapshot's Ema state must be exactly what tcnn's EmaOptimizer makes of the previous average and the NEW weights
+    ((e * decay * (1 - decay^(t-1)) + w * (1 - decay)) / (1 - decay^t): rtol 2e-6 for numpy's float32 pow against powf), the fp16 inference weights its rounding (bit for bit),
+    and a render right behind frame() reads them without the caller synchronising anything.  Run in both modes: the check does not depend on where the stage ran."""
+    import msgpack
+    import scene
+    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    tb = scene.build_testbed(ds)
+    tb.async_training_steps = True
+    tb.ema_on_side_stream = side
+    for _ in range(20):
+        tb.frame()
+
+    def state(name):
+        path = str(tmp_path / name)
+        tb.save_snapshot(path, True)
+        m = msgpack.unpackb(open(path, "rb").read(), raw=False)["snapshot"]
+        ema = m["optimizer"]
+        assert ema["otype"] == "Ema"
+        return np.frombuffer(ema["ema_binary"], np.float32).copy(), np.frombuffer(m["params_binary"], np.uint16).copy(), int(ema["ema_step"])
+    e1, i1, t1 = state("a.msgpack")
+    assert t1 == 20
+    np.testing.assert_array_equal(i1, e1.astype(np.float16).view(np.uint16))
+    tb.frame()
+    img = _render(tb, ds)                                   # reads the inference weights of step 21: ordered behind the Ema stage by render() itself
+    assert np.isfinite(img).all() and img[..., :3].max() > 0.05
+    e2, i2, t2 = state("b.msgpack")
+    w2 = np.asarray(tb.debug_params("training")).view(np.float16).astype(np.float32)
+    assert t2 == 21 and np.any(e2 != e1)
+    d = np.float32(0.95)
+    want = (e1 * d * (np.float32(1) - np.float32(d) ** np.float32(t2 - 1)) + w2 * (np.float32(1) - d)) * (np.float32(1) / (np.float32(1) - np.float32(d) ** np.float32(t2)))
+    np.testing.assert_allclose(e2, want, rtol=2e-6, atol=1e-9)
+    np.testing.assert_array_equal(i2, e2.astype(np.float16).view(np.uint16))
+    tb.shall_train = True
+    for _ in range(3):                                      # and training goes on (the next Adam stage waits for the Ema stage that reads the weights it overwrites)
+        tb.frame()
+    tb.sync()
+    assert tb.training_step == 24 and np.isfinite(tb.loss)
