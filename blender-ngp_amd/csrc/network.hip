@@ -21,6 +21,8 @@
 //
 // Roofline: the hash pass is HBM/L2-request bound (512 B gathered per sample, 4 B per request); the MLP is ~20 kFLOP per
 // sample, i.e. a few % of the MFMA peak by construction (SURVEY §7 "Tiny-N MFMA").
+#include <mutex>
+#include <string.h>
 #include "ngp_device.cuh"
 #include "ngp_dev_knobs.h"
 
@@ -2571,10 +2573,35 @@ static int nx_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* d
 	return 0;
 }
 
+// desc_host lays out the host's side of the backward pass (the levels' record offsets, the owners' launch grid), desc_dev is what the kernels read: the two must be the same
+// table.  The first call with a new (desc_dev, contents of desc_host) pair reads desc_dev back once — stream-ordered, then the host waits for it — and compares; later calls
+// with the same pair cost a hash of 400 bytes.  (a mismatch used to leave gradient entries unwritten; with the packed record space it would write out of bounds.)
+static int verify_desc_pair(hipStream_t st, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host) {
+	struct Seen { const void* dev; uint64_t hash; };
+	static std::mutex mu;
+	static Seen seen[8] = {};
+	static unsigned next = 0;
+	uint64_t h = 1469598103934665603ull;
+	const unsigned char* b = (const unsigned char*)desc_host;
+	for (size_t i = 0; i < sizeof(NgpNetDesc); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		for (const Seen& e : seen) if (e.dev == (const void*)desc_dev && e.hash == h) return 0;
+	}
+	NgpNetDesc on_device;
+	NGP_HIP_TRY(hipMemcpyAsync(&on_device, desc_dev, sizeof(NgpNetDesc), hipMemcpyDeviceToHost, st));
+	NGP_HIP_TRY(hipStreamSynchronize(st));
+	if (memcmp(&on_device, desc_host, sizeof(NgpNetDesc)) != 0) { set_last_error("ngp_hip_nerf_backward: desc_host is not the level table desc_dev points to (pass the host copy of the SAME NgpNetDesc, or NULL)", hipErrorInvalidValue); return -1; }
+	std::lock_guard<std::mutex> lock(mu);
+	seen[next++ % 8u] = Seen{(const void*)desc_dev, h};
+	return 0;
+}
+
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant) {
 	if (variant_check(variant, "ngp_hip_nerf_backward: at most 16 extra dims and 3 hidden colour layers")) return -1;
+	if (desc_host && verify_desc_pair((hipStream_t)stream, desc_dev, desc_host)) return -1;
 	if (variant_is_generic(variant)) {
 		if (!variant_scalar(variant)) return nx_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
 		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }

@@ -163,7 +163,10 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, ui
  *                         requests when camera parameters train (prepare_input_gradients, src/testbed_nerf.cu:3324-3346): d/d(pos x, y, z) through the hash encoding
  *                         ([tcnn] GridEncoding backward to the input: fp32 sum over levels and features of dL/dy * dy/dx of the trilinear interpolation) and
  *                         d/d(dir x, y, z) through the SH basis, both in the warped [0, 1] coordinates of NgpCoord; dt carries no gradient (base family only);
- *   variant               see NgpNetVariant (its dL_dextra receives the extra-dim gradients). */
+ *   variant               see NgpNetVariant (its dL_dextra receives the extra-dim gradients).
+ * desc_host (may be NULL) is the host copy of the level table `desc_dev` points to: the host side lays out the sort's record space and the owners' launch grid from it
+ * while the kernels read desc_dev.  The first call with a new (desc_dev, contents of desc_host) pair reads desc_dev back once (stream-ordered; the host waits) and refuses a
+ * desc_host that is a different table; NULL = every level priced as the worst case, whole owner grid launched. */
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant);

@@ -128,6 +128,28 @@ def test_backward_in_a_scratch_sized_for_its_level_table(ngp, cuda, log2, aabb_s
     assert b"scratch too small" in ngp.ngp_hip_last_error()
 
 
+def test_backward_refuses_a_host_level_table_that_is_not_the_device_one(ngp, cuda):
+    """the host side of the backward pass (record offsets, owners' grid) is laid out from `desc_host`, the kernels read `desc_dev`.  A desc_host that describes another
+    table (here: aabb_scale 4 against a device table of aabb_scale 1) is refused on the first call instead of writing gradients to the wrong places; NULL and the true copy pass."""
+    n = 1024
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=15, n=n, grid_amp=0.5)
+    other = H.make_desc(ngp, log2_hashmap_size=15, aabb_scale=4)
+    assert other.tobytes() != desc.tobytes()
+    dl = H.to_dev((np.random.RandomState(3).randn(n, 4) * 0.01).astype(np.float16), cuda)
+    out, xs = H.dev_zeros(n * 4 * 2, cuda), H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch, grads = H.dev_zeros(sb, cuda), H.dev_zeros(H.n_params(desc) * 2, cuda)
+    args = (d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), dl.data_ptr(), 4, grads.data_ptr(), scratch.data_ptr(), sb)
+    assert ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), other.ctypes.data, *args) != 0
+    assert b"desc_host is not the level table" in ngp.ngp_hip_last_error()
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, *args))
+    a = H.to_host(grads, np.uint16).copy()
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), None, *args))
+    np.testing.assert_array_equal(a, H.to_host(grads, np.uint16))
+    assert ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), other.ctypes.data, *args) != 0     # still refused after the good pair was remembered
+
+
 def test_inference_ragged_and_empty(ngp, oracle, cuda):
     desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=33)
     for n in (0, 1, 31, 33):
