@@ -44,6 +44,8 @@ def dev_overrides(tb):
     """dev A / B switches of the bench scripts (never read by the library): NGP_BENCH_SIDE_EMA=0 puts the optimizer step's Ema stage back on the training chain"""
     if os.environ.get("NGP_BENCH_SIDE_EMA") is not None:
         tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
+    if os.environ.get("NGP_BENCH_COMPACT_BWD") is not None:   # 0 = the backward pass over all B slots
+        tb.compact_backward = bool(int(os.environ["NGP_BENCH_COMPACT_BWD"]))
     return tb
 
 

@@ -1150,7 +1150,7 @@ template <int D, bool SCATTER, bool ORDERED = true>   // ORDERED: the batch is i
 // (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? 4 : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, void* __restrict__ records, const GbRecordOffsets rec_off, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
-                                                        WgradJob wgrad) {
+                                                        WgradJob wgrad, const uint32_t* __restrict__ n_live) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	static_assert(GB_FX_CHUNK * 8 <= 65536, "rank field");
 	static_assert(GB_STAGE * 4u >= 16u * 64u * 4u, "the weight-gradient rows' 16 x 64 sums fit the count pass's LDS words");
@@ -1162,6 +1162,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTE
 		return;
 	}
 	if (!((level_mask >> level) & 1u)) return;   // dev-only ablation, see grid_backward_kernel
+	if (n_live && blockIdx.x * GB_FX_CHUNK >= *n_live) return;   // a chunk behind the live samples: its dL/dx is all zeros, it leaves no record (both passes skip it alike)
 	const NgpGridLevel lv = desc->levels[level];
 	const bool dense = level_is_dense<D>(lv) && gb_dense_binned(lv.size);
 	const bool fx = gb_uses_fx(lv.size, lv.resolution, level_is_dense<D>(lv));
@@ -1540,6 +1541,9 @@ __device__ __forceinline__ v3 sh4_grad_half(int g, float dx_, float dy_, float d
 	return mk(ax, ay, az);
 }
 
+// a batch whose first *n_live slots carry the samples with a non-zero loss gradient (ngp_hip_compact_live_samples); zero_next: a word the kernel clears (the counter of the next step)
+struct LiveSamples { const uint32_t* n_live; uint32_t* zero_next; const uint32_t* src_index /* slot -> row of x_saved / dL_dout / coords (NULL: the slot itself) */; };
+
 // DIR_GRAD: additionally dL/d(direction) of every sample into dL_dinput[s][3..5] (fp32) — the input gradient a training step asks for when
 // camera parameters train (NerfNetwork::backward_impl with dL_dinput, nerf_network.h:187-266; testbed_nerf.cu:3324-3346)
 template <bool DIR_GRAD>
@@ -1547,7 +1551,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
                                                                   const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                                   const half_t* __restrict__ x_saved, const half_t* __restrict__ dL_dout, uint32_t dl_stride,
                                                                   h2* __restrict__ dx_planes, float* __restrict__ partials /* [gridDim.x][10240] */, uint32_t* __restrict__ zero_words, uint32_t n_zero_words,
-                                                                  float* __restrict__ dL_dinput /* [n][6] or NULL */) {
+                                                                  float* __restrict__ dL_dinput /* [n][6] or NULL */, const LiveSamples live) {
 	NGP_RAISE_CHAIN_PRIORITY();
 	__shared__ __attribute__((aligned(16))) h8 lds_tiles[N_ALL_TILES * 64];
 	__shared__ __attribute__((aligned(16))) char stage[FB_STAGE_BYTES];
@@ -1555,7 +1559,11 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 	stage_tiles<GRID_OFF, N_ALL_TILES>(lds_tiles, params, gather_tile);
 
 	const int lane = threadIdx.x & 63, j = lane & 31, g = lane >> 5, w = threadIdx.x >> 6;
-	const uint32_t n_quads = n / 128;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
+	// live.n_live (ngp_hip_nerf_backward_live): only the first *n_live samples of the batch carry a gradient — the rest of the n slots is not read, its dL/dx is written as zeros
+	uint32_t n_eff = n;
+	if (live.n_live) { const uint32_t v = *live.n_live; n_eff = v < n ? v : n; }
+	if (live.zero_next && blockIdx.x == 0 && threadIdx.x == 0) *live.zero_next = 0u;   // the other step parity's counter: its last reader (the previous step's launch of this kernel) is done
+	const uint32_t n_quads = (n_eff + 127u) / 128u;   // 4 tiles of 32 samples per workgroup iteration (n % 256 == 0)
 	const f32x16 zero = {};
 	// 12 output tiles over 4 waves, each over all 128 samples of an iteration: W4 one tile per wave; waves 0 / 1 additionally the two tiles of W5
 	// and of W3, waves 2 / 3 those of W2 and of W1 (24 MFMAs per wave and iteration either way) — 48 accumulator registers per wave
@@ -1565,9 +1573,12 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 
 	for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
 		const uint32_t s = (quad * 4 + w) * 32 + j;
-		const float* c = coords + (size_t)s * coord_stride;
-		const h8* xs = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
-		const h8 x0 = xs[0], x1 = xs[1];
+		const bool on = s < n_eff;               // (the last quad of a live batch: slots behind the live samples hold nothing — zero encoding, zero gradient)
+		const uint32_t sl = on ? (live.src_index ? live.src_index[s] : s) : 0u;
+		const float* c = coords + (size_t)sl * coord_stride;
+		const h8* xs = (const h8*)(x_saved + (size_t)sl * 32 + 16 * g);
+		h8 x0 = xs[0], x1 = xs[1];
+		if (!on) { x0 = h8{}; x1 = h8{}; }
 		const h8 sh = sh4_half(g, c[4], c[5], c[6]);
 		FwdActs a;
 		f32x16 dd, oo;
@@ -1576,10 +1587,10 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 		const h8* lt = lds_tiles + lt_off;
 		mlp_forward<false, true>(lt, lane, x0, x1, sh, dd, oo, &a);
 
-		const half_t* dl = dL_dout + (size_t)s * dl_stride;
+		const half_t* dl = dL_dout + (size_t)sl * dl_stride;
 		h8 dout = {};
-		if (g == 0) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; }
-		const half_t dsigma = dl[3];
+		if (g == 0 && on) { dout[0] = dl[0]; dout[1] = dl[1]; dout[2] = dl[2]; }
+		const half_t dsigma = on ? dl[3] : (half_t)0.0f;
 
 		// ---- W5: dY = dout (16 rows), H = h3
 		fb_put(stage, 0, MAP_CH, 0, g, col, dout);
@@ -1654,12 +1665,14 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 #pragma unroll
 		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]);
 		{   // the encoding again (64 B per sample, an L2 hit): keeping x0 / x1 live through the chain costs 8 registers of a kernel that is at its limit
-			const h8* xr = (const h8*)(x_saved + (size_t)s * 32 + 16 * g);
+			const h8* xr = (const h8*)(x_saved + (size_t)sl * 32 + 16 * g);
 			uint32_t zero_off = 0;
 			asm volatile("" : "+v"(zero_off));
 			xr = (const h8*)((const char*)xr + zero_off);
-			fb_put(stage, 64, MAP_ENC, 0, g, col, xr[0]);
-			fb_put(stage, 64, MAP_ENC, 1, g, col, xr[1]);
+			h8 xa = xr[0], xb = xr[1];
+			if (!on) { xa = h8{}; xb = h8{}; }
+			fb_put(stage, 64, MAP_ENC, 0, g, col, xa);
+			fb_put(stage, 64, MAP_ENC, 1, g, col, xb);
 		}
 		__syncthreads();
 		if (!low_pair) fb_job_m2n1(stage, 0, 64, w - 2, lane, acc_b);
@@ -1679,6 +1692,12 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 			dx_planes[(size_t)(lvl + 1) * n + s] = v;
 		}
 		__syncthreads();
+	}
+	if (live.n_live) {   // dL/dx of the slots behind the live samples: zeros (the hash-grid backward skips zero pairs; its binning skips whole chunks of them)
+		const uint32_t first = n_quads * 128u, tail = n - first;
+		const h2 z2 = {(half_t)0.0f, (half_t)0.0f};
+		for (uint32_t l = 0; l < 16u; ++l)
+			for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tail; i += gridDim.x * blockDim.x) dx_planes[(size_t)l * n + first + i] = z2;
 	}
 	// ---- this workgroup's partial weight gradients
 	float* __restrict__ dst = partials + (size_t)blockIdx.x * NGP_MLP_N_PARAMS;
@@ -2192,7 +2211,8 @@ template <int D>
 static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, const float* pos, uint32_t stride, uint32_t n, const h2* dx_planes, h2* gb_partials, void* fx_scratch, h2* grid_grad,
                                 bool counters_cleared = false /* by the kernel that produced dx_planes */, bool ordered = true /* the batch is in ray order: NeRF training */,
                                 WgradJob wgrad = WgradJob{nullptr, 0u, nullptr, 0u} /* sum these weight-gradient partials in the count pass's launch */,
-                                const NgpNetDesc* desc_host = nullptr /* the level table on the host: only the owners that own something are launched */) {
+                                const NgpNetDesc* desc_host = nullptr /* the level table on the host: only the owners that own something are launched */,
+                                const uint32_t* n_live = nullptr /* device word: the samples behind the first *n_live carry zero gradients (the binning skips their chunks) */) {
 	GbFxCounters* ctr = (GbFxCounters*)fx_scratch;
 	static_assert(sizeof(GbFxCounters) <= GB_FX_COUNTER_BYTES, "counter block");
 	uint32_t* wg_hist = (uint32_t*)((char*)fx_scratch + GB_FX_COUNTER_BYTES);   // the dense levels' per-workgroup bin counts
@@ -2203,13 +2223,13 @@ static int launch_grid_backward(hipStream_t st, const NgpNetDesc* desc_dev, cons
 	const dim3 bin_grid(div_up(n, GB_FX_CHUNK), 16);
 	const dim3 count_grid(bin_grid.x, 16u + (wgrad.partials ? div_up(div_up(wgrad.n_params, 64u), bin_grid.x) : 0u));
 	const WgradJob no_job{nullptr, 0u, nullptr, 0u};
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, true>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad, n_live);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, false, false>), count_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, wgrad, n_live);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<count>");
 	// (round 5: write-combining the records through LDS — ranks and a per-bin image in LDS, coalesced copy-out — was built in two versions and measured slower than these
 	// register-to-global stores: the pass is within 1.5x of the rate at which the part writes its 76-138 MB of records; profiles/r05_experiments.md)
-	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job);
-	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job);
+	if (ordered) hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, true>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job, n_live);
+	else hipLaunchKernelGGL((gb_fx_bin_kernel<D, true, false>), bin_grid, dim3(256), 0, st, desc_dev, pos, stride, n, dx_planes, ctr, records, rec_off, wg_hist, level_mask, no_job, n_live);
 	NGP_LAUNCH_CHECK("gb_fx_bin_kernel<scatter>");
 	static const uint32_t owner_threads = ngp_dev_knob_u32("NGP_HIP_GB_OWNER_THREADS", 1024u);   // dev: sweep (256 / 512 / 1024)
 	GbOwnerMap map{};
@@ -2517,7 +2537,7 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, ui
 
 static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput);
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, LiveSamples live, const float* grid_coords = nullptr);
 
 static int gen_backward(void* stream, const NgpNetVariant* v, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords, uint32_t stride, uint32_t n, const uint16_t* x_saved,
                         const uint16_t* dL_dout, uint32_t dl_stride, uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* grid_gradients_event) {
@@ -2607,7 +2627,67 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }
 		return gen_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
 	}
-	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput, LiveSamples{nullptr, nullptr, nullptr});
+}
+
+// The backward pass over the LIVE samples of a batch (ngp_hip_compact_live_samples): slot k < *n_live_dev stands for row live_index[k] of coords / x_saved / dL_dout; the
+// hash-grid backward reads the live samples' positions from coords_live (their rows, packed).  Base network family, no input gradient.
+int ngp_hip_nerf_backward_live(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                               uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event,
+                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev) {
+	if (!n_live_dev || !live_index || !coords_live) { set_last_error("ngp_hip_nerf_backward_live: live_index / coords_live / n_live_dev is NULL (ngp_hip_nerf_backward is the entry without a live list)", hipErrorInvalidValue); return -1; }
+	if (desc_host && verify_desc_pair((hipStream_t)stream, desc_dev, desc_host)) return -1;
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, nullptr,
+	                          LiveSamples{n_live_dev, zero_word_dev, live_index}, coords_live);
+}
+
+// Samples of a training batch whose loss gradient is zero in all four channels — in fp16, after the roll-over: the tails of the rays, 30-45 % of a batch — contribute exact
+// zeros to every sum of the backward pass.  This pass lists the others (the 2048 rows of a workgroup keep their order, the workgroups take their ranges in arrival order), copies
+// their coordinate rows next to each other and counts them; ngp_hip_nerf_backward_live then runs its MFMA kernel and the binning of the hash-grid backward over them only.
+constexpr uint32_t CL_ROWS = 2048;   // rows per workgroup: one atomic on the counter per 2048 rows (a workgroup per 256 rows spent 15 us of 17 queueing on that one word)
+__global__ void __launch_bounds__(256) compact_live_samples_kernel(uint32_t n, const half_t* __restrict__ dl, uint32_t dl_stride, const float* __restrict__ coords, uint32_t coord_stride,
+                                                                   uint32_t* __restrict__ live_index, float* __restrict__ coords_out, uint32_t* __restrict__ n_live) {
+	constexpr uint32_t PER = CL_ROWS / 256;
+	__shared__ uint32_t s_cnt[PER * 4 + 1], s_base, s_src[CL_ROWS];
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	unsigned long long masks[PER];
+#pragma unroll
+	for (uint32_t u = 0; u < PER; ++u) {
+		const uint32_t s = blockIdx.x * CL_ROWS + u * 256u + threadIdx.x;
+		uint2 d = {0u, 0u};
+		if (s < n) d = *(const uint2*)(dl + (size_t)s * dl_stride);
+		masks[u] = __ballot(((d.x | d.y) & 0x7fff7fffu) != 0u);   // +-0 in all four channels: nothing to propagate
+		if (lane == 0) s_cnt[u * 4 + w] = (uint32_t)__popcll(masks[u]);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {   // exclusive prefix over the 32 (pass, wave) counts, in row order
+		uint32_t run = 0;
+		for (uint32_t k = 0; k < PER * 4; ++k) { const uint32_t c = s_cnt[k]; s_cnt[k] = run; run += c; }
+		s_cnt[PER * 4] = run;
+		s_base = run ? atomicAdd(n_live, run) : 0u;
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t u = 0; u < PER; ++u)
+		if ((masks[u] >> lane) & 1ull) s_src[s_cnt[u * 4 + w] + (uint32_t)__popcll(masks[u] & ((1ull << lane) - 1ull))] = blockIdx.x * CL_ROWS + u * 256u + threadIdx.x;
+	__syncthreads();
+	const uint32_t total = s_cnt[PER * 4], base = s_base;
+	for (uint32_t k = threadIdx.x; k < total; k += 256u) live_index[base + k] = s_src[k];
+	// the rows leave as one contiguous run of total * coord_stride floats
+	for (uint32_t e = threadIdx.x; e < total * coord_stride; e += 256u) {
+		const uint32_t k = e / coord_stride, f = e - k * coord_stride;
+		coords_out[(size_t)base * coord_stride + e] = coords[(size_t)s_src[k] * coord_stride + f];
+	}
+}
+int ngp_hip_compact_live_samples(void* stream, uint32_t n, const uint16_t* dL_dout, uint32_t dl_stride, const float* coords, uint32_t coord_stride_floats,
+                                 uint32_t* live_index_out, float* coords_out, uint32_t* n_live_dev) {
+	if (n == 0) return 0;
+	if (dl_stride < 4 || (dl_stride & 3) || coord_stride_floats < 3) { set_last_error("ngp_hip_compact_live_samples: dl_stride must be a multiple of 4 halves (8-byte rows), coords rows start with the position", hipErrorInvalidValue); return -1; }
+	if (!n_live_dev || !live_index_out || !coords_out) { set_last_error("ngp_hip_compact_live_samples: NULL output", hipErrorInvalidValue); return -1; }
+	hipLaunchKernelGGL(compact_live_samples_kernel, dim3(div_up(n, CL_ROWS)), dim3(256), 0, (hipStream_t)stream, n, (const half_t*)dL_dout, dl_stride, coords, coord_stride_floats, live_index_out, coords_out, n_live_dev);
+	NGP_LAUNCH_CHECK("compact_live_samples_kernel");
+	return 0;
 }
 
 // per-image extra dims of a training step (src/testbed_nerf.cu:1136, 1246: every sample of a ray carries its image's row; :1710-1746: their gradient)
@@ -2640,7 +2720,7 @@ int ngp_hip_extra_dims_gradient(void* stream, uint32_t n_rays_capacity, const ui
 
 static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput) {
+                              uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, LiveSamples live, const float* grid_coords /* positions for the hash-grid backward (NULL: coords) */) {
 	if (n == 0 || (n % 256) != 0) { set_last_error("ngp_hip_nerf_backward: n must be a positive multiple of 256", hipErrorInvalidValue); return -1; }
 	if (scratch_bytes < ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n)) { set_last_error("ngp_hip_nerf_backward: scratch too small (ngp_hip_nerf_backward_scratch_bytes_for(desc_host, n), or ngp_hip_nerf_backward_scratch_bytes(n) without a host level table)", hipErrorInvalidValue); return -1; }
 	hipStream_t st = (hipStream_t)stream;
@@ -2650,9 +2730,9 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	const uint32_t n_quads = n / 128;
 	const uint32_t grid = n_quads < FB_MAX_WORKGROUPS ? n_quads : FB_MAX_WORKGROUPS;
 	if (dL_dinput) hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-	                                  dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), dL_dinput);
+	                                  dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), dL_dinput, live);
 	else hipLaunchKernelGGL(nerf_backward_fused_kernel<false>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dL_dout, dl_stride,
-	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr);
+	                        dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx_for(desc_host, n)), (uint32_t)(sizeof(GbFxCounters) / 4), (float*)nullptr, live);
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel");
 	if (dL_dinput) {
 		hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, coords, coord_stride_floats, n, (const h2*)dx_planes, dL_dinput, (uint32_t)GRID_OFF);
@@ -2661,8 +2741,8 @@ static int nerf_backward_impl(void* stream, const NgpNetDesc* desc_dev, const Ng
 	if (mlp_done_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)mlp_done_event, st));
 	// EGradientMode::Overwrite: every table entry is written exactly once (no memset, no global float atomics).  The weight-gradient partials are summed by extra
 	// rows of the hash-grid backward's first launch.
-	if (launch_grid_backward<3>(st, desc_dev, coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx_for(desc_host, n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
-	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS}, desc_host)) return -1;
+	if (launch_grid_backward<3>(st, desc_dev, grid_coords ? grid_coords : coords, coord_stride_floats, n, (const h2*)dx_planes, gb_partials, (char*)scratch + scratch_off_fx_for(desc_host, n), (h2*)(grads + NGP_MLP_N_PARAMS), true, true,
+	                            WgradJob{(const float*)partials, grid, (half_t*)grads, (uint32_t)NGP_MLP_N_PARAMS}, desc_host, live.n_live)) return -1;
 	if (grid_gradients_event) NGP_HIP_TRY(hipEventRecord((hipEvent_t)grid_gradients_event, st));
 	return 0;
 }
@@ -2710,7 +2790,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 		return 0;
 	}
 	hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u,
-	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din);
+	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din, LiveSamples{nullptr, nullptr, nullptr});
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel (input gradient)");
 	hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din, (uint32_t)GRID_OFF);
 	NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");

@@ -316,6 +316,13 @@ void Testbed::check(int rc, const char* what) {
 		fprintf(stderr, " done\n"); fflush(stderr);
 	}
 }
+float Testbed::backward_live_fraction() {
+	if (!m_live_last_batch || m_live_count.bytes() == 0) return 1.0f;
+	sync();
+	uint32_t words[2] = {0u, 0u};
+	m_live_count.copy_to_host(words, 8);
+	return (float)words[m_live_last_parity] / (float)m_live_last_batch;
+}
 void Testbed::join_side_ema() {
 	if (!m_ema_pending) return;
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_ema_event, 0));
@@ -755,6 +762,7 @@ void Testbed::reset_network(bool clear_density_grid) {  // testbed.cu:2249-2470
 	join_side_ema();
 	if (m_testbed_mode != ETestbedMode::Nerf) { reset_network_gridmlp(); return; }
 	drop_prefetch();
+	if (m_live_count.bytes()) { m_live_count.memset(0, m_stream); m_live_parity = 0; m_live_last_batch = 0; }   // (a step that threw between the compaction and the backward pass may have left its counter behind)
 	++m_state_version;
 	m_n_matrix_params = NGP_MLP_N_PARAMS;
 	m_rng = Pcg32(m_seed);
@@ -1437,6 +1445,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_post_tag = m_post_tag + 1 ? m_post_tag + 1 : 1;
 	m_next_slot_zeroed = m_compact_slot_zeroed = m_gen_slot ^ 1;
 	uint32_t* next_slot = m_gen_counters.as<uint32_t>() + 4 * (m_gen_slot ^ 1);   // its ray, sample and compaction counters + the forward pass's ray queue
+	const bool compact_now = m_compact_backward && net_is_base_family() && !m_want_counters_event && !m_separate_forward && !(tr.optimize_extrinsics || tr.optimize_distortion);
 	if (m_want_counters_event) {
 		// somebody waits on the counters event (stream_wait_counters: a data-parallel host that reduces the counters in stream order): it is recorded right behind the post,
 		// in front of the roll-overs, which are not needed for the counters
@@ -1444,6 +1453,16 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
 		                                     m_x_saved.as<float>(), 16), "fill_rollover");
+	} else if (compact_now) {
+		// the backward pass over the live samples: roll-overs, then the list of the samples with a non-zero loss gradient, THEN the post — the host launches the next step's march
+		// when it sees it, and the backward pass's MFMA kernel (80 KiB of LDS per workgroup) must already be resident when that march arrives, or it runs at half its occupancy
+		// beside it (measured: 47 -> 87 us with the post 20 us ahead of the kernel)
+		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7, m_x_saved.as<float>(), 16), "fill_rollover");
+		m_coords_live.enlarge((size_t)target_batch_size * sizeof(NgpCoord)); m_live_index.enlarge((size_t)target_batch_size * 4);
+		if (m_live_count.bytes() == 0) { m_live_count.resize(8); m_live_count.memset(0, m_stream); m_live_parity = 0; }
+		check(ngp_hip_compact_live_samples(m_stream, target_batch_size, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7, m_live_index.as<uint32_t>(), m_coords_live.as<float>(),
+		                                   m_live_count.as<uint32_t>() + m_live_parity), "compact_live_samples");
+		check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4, (double*)m_dp_counters_dev), "post_words");
 	} else {
 		// the polling host needs no event (a record costs a few microseconds of dispatch gap): post and roll-overs in one launch, the post first
 		check(ngp_hip_post_words_and_fill_rollover_training(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4,
@@ -1494,6 +1513,14 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		const bool train_extra_dims = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;   // testbed_nerf.cu:2925
 		if (train_extra_dims) m_dl_dextra.enlarge((size_t)target_batch_size * m_n_extra_dims * 4);
 		const NgpNetVariant* variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims ? m_dl_dextra.as<float>() : nullptr);
+		if (compact_now) {
+			uint32_t* n_live = m_live_count.as<uint32_t>() + m_live_parity;
+			check(ngp_hip_nerf_backward_live(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+			                                 OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, m_want_grid_grad_event ? m_grid_grad_event : nullptr,
+			                                 m_live_index.as<uint32_t>(), m_coords_live.as<float>(), n_live, m_live_count.as<uint32_t>() + (m_live_parity ^ 1u)), "nerf_backward (live samples)");
+			m_live_last_batch = target_batch_size; m_live_last_parity = m_live_parity;
+			m_live_parity ^= 1u;
+		} else
 		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
 		                            m_want_grid_grad_event ? m_grid_grad_event : nullptr, nullptr, variant), "nerf_backward");

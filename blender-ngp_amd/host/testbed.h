@@ -398,6 +398,13 @@ public:
 	void bl_end_render();
 	uint64_t m_bl_render_samples = 0;
 	uint32_t m_bl_render_passes = 0;
+	// the backward pass over the live samples of the batch (round 5): samples whose loss gradient is zero in all four channels (ray tails in fp16: 30-45 % of a batch) are
+	// left out of the MFMA kernel and of the hash-grid binning (ngp_hip_compact_live_samples + ngp_hip_nerf_backward_live; same hash-grid gradients bit for bit)
+	bool m_compact_backward = false;         // pyngp: compact_backward (off: measured neutral on the whole step, profiles/r05_experiments.md section 8)
+	DeviceBuffer m_coords_live, m_live_index, m_live_count;   // the live samples' coordinate rows next to each other, their rows in the batch; two counters (step parity: one is read while the other is cleared)
+	uint32_t m_live_parity = 0;
+	float backward_live_fraction();          // pyngp (read-only; drains the stream): live samples / batch of the last compacted step
+	uint32_t m_live_last_batch = 0, m_live_last_parity = 0;
 	bool m_ema_on_side_stream = false;       // pyngp: ema_on_side_stream — the optimizer step's Ema stage on stream B (optimizer_step()); off: measured slower on three of four workloads
 	void join_side_ema();                    // stream A waits for the pending Ema stage (readers of m_ema / m_inference_params call it; so does sync())
 	bool m_bl_fused_passes = true;            // NerfRenderer::fused_passes and its schedule knobs (nerf_renderer.h)

@@ -170,6 +170,23 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, ui
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                           uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant);
+/* The backward pass over the LIVE samples of a batch.  A sample whose loss gradient is zero in all four channels — after the loss kernel and fill_rollover_and_rescale
+ * (src/testbed_nerf.cu:1280-1597, 3314-3322), in fp16: the tails of the rays, where the transmittance has not yet reached the 1e-4 cut but weight x loss_scale has left the
+ * fp16 range; 30-45 % of a training batch — adds exact zeros to every sum NerfNetwork::backward_impl forms.
+ *   ngp_hip_compact_live_samples   lists the other samples: live_index_out[k] = the row of the k-th live sample (within a workgroup of 256 rows in order, the workgroups in
+ *                                  arrival order), coords_out = their coordinate rows next to each other (same stride), *n_live_dev += their number (must be 0 on entry);
+ *   ngp_hip_nerf_backward_live     ngp_hip_nerf_backward (base network family, no dL_dinput) over those samples: the MFMA kernel reads rows live_index[k] of coords / x_saved /
+ *                                  dL_dout for k < *n_live_dev, the binning passes of the hash-grid backward read coords_live and stop behind the live samples (the wave lanes
+ *                                  that would have carried zeros are gone).  zero_word_dev (may be NULL): a device word the first kernel clears — the counter the NEXT step's
+ *                                  compaction adds to.
+ * Hash-grid gradients: the same bits as the whole batch gives (exact sums; zeros change nothing).  MLP weight gradients: the same sums with another association of the fp32
+ * adds (inside the oracle tolerance of ngp_hip_nerf_backward). */
+int ngp_hip_compact_live_samples(void* stream, uint32_t n, const uint16_t* dL_dout, uint32_t dl_stride, const float* coords, uint32_t coord_stride_floats,
+                                 uint32_t* live_index_out, float* coords_out, uint32_t* n_live_dev);
+int ngp_hip_nerf_backward_live(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
+                               uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
+                               uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event,
+                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev);
 /* Per-image extra dims of a training step.  ray_image[i] = the image of kept ray i (what image_idx gives the ray generator, src/testbed_nerf.cu:1131-1136);
  * numsteps = (count, base) pairs of the kept rays (the ray generator's before compaction, the loss kernel's after).
  *   ngp_hip_ray_images            ray_image[i] = image_idx(ray_indices[i], ...) for the kept rays (:1062-1083);

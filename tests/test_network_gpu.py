@@ -150,6 +150,76 @@ def test_backward_refuses_a_host_level_table_that_is_not_the_device_one(ngp, cud
     assert ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), other.ctypes.data, *args) != 0     # still refused after the good pair was remembered
 
 
+@pytest.mark.parametrize("zero_fraction", [0.45, 0.0, 1.0, 0.999])
+@pytest.mark.parametrize("aabb_scale", [1, 4])
+def test_backward_over_the_live_samples_is_the_backward_over_the_batch(ngp, cuda, zero_fraction, aabb_scale):
+    """ngp_hip_compact_live_samples + ngp_hip_nerf_backward_live against ngp_hip_nerf_backward on the whole batch.  A third to a half of a training batch carries a loss
+    gradient that is zero in all four channels (ray tails, fp16): the live entry runs the MFMA kernel and the hash-grid binning over the other samples only.
+      * the count is the number of rows with a non-zero channel, the list holds every such row once (256-row workgroups keep their order), the coordinate rows sit beside it;
+      * hash-grid gradients: bit for bit those of the whole batch (exact sums: a zero term changes nothing) — with poison in every list slot behind the live samples;
+      * MLP weight gradients: the same sums in another association: |difference| <= 2e-3 of the largest weight gradient (fp32 accumulation of fp16 products)."""
+    n = 16384
+    desc = H.make_desc(ngp, log2_hashmap_size=17, aabb_scale=aabb_scale)
+    params = H.random_params(desc, seed=5, grid_amp=0.5)
+    coords = H.random_coords(n, seed=9)
+    rs = np.random.RandomState(int(zero_fraction * 1000) + aabb_scale)
+    dl = (rs.randn(n, 4) * 0.02).astype(np.float16)
+    # zero rows in runs, like ray tails; some rows with a single live channel, some with -0.0 only (dead)
+    dead = np.zeros(n, bool)
+    if zero_fraction >= 1.0:
+        dead[:] = True
+    elif zero_fraction > 0:
+        starts = rs.randint(0, n, size=int(n * zero_fraction / 12))
+        for st in starts:
+            dead[st:st + rs.randint(1, 40)] = True
+        if zero_fraction > 0.99:
+            dead[:] = True; dead[rs.randint(0, n, size=5)] = False
+    dl[dead] = 0
+    dl[dead & (rs.rand(n) < 0.1), 3] = np.float16(-0.0)
+    one = (~dead) & (rs.rand(n) < 0.05)
+    dl[one, :3] = 0
+    live_rows = np.flatnonzero((dl.view(np.uint16) & 0x7fff).any(axis=1))
+    d_desc, d_P, d_c, d_dl = H.to_dev(desc, cuda), H.to_dev(params, cuda), H.to_dev(coords, cuda), H.to_dev(dl, cuda)
+    out, xs = H.dev_zeros(n * 4 * 2, cuda), H.dev_zeros(n * 32 * 2, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes_for(desc.ctypes.data, n)
+    scratch, g_full = H.dev_zeros(sb, cuda), H.dev_zeros(H.n_params(desc) * 2, cuda)
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4, g_full.data_ptr(), scratch.data_ptr(), sb))
+    full = H.to_host(g_full, np.uint16).copy()
+    # ---- the live list, into poisoned buffers
+    p_idx = torch.full((n,), -1, dtype=torch.int32, device=cuda)
+    p_c = torch.full((n * 7,), float("nan"), dtype=torch.float32, device=cuda)
+    counters = torch.tensor([0, 12345], dtype=torch.int32, device=cuda)
+    check(ngp.ngp_hip_compact_live_samples(None, n, d_dl.data_ptr(), 4, d_c.data_ptr(), 7, p_idx.data_ptr(), p_c.data_ptr(), counters.data_ptr()))
+    torch.cuda.synchronize()
+    n_live = int(counters[0])
+    assert n_live == live_rows.size
+    got_idx = p_idx.cpu().numpy()[:n_live].astype(np.int64)
+    got_c = p_c.cpu().numpy().reshape(n, 7)[:n_live]
+    c_host = np.frombuffer(coords.tobytes(), np.float32).reshape(n, 7)
+    np.testing.assert_array_equal(np.sort(got_idx), live_rows)                       # every live row once
+    np.testing.assert_array_equal(got_c.view(np.uint32), c_host[got_idx].view(np.uint32))   # its coordinate row beside it
+    blocks = got_idx // 256
+    assert (np.diff(got_idx)[np.diff(blocks) == 0] > 0).all()                        # inside a workgroup of 256 the rows keep their order ...
+    assert np.unique(blocks[np.flatnonzero(np.diff(blocks) != 0) + 1]).size == np.flatnonzero(np.diff(blocks) != 0).size if n_live else True   # ... and a workgroup's rows are one run
+    # ---- the live backward
+    g_live = H.dev_zeros(H.n_params(desc) * 2, cuda)
+    scratch2 = torch.full((sb,), 0xA5, dtype=torch.uint8, device=cuda)
+    check(ngp.ngp_hip_nerf_backward_live(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4, g_live.data_ptr(), scratch2.data_ptr(), sb,
+                                         None, None, p_idx.data_ptr(), p_c.data_ptr(), counters.data_ptr(), counters.data_ptr() + 4))
+    torch.cuda.synchronize()
+    assert int(counters[1]) == 0 and int(counters[0]) == n_live    # the next step's word is cleared, this step's stays
+    live = H.to_host(g_live, np.uint16)
+    np.testing.assert_array_equal(live[10240:], full[10240:])
+    a, b = live[:10240].view(np.float16).astype(np.float32), full[:10240].view(np.float16).astype(np.float32)
+    assert np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-6) + 1e-7, (np.abs(a - b).max(), np.abs(b).max())
+    if n_live:
+        assert np.any(full[10240:] != 0) and np.any(b != 0)
+    else:
+        assert not np.any(live & 0x7fff)
+
+
 def test_inference_ragged_and_empty(ngp, oracle, cuda):
     desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=33)
     for n in (0, 1, 31, 33):

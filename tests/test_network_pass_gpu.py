@@ -122,3 +122,36 @@ def test_plumbing_modes_go_through_the_same_policy(cuda, mode):
     # the same model whichever organisation ran (identical forward bits; the backward's partial sums are the same launches): the loss of step 32 agrees closely
     assert np.isfinite(list(losses.values())).all()
     assert max(losses.values()) - min(losses.values()) <= 0.02 * max(abs(v) for v in losses.values()) + 1e-7, losses
+
+
+def test_backward_over_the_live_samples_inside_a_training_step(ngp, cuda):
+    """`compact_backward` (opt-in): the step lists the samples of its compacted batch whose loss gradient is not zero in all four channels and runs the backward pass over
+    those (ngp_hip_compact_live_samples + ngp_hip_nerf_backward_live).  A captured step's gradient against the whole-batch entry point on the step's own buffers:
+    hash-grid part bit for bit, MLP part within 2e-3 of the largest weight gradient; a good part of the batch is dead (ray tails), and training goes on."""
+    ds, tb = _testbed(cuda, n_train=12, res=96)
+    tb.compact_backward = True
+    for _ in range(60):
+        tb.frame()
+    tb.debug_capture_next_step()
+    tb.frame()
+    cap = tb.debug_captured()
+    frac = float(tb.backward_live_fraction)
+    n = int(cap["target_batch_size"])
+    dl = np.ascontiguousarray(cap["dloss_rolled"]).reshape(n, 4)
+    live = int(((dl & 0x7fff) != 0).any(axis=1).sum())
+    assert 0 < live < n and abs(frac - live / n) < 1e-6, (frac, live, n)
+    desc = np.frombuffer(tb.debug_scene()["desc"].tobytes(), dtype=H.NET_DESC).copy()
+    d_desc, d_p = H.to_dev(desc, cuda), H.to_dev(np.ascontiguousarray(cap["params"]), cuda)
+    d_c, d_x, d_dl = H.to_dev(np.ascontiguousarray(cap["coords_compacted_rolled"]), cuda), H.to_dev(np.ascontiguousarray(cap["x_saved"]), cuda), H.to_dev(dl, cuda)
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch, grads = H.dev_zeros(sb, cuda), H.dev_zeros(H.n_params(desc) * 2, cuda)
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), None, d_p.data_ptr(), d_c.data_ptr(), 7, n, d_x.data_ptr(), d_dl.data_ptr(), 4, grads.data_ptr(), scratch.data_ptr(), sb, None, None, None, None))
+    want, got = H.to_host(grads, np.uint16), np.asarray(cap["grads"])
+    np.testing.assert_array_equal(got[10240:], want[10240:])
+    a, b = got[:10240].view(np.float16).astype(np.float32), want[:10240].view(np.float16).astype(np.float32)
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() + 1e-7 and np.abs(b).max() > 0
+    for _ in range(10):
+        tb.frame()
+    tb.sync()
+    assert np.isfinite(tb.loss) and tb.training_step == 71
+    print("live samples of the captured step: %.1f %% of %d" % (100.0 * frac, n))
