@@ -32,7 +32,7 @@ OPT_BYTES_PER_PARAM = 36       # grads 2 + master 4+4 + m 4+4 + v 4+4 + fp16 2 +
 BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
 MARCH_BYTES_PER_SAMPLE = 28    # one NerfCoordinate written per sample (nerf.h:62-107)
 MARCH_BYTES_PER_RAY = 40       # ray index 4 + Ray 24 + numsteps 8 written, one RGBA8 pixel read (testbed_nerf.cu:1232-1258)
-KERNEL_SET = "r05b"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
+KERNEL_SET = "r05c"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
 GROUP_KERNELS = {"grad_exchange": "data-parallel step: fp16 -> fp32 copy, RCCL reduce-scatter (fp32 sums), fp32 -> fp16 of this rank's shard", "param_gather": "data-parallel step: RCCL all-gather of the fp16 weights",
                  "nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
                  "nerf_inference": "one ngp_hip_nerf_forward call: fused hash-grid encode + both MLPs (single kernel)", "optimizer_step": "adam_ema_vec4_kernel (single kernel)"}
