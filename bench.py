@@ -441,8 +441,6 @@ def main():
         tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
     if os.environ.get("NGP_BENCH_COMPACT_BWD") is not None:   # dev A / B: 0 = the backward pass over all B slots
         tb.compact_backward = bool(int(os.environ["NGP_BENCH_COMPACT_BWD"]))
-    if os.environ.get("NGP_BENCH_MARCH_BEHIND_MLP") is not None:
-        tb.march_behind_mlp = bool(int(os.environ["NGP_BENCH_MARCH_BEHIND_MLP"]))
     if os.environ.get("BENCH_NO_PREFETCH"):   # dev: the march in stream order, i.e. uncontended (its in-situ stand-alone time)
         tb.prefetch_samples = False
     tb.async_training_steps = True   # frame() without the reference's per-step stream drain (pyngp property; the timed region is still bracketed by syncs)

@@ -46,8 +46,6 @@ def dev_overrides(tb):
         tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
     if os.environ.get("NGP_BENCH_COMPACT_BWD") is not None:   # 0 = the backward pass over all B slots
         tb.compact_backward = bool(int(os.environ["NGP_BENCH_COMPACT_BWD"]))
-    if os.environ.get("NGP_BENCH_MARCH_BEHIND_MLP") is not None:
-        tb.march_behind_mlp = bool(int(os.environ["NGP_BENCH_MARCH_BEHIND_MLP"]))
     return tb
 
 

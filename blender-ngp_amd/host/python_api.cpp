@@ -501,7 +501,6 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_readonly("bl_render_passes", &Testbed::m_bl_render_passes)
 		.def_readwrite("compact_backward", &Testbed::m_compact_backward, "training step (base network family): False (default) = the backward pass over all B slots as the reference does; True = the backward pass runs over the samples whose loss gradient is not zero in all four channels (ray tails in fp16: 30-45 % of a batch are), moved to the front of a second set of buffers and counted on the device — same hash-grid gradients bit for bit, MLP weight gradients the same sums in another order.  The kernels of the backward pass get 5-20 us faster each, the step does not (profiles/r05_experiments.md section 8)")
 		.def_property_readonly("backward_live_fraction", &Testbed::backward_live_fraction, "live samples / batch size of the last step whose backward pass ran over the live samples (drains the stream; 1.0 if none did)")
-		.def_readwrite("march_behind_mlp", &Testbed::m_march_behind_mlp, "the next step's march (second stream) waits for the running step's MFMA backward kernel (an event behind it) instead of starting as soon as the host has seen the step's counters")
 		.def_readwrite("ema_on_side_stream", &Testbed::m_ema_on_side_stream, "optimizer step: False (default) = one launch, Adam + Ema, on the training chain; True = the Ema stage (what renderers and snapshots read) runs on the second stream beside the next step's network pass (a gain on the fox photographs only: profiles/r05_experiments.md section 7).  The same bits either way")
 		.def_readwrite("bl_fused_passes", &Testbed::m_bl_fused_passes, "Blender renderer pass loop: True (default) = one fused launch (march + cull + compact + per-NeRF lists) and one host-mailbox poll per pass on the stock tracer's sample budget; False = the reference's launch sequence with its two blocking read-backs per pass (same pixels)")
 		.def_readwrite("bl_reference_schedule", &Testbed::m_bl_reference_schedule, "fused pass loop on the unfused loop's schedule (n_steps from the rays that entered the pass, no resting rays): the same frame bit for bit; the fork's sampler depends on where the pass boundaries fall")

@@ -301,7 +301,6 @@ Testbed::~Testbed() {
 	if (m_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_prefetch_event);
 	if (m_grid_prefetch_event) (void)hipEventDestroy((hipEvent_t)m_grid_prefetch_event);
 	if (m_adam_event) (void)hipEventDestroy((hipEvent_t)m_adam_event);
-	if (m_mlp_done_event) (void)hipEventDestroy((hipEvent_t)m_mlp_done_event);
 	if (m_ema_event) (void)hipEventDestroy((hipEvent_t)m_ema_event);
 	if (m_stream_b) (void)hipStreamSynchronize((hipStream_t)m_stream_b);
 	if (m_stream) (void)hipStreamSynchronize((hipStream_t)m_stream);
@@ -1240,14 +1239,14 @@ void Testbed::maybe_prefetch_next(uint32_t target_batch_size) {
 	p.version = m_state_version; p.n_images = m_nerf.training.n_images_for_training; p.batch = target_batch_size; p.slot = m_gen_slot ^ 1;
 	p.cdf_mode = m_nerf.training.cdf_mode();
 	order_stream_b_behind_counters();
-	// (holding the march back until the step's MLP backward kernel is through was measured: no gain, 0.587 -> 0.593 ms)
+	// (holding the march back until the step's MLP backward kernel is through was measured twice: round 3 0.587 -> 0.593 ms; round 5 0.515 -> 0.548 ms on lego, fox unchanged — the march,
+	// squeezed into a shorter window, costs the binning passes more than the MFMA kernel gains: profiles/r05_experiments.md section 8)
 	// Data parallel over more than one rank: the gradient exchange (reduce-scatter, all-gather: RCCL kernels on a few workgroups, bound by the xGMI links) follows the
 	// backward pass on stream A and leaves the chip idle for as long as the march takes on its own (~140 us vs 61-370 us of wire time at 8-2 ranks).  The
 	// march is therefore held back until the gradients are final and runs BESIDE THE EXCHANGE with all its workgroups: the backward pass loses the neighbour that costs it
 	// ~45 us (183 us alone, 229 beside the march), the march costs nothing.  Same kernel, same inputs, same samples.
 	const bool behind_exchange = m_dp_comm && m_dp_march_behind_exchange && m_grid_grad_event_recorded;
 	if (behind_exchange) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_grid_grad_event, 0));
-	else if (m_march_behind_mlp && m_mlp_done_recorded) HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_mlp_done_event, 0));   // the running step's MFMA kernel first: it needs its two workgroups per CU
 	launch_generate(m_stream_b, p.slot, p.R, p.max_inference, rng, !behind_exchange);
 	if (!m_prefetch_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_prefetch_event = e; }
 	HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_prefetch_event, (hipStream_t)m_stream_b));
@@ -1515,22 +1514,16 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		const bool train_extra_dims = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;   // testbed_nerf.cu:2925
 		if (train_extra_dims) m_dl_dextra.enlarge((size_t)target_batch_size * m_n_extra_dims * 4);
 		const NgpNetVariant* variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims ? m_dl_dextra.as<float>() : nullptr);
-		void* mlp_done = nullptr;
-		m_mlp_done_recorded = false;
-		if (m_march_behind_mlp) {
-			if (!m_mlp_done_event) { hipEvent_t e; HIP_CHECK_THROW(hipEventCreateWithFlags(&e, STEP_EVENT_FLAGS)); m_mlp_done_event = e; }
-			mlp_done = m_mlp_done_event; m_mlp_done_recorded = true;
-		}
 		if (compact_now) {
 			uint32_t* n_live = m_live_count.as<uint32_t>() + m_live_parity;
 			check(ngp_hip_nerf_backward_live(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-			                                 OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), mlp_done, m_want_grid_grad_event ? m_grid_grad_event : nullptr,
+			                                 OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, m_want_grid_grad_event ? m_grid_grad_event : nullptr,
 			                                 m_live_index.as<uint32_t>(), m_coords_live.as<float>(), n_live, m_live_count.as<uint32_t>() + (m_live_parity ^ 1u)), "nerf_backward (live samples)");
 			m_live_last_batch = target_batch_size; m_live_last_parity = m_live_parity;
 			m_live_parity ^= 1u;
 		} else
 		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), mlp_done,
+		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
 		                            m_want_grid_grad_event ? m_grid_grad_event : nullptr, nullptr, variant), "nerf_backward");
 		profile_end(PK_BACKWARD, target_batch_size);
 		if (train_extra_dims) {   // compute_extra_dims_gradient_train_nerf (2925-2931, 3333-3346): per image, the sum over its rays' compacted samples

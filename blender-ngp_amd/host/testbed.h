@@ -405,9 +405,6 @@ public:
 	uint32_t m_live_parity = 0;
 	float backward_live_fraction();          // pyngp (read-only; drains the stream): live samples / batch of the last compacted step
 	uint32_t m_live_last_batch = 0, m_live_last_parity = 0;
-	bool m_march_behind_mlp = false;         // pyngp: march_behind_mlp — the run-ahead march waits (stream B) for the backward pass's MFMA kernel of the running step
-	void* m_mlp_done_event = nullptr;
-	bool m_mlp_done_recorded = false;
 	bool m_ema_on_side_stream = false;       // pyngp: ema_on_side_stream — the optimizer step's Ema stage on stream B (optimizer_step()); off: measured slower on three of four workloads
 	void join_side_ema();                    // stream A waits for the pending Ema stage (readers of m_ema / m_inference_params call it; so does sync())
 	bool m_bl_fused_passes = true;            // NerfRenderer::fused_passes and its schedule knobs (nerf_renderer.h)
