@@ -134,6 +134,11 @@ def fox_leg(steps, bytes_per_unit, min_train_step=1000, survey_steps=32, hbm_pea
         focal_px = 0.5 * float((w, h)[int(tb.fov_axis)]) / float(np.tan(0.5 * float(tb.fov) * np.pi / 180.0))
         lo, hi = tb.aabb
         bl = bl_render_on(tb, w, h, set_view, focal_px, (list(lo), list(hi)), ([lo[0] - 1.0, lo[1] - 1.0, lo[2] - 1.0], [hi[0] + 1.0, hi[1] + 1.0, hi[2] + 1.0]), 0.0, frames=4, n_nerfs_list=(1,))
+        if bl.get("bl_network_samples_1nerf") and bl.get("stock_network_samples"):
+            bl["bl_over_stock_samples_1nerf"] = round(bl["bl_network_samples_1nerf"] / bl["stock_network_samples"], 2)
+            bl["note"] = ("the fork's renderer takes this many times the stock tracer's samples at the same rate per sample: its rays restart t = 0 (and with it the cone's step size) where they enter the "
+                          "render box (src/nerf_renderer.cu:127-145) and this fork's loader (NERF_SCALE 1, offset 0) leaves the fox cameras outside the box; with the camera inside the box the two renderers' "
+                          "sample counts agree within 2 % (profiles/r05_experiments.md section 6; tests/test_baseline_configs_gpu.py::test_fox_blender_renderer_frame_matches_oracle_and_its_cone_restarts_at_the_box)")
         out["bl_render"] = bl
     except Exception as e:   # the leg's other numbers stand on their own
         out["bl_render"] = {"failed": "%s: %s" % (type(e).__name__, e)}
