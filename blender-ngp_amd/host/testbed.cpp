@@ -1264,7 +1264,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_dloss.enlarge((size_t)target_batch_size * OUT_STRIDE * 2);
 	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
 	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
-	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes_for(&m_desc, target_batch_size));   // sized for this level table (776 -> 453 MB at 2^18 with base.json)
+	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes_for(&m_desc, target_batch_size));   // sized for this level table (778 -> 405 MB at 2^18 with base.json)
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(target_batch_size, next_max_inference(target_batch_size))));
 
 	// prepare_for_training_steps (testbed_nerf.cu:2861-2868)

@@ -145,7 +145,7 @@ int ngp_hip_nerf_forward_ws(void* stream, const NgpNetDesc* desc_dev, const uint
 /* bytes of scratch ngp_hip_nerf_backward needs for a batch of n (n must be a multiple of 256). Host only.
  *   ..._bytes(n)                  enough for ANY level table (every level priced as a dense one: 160 bytes of sort records per sample and level);
  *   ..._bytes_for(desc_host, n)   what THIS level table needs: the records of the 16 levels are packed, a hashed level takes 48 bytes per sample, a dense one 160
- *                                 (configs/nerf/base.json at n = 2^18: 453 MB instead of 776 MB).  A caller that sizes its scratch this way passes the same
+ *                                 (configs/nerf/base.json at n = 2^18: 405 MB instead of 778 MB).  A caller that sizes its scratch this way passes the same
  *                                 `desc_host` to ngp_hip_nerf_backward, and `desc_dev` must be a device copy of exactly that struct: host and device derive the
  *                                 record offsets from their own copy (desc_host == NULL: the size check falls back to ..._bytes(n)). */
 uint64_t ngp_hip_nerf_backward_scratch_bytes(uint32_t n);
