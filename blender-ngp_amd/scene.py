@@ -10,6 +10,7 @@ The driver mirrors scripts/run.py: `while testbed.frame()` until training_step >
 test-view PSNR / SSIM loop (run.py:216-303) via metrics.eval_psnr_ssim.
 """
 import math
+import json
 import os
 import sys
 import time
@@ -140,6 +141,10 @@ def build_testbed(ds, config_path=None, seed=1337):
     t.nerf.render_with_lens_distortion = True
     t.exposure = 0.0
     t.shall_train = True
+    # soak runs of the host-side options (INTEGRATION.md "Host-side options"): NGP_SCENE_TESTBED_OPTIONS='{"compact_backward": true}' python -m pytest tests -m gpu
+    # sets them on every Testbed built here (the tests and the bench build theirs through this function); unset = the product defaults
+    for key, value in json.loads(os.environ.get("NGP_SCENE_TESTBED_OPTIONS", "{}")).items():
+        setattr(t, key, value)
     return t
 
 
