@@ -1148,12 +1148,15 @@ static uint64_t gb_partials_bytes(const NgpNetDesc* desc_host) {
 
 // waves per SIMD of the scatter pass for batches that are not in ray order (SDF: dense levels as pair records): at 4 (128 registers) the kernel spills 37 registers; at 3 it does
 // not and the SDF backward group is 2.5-5 % shorter (237-245 -> 231-233 us; 2: no gain) — tools: NGP_EXTRA_HIP_FLAGS=-DNGP_GB_UNORDERED_SCATTER_WAVES=n python build.py --force
+#ifndef NGP_GB_ORDERED_SCATTER_WAVES
+#define NGP_GB_ORDERED_SCATTER_WAVES 4   // ray-ordered batches; round 5, lego step 0.512-0.518 ms at 4, 0.532-0.547 at 3, 0.536-0.540 at 5 (fox 0.638-0.639 / 0.642-0.653 / 0.641-0.654)
+#endif
 #ifndef NGP_GB_UNORDERED_SCATTER_WAVES
 #define NGP_GB_UNORDERED_SCATTER_WAVES 3
 #endif
 template <int D, bool SCATTER, bool ORDERED = true>   // ORDERED: the batch is in ray order (NeRF training): dense levels merge runs of samples that share a cell; false: pair records
 // (38 KiB of LDS: four workgroups per CU = four waves per SIMD; the register cap keeps the kernel there — and inside what the run-ahead march leaves beside it)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? (ORDERED ? 4 : NGP_GB_UNORDERED_SCATTER_WAVES) : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SCATTER ? (ORDERED ? NGP_GB_ORDERED_SCATTER_WAVES : NGP_GB_UNORDERED_SCATTER_WAVES) : 8, 8))) gb_fx_bin_kernel(const NgpNetDesc* __restrict__ desc, const float* __restrict__ coords, uint32_t coord_stride, uint32_t n,
                                                         const h2* __restrict__ dx_planes, GbFxCounters* __restrict__ ctr, void* __restrict__ records, const GbRecordOffsets rec_off, uint32_t* __restrict__ wg_hist, uint32_t level_mask,
                                                         WgradJob wgrad, const uint32_t* __restrict__ n_live) {
 	NGP_RAISE_CHAIN_PRIORITY();
