@@ -2142,7 +2142,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 		int cur = 1;
 		uint32_t n_alive = read_alive(), i = 1;
 		while (n_alive > 0 && i < MARCH_ITER) {
-			const uint32_t n_steps = std::min(std::max(pass_samples / n_alive, 1u), m_nerf.render_max_steps_per_pass);   // NerfTracer::trace (2231), cap raised (see below)
+			const uint32_t n_steps = std::min(std::max(pass_samples / n_alive, 1u), m_nerf.render_steps_cap());   // NerfTracer::trace (2231), cap raised (see below)
 			if (trace) fprintf(stderr, "render pass i=%u n_alive=%u n_steps=%u t=%.3f ms\n", i, n_alive, n_steps, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - trace_t0).count());
 			NgpPayload* payloads = m_tr_payload[cur].as<NgpPayload>();
 			NgpCoord* net_in = m_tr_net_in.as<NgpCoord>();
@@ -2234,7 +2234,7 @@ void Testbed::render_nerf(RenderBuffer& rb, const float focal_length[2], const M
 			any = true;
 			// NerfTracer::trace (2231): clamp(n_rays_initialized / n_alive, 1, 8).  The per-ray sample sequence does not depend on how it is cut
 			// into passes and n_alive * n_steps <= n_rays keeps every buffer as sized for 8, so the cap is raised once few rays are left.
-			const uint32_t n_steps = std::min(std::max(pt.count / pt.n_alive, 1u), m_nerf.render_max_steps_per_pass);
+			const uint32_t n_steps = std::min(std::max(pt.count / pt.n_alive, 1u), m_nerf.render_steps_cap());
 			if (trace) fprintf(stderr, "render pass part=%u i=%u n_alive=%u n_steps=%u\n", p, pt.i, pt.n_alive, n_steps);
 			NgpPayload* payloads = (NgpPayload*)buf(m_tr_payload[cur], sizeof(NgpPayload), pt.start);
 			NgpCoord* net_in = (NgpCoord*)buf(m_tr_net_in, 8 * sizeof(NgpCoord), pt.start);

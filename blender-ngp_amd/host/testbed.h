@@ -243,7 +243,9 @@ struct Nerf {
 	uint32_t render_n_streams = 1;           // >1 traces the frame as independent pixel ranges on separate streams (measured slower on ROCm 7.0: 16 -> 28 ms at 2)
 	uint32_t render_max_skips_per_pass = 96; // fused-compaction tracer: empty voxels a ray may step over per pass before it rests until the next one (ngp_hip_generate_next_inputs); 0: no limit, as the reference.  Same image.
 	float render_pass_samples_factor = 4.0f; // fused-compaction tracer: network samples per pass = this x the frame's pixels (the reference: 1); [1, 4].  Same image; 800x800 on MI355X: 1 -> 7.3 ms, 2 -> 5.8, 3 -> 5.4, 4 -> 5.35 (fewer, larger passes: tools/render_probe.py)  Round 3 re-sweep at HEAD (tools/render_probe.py NGP_PROBE_SWEEP): 3 -> 5.63 ms, 4 -> 5.48 ms: 4.
-	uint32_t render_max_steps_per_pass = 64; // the reference's m_max_steps_inbetween_compactions is 8 (testbed.h NerfTracer)
+	uint32_t render_max_steps_per_pass = 0;  // 0 = by the scene (round 5): 64 with one cascade (lego stand-in: 5.2 ms per 800 x 800 frame; 5.6 at 16, 6.9 at 8), 8 — the reference's
+	                                         // m_max_steps_inbetween_compactions (testbed.h NerfTracer) — with several (fox photographs: 18.1 ms per 1080 x 1920 frame; 18.4 at 16, 19.2 at 64); same pixels
+	uint32_t render_steps_cap() const { return render_max_steps_per_pass ? render_max_steps_per_pass : (max_cascade > 0 ? 8u : 64u); }
 	bool render_with_lens_distortion = false;
 	float sharpen = 0.f;
 	int show_accel = -1;
