@@ -197,7 +197,7 @@ def bl_render_on(tb, w, h, set_view, focal, nerf_box, scene_box, second_nerf_shi
 
         bl = pyngp.Testbed(pyngp.TestbedMode.Nerf)
         bl.render_trace = bool(tb.render_trace)
-        for knob, env in (("bl_max_skips_per_pass", "BL_SKIPS"), ("bl_pass_samples_factor", "BL_FACTOR"), ("bl_fused_passes", "BL_FUSED")):   # dev: schedule sweeps
+        for knob, env in (("bl_max_skips_per_pass", "BL_SKIPS"), ("bl_max_steps_per_pass", "BL_STEPS"), ("bl_pass_samples_factor", "BL_FACTOR"), ("bl_fused_passes", "BL_FUSED")):   # dev: schedule sweeps
             if os.environ.get(env):
                 setattr(bl, knob, type(getattr(bl, knob))(float(os.environ[env])))
         out["bl_schedule"] = {"fused_passes": bool(bl.bl_fused_passes), "max_skips_per_pass": int(bl.bl_max_skips_per_pass), "pass_samples_factor": float(bl.bl_pass_samples_factor), "max_steps_per_pass": int(bl.bl_max_steps_per_pass)}
