@@ -2474,7 +2474,8 @@ static int launch_encode(void* stream, const NgpNetDesc* desc_dev, const uint16_
 	const uint32_t items = 16u * (n_pad / ENC_CHUNK);
 	// persistent workgroups and items per claim by the size of the pass (round 5, profiles/r05_encoder_constants.md: swept on a fox step's own 515 k samples and on 2^18 ... 8 M random points): a
 	// small pass wants single-item claims (its tail is a third of it), a large one four items per claim; four workgroups per CU beat eight at every size
-	const uint32_t blocks_default = 1024u, claim_default = items <= 12288u ? 1u : items <= 32768u ? 2u : 4u;
+	// (a pass of 2^18 samples or fewer — the SDF config's batch, a tracer's late passes — is 6-8 % faster on 768 workgroups: 104 / 123 us against 113 / 131)
+	const uint32_t blocks_default = items <= 4096u ? 768u : 1024u, claim_default = items <= 12288u ? 1u : items <= 32768u ? 2u : 4u;
 	const uint32_t blocks_cap = ngp_dev_knob_u32("NGP_HIP_ENC_BLOCKS", blocks_default), items_per_claim = ngp_dev_knob_u32("NGP_HIP_ENC_CLAIM", claim_default);
 	const uint32_t blocks = items < blocks_cap ? items : blocks_cap;
 	static const uint32_t cost_model = ngp_dev_knob_u32("NGP_HIP_ENC_COST", 0u);   // dev: A / B of the queue cut
