@@ -50,14 +50,23 @@ RcclApi* rccl() {
 	static bool tried = false;
 	if (tried) return api.handle ? &api : nullptr;
 	tried = true;
+	// 0. NGP_RCCL_LIBRARY: the operator's choice (another RCCL build; tests/loopback's several-ranks-on-one-GPU stand-in) — used or the binding fails, never skipped;
 	// 1. an RCCL this process already carries; 2. the one that sits NEXT TO the HIP runtime in use (PyTorch ships librccl.so beside its own
 	// libamdhip64 and loads it lazily: binding /opt/rocm's copy instead would pull a second HIP runtime into the process); 3. the system's
+	if (const char* forced = getenv("NGP_RCCL_LIBRARY")) {
+		if (*forced) {
+			api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+			if (!api.handle) return nullptr;
+			api.where = forced;
+		}
+	}
 	Loaded l;
-	dl_iterate_phdr(find_loaded, &l);
+	if (!api.handle) dl_iterate_phdr(find_loaded, &l);
 	const std::string beside = l.hip_dir.empty() ? std::string() : l.hip_dir + "librccl.so", beside1 = l.hip_dir.empty() ? std::string() : l.hip_dir + "librccl.so.1";
 	const char* candidates[] = {l.rccl.empty() ? nullptr : l.rccl.c_str(), beside.empty() ? nullptr : beside.c_str(), beside1.empty() ? nullptr : beside1.c_str(),
 	                            "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	for (const char* c : candidates) {
+		if (api.handle) break;
 		if (!c) continue;
 		api.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
 		if (api.handle) { api.where = c; break; }

@@ -323,10 +323,14 @@ float Testbed::backward_live_fraction() {
 	m_live_count.copy_to_host(words, 8);
 	return (float)words[m_live_last_parity] / (float)m_live_last_batch;
 }
+// (readers on another thread — the worker of request_nerf_render_async — come through here too: the flag is atomic and the wait + clear is one critical section with
+// the record + set of optimizer_step, so a stage is never left un-joined and the event is never waited on while it is being re-recorded)
 void Testbed::join_side_ema() {
-	if (!m_ema_pending) return;
+	if (!m_ema_pending.load(std::memory_order_acquire)) return;
+	std::lock_guard<std::mutex> lock(m_ema_mutex);
+	if (!m_ema_pending.load(std::memory_order_relaxed)) return;
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream, (hipEvent_t)m_ema_event, 0));
-	m_ema_pending = false;
+	m_ema_pending.store(false, std::memory_order_release);
 }
 void Testbed::sync() { join_side_ema(); HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream)); }
 void Testbed::invalidate_training_inputs() { drop_prefetch(); ++m_state_version; }
@@ -1038,6 +1042,13 @@ void Testbed::init_data_parallel(uint32_t rank, uint32_t world_size, const std::
 	m_dp_comm = ngp_rccl_init((int)rank, (int)world_size, id);
 	if (!m_dp_comm) { m_dp_shm.reset(); set_distributed(0, 1); throw std::runtime_error{std::string{"ngp_rccl_init failed: "} + ngp_hip_last_error()}; }
 	m_dp_shm->barrier();
+	// strong scaling keeps the GLOBAL step of the single-GPU run: each rank marches 1 / world of the rays the counter feedback has settled on (at step 0: of the
+	// reference's initial 4096, testbed.cu:2284), so the first data-parallel step is the single-rank step on the same rays instead of a world-times larger one that
+	// overflows the per-rank sample buffer (tests/test_dp_loopback_gpu.py); the feedback carries on from there
+	if (strong_scaling && world_size > 1) {
+		NerfCounters& c = m_nerf.training.counters_rgb;
+		c.rays_per_batch = std::max(next_multiple(c.rays_per_batch / world_size, BATCH_SIZE_GRANULARITY), BATCH_SIZE_GRANULARITY);
+	}
 	// with more than one rank the run-ahead march waits for the gradients and runs beside the exchange (maybe_prefetch_next): that needs the event behind the backward pass
 	m_dp_march_behind_exchange = world_size > 1;
 	if (m_dp_march_behind_exchange) m_want_grid_grad_event = true;
@@ -1654,9 +1665,18 @@ void Testbed::optimizer_step_sharded() {
 // The inference (Ema) fp16 weights after sharded steps: current inside this rank's shard only.  COLLECTIVE (every rank of the communicator): in-place all-gather, 2 B / parameter.
 void Testbed::dp_gather_inference_params() {
 	if (!m_dp_inference_stale) return;
-	if (!m_dp_comm) throw std::runtime_error{"dp_gather_inference_params: the inference (Ema) weights are stale outside this rank's shard and the data-parallel communicator is gone — gather on ALL ranks BEFORE shutdown_data_parallel(); now only reset_network() / load_snapshot() rebuild them"};
+	if (!m_dp_comm) { inference_params_from_training_weights("dp_gather_inference_params"); return; }
 	const uint32_t shard = next_multiple(((uint32_t)m_n_params + m_world_size - 1) / m_world_size, 8u);
 	check(ngp_rccl_allgather_f16(m_dp_comm, m_stream, m_inference_params.as<uint16_t>(), shard), "ngp_rccl_allgather_f16 (inference weights)");
+	sync();
+	m_dp_inference_stale = false;
+}
+// The communicator is gone (shutdown_data_parallel before a gather, a peer that died) and the Ema weights of the other ranks' shards with it.  What every rank still
+// holds whole are the fp16 TRAINING weights (all-gathered at every step): a survivor renders and saves those — the model without the Ema smoothing — instead of
+// being locked out until reset_network / load_snapshot.  Said once on stderr; the fp32 optimizer state stays marked stale (it cannot be rebuilt).
+void Testbed::inference_params_from_training_weights(const char* who) {
+	fprintf(stderr, "%s: the Ema (inference) weights were sharded over data-parallel ranks that are gone; falling back to the training weights of step %u (no Ema smoothing)\n", who, m_training_step);
+	HIP_CHECK_THROW(hipMemcpyAsync(m_inference_params.data(), m_params.data(), (size_t)m_n_params * 2, hipMemcpyDeviceToDevice, (hipStream_t)m_stream));
 	sync();
 	m_dp_inference_stale = false;
 }
@@ -1665,6 +1685,7 @@ void Testbed::require_inference_params(const char* who, bool collective) {
 	join_side_ema();
 	if (!m_dp_inference_stale) return;
 	if (collective && m_dp_comm) { dp_gather_inference_params(); return; }
+	if (!m_dp_comm) { inference_params_from_training_weights(who); return; }
 	throw std::runtime_error{std::string(who) + ": the inference (Ema) weights are sharded over the data-parallel ranks (dp_sharded_ema) and stale outside this rank's shard — call dp_gather_inference_params() on ALL ranks first (a collective), or set render_sharded on every rank so that render() is a collective and gathers by itself"};
 }
 
@@ -1700,8 +1721,9 @@ void Testbed::optimizer_step() {  // Trainer::optimizer_step(stream, LOSS_SCALE)
 		HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)m_stream_b, (hipEvent_t)m_adam_event, 0));
 		check(ngp_hip_optimizer_step(m_stream_b, (uint32_t)m_n_params, m_n_matrix_params, m_optimizer_step, m_learning_rate, m_beta1, m_beta2, m_epsilon, m_l2_reg, LOSS_SCALE, ema_decay, nullptr, nullptr,
 		                                    m_params.as<uint16_t>(), nullptr, nullptr, m_ema.as<float>(), m_inference_params.as<uint16_t>(), NGP_OPT_EMA_ONLY), "optimizer_step (Ema stage, stream B)");
+		std::lock_guard<std::mutex> lock(m_ema_mutex);
 		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_ema_event, (hipStream_t)m_stream_b));
-		m_ema_pending = true;
+		m_ema_pending.store(true, std::memory_order_release);
 	}
 	// tcnn ExponentialDecay::step: after the nested step, lr *= decay_base whenever the step count hits start + k * interval
 	if (m_has_decay && m_optimizer_step >= m_decay_start && (m_decay_end == 0 || m_optimizer_step < m_decay_end) && m_decay_interval && m_optimizer_step % m_decay_interval == 0) {
@@ -1879,7 +1901,11 @@ void Testbed::update_after_training(uint32_t target_batch_size, uint32_t counter
 // array: the runtime pins such a destination for the DMA, and when the array is freed — a 1080 x 1920 frame is 33 MB, above glibc's largest mmap threshold, so every
 // frame's array is a mapping of its own — the unmap of pages the GPU had mapped stalls the process's queues for 18-25 ms.  That, not the tracer, was the fox leg's
 // "38 MP/s" of round 4 (profiles/r05_fox_render_timeline.txt: 20 ms of kernels per frame, 25-30 ms of idle GPU between two frames; 105 MP/s with the staging buffer).
+// One staging buffer, two possible callers at once (render() on the caller's thread, the worker thread of request_nerf_render_async): the whole copy-out is one critical
+// section, so a larger frame on one thread never frees the buffer the other is reading.  Only the training stream is drained — the copy is queued on it;
+// joining the side-stream Ema stage is the business of whoever reads the inference weights, not of a frame copy.
 void Testbed::download(const void* device_src, size_t bytes, void* host_dst) {
+	std::lock_guard<std::mutex> lock(m_download_mutex);
 	if (m_pinned_bytes < bytes) {
 		if (m_pinned) (void)hipHostFree(m_pinned);
 		m_pinned = nullptr; m_pinned_bytes = 0;
@@ -1887,7 +1913,7 @@ void Testbed::download(const void* device_src, size_t bytes, void* host_dst) {
 		m_pinned_bytes = bytes;
 	}
 	HIP_CHECK_THROW(hipMemcpyAsync(m_pinned, device_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)m_stream));
-	sync();
+	HIP_CHECK_THROW(hipStreamSynchronize((hipStream_t)m_stream));
 	memcpy(host_dst, m_pinned, bytes);
 }
 

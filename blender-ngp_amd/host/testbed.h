@@ -317,6 +317,7 @@ public:
 	void fetch_render_surface(RenderBuffer& rb, float* out);
 	void download(const void* device_src, size_t bytes, void* host_dst);   // device -> pinned staging (kept) -> host_dst; never a DMA into the caller's pageable memory (testbed.cpp)
 	void* m_pinned = nullptr; size_t m_pinned_bytes = 0;
+	std::mutex m_download_mutex;             // download() may be entered by the caller's thread and by the async render worker at once
 	uint32_t m_render_shard_rank = 0, m_render_shard_world = 1;
 	DeviceBuffer m_render_gather;
 	// the data-parallel optimizer step (testbed.cpp optimizer_step_sharded): reduce-scatter -> Adam on the rank's shard -> all-gather; false: fp16 all-reduce + replicated step
@@ -328,6 +329,7 @@ public:
 	bool m_dp_inference_stale = false;        // sharded-Ema steps ran since the last dp_gather_inference_params: the inference weights outside this rank's shard are old
 	void set_dp_sharded_ema(bool on);         // only without a live communicator
 	void dp_gather_inference_params();        // COLLECTIVE: in-place all-gather of the fp16 inference weights
+	void inference_params_from_training_weights(const char* who);   // stale sharded Ema weights and no communicator left: fall back to the (whole) training weights
 	void require_inference_params(const char* who, bool collective);
 	bool m_render_sharded = false;            // render() is a collective over the data-parallel ranks (rows per rank + all-gather); off: local, whole frame
 	bool render_is_collective() const { return m_dp_comm && m_render_sharded; }   // (a one-rank communicator runs the same path: split, gather buffer, RCCL call)
@@ -612,7 +614,7 @@ private:
 	// chain; m_adam_event orders it behind the Adam stage, m_ema_event orders the next Adam stage (which overwrites the weights it reads) and every reader behind it
 	void* m_adam_event = nullptr;
 	void* m_ema_event = nullptr;
-	bool m_ema_pending = false;              // stream A has not yet been ordered behind the last Ema launch
+	std::atomic<bool> m_ema_pending{false}; std::mutex m_ema_mutex;              // stream A has not yet been ordered behind the last Ema launch
 	void maybe_prefetch_grid_samples(uint32_t next_step);
 	void launch_grid_samples(void* stream, uint32_t n_uniform, uint32_t n_nonuniform);   // memset of the splat buffer + the two generators; advances density_grid_rng twice
 	void* m_counters_event = nullptr;
