@@ -416,6 +416,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("rank %d of %d: bench.py needs a GPU (no CPU fallback in the product path)" % (rank, world))
+    # NGP_BENCH_LOOPBACK=1 (tests only): all ranks on device 0, the nccl* names served by tests/loopback/librccl_loopback.so (NGP_RCCL_LIBRARY) and this script's own
+    # control traffic (barriers, max-over-ranks) on gloo — the N > 1 code path of this file and of the Testbed on a one-GPU box.  Its timings say nothing about scaling.
+    loopback = os.environ.get("NGP_BENCH_LOOPBACK") == "1"
+    if loopback:
+        if not os.environ.get("NGP_RCCL_LIBRARY"):
+            raise SystemExit("NGP_BENCH_LOOPBACK=1 needs NGP_RCCL_LIBRARY=<tests/loopback/librccl_loopback.so>: real RCCL refuses two ranks on one device")
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d of %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, world, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -429,11 +436,16 @@ def main():
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: its env:// rendezvous
+        if loopback:
+            dist.init_process_group("gloo")
+            if a.dp_impl != "product":
+                raise SystemExit("NGP_BENCH_LOOPBACK: only --dp_impl product (the torch driver all-reduces the gradients with torch's own RCCL)")
+        elif world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run: its env:// rendezvous
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 1000), rank=0, world_size=1, device_id=dev)
 
+    ctl_dev = torch.device("cpu") if loopback else dev   # where this script's own control reductions live (gloo reduces host tensors)
     B = 1 << 18
     ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
     tb = scene.build_testbed(ds)
@@ -454,7 +466,9 @@ def main():
         except Exception as e:   # e.g. no RCCL to bind, a rendezvous that times out
             print("rank %d: product data-parallel path failed to initialise (%s); using the torch.distributed driver" % (rank, e), file=sys.stderr, flush=True)
             ok = 0.0
-        t = torch.tensor([ok], dtype=torch.float64, device=dev)
+            if loopback:
+                raise
+        t = torch.tensor([ok], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)   # all ranks or none
         if float(t.item()) == 1.0:
             dp_impl = "product"
@@ -494,7 +508,7 @@ def main():
             v = scene.eval_test_views(tb, ds, spp=1, max_views=min(a.n_test, 2))[0]
             tb.shall_train = True   # eval_test_views switches training off like run.py does
             if use_dp:              # every rank must take the same decision
-                t = torch.tensor([v], dtype=torch.float64, device=dev)
+                t = torch.tensor([v], dtype=torch.float64, device=ctl_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 v = float(t.item())
             return v
@@ -540,10 +554,10 @@ def main():
     tb.set_profiling(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([samples, rays, pre_compaction], dtype=torch.float64, device=dev)
+        s = torch.tensor([samples, rays, pre_compaction], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(s)
         samples, rays, pre_compaction = (float(x) for x in s.tolist())
 
@@ -560,8 +574,8 @@ def main():
             w_samples += min(one_step(), B)
         tb.sync(); torch.cuda.synchronize(); dist.barrier()
         w_dt = time.perf_counter() - t1
-        t = torch.tensor([w_dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); w_dt = float(t.item())
-        t = torch.tensor([w_samples], dtype=torch.float64, device=dev); dist.all_reduce(t); w_samples = float(t.item())
+        t = torch.tensor([w_dt], dtype=torch.float64, device=ctl_dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); w_dt = float(t.item())
+        t = torch.tensor([w_samples], dtype=torch.float64, device=ctl_dev); dist.all_reduce(t); w_samples = float(t.item())
         weak = {"value": round(w_samples / w_dt, 1), "unit": "samples/s", "ms_per_step": round(1000.0 * w_dt / a.steps, 4), "steps": a.steps, "global_batch": B * world,
                 "note": "same run, after the strong-scaled timed region: 2^18 compacted samples per GPU and step, 96 untimed steps for rays_per_batch to re-adapt"}
         tb.strong_scaling = True
@@ -591,10 +605,10 @@ def main():
         rdt = sum(frame_ms) / n_frames / 1e3
         n_render_samples = float(tb.render_samples_evaluated)
         if render_sharded and world > 1:
-            t = torch.tensor([rdt], dtype=torch.float64, device=dev)
+            t = torch.tensor([rdt], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rdt = float(t.item())
-            t = torch.tensor([n_render_samples], dtype=torch.float64, device=dev)
+            t = torch.tensor([n_render_samples], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(t)
             n_render_samples = float(t.item())
         extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_warmup_frames": n_warm, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
@@ -716,7 +730,7 @@ def main():
     if weak is not None:
         line["weak_scaling"] = weak
     if use_dp:   # what the communicator itself says, and what the step's exchanges cost (HIP events on the training stream, survey steps)
-        dp_info = {"impl": dp_impl, "world_size_env": world, "rccl_comm_ranks": int(tb.dp_comm_size) if dp_impl == "product" else int(dist.get_world_size()),
+        dp_info = {"impl": dp_impl, "world_size_env": world, "loopback_on_one_device": loopback, "rccl_comm_ranks": int(tb.dp_comm_size) if dp_impl == "product" else int(dist.get_world_size()),
                    "sharded_optimizer": bool(tb.dp_sharded_optimizer) if dp_impl == "product" else False}
         for k_name, label in (("grad_exchange", "grad_exchange_us_per_step"), ("param_gather", "param_gather_us_per_step")):
             if k_name in kernels:

@@ -171,3 +171,30 @@ def test_exchange_variants_over_two_ranks(variant, single, tmp_path):
     assert bool(a["refused_stale_inference"]) == (variant not in ("replicated_optimizer", "replicated_ema"))
     assert np.isfinite(float(a["loss"])) and 0.5 < float(a["loss"]) / single["loss"] < 2.0      # (weak: twice the global batch)
     assert open(os.path.join(str(tmp_path), "rank0.msgpack"), "rb").read() == open(os.path.join(str(tmp_path), "rank1.msgpack"), "rb").read()
+
+
+def _bench(args, timeout=600):
+    env = loopback_env()
+    env.update(NGP_BENCH_LOOPBACK="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert r.returncode == 0 and lines, "bench.py %s: exit %d\n%s\n%s" % (" ".join(args), r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return lines
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's own N > 1 path — self-launch through torch.distributed.run, --preflight, the product data-parallel step under its timing protocol, the weak-scaled
+    figure of the same run, the row-sharded evaluation renders — with two ranks on the one GPU (NGP_BENCH_LOOPBACK: device 0 for every rank, control traffic on gloo).
+    What it proves is that the line the driver will ask an 8-GPU node for can be produced; its numbers are two processes sharing one GPU, not a scaling figure."""
+    pre = _bench(["--gpus", "2", "--preflight"])
+    assert pre[-1]["preflight"] == "ok" and pre[-1]["n_gpus"] == 2
+    line = _bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--res", "128", "--n_train", "12", "--n_test", "2", "--min_train_step", "60", "--psnr_gate", "0", "--no_cpu_baseline"])[-1]
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["scaling"] == "strong" and line["unit"] == "samples/s"
+    dp = line["data_parallel"]
+    assert dp["impl"] == "product" and dp["rccl_comm_ranks"] == 2 and dp["loopback_on_one_device"] is True and dp["sharded_optimizer"] is True
+    assert line["config"]["global_batch"] == 1 << 18 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["timed_from_training_step"] >= 60
+    assert line["weak_scaling"]["global_batch"] == 2 << 18 and line["weak_scaling"]["value"] > 0
+    assert line["render_ranks"] == 2 and line["render_rows_per_rank"] == 64 and np.isfinite(line["psnr_db"]) and line["psnr_db"] > 15.0
+    assert line["roofline"]["achieved"] > 0 and "cpu_baseline" not in line
