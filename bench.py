@@ -401,6 +401,12 @@ def main():
                     "multi-NeRF renderer next to the stock tracer, plumbing = configs #1 / #5 at 2^18; 'none' switches them off")
     ap.add_argument("--preflight", action="store_true", help="multi-GPU plumbing check only (no training): library, RCCL binding, init_data_parallel's rendezvous, a communicator over all ranks and one "
                     "1 KiB collective of each kind the step uses, every stage under a 30 s watchdog that names the stage and the rank; prints {\"preflight\": \"ok\"} on rank 0")
+    ap.add_argument("--scene", default="", help="transforms_train.json of a dataset ON DISK in the nerf-synthetic layout (e.g. .../nerf_synthetic/lego/transforms_train.json; pass the file, not the "
+                    "directory: a directory loads every *.json in it, testbed_nerf.cu:2738-2743).  Training data then goes through the product loader (Testbed.load_training_data: mini_json, PNG / JPEG / EXR "
+                    "readers, nerf_matrix_to_ngp) instead of the in-memory procedural scene; a file without \"scale\" / \"offset\" / \"aabb\" keys gets \"scale\": 0.33, \"offset\": [0.5, 0.5, 0.5] injected in a "
+                    "patched copy (this fork defaults to 1.0 / 0: SURVEY.md fact 5).  `data` becomes \"real\" and config.workload names the path")
+    ap.add_argument("--test_scene", default="", help="transforms_test.json for the PSNR gate and the evaluation renders (run.py --test_transforms: run.py:216-303); without it the gate is off and the "
+                    "render leg traces training poses")
     ap.add_argument("--psnr_gate", type=float, default=35.0, help="BASELINE config #3 'train to 35 PSNR then render': keep pre-training (untimed) until the held-out PSNR reaches this")
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -447,7 +453,15 @@ def main():
 
     ctl_dev = torch.device("cpu") if loopback else dev   # where this script's own control reductions live (gloo reduces host tensors)
     B = 1 << 18
-    ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
+    if a.scene:
+        ds = scene.load_disk_dataset(a.scene, a.test_scene or None, max_test=a.n_test, decode_train=(world == 1 and not a.no_cpu_baseline))
+        a.n_train = ds["n_train"]
+        if not ds["test_images"]:
+            a.psnr_gate = 0.0
+    else:
+        ds = scene.make_dataset(a.n_train, a.n_test, a.res, dev)
+    W, Hh = int(ds.get("w", ds["res"])), int(ds.get("h", ds["res"]))   # frame size of the render leg = the dataset's image size (800 x 800 for lego and its stand-in)
+    views = ds["test_poses"] if len(ds["test_poses"]) else ds["train_poses"]
     tb = scene.build_testbed(ds)
     if os.environ.get("NGP_BENCH_SIDE_EMA") is not None:   # dev A / B (also read by bench_legs.dev_overrides): 0 = the Ema stage back on the training chain
         tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
@@ -585,22 +599,27 @@ def main():
     extra = {}
     render_sharded = dp_impl == "product" and use_dp
     if not a.no_render and (render_sharded or rank == 0):
-        psnr, ssim, per = scene.eval_test_views(tb, ds, spp=a.eval_spp, max_views=a.n_test)
+        if len(ds["test_images"]):
+            psnr, ssim, per = scene.eval_test_views(tb, ds, spp=a.eval_spp, max_views=a.n_test)
+        else:   # a dataset on disk without test transforms: frames are timed, nothing is scored
+            psnr, ssim, per = float("nan"), float("nan"), []
+            tb.shall_train = False; tb.background_color = [0.0, 0.0, 0.0, 1.0]; tb.snap_to_pixel_centers = True; tb.nerf.render_min_transmittance = 1e-4
+            tb.fov_axis = 0; tb.fov = ds["camera_angle_x"] * 180 / np.pi
         n_frames = 9
-        tb.set_nerf_camera_matrix(ds["test_poses"][0][:3, :])
+        tb.set_nerf_camera_matrix(views[0][:3, :])
         # untimed: the PSNR / SSIM arithmetic above ran on the host for seconds and the GPU's clocks have dropped — the first frames after it take 3-5x as long
         # (r03_d: 28.2 ms, then 5.3-6.0 ms), so the leg warms up with a fixed number of frames before the timed ones, like the training leg's warm-up steps
         n_warm = 12   # (r04_k: with 4 warm-up frames the first timed frame of the driver's short run still took 14 ms — the clocks had not come back up after the host-side PSNR / SSIM seconds)
         for i in range(n_warm):
-            tb.set_nerf_camera_matrix(ds["test_poses"][i % len(ds["test_poses"])][:3, :])
-            tb.render(a.res, a.res, 1, True)
+            tb.set_nerf_camera_matrix(views[i % len(views)][:3, :])
+            tb.render(W, Hh, 1, True)
         if render_sharded:
             dist.barrier()
         frame_ms = []
         for i in range(n_frames):
             t1 = time.perf_counter()
-            tb.set_nerf_camera_matrix(ds["test_poses"][i % len(ds["test_poses"])][:3, :])
-            tb.render(a.res, a.res, 1, True)
+            tb.set_nerf_camera_matrix(views[i % len(views)][:3, :])
+            tb.render(W, Hh, 1, True)
             frame_ms.append((time.perf_counter() - t1) * 1e3)
         rdt = sum(frame_ms) / n_frames / 1e3
         n_render_samples = float(tb.render_samples_evaluated)
@@ -611,9 +630,9 @@ def main():
             t = torch.tensor([n_render_samples], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(t)
             n_render_samples = float(t.item())
-        extra = {"render_MP_per_s": round(a.res * a.res / rdt / 1e6, 2), "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_warmup_frames": n_warm, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
-                 "render_ranks": world if render_sharded else 1, "render_rows_per_rank": (a.res + world - 1) // world if render_sharded else a.res,
-                 "psnr_db": round(psnr, 2), "ssim": round(ssim, 4), "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
+        extra = {"render_MP_per_s": round(W * Hh / rdt / 1e6, 2), "render_resolution": [W, Hh], "render_ms_per_frame": round(rdt * 1e3, 2), "render_frames": n_frames, "render_warmup_frames": n_warm, "render_ms_min_max": [round(min(frame_ms), 2), round(max(frame_ms), 2)], "render_ms_frames": [round(x, 2) for x in frame_ms], "render_network_samples_per_frame": int(n_render_samples),
+                 "render_ranks": world if render_sharded else 1, "render_rows_per_rank": (Hh + world - 1) // world if render_sharded else Hh,
+                 "psnr_db": round(psnr, 2) if per else None, "ssim": round(ssim, 4) if per else None, "psnr_at_step": int(tb.training_step), "eval_views": len(per), "eval_spp": a.eval_spp}
 
     if rank != 0:
         if use_dp:
@@ -709,10 +728,14 @@ def main():
         g["note"] = "wave-per-ray march, %d persistent waves (640 4-wave workgroups: 2.5 per CU) on 1024 SIMDs; runs one step ahead on a second stream beside the backward pass" % g["resident_waves"]
 
     line = {
-        "metric": "train samples/s (compacted samples back-propagated per second), nerf-synthetic/lego stand-in",
+        "metric": "train samples/s (compacted samples back-propagated per second), " + ("dataset on disk" if a.scene else "nerf-synthetic/lego stand-in"),
         "value": round(samples / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000.0 * dt / a.steps, 4),
-        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "procedural-lego %dx%d x%d RGBA8 views (scale 0.33, offset 0.5, aabb_scale 1), configs/nerf/base.json (L=16 F=2 T=2^19, 64-wide MLPs), batch 2^18 compacted samples per GPU" % (a.res, a.res, a.n_train),
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f16", "data": "real" if a.scene else "synthetic",
+        "config": {"workload": ("%s: %d frames %dx%d through Testbed.load_training_data (scale %.4g, offset %s%s, aabb_scale %d)" % (ds["source"], a.n_train, W, Hh, ds["scale"] if not ds["scale_offset_injected"] else 0.33,
+                                ds["offset"] if not ds["scale_offset_injected"] else [0.5, 0.5, 0.5], " injected: the file has no such keys" if ds["scale_offset_injected"] else "", ds["aabb_scale"])
+                                if a.scene else "procedural-lego %dx%d x%d RGBA8 views (scale 0.33, offset 0.5, aabb_scale 1)" % (a.res, a.res, a.n_train))
+                               + ", configs/nerf/base.json (L=16 F=2 T=2^19, 64-wide MLPs), batch 2^18 compacted samples per GPU",
+                   "scene": ds.get("source"), "test_scene": os.path.abspath(a.test_scene) if a.test_scene else None,
                    "global_batch": B if a.scaling == "strong" else B * world, "parallelism": "dp%d" % world if use_dp else "single", "dp_impl": dp_impl},
         "rays_per_s": round(rays / dt, 1), "pre_compaction_samples_per_s": round(pre_compaction / dt, 1),
         "pretrain_steps": pretrain_steps, "timed_from_training_step": int(timed_from), "psnr_at_bench": None if psnr_at_bench is None else round(psnr_at_bench, 2),
@@ -738,7 +761,7 @@ def main():
         dp_info["exchange_us_per_step"] = round(sum(dp_info.get(k, 0.0) for k in ("grad_exchange_us_per_step", "param_gather_us_per_step")), 2)
         line["data_parallel"] = dp_info
     if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(tb, ds, a.res)
+        line["cpu_baseline"] = cpu_baseline(tb, ds, W)
     # ---- the other configs BASELINE names and the fork's own renderer, measured inside this run (bench_legs.py); a leg that fails says why and does not take the line down
     legs = [x for x in a.legs.split(",") if x and x != "none"] if world == 1 else []
     if legs:
@@ -758,8 +781,8 @@ def main():
             try:
                 if leg == "fox":
                     line["fox"] = bench_legs.fox_leg(max(a.steps, 100), BYTES_PER_UNIT, a.min_train_step)
-                elif leg == "bl_render" and not a.no_render:
-                    line["bl_render"] = bench_legs.bl_render_leg(tb, ds, a.res)
+                elif leg == "bl_render" and not a.no_render and len(ds["test_poses"]):
+                    line["bl_render"] = bench_legs.bl_render_leg(tb, ds, W)
                 elif leg == "plumbing":
                     line["plumbing"] = bench_legs.plumbing_leg()
                 else:

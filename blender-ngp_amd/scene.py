@@ -120,6 +120,73 @@ def make_dataset(n_train=100, n_test=20, res=800, device=None, seed=0, aabb_scal
                 test_images=[render_ground_truth(m, res, h, device) for m in test])
 
 
+# ---- a scene on disk: transforms_train.json [+ transforms_test.json] in the nerf-synthetic layout (run.py --scene / --test_transforms) -------------------------
+def _frame_image_path(base, file_path):
+    """the file a frame names: nerf_loader.cu:562-570 appends .png (then .exr) to an extension-less path; run.py:240-252 also tries .jpg / .jpeg"""
+    p = file_path if os.path.isabs(file_path) else os.path.join(base, file_path)
+    if os.path.splitext(os.path.basename(p))[1] and os.path.isfile(p):
+        return p
+    for ext in (".png", ".exr", ".jpg", ".jpeg"):
+        if os.path.isfile(p + ext):
+            return p + ext
+    return p
+
+
+def prepare_training_json(train_json, workdir):
+    """this fork loads with NERF_SCALE = 1 and offset 0 (nerf_loader.h:28, nerf_loader.cu:406-407), so a stock nerf-synthetic file — no "scale",
+    "offset" or "aabb" key — would train the object around the origin of a cube centred on (0.5, 0.5, 0.5).  To benchmark it as the paper did the file must carry
+    "scale": 0.33, "offset": [0.5, 0.5, 0.5] (honoured at nerf_loader.cu:472-474, 499-504).  A file that has the keys is used as it is; otherwise a patched copy is
+    written to `workdir` (frame paths made absolute, so that it may live anywhere) and that path is returned."""
+    meta = json.load(open(train_json))
+    if "scale" in meta or "offset" in meta or "aabb" in meta:
+        return os.path.abspath(train_json), meta, False
+    base = os.path.dirname(os.path.abspath(train_json))
+    meta["scale"], meta["offset"] = 0.33, [0.5, 0.5, 0.5]
+    for f in meta["frames"]:
+        if not os.path.isabs(f["file_path"]):
+            f["file_path"] = os.path.join(base, f["file_path"])
+    os.makedirs(workdir, exist_ok=True)
+    out = os.path.join(workdir, os.path.basename(train_json))
+    with open(out, "w") as fh:
+        json.dump(meta, fh)
+    return out, meta, True
+
+
+def load_disk_dataset(train_json, test_json=None, max_test=None, decode_train=False, workdir=None):
+    """The dict build_testbed / eval_test_views / bench.py work with, for a dataset on disk: training goes through the PRODUCT loader (Testbed.load_training_data on
+    `train_path`), evaluation reads the test transforms as run.py:216-303 does (reference images decoded by the product's own PNG / JPEG reader, pyngp.decode_image).
+    decode_train: also keep host copies of the training images in loader order (bench.py's cpu_baseline hands them to the oracle)."""
+    import tempfile
+    import pyngp
+    workdir = workdir or tempfile.mkdtemp(prefix="ngp_scene_")
+    train_path, meta, patched = prepare_training_json(train_json, workdir)
+    base = os.path.dirname(os.path.abspath(train_json))
+    frames = [f for f in meta["frames"] if os.path.isfile(_frame_image_path(base, f["file_path"]))]   # frames whose file is missing are dropped (nerf_loader.cu:383)
+    first = pyngp.decode_image(_frame_image_path(base, frames[0]["file_path"]))
+    h, w = int(meta.get("h", first.shape[0])), int(meta.get("w", first.shape[1]))
+    if "camera_angle_x" in meta:
+        angle_x = float(meta["camera_angle_x"])
+    elif "fl_x" in meta:
+        angle_x = 2.0 * math.atan(0.5 * w / float(meta["fl_x"]))
+    else:
+        raise ValueError("%s: neither camera_angle_x nor fl_x" % train_json)
+    ds = dict(train_path=train_path, source=os.path.abspath(train_json), scale_offset_injected=patched, res=w, w=w, h=h, camera_angle_x=angle_x,
+              focal=float(meta.get("fl_x", 0.5 * w / math.tan(0.5 * angle_x))), scale=float(meta.get("scale", 1.0)), offset=meta.get("offset", [0.0, 0.0, 0.0]),
+              aabb_scale=int(meta.get("aabb_scale", 1)), n_train=len(frames), train_poses=[np.asarray(f["transform_matrix"], np.float32) for f in frames],
+              test_poses=[], test_images=[])
+    if decode_train:
+        ds["train_images"] = [np.ascontiguousarray(pyngp.decode_image(_frame_image_path(base, f["file_path"]))) for f in frames]
+    if test_json:
+        tmeta = json.load(open(test_json))
+        tbase = os.path.dirname(os.path.abspath(test_json))
+        tframes = tmeta["frames"][:max_test] if max_test else tmeta["frames"]
+        ds["test_poses"] = [np.asarray(f["transform_matrix"], np.float32) for f in tframes]
+        ds["test_images"] = [_frame_image_path(tbase, f["file_path"]) for f in tframes]                  # paths: decoded one at a time by eval_test_views
+        if "camera_angle_x" in tmeta:
+            ds["test_camera_angle_x"] = float(tmeta["camera_angle_x"])
+    return ds
+
+
 def build_testbed(ds, config_path=None, seed=1337):
     """Equivalent of `testbed = ngp.Testbed(mode); testbed.load_training_data(scene); testbed.reload_network_from_file(cfg)` (run.py:84-125)
     for a dataset held in memory (create_empty_nerf_dataset + set_image / set_camera_*: python_api.cu:619, 820-830)."""
@@ -127,15 +194,18 @@ def build_testbed(ds, config_path=None, seed=1337):
     import pyngp as ngp
     t = ngp.Testbed(ngp.TestbedMode.Nerf)
     t.seed = seed
-    n = len(ds["train_images"])
-    t.create_empty_nerf_dataset(n, ds["aabb_scale"], False)
-    t.nerf.training.set_dataset_transform(ds["scale"], ds["offset"])
-    w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
-    for i in range(n):
-        t.nerf.training.set_image_rgba8(i, ds["train_images"][i])
-        t.nerf.training.set_camera_intrinsics(i, ds["focal"], ds["focal"], 0.5 * w, 0.5 * h)
-        t.nerf.training.set_camera_extrinsics(i, ds["train_poses"][i][:3, :], True)
-    t.nerf.training.n_images_for_training = n
+    if ds.get("train_path"):          # a dataset on disk: the product's transforms.json loader + image decoders (run.py:111-115)
+        t.load_training_data(ds["train_path"])
+    else:
+        n = len(ds["train_images"])
+        t.create_empty_nerf_dataset(n, ds["aabb_scale"], False)
+        t.nerf.training.set_dataset_transform(ds["scale"], ds["offset"])
+        w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
+        for i in range(n):
+            t.nerf.training.set_image_rgba8(i, ds["train_images"][i])
+            t.nerf.training.set_camera_intrinsics(i, ds["focal"], ds["focal"], 0.5 * w, 0.5 * h)
+            t.nerf.training.set_camera_extrinsics(i, ds["train_poses"][i][:3, :], True)
+        t.nerf.training.n_images_for_training = n
     t.reload_network_from_file(config_path or os.path.join(HERE, "configs", "nerf", "base.json"))
     # run.py:131-150 defaults for NeRF
     t.nerf.render_with_lens_distortion = True
@@ -169,12 +239,16 @@ def eval_test_views(testbed, ds, spp=8, max_views=None):
     testbed.snap_to_pixel_centers = True
     testbed.nerf.render_min_transmittance = 1e-4
     testbed.fov_axis = 0
-    testbed.fov = ds["camera_angle_x"] * 180 / np.pi
+    testbed.fov = ds.get("test_camera_angle_x", ds["camera_angle_x"]) * 180 / np.pi
     testbed.shall_train = False
     w, h = ds.get("w", ds["res"]), ds.get("h", ds["res"])
     psnrs, ssims = [], []
     views = list(zip(ds["test_poses"], ds["test_images"]))[:max_views]
     for pose, img8 in views:
+        if isinstance(img8, str):     # a dataset on disk: the frame's reference image, read as run.py:253 reads it
+            import pyngp
+            img8 = pyngp.decode_image(img8)
+            h, w = img8.shape[0], img8.shape[1]
         ref = metrics.read_image_rgba8(img8)
         testbed.set_nerf_camera_matrix(pose[:3, :])
         image = testbed.render(w, h, spp, True)
@@ -217,7 +291,7 @@ if __name__ == "__main__":
     print("PSNR=%.2f SSIM=%.4f per-view=%s render_ms=%.1f" % (psnr, ssim, ["%.1f" % p for p in per], tb.render_ms))
 
 
-def write_dataset(ds, directory):
+def write_dataset(ds, directory, with_test=False, stock_keys=False):
     """Write a dataset of make_dataset() in the nerf-synthetic on-disk layout (transforms_train.json + train/r_%03d.png, RGBA8): what
     `Testbed.load_training_data` ingests (src/nerf_loader.cu).  Returns the path of transforms_train.json."""
     import json
@@ -231,7 +305,19 @@ def write_dataset(ds, directory):
         frames.append({"file_path": "./" + name, "transform_matrix": m.tolist()})
     meta = {"fl_x": float(np.float32(ds["focal"])), "fl_y": float(np.float32(ds["focal"])), "cx": 0.5 * ds.get("w", ds["res"]), "cy": 0.5 * ds.get("h", ds["res"]), "w": ds.get("w", ds["res"]), "h": ds.get("h", ds["res"]),
             "camera_angle_x": ds["camera_angle_x"], "aabb_scale": ds["aabb_scale"], "scale": ds["scale"], "offset": list(ds["offset"]), "frames": frames}
+    if stock_keys:   # what a stock nerf-synthetic transforms_train.json carries: camera_angle_x and frames, nothing else (scene.prepare_training_json injects scale / offset)
+        meta = {"camera_angle_x": ds["camera_angle_x"], "frames": frames}
     path = os.path.join(directory, "transforms_train.json")
     with open(path, "w") as f:
         json.dump(meta, f)
+    if with_test and ds.get("test_images"):   # transforms_test.json + test/r_%d.png, as nerf-synthetic ships them (no scale / offset keys needed: only poses and images are read)
+        os.makedirs(os.path.join(directory, "test"), exist_ok=True)
+        tframes = []
+        for i, (img, pose) in enumerate(zip(ds["test_images"], ds["test_poses"])):
+            name = "test/r_%d" % i
+            Image.fromarray(np.ascontiguousarray(img), "RGBA").save(os.path.join(directory, name + ".png"))
+            m = np.eye(4); m[:3, :4] = np.asarray(pose)[:3, :4]
+            tframes.append({"file_path": "./" + name, "transform_matrix": m.tolist()})
+        with open(os.path.join(directory, "transforms_test.json"), "w") as f:
+            json.dump({"camera_angle_x": ds["camera_angle_x"], "frames": tframes}, f)
     return path
