@@ -46,6 +46,8 @@ def dev_overrides(tb):
         tb.ema_on_side_stream = bool(int(os.environ["NGP_BENCH_SIDE_EMA"]))
     if os.environ.get("NGP_BENCH_COMPACT_BWD") is not None:   # 0 = the backward pass over all B slots
         tb.compact_backward = bool(int(os.environ["NGP_BENCH_COMPACT_BWD"]))
+    if os.environ.get("NGP_BENCH_MORTON_GRID") is not None:   # 0 = the occupancy-grid update's samples in the reference's order
+        tb.morton_grid_samples = bool(int(os.environ["NGP_BENCH_MORTON_GRID"]))
     return tb
 
 

@@ -565,6 +565,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property("autofocus_target", [](Testbed& t) { py::array_t<float> a(3); for (int i = 0; i < 3; ++i) a.mutable_data()[i] = t.m_autofocus_target[i]; return a; },
 			[](Testbed& t, const std::vector<float>& v) { if (v.size() != 3) throw std::runtime_error{"autofocus_target takes 3 floats"}; for (int i = 0; i < 3; ++i) t.m_autofocus_target[i] = v[i]; })
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
+		.def_readwrite("morton_grid_samples", &Testbed::m_morton_grid_samples, "occupancy-grid update: True (default) = the update's samples are written in Morton order of the cell each one's first try lands in (thread per cell, the index map inverted: csrc/density_grid.hip), so that the density pass and the splat touch shared lines from neighbouring lanes; False = the reference's order (sample i in slot i).  The same (position, index) pairs either way, hence the same grid bit for bit")
 		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
 		.def_readonly("grid_prefetch_hits", &Testbed::m_grid_prefetch_hits)

@@ -961,17 +961,24 @@ void Testbed::update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t
 	NgpNetVariant nv_density;
 	check(ngp_hip_nerf_density_ws(m_stream, m_desc_gpu.as<NgpNetDesc>(), m_params.as<uint16_t>(), m_grid_positions.as<float>(), 3, n_samples, m_grid_mlp_out.as<uint16_t>(), m_enc_ws.data(), m_enc_ws.bytes(), net_variant(nv_density)), "nerf_density");
 	check(ngp_hip_splat_grid_samples_max(m_stream, n_samples, m_grid_indices.as<uint32_t>(), m_grid_mlp_out.as<uint16_t>(), m_grid_tmp.as<float>(), (int)m_nerf.density_activation), "splat");
-	check(ngp_hip_ema_grid_samples(m_stream, n_elements, decay, grid, m_grid_tmp.as<float>()), "ema");
+	// the update's tail in one call: ema + partial means, bitfield (which sums the partials itself), the pooled levels (round 6: three launches and a memset less on the chain)
+	m_nerf.density_grid_mean.enlarge(4);
+	m_nerf.density_grid_bitfield.enlarge((size_t)GRID_CELLS);
+	m_grid_mean_ws.enlarge((size_t)ngp_hip_density_grid_tail_workspace_bytes());
+	check(ngp_hip_density_grid_ema_mean_bitfield(m_stream, m_nerf.max_cascade + 1, decay, grid, m_grid_tmp.as<float>(), m_nerf.density_grid_mean.as<float>(), m_nerf.density_grid_bitfield.as<uint8_t>(),
+	                                             m_grid_mean_ws.data()), "density_grid_ema_mean_bitfield");
 	++m_nerf.density_grid_ema_step;
-	update_density_grid_mean_and_bitfield();
+	update_density_grid_mean_and_bitfield(true);
 }
 
-void Testbed::update_density_grid_mean_and_bitfield() {  // testbed_nerf.cu:2844-2859
-	m_nerf.density_grid_bitfield.enlarge((size_t)GRID_CELLS);
-	m_nerf.density_grid_mean.enlarge(4);
-	check(ngp_hip_density_grid_mean(m_stream, m_nerf.density_grid.as<float>(), GRID_CELLS, m_nerf.density_grid_mean.as<float>()), "density_grid_mean");
-	check(ngp_hip_grid_to_bitfield_and_pool(m_stream, m_nerf.density_grid.as<float>(), m_nerf.max_cascade + 1, m_nerf.density_grid_mean.as<float>(),
-	                                        m_nerf.density_grid_bitfield.as<uint8_t>()), "grid_to_bitfield_and_pool");
+void Testbed::update_density_grid_mean_and_bitfield(bool bitfield_is_current) {  // testbed_nerf.cu:2844-2859
+	if (!bitfield_is_current) {
+		m_nerf.density_grid_bitfield.enlarge((size_t)GRID_CELLS);
+		m_nerf.density_grid_mean.enlarge(4);
+		check(ngp_hip_density_grid_mean(m_stream, m_nerf.density_grid.as<float>(), GRID_CELLS, m_nerf.density_grid_mean.as<float>()), "density_grid_mean");
+		check(ngp_hip_grid_to_bitfield_and_pool(m_stream, m_nerf.density_grid.as<float>(), m_nerf.max_cascade + 1, m_nerf.density_grid_mean.as<float>(),
+		                                        m_nerf.density_grid_bitfield.as<uint8_t>()), "grid_to_bitfield_and_pool");
+	}
 	m_nerf.bitfield_brick_summary.enlarge(GRID_CELLS / 64 / 32 * 4);
 	check(ngp_hip_bitfield_brick_summary(m_stream, m_nerf.density_grid_bitfield.as<uint8_t>(), m_nerf.bitfield_brick_summary.as<uint32_t>()), "bitfield_brick_summary");
 	m_nerf.brick_summary_valid = true;
@@ -1177,12 +1184,25 @@ void Testbed::launch_grid_samples(void* stream, uint32_t n_uniform, uint32_t n_n
 	const uint32_t n_elements = GRID_CELLS * (m_nerf.max_cascade + 1);
 	float* grid = m_nerf.density_grid.as<float>();
 	HIP_CHECK_THROW(hipMemsetAsync(m_grid_tmp.data(), 0, (size_t)n_elements * 4, (hipStream_t)stream));
-	check(ngp_hip_generate_grid_samples_nonuniform(stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
-	                                               m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f), "generate_grid_samples (uniform)");
+	// (round 6) in Morton order of the cells: the same samples, neighbouring slots = neighbouring cells (density_grid.hip); `morton_grid_samples = false` is the reference's order
+	const size_t ws_words = (size_t)ngp_hip_generate_grid_samples_morton_workspace_bytes() / 4;
+	m_grid_sample_counters.enlarge(2 * ws_words * 4);   // one workspace per half: the second call must not overwrite what the first one's kernels still read
+	uint32_t* ctr = m_grid_sample_counters.as<uint32_t>();
+	if (m_morton_grid_samples)
+		check(ngp_hip_generate_grid_samples_morton(stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+		                                           m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f, ctr), "generate_grid_samples (uniform, Morton order)");
+	else
+		check(ngp_hip_generate_grid_samples_nonuniform(stream, n_uniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+		                                               m_grid_positions.as<float>(), m_grid_indices.as<uint32_t>(), m_nerf.max_cascade + 1, -0.01f), "generate_grid_samples (uniform)");
 	tr.density_grid_rng.advance();
-	check(ngp_hip_generate_grid_samples_nonuniform(stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
-	                                               m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
-	                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
+	if (m_morton_grid_samples)
+		check(ngp_hip_generate_grid_samples_morton(stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+		                                           m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
+		                                           NERF_MIN_OPTICAL_THICKNESS, ctr + ws_words), "generate_grid_samples (nonuniform, Morton order)");
+	else
+		check(ngp_hip_generate_grid_samples_nonuniform(stream, n_nonuniform, tr.density_grid_rng.state, tr.density_grid_rng.inc, m_nerf.density_grid_ema_step, &m_aabb, grid,
+		                                               m_grid_positions.as<float>() + (size_t)n_uniform * 3, m_grid_indices.as<uint32_t>() + n_uniform, m_nerf.max_cascade + 1,
+		                                               NERF_MIN_OPTICAL_THICKNESS), "generate_grid_samples (nonuniform)");
 	tr.density_grid_rng.advance();
 }
 

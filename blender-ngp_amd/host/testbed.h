@@ -300,7 +300,7 @@ public:
 	void train(uint32_t batch_size);
 	void training_prep_nerf(uint32_t batch_size);
 	void update_density_grid_nerf(float decay, uint32_t n_uniform, uint32_t n_nonuniform);
-	void update_density_grid_mean_and_bitfield();
+	void update_density_grid_mean_and_bitfield(bool bitfield_is_current = false);   // true: the update's fused tail already left mean + bitfield; only the brick summary is rebuilt
 	void train_nerf(uint32_t target_batch_size, bool get_loss_scalar);
 	// data-parallel split of train_nerf: begin = everything up to and including backward (gradients ready in
 	// gradients()), end = optimizer step + counter feedback given the GLOBAL (all-rank summed) counters.
@@ -425,6 +425,7 @@ public:
 	                                                   // instead of evaluating every marched sample; same kept samples, measured at par with the flat pass (its tiles pack worse), so off
 	bool m_trace_sync = false;                         // debugging aid: drain both streams behind every launch group and name it on stderr (finds a kernel that never returns)
 	bool m_render_trace = false;                       // debugging aid: the tracers' pass structure (alive rays, steps per pass) on stderr
+	bool m_morton_grid_samples = true;                 // occupancy-grid update: generate the samples in Morton order of their cells (coherent gathers in the density pass and the splat; the same samples, the same grid)
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
 	uint64_t m_prefetch_hits = 0;
@@ -640,6 +641,8 @@ private:
 	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;
+	DeviceBuffer m_grid_mean_ws;             // per-workgroup partial sums of the mean (the update's fused tail)
+	DeviceBuffer m_grid_sample_counters;     // per-workgroup sample counts of the Morton-ordered generators (one workspace per half)
 	DeviceBuffer m_loss_scalar_gpu;
 	// tracer scratch (NerfTracer::enlarge 2270-2295)
 	std::vector<void*> m_render_streams;

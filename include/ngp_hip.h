@@ -223,13 +223,28 @@ int ngp_hip_mark_untrained_density_grid(void* stream, uint32_t n_elements, float
 int ngp_hip_generate_grid_samples_nonuniform(void* stream, uint32_t n_elements, uint64_t rng_state, uint64_t rng_inc, uint32_t step,
                                              const NgpAabb* aabb_host, const float* grid_in, float* out_pos, uint32_t* indices,
                                              uint32_t n_cascades, float thresh);                                              /* :465 */
+/* Not in the reference: the SAME samples as the call above — the same (position, index) pairs, each produced by the reference's body for its sample number i
+ * (:465-494) — but written in another order: thread c stands on cell c (Morton order), inverts the first try's index map for i, and the samples of a workgroup's 1024 cells take
+ * one contiguous slot range in cell order.  Neighbouring slots then hold neighbouring cells, so the density pass (:2833) and the splat (:496) that follow touch shared lines from
+ * neighbouring lanes.  Order-independent consumers (max-splat) give the same grid bit for bit.  No atomics: the slot of a sample is a function of (n, step).
+ * workspace: ngp_hip_generate_grid_samples_morton_workspace_bytes() of device scratch; n_elements <= 2^24. */
+uint64_t ngp_hip_generate_grid_samples_morton_workspace_bytes(void);
+int ngp_hip_generate_grid_samples_morton(void* stream, uint32_t n_elements, uint64_t rng_state, uint64_t rng_inc, uint32_t step,
+                                         const NgpAabb* aabb_host, const float* grid_in, float* out_pos, uint32_t* indices,
+                                         uint32_t n_cascades, float thresh, uint32_t* workspace);
 int ngp_hip_splat_grid_samples_max(void* stream, uint32_t n_elements, const uint32_t* indices, const uint16_t* network_output,
                                    float* grid_out, int density_activation);                                                  /* :496 */
 int ngp_hip_ema_grid_samples(void* stream, uint32_t n_elements, float decay, float* grid_out, const float* grid_in);          /* :532 */
 /* reduce_sum(max(v,0)/n) over cascade 0 (:2851-2852): writes one float to mean_out (zeroed inside). */
 int ngp_hip_density_grid_mean(void* stream, const float* grid, uint32_t n_elements, float* mean_out);
-/* grid_to_bitfield (:563) + 7x bitfield_max_pool (:589), as update_density_grid_mean_and_bitfield (:2854-2858) issues them. */
+/* grid_to_bitfield (:563) + the 7 bitfield_max_pool levels (:589) of update_density_grid_mean_and_bitfield (:2854-2858): one launch per level that has cells of its own
+ * (n_cascades_used), ONE launch for all the levels above (pure pools of the last cascade).  Same bytes as the reference's seven launches. */
 int ngp_hip_grid_to_bitfield_and_pool(void* stream, const float* grid, uint32_t n_cascades_used, const float* mean_density, uint8_t* bitfield);
+/* The tail of update_density_grid_nerf in one call — ema (:2838 -> :532), mean of cascade 0 (:2851-2852), bitfield + pooled levels (:2854-2858): the results of
+ * ngp_hip_ema_grid_samples, ngp_hip_density_grid_mean (to the summation order; here a fixed one) and ngp_hip_grid_to_bitfield_and_pool, in two passes over the grid
+ * instead of a memset and three.  grid_out / grid_in: n_cascades_used x 2^21 cells.  workspace: ngp_hip_density_grid_tail_workspace_bytes() of scratch. */
+uint64_t ngp_hip_density_grid_tail_workspace_bytes(void);
+int ngp_hip_density_grid_ema_mean_bitfield(void* stream, uint32_t n_cascades_used, float decay, float* grid_out, const float* grid_in, float* mean_out, uint8_t* bitfield, void* workspace);
 /* Not in the reference: one bit per 4x4x4 brick of cascade 0 (Morton order: 64 consecutive cells) that is set when any of its cells is
  * occupied — 1024 words.  The training march answers most of its empty-space lookups from this summary; it builds it itself from the
  * bitfield when none is passed, which costs every workgroup a pass over the 256 KB of cascade 0. */

@@ -226,3 +226,13 @@ def error_map_cdf_struct(x_ptr, y_ptr, img_ptr, res):
     c["cdf_x_cond_y"], c["cdf_y"], c["cdf_img"] = x_ptr or 0, y_ptr or 0, img_ptr or 0
     c["res"][0] = res
     return c
+
+
+def morton3d_invert(x):
+    """compact every third bit of a Morton code (common_device.cuh morton3D_invert), vectorised"""
+    x = np.asarray(x, np.uint32) & np.uint32(0x49249249)
+    x = (x | (x >> np.uint32(2))) & np.uint32(0xC30C30C3)
+    x = (x | (x >> np.uint32(4))) & np.uint32(0x0F00F00F)
+    x = (x | (x >> np.uint32(8))) & np.uint32(0xFF0000FF)
+    x = (x | (x >> np.uint32(16))) & np.uint32(0x0000FFFF)
+    return x

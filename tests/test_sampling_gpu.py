@@ -33,7 +33,42 @@ def test_rng_and_morton_device_host_agree(ngp, oracle, cuda):
     np.testing.assert_array_equal(H.to_host(d_pos, np.float32).reshape(n, 3), ref_pos)
 
 
-@pytest.mark.parametrize("n_cascades", [1, 3])
+def _canon(idx, pos):
+    rows = np.concatenate([np.asarray(idx, np.uint32).reshape(-1, 1), np.asarray(pos, np.float32).view(np.uint32).reshape(-1, 3)], axis=1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("n_cascades,n,step,thresh", [(1, G3 // 4, 5, -0.01), (1, G3 // 4, 5, 0.01), (3, 3 * (G3 // 4), 17, 0.01), (3, 3 * (G3 // 4), 0, -0.01), (2, 2 * G3 + 12345, 3, 0.01), (1, 10000, 3, 0.01)])
+def test_grid_samples_in_morton_order_are_the_reference_samples(ngp, oracle, cuda, n_cascades, n, step, thresh):
+    """ngp_hip_generate_grid_samples_morton (round 6): thread c stands on cell c and inverts the first try's index map for the sample number — the SET of (position,
+    index) pairs must be exactly the oracle's forward loop over i = 0 .. n-1 (testbed_nerf.cu:465-494), including sample counts beyond 2^21 (several samples per first
+    cell) and grids with untrained (-1) and empty cells that send samples through their later tries; and the order must be what it is for: spatially local."""
+    grid = H.blob_density_grid(n_cascades)
+    grid[::7] = -1.0                                            # untrained cells: rejected at the uniform threshold too
+    aabb = H.unit_aabb(2 ** (n_cascades - 1))
+    st, inc = H.pcg32_state(4242)
+    ref_pos, ref_idx = np.zeros((n, 3), np.float32), np.zeros(n, np.uint32)
+    oracle.orc_generate_grid_samples_nonuniform(n, st, inc, step, aabb.ctypes.data, grid.ctypes.data, ref_pos.ctypes.data, ref_idx.ctypes.data, n_cascades, H.f32(thresh))
+    d_grid, d_pos, d_idx, d_ctr = H.to_dev(grid, cuda), H.dev_zeros(n * 12, cuda), H.dev_zeros(n * 4, cuda), H.dev_zeros(int(ngp.ngp_hip_generate_grid_samples_morton_workspace_bytes()), cuda)
+    check(ngp.ngp_hip_generate_grid_samples_morton(None, n, st, inc, step, aabb.ctypes.data, d_grid.data_ptr(), d_pos.data_ptr(), d_idx.data_ptr(), n_cascades, H.f32(thresh), d_ctr.data_ptr()))
+    got_idx, got_pos = H.to_host(d_idx, np.uint32), H.to_host(d_pos, np.float32).reshape(n, 3)
+    assert int(H.to_host(d_ctr, np.uint32).sum()) == n          # the per-workgroup counts of the first pass
+    np.testing.assert_array_equal(_canon(got_idx, got_pos), _canon(ref_idx, ref_pos))
+    # locality: the mean distance between the cells of neighbouring output slots, against the forward order's (which is that of random cells)
+    def mean_jump(idx):
+        cell = idx % G3
+        xyz = np.stack([H.morton3d_invert(cell >> k) for k in range(3)], axis=1).astype(np.float64)
+        return np.linalg.norm(np.diff(xyz, axis=0), axis=1).mean()
+    if n >= G3 // 4 and thresh < 0:
+        assert mean_jump(got_idx) < 0.5 * mean_jump(ref_idx)
+    # no atomics: a second run writes the same buffers bit for bit
+    d_pos2, d_idx2 = H.dev_zeros(n * 12, cuda), H.dev_zeros(n * 4, cuda)
+    check(ngp.ngp_hip_generate_grid_samples_morton(None, n, st, inc, step, aabb.ctypes.data, d_grid.data_ptr(), d_pos2.data_ptr(), d_idx2.data_ptr(), n_cascades, H.f32(thresh), d_ctr.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_idx2, np.uint32), got_idx)
+    np.testing.assert_array_equal(H.to_host(d_pos2, np.float32).reshape(n, 3), got_pos)
+
+
+@pytest.mark.parametrize("n_cascades", [1, 2, 3, 5, 8])
 def test_density_grid_pipeline_bit_exact(ngp, oracle, cuda, n_cascades):
     """mark_untrained -> sample -> splat -> ema -> mean -> bitfield + 7 pools (update_density_grid_nerf, testbed_nerf.cu:2761-2859)."""
     imgs, d_imgs, md_host, md_dev, xf = _cameras(cuda, radius=1.3 * n_cascades)
@@ -68,6 +103,7 @@ def test_density_grid_pipeline_bit_exact(ngp, oracle, cuda, n_cascades):
     d_tmp, d_mlp = H.dev_zeros(n_el * 4, cuda), H.to_dev(mlp, cuda)
     check(ngp.ngp_hip_splat_grid_samples_max(None, n_s, d_idx.data_ptr(), d_mlp.data_ptr(), d_tmp.data_ptr(), 1))
     np.testing.assert_array_equal(H.to_host(d_tmp, np.float32), tmp_ref)
+    grid_before_ema = ref.copy()
     oracle.orc_ema_grid_samples(n_el, H.f32(0.95), ref.ctypes.data, tmp_ref.ctypes.data)
     check(ngp.ngp_hip_ema_grid_samples(None, n_el, H.f32(0.95), d_grid.data_ptr(), d_tmp.data_ptr()))
     np.testing.assert_array_equal(H.to_host(d_grid, np.float32), ref)
@@ -84,6 +120,20 @@ def test_density_grid_pipeline_bit_exact(ngp, oracle, cuda, n_cascades):
     check(ngp.ngp_hip_grid_to_bitfield_and_pool(None, d_grid.data_ptr(), n_cascades, d_mean.data_ptr(), d_bf.data_ptr()))
     np.testing.assert_array_equal(H.to_host(d_bf, np.uint8), bf_ref)
     assert 0 < np.unpackbits(bf_ref[: G3 // 8]).mean() < 0.9
+
+    # --- the whole tail in one call (round 6: ema + partial means, bitfield summing them, pooled levels): same grid, same bitfield for the mean it reports, and the
+    # mean reproducible bit for bit (fixed summation order)
+    d_grid2, d_mean2, d_bf2 = H.to_dev(grid_before_ema, cuda), H.dev_zeros(4, cuda), H.to_dev(np.full(G3, 0x55, np.uint8), cuda)
+    d_ws = H.dev_zeros(int(ngp.ngp_hip_density_grid_tail_workspace_bytes()), cuda)
+    check(ngp.ngp_hip_density_grid_ema_mean_bitfield(None, n_cascades, H.f32(0.95), d_grid2.data_ptr(), d_tmp.data_ptr(), d_mean2.data_ptr(), d_bf2.data_ptr(), d_ws.data_ptr()))
+    np.testing.assert_array_equal(H.to_host(d_grid2, np.float32), ref)
+    mean_fused = float(H.to_host(d_mean2, np.float32)[0])
+    assert abs(mean_fused - mean_ref) <= 1e-5 * abs(mean_ref)
+    oracle.orc_update_bitfield(ref.ctypes.data, n_cascades, H.f32(mean_fused), bf_ref.ctypes.data)
+    np.testing.assert_array_equal(H.to_host(d_bf2, np.uint8), bf_ref)
+    d_grid3 = H.to_dev(grid_before_ema, cuda)
+    check(ngp.ngp_hip_density_grid_ema_mean_bitfield(None, n_cascades, H.f32(0.95), d_grid3.data_ptr(), d_tmp.data_ptr(), d_mean2.data_ptr(), d_bf2.data_ptr(), d_ws.data_ptr()))
+    assert float(H.to_host(d_mean2, np.float32)[0]) == mean_fused
 
 
 def test_splat_exponential_activation_tolerance(ngp, oracle, cuda):

@@ -97,7 +97,7 @@ def test_grid_update_samples_generated_ahead_are_the_in_order_ones(cuda):
     again = tb.debug_grid_update_samples(regenerate=True)
     assert again["pending"]
     assert ahead["positions"].size == again["positions"].size > 0
-    np.testing.assert_array_equal(ahead["indices"], again["indices"])
+    np.testing.assert_array_equal(ahead["indices"], again["indices"])                    # (round 6: Morton order of the cells — still a pure function of the generator state)
     np.testing.assert_array_equal(ahead["positions"].view(np.uint32), again["positions"].view(np.uint32))
     tb.frame()                                                                            # step 256 with its update
     assert tb.grid_prefetch_hits == 1 and not tb.debug_grid_update_samples()["pending"]

@@ -8,13 +8,13 @@ import csv,glob,os
 f=glob.glob("/tmp/tlf/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-fw=[i for i,r in enumerate(rows) if "nerf_forward_kernelILi2" in r["Kernel_Name"]]
+fw=[i for i,r in enumerate(rows) if "compute_loss_kernel" in r["Kernel_Name"]]   # a step's anchor: its loss kernel
 import statistics
 per=[(int(rows[fw[k+1]]["Start_Timestamp"])-int(rows[fw[k]]["Start_Timestamp"]))/1000 for k in range(len(fw)-58, len(fw)-1)]
 print("periods of the last %d steps: mean %.1f us, median %.1f; above 700 us: %s" % (len(per), statistics.mean(per), statistics.median(per), [round(x) for x in per if x > 700]))
 ks=list(range(len(fw)-8, len(fw)-5))
 if os.environ.get("TIMELINE_UPDATE"):
-    upd=[k for k in range(len(fw)-40, len(fw)-2) if any("encode_planes" in r["Kernel_Name"] for r in rows[fw[k]:fw[k+1]])]
+    upd=[k for k in range(len(fw)-40, len(fw)-2) if any("splat_max_kernel" in r["Kernel_Name"] for r in rows[fw[k]:fw[k+1]])]
     ks=sorted(set(j for k in upd[-1:] for j in (k-1,k,k+1)))
 for k in ks:
     a,b=fw[k],fw[k+1]
