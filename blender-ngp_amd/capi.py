@@ -157,7 +157,7 @@ assert DOWNSAMPLE_INFO.itemsize == 32 and RENDER_CAMERA.itemsize == 176
 NET_VARIANT = np.dtype([("n_extra_dims", "<u4"), ("n_rgb_hidden_layers", "<u4"), ("extra_dims", "<u8"), ("sample_slot", "<u8"), ("dL_dextra", "<u8"), ("flags", "<u4")], align=True)   # NgpNetVariant
 NETX_SCALAR = 1   # NgpNetVariant.flags: the scalar checker kernels instead of the MFMA kernels
 LOSS_EXTRAS = np.dtype([("envmap_data", "<u8"), ("envmap_gradient", "<u8"), ("envmap_res", "<i4", 2), ("envmap_loss_type", "<i4"),
-                        ("sharpness_data", "<u8"), ("sharpness_res", "<i4", 2), ("sharpness_grid", "<u8")], align=True)   # NgpLossExtras
+                        ("sharpness_data", "<u8"), ("sharpness_res", "<i4", 2), ("sharpness_grid", "<u8"), ("x_row_index_out", "<u8")], align=True)   # NgpLossExtras
 RENDER_EXTRAS = np.dtype([("render_masks", "<u8"), ("n_render_masks", "<u4"), ("glow_mode", "<i4"), ("glow_y_cutoff", "<f4"), ("envmap", "<u8"), ("envmap_res", "<i4", 2),
                           ("distortion", "<u8"), ("distortion_res", "<i4", 2), ("quilting_dims", "<i4", 2), ("render_mode", "<i4"), ("frame_buffer", "<u8"),
                           ("row_begin", "<i4"), ("row_end", "<i4"), ("tile_order", "<i4")], align=True)   # NgpRenderExtras

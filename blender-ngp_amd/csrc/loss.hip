@@ -52,6 +52,7 @@ struct LossArgs {
 	float* exposure_gradient;                             // [n_images][3] or NULL (optimize_exposure off)
 	const float* envmap_data; float* envmap_gradient; int32_t envmap_res[2]; int envmap_loss_type;   // 1289-1292: fp32 [h][w][4] (TrainableBuffer<4,2,float>) or NULL
 	const float* sharpness_data; int32_t sharpness_res[2]; float* sharpness_grid;                    // 1321-1323 (include_sharpness_in_error) or NULL
+	uint32_t* x_row_out;   // optional: slot k of the compacted batch <- the uncompacted sample it came from (instead of carrying 64-byte encoding rows: NgpLossExtras::x_row_index_out)
 };
 
 typedef uint16_t us4 __attribute__((ext_vector_type(4)));
@@ -349,6 +350,7 @@ __global__ void __launch_bounds__(LOSS_RAYS_PER_BLOCK * 64) compute_loss_kernel(
 				uint4* dst = (uint4*)(a.encoded_out + (size_t)(compacted_base + j) * 32);
 				dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
 			}
+			if (a.x_row_out) a.x_row_out[compacted_base + j] = base + j;
 			if (a.max_level_rand_training) a.max_level_compacted[compacted_base + j] = max_level;
 			const v3 pos = unwarp_position(mk(cin.pos[0], cin.pos[1], cin.pos[2]), a.aabb);
 			depth = norm(pos - ray_o);
@@ -823,6 +825,7 @@ int ngp_hip_compute_loss(
 		a.envmap_data = extras_host->envmap_data; a.envmap_gradient = extras_host->envmap_gradient;
 		a.envmap_res[0] = extras_host->envmap_res[0]; a.envmap_res[1] = extras_host->envmap_res[1]; a.envmap_loss_type = extras_host->envmap_loss_type;
 	}
+	a.x_row_out = extras_host ? extras_host->x_row_index_out : nullptr;
 	a.sharpness_data = nullptr; a.sharpness_grid = nullptr; a.sharpness_res[0] = a.sharpness_res[1] = 0;
 	if (extras_host && extras_host->sharpness_data && extras_host->sharpness_grid && extras_host->sharpness_res[0] > 0 && extras_host->sharpness_res[1] > 0) {
 		a.sharpness_data = extras_host->sharpness_data; a.sharpness_grid = extras_host->sharpness_grid;

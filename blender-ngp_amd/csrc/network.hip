@@ -1550,7 +1550,8 @@ __device__ __forceinline__ v3 sh4_grad_half(int g, float dx_, float dy_, float d
 }
 
 // a batch whose first *n_live slots carry the samples with a non-zero loss gradient (ngp_hip_compact_live_samples); zero_next: a word the kernel clears (the counter of the next step)
-struct LiveSamples { const uint32_t* n_live; uint32_t* zero_next; const uint32_t* src_index /* slot -> row of x_saved / dL_dout / coords (NULL: the slot itself) */; };
+struct LiveSamples { const uint32_t* n_live; uint32_t* zero_next; const uint32_t* src_index /* slot -> row of x_saved / dL_dout / coords (NULL: the slot itself) */;
+                     const uint32_t* x_row /* row of coords / dL_dout -> row of x_saved (NULL: the same row): the loss kernel's x_row_index_out */; };
 
 // DIR_GRAD: additionally dL/d(direction) of every sample into dL_dinput[s][3..5] (fp32) — the input gradient a training step asks for when
 // camera parameters train (NerfNetwork::backward_impl with dL_dinput, nerf_network.h:187-266; testbed_nerf.cu:3324-3346)
@@ -1584,7 +1585,8 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 		const bool on = s < n_eff;               // (the last quad of a live batch: slots behind the live samples hold nothing — zero encoding, zero gradient)
 		const uint32_t sl = on ? (live.src_index ? live.src_index[s] : s) : 0u;
 		const float* c = coords + (size_t)sl * coord_stride;
-		const h8* xs = (const h8*)(x_saved + (size_t)sl * 32 + 16 * g);
+		const uint32_t xrow = live.x_row ? live.x_row[sl] : sl;   // (the compaction left an index instead of a copy of the row)
+		const h8* xs = (const h8*)(x_saved + (size_t)xrow * 32 + 16 * g);
 		h8 x0 = xs[0], x1 = xs[1];
 		if (!on) { x0 = h8{}; x1 = h8{}; }
 		const h8 sh = sh4_half(g, c[4], c[5], c[6]);
@@ -1673,7 +1675,7 @@ __global__ void __launch_bounds__(256, 2) nerf_backward_fused_kernel(const NgpNe
 #pragma unroll
 		for (int kb = 0; kb < 4; ++kb) fb_put(stage, 0, MAP_HID, kb, g, col, dh[kb]);
 		{   // the encoding again (64 B per sample, an L2 hit): keeping x0 / x1 live through the chain costs 8 registers of a kernel that is at its limit
-			const h8* xr = (const h8*)(x_saved + (size_t)sl * 32 + 16 * g);
+			const h8* xr = (const h8*)(x_saved + (size_t)xrow * 32 + 16 * g);
 			uint32_t zero_off = 0;
 			asm volatile("" : "+v"(zero_off));
 			xr = (const h8*)((const char*)xr + zero_off);
@@ -2628,15 +2630,17 @@ static int verify_desc_pair(hipStream_t st, const NgpNetDesc* desc_dev, const Ng
 
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant) {
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant,
+                          const uint32_t* x_row_index) {
 	if (variant_check(variant, "ngp_hip_nerf_backward: at most 16 extra dims and 3 hidden colour layers")) return -1;
 	if (desc_host && verify_desc_pair((hipStream_t)stream, desc_dev, desc_host)) return -1;
 	if (variant_is_generic(variant)) {
+		if (x_row_index) { set_last_error("ngp_hip_nerf_backward: x_row_index (encoding rows left in the uncompacted batch) is built for the base network family only", hipErrorNotSupported); return -1; }
 		if (!variant_scalar(variant)) return nx_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput);
 		if (dL_dinput) { set_last_error("ngp_hip_nerf_backward: dL_dinput (camera-side trainables) is not built into the scalar checker kernels (NGP_NETX_SCALAR)", hipErrorNotSupported); return -1; }
 		return gen_backward(stream, variant, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, grid_gradients_event);
 	}
-	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput, LiveSamples{nullptr, nullptr, nullptr});
+	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, dL_dinput, LiveSamples{nullptr, nullptr, nullptr, x_row_index});
 }
 
 // The backward pass over the LIVE samples of a batch (ngp_hip_compact_live_samples): slot k < *n_live_dev stands for row live_index[k] of coords / x_saved / dL_dout; the
@@ -2644,11 +2648,11 @@ int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNet
 int ngp_hip_nerf_backward_live(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event,
-                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev) {
+                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev, const uint32_t* x_row_index) {
 	if (!n_live_dev || !live_index || !coords_live) { set_last_error("ngp_hip_nerf_backward_live: live_index / coords_live / n_live_dev is NULL (ngp_hip_nerf_backward is the entry without a live list)", hipErrorInvalidValue); return -1; }
 	if (desc_host && verify_desc_pair((hipStream_t)stream, desc_dev, desc_host)) return -1;
 	return nerf_backward_impl(stream, desc_dev, desc_host, params, coords, coord_stride_floats, n, x_saved, dL_dout, dl_stride, grads, scratch, scratch_bytes, mlp_done_event, grid_gradients_event, nullptr,
-	                          LiveSamples{n_live_dev, zero_word_dev, live_index}, coords_live);
+	                          LiveSamples{n_live_dev, zero_word_dev, live_index, x_row_index}, coords_live);
 }
 
 // Samples of a training batch whose loss gradient is zero in all four channels — in fp16, after the roll-over: the tails of the rays, 30-45 % of a batch — contribute exact
@@ -2799,7 +2803,7 @@ int ngp_hip_nerf_input_gradient(void* stream, const NgpNetDesc* desc_dev, const 
 		return 0;
 	}
 	hipLaunchKernelGGL(nerf_backward_fused_kernel<true>, dim3(grid), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const half_t*)x_saved, (const half_t*)dl, 4u,
-	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din, LiveSamples{nullptr, nullptr, nullptr});
+	                   dx_planes, partials, (uint32_t*)((char*)scratch + scratch_off_fx(n)), (uint32_t)(sizeof(GbFxCounters) / 4), din, LiveSamples{nullptr, nullptr, nullptr, nullptr});
 	NGP_LAUNCH_CHECK("nerf_backward_fused_kernel (input gradient)");
 	hipLaunchKernelGGL(nerf_input_pos_gradient_kernel, dim3(div_up(n, 256)), dim3(256), 0, st, desc_dev, (const half_t*)params, (const float*)coords_inout, coord_stride_floats, n, (const h2*)dx_planes, din, (uint32_t)GRID_OFF);
 	NGP_LAUNCH_CHECK("nerf_input_pos_gradient_kernel");

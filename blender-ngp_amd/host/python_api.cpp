@@ -565,6 +565,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def_property("autofocus_target", [](Testbed& t) { py::array_t<float> a(3); for (int i = 0; i < 3; ++i) a.mutable_data()[i] = t.m_autofocus_target[i]; return a; },
 			[](Testbed& t, const std::vector<float>& v) { if (v.size() != 3) throw std::runtime_error{"autofocus_target takes 3 floats"}; for (int i = 0; i < 3; ++i) t.m_autofocus_target[i] = v[i]; })
 		.def_readwrite("prefetch_samples", &Testbed::m_enable_prefetch)
+		.def_readwrite("x_row_index_mode", &Testbed::m_x_row_index_mode, "training step (base network family): True (default) = the loss kernel's compaction leaves, per kept sample, the index of its row in the uncompacted batch's encodings and the backward pass reads through it; False = it copies the 64-byte rows next to the compacted coordinates (rounds 1-5).  The same bits reach the backward pass")
 		.def_readwrite("morton_grid_samples", &Testbed::m_morton_grid_samples, "occupancy-grid update: True (default) = the update's samples are written in Morton order of the cell each one's first try lands in (thread per cell, the index map inverted: csrc/density_grid.hip), so that the density pass and the splat touch shared lines from neighbouring lanes; False = the reference's order (sample i in slot i).  The same (position, index) pairs either way, hence the same grid bit for bit")
 		.def_readwrite("separate_forward_pass", &Testbed::m_separate_forward)   // dev / test: also run the reference's second network pass (testbed_nerf.cu:3330)
 		.def_readonly("prefetch_hits", &Testbed::m_prefetch_hits)
@@ -629,7 +630,12 @@ PYBIND11_MODULE(pyngp, m) {
 				d["mlp_out"] = u16(t.debug_buffer("mlp_out"), (size_t)c.max_inference * 4);
 				d["coords_compacted_rolled"] = f32(t.debug_buffer("coords_compacted"), (size_t)c.target_batch_size * 7);
 				d["dloss_rolled"] = u16(t.debug_buffer("dloss"), (size_t)c.target_batch_size * 4);
-				d["x_saved"] = u16(t.debug_buffer("x_saved"), (size_t)c.target_batch_size * 32);
+				{   // the compacted batch's encoding rows (gathered through the row index when the step kept the rows in the uncompacted batch)
+					const std::vector<uint16_t> rows = t.debug_x_saved((size_t)c.target_batch_size);
+					py::array_t<uint16_t> xa((py::ssize_t)rows.size());
+					if (!rows.empty()) memcpy(xa.mutable_data(), rows.data(), rows.size() * 2);
+					d["x_saved"] = xa;
+				}
 				d["grads"] = u16(t.debug_buffer("grads"), t.m_n_params);
 				if (t.m_nerf.training.optimize_extrinsics) d["coords_gradient"] = f32(t.debug_buffer("coords_gradient"), (size_t)c.target_batch_size * 6);   // dL/d(pos, dir) of the rolled-over batch
 				d["loss"] = f32(t.m_nerf.training.counters_rgb.loss, c.n_rays_global);

@@ -1294,7 +1294,11 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	m_mlp_out.enlarge((size_t)std::max(target_batch_size, max_samples) * OUT_STRIDE * 2);
 	m_dloss.enlarge((size_t)target_batch_size * OUT_STRIDE * 2);
 	m_coords_compacted.enlarge((size_t)target_batch_size * sizeof(NgpCoord));
-	m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
+	// (round 6) the compaction leaves an INDEX into the uncompacted batch's encoding rows instead of copying each kept sample's 64-byte row (128 B of traffic per sample in
+	// the loss kernel, and the row roll-over); the backward pass reads row x_index[k] of m_x_all.  Base network family, rows from the network pass (no second forward).
+	const bool use_x_index = m_x_row_index_mode && net_is_base_family() && !m_separate_forward;
+	if (use_x_index) m_x_index.enlarge((size_t)target_batch_size * 4); else m_x_saved.enlarge((size_t)target_batch_size * 32 * 2);
+	m_last_step_used_x_index = use_x_index;
 	m_bwd_scratch.enlarge(ngp_hip_nerf_backward_scratch_bytes_for(&m_desc, target_batch_size));   // sized for this level table (778 -> 405 MB at 2^18 with base.json)
 	m_enc_ws.enlarge(ngp_hip_nerf_encode_workspace_bytes(std::max(target_batch_size, next_max_inference(target_batch_size))));
 
@@ -1425,6 +1429,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		loss_extras.envmap_data = m_envmap.params.as<float>(); loss_extras.envmap_gradient = train_envmap ? m_envmap.gradients.as<float>() : nullptr;
 		loss_extras.envmap_res[0] = m_envmap.resolution[0]; loss_extras.envmap_res[1] = m_envmap.resolution[1]; loss_extras.envmap_loss_type = (int)m_envmap.loss_type;
 	}
+	loss_extras.x_row_index_out = use_x_index ? m_x_index.as<uint32_t>() : nullptr;
 	profile_begin(PK_LOSS);
 	NgpErrorMapCdf cdf_storage;
 	check(ngp_hip_compute_loss(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, target_batch_size, gen_counters + 0, LOSS_SCALE, OUT_STRIDE, m_background_color,
@@ -1433,7 +1438,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 	                           m_coords.as<NgpCoord>(), m_coords_compacted.as<NgpCoord>(), m_dloss.as<uint16_t>(), OUT_STRIDE, (int)tr.loss_type, c.loss.as<float>(),
 	                           m_max_level_rand_training, nullptr, (int)m_nerf.rgb_activation, (int)m_nerf.density_activation, tr.snap_to_pixel_centers,
 	                           tr.error_map_data.as<float>(), tr.error_map_res, m_nerf.density_grid_mean.as<float>(), tr.cam_exposure_gpu.as<float>(), tr.near_distance,
-	                           tr.error_map_cdf(cdf_storage), m_x_all.as<uint16_t>(), m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type,
+	                           tr.error_map_cdf(cdf_storage), use_x_index ? nullptr : m_x_all.as<uint16_t>(), use_x_index ? nullptr : m_x_saved.as<uint16_t>(), tr.depth_supervision_lambda, (int)tr.depth_loss_type,
 	                           tr.optimize_exposure ? tr.cam_exposure_gradient_gpu.as<float>() : nullptr, &loss_extras), "compute_loss");
 	profile_end(PK_LOSS, R);
 	if (capturing) {   // the loss kernel's products before the roll-over pads and rescales them
@@ -1484,12 +1489,12 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		check(ngp_hip_post_words(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4, (double*)m_dp_counters_dev), "post_words");
 		HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_counters_event, (hipStream_t)m_stream));
 		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
-		                                     m_x_saved.as<float>(), 16), "fill_rollover");
+		                                     use_x_index ? m_x_index.as<float>() : m_x_saved.as<float>(), use_x_index ? 1u : 16u), "fill_rollover");
 	} else if (compact_now) {
 		// the backward pass over the live samples: roll-overs, then the list of the samples with a non-zero loss gradient, THEN the post — the host launches the next step's march
 		// when it sees it, and the backward pass's MFMA kernel (80 KiB of LDS per workgroup) must already be resident when that march arrives, or it runs at half its occupancy
 		// beside it (measured: 47 -> 87 us with the post 20 us ahead of the kernel)
-		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7, m_x_saved.as<float>(), 16), "fill_rollover");
+		check(ngp_hip_fill_rollover_training(m_stream, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7, use_x_index ? m_x_index.as<float>() : m_x_saved.as<float>(), use_x_index ? 1u : 16u), "fill_rollover");
 		m_coords_live.enlarge((size_t)target_batch_size * sizeof(NgpCoord)); m_live_index.enlarge((size_t)target_batch_size * 4);
 		if (m_live_count.bytes() == 0) { m_live_count.resize(8); m_live_count.memset(0, m_stream); m_live_parity = 0; }
 		check(ngp_hip_compact_live_samples(m_stream, target_batch_size, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7, m_live_index.as<uint32_t>(), m_coords_live.as<float>(),
@@ -1499,7 +1504,7 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		// the polling host needs no event (a record costs a few microseconds of dispatch gap): post and roll-overs in one launch, the post first
 		check(ngp_hip_post_words_and_fill_rollover_training(m_stream, gen_counters + 1, compacted_counter, (const uint32_t*)loss_sum_dev, m_post_tag, (uint32_t*)m_host_words, next_slot, 4,
 		                                                    (double*)m_dp_counters_dev, target_batch_size, compacted_counter, m_dloss.as<uint16_t>(), OUT_STRIDE, m_coords_compacted.as<float>(), 7,
-		                                                    m_x_saved.as<float>(), 16), "post_words + fill_rollover");
+		                                                    use_x_index ? m_x_index.as<float>() : m_x_saved.as<float>(), use_x_index ? 1u : 16u), "post_words + fill_rollover");
 	}
 	m_counters_event_recorded = m_want_counters_event;
 
@@ -1522,8 +1527,8 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		const bool train_extra_dims_c = tr.dataset.n_extra_learnable_dims > 0 && tr.optimize_extra_dims;
 		if (train_extra_dims_c) m_dl_dextra.enlarge((size_t)target_batch_size * m_n_extra_dims * 4);
 		const NgpNetVariant* variant_c = net_variant(nvc, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims_c ? m_dl_dextra.as<float>() : nullptr);
-		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
-		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), variant_c), "nerf_backward (with input gradient)");
+		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, use_x_index ? m_x_all.as<uint16_t>() : m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, nullptr, m_coords_gradient.as<float>(), variant_c, use_x_index ? m_x_index.as<uint32_t>() : nullptr), "nerf_backward (with input gradient)");
 		if (m_want_grid_grad_event) HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream));
 		profile_end(PK_BACKWARD, target_batch_size);
 		check(ngp_hip_compute_cam_gradient(m_stream, n_rays_global, &m_aabb, m_rng.state, m_rng.inc, gen_counters + 0, tr.snap_to_pixel_centers,
@@ -1547,15 +1552,15 @@ void Testbed::train_nerf_dp_begin(uint32_t target_batch_size, uint32_t counters_
 		const NgpNetVariant* variant = net_variant(nv, tr.extra_dims_gpu.as<float>(), m_n_extra_dims ? m_sample_slot.as<uint32_t>() : nullptr, train_extra_dims ? m_dl_dextra.as<float>() : nullptr);
 		if (compact_now) {
 			uint32_t* n_live = m_live_count.as<uint32_t>() + m_live_parity;
-			check(ngp_hip_nerf_backward_live(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+			check(ngp_hip_nerf_backward_live(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, use_x_index ? m_x_all.as<uint16_t>() : m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 			                                 OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr, m_want_grid_grad_event ? m_grid_grad_event : nullptr,
-			                                 m_live_index.as<uint32_t>(), m_coords_live.as<float>(), n_live, m_live_count.as<uint32_t>() + (m_live_parity ^ 1u)), "nerf_backward (live samples)");
+			                                 m_live_index.as<uint32_t>(), m_coords_live.as<float>(), n_live, m_live_count.as<uint32_t>() + (m_live_parity ^ 1u), use_x_index ? m_x_index.as<uint32_t>() : nullptr), "nerf_backward (live samples)");
 			m_live_last_batch = target_batch_size; m_live_last_parity = m_live_parity;
 			m_live_parity ^= 1u;
 		} else
-		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
+		check(ngp_hip_nerf_backward(m_stream, desc, &m_desc, m_params.as<uint16_t>(), m_coords_compacted.as<float>(), 7, target_batch_size, use_x_index ? m_x_all.as<uint16_t>() : m_x_saved.as<uint16_t>(), m_dloss.as<uint16_t>(),
 		                            OUT_STRIDE, m_grads.as<uint16_t>(), m_bwd_scratch.data(), m_bwd_scratch.bytes(), nullptr,
-		                            m_want_grid_grad_event ? m_grid_grad_event : nullptr, nullptr, variant), "nerf_backward");
+		                            m_want_grid_grad_event ? m_grid_grad_event : nullptr, nullptr, variant, use_x_index ? m_x_index.as<uint32_t>() : nullptr), "nerf_backward");
 		profile_end(PK_BACKWARD, target_batch_size);
 		if (train_extra_dims) {   // compute_extra_dims_gradient_train_nerf (2925-2931, 3333-3346): per image, the sum over its rays' compacted samples
 			const size_t n = (size_t)m_n_extra_dims * (size_t)tr.n_images_for_training;
@@ -1598,6 +1603,22 @@ void Testbed::stream_wait_grid_gradients(void* other_stream) {
 	m_want_grid_grad_event = true;
 	if (!m_grid_grad_event_recorded) { HIP_CHECK_THROW(hipEventRecord((hipEvent_t)m_grid_grad_event, (hipStream_t)m_stream)); m_grid_grad_event_recorded = true; }
 	HIP_CHECK_THROW(hipStreamWaitEvent((hipStream_t)other_stream, (hipEvent_t)m_grid_grad_event, 0));
+}
+
+// the encoding rows of the last step's (rolled-over) compacted batch, [batch][32] fp16 — gathered through the row index when the step left one instead of copies
+std::vector<uint16_t> Testbed::debug_x_saved(size_t batch) {
+	sync();
+	std::vector<uint16_t> rows(batch * 32);
+	if (!m_last_step_used_x_index) { if (batch) m_x_saved.copy_to_host(rows.data(), batch * 64); return rows; }
+	std::vector<uint32_t> index(batch);
+	std::vector<uint16_t> all(m_x_all.bytes() / 2);
+	if (batch) m_x_index.copy_to_host(index.data(), batch * 4);
+	if (!all.empty()) m_x_all.copy_to_host(all.data(), all.size() * 2);
+	for (size_t k = 0; k < batch; ++k) {
+		if ((size_t)index[k] * 32 + 32 > all.size()) throw std::runtime_error{"debug_x_saved: row index outside the uncompacted batch"};
+		memcpy(&rows[k * 32], &all[(size_t)index[k] * 32], 64);
+	}
+	return rows;
 }
 
 const DeviceBuffer& Testbed::debug_buffer(const std::string& name) const {

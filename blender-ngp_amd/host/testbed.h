@@ -426,6 +426,8 @@ public:
 	bool m_trace_sync = false;                         // debugging aid: drain both streams behind every launch group and name it on stderr (finds a kernel that never returns)
 	bool m_render_trace = false;                       // debugging aid: the tracers' pass structure (alive rays, steps per pass) on stderr
 	bool m_morton_grid_samples = true;                 // occupancy-grid update: generate the samples in Morton order of their cells (coherent gathers in the density pass and the splat; the same samples, the same grid)
+	bool m_x_row_index_mode = true;                    // training step, base network family: the compaction leaves an index into the uncompacted batch's encoding rows instead of copying the rows (the same bits reach the backward pass)
+	std::vector<uint16_t> debug_x_saved(size_t batch);
 	bool m_enable_prefetch = true;                     // march step n+1 on a second stream while step n back-propagates
 	bool m_separate_forward = false;                   // dev / test: run the reference's second network pass over the compacted batch as well
 	uint64_t m_prefetch_hits = 0;
@@ -638,6 +640,8 @@ private:
 	// step scratch (replaces the GPUMemoryArena carve-out of train_nerf_step 3144-3170 and update_density_grid_nerf 2770-2776)
 	DeviceBuffer m_ray_indices, m_rays, m_numsteps, m_coords, m_mlp_out, m_dloss, m_coords_compacted, m_x_saved, m_bwd_scratch, m_ray_counter;
 	DeviceBuffer m_cam_rays, m_cam_ray_indices, m_coords_gradient;   // optimize_extrinsics: the step's rays kept past the next march, and the network's input gradient [sample][6]
+	DeviceBuffer m_x_index;                            // slot of the compacted batch -> row of m_x_all (x_row_index_mode)
+	bool m_last_step_used_x_index = false;
 	DeviceBuffer m_x_all;                              // encodings of the uncompacted samples (carried through the compaction by the loss kernel)
 	DeviceBuffer m_enc_ws;                             // level planes of the XCD-affine encode (ngp_hip_nerf_*_ws)
 	DeviceBuffer m_grid_positions, m_grid_indices, m_grid_tmp, m_grid_mlp_out;

@@ -169,7 +169,9 @@ uint64_t ngp_hip_nerf_backward_scratch_bytes_for(const NgpNetDesc* desc_host, ui
  * desc_host that is a different table; NULL = every level priced as the worst case, whole owner grid launched. */
 int ngp_hip_nerf_backward(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                           uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
-                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant);
+                          uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event, float* dL_dinput, const NgpNetVariant* variant,
+                          const uint32_t* x_row_index /* NULL: row k of x_saved belongs to sample k.  Else (base network family): sample k's encoding is row x_row_index[k] of
+                          x_saved — the UNCOMPACTED batch's rows, with the index list ngp_hip_compute_loss left (NgpLossExtras::x_row_index_out) instead of copies of the rows */);
 /* The backward pass over the LIVE samples of a batch.  A sample whose loss gradient is zero in all four channels — after the loss kernel and fill_rollover_and_rescale
  * (src/testbed_nerf.cu:1280-1597, 3314-3322), in fp16: the tails of the rays, where the transmittance has not yet reached the 1e-4 cut but weight x loss_scale has left the
  * fp16 range; 30-45 % of a training batch — adds exact zeros to every sum NerfNetwork::backward_impl forms.
@@ -186,7 +188,8 @@ int ngp_hip_compact_live_samples(void* stream, uint32_t n, const uint16_t* dL_do
 int ngp_hip_nerf_backward_live(void* stream, const NgpNetDesc* desc_dev, const NgpNetDesc* desc_host, const uint16_t* params, const float* coords,
                                uint32_t coord_stride_floats, uint32_t n, const uint16_t* x_saved, const uint16_t* dL_dout, uint32_t dl_stride,
                                uint16_t* grads, void* scratch, uint64_t scratch_bytes, void* mlp_done_event, void* grid_gradients_event,
-                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev);
+                               const uint32_t* live_index, const float* coords_live, const uint32_t* n_live_dev, uint32_t* zero_word_dev,
+                               const uint32_t* x_row_index /* as in ngp_hip_nerf_backward: applied to the row live_index[k] names */);
 /* Per-image extra dims of a training step.  ray_image[i] = the image of kept ray i (what image_idx gives the ray generator, src/testbed_nerf.cu:1131-1136);
  * numsteps = (count, base) pairs of the kept rays (the ray generator's before compaction, the loss kernel's after).
  *   ngp_hip_ray_images            ray_image[i] = image_idx(ray_indices[i], ...) for the kept rays (:1062-1083);
@@ -295,6 +298,10 @@ typedef struct {
 	 * 128^3 grid of the sharpest tile that has seen each cell (decayed by ngp_hip_decay_grid every training_prep, :2901-2912); the error a ray deposits into the error
 	 * map is scaled by max(sharp / grid_sharp, 0.01).  NULL: off */
 	const float* sharpness_data; int32_t sharpness_res[2]; float* sharpness_grid;
+	/* Instead of carrying encoding rows through the compaction (encoded_in / encoded_out of ngp_hip_compute_loss, 128 bytes of traffic per kept sample): slot k of the
+	 * compacted batch gets the index of the uncompacted sample it came from ([max_samples_compacted] words; roll it over like the coordinates, stride 1), and
+	 * ngp_hip_nerf_backward reads row x_row_index[k] of the UNCOMPACTED x_saved.  NULL: off */
+	uint32_t* x_row_index_out;
 } NgpLossExtras;
 /* ============================ loss + compaction (src/testbed_nerf.cu:1280-1597, 3314-3322) ============================
  * Forward pass.  The reference runs inference on all samples (:3256), compacts, then runs m_network->forward on the compacted batch

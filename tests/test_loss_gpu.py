@@ -78,8 +78,11 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
         d_cx, d_cy, d_ci = H.to_dev(C["x"], cuda), H.to_dev(C["y"], cuda), H.to_dev(C["img"], cuda)
         c_dev = H.error_map_cdf_struct(d_cx.data_ptr() if m & 1 else 0, d_cy.data_ptr() if m & 1 else 0, d_ci.data_ptr() if m & 2 else 0, C["res"])
     d_loss_fn, d_tail = ngp.ngp_hip_compute_loss, ()
-    if env is not None or sharp is not None:
+    if env is not None or sharp is not None or I.get("x_index"):
         ex_d = np.zeros(1, capi.LOSS_EXTRAS)
+        if I.get("x_index"):    # round 6: the compaction leaves, per kept sample, the index of the uncompacted sample it came from (device only: the oracle copies rows)
+            d["xidx"] = H.to_dev(np.full(B, 0xFFFFFFFF, np.uint32), cuda)
+            ex_d["x_row_index_out"] = d["xidx"].data_ptr()
         if env is not None:
             d_env, d["envg"] = H.to_dev(env["data"], cuda), H.dev_zeros(env["data"].nbytes, cuda)
             ex_d["envmap_data"], ex_d["envmap_gradient"], ex_d["envmap_res"][0], ex_d["envmap_loss_type"] = d_env.data_ptr(), d["envg"].data_ptr() if env["train"] else 0, env["res"], env["loss_type"]
@@ -98,6 +101,8 @@ def _run(ngp, oracle, cuda, I, loss_type, B, random_bg=1, color_space=0, linear=
         g["envg"] = H.to_host(d["envg"], np.float32).reshape(env["data"].shape)
     if sharp is not None:
         g["sgrid"] = H.to_host(d["sgrid"], np.float32)
+    if I.get("x_index"):
+        g["xidx"] = H.to_host(d["xidx"], np.uint32)
     return o, g
 
 
@@ -151,6 +156,33 @@ def test_loss_and_compaction_match_oracle(ngp, oracle, cuda, loss_type):
     np.testing.assert_allclose(g["loss"][keep], o["loss"][keep], rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(g["em"], o["em"], rtol=2e-3, atol=1e-6 * max(1.0, float(o["em"].max())))
     assert np.abs(o["dl"].astype(np.float32)).max() > 1e-4
+
+
+def test_compaction_leaves_the_index_of_every_kept_sample(ngp, oracle, cuda):
+    """NgpLossExtras.x_row_index_out (round 6): slot k of the compacted batch <- the uncompacted sample it came from, so that the backward pass can read the encoding
+    row where the network pass wrote it instead of a copy.  Every compacted coordinate row must be the row of the sample its index names, the indices of a ray run up
+    by one from the ray's first sample, slots behind the compacted samples stay untouched, and everything else the kernel produces is what it produces without the index."""
+    I = _inputs(oracle, cuda)
+    B = I["n_samples"] + 128
+    o0, g0 = _run(ngp, oracle, cuda, I, 4, B)
+    I["x_index"] = True
+    o, g = _run(ngp, oracle, cuda, I, 4, B)
+    n_c = int(g["cnt"][0])
+    assert 0 < n_c < I["n_samples"] and n_c == int(g0["cnt"][0])
+    idx = g["xidx"]
+    assert (idx[n_c:] == 0xFFFFFFFF).all() and (idx[:n_c] < I["n_samples"]).all()
+    assert g["co"][:n_c].tobytes() == I["r"]["co"][idx[:n_c]].tobytes()
+    for i in range(I["n_alive"]):
+        n, b_out, b_in = int(g["ns"][2 * i]), int(g["ns"][2 * i + 1]), int(I["r"]["ns"][2 * i + 1])
+        if n:
+            np.testing.assert_array_equal(idx[b_out:b_out + n], np.arange(b_in, b_in + n, dtype=np.uint32))
+    # slot order is decided by an atomic: compare the two runs ray by ray
+    for i in range(I["n_alive"]):
+        n = int(g["ns"][2 * i])
+        assert n == int(g0["ns"][2 * i])
+        a, b = int(g["ns"][2 * i + 1]), int(g0["ns"][2 * i + 1])
+        assert g["dl"][a:a + n].tobytes() == g0["dl"][b:b + n].tobytes()
+    np.testing.assert_array_equal(g["loss"], g0["loss"])
 
 
 def test_compaction_carries_the_saved_encoding(ngp, oracle, cuda):

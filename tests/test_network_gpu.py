@@ -291,6 +291,35 @@ def test_backward_matches_oracle(ngp, oracle, cuda):
     np.testing.assert_allclose(gg, rg, rtol=5e-2, atol=5e-3 * np.abs(rg).max())
 
 
+def test_backward_through_a_row_index_is_the_backward_over_the_rows(ngp, cuda):
+    """round 6: ngp_hip_nerf_backward(..., x_row_index): sample k's encoding is row x_row_index[k] of a LARGER x_saved (the uncompacted batch's rows, which the loss
+    kernel's compaction no longer copies).  Same kernels, same sums: the gradients of the indexed call are bit for bit those of the call over the gathered rows."""
+    n = 4096
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=14, n=n, grid_amp=0.5)
+    rs = np.random.RandomState(21)
+    dl = (rs.randn(n, 4) * 0.05).astype(np.float16)
+    d_dl = H.to_dev(dl, cuda)
+    out, xs = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 64, cuda)
+    check(ngp.ngp_hip_nerf_forward(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, out.data_ptr(), 4, xs.data_ptr()))
+    rows = H.to_host(xs, np.uint16).reshape(n, 32)
+    n_all = 3 * n
+    where = rs.permutation(n_all)[:n].astype(np.uint32)              # row k lives at where[k] of the big buffer; the rest is poison
+    big = np.full((n_all, 32), 0x7E00, np.uint16)                     # fp16 NaN
+    big[where] = rows
+    d_big, d_where = H.to_dev(big, cuda), H.to_dev(where, cuda)
+    np_ = H.n_params(desc)
+    sb = ngp.ngp_hip_nerf_backward_scratch_bytes(n)
+    scratch = H.dev_zeros(sb, cuda)
+    g_rows, g_index = H.dev_zeros(np_ * 2, cuda), H.dev_zeros(np_ * 2, cuda)
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, xs.data_ptr(), d_dl.data_ptr(), 4,
+                                    g_rows.data_ptr(), scratch.data_ptr(), sb))
+    check(ngp.ngp_hip_nerf_backward(None, d_desc.data_ptr(), desc.ctypes.data, d_P.data_ptr(), d_c.data_ptr(), 7, n, d_big.data_ptr(), d_dl.data_ptr(), 4,
+                                    g_index.data_ptr(), scratch.data_ptr(), sb, None, None, None, None, d_where.data_ptr()))
+    a, b = H.to_host(g_rows, np.uint16), H.to_host(g_index, np.uint16)
+    assert np.isfinite(a.view(np.float16).astype(np.float32)).all() and (a != 0).any()
+    np.testing.assert_array_equal(a, b)
+
+
 def test_backward_input_gradient_matches_oracle(ngp, oracle, cuda):
     """ngp_hip_nerf_backward with dL_dinput: the same parameter gradients as ngp_hip_nerf_backward plus dL/d(pos, dir) per sample (what tcnn's backward writes when the
     caller passes dL_dinput, testbed_nerf.cu:3329-3330).  The position gradient runs through 16 levels of fp16 feature gradients, the direction gradient
