@@ -32,7 +32,7 @@ OPT_BYTES_PER_PARAM = 36       # grads 2 + master 4+4 + m 4+4 + v 4+4 + fp16 2 +
 BYTES_PER_UNIT = {"nerf_inference": FWD_BYTES_PER_SAMPLE, "nerf_forward": FWD_BYTES_PER_SAMPLE, "nerf_backward": BWD_BYTES_PER_SAMPLE, "optimizer_step": OPT_BYTES_PER_PARAM}
 MARCH_BYTES_PER_SAMPLE = 28    # one NerfCoordinate written per sample (nerf.h:62-107)
 MARCH_BYTES_PER_RAY = 40       # ray index 4 + Ray 24 + numsteps 8 written, one RGBA8 pixel read (testbed_nerf.cu:1232-1258)
-KERNEL_SET = "r05c"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
+KERNEL_SET = "r06a"            # bumped whenever a kernel of a timed launch group changes: PMC numbers of another set are not quoted
 GROUP_KERNELS = {"grad_exchange": "data-parallel step: fp16 -> fp32 copy, RCCL reduce-scatter (fp32 sums), fp32 -> fp16 of this rank's shard", "param_gather": "data-parallel step: RCCL all-gather of the fp16 weights",
                  "nerf_backward": "one ngp_hip_nerf_backward call: MLP dgrad+wgrad kernel, hash-grid backward (bin count, scan, bin scatter, owners, combine)",
                  "nerf_inference": "one ngp_hip_nerf_forward call: fused hash-grid encode + both MLPs (single kernel)", "optimizer_step": "adam_ema_vec4_kernel (single kernel)"}
@@ -191,6 +191,33 @@ def dp_step(tb, torch, dist, B, st):
         dist.all_reduce(st.grads)
     tb.train_nerf_dp_end()
     return c1
+
+
+def request_rate_roofs(torch, dev):
+    """The box's random-gather ceilings, measured in this run (~20 ms): ngp_hip_probe_gather_rate (csrc/probe.hip: independent random 4-byte loads, 8 in flight per lane) on
+    a table inside the vector L1's reach (16 KiB), on one 2 MiB slice per XCD (its L2 holds it: the XCD-affine encoder's situation), and on 24 MiB shared by all XCDs (the
+    hash table of base.json: Infinity-Cache resident, every L2 miss crosses the fabric).  G gathers / s, chip-wide, best of 3 after a warm-up launch."""
+    import ctypes
+    import capi
+    ngp = capi.load_ngp_hip()
+    table = torch.ones(8 << 20, dtype=torch.int32, device=dev)     # 32 MiB
+    sink = torch.zeros(16, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name, n_entries, per_xcd in (("L1", 4096, 0), ("L2", 8 * (1 << 19), 1), ("fabric", 6 << 20, 0)):
+        n = ctypes.c_uint64(0)
+        best = None
+        for rep in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            capi.check(ngp.ngp_hip_probe_gather_rate(st, table.data_ptr(), n_entries, per_xcd, 4096, 64, rep, sink.data_ptr(), ctypes.addressof(n)))
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if rep and (best is None or ms < best):
+                best = ms
+        out[name] = round(n.value / (best * 1e-3) / 1e9, 1)
+    return out
 
 
 def cpu_baseline(tb, ds, res, budget_s=12.0):
@@ -708,6 +735,30 @@ def main():
                        "measured": "HIP events on the launch stream, %d untimed survey steps" % SURVEY_STEPS}
     else:
         line_single = None
+    # ---- the request-rate roof beside the byte roof: a gather is one look-up in the vector L1 wherever it ends up hitting, and
+    # profiles/r04_forward_counters.md has the pass at 0.55 look-ups / clock / CU with the L1 90 % busy — that, not a byte figure, is what binds it.  Peaks: measured here.
+    if line_single is not None:
+        try:
+            roofs = request_rate_roofs(torch, dev)
+            two_kernel = str(dict(tb.network_pass_report).get("running", "")) == "two_kernel"
+            per_sample = 64 if two_kernel else 128   # 16 levels x 8 corners as 4-byte gathers (fused kernel) or x 4 x-pairs as 8-byte gathers (encode_planes_kernel)
+            fk = kernels["nerf_inference"]
+            ach = per_sample * fk["units_per_launch"] / (fk["avg_us"] * 1e-6) / 1e9
+            rr = {"achieved_G_per_s": round(ach, 1), "peak_G_per_s": roofs["L1"], "level": "L1", "frac": round(ach / roofs["L1"], 4), "gathers_per_sample": per_sample,
+                  "peaks_G_per_s": roofs, "measured": "ngp_hip_probe_gather_rate in this run (4096 x 256 threads x 64 random 4-byte loads; tables of 16 KiB / 8 x 2 MiB per XCD / 24 MiB shared)",
+                  "note": "every gather passes the vector L1's tag look-up (the L1 level's peak); the coarse levels and ray-coherent samples hit there, the fine hashed levels go on to the L2 (peak 'L2') "
+                          "and, in the fused kernel where every XCD walks all 16 tables, across the fabric to the Infinity Cache (peak 'fabric')"}
+            line_single["request_rate"] = rr
+            byte_headroom, req_headroom = 1.0 / max(line_single["frac"], 1e-9), 1.0 / max(rr["frac"], 1e-9)
+            line_single["bound"] = "l1_request_rate" if req_headroom < byte_headroom else "hbm"
+            line_single["headroom"] = {"bytes_x": round(byte_headroom, 2), "requests_x": round(req_headroom, 2), "bound_is": "the roof with the smaller headroom"}
+            if dom == "nerf_inference":
+                roofline["request_rate"], roofline["bound"] = rr, line_single["bound"]
+        except Exception as e:   # the probe is an extra: say why it is missing and keep the line
+            line_single["request_rate"] = {"failed": repr(e)}
+    if line_single is not None and line_single.get("traffic"):
+        line_single["traffic_over_algorithmic"] = round(line_single["traffic"] / (line_single["algorithmic_bytes_per_unit"] * line_single["units_per_launch"]), 2)
+        line_single["traffic_factor"] = "2 x FETCH_SIZE + WRITE_SIZE; the factor 2 holds for this pass's 4-byte and 8-byte gathers too: profiles/r06_fetch_calibration.json (one 128-byte line per touch, tallied at 64)"
     mpath = os.path.join(ROOT, "profiles", "mfma_util.json")
     if os.path.exists(mpath):
         try:

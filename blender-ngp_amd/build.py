@@ -19,7 +19,7 @@ OBJDIR = os.path.join(HERE, "build")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-KERNEL_SOURCES = ["density_grid.hip", "train_samples.hip", "network.hip", "loss.hip", "render.hip", "multi_render.hip", "comm.hip"]
+KERNEL_SOURCES = ["density_grid.hip", "train_samples.hip", "network.hip", "loss.hip", "render.hip", "multi_render.hip", "comm.hip", "probe.hip"]
 HOST_SOURCES = ["testbed.cpp", "python_api.cpp", "mini_json.cpp", "snapshot.cpp", "nerf_renderer.cpp", "nerf_loader.cpp", "png_reader.cpp", "exr_reader.cpp", "jpeg_reader.cpp", "hdr_reader.cpp", "image_io.cpp", "plumbing.cpp", "dp.cpp"]
 
 # -ffp-contract=off: the index / count paths must round exactly like the CPU oracle; network.hip re-enables contraction locally.

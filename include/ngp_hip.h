@@ -623,6 +623,12 @@ int ngp_rccl_comm_size(void* comm);                              /* ncclCommCoun
 int ngp_rccl_comm_rank(void* comm);
 int ngp_rccl_finalize(void* comm);
 
+/* ============================ measuring stick (not a stage of the path) ============================
+ * Random 4-byte gathers from table[0 .. n_entries) — n_blocks x 256 threads, per_thread independent loads each; per_xcd != 0 confines every XCD to its own eighth of
+ * the table.  A benchmark times launches of it (HIP events) to state the request-rate roofs of the box it runs on — vector-L1 reach, one XCD's L2, the Infinity Cache
+ * across the fabric — next to the byte roof (bench.py `roofline.request_rate`).  *n_gathers_out (host): gathers per launch. */
+int ngp_hip_probe_gather_rate(void* stream, const uint32_t* table, uint32_t n_entries, int per_xcd, uint32_t n_blocks, uint32_t per_thread, uint32_t seed, uint32_t* sink, uint64_t* n_gathers_out);
+
 #ifdef __cplusplus
 }
 #endif

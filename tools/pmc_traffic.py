@@ -14,7 +14,8 @@ import sys
 
 # kernel-name substring -> stage (one stage = one ngp_hip_* entry point as bench.py times it)
 STAGES = [("nerf_forward_kernelILi2ELi0E", "nerf_inference"),   # the training step's one network pass (MODE 2 = forward with saved encodings, PRE 0 = gathers inside); bench.py's group name
-          ("nerf_forward_kernelILi1E", "density_grid_prep"),
+          ("nerf_forward_kernelILi2ELi1E", "nerf_inference"),   # ... or its two-kernel organisation: the MLP-only kernel over encode_planes_kernel's level planes (the encode launches of the
+          ("nerf_forward_kernelILi1E", "density_grid_prep"),    # training pass and of the occupancy update share one kernel name: see _kernels for the split by dispatch count)
           ("encode_planes_kernel", "density_grid_prep"),
           ("nerf_backward_fused_kernel", "nerf_backward"), ("grid_backward_kernel", "nerf_backward"), ("grid_combine_kernel", "nerf_backward"),
           ("gb_fx_bin_kernel", "nerf_backward"), ("gb_fx_scan_kernel", "nerf_backward"),
@@ -56,7 +57,10 @@ def main():
     res = {s: round(v) for s, v in out.items()}
     ks = re.search(r'KERNEL_SET = "([^"]+)"', open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read())
     res["_meta"] = {"tag": sys.argv[4] if len(sys.argv) > 4 else os.path.basename(sys.argv[3]).replace("_pmc_traffic.json", ""), "kernel_set": ks.group(1) if ks else None}
-    res["_method"] = "per call: sum over the stage's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 B, dispatch averages; separate --pmc passes"
+    res["_method"] = ("per call: sum over the stage's kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 B, dispatch averages; separate --pmc passes.  The factor 2 is calibrated on this "
+                      "code's access patterns (tools/fetch_calibration.hip -> profiles/r06_fetch_calibration.json): a wide stream, one 4-byte touch per 128-byte line and random 4- / 8-byte "
+                      "gathers from a 2 GiB table all show ONE read request and FETCH_SIZE = 64 B per 128-byte line moved (the touch-per-line kernel takes the stream's time), so 2 x "
+                      "FETCH_SIZE is the bytes that crossed the L2's memory side for gathers as for streams; Infinity-Cache hits are included (an upper bound on HBM bytes)")
     res["_kernels"] = detail
     json.dump(res, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
