@@ -241,6 +241,24 @@ __device__ __forceinline__ LevelPos level_pos(const NgpGridLevel& lv, float px, 
 	return p;
 }
 
+// Trilinear blend of the eight corner entries, spelled out: products in x, y, z order, one fused multiply-add per corner and feature.  No implicit contraction in
+// here — under `fp contract(fast)` the compiler chose per INSTANTIATION what to fuse, and the encoder kernel that can read de-hashed level copies rounded 23 of 20 000
+// samples' features differently from the one that cannot (round 6).  Every gather flavour (4-byte, x-pair, de-hashed) ends in this one function.
+__device__ __forceinline__ void blend_corners(const LevelPos& p, const h2 (&v)[8], half_t& o0, half_t& o1) {
+#pragma clang fp contract(off)
+	float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+	for (int c = 0; c < 8; ++c) {
+		// weight = prod_d (bit ? frac : 1 - frac), multiplied in x, y, z order
+		float w = (c & 1) ? p.fx : (1.0f - p.fx);
+		w = w * (((c >> 1) & 1) ? p.fy : (1.0f - p.fy));
+		w = w * (((c >> 2) & 1) ? p.fz : (1.0f - p.fz));
+		r0 = __builtin_fmaf(w, (float)v[c][0], r0);
+		r1 = __builtin_fmaf(w, (float)v[c][1], r1);
+	}
+	o0 = (half_t)r0; o1 = (half_t)r1;
+}
+
 // PAIR: the two corners that differ in x only sit in one aligned 8-byte pair whenever their indices differ in bit 0 alone (always for
 // a hashed level at even x, because the x term of the hash is x itself; for a dense level at even index).  One 8-byte load then
 // replaces two 4-byte loads of the same cache line, the second of which would otherwise queue behind the pending miss of the first.
@@ -270,17 +288,7 @@ __device__ __forceinline__ void encode_level(const NgpGridLevel lv, const h2* __
 			}
 		}
 	}
-	float r0 = 0.0f, r1 = 0.0f;
-#pragma unroll
-	for (int c = 0; c < 8; ++c) {
-		// weight = prod_d (bit ? frac : 1 - frac), multiplied in x, y, z order
-		float w = (c & 1) ? p.fx : (1.0f - p.fx);
-		w *= ((c >> 1) & 1) ? p.fy : (1.0f - p.fy);
-		w *= ((c >> 2) & 1) ? p.fz : (1.0f - p.fz);
-		r0 += w * (float)v[c][0];
-		r1 += w * (float)v[c][1];
-	}
-	o0 = (half_t)r0; o1 = (half_t)r1;
+	blend_corners(p, v, o0, o1);
 }
 
 // 2-D (image fitting, 4 corners) or 3-D level; PAIR (3-D only): see encode_level

@@ -291,6 +291,23 @@ def test_backward_matches_oracle(ngp, oracle, cuda):
     np.testing.assert_allclose(gg, rg, rtol=5e-2, atol=5e-3 * np.abs(rg).max())
 
 
+def test_network_pass_organisations_agree_bit_for_bit(ngp, cuda):
+    """The fused kernel (4-byte corner gathers) and the two-kernel pass (x-pair gathers into level planes, then the MLP kernel) end in ONE spelled-out trilinear blend
+    (blend_corners: no implicit contraction), so their outputs are the same bits — round 6 found a third instantiation of the encoder rounding 23 of 20 000 samples'
+    features differently while the blend was left to `fp contract(fast)`."""
+    n = 20000
+    desc, params, coords, d_desc, d_P, d_c = _setup(ngp, cuda, log2=15, n=n, grid_amp=1.0)
+    coords["pos"][:64] = 1.0
+    coords["pos"][64:128] = 0.0
+    d_c = H.to_dev(coords, cuda)
+    ws_bytes = int(ngp.ngp_hip_nerf_encode_workspace_bytes(n))
+    ws = H.dev_zeros(ws_bytes, cuda)
+    a, b = H.dev_zeros(n * 8, cuda), H.dev_zeros(n * 8, cuda)
+    check(ngp.ngp_hip_nerf_inference_ws(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, a.data_ptr(), 4, ws.data_ptr(), ws_bytes))
+    check(ngp.ngp_hip_nerf_inference(None, d_desc.data_ptr(), d_P.data_ptr(), d_c.data_ptr(), 7, n, b.data_ptr(), 4))
+    np.testing.assert_array_equal(H.to_host(a, np.uint16), H.to_host(b, np.uint16))
+
+
 def test_backward_through_a_row_index_is_the_backward_over_the_rows(ngp, cuda):
     """round 6: ngp_hip_nerf_backward(..., x_row_index): sample k's encoding is row x_row_index[k] of a LARGER x_saved (the uncompacted batch's rows, which the loss
     kernel's compaction no longer copies).  Same kernels, same sums: the gradients of the indexed call are bit for bit those of the call over the gathered rows."""
