@@ -415,6 +415,13 @@ void Testbed::tuner_collect(bool wait) {
 bool Testbed::tuner_pick(void* stream) {
 	NetworkPassTuner& t = m_pass_tuner;
 	t.measuring = -1;
+	// a bracket whose closing event was never recorded — the launch between tuner_pick and tuner_done threw — would sit in `pending` for ever and with it the
+	// calibration (tuner_collect keeps entries without e1): drop such entries here, their sample is simply not taken
+	for (size_t i = 0; i < t.pending.size();) {
+		if (t.pending[i].e1) { ++i; continue; }
+		if (t.pending[i].e0) m_prof_event_pool.push_back(t.pending[i].e0);
+		t.pending.erase(t.pending.begin() + (long)i);
+	}
 	if (m_network_pass != ENetworkPass::Auto) return m_network_pass == ENetworkPass::TwoKernel;
 	if (!t.pending.empty() || t.count[0] || t.count[1]) tuner_collect(false);
 	if (t.remaining == 0 && t.pending.empty() && m_training_step >= t.next_calibration_step) {

@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 def _train(cuda, async_steps, n_steps=48):
     import scene
-    ds = scene.make_dataset(n_train=8, n_test=1, res=64, device=cuda)
+    ds = scene.make_dataset(n_train=12, n_test=1, res=96, device=cuda)    # (enough rays per step for the per-step counts to average out: ADVICE r05)
     tb = scene.build_testbed(ds)
+    tb.network_pass = "fused"            # the auto tuner picks the organisation of the pass by timing: pinned, so that both runs execute the same kernels
     tb.async_training_steps = async_steps
     rays, sizes = [], []
     for _ in range(n_steps):
@@ -45,11 +46,13 @@ def test_async_training_steps_train_the_same_model(cuda):
     # mode: the compaction assigns batch slots by atomics, so the weight-gradient sums see the samples in a different order, the weights
     # differ in the last bits after one step and with them the number of samples that survive the transmittance cut (~0.1 %)
     assert rays_a[0] == rays_b[0] and sizes_a[0] == sizes_b[0]
-    # ... and after the first occupancy-grid update (step 16) the tiny scene's per-step counts wander by ~10 % between any two runs (14 % seen once in ~10 runs: the bar is 25 %)
+    # ... and over the whole run the mean batch size and ray count agree to 10 % (the bar ADVICE r05 asked to keep: the scene is large enough for the per-step wander
+    # behind the first occupancy-grid update to average out, and the network pass is pinned)
     np.testing.assert_allclose(sizes_a[:12], sizes_b[:12], rtol=0.05)
     np.testing.assert_allclose(rays_a[:12], rays_b[:12], rtol=0.05)
-    assert abs(sizes_a[1:].mean() - sizes_b[1:].mean()) < 0.25 * sizes_a[1:].mean()
-    assert abs(rays_a[1:].mean() - rays_b[1:].mean()) < 0.25 * rays_a[1:].mean()
+    print("async vs sync: mean batch size %.0f / %.0f, mean rays %.0f / %.0f" % (sizes_b[1:].mean(), sizes_a[1:].mean(), rays_b[1:].mean(), rays_a[1:].mean()))
+    assert abs(sizes_a[1:].mean() - sizes_b[1:].mean()) < 0.10 * sizes_a[1:].mean()
+    assert abs(rays_a[1:].mean() - rays_b[1:].mean()) < 0.10 * rays_a[1:].mean()
     assert np.isfinite(a.loss) and np.isfinite(b.loss) and abs(a.loss - b.loss) < 0.5 * max(a.loss, b.loss)
     ia, ib = _render(a, ds), _render(b, ds)
     mse = float(np.mean((ia[..., :3] - ib[..., :3]) ** 2))
