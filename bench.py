@@ -754,6 +754,10 @@ def main():
             line_single["headroom"] = {"bytes_x": round(byte_headroom, 2), "requests_x": round(req_headroom, 2), "bound_is": "the roof with the smaller headroom"}
             if dom == "nerf_inference":
                 roofline["request_rate"], roofline["bound"] = rr, line_single["bound"]
+            else:   # the backward group: five kernels in a row, none of them a gather stream — its byte fraction is reported, a look-up roof would not describe it
+                roofline["bound_note"] = ("launch group of five latency-bound kernels (MFMA chain of the MLP backward, LDS-atomic ranks, scattered 12-byte record stores, ds_add_u64 owners, combine: "
+                                          "DESIGN.md 5.2-5.3); `bound` is the byte roof SURVEY 8(d) assigns the hash pass, the request-rate roof measured in this run is quoted for the network pass in "
+                                          "roofline_longest_single_kernel, whose bound it is")
         except Exception as e:   # the probe is an extra: say why it is missing and keep the line
             line_single["request_rate"] = {"failed": repr(e)}
     if line_single is not None and line_single.get("traffic"):

@@ -514,7 +514,7 @@ PYBIND11_MODULE(pyngp, m) {
 		.def("set_distributed", &Testbed::set_distributed, py::arg("rank"), py::arg("world_size"))
 		.def("init_data_parallel", &Testbed::init_data_parallel, py::call_guard<py::gil_scoped_release>(), py::arg("rank"), py::arg("world_size"), py::arg("key") = std::string("0"), py::arg("strong_scaling") = false,
 			"One process per GPU of one node: after this call frame() / train() run the data-parallel step (shared-memory counter exchange, RCCL gradient all-reduce over xGMI). "
-			"`key` names the rendezvous and must be the same on every rank of the job (e.g. MASTER_PORT). strong_scaling: train(B) back-propagates B / world_size samples per rank.")
+			"`key` names the rendezvous and must be the same on every rank of the job (e.g. MASTER_PORT). strong_scaling: train(B) back-propagates B / world_size samples per rank, and rays_per_batch is divided by the world size here (once per call), so the first data-parallel step marches the global rays of the single-rank step.")
 		.def("shutdown_data_parallel", &Testbed::shutdown_data_parallel, py::call_guard<py::gil_scoped_release>(), "tears the communicator down; NO collective (a rank may leave alone).  Call dp_gather_optimizer_state() on all ranks first if the Testbed is to train on or to save its optimizer state")
 		.def("dp_gather_optimizer_state", &Testbed::dp_gather_optimizer_state, py::call_guard<py::gil_scoped_release>(), "COLLECTIVE (every rank): all-gather of the fp32 master weights and Adam moments the sharded optimizer step keeps current only inside each rank's shard; required before save_snapshot(include_optimizer_state=True) and before training on after shutdown_data_parallel")
 		.def("set_render_shard", &Testbed::set_render_shard, py::arg("rank"), py::arg("world_size"),
