@@ -463,3 +463,41 @@ def test_fp16_wire_and_sharded_ema_equal_the_replicated_step_bit_for_bit(world):
             # three addends: the fp32 sum depends on the order where it is inexact; after the one fp16 rounding the library-ordered sum and the rank-ordered
             # sum differ in a handful of elements at most — the rank-ordered one is the DEFINED result from this round on
             assert n_differ_from_round3 <= n // 500, n_differ_from_round3
+
+
+def test_loopback_librccl_is_what_the_binding_resolves(tmp_path):
+    """tests/loopback/librccl_loopback.so (the several-ranks-on-one-GPU stand-in of tests/test_dp_loopback_gpu.py) exports every nccl* name csrc/comm.hip looks up, and
+    NGP_RCCL_LIBRARY makes the product library bind it: checked without a GPU (unique id, a one-rank communicator, the refusal of an id it did not make)."""
+    import ctypes
+    import subprocess
+    lb_dir = os.path.join(ROOT, "tests", "loopback")
+    so = os.path.join(lb_dir, "librccl_loopback.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(lb_dir, "rccl_loopback.hip")):
+        subprocess.check_call(["make", "-C", lb_dir], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclAllGather", "ncclReduceScatter", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd",
+                 "ncclCommCount", "ncclCommDestroy", "ncclGetErrorString"):
+        assert hasattr(lib, name), name
+    code = """
+import sys, numpy as np
+sys.path[:0] = [%r]
+import capi
+ngp = capi.load_ngp_hip()
+assert ngp.ngp_rccl_available() == 1
+uid = np.zeros(128, np.uint8)
+capi.check(ngp.ngp_rccl_get_unique_id(uid.ctypes.data))
+assert bytes(uid[:14]) == b"/ngp_loopback_", bytes(uid[:20])
+comm = ngp.ngp_rccl_init(0, 1, uid.ctypes.data)
+assert comm and ngp.ngp_rccl_comm_size(comm) == 1 and ngp.ngp_rccl_comm_rank(comm) == 0
+capi.check(ngp.ngp_rccl_finalize(comm))
+bad = np.zeros(128, np.uint8); bad[:4] = [1, 2, 3, 4]
+assert ngp.ngp_rccl_init(0, 1, bad.ctypes.data) is None          # an id of another library is refused, not dereferenced
+print("ok")
+""" % os.path.join(ROOT, "blender-ngp_amd")
+    env = dict(os.environ, NGP_RCCL_LIBRARY=so)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:]
+    # a path that does not exist is an error of the binding, not a silent fall-back to another RCCL
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path[:0] = [%r]; import capi; print(capi.load_ngp_hip().ngp_rccl_available())" % os.path.join(ROOT, "blender-ngp_amd")],
+                       env=dict(os.environ, NGP_RCCL_LIBRARY=str(tmp_path / "nope.so")), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0"), r.stdout[-500:]
