@@ -137,7 +137,11 @@ def prepare_training_json(train_json, workdir):
     "offset" or "aabb" key — would train the object around the origin of a cube centred on (0.5, 0.5, 0.5).  To benchmark it as the paper did the file must carry
     "scale": 0.33, "offset": [0.5, 0.5, 0.5] (honoured at nerf_loader.cu:472-474, 499-504).  A file that has the keys is used as it is; otherwise a patched copy is
     written to `workdir` (frame paths made absolute, so that it may live anywhere) and that path is returned."""
+    if os.path.isdir(train_json):   # a directory would make the loader take EVERY *.json in it, test and validation frames included (testbed_nerf.cu:2738-2743)
+        raise ValueError("%s is a directory: pass the transforms_train.json itself (README.md:117 of the reference does the same)" % train_json)
     meta = json.load(open(train_json))
+    if "frames" not in meta or not meta["frames"]:
+        raise ValueError("%s: no \"frames\"" % train_json)
     if "scale" in meta or "offset" in meta or "aabb" in meta:
         return os.path.abspath(train_json), meta, False
     base = os.path.dirname(os.path.abspath(train_json))
