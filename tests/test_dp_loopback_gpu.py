@@ -105,8 +105,8 @@ def _f16(bits):
     return np.asarray(bits).view(np.float16).astype(np.float32)
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3, 8])   # 8: the node size the north star names (shards of 1 / 8 of the vector, 8-way all-to-all, 6 rows per rank of the 45-row frame)
 def test_strong_scaled_training_over_several_ranks_on_one_gpu(world, single, tmp_path):
     out = str(tmp_path)
     ranks = run_world(world, out, dict(steps=STEPS, strong=True, abi=True, snapshot=single["snapshot"]))
@@ -135,7 +135,7 @@ def test_strong_scaled_training_over_several_ranks_on_one_gpu(world, single, tmp
         assert stats[0] > 0.85 and stats[1] <= 1.1e-2 and stats[2] < 0.03 and stats[3] > 0.95, stats
     # STEPS - START steps later: the same training run within the noise of fp16 rounding (world 3 trains a batch of 3 x 2^16 x 1 samples, 3 / 4 of the single run's)
     assert 0.7 < float(r0["loss"]) / single["loss"] < 1.4
-    assert (0.85 if world == 2 else 0.6) < int(r0["rays_per_batch"]) * world / single["rays_per_batch"] < (1.15 if world == 2 else 1.5)
+    assert (0.85 if world == 2 else 0.6) < int(r0["rays_per_batch"]) * world / single["rays_per_batch"] < (1.15 if world == 2 else 1.6)
     for r in ranks:
         assert r["stale"].tolist() == [True, True]        # sharded Adam + Ema: fp32 state and inference weights current only inside the rank's shard ...
         assert bool(r["refused_stale_inference"])         # ... and a rank-local read refuses them
