@@ -76,6 +76,7 @@ def test_bench_line_of_an_on_disk_scene_agrees_with_the_in_memory_run(on_disk):
     assert disk["render_resolution"] == [RES, RES] and disk["eval_views"] == N_TEST
     print("in memory: %.4f ms/step, %.2f dB, %.1f MP/s | on disk: %.4f ms/step, %.2f dB, %.1f MP/s" % (mem["ms_per_step"], mem["psnr_db"], mem["render_MP_per_s"], disk["ms_per_step"], disk["psnr_db"], disk["render_MP_per_s"]))
     # the same scene, the same step: two runs of a training that is not bit-reproducible (atomic compaction order) on a box whose clocks wander by a few per cent
-    assert abs(disk["ms_per_step"] / mem["ms_per_step"] - 1.0) < 0.06
+    # (measured: 1.4 % here, 2.2 % and 0.01 dB at full size — profiles/r06_e_scene_ab.txt; the bar leaves room for the network-pass tuner deciding differently in the two runs)
+    assert abs(disk["ms_per_step"] / mem["ms_per_step"] - 1.0) < 0.10
     assert abs(disk["psnr_db"] - mem["psnr_db"]) < 0.5
-    assert abs(disk["value"] / mem["value"] - 1.0) < 0.06
+    assert abs(disk["value"] / mem["value"] - 1.0) < 0.10
